@@ -1,0 +1,79 @@
+"""Differential fuzz: CPU oracle vs the imported upstream reference (development container only).
+
+For each env id: drive the reference EnvWrapper (philox-patched RNG) and the oracle with the same
+uniformly-random legal actions; after every step compare masks (325), full state blob (736),
+reward[4], done, deciding player, and every `obs_every` steps the observation (1787 floats + 5 lists).
+Usage: python tools/fuzz_oracle_vs_ref.py [n_envs] [steps_per_env] [seed]
+"""
+import sys
+import os
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+import ref_harness as rh  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+from settlers_of_catan_rl_amd import spec  # noqa: E402
+
+
+def compare_obs(ref_obs, orc):
+    f, lists, lens, pid = rh.obs_flat(ref_obs)
+    of, olists, olens, opid = orc.obs()
+    assert pid == opid, (pid, opid)
+    if not np.array_equal(f, of):
+        bad = np.flatnonzero(f != of)
+        raise AssertionError(f"obs floats differ at {bad[:10]} ref={f[bad[:10]]} orc={of[bad[:10]]}")
+    assert np.array_equal(lens, olens), (lens, olens)
+    assert np.array_equal(lists, olists), (lists, olists)
+
+
+def fuzz(n_envs, steps, seed, obs_every=7, verbose=True):
+    t0 = time.time()
+    total = 0
+    games = 0
+    for env_id in range(n_envs):
+        rng = np.random.default_rng(seed * 1000003 + env_id)
+        ref = rh.RefEnv(seed, env_id)
+        orc = ol.OracleEnv(seed, env_id)
+        ref_obs = ref.reset()
+        orc.reset()
+        for s in range(steps):
+            rb, ob = ref.state_blob(), orc.export()
+            if not np.array_equal(rb, ob):
+                raise AssertionError(f"env {env_id} step {s}: state differs\n" + spec.describe_state_diff(rb, ob))
+            rm = rh.masks_flat(ref.masks())
+            om = orc.masks()
+            if not np.array_equal(rm, om):
+                bad = np.flatnonzero(rm != om)
+                raise AssertionError(f"env {env_id} step {s}: masks differ at {bad[:20]}")
+            assert ref.deciding_player() == orc.deciding_player()
+            if s % obs_every == 0:
+                compare_obs(ref_obs, orc)
+            a = rh.random_legal_action(ref.masks(), ref.env, rng)
+            assert orc.is_legal(a), (env_id, s, a)
+            ref_obs, rrew, rdone = ref.step(a)
+            orew, odone = orc.step(a)
+            assert rdone == odone and np.array_equal(rrew, orew), (env_id, s, a, rrew, orew, rdone, odone)
+            total += 1
+            if rdone:
+                compare_obs(ref_obs, orc)
+                rb, ob = ref.state_blob(), orc.export()
+                if not np.array_equal(rb, ob):
+                    raise AssertionError(f"env {env_id} step {s} (terminal): state differs\n" + spec.describe_state_diff(rb, ob))
+                games += 1
+                ref_obs = ref.reset()
+                orc.reset()
+        if verbose and (env_id % 5 == 0):
+            print(f"env {env_id}: ok ({total} steps, {games} games, {time.time()-t0:.1f}s)", flush=True)
+    return total, games
+
+
+if __name__ == "__main__":
+    n_envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    total, games = fuzz(n_envs, steps, seed)
+    print(f"PASS: {total} steps, {games} complete games, zero mismatches")
