@@ -1,0 +1,92 @@
+"""ctypes binding of libcatan_hip.so (the C ABI declared in include/catan_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or there is no HIP device the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libcatan_hip.so")
+
+
+class CatanHipError(RuntimeError):
+    pass
+
+
+class CatanCfg(C.Structure):
+    _fields_ = [("max_proposed_trades_per_turn", C.c_int32), ("win_reward", C.c_float), ("dense_reward", C.c_int32),
+                ("reward_annealing_factor", C.c_float), ("validate_actions", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))]
+    out.append(os.path.join(os.path.dirname(PKG_DIR), "include", "catan_hip.h"))
+    return out
+
+
+def build_library(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (it travels with the repo snapshot)."""
+    srcs = _sources()
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+_vp = C.c_void_p
+
+_SIGS = {
+    "catan_cfg_default": (None, [C.POINTER(CatanCfg)]),
+    "catan_state_words": (C.c_int32, []),
+    "catan_mask_words": (C.c_int32, []),
+    "catan_action_words": (C.c_int32, []),
+    "catan_obs_floats": (C.c_int32, []),
+    "catan_state_bytes_per_game": (C.c_int32, []),
+    "catan_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.POINTER(CatanCfg)]),
+    "catan_destroy": (None, [_vp]),
+    "catan_last_error": (C.c_char_p, []),
+    "catan_num_envs": (C.c_int64, [_vp]),
+    "catan_reset": (C.c_int, [_vp, _vp, _vp]),
+    "catan_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "catan_masks": (C.c_int, [_vp, _vp, _vp]),
+    "catan_masks_packed": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "catan_deciding_seat": (C.c_int, [_vp, _vp, _vp]),
+    "catan_sample_random_actions": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
+    "catan_state_export": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_state_import": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_set_reward_annealing": (C.c_int, [_vp, C.c_float]),
+    "catan_invalid_action_count": (C.c_int64, [_vp, _vp]),
+    "catan_random_rollout": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp]),
+    "catan_random_rollout_timed": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp, C.POINTER(C.c_float)]),
+}
+
+
+def declared_symbols():
+    """Every entry point include/catan_hip.h declares (the CPU test-suite checks the built .so exports them)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CatanHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the HIP path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CatanHipError(f"libcatan_hip: error {rc}: {lib().catan_last_error().decode()}")

@@ -1,0 +1,236 @@
+// catan_abi.hip - host side of libcatan_hip.so: handle, launches, C ABI (include/catan_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/catan_hip.h"
+#include "catan_kernels.hip"
+
+using namespace catan;
+
+struct catan_env {
+    int device;
+    long n, N;
+    Ctx ctx;
+    catan_cfg_t cfg;
+    void* state;          // W rows then B rows
+    u32* mpk;             // packed masks [11][N]
+    u32* err;             // invalid-action counter
+    // scratch for catan_random_rollout
+    i32* scratch_actions; // [18][n]
+    float* scratch_reward;// [4][n]
+    u8* scratch_done;     // [n]
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail(CATAN_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char* catan_last_error(void) { return g_err.c_str(); }
+
+void catan_cfg_default(catan_cfg_t* c) {
+    c->max_proposed_trades_per_turn = 4; c->win_reward = 500.0f; c->dense_reward = 0;
+    c->reward_annealing_factor = 1.0f; c->validate_actions = 1; c->auto_reset = 1;
+}
+int32_t catan_state_words(void) { return STATE_WORDS; }
+int32_t catan_mask_words(void) { return MASK_BITS; }
+int32_t catan_action_words(void) { return ACTION_WORDS; }
+int32_t catan_obs_floats(void) { return OBS_FLOATS; }
+int32_t catan_state_bytes_per_game(void) { return STATE_BYTES_PER_GAME; }
+int64_t catan_num_envs(const catan_env_t* e) { return e ? e->n : 0; }
+
+static inline hipStream_t S(catan_stream_t s) { return (hipStream_t)s; }
+static inline unsigned blocks(long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+static int launch_masks(catan_env_t* e, hipStream_t st) {
+    hipLaunchKernelGGL(k_masks, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, uint64_t env_id0, const catan_cfg_t* cfg) {
+    if (!out || n_envs <= 0) return fail(CATAN_EINVAL, "catan_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CATAN_ENODEV, "catan_create: no HIP device (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(CATAN_EINVAL, "catan_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    catan_env* e = new (std::nothrow) catan_env();
+    if (!e) return fail(CATAN_ENOMEM, "catan_create: host allocation failed");
+    memset(e, 0, sizeof *e);
+    e->device = device;
+    e->n = n_envs;
+    e->N = (n_envs + BLOCK - 1) / BLOCK * BLOCK;
+    if (cfg) e->cfg = *cfg; else catan_cfg_default(&e->cfg);
+    size_t bytes = (size_t)e->N * STATE_BYTES_PER_GAME;
+    hipError_t rc = hipMalloc(&e->state, bytes);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->mpk, (size_t)e->N * MASK_WORDS * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->err, 64);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_actions, (size_t)e->n * ACTION_WORDS * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_reward, (size_t)e->n * 4 * sizeof(float));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_done, (size_t)e->n);
+    if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
+    HIPCHK(hipMemset(e->state, 0, bytes));
+    HIPCHK(hipMemset(e->err, 0, 64));
+    e->ctx.W = (u32*)e->state;
+    e->ctx.B = (u8*)e->state + (size_t)e->N * NW * sizeof(u32);
+    e->ctx.N = e->N; e->ctx.n = e->n;
+    e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
+    e->ctx.env_id0 = env_id0;
+    int r = catan_reset(e, nullptr, nullptr);
+    if (r != CATAN_OK) { catan_destroy(e); return r; }
+    HIPCHK(hipStreamSynchronize(nullptr));
+    *out = e;
+    return CATAN_OK;
+}
+
+void catan_destroy(catan_env_t* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->state) hipFree(e->state);
+    if (e->mpk) hipFree(e->mpk);
+    if (e->err) hipFree(e->err);
+    if (e->scratch_actions) hipFree(e->scratch_actions);
+    if (e->scratch_reward) hipFree(e->scratch_reward);
+    if (e->scratch_done) hipFree(e->scratch_done);
+    delete e;
+}
+
+int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
+    if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
+    hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, reset_mask);
+    HIPCHK(hipGetLastError());
+    return launch_masks(e, S(stream));
+}
+
+static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
+    StepCfg sc;
+    sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
+    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn;
+    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc);
+    HIPCHK(hipGetLastError());
+    if (e->cfg.auto_reset) {
+        hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const u8*)done);
+        HIPCHK(hipGetLastError());
+    }
+    return launch_masks(e, st);
+}
+
+int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
+    if (!e || !actions || !reward || !done) return fail(CATAN_EINVAL, "catan_step: null argument");
+    return step_impl(e, actions, reward, done, S(stream));
+}
+
+int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_masks: null argument");
+    long total = e->n * MASK_BITS;
+    hipLaunchKernelGGL(k_expand_masks, dim3(blocks(total, BLOCK)), dim3(BLOCK), 0, S(stream), e->mpk, e->N, e->n, out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_masks_packed(catan_env_t* e, const uint32_t** out_ptr, int64_t* out_pitch) {
+    if (!e || !out_ptr || !out_pitch) return fail(CATAN_EINVAL, "catan_masks_packed: null argument");
+    *out_ptr = e->mpk; *out_pitch = e->N;
+    return CATAN_OK;
+}
+
+int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_deciding_seat: null argument");
+    hipLaunchKernelGGL(k_deciding, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
+    if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
+    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
+    if (!e || !blob || cnt <= 0 || (!env_idx && cnt > e->n)) return fail(CATAN_EINVAL, "catan_state_export: bad arguments");
+    hipLaunchKernelGGL(k_export, dim3(blocks(cnt, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, (const long*)env_idx, (long)cnt, blob);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
+    if (!e || !blob || cnt <= 0 || (!env_idx && cnt > e->n)) return fail(CATAN_EINVAL, "catan_state_import: bad arguments");
+    hipLaunchKernelGGL(k_import, dim3(blocks(cnt, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, (const long*)env_idx, (long)cnt, blob);
+    HIPCHK(hipGetLastError());
+    return launch_masks(e, S(stream));
+}
+
+int catan_set_reward_annealing(catan_env_t* e, float f) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_reward_annealing: null handle");
+    e->cfg.reward_annealing_factor = f;
+    return CATAN_OK;
+}
+
+int64_t catan_invalid_action_count(catan_env_t* e, catan_stream_t stream) {
+    if (!e) return -1;
+    u32 v = 0;
+    if (hipMemcpyAsync(&v, e->err, sizeof v, hipMemcpyDeviceToHost, S(stream)) != hipSuccess) return -1;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream) {
+    if (!e || steps < 0) return fail(CATAN_EINVAL, "catan_random_rollout: bad arguments");
+    for (int64_t s = 0; s < steps; s++) {
+        int r = catan_sample_random_actions(e, step_idx0 + (uint32_t)s, e->scratch_actions, stream);
+        if (r != CATAN_OK) return r;
+        r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, S(stream));
+        if (r != CATAN_OK) return r;
+    }
+    return CATAN_OK;
+}
+
+// Same loop as catan_random_rollout but with a hipEvent pair around every kernel launch (events recorded on
+// `stream`, the stream the kernels run on).  kernel_ms (host, float[4]) receives the summed elapsed
+// milliseconds of: [0] k_sample_random  [1] k_step  [2] k_reset  [3] k_masks.  Used by bench.py's roofline leg.
+int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms) {
+    if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
+    hipStream_t st = S(stream);
+    const int K = 4;
+    std::vector<hipEvent_t> ev((size_t)steps * (K + 1));
+    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    StepCfg sc;
+    sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
+    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn;
+    for (int64_t s = 0; s < steps; s++) {
+        hipEvent_t* v = &ev[(size_t)s * (K + 1)];
+        HIPCHK(hipEventRecord(v[0], st));
+        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, step_idx0 + (uint32_t)s, e->scratch_actions);
+        HIPCHK(hipEventRecord(v[1], st));
+        hipLaunchKernelGGL(k_step, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const i32*)e->scratch_actions, (const u32*)e->mpk, e->scratch_reward, e->scratch_done, e->err, sc);
+        HIPCHK(hipEventRecord(v[2], st));
+        hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const u8*)e->scratch_done);
+        HIPCHK(hipEventRecord(v[3], st));
+        hipLaunchKernelGGL(k_masks, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn);
+        HIPCHK(hipEventRecord(v[4], st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (int k = 0; k < K; k++) kernel_ms[k] = 0.0f;
+    for (int64_t s = 0; s < steps; s++)
+        for (int k = 0; k < K; k++) {
+            float ms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)s * (K + 1) + k], ev[(size_t)s * (K + 1) + k + 1]));
+            kernel_ms[k] += ms;
+        }
+    for (auto& x : ev) hipEventDestroy(x);
+    return CATAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1368 @@
+// catan_kernels.hip - hand-written gfx950 kernels for the batched Catan env (one game per lane).
+//
+// What each kernel replaces in the reference (henrycharlesworth/settlers_of_catan_RL):
+//   k_reset         Board.reset + Game.reset + EnvWrapper.reset      game/components/board.py:67-100, game/game.py:39-136, env/wrapper.py:30-34
+//   k_step          EnvWrapper.step = _translate_action + Game.apply_action + _get_done_and_rewards
+//                                                                      env/wrapper.py:36-50,114-166,85-112, game/game.py:527-815
+//   k_masks         EnvWrapper.get_action_masks                        env/wrapper.py:168-412
+//   k_sample_random uniform-random legal policy (bench config 2)       (reference: none; rule in DESIGN.md)
+//   k_export/import Game.save_current_state / restore_state            game/game.py:1013-1205
+//   k_expand_masks  packed 325-bit masks -> float32 [N][325]           (wrapper returns float arrays)
+//
+// Design notes (gfx950 / wave64):
+//  * lane = game.  All state accesses are row accesses of a [row][N] array -> the 64 lanes of a wave
+//    read/write 64 consecutive elements (coalesced 64 B / 256 B segments).
+//  * board occupancy is kept as bitboards (54-bit corners, 72-bit edges) so placement legality, production and
+//    the robber/steal masks are a handful of 64-bit and/popcount ops instead of graph walks.
+//  * longest road (vertex-simple longest path, game/game.py:843-862 + game/utils.py:3-15) is the one genuinely
+//    divergent graph walk; it is executed wave-cooperatively: lanes that need it are found with a ballot, their
+//    bitboards are broadcast one at a time, and the 64 lanes each run the DFS from a different start corner,
+//    followed by a wave max-reduction.
+//  * integer/byte work only - no MFMA, by design (HBM/latency-bound; see DESIGN.md roofline section).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "catan_state.h"
+
+#define CATAN_TABLE static __device__ __constant__ const
+#include "catan_topology.inc"
+
+namespace catan {
+
+#define DEVI __device__ __forceinline__
+
+constexpr int BLOCK = 256;
+constexpr u64 ALL54 = (1ull << 54) - 1;
+
+// ------------------------------------------------------------------------------------------------ state view
+struct St {
+    u32* W;
+    u8* B;
+    long N;   // padded number of games (row pitch)
+    long e;   // this lane's game
+    DEVI u32 w(int r) const { return W[(long)r * N + e]; }
+    DEVI void sw(int r, u32 v) const { W[(long)r * N + e] = v; }
+    DEVI int b(int r) const { return B[(long)r * N + e]; }
+    DEVI void sb(int r, int v) const { B[(long)r * N + e] = (u8)v; }
+    DEVI int pb(int p, int f) const { return b(B_PLAYER + p * PB + f); }
+    DEVI void spb(int p, int f, int v) const { sb(B_PLAYER + p * PB + f, v); }
+    DEVI u64 settle(int p) const { return (u64)w(W_SETTLE_LO + p) | ((u64)w(W_SETTLE_HI + p) << 32); }
+    DEVI u64 city(int p) const { return (u64)w(W_CITY_LO + p) | ((u64)w(W_CITY_HI + p) << 32); }
+    DEVI void set_settle(int p, u64 v) const { sw(W_SETTLE_LO + p, (u32)v); sw(W_SETTLE_HI + p, (u32)(v >> 32)); }
+    DEVI void set_city(int p, u64 v) const { sw(W_CITY_LO + p, (u32)v); sw(W_CITY_HI + p, (u32)(v >> 32)); }
+    DEVI u64 road_lo(int p) const { return (u64)w(W_ROAD0 + p) | ((u64)w(W_ROAD1 + p) << 32); }
+    DEVI u32 road_hi(int p) const { return w(W_ROAD2 + p); }
+    DEVI int flags() const { return b(B_FLAGS); }
+    DEVI int res(int p, int r0) const { return pb(p, P_RES + r0); }
+    DEVI int total(int p) const { return res(p, 0) + res(p, 1) + res(p, 2) + res(p, 3) + res(p, 4); }
+};
+
+struct Ctx {          // launch-invariant handle fields
+    u32* W;
+    u8* B;
+    long N;           // padded
+    long n;           // real number of games
+    u32 key0, key1;   // philox key = seed
+    u64 env_id0;      // global id of game 0 (multi-GPU shards keep their global ids)
+};
+
+DEVI int seat_of(int seatof, int p) { return (seatof >> (2 * p)) & 3; }
+DEVI int pid_at(int order, int seat) { return (order >> (2 * (seat & 3))) & 3; }
+// ref: game/components/player.py:12-20
+DEVI int label_of(int seatof, int me, int other) { return ((seat_of(seatof, other) - seat_of(seatof, me)) & 3) - 1; }
+DEVI int player_at_label(int order, int seatof, int me, int label) { return pid_at(order, seat_of(seatof, me) + 1 + label); }
+DEVI int clipi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// ------------------------------------------------------------------------------------------------ RNG
+// Philox4x32-10 (Salmon et al., SC'11).  Contract: SURVEY.md 8.4 / DESIGN.md "RNG".
+DEVI void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct Rng {
+    u32 k0, k1, e0, e1, draws;
+    DEVI u32 next() {
+        u32 o[4];
+        philox4x32_10(draws >> 2, 0u, e0, e1, k0, k1, o);
+        u32 sel = draws & 3;
+        draws++;
+        return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
+    }
+    // masked rejection (numpy legacy rk_interval shape)
+    DEVI u32 bounded(u32 mx) {
+        if (mx == 0) return 0;
+        u32 mask = 0xFFFFFFFFu >> __clz(mx);
+        u32 v;
+        do { v = next() & mask; } while (v > mx);
+        return v;
+    }
+};
+DEVI Rng rng_load(const Ctx& c, const St& s) {
+    Rng r;
+    u64 id = c.env_id0 + (u64)s.e;
+    r.k0 = c.key0; r.k1 = c.key1; r.e0 = (u32)id; r.e1 = (u32)(id >> 32); r.draws = s.w(W_RNG);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ estimates
+struct Est { int mn[5], mx[5]; };
+DEVI void est_load(const St& s, int o, int l, Est& E) {
+    int base = W_EST + (o * 3 + l) * 3;
+    u32 a = s.w(base), b = s.w(base + 1), c = s.w(base + 2);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { E.mn[r] = (a >> (8 * r)) & 255; E.mx[r] = (b >> (8 * r)) & 255; }
+    E.mn[4] = c & 255; E.mx[4] = (c >> 8) & 255;
+}
+DEVI void est_store(const St& s, int o, int l, const Est& E) {
+    int base = W_EST + (o * 3 + l) * 3;
+    u32 a = 0, b = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { a |= (u32)(E.mn[r] & 255) << (8 * r); b |= (u32)(E.mx[r] & 255) << (8 * r); }
+    s.sw(base, a); s.sw(base + 1, b); s.sw(base + 2, (u32)(E.mn[4] & 255) | ((u32)(E.mx[4] & 255) << 8));
+}
+struct D5 { int v[5]; };
+DEVI D5 d5_zero() { D5 d; d.v[0] = d.v[1] = d.v[2] = d.v[3] = d.v[4] = 0; return d; }
+DEVI void d5_add(D5& d, int r0, int x) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) d.v[k] += (k == r0) ? x : 0;
+}
+// ref: game/game.py:921-971.  delta per r0, `touched` = bitmask of r0 keys present in the dict, thief = -1 for none.
+DEVI void update_estimates(const St& s, int seatof, const D5& delta, int touched, int upd, int thief) {
+    int total = s.total(upd);
+    int total_thief = thief >= 0 ? s.total(thief) : 0;
+    for (int o = 0; o < 4; o++) {
+        Est E;
+        if (o == upd) {
+            if (thief < 0) continue;
+            int sl = label_of(seatof, o, thief);
+            est_load(s, o, sl, E);
+#pragma unroll
+            for (int r = 0; r < 5; r++) if ((touched >> r) & 1) { E.mx[r] -= delta.v[r]; E.mn[r] -= delta.v[r]; }
+            est_store(s, o, sl, E);
+        } else {
+            int l = label_of(seatof, o, upd);
+            est_load(s, o, l, E);
+            if (thief < 0 || o == thief) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) if ((touched >> r) & 1) {
+                    E.mx[r] = clipi(E.mx[r] + delta.v[r], 0, total);
+                    E.mn[r] = clipi(E.mn[r] + delta.v[r], 0, total);
+                }
+                est_store(s, o, l, E);
+            } else {
+                int sl = label_of(seatof, o, thief);
+                Est S;
+                est_load(s, o, sl, S);
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    int cmax = E.mx[r], cmin = E.mn[r];
+                    E.mx[r] = clipi(cmax, 0, total);
+                    E.mn[r] = clipi(cmin - 1, 0, total);
+                    if (cmax > 0) {
+                        S.mx[r] = clipi(S.mx[r] + 1, 0, total_thief);
+                        S.mn[r] = clipi(S.mn[r], 0, total_thief);
+                    }
+                }
+                est_store(s, o, l, E);
+                est_store(s, o, sl, S);
+            }
+        }
+    }
+}
+DEVI void update_estimates1(const St& s, int seatof, int r0, int d, int upd) {
+    D5 dl = d5_zero();
+    d5_add(dl, r0, d);
+    update_estimates(s, seatof, dl, 1 << r0, upd, -1);
+}
+// ref: game/game.py:973-1010.  lost = per-pid0 count packed one byte each.
+DEVI void update_estimates_monopoly(const St& s, int seatof, int mono, int r0, u32 lost) {
+    int total = 0;
+    for (int p = 0; p < 4; p++) if (p != mono) total += (lost >> (8 * p)) & 255;
+    for (int p = 0; p < 4; p++) {
+        if (p == mono) {
+            for (int o = 0; o < 4; o++) if (o != p) {
+                int l = label_of(seatof, o, p);
+                Est E; est_load(s, o, l, E);
+#pragma unroll
+                for (int r = 0; r < 5; r++) if (r == r0) { E.mn[r] += total; E.mx[r] += total; }
+                est_store(s, o, l, E);
+            }
+        } else {
+            int ptotal = s.total(p), pl = (lost >> (8 * p)) & 255;
+            for (int o = 0; o < 4; o++) if (o != p) {
+                int l = label_of(seatof, o, p);
+                Est E; est_load(s, o, l, E);
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    int cmax = E.mx[r], cmin = E.mn[r];
+                    if (r == r0) { cmax -= pl; cmin -= pl; }
+                    E.mx[r] = clipi(cmax, 0, ptotal);
+                    E.mn[r] = clipi(cmin, 0, ptotal);
+                }
+                est_store(s, o, l, E);
+            }
+        }
+    }
+}
+
+// resource -> bank with the visible-resources clamp (e.g. game/game.py:197-208)
+DEVI void pay(const St& s, int p, int r0, int n) {
+    s.spb(p, P_RES + r0, s.pb(p, P_RES + r0) - n);
+    s.spb(p, P_VIS + r0, max(s.pb(p, P_VIS + r0) - n, 0));
+    s.sb(B_BANK + r0, s.b(B_BANK + r0) + n);
+}
+// ref: game/game.py:253-262
+DEVI void update_players_go(const St& s, int order, bool left) {
+    int id = s.b(B_ORDER_ID);
+    id = left ? (id == 0 ? 3 : id - 1) : (id == 3 ? 0 : id + 1);
+    s.sb(B_ORDER_ID, id);
+    s.sb(B_GO, pid_at(order, id));
+}
+
+// ------------------------------------------------------------------------------------------------ longest road
+struct CoopLds {
+    u8 nbr_c[54 * 3];
+    u8 nbr_e[54 * 3];
+    u8 stack[BLOCK / 64][54][64];   // per wave, per depth, per lane: corner | k << 6
+};
+DEVI void coop_init(CoopLds& L) {
+    for (int i = threadIdx.x; i < 54 * 3; i += BLOCK) {
+        L.nbr_c[i] = CORNER_NBR_C[i / 3][i % 3];
+        L.nbr_e[i] = CORNER_NBR_E[i / 3][i % 3];
+    }
+    __syncthreads();
+}
+// Longest vertex-simple path of `pid` for every lane with want=true (all 64 lanes of the wave cooperate).
+// ref: game/game.py:843-862, game/utils.py:3-15.  A corner holding an opponent building has no outgoing arcs.
+DEVI int coop_longest_path(bool want, const St& s, int pid, CoopLds& L) {
+    u64 bal = __ballot(want);
+    if (bal == 0) return 0;
+    u64 rlo = 0, blocked = 0;
+    u32 rhi = 0;
+    if (want) {
+        rlo = s.road_lo(pid); rhi = s.road_hi(pid);
+        for (int o = 0; o < 4; o++) if (o != pid) blocked |= s.settle(o) | s.city(o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int result = 0;
+    while (bal) {
+        int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        u64 R = ((u64)(u32)__shfl((int)(u32)(rlo >> 32), src) << 32) | (u32)__shfl((int)(u32)rlo, src);
+        u32 RH = (u32)__shfl((int)rhi, src);
+        u64 BL = ((u64)(u32)__shfl((int)(u32)(blocked >> 32), src) << 32) | (u32)__shfl((int)(u32)blocked, src);
+        int best = 0;
+        if (lane < 54 && !((BL >> lane) & 1)) {
+            int cur = lane, k = 0, d = 0;
+            u64 seen = 1ull << lane;
+            while (true) {
+                if (k < 3) {
+                    int t = L.nbr_c[cur * 3 + k], ed = L.nbr_e[cur * 3 + k];
+                    k++;
+                    if (t != 255) {
+                        bool has = ed < 64 ? ((R >> ed) & 1) : ((RH >> (ed - 64)) & 1);
+                        if (has && !((seen >> t) & 1)) {
+                            best = max(best, d + 1);
+                            if (!((BL >> t) & 1)) {
+                                L.stack[wave][d][lane] = (u8)(cur | (k << 6));
+                                d++; cur = t; k = 0; seen |= 1ull << t;
+                            }
+                        }
+                    }
+                } else {
+                    if (d == 0) break;
+                    seen &= ~(1ull << cur);
+                    d--;
+                    int pk = L.stack[wave][d][lane];
+                    cur = pk & 63; k = pk >> 6;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (lane == src) result = best;
+    }
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+// Fisher-Yates from the top (np.random.shuffle on a list), array in LDS column `col`.
+template <int NMAX>
+DEVI void shuffle_lds(u8 (&a)[NMAX][64], int n, int col, Rng& rng) {
+    for (int i = n - 1; i >= 1; i--) {
+        int j = (int)rng.bounded((u32)i);
+        u8 t = a[i][col]; a[i][col] = a[j][col]; a[j][col] = t;
+    }
+}
+// ref: game/components/board.py:67-100, game/game.py:39-136, game/components/player.py:9-58, env/wrapper.py:30-34
+__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
+    __shared__ u8 arr[25][64];
+    __shared__ u8 terr[19][64];
+    const int col = threadIdx.x;
+    St s{ c.W, c.B, c.N, (long)blockIdx.x * 64 + threadIdx.x };
+    if (s.e >= c.N) return;
+    if (sel != nullptr && (s.e >= c.n || sel[s.e] == 0)) return;
+    Rng rng = rng_load(c, s);
+    for (int r = 0; r < NW; r++) if (r != W_RNG) s.sw(r, 0);
+    for (int r = 0; r < NB; r++) s.sb(r, 0);
+    // terrain: Desert, 3 Hills, 4 Fields, 4 Forest, 3 Mountains, 4 Pastures (board.py:27-28; Terrain == Resource value)
+    for (int i = 0; i < 19; i++) {
+        int v = i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4))));
+        terr[i][col] = (u8)v;
+    }
+    shuffle_lds<19>(terr, 19, col, rng);                       // board.py:72
+    // number tokens (board.py:25), reshuffled until no 6/8 are adjacent (board.py:79-81, 50-65)
+    {
+        const u8 nums[18] = { 5, 2, 6, 3, 8, 10, 9, 12, 11, 4, 8, 10, 9, 4, 5, 6, 3, 11 };
+        for (int i = 0; i < 18; i++) arr[i][col] = nums[i];
+    }
+    bool ok = false;
+    do {
+        shuffle_lds<25>(arr, 18, col, rng);
+        u32 reds = 0;
+        int n = 0;
+        for (int i = 0; i < 19; i++) {
+            int t = PLACEMENT[i];
+            int v = terr[t][col] == 0 ? 7 : arr[n][col];
+            if (terr[t][col] != 0) n++;
+            if (v == 6 || v == 8) reds |= 1u << t;
+        }
+        ok = true;
+        for (int t = 0; t < 19; t++) if (((reds >> t) & 1) && (TILE_NBR_MASK[t] & reds)) ok = false;
+    } while (!ok);
+    {
+        int n = 0;
+        for (int i = 0; i < 19; i++) {                        // board.py:91-100
+            int t = PLACEMENT[i], tr = terr[t][col], v;
+            if (tr == 0) { v = 7; s.sb(B_ROBBER, t); } else v = arr[n++][col];
+            s.sb(B_TILE + t, tr | (v << 4));
+        }
+    }
+    for (int i = 0; i < 9; i++) arr[i][col] = (u8)i;
+    shuffle_lds<25>(arr, 9, col, rng);                         // board.py:84
+    for (int i = 0; i < 9; i++) s.sb(B_HARB + i, arr[i][col]);
+    for (int i = 0; i < 4; i++) arr[i][col] = (u8)i;           // game.py:41 [White, Blue, Orange, Red] as pid0
+    shuffle_lds<25>(arr, 4, col, rng);                         // game.py:42
+    {
+        int order = 0, seatof = 0;
+        for (int i = 0; i < 4; i++) { int p = arr[i][col]; order |= p << (2 * i); seatof |= i << (2 * p); }
+        s.sb(B_ORDER, order); s.sb(B_SEATOF, seatof);
+        s.sb(B_GO, order & 3); s.sb(B_ORDER_ID, 0);
+    }
+    for (int r = 0; r < 5; r++) s.sb(B_BANK + r, 19);         // game.py:48-54
+    for (int p = 0; p < 4; p++) { s.spb(p, P_SLEFT, 5); s.spb(p, P_CLEFT, 4); s.spb(p, P_ISECOND, 255); }
+    for (int i = 0; i < 25; i++)                               // game.py:75-76
+        arr[i][col] = (u8)(i < 14 ? C_KNIGHT : (i < 19 ? C_VP : (i < 21 ? C_YOP : (i < 23 ? C_RB : C_MONO))));
+    shuffle_lds<25>(arr, 25, col, rng);                        // game.py:77
+    for (int i = 0; i < 25; i++) s.sb(B_PILE + i, arr[i][col]);
+    s.sb(B_PILE_LEN, 25);
+    s.sb(B_FLAGS, F_INITIAL);
+    s.sw(W_RNG, rng.draws);
+}
+
+// ------------------------------------------------------------------------------------------------ masks
+template <int OFF, int NBITS>
+DEVI void setr(u32 (&m)[MASK_WORDS], u64 v) {      // overwrite bit range [OFF, OFF+NBITS) with the low NBITS of v
+    constexpr int w0 = OFF >> 5, sh = OFF & 31;
+    constexpr u64 full = NBITS >= 64 ? ~0ull : ((1ull << NBITS) - 1);
+    v &= full;
+    m[w0] = (m[w0] & ~(u32)(full << sh)) | (u32)(v << sh);
+    if constexpr (sh + NBITS > 32) m[w0 + 1] = (m[w0 + 1] & ~(u32)(full >> (32 - sh))) | (u32)(v >> (32 - sh));
+    if constexpr (sh + NBITS > 64) m[w0 + 2] = (m[w0 + 2] & ~(u32)(full >> (64 - sh))) | (u32)(v >> (64 - sh));
+}
+template <int OFF, int NBITS>
+DEVI u64 getr(const u32 (&m)[MASK_WORDS]) {
+    constexpr int w0 = OFF >> 5, sh = OFF & 31;
+    constexpr u64 full = NBITS >= 64 ? ~0ull : ((1ull << NBITS) - 1);
+    u64 v = (u64)m[w0] >> sh;
+    if constexpr (sh + NBITS > 32) v |= (u64)m[w0 + 1] << (32 - sh);
+    if constexpr (sh + NBITS > 64) v |= (u64)m[w0 + 2] << (64 - sh);
+    return v & full;
+}
+struct Boards { u64 occ, own_bld, own_set; u64 rlo[4]; u32 rhi[4]; };
+DEVI void load_boards(const St& s, int pid, Boards& b) {
+    b.occ = 0;
+    for (int p = 0; p < 4; p++) {
+        u64 st = s.settle(p), ct = s.city(p);
+        b.occ |= st | ct;
+        if (p == pid) { b.own_bld = st | ct; b.own_set = st; }
+        b.rlo[p] = s.road_lo(p); b.rhi[p] = s.road_hi(p);
+    }
+}
+// ref: game/components/corner.py:24-39 over all corners.  initial=true ignores the own-road requirement.
+DEVI u64 settle_spots(const Boards& b, int pid, bool initial) {
+    u64 blocked = b.occ, touched = 0;
+    for (int c = 0; c < 54; c++) if (CORNER_NBR_MASK[c] & b.occ) blocked |= 1ull << c;
+    if (!initial) {
+        u64 rl = b.rlo[pid]; u32 rh = b.rhi[pid];
+        for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
+        for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
+        return ~blocked & touched & ALL54;
+    }
+    return ~blocked & ALL54;
+}
+// ref: env/wrapper.py:322-339 + game/components/edge.py:23-42.  Returns 73 bits (lo 64, hi 9; bit 72 = dummy edge).
+DEVI void road_spots(const St& s, const Boards& b, int pid, int flags, bool road_building, u64& lo, u32& hi) {
+    u64 elo = ~(b.rlo[0] | b.rlo[1] | b.rlo[2] | b.rlo[3]);
+    u32 ehi = ~(b.rhi[0] | b.rhi[1] | b.rhi[2] | b.rhi[3]) & 0xFFu;
+    u64 anchors;
+    if ((flags & F_INITIAL) && s.pb(pid, P_ISET) == 2) {
+        anchors = 1ull << s.pb(pid, P_ISECOND);
+    } else {
+        u64 touched = 0, rl = b.rlo[pid]; u32 rh = b.rhi[pid];
+        for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
+        for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
+        anchors = b.own_bld | (touched & ~b.occ);
+    }
+    lo = 0; hi = 0;
+    for (int e = 0; e < 64; e++) if (EDGE_CORNER_MASK[e] & anchors) lo |= 1ull << e;
+    for (int e = 64; e < 72; e++) if (EDGE_CORNER_MASK[e] & anchors) hi |= 1u << (e - 64);
+    lo &= elo; hi &= ehi;
+    if (road_building && lo == 0 && hi == 0) hi = 1u << 8;
+}
+// ref: env/wrapper.py:368-388.  returns 5-bit card mask; yop_ok -> bank vector valid
+DEVI int dev_card_mask(const St& s, int pid, u32& bank_bits) {
+    int m = 0, banksum = 0;
+    bank_bits = 0;
+    for (int r = 0; r < 5; r++) { int v = s.b(B_BANK + r); banksum += v; if (v > 0) bank_bits |= 1u << r; }
+    for (int cd = 0; cd < 5; cd++) {
+        int k = s.pb(pid, P_HCNT + cd);
+        if (k > 0 && s.b(B_BOUGHT + cd) < k && (cd != C_YOP || banksum > 0)) m |= 1 << cd;
+    }
+    return m;
+}
+// ref: env/wrapper.py:168-290
+DEVI void compute_masks(const St& s, u32 (&m)[MASK_WORDS], int max_trades) {
+    // defaults: head 0 zeros, every other head all ones (wrapper.py:172-185)
+    m[0] = 0xFFFFE000u;
+#pragma unroll
+    for (int i = 1; i < 10; i++) m[i] = 0xFFFFFFFFu;
+    m[10] = 0x1Fu;
+    const int flags = s.flags();
+    const int pid = s.b(B_GO);
+    const int ndisc = s.b(B_NDISC);
+    if (ndisc > 0) {                                                       // wrapper.py:186-192
+        int d = s.b(B_DISC);
+        u32 rb = 0;
+        for (int r = 0; r < 5; r++) if (s.res(d, r) > 0) rb |= 1u << r;
+        setr<M0, 13>(m, 1u << T_DISCARD);
+        setr<M11, 5>(m, rb);
+        return;
+    }
+    Boards b;
+    if (flags & F_INITIAL) {                                               // wrapper.py:195-204
+        load_boards(s, pid, b);
+        int iset = s.pb(pid, P_ISET), iroad = s.pb(pid, P_IROAD);
+        if (iset == 0 || (iset == 1 && iroad == 1)) {
+            setr<M0, 13>(m, 1u << T_SETTLE);
+            setr<M1, 54>(m, settle_spots(b, pid, true));
+        } else {
+            u64 lo; u32 hi;
+            road_spots(s, b, pid, flags, false, lo, hi);
+            setr<M0, 13>(m, 1u << T_ROAD);
+            setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi);
+        }
+        return;
+    }
+    if (flags & F_RB_ACTIVE) {                                             // wrapper.py:206-209
+        load_boards(s, pid, b);
+        u64 lo; u32 hi;
+        road_spots(s, b, pid, flags, true, lo, hi);
+        setr<M0, 13>(m, 1u << T_ROAD);
+        setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi);
+        return;
+    }
+    if (flags & F_JUST_ROBBER) {                                           // wrapper.py:210-213, 341-351
+        int seatof = s.b(B_SEATOF);
+        u64 tm = TILE_CORNER_MASK[s.b(B_ROBBER)];
+        u32 tg = 0;
+        for (int o = 0; o < 4; o++) if (o != pid && ((s.settle(o) | s.city(o)) & tm)) tg |= 1u << label_of(seatof, pid, o);
+        setr<M0, 13>(m, 1u << T_STEAL);
+        setr<M6 + 3, 3>(m, tg);
+        return;
+    }
+    if (flags & F_MUST_RESPOND) {                                          // wrapper.py:214-218, 353-365
+        int tgt = s.b(B_TRADE_TGT), nr = s.b(B_TRADE_NR);
+        int need[5] = { 0, 0, 0, 0, 0 };
+        for (int i = 0; i < 4; i++) if (i < nr) {
+            int r = s.b(B_TRADE_RECV + i) - 1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) need[k] += (k == r) ? 1 : 0;
+        }
+        bool have = true;
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (need[k] > s.res(tgt, k)) have = false;
+        setr<M0, 13>(m, 1u << T_RESPOND);
+        setr<M5, 2>(m, have ? 3u : 2u);
+        return;
+    }
+    u32 types = 0;
+    if (!(flags & F_ROLLED)) {                                             // wrapper.py:219-229
+        types = 1u << T_ROLL;
+        if (s.pb(pid, P_NHID) > 0 && !(flags & F_PLAYED_DEV)) {
+            u32 bank_bits;
+            int cm = dev_card_mask(s, pid, bank_bits);
+            if (cm) {
+                types |= 1u << T_PLAYDEV;
+                setr<M4, 5>(m, cm);
+                if (cm & (1 << C_YOP)) { setr<M9 + 10, 5>(m, bank_bits); setr<M10, 5>(m, bank_bits); }
+            }
+        }
+        setr<M0, 13>(m, types);
+        return;
+    }
+    types = 1u << T_ENDTURN;                                               // wrapper.py:232 (max_actions_per_turn = inf)
+    load_boards(s, pid, b);
+    int res[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) res[r] = s.res(pid, r);
+    if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_WOOD] > 0 && res[R_BRICK] > 0) {   // :238-243
+        u64 v = settle_spots(b, pid, false);
+        if (v && s.pb(pid, P_SLEFT) > 0) { types |= 1u << T_SETTLE; setr<M1, 54>(m, v); }
+    }
+    if (res[R_WHEAT] >= 2 && res[R_ORE] >= 3 && s.pb(pid, P_CLEFT) > 0 && b.own_set) {   // :245-250
+        types |= 1u << T_CITY; setr<M1 + 54, 54>(m, b.own_set);
+    }
+    if (res[R_WOOD] > 0 && res[R_BRICK] > 0) {                                            // :252-256
+        u64 lo; u32 hi;
+        road_spots(s, b, pid, flags, false, lo, hi);
+        if (lo | hi) { types |= 1u << T_ROAD; setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi); }
+    }
+    if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_ORE] > 0 && s.b(B_PILE_LEN) > 0) types |= 1u << T_BUYDEV;   // :258-260
+    u32 bank_bits;
+    {
+        int cm = dev_card_mask(s, pid, bank_bits);
+        if (s.pb(pid, P_NHID) > 0 && !(flags & F_PLAYED_DEV) && cm) {                      // :262-269
+            types |= 1u << T_PLAYDEV;
+            setr<M4, 5>(m, cm);
+            if (cm & (1 << C_YOP)) { setr<M9 + 10, 5>(m, bank_bits); setr<M10, 5>(m, bank_bits); }
+        }
+    }
+    {                                                                                      // :271-276, 390-412
+        int hb = s.pb(pid, P_HARB);
+        u32 give = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            if ((hb & 1) && res[r] >= 3) give |= 1u << r;
+            if (((hb >> (r + 1)) & 1) && res[r] >= 2) give |= 1u << r;
+            if (res[r] >= 4) give |= 1u << r;
+        }
+        if (give && bank_bits) { types |= 1u << T_EXCHANGE; setr<M9, 5>(m, give); setr<M10, 5>(m, bank_bits); }
+    }
+    if (flags & F_CAN_ROBBER) {                                                            // :278-281, 308-320
+        u32 tv = 0;
+        for (int t = 0; t < 19; t++) if (TILE_CORNER_MASK[t] & b.occ) tv |= 1u << t;
+        types |= 1u << T_ROBBER; setr<M3, 19>(m, tv);
+    }
+    {                                                                                      // :283-289
+        int tot = res[0] + res[1] + res[2] + res[3] + res[4];
+        if (tot > 0 && (max_trades < 0 || s.b(B_TRADES) < max_trades)) types |= 1u << T_PROPOSE;
+    }
+    setr<M0, 13>(m, types);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, int max_trades) {
+    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    if (s.e >= c.N) return;
+    u32 m[MASK_WORDS];
+    compute_masks(s, m, max_trades);
+#pragma unroll
+    for (int i = 0; i < MASK_WORDS; i++) mpk[(long)i * c.N + s.e] = m[i];
+}
+
+// packed [11][Npad] -> float32 [n][325] row-major (what EnvWrapper.get_action_masks returns, batched)
+__global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ mpk, long N, long n, float* __restrict__ out) {
+    long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n * MASK_BITS) return;
+    long e = i / MASK_BITS;
+    int j = (int)(i - e * MASK_BITS);
+    out[i] = (float)((mpk[(long)(j >> 5) * N + e] >> (j & 31)) & 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ step
+// "mask bit set" legality (validate mode): every head relevant to the chosen type must be unmasked, plus the
+// ownership check of game/game.py:455-466 for ProposeTrade.
+DEVI bool action_legal(const St& s, const u32 (&m)[MASK_WORDS], const int (&a)[ACTION_WORDS]) {
+    auto bit = [&](int i) { return (m[i >> 5] >> (i & 31)) & 1u; };
+    int t = a[0];
+    if (t < 0 || t > 12 || !bit(M0 + t)) return false;
+    switch (t) {
+    case T_SETTLE: return a[1] >= 0 && a[1] < 54 && bit(M1 + a[1]);
+    case T_CITY: return a[1] >= 0 && a[1] < 54 && bit(M1 + 54 + a[1]);
+    case T_ROAD: return a[2] >= 0 && a[2] <= 72 && bit(M2 + a[2]);
+    case T_ROBBER: return a[3] >= 0 && a[3] < 19 && bit(M3 + a[3]);
+    case T_PLAYDEV:
+        if (a[4] < 0 || a[4] > 4 || !bit(M4 + a[4])) return false;
+        if (a[4] == C_MONO) return a[15] >= 0 && a[15] < 5 && bit(M9 + 10 + a[15]);
+        if (a[4] == C_YOP) return a[15] >= 0 && a[15] < 5 && a[16] >= 0 && a[16] < 5 && bit(M9 + 15 + a[15]) && bit(M10 + a[16]);
+        return true;
+    case T_EXCHANGE: return a[15] >= 0 && a[15] < 5 && a[16] >= 0 && a[16] < 5 && bit(M9 + a[15]) && bit(M10 + a[16]);
+    case T_PROPOSE: {
+        if (a[6] < 0 || a[6] > 2) return false;
+        int cnt[5] = { 0, 0, 0, 0, 0 };
+        bool stop = false;
+        for (int i = 0; i < 4; i++) {
+            int v = a[7 + i];
+            if (v == 0) stop = true;
+            if (!stop) {
+                if (v < 0 || v > 5) return false;
+#pragma unroll
+                for (int k = 0; k < 5; k++) cnt[k] += (k == v - 1) ? 1 : 0;
+            }
+        }
+        stop = false;
+        for (int i = 0; i < 4; i++) { int v = a[11 + i]; if (v == 0) stop = true; if (!stop && (v < 0 || v > 5)) return false; }
+        int pid = s.b(B_GO);
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (s.res(pid, k) < cnt[k]) return false;
+        return true;
+    }
+    case T_RESPOND: return a[5] >= 0 && a[5] < 2 && bit(M5 + a[5]);
+    case T_STEAL: return a[6] >= 0 && a[6] < 3 && bit(M6 + 3 + a[6]);
+    case T_DISCARD: return a[17] >= 0 && a[17] < 5 && bit(M11 + a[17]);
+    default: return true;
+    }
+}
+
+// ref: game/game.py:138-177
+DEVI int roll_dice(const St& s, Rng& rng, int order, int seatof) {
+    int d1 = 1 + (int)rng.bounded(5), d2 = 1 + (int)rng.bounded(5);
+    s.sb(B_DIE1, d1); s.sb(B_DIE2, d2);
+    int roll = d1 + d2;
+    if (roll == 7) {
+        int n = 0;
+        for (int i = 0; i < 4; i++) {
+            int p = pid_at(order, i);
+            if (s.total(p) > 7) { s.sb(B_DISC + n, p); n++; }
+        }
+        s.sb(B_NDISC, n);
+        return roll;
+    }
+    // at most two tiles carry any number token
+    int robber = s.b(B_ROBBER);
+    u32 alloc[5] = { 0, 0, 0, 0, 0 };     // per resource: one byte per pid0
+    u64 st[4], ct[4];
+    for (int p = 0; p < 4; p++) { st[p] = s.settle(p); ct[p] = s.city(p); }
+    for (int t = 0; t < 19; t++) {
+        int tb = s.b(B_TILE + t);
+        if ((tb >> 4) != roll || t == robber) continue;
+        int r0 = (tb & 15) - 1;
+        u64 tm = TILE_CORNER_MASK[t];
+        u32 add = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) add |= (u32)(__popcll(st[p] & tm) + 2 * __popcll(ct[p] & tm)) << (8 * p);
+#pragma unroll
+        for (int k = 0; k < 5; k++) alloc[k] += (k == r0) ? add : 0u;
+    }
+    // game.py:170-175: per resource all-or-nothing, in dict order Wood, Ore, Brick, Wheat, Sheep
+    const int res_order[5] = { R_WOOD, R_ORE, R_BRICK, R_WHEAT, R_SHEEP };
+    u32 okbits = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        int r0 = res_order[i];
+        u32 al = alloc[r0];
+        int tot = (al & 255) + ((al >> 8) & 255) + ((al >> 16) & 255) + (al >> 24);
+        int bank = s.b(B_BANK + r0);
+        if (tot <= bank) { okbits |= 1u << r0; if (tot) s.sb(B_BANK + r0, bank - tot); }
+    }
+    // hands + estimates.  For a fixed receiving player X the five per-resource updates are sequential (the clip bound
+    // is X's running hand total); different X touch disjoint estimate entries, so the player order is free.
+    for (int X = 0; X < 4; X++) {
+        int base_total = s.total(X);
+        int add[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) add[r] = (alloc[r] >> (8 * X)) & 255;
+#pragma unroll
+        for (int r = 0; r < 5; r++) if (((okbits >> r) & 1) && add[r]) s.spb(X, P_RES + r, s.pb(X, P_RES + r) + add[r]);
+        for (int o = 0; o < 4; o++) {
+            if (o == X) continue;
+            int l = label_of(seatof, o, X);
+            Est E; est_load(s, o, l, E);
+            int tot = base_total;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                int r = res_order[i];
+                if ((okbits >> r) & 1) {
+                    tot += add[r];
+                    E.mx[r] = clipi(E.mx[r] + add[r], 0, tot);
+                    E.mn[r] = clipi(E.mn[r] + add[r], 0, tot);
+                }
+            }
+            est_store(s, o, l, E);
+        }
+    }
+    return roll;
+}
+
+// ref: game/game.py:817-841
+DEVI void update_largest_army(const St& s) {
+    const int order[4] = { 1, 0, 3, 2 };   // Blue, White, Red, Orange as pid0
+    int max_count = 0, who = -1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int p = order[i], k = s.pb(p, P_ARMY);
+        if (k >= 3 && k > max_count) { max_count = k; who = p; }
+    }
+    if (who < 0) return;
+    int la = s.b(B_LA_PLAYER);
+    if (la == 0) { s.sb(B_LA_PLAYER, who + 1); s.sb(B_LA_COUNT, max_count); s.spb(who, P_VP, s.pb(who, P_VP) + 2); }
+    else if (la == who + 1) s.sb(B_LA_COUNT, max_count);
+    else if (max_count > s.b(B_LA_COUNT)) {
+        s.spb(la - 1, P_VP, s.pb(la - 1, P_VP) - 2);
+        s.sb(B_LA_PLAYER, who + 1); s.sb(B_LA_COUNT, max_count);
+        s.spb(who, P_VP, s.pb(who, P_VP) + 2);
+    }
+}
+
+struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; };
+
+// actions: int32 [18][n] head-major; reward: float [4][n] (PlayerId-1 major); done: u8 [n]; err: [1] invalid-action counter
+__global__ __launch_bounds__(BLOCK) void k_step(Ctx c, const i32* __restrict__ actions, const u32* __restrict__ mpk,
+                                                float* __restrict__ reward, u8* __restrict__ done,
+                                                u32* __restrict__ err, StepCfg cfg) {
+    __shared__ CoopLds L;
+    coop_init(L);
+    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    const bool live = s.e < c.n;
+    int a[ACTION_WORDS];
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = live ? actions[(long)i * c.n + s.e] : 0;
+    int type = live ? a[0] : -1;
+    if (live && cfg.validate) {
+        u32 m[MASK_WORDS];
+#pragma unroll
+        for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[(long)i * c.N + s.e];
+        if (!action_legal(s, m, a)) { atomicAdd(err, 1u); type = -1; }
+    }
+    if (type < 0 || type > 12) type = -1;
+    // clamp indices so that an unvalidated bad action cannot touch memory outside the game's rows
+    a[1] = min(max(a[1], 0), 53); a[2] = min(max(a[2], 0), 72); a[3] = min(max(a[3], 0), 18);
+    a[4] = min(max(a[4], 0), 4); a[6] = min(max(a[6], 0), 2);
+    a[15] = min(max(a[15], 0), 4); a[16] = min(max(a[16], 0), 4); a[17] = min(max(a[17], 0), 4);
+
+    const int order = s.b(B_ORDER), seatof = s.b(B_SEATOF);
+    const int pid = s.b(B_GO);
+    int flags = s.flags();
+    int lr_who = -1;
+
+    switch (type) {
+    case T_SETTLE: {                                                       // game.py:530-555, 195-212
+        int cn = a[1];
+        if (!(flags & F_INITIAL)) { pay(s, pid, R_WHEAT, 1); pay(s, pid, R_SHEEP, 1); pay(s, pid, R_WOOD, 1); pay(s, pid, R_BRICK, 1); }
+        s.set_settle(pid, s.settle(pid) | (1ull << cn));                   // board.py:178-184
+        int slot = CORNER_HSLOT[cn];
+        if (slot != 255) {
+            int hid = s.b(B_HARB + slot);
+            // harbour id -> resource (board.py:29-33): 0 Ore, 1 Sheep, 2 Wheat, 3 Wood, 4 Brick, 5..8 generic
+            int bitpos = hid == 0 ? R_ORE + 1 : hid == 1 ? R_SHEEP + 1 : hid == 2 ? R_WHEAT + 1 : hid == 3 ? R_WOOD + 1 : hid == 4 ? R_BRICK + 1 : 0;
+            s.spb(pid, P_HARB, s.pb(pid, P_HARB) | (1 << bitpos));
+        }
+        s.spb(pid, P_SLEFT, s.pb(pid, P_SLEFT) - 1);
+        s.spb(pid, P_VP, s.pb(pid, P_VP) + 1);
+        if (flags & F_INITIAL) {
+            int k = s.pb(pid, P_ISET) + 1;
+            s.spb(pid, P_ISET, k);
+            if (k == 2) {
+                D5 d = d5_zero();
+                int touched = 0;
+                for (int q = 0; q < 3; q++) {
+                    int t = CORNER_TILE[cn][q];
+                    if (t == 255) continue;
+                    int r0 = (s.b(B_TILE + t) & 15) - 1;
+                    if (r0 < 0) continue;
+                    s.spb(pid, P_RES + r0, s.pb(pid, P_RES + r0) + 1);
+                    s.spb(pid, P_VIS + r0, s.pb(pid, P_VIS + r0) + 1);
+                    s.sb(B_BANK + r0, s.b(B_BANK + r0) - 1);
+                    d5_add(d, r0, 1); touched |= 1 << r0;
+                }
+                update_estimates(s, seatof, d, touched, pid, -1);
+                s.spb(pid, P_ISECOND, cn);
+            }
+        } else {
+            D5 d; d.v[R_BRICK] = -1; d.v[R_WOOD] = -1; d.v[R_ORE] = 0; d.v[R_SHEEP] = -1; d.v[R_WHEAT] = -1;
+            update_estimates(s, seatof, d, 0b11011, pid, -1);
+            int lrp = s.b(B_LR_PLAYER);
+            if (lrp) lr_who = lrp - 1;
+        }
+        break;
+    }
+    case T_ROAD: {                                                         // game.py:556-597, 222-232
+        bool final_init = false;
+        int ed = a[2];
+        if (ed != 72) {
+            if (!(flags & F_INITIAL) && !(flags & F_RB_ACTIVE)) { pay(s, pid, R_WOOD, 1); pay(s, pid, R_BRICK, 1); }
+            int wrow = ed < 32 ? W_ROAD0 : (ed < 64 ? W_ROAD1 : W_ROAD2);
+            s.sw(wrow + pid, s.w(wrow + pid) | (1u << (ed & 31)));
+            if (flags & F_INITIAL) {
+                s.spb(pid, P_IROAD, s.pb(pid, P_IROAD) + 1);
+                int first = 0, second = 0;
+                for (int p = 0; p < 4; p++) { int k = s.pb(p, P_ISET); if (k >= 1) first++; if (k == 2) second++; }
+                if (first < 4) update_players_go(s, order, false);
+                else if (second == 0) { }
+                else if (second < 4) update_players_go(s, order, true);
+                else { flags &= ~F_INITIAL; final_init = true; }
+            }
+        }
+        lr_who = pid;
+        if (flags & F_RB_ACTIVE) {
+            int k = s.b(B_RB_COUNT) + 1;
+            if (k >= 2) { flags &= ~(F_RB_ACTIVE | F_MUST_USE_DEV); k = 0; }
+            s.sb(B_RB_COUNT, k);
+        } else if (!(flags & F_INITIAL) && !final_init) {
+            D5 d = d5_zero(); d.v[R_BRICK] = -1; d.v[R_WOOD] = -1;
+            update_estimates(s, seatof, d, 0b00011, pid, -1);
+        }
+        s.sb(B_FLAGS, flags);
+        break;
+    }
+    case T_CITY: {                                                         // game.py:598-604, 240-251
+        pay(s, pid, R_WHEAT, 2); pay(s, pid, R_ORE, 3);
+        u64 bit = 1ull << a[1];
+        s.set_settle(pid, s.settle(pid) & ~bit);
+        s.set_city(pid, s.city(pid) | bit);
+        s.spb(pid, P_VP, s.pb(pid, P_VP) + 1);
+        s.spb(pid, P_CLEFT, s.pb(pid, P_CLEFT) - 1);
+        s.spb(pid, P_SLEFT, s.pb(pid, P_SLEFT) + 1);
+        D5 d = d5_zero(); d.v[R_ORE] = -3; d.v[R_WHEAT] = -2;
+        update_estimates(s, seatof, d, (1 << R_ORE) | (1 << R_WHEAT), pid, -1);
+        break;
+    }
+    case T_ROLL: {                                                         // game.py:605-611
+        Rng rng = rng_load(c, s);
+        int roll = roll_dice(s, rng, order, seatof);
+        s.sw(W_RNG, rng.draws);
+        flags |= F_ROLLED;
+        if (roll == 7) flags |= F_CAN_ROBBER;
+        s.sb(B_FLAGS, flags);
+        break;
+    }
+    case T_ENDTURN: {                                                      // game.py:612-622
+        flags &= ~(F_CAN_ROBBER | F_ROLLED | F_PLAYED_DEV);
+        s.sb(B_FLAGS, flags);
+        update_players_go(s, order, false);
+        s.sw(W_TURN, s.w(W_TURN) + 1);
+        for (int k = 0; k < 5; k++) s.sb(B_BOUGHT + k, 0);
+        s.sb(B_TRADES, 0);
+        s.sw(W_ACTIONS, 0);
+        break;
+    }
+    case T_ROBBER: {                                                       // game.py:623-634
+        s.sb(B_ROBBER, a[3]);
+        flags &= ~F_CAN_ROBBER;
+        u64 tm = TILE_CORNER_MASK[a[3]], opp = 0;
+        for (int o = 0; o < 4; o++) if (o != pid) opp |= s.settle(o) | s.city(o);
+        if (opp & tm) flags |= F_JUST_ROBBER;
+        s.sb(B_FLAGS, flags);
+        break;
+    }
+    case T_STEAL: {                                                        // game.py:635-652, wrapper.py:129-139
+        int victim = player_at_label(order, seatof, pid, a[6]);
+        int n = s.total(victim);
+        if (n > 0) {
+            Rng rng = rng_load(c, s);
+            int k = (int)rng.bounded((u32)(n - 1));
+            s.sw(W_RNG, rng.draws);
+            const int ord[5] = { R_BRICK, R_WHEAT, R_WOOD, R_SHEEP, R_ORE };   // game.py:638
+            int r0 = 0;
+            bool found = false;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                int h = s.res(victim, ord[i]);
+                if (!found) { if (k < h) { r0 = ord[i]; found = true; } else k -= h; }
+            }
+            s.spb(pid, P_RES + r0, s.pb(pid, P_RES + r0) + 1);
+            s.spb(victim, P_RES + r0, s.pb(victim, P_RES + r0) - 1);
+            for (int q = 0; q < 5; q++) s.spb(victim, P_VIS + q, max(s.pb(victim, P_VIS + q) - 1, 0));
+            D5 d = d5_zero(); d5_add(d, r0, -1);
+            update_estimates(s, seatof, d, 1 << r0, victim, pid);
+        }
+        flags &= ~F_JUST_ROBBER;
+        s.sb(B_FLAGS, flags);
+        break;
+    }
+    case T_PLAYDEV: {                                                      // game.py:653-693, wrapper.py:140-147
+        int card = a[4];
+        int nh = s.pb(pid, P_NHID), at = -1;
+        for (int i = 0; i < nh; i++) if (at < 0 && s.pb(pid, P_HIDDEN + i) == card) at = i;
+        if (at >= 0) {
+            for (int i = at; i + 1 < nh; i++) s.spb(pid, P_HIDDEN + i, s.pb(pid, P_HIDDEN + i + 1));
+            s.spb(pid, P_NHID, nh - 1);
+            s.spb(pid, P_HCNT + card, s.pb(pid, P_HCNT + card) - 1);
+        }
+        int np = s.pb(pid, P_NPLAYED);
+        s.spb(pid, P_PLAYED + np, card);
+        s.spb(pid, P_NPLAYED, np + 1);
+        flags |= F_PLAYED_DEV;
+        if (card == C_VP) s.spb(pid, P_VP, s.pb(pid, P_VP) + 1);
+        else if (card == C_KNIGHT) {
+            flags |= F_CAN_ROBBER;
+            s.spb(pid, P_ARMY, s.pb(pid, P_ARMY) + 1);
+            update_largest_army(s);
+        } else if (card == C_RB) { flags |= F_RB_ACTIVE | F_MUST_USE_DEV; s.sb(B_RB_COUNT, 0); }
+        else if (card == C_MONO) {
+            int r0 = a[15];
+            u32 lost = 0;
+            int got = 0;
+            for (int o = 0; o < 4; o++) if (o != pid) {
+                int k = s.res(o, r0);
+                s.spb(o, P_RES + r0, 0); s.spb(o, P_VIS + r0, 0);
+                lost |= (u32)k << (8 * o); got += k;
+            }
+            s.spb(pid, P_RES + r0, s.pb(pid, P_RES + r0) + got);
+            s.spb(pid, P_VIS + r0, s.pb(pid, P_VIS + r0) + got);
+            update_estimates_monopoly(s, seatof, pid, r0, lost);
+        } else if (card == C_YOP) {
+            for (int i = 0; i < 2; i++) {
+                int r0 = i == 0 ? a[15] : a[16];
+                int bank = s.b(B_BANK + r0);
+                if (bank > 0) {
+                    s.sb(B_BANK + r0, bank - 1);
+                    s.spb(pid, P_RES + r0, s.pb(pid, P_RES + r0) + 1);
+                    s.spb(pid, P_VIS + r0, s.pb(pid, P_VIS + r0) + 1);
+                    update_estimates1(s, seatof, r0, 1, pid);
+                }
+            }
+        }
+        s.sb(B_FLAGS, flags);
+        break;
+    }
+    case T_BUYDEV: {                                                       // game.py:694-710
+        pay(s, pid, R_SHEEP, 1); pay(s, pid, R_ORE, 1); pay(s, pid, R_WHEAT, 1);
+        D5 d = d5_zero(); d.v[R_SHEEP] = -1; d.v[R_ORE] = -1; d.v[R_WHEAT] = -1;
+        update_estimates(s, seatof, d, (1 << R_SHEEP) | (1 << R_ORE) | (1 << R_WHEAT), pid, -1);
+        int pl = s.b(B_PILE_LEN) - 1;
+        int card = s.b(B_PILE + pl);
+        s.sb(B_PILE_LEN, pl);
+        int nh = s.pb(pid, P_NHID);
+        s.spb(pid, P_HIDDEN + nh, card);
+        s.spb(pid, P_NHID, nh + 1);
+        s.spb(pid, P_HCNT + card, s.pb(pid, P_HCNT + card) + 1);
+        s.sb(B_BOUGHT + card, s.b(B_BOUGHT + card) + 1);
+        break;
+    }
+    case T_EXCHANGE: {                                                     // game.py:711-734, wrapper.py:148-153, 428-438
+        int give = a[15], want = a[16];
+        int hb = s.pb(pid, P_HARB);
+        int rate = ((hb >> (give + 1)) & 1) ? 2 : ((hb & 1) ? 3 : 4);
+        s.spb(pid, P_RES + want, s.pb(pid, P_RES + want) + 1);
+        s.spb(pid, P_VIS + want, s.pb(pid, P_VIS + want) + 1);
+        s.spb(pid, P_RES + give, s.pb(pid, P_RES + give) - rate);
+        s.spb(pid, P_VIS + give, max(s.pb(pid, P_VIS + give) - rate, 0));
+        s.sb(B_BANK + give, s.b(B_BANK + give) + rate);
+        s.sb(B_BANK + want, s.b(B_BANK + want) - 1);
+        D5 d = d5_zero();
+        d5_add(d, want, 1); d5_add(d, give, -rate);
+        update_estimates(s, seatof, d, (1 << want) | (1 << give), pid, -1);
+        break;
+    }
+    case T_PROPOSE: {                                                      // game.py:735-750, wrapper.py:440-486
+        flags |= F_MUST_RESPOND;
+        s.sb(B_FLAGS, flags);
+        s.sb(B_TRADE_PROP, pid);
+        s.sb(B_TRADE_TGT, player_at_label(order, seatof, pid, a[6]));
+        int ng = 0, nr = 0;
+        bool stop = false;
+        for (int i = 0; i < 4; i++) { int v = a[7 + i]; if (v <= 0 || v > 5) stop = true; s.sb(B_TRADE_GIVE + i, stop ? 0 : v); if (!stop) ng++; }
+        stop = false;
+        for (int i = 0; i < 4; i++) { int v = a[11 + i]; if (v <= 0 || v > 5) stop = true; s.sb(B_TRADE_RECV + i, stop ? 0 : v); if (!stop) nr++; }
+        s.sb(B_TRADE_NG, ng); s.sb(B_TRADE_NR, nr);
+        s.sb(B_TRADES, s.b(B_TRADES) + 1);
+        break;
+    }
+    case T_RESPOND: {                                                      // game.py:751-784
+        if (a[5] == 0) {
+            int p1 = s.b(B_TRADE_PROP), p2 = s.b(B_TRADE_TGT);
+            int ng = s.b(B_TRADE_NG), nr = s.b(B_TRADE_NR);
+            D5 d1 = d5_zero(), d2 = d5_zero();
+            int t1 = 0;
+            for (int i = 0; i < 4; i++) if (i < ng) {
+                int r0 = s.b(B_TRADE_GIVE + i) - 1;
+                s.spb(p1, P_RES + r0, s.pb(p1, P_RES + r0) - 1);
+                s.spb(p1, P_VIS + r0, max(s.pb(p1, P_VIS + r0) - 1, 0));
+                s.spb(p2, P_RES + r0, s.pb(p2, P_RES + r0) + 1);
+                s.spb(p2, P_VIS + r0, s.pb(p2, P_VIS + r0) + 1);
+                d5_add(d1, r0, -1); d5_add(d2, r0, 1); t1 |= 1 << r0;
+            }
+            for (int i = 0; i < 4; i++) if (i < nr) {
+                int r0 = s.b(B_TRADE_RECV + i) - 1;
+                s.spb(p1, P_RES + r0, s.pb(p1, P_RES + r0) + 1);
+                s.spb(p1, P_VIS + r0, s.pb(p1, P_VIS + r0) + 1);
+                s.spb(p2, P_RES + r0, s.pb(p2, P_RES + r0) - 1);
+                s.spb(p2, P_VIS + r0, max(s.pb(p2, P_VIS + r0) - 1, 0));
+                d5_add(d1, r0, 1); d5_add(d2, r0, -1); t1 |= 1 << r0;
+            }
+            update_estimates(s, seatof, d1, t1, p1, -1);
+            update_estimates(s, seatof, d2, t1, p2, -1);
+        }
+        flags &= ~F_MUST_RESPOND;
+        s.sb(B_FLAGS, flags);
+        s.sb(B_TRADE_PROP, 0); s.sb(B_TRADE_TGT, 0); s.sb(B_TRADE_NG, 0); s.sb(B_TRADE_NR, 0);
+        for (int i = 0; i < 4; i++) { s.sb(B_TRADE_GIVE + i, 0); s.sb(B_TRADE_RECV + i, 0); }
+        break;
+    }
+    case T_DISCARD: {                                                      // game.py:785-807
+        int who = s.b(B_DISC), r0 = a[17];
+        s.spb(who, P_RES + r0, s.pb(who, P_RES + r0) - 1);
+        s.sb(B_BANK + r0, s.b(B_BANK + r0) + 1);
+        update_estimates1(s, seatof, r0, -1, who);
+        if (s.total(who) <= 7) {
+            int n = s.b(B_NDISC);
+            for (int i = 0; i + 1 < 4; i++) s.sb(B_DISC + i, (i + 1 < n) ? s.b(B_DISC + i + 1) : 0);
+            s.sb(B_DISC + 3, 0);
+            s.sb(B_NDISC, n - 1);
+        }
+        break;
+    }
+    default: break;
+    }
+    if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
+
+    // ---- update_longest_road (game.py:864-919), path lengths computed wave-cooperatively
+    {
+        int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L);
+        bool cut = false;
+        int holder = 0, hcount = 0;
+        if (lr_who >= 0) {
+            s.spb(lr_who, P_CURLP, len);
+            holder = s.b(B_LR_PLAYER); hcount = s.b(B_LR_COUNT);
+            if (holder == 0) {
+                if (len >= 5) { s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2); }
+            } else if (holder == lr_who + 1) {
+                if (hcount > len) cut = true; else s.sb(B_LR_COUNT, len);
+            } else if (len > hcount) {
+                s.spb(holder - 1, P_VP, s.pb(holder - 1, P_VP) - 2);
+                s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2);
+                s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len);
+            }
+        }
+        if (__ballot(cut)) {                                               // game.py:880-912 (rare)
+            int max_len = len, player = lr_who;
+            bool tied = false;
+            for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
+                int pl = coop_longest_path(cut && o != lr_who, s, o, L);
+                if (cut && o != lr_who) {
+                    if (pl == max_len) tied = true;
+                    else if (pl > max_len) { max_len = pl; tied = false; player = o; }
+                }
+            }
+            if (cut) {
+                if (max_len >= 5) {
+                    if (tied) {
+                        if (player == lr_who) s.sb(B_LR_COUNT, len);
+                        else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
+                    } else {
+                        s.sb(B_LR_PLAYER, player + 1); s.sb(B_LR_COUNT, max_len);
+                        s.spb(player, P_VP, s.pb(player, P_VP) + 2);
+                        s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2);
+                    }
+                } else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
+            }
+        }
+    }
+
+    // ---- done / rewards (wrapper.py:85-112)
+    if (live) {
+        const int dict_order[4] = { 1, 3, 2, 0 };                          // Blue, Red, Orange, White (game.py:18-23)
+        int vps[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) vps[p] = s.pb(p, P_VP);
+        int winner = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (vps[dict_order[i]] >= 10) winner = dict_order[i] + 1;
+        bool dn = winner != 0 && type >= 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float r = 0.0f;
+            if (type >= 0) {
+                if (cfg.dense_reward) {
+                    r += 5.0f * (float)(vps[p] - s.b(B_CURVP + p));
+                    if (type == T_PLAYDEV) r += 5.0f;
+                    if (type == T_ROBBER) r += 1.0f;
+                    if (type == T_DISCARD) r -= 0.3f;
+                    if (type == T_CITY) r += 2.5f;
+                    r *= cfg.annealing;
+                }
+                s.sb(B_CURVP + p, vps[p]);
+                if (dn && winner == p + 1) r += cfg.win_reward;
+            }
+            reward[(long)p * c.n + s.e] = r;
+        }
+        if (dn) s.sb(B_WINNER, winner);
+        done[s.e] = dn ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ random policy
+DEVI int nth_set(u64 v, int nth) {
+    for (int i = 0; i < nth; i++) v &= v - 1;
+    return __ffsll((long long)v) - 1;
+}
+DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * k) >> 32)-th
+    int k = __popcll(v);
+    if (k == 0) return 0;
+    return nth_set(v, (int)__umulhi(w, (u32)k));
+}
+// DESIGN.md "random policy": philox stream 1, blocks 2*step_idx and 2*step_idx+1 -> words w0..w7
+__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions) {
+    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    if (s.e >= c.n) return;
+    u32 m[MASK_WORDS];
+#pragma unroll
+    for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[(long)i * c.N + s.e];
+    u64 id = c.env_id0 + (u64)s.e;
+    u32 w[8];
+    {
+        u32 o[4];
+        philox4x32_10(2 * step_idx, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
+        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+    }
+    int a[ACTION_WORDS];
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
+    int t = pick64(getr<M0, 13>(m), w[0]);
+    a[0] = t;
+    switch (t) {
+    case T_SETTLE: a[1] = pick64(getr<M1, 54>(m), w[1]); break;
+    case T_CITY: a[1] = pick64(getr<M1 + 54, 54>(m), w[1]); break;
+    case T_ROAD: {
+        u64 lo = getr<M2, 64>(m), hi = getr<M2 + 64, 9>(m);
+        int k = __popcll(lo) + __popcll(hi);
+        int nth = k ? (int)__umulhi(w[1], (u32)k) : 0;
+        int nlo = __popcll(lo);
+        a[2] = k == 0 ? 0 : (nth < nlo ? nth_set(lo, nth) : 64 + nth_set(hi, nth - nlo));
+        break;
+    }
+    case T_ROBBER: a[3] = pick64(getr<M3, 19>(m), w[1]); break;
+    case T_PLAYDEV:
+        a[4] = pick64(getr<M4, 5>(m), w[1]);
+        if (a[4] == C_MONO) a[15] = pick64(getr<M9 + 10, 5>(m), w[2]);
+        else if (a[4] == C_YOP) { a[15] = pick64(getr<M9 + 15, 5>(m), w[2]); a[16] = pick64(getr<M10, 5>(m), w[3]); }
+        break;
+    case T_EXCHANGE: a[15] = pick64(getr<M9, 5>(m), w[1]); a[16] = pick64(getr<M10, 5>(m), w[2]); break;
+    case T_PROPOSE: {
+        {
+            u32 o[4];
+            philox4x32_10(2 * step_idx + 1, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
+            w[4] = o[0]; w[5] = o[1]; w[6] = o[2]; w[7] = o[3];
+        }
+        int pid = s.b(B_GO);
+        int hand[5], tot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { hand[r] = s.res(pid, r); tot += hand[r]; }
+        a[6] = (int)__umulhi(w[1], 3u);
+        int n_give = 1 + (int)(w[2] & 1u), n_recv = 1 + (int)((w[2] >> 1) & 1u);
+        if (n_give > tot) n_give = tot;
+#pragma unroll
+        for (int i = 0; i < 2; i++) if (i < n_give) {
+            int nth = (int)__umulhi(w[3 + i], (u32)tot), r = 0;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 5; k++) if (!found) { if (nth < hand[k]) { r = k; found = true; } else nth -= hand[k]; }
+            a[7 + i] = r + 1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) hand[k] -= (k == r) ? 1 : 0;
+            tot--;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) if (i < n_recv) a[11 + i] = 1 + (int)__umulhi(w[5 + i], 5u);
+        break;
+    }
+    case T_RESPOND: a[5] = pick64(getr<M5, 2>(m), w[1]); break;
+    case T_STEAL: a[6] = pick64(getr<M6 + 3, 3>(m), w[1]); break;
+    case T_DISCARD: a[17] = pick64(getr<M11, 5>(m), w[1]); break;
+    default: break;
+    }
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) actions[(long)i * c.n + s.e] = a[i];
+}
+
+// ------------------------------------------------------------------------------------------------ deciding seat
+// ref: env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.  out = PlayerId 1..4
+__global__ __launch_bounds__(BLOCK) void k_deciding(Ctx c, i32* __restrict__ out) {
+    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    if (s.e >= c.n) return;
+    int p;
+    if (s.b(B_NDISC) > 0) p = s.b(B_DISC);
+    else if (s.flags() & F_MUST_RESPOND) p = s.b(B_TRADE_TGT);
+    else p = s.b(B_GO);
+    out[s.e] = p + 1;
+}
+
+// ------------------------------------------------------------------------------------------------ export / import
+// canonical int32 blob, layout spec.py STATE_FIELDS; blob is [STATE_WORDS][cnt] (word-major); idx = game ids or null
+struct BlobW {
+    i32* p; long cnt, i; int k;
+    DEVI void put(int v) { p[(long)k * cnt + i] = v; k++; }
+};
+__global__ __launch_bounds__(BLOCK) void k_export(Ctx c, const long* __restrict__ idx, long cnt, i32* __restrict__ blob) {
+    long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= cnt) return;
+    St s{ c.W, c.B, c.N, idx ? idx[i] : i };
+    BlobW o{ blob, cnt, i, 0 };
+    for (int t = 0; t < 19; t++) o.put(s.b(B_TILE + t) & 15);
+    for (int t = 0; t < 19; t++) o.put(s.b(B_TILE + t) >> 4);
+    o.put(s.b(B_ROBBER));
+    for (int t = 0; t < 9; t++) o.put(s.b(B_HARB + t));
+    u64 st[4], ct[4], rl[4]; u32 rh[4];
+    for (int p = 0; p < 4; p++) { st[p] = s.settle(p); ct[p] = s.city(p); rl[p] = s.road_lo(p); rh[p] = s.road_hi(p); }
+    for (int cn = 0; cn < 54; cn++) { int v = 0; for (int p = 0; p < 4; p++) { if ((st[p] >> cn) & 1) v = 1; if ((ct[p] >> cn) & 1) v = 2; } o.put(v); }
+    for (int cn = 0; cn < 54; cn++) { int v = 0; for (int p = 0; p < 4; p++) if (((st[p] | ct[p]) >> cn) & 1) v = p + 1; o.put(v); }
+    for (int e = 0; e < 72; e++) { int v = 0; for (int p = 0; p < 4; p++) if (e < 64 ? ((rl[p] >> e) & 1) : ((rh[p] >> (e - 64)) & 1)) v = p + 1; o.put(v); }
+    for (int p = 0; p < 4; p++) {
+        for (int r = 0; r < 5; r++) o.put(s.pb(p, P_RES + r));
+        for (int r = 0; r < 5; r++) o.put(s.pb(p, P_VIS + r));
+        Est E[3];
+        for (int l = 0; l < 3; l++) est_load(s, p, l, E[l]);
+        for (int l = 0; l < 3; l++) for (int r = 0; r < 5; r++) o.put(E[l].mn[r]);
+        for (int l = 0; l < 3; l++) for (int r = 0; r < 5; r++) o.put(E[l].mx[r]);
+        int hb = s.pb(p, P_HARB);
+        for (int k = 0; k < 6; k++) o.put((hb >> k) & 1);
+        int nh = s.pb(p, P_NHID);
+        o.put(nh);
+        for (int k = 0; k < 25; k++) o.put(k < nh ? s.pb(p, P_HIDDEN + k) : -1);
+        int np = s.pb(p, P_NPLAYED);
+        o.put(np);
+        for (int k = 0; k < 25; k++) o.put(k < np ? s.pb(p, P_PLAYED + k) : -1);
+        o.put(s.pb(p, P_VP));
+    }
+    for (int r = 0; r < 5; r++) o.put(s.b(B_BANK + r));
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_SLEFT));
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_CLEFT));
+    int pl = s.b(B_PILE_LEN);
+    o.put(pl);
+    for (int k = 0; k < 25; k++) o.put(k < pl ? s.b(B_PILE + k) : -1);
+    int order = s.b(B_ORDER);
+    for (int k = 0; k < 4; k++) o.put(pid_at(order, k) + 1);
+    o.put(s.b(B_ORDER_ID)); o.put(s.b(B_GO) + 1);
+    int fl = s.flags();
+    o.put((fl & F_INITIAL) ? 1 : 0);
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_ISET));
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_IROAD));
+    for (int p = 0; p < 4; p++) { int v = s.pb(p, P_ISECOND); o.put(v == 255 ? -1 : v); }
+    o.put((fl & F_ROLLED) ? 1 : 0); o.put((fl & F_PLAYED_DEV) ? 1 : 0); o.put((fl & F_MUST_USE_DEV) ? 1 : 0);
+    int mr = (fl & F_MUST_RESPOND) ? 1 : 0;
+    o.put(mr);
+    o.put(mr ? s.b(B_TRADE_PROP) + 1 : 0); o.put(mr ? s.b(B_TRADE_TGT) + 1 : 0);
+    o.put(s.b(B_TRADE_NG));
+    for (int k = 0; k < 4; k++) o.put(s.b(B_TRADE_GIVE + k));
+    o.put(s.b(B_TRADE_NR));
+    for (int k = 0; k < 4; k++) o.put(s.b(B_TRADE_RECV + k));
+    o.put((fl & F_RB_ACTIVE) ? 1 : 0); o.put(s.b(B_RB_COUNT));
+    o.put((fl & F_CAN_ROBBER) ? 1 : 0); o.put((fl & F_JUST_ROBBER) ? 1 : 0);
+    int nd = s.b(B_NDISC);
+    o.put(nd > 0 ? 1 : 0); o.put(nd);
+    for (int k = 0; k < 4; k++) o.put(k < nd ? s.b(B_DISC + k) + 1 : 0);
+    o.put(s.b(B_DIE1)); o.put(s.b(B_DIE2));
+    o.put(s.b(B_TRADES)); o.put((int)s.w(W_ACTIONS)); o.put((int)s.w(W_TURN));
+    for (int k = 0; k < 5; k++) o.put(s.b(B_BOUGHT + k));
+    o.put(s.b(B_LR_PLAYER)); o.put(s.b(B_LR_COUNT)); o.put(s.b(B_LA_PLAYER)); o.put(s.b(B_LA_COUNT));
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_CURLP));
+    for (int p = 0; p < 4; p++) o.put(s.pb(p, P_ARMY));
+    for (int p = 0; p < 4; p++) o.put(s.b(B_CURVP + p));
+    o.put(s.b(B_WINNER));
+    o.put((int)s.w(W_RNG));
+}
+
+struct BlobR {
+    const i32* p; long cnt, i; int k;
+    DEVI int get() { int v = p[(long)k * cnt + i]; k++; return v; }
+};
+__global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict__ idx, long cnt, const i32* __restrict__ blob) {
+    long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= cnt) return;
+    St s{ c.W, c.B, c.N, idx ? idx[i] : i };
+    BlobR in{ blob, cnt, i, 0 };
+    for (int r = 0; r < NW; r++) s.sw(r, 0);
+    for (int r = 0; r < NB; r++) s.sb(r, 0);
+    int tr[19];
+    for (int t = 0; t < 19; t++) tr[t] = in.get();
+    for (int t = 0; t < 19; t++) s.sb(B_TILE + t, tr[t] | (in.get() << 4));
+    s.sb(B_ROBBER, in.get());
+    for (int t = 0; t < 9; t++) s.sb(B_HARB + t, in.get());
+    u64 bld1 = 0, bld2 = 0;
+    for (int cn = 0; cn < 54; cn++) { int v = in.get(); if (v == 1) bld1 |= 1ull << cn; if (v == 2) bld2 |= 1ull << cn; }
+    u64 st[4] = { 0, 0, 0, 0 }, ct[4] = { 0, 0, 0, 0 };
+    for (int cn = 0; cn < 54; cn++) {
+        int v = in.get();
+        for (int p = 0; p < 4; p++) if (v == p + 1) { if ((bld1 >> cn) & 1) st[p] |= 1ull << cn; if ((bld2 >> cn) & 1) ct[p] |= 1ull << cn; }
+    }
+    for (int p = 0; p < 4; p++) { s.set_settle(p, st[p]); s.set_city(p, ct[p]); }
+    u32 rd[4][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    for (int e = 0; e < 72; e++) { int v = in.get(); for (int p = 0; p < 4; p++) if (v == p + 1) rd[p][e >> 5] |= 1u << (e & 31); }
+    for (int p = 0; p < 4; p++) { s.sw(W_ROAD0 + p, rd[p][0]); s.sw(W_ROAD1 + p, rd[p][1]); s.sw(W_ROAD2 + p, rd[p][2]); }
+    for (int p = 0; p < 4; p++) {
+        for (int r = 0; r < 5; r++) s.spb(p, P_RES + r, in.get());
+        for (int r = 0; r < 5; r++) s.spb(p, P_VIS + r, in.get());
+        Est E[3];
+        for (int l = 0; l < 3; l++) for (int r = 0; r < 5; r++) E[l].mn[r] = in.get();
+        for (int l = 0; l < 3; l++) for (int r = 0; r < 5; r++) E[l].mx[r] = in.get();
+        for (int l = 0; l < 3; l++) est_store(s, p, l, E[l]);
+        int hb = 0;
+        for (int k = 0; k < 6; k++) hb |= (in.get() ? 1 : 0) << k;
+        s.spb(p, P_HARB, hb);
+        int nh = in.get();
+        s.spb(p, P_NHID, nh);
+        int cnt5[5] = { 0, 0, 0, 0, 0 };
+        for (int k = 0; k < 25; k++) {
+            int v = in.get();
+            if (k < nh) { s.spb(p, P_HIDDEN + k, v); for (int q = 0; q < 5; q++) cnt5[q] += (q == v) ? 1 : 0; }
+        }
+        for (int q = 0; q < 5; q++) s.spb(p, P_HCNT + q, cnt5[q]);
+        int np = in.get();
+        s.spb(p, P_NPLAYED, np);
+        for (int k = 0; k < 25; k++) { int v = in.get(); if (k < np) s.spb(p, P_PLAYED + k, v); }
+        s.spb(p, P_VP, in.get());
+    }
+    for (int r = 0; r < 5; r++) s.sb(B_BANK + r, in.get());
+    for (int p = 0; p < 4; p++) s.spb(p, P_SLEFT, in.get());
+    for (int p = 0; p < 4; p++) s.spb(p, P_CLEFT, in.get());
+    int pl = in.get();
+    s.sb(B_PILE_LEN, pl);
+    for (int k = 0; k < 25; k++) { int v = in.get(); if (k < pl) s.sb(B_PILE + k, v); }
+    int order = 0, seatof = 0;
+    for (int k = 0; k < 4; k++) { int p = in.get() - 1; order |= p << (2 * k); seatof |= k << (2 * p); }
+    s.sb(B_ORDER, order); s.sb(B_SEATOF, seatof);
+    s.sb(B_ORDER_ID, in.get()); s.sb(B_GO, in.get() - 1);
+    int fl = 0;
+    if (in.get()) fl |= F_INITIAL;
+    for (int p = 0; p < 4; p++) s.spb(p, P_ISET, in.get());
+    for (int p = 0; p < 4; p++) s.spb(p, P_IROAD, in.get());
+    for (int p = 0; p < 4; p++) { int v = in.get(); s.spb(p, P_ISECOND, v < 0 ? 255 : v); }
+    if (in.get()) fl |= F_ROLLED;
+    if (in.get()) fl |= F_PLAYED_DEV;
+    if (in.get()) fl |= F_MUST_USE_DEV;
+    int mr = in.get();
+    if (mr) fl |= F_MUST_RESPOND;
+    { int a = in.get(), b = in.get(); s.sb(B_TRADE_PROP, mr ? a - 1 : 0); s.sb(B_TRADE_TGT, mr ? b - 1 : 0); }
+    s.sb(B_TRADE_NG, in.get());
+    for (int k = 0; k < 4; k++) s.sb(B_TRADE_GIVE + k, in.get());
+    s.sb(B_TRADE_NR, in.get());
+    for (int k = 0; k < 4; k++) s.sb(B_TRADE_RECV + k, in.get());
+    if (in.get()) fl |= F_RB_ACTIVE;
+    s.sb(B_RB_COUNT, in.get());
+    if (in.get()) fl |= F_CAN_ROBBER;
+    if (in.get()) fl |= F_JUST_ROBBER;
+    s.sb(B_FLAGS, fl);
+    in.get();                      // need_discard (derived from n_to_discard)
+    int nd = in.get();
+    s.sb(B_NDISC, nd);
+    for (int k = 0; k < 4; k++) { int v = in.get(); s.sb(B_DISC + k, k < nd ? v - 1 : 0); }
+    s.sb(B_DIE1, in.get()); s.sb(B_DIE2, in.get());
+    s.sb(B_TRADES, in.get()); s.sw(W_ACTIONS, (u32)in.get()); s.sw(W_TURN, (u32)in.get());
+    for (int k = 0; k < 5; k++) s.sb(B_BOUGHT + k, in.get());
+    s.sb(B_LR_PLAYER, in.get()); s.sb(B_LR_COUNT, in.get()); s.sb(B_LA_PLAYER, in.get()); s.sb(B_LA_COUNT, in.get());
+    for (int p = 0; p < 4; p++) s.spb(p, P_CURLP, in.get());
+    for (int p = 0; p < 4; p++) s.spb(p, P_ARMY, in.get());
+    for (int p = 0; p < 4; p++) s.sb(B_CURVP + p, in.get());
+    s.sb(B_WINNER, in.get());
+    s.sw(W_RNG, (u32)in.get());
+}
+
+}  // namespace catan

@@ -1,0 +1,111 @@
+// catan_state.h - packed struct-of-arrays game state in HBM (one game per lane).
+//
+// Layout: one allocation per handle, `N` = number of games padded to a multiple of 64.
+//   u32 rows  W[NW][N]   bitboards (corners 54 bit, edges 72 bit), packed opponent-hand estimates, counters
+//   u8  rows  B[NB][N]   every other small integer of the game
+// Row r of game e lives at W[r*N + e] / B[r*N + e]: the 64 lanes of a wave touch 64 consecutive
+// elements of one row (one 256 B / 64 B segment) on every access.  672 B per game in total
+// (the reference-like int32 form of the same state is 736 words = 2944 B, see spec.py STATE_FIELDS).
+//
+// Players are indexed by pid0 = PlayerId-1 (0 White, 1 Blue, 2 Orange, 3 Red; reference game/enums.py:8-12).
+// Resources r0 = Resource-1 (0 Brick, 1 Wood, 2 Ore, 3 Sheep, 4 Wheat; game/enums.py:22-28).
+#pragma once
+#include <stdint.h>
+
+namespace catan {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+// ---- u32 rows
+constexpr int W_SETTLE_LO = 0;    // +p : settlements of player p, corners 0..31
+constexpr int W_SETTLE_HI = 4;    // +p : corners 32..53
+constexpr int W_CITY_LO = 8;      // +p
+constexpr int W_CITY_HI = 12;     // +p
+constexpr int W_ROAD0 = 16;       // +p : edges 0..31
+constexpr int W_ROAD1 = 20;       // +p : edges 32..63
+constexpr int W_ROAD2 = 24;       // +p : edges 64..71
+// opponent-hand estimates (Player.opponent_min_res / opponent_max_res, reference game/components/player.py:39-44):
+// for observer o and label l (0 next, 1 next_next, 2 next_next_next) three words:
+//   +0 : min of resources r0=0..3 (one byte each)   +1 : max of r0=0..3   +2 : min(r0=4) | max(r0=4) << 8
+constexpr int W_EST = 28;         // + (o*3 + l)*3 + k   (36 rows)
+constexpr int W_RNG = 64;         // philox draw counter of the game stream
+constexpr int W_TURN = 65;
+constexpr int W_ACTIONS = 66;     // actions_this_turn
+constexpr int NW = 67;
+
+// ---- u8 rows
+constexpr int B_TILE = 0;         // +t (19): resource | value << 4
+constexpr int B_HARB = 19;        // +slot (9): harbour id placed at slot
+constexpr int B_ROBBER = 28;
+constexpr int B_BANK = 29;        // +r0 (5)
+constexpr int B_PILE_LEN = 34;
+constexpr int B_PILE = 35;        // +i (25): dev-card pile, popped from index pile_len-1
+constexpr int B_ORDER = 60;       // player_order packed: seat i -> pid0 in bits 2i..2i+1
+constexpr int B_SEATOF = 61;      // inverse: pid0 p -> seat in bits 2p..2p+1
+constexpr int B_ORDER_ID = 62;
+constexpr int B_GO = 63;          // players_go as pid0
+constexpr int B_FLAGS = 64;
+constexpr int B_RB_COUNT = 65;
+constexpr int B_TRADE_PROP = 66;  // pid0
+constexpr int B_TRADE_TGT = 67;   // pid0
+constexpr int B_TRADE_NG = 68;
+constexpr int B_TRADE_GIVE = 69;  // +i (4): Resource value 1..5
+constexpr int B_TRADE_NR = 73;
+constexpr int B_TRADE_RECV = 74;  // +i (4)
+constexpr int B_NDISC = 78;       // len(players_to_discard); players_need_to_discard == (n > 0)
+constexpr int B_DISC = 79;        // +i (4): pid0
+constexpr int B_DIE1 = 83;
+constexpr int B_DIE2 = 84;
+constexpr int B_TRADES = 85;      // trades_proposed_this_turn
+constexpr int B_LR_PLAYER = 86;   // 0 none, else PlayerId
+constexpr int B_LR_COUNT = 87;
+constexpr int B_LA_PLAYER = 88;   // 0 none, else PlayerId
+constexpr int B_LA_COUNT = 89;
+constexpr int B_BOUGHT = 90;      // +card (5): development_cards_bought_this_turn counts
+constexpr int B_CURVP = 95;       // +p (4): EnvWrapper.curr_vps
+constexpr int B_WINNER = 99;      // 0 none, else PlayerId
+constexpr int B_PLAYER = 100;     // + p*PB + field
+constexpr int PB = 76;
+constexpr int P_RES = 0;          // +r0 (5)
+constexpr int P_VIS = 5;          // +r0 (5)
+constexpr int P_HARB = 10;        // bit 0 generic 3:1, bit r0+1 the 2:1 harbour of resource r0
+constexpr int P_VP = 11;
+constexpr int P_NHID = 12;
+constexpr int P_NPLAYED = 13;
+constexpr int P_HCNT = 14;        // +card (5): count of each card type in hidden_cards (derived)
+constexpr int P_SLEFT = 19;
+constexpr int P_CLEFT = 20;
+constexpr int P_ISET = 21;
+constexpr int P_IROAD = 22;
+constexpr int P_ISECOND = 23;     // 255 = None
+constexpr int P_CURLP = 24;       // current_longest_path
+constexpr int P_ARMY = 25;        // current_army_size
+constexpr int P_HIDDEN = 26;      // +i (25) ordered
+constexpr int P_PLAYED = 51;      // +i (25) ordered
+constexpr int NB = B_PLAYER + 4 * PB;   // 404
+
+constexpr int STATE_BYTES_PER_GAME = NW * 4 + NB;   // 672
+static_assert(STATE_BYTES_PER_GAME == 672, "restate DESIGN.md byte table when the layout changes");
+
+// B_FLAGS bits
+constexpr int F_INITIAL = 1, F_ROLLED = 2, F_PLAYED_DEV = 4, F_MUST_USE_DEV = 8, F_MUST_RESPOND = 16,
+              F_RB_ACTIVE = 32, F_CAN_ROBBER = 64, F_JUST_ROBBER = 128;
+
+// enums (reference game/enums.py:30-50)
+enum { C_KNIGHT = 0, C_VP = 1, C_YOP = 2, C_RB = 3, C_MONO = 4 };
+enum { T_SETTLE = 0, T_ROAD = 1, T_CITY = 2, T_BUYDEV = 3, T_PLAYDEV = 4, T_EXCHANGE = 5, T_PROPOSE = 6,
+       T_RESPOND = 7, T_ROBBER = 8, T_ROLL = 9, T_ENDTURN = 10, T_STEAL = 11, T_DISCARD = 12 };
+// r0 indices
+enum { R_BRICK = 0, R_WOOD = 1, R_ORE = 2, R_SHEEP = 3, R_WHEAT = 4 };
+
+// flat mask offsets (EnvWrapper.get_action_masks, reference env/wrapper.py:172-185)
+constexpr int M0 = 0, M1 = 13, M2 = 175, M3 = 248, M4 = 267, M5 = 272, M6 = 274, M7 = 283, M8 = 289, M9 = 295,
+              M10 = 315, M11 = 320, MASK_BITS = 325, MASK_WORDS = 11;
+constexpr int ACTION_WORDS = 18;
+constexpr int STATE_WORDS = 736;   // canonical int32 blob (spec.py)
+constexpr int OBS_FLOATS = 1787;
+
+}  // namespace catan

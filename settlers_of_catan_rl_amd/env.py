@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference env interface over libcatan_hip.so.
+
+* `VecCatanEnv`  - N games on one GPU; torch tensors in, torch tensors out (zero-copy device pointers).
+* `EnvWrapper`   - single-game view with the reference's signatures (`reset() -> obs`, `step(action) ->
+                   (obs, reward_dict, done, info)`, `get_action_masks() -> list of 12 np.ndarray`,
+                   `save_state()/restore_state()`), reference env/wrapper.py:11-50,168-185,711-721, so that
+                   RL/ppo/game_manager.py style callers keep working.
+PyTorch is only plumbing here (device memory + streams); all game logic runs in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, spec
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class VecCatanEnv(object):
+    def __init__(self, num_envs, seed=0, env_id0=0, device=None, max_proposed_trades_per_turn=4, win_reward=500.0,
+                 dense_reward=False, validate_actions=True, auto_reset=True):
+        if not torch.cuda.is_available():
+            raise _lib.CatanHipError("VecCatanEnv needs a HIP device (no CPU fallback)")
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n = int(num_envs)
+        cfg = _lib.CatanCfg()
+        self.L.catan_cfg_default(C.byref(cfg))
+        cfg.max_proposed_trades_per_turn = -1 if max_proposed_trades_per_turn is None else int(max_proposed_trades_per_turn)
+        cfg.win_reward = float(win_reward)
+        cfg.dense_reward = int(bool(dense_reward))
+        cfg.validate_actions = int(bool(validate_actions))
+        cfg.auto_reset = int(bool(auto_reset))
+        self.cfg = cfg
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.catan_create(C.byref(h), self.device.index or 0, self.n, seed, env_id0, C.byref(cfg)))
+        self.h = h
+        self.reward = torch.zeros((4, self.n), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.catan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference-shaped calls, batched
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self.L.catan_reset(self.h, _ptr(m), _stream()))
+
+    def step(self, actions):
+        """actions: int32 [18][n] (head-major).  Returns (reward [4][n] float32, done [n] uint8) - views of
+        buffers owned by the env, overwritten by the next step."""
+        a = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        assert a.shape == (spec.ACTION_WORDS, self.n), a.shape
+        _lib.check(self.L.catan_step(self.h, _ptr(a), _ptr(self.reward), _ptr(self.done), _stream()))
+        return self.reward, self.done
+
+    def get_action_masks(self, out=None):
+        """float32 [n][325]; slice with spec.MASK_OFFSETS / MASK_SHAPES for the 12 heads."""
+        if out is None:
+            out = torch.empty((self.n, spec.MASK_WORDS), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.catan_masks(self.h, _ptr(out), _stream()))
+        return out
+
+    def get_action_masks_by_head(self):
+        flat = self.get_action_masks()
+        return [flat[:, o:o + s].reshape((self.n,) + shp)
+                for o, s, shp in zip(spec.MASK_OFFSETS, spec.MASK_SIZES, spec.MASK_SHAPES)]
+
+    def deciding_player(self):
+        out = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_deciding_seat(self.h, _ptr(out), _stream()))
+        return out
+
+    def sample_random_actions(self, step_idx, out=None):
+        if out is None:
+            out = torch.empty((spec.ACTION_WORDS, self.n), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_sample_random_actions(self.h, int(step_idx), _ptr(out), _stream()))
+        return out
+
+    def random_rollout(self, step_idx0, steps):
+        _lib.check(self.L.catan_random_rollout(self.h, int(step_idx0), int(steps), _stream()))
+
+    def random_rollout_timed(self, step_idx0, steps):
+        """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream)."""
+        ms = (C.c_float * 4)()
+        _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), _stream(), ms))
+        return dict(zip(("k_sample_random", "k_step", "k_reset", "k_masks"), [float(x) for x in ms]))
+
+    def export_state(self, env_idx=None):
+        """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""
+        idx = None
+        cnt = self.n
+        if env_idx is not None:
+            idx = torch.as_tensor(env_idx, dtype=torch.int64, device=self.device).contiguous()
+            cnt = idx.numel()
+        blob = torch.empty((spec.STATE_WORDS, cnt), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_state_export(self.h, _ptr(blob), _ptr(idx), cnt, _stream()))
+        return blob.t().contiguous()
+
+    def import_state(self, blobs, env_idx=None):
+        b = torch.as_tensor(np.asarray(blobs), dtype=torch.int32).to(self.device)
+        if b.dim() == 1:
+            b = b[None]
+        cnt = b.shape[0]
+        idx = None
+        if env_idx is not None:
+            idx = torch.as_tensor(env_idx, dtype=torch.int64, device=self.device).contiguous()
+            assert idx.numel() == cnt
+        bt = b.t().contiguous()
+        _lib.check(self.L.catan_state_import(self.h, _ptr(bt), _ptr(idx), cnt, _stream()))
+
+    def invalid_action_count(self):
+        return int(self.L.catan_invalid_action_count(self.h, _stream()))
+
+    def set_reward_annealing_factor(self, f):
+        _lib.check(self.L.catan_set_reward_annealing(self.h, float(f)))
+
+
+class _GameView(object):
+    """The `env.game.*` attributes the reference's callers read: players_need_to_discard,
+    players_to_discard, must_respond_to_trade, proposed_trade["target_player"], players_go."""
+
+    def __init__(self, wrapper):
+        self._w = wrapper
+
+    def _field(self, name):
+        return spec.state_field(self._w._blob(), name)
+
+    @property
+    def players_need_to_discard(self):
+        return bool(self._field("need_discard")[0])
+
+    @property
+    def players_to_discard(self):
+        n = int(self._field("n_to_discard")[0])
+        return [int(x) for x in self._field("to_discard")[:n]]
+
+    @property
+    def must_respond_to_trade(self):
+        return bool(self._field("must_respond")[0])
+
+    @property
+    def proposed_trade(self):
+        if not self.must_respond_to_trade:
+            return None
+        ng, nr = int(self._field("trade_n_give")[0]), int(self._field("trade_n_recv")[0])
+        return {"player_proposing": int(self._field("trade_proposer")[0]),
+                "target_player": int(self._field("trade_target")[0]),
+                "player_proposing_res": [int(x) for x in self._field("trade_give")[:ng]],
+                "target_player_res": [int(x) for x in self._field("trade_recv")[:nr]]}
+
+    @property
+    def players_go(self):
+        return int(self._field("players_go")[0])
+
+
+class EnvWrapper(object):
+    """Single-game view with the reference EnvWrapper signatures (env/wrapper.py:11-50)."""
+
+    def __init__(self, max_proposed_trades_per_turn=4, validate_actions=True, win_reward=500, dense_reward=False,
+                 seed=0, env_id=0, **_ignored):
+        self.vec = VecCatanEnv(1, seed=seed, env_id0=env_id, max_proposed_trades_per_turn=max_proposed_trades_per_turn,
+                               win_reward=win_reward, dense_reward=dense_reward, validate_actions=validate_actions,
+                               auto_reset=False)
+        self.validate_actions = validate_actions
+        self.game = _GameView(self)
+        self._cache = None
+        self._reward_annealing_factor = 1.0
+
+    @property
+    def reward_annealing_factor(self):
+        return self._reward_annealing_factor
+
+    @reward_annealing_factor.setter
+    def reward_annealing_factor(self, f):
+        self._reward_annealing_factor = f
+        self.vec.set_reward_annealing_factor(f)
+
+    def _blob(self):
+        if self._cache is None:
+            self._cache = self.vec.export_state()[0].cpu().numpy()
+        return self._cache
+
+    def reset(self):
+        self.vec.reset()
+        self._cache = None
+        return self._get_obs()
+
+    def get_action_masks(self):
+        flat = self.vec.get_action_masks()[0].cpu().numpy().astype(np.float64)
+        return [flat[o:o + s].reshape(shp).copy()
+                for o, s, shp in zip(spec.MASK_OFFSETS, spec.MASK_SIZES, spec.MASK_SHAPES)]
+
+    def step(self, action):
+        flat = np.zeros((spec.ACTION_WORDS,), dtype=np.int32)
+        for h, (off, ln) in enumerate(spec.ACTION_HEAD_SLICES):
+            v = np.asarray(action[h]).reshape(-1)
+            flat[off:off + min(ln, len(v))] = v[:ln]
+        bad0 = self.vec.invalid_action_count() if self.validate_actions else 0
+        reward, done = self.vec.step(torch.from_numpy(flat).view(spec.ACTION_WORDS, 1))
+        self._cache = None
+        if self.validate_actions and self.vec.invalid_action_count() != bad0:
+            raise RuntimeError("invalid action (its legal-action mask bit is clear)")   # reference env/wrapper.py:38-41
+        r = reward[:, 0].cpu().numpy()
+        rew = {pid: float(r[pid - 1]) for pid in (1, 2, 3, 4)}
+        return self._get_obs(), rew, bool(done[0].item()), {"log": None}
+
+    def _get_obs(self):
+        from . import obs as _obs   # the observation encoder is a separate kernel + binding
+        return _obs.single_env_obs(self.vec)
+
+    def save_state(self):
+        return {"blob": self._blob().copy()}
+
+    def restore_state(self, state):
+        self.vec.import_state(state["blob"][None])
+        self._cache = None
+
+    @property
+    def winner(self):
+        w = int(spec.state_field(self._blob(), "winner")[0])
+        return None if w == 0 else type("Winner", (), {"id": w})()
+
+    @property
+    def curr_vps(self):
+        v = spec.state_field(self._blob(), "curr_vps")
+        return {pid: int(v[pid - 1]) for pid in (1, 2, 3, 4)}
