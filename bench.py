@@ -26,9 +26,12 @@ sys.path.insert(0, ROOT)
 # DESIGN.md "Roofline"): the minimum live set an ideal kernel must move, not what the kernel happens to touch.
 ALGO_BYTES = {
     "k_sample_random": 44 + 5 + 72,                 # packed masks + own hand + action out
-    "k_step": 72 + 44 + 17 + 216 + 96,              # action + masks(validate) + reward/done + state read + write-back
-    "k_reset": 1,                                   # done flag (a reset itself rewrites the 672 B game, ~1/2000 steps)
-    "k_masks": 28 * 4 + 48 + 44,                    # bitboards + control/hand/bank bytes + packed masks out
+    # fused step: action in (72) + packed masks in/out (44 + 44) + reward/done out (17) + the HOT state tile read
+    # (112 rows x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
+    # one bitboard word: ~40 rows x 4 B = 160)
+    "k_step": 72 + 44 + 44 + 17 + 448 + 160,
+    "k_lr_heavy": 0,                                # tier-2 longest road: LDS/ALU only (3 bitboard words per request)
+    "k_step_finish": 1,                             # pending flag; finishes the few games tier 2 handled
 }
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -108,7 +111,7 @@ def main():
         # per-kernel durations: HIP events on the launch stream, a separate short pass right after the timed region
         prof_steps = min(args.steps, 512)
         kms = env.random_rollout_timed(args.warmup + args.steps, prof_steps)
-        per_launch_us = {k: v * 1e3 / prof_steps for k, v in kms.items()}
+        per_launch_us = {k: v * 1e3 / prof_steps for k, v in kms.items() if k in ALGO_BYTES}
         dom = max(per_launch_us, key=per_launch_us.get)
         achieved = ALGO_BYTES[dom] * n / (per_launch_us[dom] * 1e-6) / 1e9
         total_us = sum(per_launch_us.values())

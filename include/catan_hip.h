@@ -96,8 +96,14 @@ int64_t catan_invalid_action_count(catan_env_t* env, catan_stream_t stream);
 int catan_random_rollout(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream);
 
 /* the same loop with a hipEvent pair around every kernel launch (recorded on `stream`); kernel_ms is a HOST
- * float[4] receiving the summed milliseconds of k_sample_random, k_step, k_reset, k_masks (bench.py roofline). */
+ * float[4] receiving the summed milliseconds of k_sample_random, k_step, k_lr_heavy, k_step_finish (bench.py roofline). */
 int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms);
+
+/* k_step phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums over waves then 8
+ * per-wave maxima, in 100 MHz wall-clock ticks, for the phases stage-in, validate+apply, tier-1 longest road,
+ * holder logic (+cut), done/reward, reset, masks, write-back. */
+int catan_profile_enable(catan_env_t* env, int on);
+int catan_profile_read(catan_env_t* env, uint64_t* out16);
 
 #ifdef __cplusplus
 }

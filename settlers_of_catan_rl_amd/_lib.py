@@ -64,6 +64,8 @@ _SIGS = {
     "catan_set_reward_annealing": (C.c_int, [_vp, C.c_float]),
     "catan_invalid_action_count": (C.c_int64, [_vp, _vp]),
     "catan_random_rollout": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp]),
+    "catan_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "catan_profile_read": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "catan_random_rollout_timed": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp, C.POINTER(C.c_float)]),
 }
 
@@ -79,6 +81,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CatanHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(the HIP path has no CPU fallback)")
+        # torch first: libcatan_hip.so must bind to the SAME libamdhip64 instance torch loaded, otherwise the
+        # process ends up with two HIP runtimes and device pointers / streams cannot be shared.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

@@ -24,6 +24,9 @@ struct catan_env {
     i32* scratch_actions; // [18][n]
     float* scratch_reward;// [4][n]
     u8* scratch_done;     // [n]
+    Pending pend;         // tier-2 longest-road hand-off (device arrays)
+    unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
+    int prof_on;
 };
 
 static thread_local std::string g_err;
@@ -78,11 +81,18 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_actions, (size_t)e->n * ACTION_WORDS * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_done, (size_t)e->n);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.count, 64);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req, (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, 2 * PROF_PHASES * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
-    e->ctx.W = (u32*)e->state;
-    e->ctx.B = (u8*)e->state + (size_t)e->N * NW * sizeof(u32);
+    HIPCHK(hipMemset(e->pend.count, 0, 64));
+    HIPCHK(hipMemset(e->pend.type, 0, (size_t)e->N));
+    e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
     e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
     e->ctx.env_id0 = env_id0;
@@ -102,6 +112,12 @@ void catan_destroy(catan_env_t* e) {
     if (e->scratch_actions) hipFree(e->scratch_actions);
     if (e->scratch_reward) hipFree(e->scratch_reward);
     if (e->scratch_done) hipFree(e->scratch_done);
+    if (e->prof) hipFree(e->prof);
+    if (e->pend.count) hipFree(e->pend.count);
+    if (e->pend.req) hipFree(e->pend.req);
+    if (e->pend.type) hipFree(e->pend.type);
+    if (e->pend.who) hipFree(e->pend.who);
+    if (e->pend.len) hipFree(e->pend.len);
     delete e;
 }
 
@@ -112,17 +128,24 @@ int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream
     return launch_masks(e, S(stream));
 }
 
-static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
+static StepCfg step_cfg(const catan_env_t* e) {
     StepCfg sc;
     sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
-    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn;
-    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc);
+    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn; sc.auto_reset = e->cfg.auto_reset;
+    sc.prof = e->prof_on ? e->prof : nullptr;
+    return sc;
+}
+// One env step = k_step (fused: apply + tier-1 longest road + done/reward + auto-reset + next masks) followed by the
+// two tier-2 kernels, which are no-ops unless some game's longest-road search overflowed its budget.
+constexpr int LR_HEAVY_GRID = 512;
+static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
+    StepCfg sc = step_cfg(e);
+    HIPCHK(hipMemsetAsync(e->pend.count, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
+    hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)e->pend.count, (const u64*)e->pend.req, e->pend.len);
+    hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
     HIPCHK(hipGetLastError());
-    if (e->cfg.auto_reset) {
-        hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const u8*)done);
-        HIPCHK(hipGetLastError());
-    }
-    return launch_masks(e, st);
+    return CATAN_OK;
 }
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
@@ -199,30 +222,29 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 
 // Same loop as catan_random_rollout but with a hipEvent pair around every kernel launch (events recorded on
 // `stream`, the stream the kernels run on).  kernel_ms (host, float[4]) receives the summed elapsed
-// milliseconds of: [0] k_sample_random  [1] k_step  [2] k_reset  [3] k_masks.  Used by bench.py's roofline leg.
+// milliseconds of: [0] k_sample_random  [1] k_step  [2] k_lr_heavy  [3] k_step_finish.
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
     const int K = 4;
     std::vector<hipEvent_t> ev((size_t)steps * (K + 1));
-    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
-    StepCfg sc;
-    sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
-    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn;
+    for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableSystemFence));   // no L2 flush between kernels
+    StepCfg sc = step_cfg(e);
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * (K + 1)];
+        HIPCHK(hipMemsetAsync(e->pend.count, 0, sizeof(u32), st));
         HIPCHK(hipEventRecord(v[0], st));
-        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, step_idx0 + (uint32_t)s, e->scratch_actions);
+        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s, e->scratch_actions);
         HIPCHK(hipEventRecord(v[1], st));
-        hipLaunchKernelGGL(k_step, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const i32*)e->scratch_actions, (const u32*)e->mpk, e->scratch_reward, e->scratch_done, e->err, sc);
+        hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const i32*)e->scratch_actions, e->mpk, e->scratch_reward, e->scratch_done, e->err, sc, e->pend);
         HIPCHK(hipEventRecord(v[2], st));
-        hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const u8*)e->scratch_done);
+        hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)e->pend.count, (const u64*)e->pend.req, e->pend.len);
         HIPCHK(hipEventRecord(v[3], st));
-        hipLaunchKernelGGL(k_masks, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn);
+        hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, e->scratch_reward, e->scratch_done, sc, e->pend);
         HIPCHK(hipEventRecord(v[4], st));
     }
     HIPCHK(hipStreamSynchronize(st));
-    for (int k = 0; k < K; k++) kernel_ms[k] = 0.0f;
+    for (int k = 0; k < 4; k++) kernel_ms[k] = 0.0f;
     for (int64_t s = 0; s < steps; s++)
         for (int k = 0; k < K; k++) {
             float ms = 0.0f;
@@ -230,6 +252,22 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
             kernel_ms[k] += ms;
         }
     for (auto& x : ev) hipEventDestroy(x);
+    return CATAN_OK;
+}
+
+// k_step phase profile (100 MHz wall_clock64 ticks): enable/zero, then read [8] sums over waves + [8] maxima.
+// phases: stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back.
+int catan_profile_enable(catan_env_t* e, int on) {
+    if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(e->prof, 0, 2 * PROF_PHASES * sizeof(unsigned long long)));
+    e->prof_on = on;
+    return CATAN_OK;
+}
+int catan_profile_read(catan_env_t* e, uint64_t* out16) {
+    if (!e || !out16) return fail(CATAN_EINVAL, "catan_profile_read: bad arguments");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out16, e->prof, 2 * PROF_PHASES * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 

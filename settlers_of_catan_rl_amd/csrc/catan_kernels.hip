@@ -35,35 +35,61 @@ constexpr int BLOCK = 256;
 constexpr u64 ALL54 = (1ull << 54) - 1;
 
 // ------------------------------------------------------------------------------------------------ state view
-struct St {
-    u32* W;
-    u8* B;
-    long N;   // padded number of games (row pitch)
-    long e;   // this lane's game
-    DEVI u32 w(int r) const { return W[(long)r * N + e]; }
-    DEVI void sw(int r, u32 v) const { W[(long)r * N + e] = v; }
-    DEVI int b(int r) const { return B[(long)r * N + e]; }
-    DEVI void sb(int r, int v) const { B[(long)r * N + e] = (u8)v; }
-    DEVI int pb(int p, int f) const { return b(B_PLAYER + p * PB + f); }
-    DEVI void spb(int p, int f, int v) const { sb(B_PLAYER + p * PB + f, v); }
-    DEVI u64 settle(int p) const { return (u64)w(W_SETTLE_LO + p) | ((u64)w(W_SETTLE_HI + p) << 32); }
-    DEVI u64 city(int p) const { return (u64)w(W_CITY_LO + p) | ((u64)w(W_CITY_HI + p) << 32); }
-    DEVI void set_settle(int p, u64 v) const { sw(W_SETTLE_LO + p, (u32)v); sw(W_SETTLE_HI + p, (u32)(v >> 32)); }
-    DEVI void set_city(int p, u64 v) const { sw(W_CITY_LO + p, (u32)v); sw(W_CITY_HI + p, (u32)(v >> 32)); }
-    DEVI u64 road_lo(int p) const { return (u64)w(W_ROAD0 + p) | ((u64)w(W_ROAD1 + p) << 32); }
-    DEVI u32 road_hi(int p) const { return w(W_ROAD2 + p); }
-    DEVI int flags() const { return b(B_FLAGS); }
-    DEVI int res(int p, int r0) const { return pb(p, P_RES + r0); }
-    DEVI int total(int p) const { return res(p, 0) + res(p, 1) + res(p, 2) + res(p, 3) + res(p, 4); }
-};
-
 struct Ctx {          // launch-invariant handle fields
-    u32* W;
-    u8* B;
-    long N;           // padded
+    u32* R;           // [NROWS][N]
+    long N;           // padded number of games (row pitch)
     long n;           // real number of games
     u32 key0, key1;   // philox key = seed
     u64 env_id0;      // global id of game 0 (multi-GPU shards keep their global ids)
+};
+
+// Derived helpers shared by the two state views (CRTP).
+template <class D>
+struct StOps {
+    DEVI const D& self() const { return *static_cast<const D*>(this); }
+    DEVI int pb(int p, int f) const { return self().b(B_PLAYER + p * PB + f); }
+    DEVI void spb(int p, int f, int v) const { self().sb(B_PLAYER + p * PB + f, v); }
+    DEVI u64 settle(int p) const { return (u64)self().w(W_SETTLE_LO + p) | ((u64)self().w(W_SETTLE_HI + p) << 32); }
+    DEVI u64 city(int p) const { return (u64)self().w(W_CITY_LO + p) | ((u64)self().w(W_CITY_HI + p) << 32); }
+    DEVI void set_settle(int p, u64 v) const { self().sw(W_SETTLE_LO + p, (u32)v); self().sw(W_SETTLE_HI + p, (u32)(v >> 32)); }
+    DEVI void set_city(int p, u64 v) const { self().sw(W_CITY_LO + p, (u32)v); self().sw(W_CITY_HI + p, (u32)(v >> 32)); }
+    DEVI u64 road_lo(int p) const { return (u64)self().w(W_ROAD0 + p) | ((u64)self().w(W_ROAD1 + p) << 32); }
+    DEVI u32 road_hi(int p) const { return self().w(W_ROAD2 + p); }
+    DEVI int flags() const { return self().b(B_FLAGS); }
+    DEVI int res(int p, int r0) const { return pb(p, P_RES + r0); }
+    DEVI int total(int p) const { return res(p, 0) + res(p, 1) + res(p, 2) + res(p, 3) + res(p, 4); }
+    // cold byte fields (always global): ordered card lists and the pile
+    DEVI int hidden(int p, int i) const { return self().cold(B_CARDS + p * 50 + i); }
+    DEVI void set_hidden(int p, int i, int v) const { self().scold(B_CARDS + p * 50 + i, v); }
+    DEVI int played(int p, int i) const { return self().cold(B_CARDS + p * 50 + 25 + i); }
+    DEVI void set_played(int p, int i, int v) const { self().scold(B_CARDS + p * 50 + 25 + i, v); }
+    DEVI int pile(int i) const { return self().cold(B_PILE + i); }
+    DEVI void set_pile(int i, int v) const { self().scold(B_PILE + i, v); }
+};
+// view 1: everything in HBM (k_masks, k_reset, k_sample_random, export/import)
+struct St : StOps<St> {
+    u32* R;
+    long N, e;
+    DEVI St(u32* R_, long N_, long e_) : R(R_), N(N_), e(e_) {}
+    DEVI u32 w(int r) const { return R[(long)r * N + e]; }
+    DEVI void sw(int r, u32 v) const { R[(long)r * N + e] = v; }
+    DEVI int cold(int f) const { return ((const u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3]; }
+    DEVI void scold(int f, int v) const { ((u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3] = (u8)v; }
+    DEVI int b(int f) const { return cold(f); }
+    DEVI void sb(int f, int v) const { scold(f, v); }
+};
+// view 2: the wave's HOT rows staged in LDS as tile[row][lane] (k_step); cold fields stay in HBM
+struct StL : StOps<StL> {
+    u32* T;           // LDS tile base, already offset by the lane: element (row) at T[row * 64]
+    u32* R;
+    long N, e;
+    DEVI StL(u32* T_, u32* R_, long N_, long e_) : T(T_), R(R_), N(N_), e(e_) {}
+    DEVI u32 w(int r) const { return T[r * 64]; }
+    DEVI void sw(int r, u32 v) const { T[r * 64] = v; }
+    DEVI int b(int f) const { return ((const u8*)(T + (NW + (f >> 2)) * 64))[f & 3]; }
+    DEVI void sb(int f, int v) const { ((u8*)(T + (NW + (f >> 2)) * 64))[f & 3] = (u8)v; }
+    DEVI int cold(int f) const { return ((const u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3]; }
+    DEVI void scold(int f, int v) const { ((u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3] = (u8)v; }
 };
 
 DEVI int seat_of(int seatof, int p) { return (seatof >> (2 * p)) & 3; }
@@ -88,12 +114,17 @@ DEVI void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&ou
 }
 struct Rng {
     u32 k0, k1, e0, e1, draws;
+    u32 blk_idx, o0, o1, o2, o3;      // cached philox block (4 draws per block)
     DEVI u32 next() {
-        u32 o[4];
-        philox4x32_10(draws >> 2, 0u, e0, e1, k0, k1, o);
-        u32 sel = draws & 3;
+        const u32 bi = draws >> 2;
+        if (bi != blk_idx) {
+            u32 o[4];
+            philox4x32_10(bi, 0u, e0, e1, k0, k1, o);
+            o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3]; blk_idx = bi;
+        }
+        const u32 sel = draws & 3;
         draws++;
-        return sel == 0 ? o[0] : (sel == 1 ? o[1] : (sel == 2 ? o[2] : o[3]));
+        return sel == 0 ? o0 : (sel == 1 ? o1 : (sel == 2 ? o2 : o3));
     }
     // masked rejection (numpy legacy rk_interval shape)
     DEVI u32 bounded(u32 mx) {
@@ -104,23 +135,26 @@ struct Rng {
         return v;
     }
 };
-DEVI Rng rng_load(const Ctx& c, const St& s) {
+template <class S>
+DEVI Rng rng_load(const Ctx& c, const S& s) {
     Rng r;
     u64 id = c.env_id0 + (u64)s.e;
-    r.k0 = c.key0; r.k1 = c.key1; r.e0 = (u32)id; r.e1 = (u32)(id >> 32); r.draws = s.w(W_RNG);
+    r.k0 = c.key0; r.k1 = c.key1; r.e0 = (u32)id; r.e1 = (u32)(id >> 32); r.draws = s.w(W_RNG); r.blk_idx = 0xFFFFFFFFu; r.o0 = r.o1 = r.o2 = r.o3 = 0;
     return r;
 }
 
 // ------------------------------------------------------------------------------------------------ estimates
 struct Est { int mn[5], mx[5]; };
-DEVI void est_load(const St& s, int o, int l, Est& E) {
+template <class S>
+DEVI void est_load(const S& s, int o, int l, Est& E) {
     int base = W_EST + (o * 3 + l) * 3;
     u32 a = s.w(base), b = s.w(base + 1), c = s.w(base + 2);
 #pragma unroll
     for (int r = 0; r < 4; r++) { E.mn[r] = (a >> (8 * r)) & 255; E.mx[r] = (b >> (8 * r)) & 255; }
     E.mn[4] = c & 255; E.mx[4] = (c >> 8) & 255;
 }
-DEVI void est_store(const St& s, int o, int l, const Est& E) {
+template <class S>
+DEVI void est_store(const S& s, int o, int l, const Est& E) {
     int base = W_EST + (o * 3 + l) * 3;
     u32 a = 0, b = 0;
 #pragma unroll
@@ -134,7 +168,8 @@ DEVI void d5_add(D5& d, int r0, int x) {
     for (int k = 0; k < 5; k++) d.v[k] += (k == r0) ? x : 0;
 }
 // ref: game/game.py:921-971.  delta per r0, `touched` = bitmask of r0 keys present in the dict, thief = -1 for none.
-DEVI void update_estimates(const St& s, int seatof, const D5& delta, int touched, int upd, int thief) {
+template <class S>
+DEVI void update_estimates(const S& s, int seatof, const D5& delta, int touched, int upd, int thief) {
     int total = s.total(upd);
     int total_thief = thief >= 0 ? s.total(thief) : 0;
     for (int o = 0; o < 4; o++) {
@@ -158,31 +193,33 @@ DEVI void update_estimates(const St& s, int seatof, const D5& delta, int touched
                 est_store(s, o, l, E);
             } else {
                 int sl = label_of(seatof, o, thief);
-                Est S;
-                est_load(s, o, sl, S);
+                Est TS;
+                est_load(s, o, sl, TS);
 #pragma unroll
                 for (int r = 0; r < 5; r++) {
                     int cmax = E.mx[r], cmin = E.mn[r];
                     E.mx[r] = clipi(cmax, 0, total);
                     E.mn[r] = clipi(cmin - 1, 0, total);
                     if (cmax > 0) {
-                        S.mx[r] = clipi(S.mx[r] + 1, 0, total_thief);
-                        S.mn[r] = clipi(S.mn[r], 0, total_thief);
+                        TS.mx[r] = clipi(TS.mx[r] + 1, 0, total_thief);
+                        TS.mn[r] = clipi(TS.mn[r], 0, total_thief);
                     }
                 }
                 est_store(s, o, l, E);
-                est_store(s, o, sl, S);
+                est_store(s, o, sl, TS);
             }
         }
     }
 }
-DEVI void update_estimates1(const St& s, int seatof, int r0, int d, int upd) {
+template <class S>
+DEVI void update_estimates1(const S& s, int seatof, int r0, int d, int upd) {
     D5 dl = d5_zero();
     d5_add(dl, r0, d);
     update_estimates(s, seatof, dl, 1 << r0, upd, -1);
 }
 // ref: game/game.py:973-1010.  lost = per-pid0 count packed one byte each.
-DEVI void update_estimates_monopoly(const St& s, int seatof, int mono, int r0, u32 lost) {
+template <class S>
+DEVI void update_estimates_monopoly(const S& s, int seatof, int mono, int r0, u32 lost) {
     int total = 0;
     for (int p = 0; p < 4; p++) if (p != mono) total += (lost >> (8 * p)) & 255;
     for (int p = 0; p < 4; p++) {
@@ -213,13 +250,15 @@ DEVI void update_estimates_monopoly(const St& s, int seatof, int mono, int r0, u
 }
 
 // resource -> bank with the visible-resources clamp (e.g. game/game.py:197-208)
-DEVI void pay(const St& s, int p, int r0, int n) {
+template <class S>
+DEVI void pay(const S& s, int p, int r0, int n) {
     s.spb(p, P_RES + r0, s.pb(p, P_RES + r0) - n);
     s.spb(p, P_VIS + r0, max(s.pb(p, P_VIS + r0) - n, 0));
     s.sb(B_BANK + r0, s.b(B_BANK + r0) + n);
 }
 // ref: game/game.py:253-262
-DEVI void update_players_go(const St& s, int order, bool left) {
+template <class S>
+DEVI void update_players_go(const S& s, int order, bool left) {
     int id = s.b(B_ORDER_ID);
     id = left ? (id == 0 ? 3 : id - 1) : (id == 3 ? 0 : id + 1);
     s.sb(B_ORDER_ID, id);
@@ -227,21 +266,99 @@ DEVI void update_players_go(const St& s, int order, bool left) {
 }
 
 // ------------------------------------------------------------------------------------------------ longest road
-struct CoopLds {
-    u8 nbr_c[54 * 3];
-    u8 nbr_e[54 * 3];
-    u8 stack[BLOCK / 64][54][64];   // per wave, per depth, per lane: corner | k << 6
-};
-DEVI void coop_init(CoopLds& L) {
-    for (int i = threadIdx.x; i < 54 * 3; i += BLOCK) {
-        L.nbr_c[i] = CORNER_NBR_C[i / 3][i % 3];
-        L.nbr_e[i] = CORNER_NBR_E[i / 3][i % 3];
+// Longest vertex-simple path (game/game.py:843-862 + game/utils.py:3-15): directed arcs u->t over the player's
+// roads exist iff u holds no opponent building; a path may END on an opponent's corner but not start on or pass it.
+// The number of simple paths is heavy-tailed under random play (mean ~150 DFS expansions per call, p99.9 > 10^4,
+// extremes > 10^6), so the search is two-tiered:
+//   tier 1 (inside k_step, one wave): lane v enumerates the simple paths that start at corner v; busy lanes hand
+//           untaken sibling subtrees to an LDS task queue whenever other lanes are idle; iteration budget LR_BUDGET.
+//   tier 2 (k_lr_heavy, one 512-thread workgroup per overflowed game): the same DFS, bulk-synchronous work sharing
+//           through a workgroup pool, so a dense road network gets a whole CU (and different heavy games get
+//           different CUs) instead of stalling one wave of k_step; k_step_finish then completes those games.
+// DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
+// adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
+constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
+constexpr int LR_BUDGET = 160;      // tier-1 iterations per lane before the game is handed to tier 2
+constexpr int LR_HEAVY_THREADS = 512;
+constexpr int LR_POOL = 4096;       // tier-2 workgroup pool entries
+constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round
+
+struct Dfs { bool active; int cur, d, base, best; u64 seen, cand; };
+struct DfsQueue { u64* seen; unsigned short* cd; int* n; int cap; };
+
+// One DFS step of one lane.  adj[v]: bitmask of road neighbours of v (0 if v is blocked).  path: this lane's column
+// (element for level d at path[d * stride]).
+DEVI void dfs_iter(Dfs& t, const u64* adj, u8* path, int stride, bool donate, const DfsQueue& q) {
+    if (!t.active) return;
+    if (t.cand) {
+        const int v = __ffsll((long long)t.cand) - 1;
+        t.cand &= t.cand - 1;
+        t.best = max(t.best, t.d + 1);
+        const u64 a = adj[v] & ~t.seen & ~(1ull << v);
+        if (a) {
+            int donated = 0;
+            if (t.cand && donate) {                       // give the untaken siblings (<= 2) away
+                donated = 1;
+                u64 cc = t.cand;
+                while (cc) {
+                    const int sb = __ffsll((long long)cc) - 1;
+                    cc &= cc - 1;
+                    t.best = max(t.best, t.d + 1);
+                    if (adj[sb] & ~t.seen & ~(1ull << sb)) {
+                        const int qi = atomicAdd(q.n, 1);
+                        if (qi < q.cap) { q.seen[qi] = t.seen | (1ull << sb); q.cd[qi] = (unsigned short)(sb | ((t.d + 1) << 8)); }
+                        else { atomicSub(q.n, 1); donated = 0; }   // pool full: keep (an already pushed sibling is re-explored; harmless)
+                    }
+                }
+                if (donated) t.cand = 0;
+            }
+            path[t.d * stride] = (u8)(t.cur | (donated << 6));
+            t.cur = v; t.seen |= 1ull << v; t.d++; t.cand = a;
+        }
+    } else if (t.d == t.base) {
+        t.active = false;
+    } else {
+        t.seen &= ~(1ull << t.cur);
+        const int child = t.cur;
+        t.d--;
+        const int pk = path[t.d * stride];
+        t.cur = pk & 63;
+        t.cand = (pk >> 6) ? 0ull : (adj[t.cur] & ~t.seen & ~((2ull << child) - 1));
     }
-    __syncthreads();
 }
-// Longest vertex-simple path of `pid` for every lane with want=true (all 64 lanes of the wave cooperate).
-// ref: game/game.py:843-862, game/utils.py:3-15.  A corner holding an opponent building has no outgoing arcs.
-DEVI int coop_longest_path(bool want, const St& s, int pid, CoopLds& L) {
+DEVI void dfs_take(Dfs& t, const u64* adj, u64 seen, int cd) {
+    t.seen = seen; t.cur = cd & 255; t.d = cd >> 8; t.base = t.d;
+    t.cand = adj[t.cur] & ~seen;
+    t.active = true;
+}
+// adjacency bitmask of corner v over road set (R, RH) with blocked corners BL
+DEVI u64 lr_adj_of(int v, u64 R, u32 RH, u64 BL) {
+    u64 m = 0;
+    if (v < 54 && !((BL >> v) & 1)) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int t = CORNER_NBR_C[v][k], ed = CORNER_NBR_E[v][k];
+            if (t != 255) {
+                bool has = ed < 64 ? ((R >> ed) & 1) : ((RH >> (ed - 64)) & 1);
+                if (has) m |= 1ull << t;
+            }
+        }
+    }
+    return m;
+}
+
+struct LrWave {
+    u64 adj[54];
+    u64 q_seen[LR_QN];
+    unsigned short q_cd[LR_QN];
+    int qn;
+    u8 path[54][64];
+};
+
+// tier 1.  Returns the path length for lanes with want=true, or -1 if the search ran out of budget (budget <= 0:
+// unlimited).  Must be called by all 64 lanes of the wave.
+template <class S>
+DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget) {
     u64 bal = __ballot(want);
     if (bal == 0) return 0;
     u64 rlo = 0, blocked = 0;
@@ -250,88 +367,144 @@ DEVI int coop_longest_path(bool want, const St& s, int pid, CoopLds& L) {
         rlo = s.road_lo(pid); rhi = s.road_hi(pid);
         for (int o = 0; o < 4; o++) if (o != pid) blocked |= s.settle(o) | s.city(o);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     int result = 0;
+    const DfsQueue q{ L.q_seen, L.q_cd, &L.qn, LR_QN };
     while (bal) {
-        int src = __ffsll((long long)bal) - 1;
+        const int src = __ffsll((long long)bal) - 1;
         bal &= bal - 1;
-        u64 R = ((u64)(u32)__shfl((int)(u32)(rlo >> 32), src) << 32) | (u32)__shfl((int)(u32)rlo, src);
-        u32 RH = (u32)__shfl((int)rhi, src);
-        u64 BL = ((u64)(u32)__shfl((int)(u32)(blocked >> 32), src) << 32) | (u32)__shfl((int)(u32)blocked, src);
-        int best = 0;
-        if (lane < 54 && !((BL >> lane) & 1)) {
-            int cur = lane, k = 0, d = 0;
-            u64 seen = 1ull << lane;
-            while (true) {
-                if (k < 3) {
-                    int t = L.nbr_c[cur * 3 + k], ed = L.nbr_e[cur * 3 + k];
-                    k++;
-                    if (t != 255) {
-                        bool has = ed < 64 ? ((R >> ed) & 1) : ((RH >> (ed - 64)) & 1);
-                        if (has && !((seen >> t) & 1)) {
-                            best = max(best, d + 1);
-                            if (!((BL >> t) & 1)) {
-                                L.stack[wave][d][lane] = (u8)(cur | (k << 6));
-                                d++; cur = t; k = 0; seen |= 1ull << t;
-                            }
-                        }
-                    }
-                } else {
-                    if (d == 0) break;
-                    seen &= ~(1ull << cur);
-                    d--;
-                    int pk = L.stack[wave][d][lane];
-                    cur = pk & 63; k = pk >> 6;
-                }
+        const u64 R = ((u64)(u32)__shfl((int)(u32)(rlo >> 32), src) << 32) | (u32)__shfl((int)(u32)rlo, src);
+        const u32 RH = (u32)__shfl((int)rhi, src);
+        const u64 BL = ((u64)(u32)__shfl((int)(u32)(blocked >> 32), src) << 32) | (u32)__shfl((int)(u32)blocked, src);
+        const u64 myadj = lr_adj_of(lane, R, RH, BL);
+        if (lane < 54) L.adj[lane] = myadj;
+        if (lane == 0) L.qn = 0;
+        __builtin_amdgcn_wave_barrier();
+        Dfs t;
+        t.active = myadj != 0; t.cur = lane; t.d = 0; t.base = 0; t.best = 0;
+        t.seen = 1ull << (lane & 63); t.cand = myadj;
+        u64 idle = __ballot(!t.active);
+        int it = 0;
+        bool overflow = false;
+        while (true) {
+            dfs_iter(t, L.adj, &L.path[0][lane], 64, idle != 0, q);
+            idle = __ballot(!t.active);
+            const int qn = L.qn;
+            if (idle == ~0ull && qn <= 0) break;
+            if (budget > 0 && ++it > budget) { overflow = true; break; }
+            if (!t.active && qn > 0) {
+                const int qi = atomicSub(&L.qn, 1) - 1;
+                if (qi >= 0) dfs_take(t, L.adj, L.q_seen[qi], L.q_cd[qi]);
+                else atomicAdd(&L.qn, 1);
             }
         }
+        int best = t.best;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
-        if (lane == src) result = best;
+        if (lane == src) result = overflow ? -1 : best;
+        __builtin_amdgcn_wave_barrier();
     }
     return result;
 }
 
-// ------------------------------------------------------------------------------------------------ reset
-// Fisher-Yates from the top (np.random.shuffle on a list), array in LDS column `col`.
-template <int NMAX>
-DEVI void shuffle_lds(u8 (&a)[NMAX][64], int n, int col, Rng& rng) {
-    for (int i = n - 1; i >= 1; i--) {
-        int j = (int)rng.bounded((u32)i);
-        u8 t = a[i][col]; a[i][col] = a[j][col]; a[j][col] = t;
+// tier 2: one workgroup per request.  req[i] = game | pid0 << 56; out_len[game] receives the path length.
+__global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
+                                                              const u64* __restrict__ req, i32* __restrict__ out_len) {
+    __shared__ u64 adj[54];
+    __shared__ u64 pool_seen[LR_POOL];
+    __shared__ unsigned short pool_cd[LR_POOL];
+    __shared__ int pool_n, best_all;
+    __shared__ u8 path[54][LR_HEAVY_THREADS];
+    const int tid = threadIdx.x;
+    const u32 count = *req_count;
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        const u64 rq = req[r];
+        const long game = (long)(rq & 0x00FFFFFFFFFFFFFFull);
+        const int pid = (int)(rq >> 56);
+        St s(c.R, c.N, game);
+        __syncthreads();
+        if (tid < 54) {
+            u64 BL = 0;
+            for (int o = 0; o < 4; o++) if (o != pid) BL |= s.settle(o) | s.city(o);
+            adj[tid] = lr_adj_of(tid, s.road_lo(pid), s.road_hi(pid), BL);
+        }
+        if (tid == 0) { pool_n = 0; best_all = 0; }
+        __syncthreads();
+        Dfs t;
+        t.active = tid < 54 && adj[tid < 54 ? tid : 0] != 0;
+        t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
+        const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
+        bool hint = true;
+        while (true) {
+            for (int it = 0; it < LR_ROUND; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
+            __syncthreads();                       // all pushes of this round are complete
+            if (!t.active) {
+                const int qi = atomicSub(&pool_n, 1) - 1;
+                if (qi >= 0) dfs_take(t, adj, pool_seen[qi], pool_cd[qi]);
+                else atomicAdd(&pool_n, 1);
+            }
+            const int busy = __syncthreads_count(t.active);   // all pops complete
+            if (busy == 0) break;                  // nobody active -> the pool is empty too (idle threads drained it)
+            hint = busy < LR_HEAVY_THREADS;
+        }
+        atomicMax(&best_all, t.best);
+        __syncthreads();
+        if (tid == 0) out_len[game] = best_all;
     }
 }
-// ref: game/components/board.py:67-100, game/game.py:39-136, game/components/player.py:9-58, env/wrapper.py:30-34
-__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
-    __shared__ u8 arr[25][64];
-    __shared__ u8 terr[19][64];
-    const int col = threadIdx.x;
-    St s{ c.W, c.B, c.N, (long)blockIdx.x * 64 + threadIdx.x };
-    if (s.e >= c.N) return;
-    if (sel != nullptr && (s.e >= c.n || sel[s.e] == 0)) return;
-    Rng rng = rng_load(c, s);
-    for (int r = 0; r < NW; r++) if (r != W_RNG) s.sw(r, 0);
-    for (int r = 0; r < NB; r++) s.sb(r, 0);
-    // terrain: Desert, 3 Hills, 4 Fields, 4 Forest, 3 Mountains, 4 Pastures (board.py:27-28; Terrain == Resource value)
-    for (int i = 0; i < 19; i++) {
-        int v = i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4))));
-        terr[i][col] = (u8)v;
+
+// Small integer arrays packed in a register pair: field i holds BITS bits; fields 0..PER-1 live in lo, the rest in hi.
+// The reset shuffles run entirely in registers (no LDS/HBM round trips between dependent draws).
+template <int BITS, int PER>
+struct Packed {
+    u64 lo, hi;
+    DEVI int get(int i) const {
+        const u64 w = i < PER ? lo : hi;
+        const int sh = BITS * (i < PER ? i : i - PER);
+        return (int)((w >> sh) & ((1u << BITS) - 1));
     }
-    shuffle_lds<19>(terr, 19, col, rng);                       // board.py:72
+    DEVI void set(int i, int v) {
+        const int sh = BITS * (i < PER ? i : i - PER);
+        const u64 m = (u64)((1u << BITS) - 1) << sh, x = (u64)v << sh;
+        if (i < PER) lo = (lo & ~m) | x; else hi = (hi & ~m) | x;
+    }
+    // Fisher-Yates from the top (np.random.shuffle on a list)
+    DEVI void shuffle(int n, Rng& rng) {
+        for (int i = n - 1; i >= 1; i--) {
+            const int j = (int)rng.bounded((u32)i);
+            const int a = get(i), b = get(j);
+            set(i, b); set(j, a);
+        }
+    }
+};
+struct ResetScratch { int unused; };
+// ref: game/components/board.py:67-100, game/game.py:39-136, game/components/player.py:9-58, env/wrapper.py:30-34.
+// `hot_rows` rows of the state view are zeroed through s.sw (all of them for the HBM view, the LDS tile for StL).
+template <class S>
+DEVI void reset_game(const S& s, Rng& rng, ResetScratch&, int, int hot_rows) {
+    for (int r = 0; r < hot_rows; r++) if (r != W_RNG) s.sw(r, 0);
+    // terrain: Desert, 3 Hills, 4 Fields, 4 Forest, 3 Mountains, 4 Pastures (board.py:27-28; Terrain == Resource value)
+    Packed<3, 21> terr; terr.lo = 0; terr.hi = 0;
+#pragma unroll
+    for (int i = 0; i < 19; i++) terr.set(i, i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4)))));
+    terr.shuffle(19, rng);                                     // board.py:72
     // number tokens (board.py:25), reshuffled until no 6/8 are adjacent (board.py:79-81, 50-65)
+    Packed<4, 16> nums; nums.lo = 0; nums.hi = 0;
     {
-        const u8 nums[18] = { 5, 2, 6, 3, 8, 10, 9, 12, 11, 4, 8, 10, 9, 4, 5, 6, 3, 11 };
-        for (int i = 0; i < 18; i++) arr[i][col] = nums[i];
+        const int nv[18] = { 5, 2, 6, 3, 8, 10, 9, 12, 11, 4, 8, 10, 9, 4, 5, 6, 3, 11 };
+#pragma unroll
+        for (int i = 0; i < 18; i++) nums.set(i, nv[i]);
     }
     bool ok = false;
     do {
-        shuffle_lds<25>(arr, 18, col, rng);
+        nums.shuffle(18, rng);
         u32 reds = 0;
         int n = 0;
         for (int i = 0; i < 19; i++) {
-            int t = PLACEMENT[i];
-            int v = terr[t][col] == 0 ? 7 : arr[n][col];
-            if (terr[t][col] != 0) n++;
+            const int t = PLACEMENT[i];
+            const int tr = terr.get(t);
+            const int v = tr == 0 ? 7 : nums.get(n);
+            if (tr != 0) n++;
             if (v == 6 || v == 8) reds |= 1u << t;
         }
         ok = true;
@@ -340,31 +513,41 @@ __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel)
     {
         int n = 0;
         for (int i = 0; i < 19; i++) {                        // board.py:91-100
-            int t = PLACEMENT[i], tr = terr[t][col], v;
-            if (tr == 0) { v = 7; s.sb(B_ROBBER, t); } else v = arr[n++][col];
+            const int t = PLACEMENT[i], tr = terr.get(t);
+            int v;
+            if (tr == 0) { v = 7; s.sb(B_ROBBER, t); } else { v = nums.get(n); n++; }
             s.sb(B_TILE + t, tr | (v << 4));
         }
     }
-    for (int i = 0; i < 9; i++) arr[i][col] = (u8)i;
-    shuffle_lds<25>(arr, 9, col, rng);                         // board.py:84
-    for (int i = 0; i < 9; i++) s.sb(B_HARB + i, arr[i][col]);
-    for (int i = 0; i < 4; i++) arr[i][col] = (u8)i;           // game.py:41 [White, Blue, Orange, Red] as pid0
-    shuffle_lds<25>(arr, 4, col, rng);                         // game.py:42
+    Packed<4, 16> harb; harb.lo = 0x876543210ull; harb.hi = 0;
+    harb.shuffle(9, rng);                                      // board.py:84
+    for (int i = 0; i < 9; i++) s.sb(B_HARB + i, harb.get(i));
+    Packed<2, 32> ord; ord.lo = 0xE4ull; ord.hi = 0;          // game.py:41 [White, Blue, Orange, Red] as pid0 = 0,1,2,3
+    ord.shuffle(4, rng);                                       // game.py:42
     {
-        int order = 0, seatof = 0;
-        for (int i = 0; i < 4; i++) { int p = arr[i][col]; order |= p << (2 * i); seatof |= i << (2 * p); }
+        int order = (int)(ord.lo & 0xFF), seatof = 0;
+        for (int i = 0; i < 4; i++) seatof |= i << (2 * ord.get(i));
         s.sb(B_ORDER, order); s.sb(B_SEATOF, seatof);
         s.sb(B_GO, order & 3); s.sb(B_ORDER_ID, 0);
     }
     for (int r = 0; r < 5; r++) s.sb(B_BANK + r, 19);         // game.py:48-54
     for (int p = 0; p < 4; p++) { s.spb(p, P_SLEFT, 5); s.spb(p, P_CLEFT, 4); s.spb(p, P_ISECOND, 255); }
-    for (int i = 0; i < 25; i++)                               // game.py:75-76
-        arr[i][col] = (u8)(i < 14 ? C_KNIGHT : (i < 19 ? C_VP : (i < 21 ? C_YOP : (i < 23 ? C_RB : C_MONO))));
-    shuffle_lds<25>(arr, 25, col, rng);                        // game.py:77
-    for (int i = 0; i < 25; i++) s.sb(B_PILE + i, arr[i][col]);
+    Packed<3, 21> deck; deck.lo = 0; deck.hi = 0;             // game.py:75-76
+#pragma unroll
+    for (int i = 0; i < 25; i++) deck.set(i, i < 14 ? C_KNIGHT : (i < 19 ? C_VP : (i < 21 ? C_YOP : (i < 23 ? C_RB : C_MONO))));
+    deck.shuffle(25, rng);                                     // game.py:77
+    for (int i = 0; i < 25; i++) s.set_pile(i, deck.get(i));  // card lists need no clearing: their lengths are 0
     s.sb(B_PILE_LEN, 25);
     s.sb(B_FLAGS, F_INITIAL);
     s.sw(W_RNG, rng.draws);
+}
+__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
+    ResetScratch sc;
+    St s(c.R, c.N, (long)blockIdx.x * 64 + threadIdx.x);
+    if (s.e >= c.N) return;
+    if (sel != nullptr && (s.e >= c.n || sel[s.e] == 0)) return;
+    Rng rng = rng_load(c, s);
+    reset_game(s, rng, sc, threadIdx.x, NROWS);
 }
 
 // ------------------------------------------------------------------------------------------------ masks
@@ -386,22 +569,23 @@ DEVI u64 getr(const u32 (&m)[MASK_WORDS]) {
     if constexpr (sh + NBITS > 64) v |= (u64)m[w0 + 2] << (64 - sh);
     return v & full;
 }
-struct Boards { u64 occ, own_bld, own_set; u64 rlo[4]; u32 rhi[4]; };
-DEVI void load_boards(const St& s, int pid, Boards& b) {
-    b.occ = 0;
+struct Boards { u64 occ, own_bld, own_set, own_rlo, all_rlo; u32 own_rhi, all_rhi; };
+template <class S>
+DEVI void load_boards(const S& s, int pid, Boards& b) {
+    b.occ = 0; b.own_bld = 0; b.own_set = 0; b.own_rlo = 0; b.all_rlo = 0; b.own_rhi = 0; b.all_rhi = 0;
     for (int p = 0; p < 4; p++) {
-        u64 st = s.settle(p), ct = s.city(p);
-        b.occ |= st | ct;
-        if (p == pid) { b.own_bld = st | ct; b.own_set = st; }
-        b.rlo[p] = s.road_lo(p); b.rhi[p] = s.road_hi(p);
+        u64 st = s.settle(p), ct = s.city(p), rl = s.road_lo(p);
+        u32 rh = s.road_hi(p);
+        b.occ |= st | ct; b.all_rlo |= rl; b.all_rhi |= rh;
+        if (p == pid) { b.own_bld = st | ct; b.own_set = st; b.own_rlo = rl; b.own_rhi = rh; }
     }
 }
 // ref: game/components/corner.py:24-39 over all corners.  initial=true ignores the own-road requirement.
-DEVI u64 settle_spots(const Boards& b, int pid, bool initial) {
+DEVI u64 settle_spots(const Boards& b, bool initial) {
     u64 blocked = b.occ, touched = 0;
     for (int c = 0; c < 54; c++) if (CORNER_NBR_MASK[c] & b.occ) blocked |= 1ull << c;
     if (!initial) {
-        u64 rl = b.rlo[pid]; u32 rh = b.rhi[pid];
+        u64 rl = b.own_rlo; u32 rh = b.own_rhi;
         for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
         for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
         return ~blocked & touched & ALL54;
@@ -409,14 +593,15 @@ DEVI u64 settle_spots(const Boards& b, int pid, bool initial) {
     return ~blocked & ALL54;
 }
 // ref: env/wrapper.py:322-339 + game/components/edge.py:23-42.  Returns 73 bits (lo 64, hi 9; bit 72 = dummy edge).
-DEVI void road_spots(const St& s, const Boards& b, int pid, int flags, bool road_building, u64& lo, u32& hi) {
-    u64 elo = ~(b.rlo[0] | b.rlo[1] | b.rlo[2] | b.rlo[3]);
-    u32 ehi = ~(b.rhi[0] | b.rhi[1] | b.rhi[2] | b.rhi[3]) & 0xFFu;
+template <class S>
+DEVI void road_spots(const S& s, const Boards& b, int pid, int flags, bool road_building, u64& lo, u32& hi) {
+    u64 elo = ~b.all_rlo;
+    u32 ehi = ~b.all_rhi & 0xFFu;
     u64 anchors;
     if ((flags & F_INITIAL) && s.pb(pid, P_ISET) == 2) {
         anchors = 1ull << s.pb(pid, P_ISECOND);
     } else {
-        u64 touched = 0, rl = b.rlo[pid]; u32 rh = b.rhi[pid];
+        u64 touched = 0, rl = b.own_rlo; u32 rh = b.own_rhi;
         for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
         for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
         anchors = b.own_bld | (touched & ~b.occ);
@@ -428,7 +613,8 @@ DEVI void road_spots(const St& s, const Boards& b, int pid, int flags, bool road
     if (road_building && lo == 0 && hi == 0) hi = 1u << 8;
 }
 // ref: env/wrapper.py:368-388.  returns 5-bit card mask; yop_ok -> bank vector valid
-DEVI int dev_card_mask(const St& s, int pid, u32& bank_bits) {
+template <class S>
+DEVI int dev_card_mask(const S& s, int pid, u32& bank_bits) {
     int m = 0, banksum = 0;
     bank_bits = 0;
     for (int r = 0; r < 5; r++) { int v = s.b(B_BANK + r); banksum += v; if (v > 0) bank_bits |= 1u << r; }
@@ -439,7 +625,8 @@ DEVI int dev_card_mask(const St& s, int pid, u32& bank_bits) {
     return m;
 }
 // ref: env/wrapper.py:168-290
-DEVI void compute_masks(const St& s, u32 (&m)[MASK_WORDS], int max_trades) {
+template <class S>
+DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
     // defaults: head 0 zeros, every other head all ones (wrapper.py:172-185)
     m[0] = 0xFFFFE000u;
 #pragma unroll
@@ -462,7 +649,7 @@ DEVI void compute_masks(const St& s, u32 (&m)[MASK_WORDS], int max_trades) {
         int iset = s.pb(pid, P_ISET), iroad = s.pb(pid, P_IROAD);
         if (iset == 0 || (iset == 1 && iroad == 1)) {
             setr<M0, 13>(m, 1u << T_SETTLE);
-            setr<M1, 54>(m, settle_spots(b, pid, true));
+            setr<M1, 54>(m, settle_spots(b, true));
         } else {
             u64 lo; u32 hi;
             road_spots(s, b, pid, flags, false, lo, hi);
@@ -524,7 +711,7 @@ DEVI void compute_masks(const St& s, u32 (&m)[MASK_WORDS], int max_trades) {
 #pragma unroll
     for (int r = 0; r < 5; r++) res[r] = s.res(pid, r);
     if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_WOOD] > 0 && res[R_BRICK] > 0) {   // :238-243
-        u64 v = settle_spots(b, pid, false);
+        u64 v = settle_spots(b, false);
         if (v && s.pb(pid, P_SLEFT) > 0) { types |= 1u << T_SETTLE; setr<M1, 54>(m, v); }
     }
     if (res[R_WHEAT] >= 2 && res[R_ORE] >= 3 && s.pb(pid, P_CLEFT) > 0 && b.own_set) {   // :245-250
@@ -569,7 +756,7 @@ DEVI void compute_masks(const St& s, u32 (&m)[MASK_WORDS], int max_trades) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, int max_trades) {
-    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.N) return;
     u32 m[MASK_WORDS];
     compute_masks(s, m, max_trades);
@@ -589,7 +776,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ 
 // ------------------------------------------------------------------------------------------------ step
 // "mask bit set" legality (validate mode): every head relevant to the chosen type must be unmasked, plus the
 // ownership check of game/game.py:455-466 for ProposeTrade.
-DEVI bool action_legal(const St& s, const u32 (&m)[MASK_WORDS], const int (&a)[ACTION_WORDS]) {
+template <class S>
+DEVI bool action_legal(const S& s, const u32 (&m)[MASK_WORDS], const int (&a)[ACTION_WORDS]) {
     auto bit = [&](int i) { return (m[i >> 5] >> (i & 31)) & 1u; };
     int t = a[0];
     if (t < 0 || t > 12 || !bit(M0 + t)) return false;
@@ -632,7 +820,8 @@ DEVI bool action_legal(const St& s, const u32 (&m)[MASK_WORDS], const int (&a)[A
 }
 
 // ref: game/game.py:138-177
-DEVI int roll_dice(const St& s, Rng& rng, int order, int seatof) {
+template <class S>
+DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof) {
     int d1 = 1 + (int)rng.bounded(5), d2 = 1 + (int)rng.bounded(5);
     s.sb(B_DIE1, d1); s.sb(B_DIE2, d2);
     int roll = d1 + d2;
@@ -702,7 +891,8 @@ DEVI int roll_dice(const St& s, Rng& rng, int order, int seatof) {
 }
 
 // ref: game/game.py:817-841
-DEVI void update_largest_army(const St& s) {
+template <class S>
+DEVI void update_largest_army(const S& s) {
     const int order[4] = { 1, 0, 3, 2 };   // Blue, White, Red, Orange as pid0
     int max_count = 0, who = -1;
 #pragma unroll
@@ -721,15 +911,151 @@ DEVI void update_largest_army(const St& s) {
     }
 }
 
-struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; };
+struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; int auto_reset;
+                 unsigned long long* prof; };   // optional phase profile: [6] cycle sums then [6] per-wave maxima
+constexpr int PROF_PHASES = 8;    // stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back
+DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
+    if (cfg.prof == nullptr) return;
+    long long t = wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long dt = (unsigned long long)(t - t_prev);
+        atomicAdd(&cfg.prof[phase], dt);
+        atomicMax(&cfg.prof[PROF_PHASES + phase], dt);
+    }
+    t_prev = wall_clock64();
+}
 
-// actions: int32 [18][n] head-major; reward: float [4][n] (PlayerId-1 major); done: u8 [n]; err: [1] invalid-action counter
-__global__ __launch_bounds__(BLOCK) void k_step(Ctx c, const i32* __restrict__ actions, const u32* __restrict__ mpk,
-                                                float* __restrict__ reward, u8* __restrict__ done,
-                                                u32* __restrict__ err, StepCfg cfg) {
-    __shared__ CoopLds L;
-    coop_init(L);
-    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+struct Pending { u32* count; u64* req; u8* type; u8* who; i32* len; };   // games handed to tier 2 (all device arrays)
+struct StepCfg;
+DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
+struct StepScratch { LrWave lr; ResetScratch rs; };
+
+// Everything of a step that needs the longest-road length: the holder logic of game/game.py:864-919, done/rewards
+// (env/wrapper.py:85-112), auto-reset (RL/ppo/game_manager.py:112-113) and the next legal-action masks.
+// Must be called by all 64 lanes; `doit` selects the lanes it applies to.
+template <class S>
+DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
+                      int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
+                      long long& tprof);
+
+template <class S>
+DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
+                      int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
+                      long long& tprof) {
+    const long e = s.e;
+    const bool doit_or_pad = doit || e >= c.n;       // padding games keep valid masks too
+    {
+        bool cut = false;
+        int holder = 0, hcount = 0;
+        if (doit && lr_who >= 0) {
+            s.spb(lr_who, P_CURLP, len);
+            holder = s.b(B_LR_PLAYER); hcount = s.b(B_LR_COUNT);
+            if (holder == 0) {
+                if (len >= 5) { s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2); }
+            } else if (holder == lr_who + 1) {
+                if (hcount > len) cut = true; else s.sb(B_LR_COUNT, len);
+            } else if (len > hcount) {
+                s.spb(holder - 1, P_VP, s.pb(holder - 1, P_VP) - 2);
+                s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2);
+                s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len);
+            }
+        }
+        if (__ballot(cut)) {                                               // game.py:880-912 (rare)
+            int max_len = len, player = lr_who;
+            bool tied = false;
+            for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
+                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch.lr, 0);
+                if (cut && o != lr_who) {
+                    if (pl == max_len) tied = true;
+                    else if (pl > max_len) { max_len = pl; tied = false; player = o; }
+                }
+            }
+            if (cut) {
+                if (max_len >= 5) {
+                    if (tied) {
+                        if (player == lr_who) s.sb(B_LR_COUNT, len);
+                        else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
+                    } else {
+                        s.sb(B_LR_PLAYER, player + 1); s.sb(B_LR_COUNT, max_len);
+                        s.spb(player, P_VP, s.pb(player, P_VP) + 2);
+                        s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2);
+                    }
+                } else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
+            }
+        }
+    }
+    prof_mark(cfg, 3, tprof);
+    // ---- done / rewards (wrapper.py:85-112)
+    bool want_reset = false;
+    if (doit) {
+        const int dict_order[4] = { 1, 3, 2, 0 };                          // Blue, Red, Orange, White (game.py:18-23)
+        int vps[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) vps[p] = s.pb(p, P_VP);
+        int winner = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (vps[dict_order[i]] >= 10) winner = dict_order[i] + 1;
+        bool dn = winner != 0 && type >= 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float r = 0.0f;
+            if (type >= 0) {
+                if (cfg.dense_reward) {
+                    r += 5.0f * (float)(vps[p] - s.b(B_CURVP + p));
+                    if (type == T_PLAYDEV) r += 5.0f;
+                    if (type == T_ROBBER) r += 1.0f;
+                    if (type == T_DISCARD) r -= 0.3f;
+                    if (type == T_CITY) r += 2.5f;
+                    r *= cfg.annealing;
+                }
+                s.sb(B_CURVP + p, vps[p]);
+                if (dn && winner == p + 1) r += cfg.win_reward;
+            }
+            reward[(long)p * c.n + s.e] = r;
+        }
+        if (dn) s.sb(B_WINNER, winner);
+        done[s.e] = dn ? 1 : 0;
+        want_reset = dn && cfg.auto_reset;
+    }
+    prof_mark(cfg, 4, tprof);
+    if (want_reset) {                                                      // RL/ppo/game_manager.py:112-113
+        Rng rng = rng_load(c, s);
+        reset_game(s, rng, scratch.rs, lane, ROWS_HOT);
+    }
+    prof_mark(cfg, 5, tprof);
+    // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
+    if (doit_or_pad) {
+        u32 m[MASK_WORDS];
+        compute_masks(s, m, cfg.max_trades);
+#pragma unroll
+        for (int i = 0; i < MASK_WORDS; i++) mpk[(long)i * c.N + e] = m[i];
+    }
+    prof_mark(cfg, 6, tprof);
+}
+
+// The fused env step.  One wave = 64 games; the wave's HOT state rows are staged in LDS as tile[row][lane]
+// (112 coalesced 256 B row loads, conflict-free LDS columns), the whole step runs out of LDS - translate + validate,
+// apply_action, longest road (wave-cooperative), done/rewards, auto-reset of finished games, next legal-action
+// masks - and the tile is written back once.  With 65 536 games there is exactly one wave per SIMD, so the launch
+// time is the dependent-latency chain of a single wave: LDS (~64 cycles) instead of HBM/L2 (~200-900 cycles) per hop.
+// actions: int32 [18][n] head-major; reward: float [4][n] (PlayerId-1 major); done: u8 [n]; err: [1] invalid-action
+// counter; mpk: packed masks [11][N], read for validation, rewritten with the masks of the new state.
+__global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
+                                             float* __restrict__ reward, u8* __restrict__ done,
+                                             u32* __restrict__ err, StepCfg cfg, Pending pend) {
+    __shared__ u32 tile[ROWS_HOT * 64];
+    __shared__ StepScratch scratch;
+    LrWave& L = scratch.lr;
+    const int lane = threadIdx.x;
+    const long e = (long)blockIdx.x * 64 + lane;
+    long long tprof = cfg.prof ? wall_clock64() : 0;
+    {
+        const u32* __restrict__ src = c.R + e;
+#pragma unroll 16
+        for (int r = 0; r < ROWS_HOT; r++) tile[r * 64 + lane] = src[(long)r * c.N];
+    }
+    StL s(tile + lane, c.R, c.N, e);
+    prof_mark(cfg, 0, tprof);
     const bool live = s.e < c.n;
     int a[ACTION_WORDS];
 #pragma unroll
@@ -890,14 +1216,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(Ctx c, const i32* __restrict__ a
     case T_PLAYDEV: {                                                      // game.py:653-693, wrapper.py:140-147
         int card = a[4];
         int nh = s.pb(pid, P_NHID), at = -1;
-        for (int i = 0; i < nh; i++) if (at < 0 && s.pb(pid, P_HIDDEN + i) == card) at = i;
+        for (int i = 0; i < nh; i++) if (at < 0 && s.hidden(pid, i) == card) at = i;
         if (at >= 0) {
-            for (int i = at; i + 1 < nh; i++) s.spb(pid, P_HIDDEN + i, s.pb(pid, P_HIDDEN + i + 1));
+            for (int i = at; i + 1 < nh; i++) s.set_hidden(pid, i, s.hidden(pid, i + 1));
             s.spb(pid, P_NHID, nh - 1);
             s.spb(pid, P_HCNT + card, s.pb(pid, P_HCNT + card) - 1);
         }
         int np = s.pb(pid, P_NPLAYED);
-        s.spb(pid, P_PLAYED + np, card);
+        s.set_played(pid, np, card);
         s.spb(pid, P_NPLAYED, np + 1);
         flags |= F_PLAYED_DEV;
         if (card == C_VP) s.spb(pid, P_VP, s.pb(pid, P_VP) + 1);
@@ -938,10 +1264,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(Ctx c, const i32* __restrict__ a
         D5 d = d5_zero(); d.v[R_SHEEP] = -1; d.v[R_ORE] = -1; d.v[R_WHEAT] = -1;
         update_estimates(s, seatof, d, (1 << R_SHEEP) | (1 << R_ORE) | (1 << R_WHEAT), pid, -1);
         int pl = s.b(B_PILE_LEN) - 1;
-        int card = s.b(B_PILE + pl);
+        int card = s.pile(pl);
         s.sb(B_PILE_LEN, pl);
         int nh = s.pb(pid, P_NHID);
-        s.spb(pid, P_HIDDEN + nh, card);
+        s.set_hidden(pid, nh, card);
         s.spb(pid, P_NHID, nh + 1);
         s.spb(pid, P_HCNT + card, s.pb(pid, P_HCNT + card) + 1);
         s.sb(B_BOUGHT + card, s.b(B_BOUGHT + card) + 1);
@@ -1024,78 +1350,56 @@ __global__ __launch_bounds__(BLOCK) void k_step(Ctx c, const i32* __restrict__ a
     }
     if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
 
-    // ---- update_longest_road (game.py:864-919), path lengths computed wave-cooperatively
-    {
-        int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L);
-        bool cut = false;
-        int holder = 0, hcount = 0;
-        if (lr_who >= 0) {
-            s.spb(lr_who, P_CURLP, len);
-            holder = s.b(B_LR_PLAYER); hcount = s.b(B_LR_COUNT);
-            if (holder == 0) {
-                if (len >= 5) { s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2); }
-            } else if (holder == lr_who + 1) {
-                if (hcount > len) cut = true; else s.sb(B_LR_COUNT, len);
-            } else if (len > hcount) {
-                s.spb(holder - 1, P_VP, s.pb(holder - 1, P_VP) - 2);
-                s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) + 2);
-                s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len);
-            }
-        }
-        if (__ballot(cut)) {                                               // game.py:880-912 (rare)
-            int max_len = len, player = lr_who;
-            bool tied = false;
-            for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
-                int pl = coop_longest_path(cut && o != lr_who, s, o, L);
-                if (cut && o != lr_who) {
-                    if (pl == max_len) tied = true;
-                    else if (pl > max_len) { max_len = pl; tied = false; player = o; }
-                }
-            }
-            if (cut) {
-                if (max_len >= 5) {
-                    if (tied) {
-                        if (player == lr_who) s.sb(B_LR_COUNT, len);
-                        else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
-                    } else {
-                        s.sb(B_LR_PLAYER, player + 1); s.sb(B_LR_COUNT, max_len);
-                        s.spb(player, P_VP, s.pb(player, P_VP) + 2);
-                        s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2);
-                    }
-                } else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
-            }
-        }
+    prof_mark(cfg, 1, tprof);
+    // ---- update_longest_road (game.py:864-919): tier-1 path length, or hand the game to tier 2
+    int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L, LR_BUDGET);
+    const bool pending = lr_who >= 0 && len < 0;
+    if (pending) {                                   // finished later by k_lr_heavy + k_step_finish
+        const u32 slot = atomicAdd(pend.count, 1u);
+        pend.req[slot] = (u64)e | ((u64)lr_who << 56);
+        pend.type[e] = (u8)(type + 1);
+        pend.who[e] = (u8)lr_who;
     }
+    prof_mark(cfg, 2, tprof);
+    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof);
+    // ---- write the tile back
+    {
+        u32* __restrict__ dst = c.R + e;
+#pragma unroll 16
+        for (int r = 0; r < ROWS_HOT; r++) dst[(long)r * c.N] = tile[r * 64 + lane];
+    }
+    prof_mark(cfg, 7, tprof);
+}
 
-    // ---- done / rewards (wrapper.py:85-112)
-    if (live) {
-        const int dict_order[4] = { 1, 3, 2, 0 };                          // Blue, Red, Orange, White (game.py:18-23)
-        int vps[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) vps[p] = s.pb(p, P_VP);
-        int winner = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (vps[dict_order[i]] >= 10) winner = dict_order[i] + 1;
-        bool dn = winner != 0 && type >= 0;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            float r = 0.0f;
-            if (type >= 0) {
-                if (cfg.dense_reward) {
-                    r += 5.0f * (float)(vps[p] - s.b(B_CURVP + p));
-                    if (type == T_PLAYDEV) r += 5.0f;
-                    if (type == T_ROBBER) r += 1.0f;
-                    if (type == T_DISCARD) r -= 0.3f;
-                    if (type == T_CITY) r += 2.5f;
-                    r *= cfg.annealing;
-                }
-                s.sb(B_CURVP + p, vps[p]);
-                if (dn && winner == p + 1) r += cfg.win_reward;
-            }
-            reward[(long)p * c.n + s.e] = r;
-        }
-        if (dn) s.sb(B_WINNER, winner);
-        done[s.e] = dn ? 1 : 0;
+// Completes the games k_step handed to tier 2 (their longest-road length now sits in pend.len).  A wave with no
+// pending game exits after one load.
+__global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward,
+                                                    u8* __restrict__ done, StepCfg cfg, Pending pend) {
+    __shared__ u32 tile[ROWS_HOT * 64];
+    __shared__ StepScratch scratch;
+    const int lane = threadIdx.x;
+    const long e = (long)blockIdx.x * 64 + lane;
+    const int pt = e < c.n ? pend.type[e] : 0;
+    if (__ballot(pt != 0) == 0) return;
+    {
+        const u32* __restrict__ src = c.R + e;
+#pragma unroll 16
+        for (int r = 0; r < ROWS_HOT; r++) tile[r * 64 + lane] = src[(long)r * c.N];
+    }
+    StL s(tile + lane, c.R, c.N, e);
+    long long tprof = 0;
+    StepCfg cfg2 = cfg;
+    cfg2.prof = nullptr;
+    const bool doit = pt != 0;
+    const int who = doit ? pend.who[e] : -1;
+    const int len = doit ? pend.len[e] : 0;
+    if (doit) pend.type[e] = 0;
+    // finish_step refreshes masks for `doit` and padding lanes only; the other lanes keep the masks k_step wrote
+    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof);
+    {
+        u32* __restrict__ dst = c.R + e;
+#pragma unroll 16
+        for (int r = 0; r < ROWS_HOT; r++) dst[(long)r * c.N] = tile[r * 64 + lane];
     }
 }
 
@@ -1111,7 +1415,7 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
 }
 // DESIGN.md "random policy": philox stream 1, blocks 2*step_idx and 2*step_idx+1 -> words w0..w7
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions) {
-    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.n) return;
     u32 m[MASK_WORDS];
 #pragma unroll
@@ -1186,7 +1490,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
 // ------------------------------------------------------------------------------------------------ deciding seat
 // ref: env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.  out = PlayerId 1..4
 __global__ __launch_bounds__(BLOCK) void k_deciding(Ctx c, i32* __restrict__ out) {
-    St s{ c.W, c.B, c.N, (long)blockIdx.x * BLOCK + threadIdx.x };
+    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.n) return;
     int p;
     if (s.b(B_NDISC) > 0) p = s.b(B_DISC);
@@ -1204,7 +1508,7 @@ struct BlobW {
 __global__ __launch_bounds__(BLOCK) void k_export(Ctx c, const long* __restrict__ idx, long cnt, i32* __restrict__ blob) {
     long i = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= cnt) return;
-    St s{ c.W, c.B, c.N, idx ? idx[i] : i };
+    St s(c.R, c.N, idx ? idx[i] : i);
     BlobW o{ blob, cnt, i, 0 };
     for (int t = 0; t < 19; t++) o.put(s.b(B_TILE + t) & 15);
     for (int t = 0; t < 19; t++) o.put(s.b(B_TILE + t) >> 4);
@@ -1226,10 +1530,10 @@ __global__ __launch_bounds__(BLOCK) void k_export(Ctx c, const long* __restrict_
         for (int k = 0; k < 6; k++) o.put((hb >> k) & 1);
         int nh = s.pb(p, P_NHID);
         o.put(nh);
-        for (int k = 0; k < 25; k++) o.put(k < nh ? s.pb(p, P_HIDDEN + k) : -1);
+        for (int k = 0; k < 25; k++) o.put(k < nh ? s.hidden(p, k) : -1);
         int np = s.pb(p, P_NPLAYED);
         o.put(np);
-        for (int k = 0; k < 25; k++) o.put(k < np ? s.pb(p, P_PLAYED + k) : -1);
+        for (int k = 0; k < 25; k++) o.put(k < np ? s.played(p, k) : -1);
         o.put(s.pb(p, P_VP));
     }
     for (int r = 0; r < 5; r++) o.put(s.b(B_BANK + r));
@@ -1237,7 +1541,7 @@ __global__ __launch_bounds__(BLOCK) void k_export(Ctx c, const long* __restrict_
     for (int p = 0; p < 4; p++) o.put(s.pb(p, P_CLEFT));
     int pl = s.b(B_PILE_LEN);
     o.put(pl);
-    for (int k = 0; k < 25; k++) o.put(k < pl ? s.b(B_PILE + k) : -1);
+    for (int k = 0; k < 25; k++) o.put(k < pl ? s.pile(k) : -1);
     int order = s.b(B_ORDER);
     for (int k = 0; k < 4; k++) o.put(pid_at(order, k) + 1);
     o.put(s.b(B_ORDER_ID)); o.put(s.b(B_GO) + 1);
@@ -1277,10 +1581,9 @@ struct BlobR {
 __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict__ idx, long cnt, const i32* __restrict__ blob) {
     long i = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= cnt) return;
-    St s{ c.W, c.B, c.N, idx ? idx[i] : i };
+    St s(c.R, c.N, idx ? idx[i] : i);
     BlobR in{ blob, cnt, i, 0 };
-    for (int r = 0; r < NW; r++) s.sw(r, 0);
-    for (int r = 0; r < NB; r++) s.sb(r, 0);
+    for (int r = 0; r < NROWS; r++) s.sw(r, 0);
     int tr[19];
     for (int t = 0; t < 19; t++) tr[t] = in.get();
     for (int t = 0; t < 19; t++) s.sb(B_TILE + t, tr[t] | (in.get() << 4));
@@ -1312,12 +1615,12 @@ __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict_
         int cnt5[5] = { 0, 0, 0, 0, 0 };
         for (int k = 0; k < 25; k++) {
             int v = in.get();
-            if (k < nh) { s.spb(p, P_HIDDEN + k, v); for (int q = 0; q < 5; q++) cnt5[q] += (q == v) ? 1 : 0; }
+            if (k < nh) { s.set_hidden(p, k, v); for (int q = 0; q < 5; q++) cnt5[q] += (q == v) ? 1 : 0; }
         }
         for (int q = 0; q < 5; q++) s.spb(p, P_HCNT + q, cnt5[q]);
         int np = in.get();
         s.spb(p, P_NPLAYED, np);
-        for (int k = 0; k < 25; k++) { int v = in.get(); if (k < np) s.spb(p, P_PLAYED + k, v); }
+        for (int k = 0; k < 25; k++) { int v = in.get(); if (k < np) s.set_played(p, k, v); }
         s.spb(p, P_VP, in.get());
     }
     for (int r = 0; r < 5; r++) s.sb(B_BANK + r, in.get());
@@ -1325,7 +1628,7 @@ __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict_
     for (int p = 0; p < 4; p++) s.spb(p, P_CLEFT, in.get());
     int pl = in.get();
     s.sb(B_PILE_LEN, pl);
-    for (int k = 0; k < 25; k++) { int v = in.get(); if (k < pl) s.sb(B_PILE + k, v); }
+    for (int k = 0; k < 25; k++) { int v = in.get(); if (k < pl) s.set_pile(k, v); }
     int order = 0, seatof = 0;
     for (int k = 0; k < 4; k++) { int p = in.get() - 1; order |= p << (2 * k); seatof |= k << (2 * p); }
     s.sb(B_ORDER, order); s.sb(B_SEATOF, seatof);

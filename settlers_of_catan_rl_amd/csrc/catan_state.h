@@ -1,11 +1,14 @@
 // catan_state.h - packed struct-of-arrays game state in HBM (one game per lane).
 //
-// Layout: one allocation per handle, `N` = number of games padded to a multiple of 64.
-//   u32 rows  W[NW][N]   bitboards (corners 54 bit, edges 72 bit), packed opponent-hand estimates, counters
-//   u8  rows  B[NB][N]   every other small integer of the game
-// Row r of game e lives at W[r*N + e] / B[r*N + e]: the 64 lanes of a wave touch 64 consecutive
-// elements of one row (one 256 B / 64 B segment) on every access.  672 B per game in total
-// (the reference-like int32 form of the same state is 736 words = 2944 B, see spec.py STATE_FIELDS).
+// Layout: one allocation per handle, `N` = number of games padded to a multiple of 256.
+//   u32 rows  R[NROWS][N]
+//     rows 0 .. NW-1            : 32-bit fields (bitboards: corners 54 bit, edges 72 bit; packed estimates; counters)
+//     rows NW .. NW+NB/4-1      : byte fields, four per word: byte field b of game e lives at byte (b&3) of word
+//                                 row NW + (b>>2)  ->  byte address ((NW + (b>>2))*N + e)*4 + (b&3)
+// The 64 lanes of a wave therefore touch one 256 B segment per row access, and a whole wave-tile of the HOT rows
+// (rows 0 .. ROWS_HOT-1, everything but the ordered dev-card lists and the pile) is 112 coalesced 256 B loads -
+// that tile is what k_step stages in LDS ([row][lane], conflict-free) for the duration of a step.
+// 676 B per game in total (the reference-like int32 form of the same state is 736 words = 2944 B, spec.py).
 //
 // Players are indexed by pid0 = PlayerId-1 (0 White, 1 Blue, 2 Orange, 3 Red; reference game/enums.py:8-12).
 // Resources r0 = Resource-1 (0 Brick, 1 Wood, 2 Ore, 3 Sheep, 4 Wheat; game/enums.py:22-28).
@@ -36,39 +39,38 @@ constexpr int W_TURN = 65;
 constexpr int W_ACTIONS = 66;     // actions_this_turn
 constexpr int NW = 67;
 
-// ---- u8 rows
+// ---- byte fields, HOT part (staged in LDS by k_step)
 constexpr int B_TILE = 0;         // +t (19): resource | value << 4
 constexpr int B_HARB = 19;        // +slot (9): harbour id placed at slot
 constexpr int B_ROBBER = 28;
 constexpr int B_BANK = 29;        // +r0 (5)
 constexpr int B_PILE_LEN = 34;
-constexpr int B_PILE = 35;        // +i (25): dev-card pile, popped from index pile_len-1
-constexpr int B_ORDER = 60;       // player_order packed: seat i -> pid0 in bits 2i..2i+1
-constexpr int B_SEATOF = 61;      // inverse: pid0 p -> seat in bits 2p..2p+1
-constexpr int B_ORDER_ID = 62;
-constexpr int B_GO = 63;          // players_go as pid0
-constexpr int B_FLAGS = 64;
-constexpr int B_RB_COUNT = 65;
-constexpr int B_TRADE_PROP = 66;  // pid0
-constexpr int B_TRADE_TGT = 67;   // pid0
-constexpr int B_TRADE_NG = 68;
-constexpr int B_TRADE_GIVE = 69;  // +i (4): Resource value 1..5
-constexpr int B_TRADE_NR = 73;
-constexpr int B_TRADE_RECV = 74;  // +i (4)
-constexpr int B_NDISC = 78;       // len(players_to_discard); players_need_to_discard == (n > 0)
-constexpr int B_DISC = 79;        // +i (4): pid0
-constexpr int B_DIE1 = 83;
-constexpr int B_DIE2 = 84;
-constexpr int B_TRADES = 85;      // trades_proposed_this_turn
-constexpr int B_LR_PLAYER = 86;   // 0 none, else PlayerId
-constexpr int B_LR_COUNT = 87;
-constexpr int B_LA_PLAYER = 88;   // 0 none, else PlayerId
-constexpr int B_LA_COUNT = 89;
-constexpr int B_BOUGHT = 90;      // +card (5): development_cards_bought_this_turn counts
-constexpr int B_CURVP = 95;       // +p (4): EnvWrapper.curr_vps
-constexpr int B_WINNER = 99;      // 0 none, else PlayerId
-constexpr int B_PLAYER = 100;     // + p*PB + field
-constexpr int PB = 76;
+constexpr int B_ORDER = 35;       // player_order packed: seat i -> pid0 in bits 2i..2i+1
+constexpr int B_SEATOF = 36;      // inverse: pid0 p -> seat in bits 2p..2p+1
+constexpr int B_ORDER_ID = 37;
+constexpr int B_GO = 38;          // players_go as pid0
+constexpr int B_FLAGS = 39;
+constexpr int B_RB_COUNT = 40;
+constexpr int B_TRADE_PROP = 41;  // pid0
+constexpr int B_TRADE_TGT = 42;   // pid0
+constexpr int B_TRADE_NG = 43;
+constexpr int B_TRADE_GIVE = 44;  // +i (4): Resource value 1..5
+constexpr int B_TRADE_NR = 48;
+constexpr int B_TRADE_RECV = 49;  // +i (4)
+constexpr int B_NDISC = 53;       // len(players_to_discard); players_need_to_discard == (n > 0)
+constexpr int B_DISC = 54;        // +i (4): pid0
+constexpr int B_DIE1 = 58;
+constexpr int B_DIE2 = 59;
+constexpr int B_TRADES = 60;      // trades_proposed_this_turn
+constexpr int B_LR_PLAYER = 61;   // 0 none, else PlayerId
+constexpr int B_LR_COUNT = 62;
+constexpr int B_LA_PLAYER = 63;   // 0 none, else PlayerId
+constexpr int B_LA_COUNT = 64;
+constexpr int B_BOUGHT = 65;      // +card (5): development_cards_bought_this_turn counts
+constexpr int B_CURVP = 70;       // +p (4): EnvWrapper.curr_vps
+constexpr int B_WINNER = 74;      // 0 none, else PlayerId
+constexpr int B_PLAYER = 76;      // + p*PB + field
+constexpr int PB = 26;
 constexpr int P_RES = 0;          // +r0 (5)
 constexpr int P_VIS = 5;          // +r0 (5)
 constexpr int P_HARB = 10;        // bit 0 generic 3:1, bit r0+1 the 2:1 harbour of resource r0
@@ -83,12 +85,17 @@ constexpr int P_IROAD = 22;
 constexpr int P_ISECOND = 23;     // 255 = None
 constexpr int P_CURLP = 24;       // current_longest_path
 constexpr int P_ARMY = 25;        // current_army_size
-constexpr int P_HIDDEN = 26;      // +i (25) ordered
-constexpr int P_PLAYED = 51;      // +i (25) ordered
-constexpr int NB = B_PLAYER + 4 * PB;   // 404
+constexpr int B_HOT = B_PLAYER + 4 * PB;    // 180 byte fields = 45 word rows
+// ---- byte fields, COLD part (global only; touched by buy/play development card, reset, export)
+constexpr int B_PILE = 180;       // +i (25): dev-card pile, popped from index pile_len-1
+constexpr int B_CARDS = 208;      // + p*50 : hidden_cards[25] (ordered) then visible_cards[25] (ordered)
+constexpr int NB = B_CARDS + 4 * 50;        // 408
+static_assert(B_HOT % 4 == 0 && NB % 4 == 0, "byte fields are packed four per word row");
 
-constexpr int STATE_BYTES_PER_GAME = NW * 4 + NB;   // 672
-static_assert(STATE_BYTES_PER_GAME == 672, "restate DESIGN.md byte table when the layout changes");
+constexpr int ROWS_HOT = NW + B_HOT / 4;    // 112
+constexpr int NROWS = NW + NB / 4;          // 169
+constexpr int STATE_BYTES_PER_GAME = NROWS * 4;
+static_assert(STATE_BYTES_PER_GAME == 676 && ROWS_HOT == 112, "restate DESIGN.md byte table when the layout changes");
 
 // B_FLAGS bits
 constexpr int F_INITIAL = 1, F_ROLLED = 2, F_PLAYED_DEV = 4, F_MUST_USE_DEV = 8, F_MUST_RESPOND = 16,

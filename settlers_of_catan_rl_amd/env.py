@@ -102,7 +102,7 @@ class VecCatanEnv(object):
         """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream)."""
         ms = (C.c_float * 4)()
         _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), _stream(), ms))
-        return dict(zip(("k_sample_random", "k_step", "k_reset", "k_masks"), [float(x) for x in ms]))
+        return dict(zip(("k_sample_random", "k_step", "k_lr_heavy", "k_step_finish"), [float(x) for x in ms]))
 
     def export_state(self, env_idx=None):
         """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""

@@ -1,0 +1,25 @@
+"""Diagnostics: per-phase time of the fused k_step kernel at several game ages (run on the GPU box)."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd import _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+env = VecCatanEnv(n, seed=0)
+L = _lib.lib()
+names = ["stage-in", "validate+apply", "tier-1 longest road", "holder logic (+cut)", "done/reward", "reset", "masks", "write-back"]
+NP = len(names)
+done = 0
+for upto, chunk in [(128, 128), (3000, 256)]:
+    env.random_rollout(done, upto - chunk - done); done = upto - chunk
+    L.catan_profile_enable(env.h, 1)
+    env.random_rollout(done, chunk); done = upto
+    out = (C.c_uint64 * (2 * NP))()
+    L.catan_profile_read(env.h, out)
+    L.catan_profile_enable(env.h, 0)
+    waves = (n + 63) // 64
+    print(f"--- steps {upto-chunk}..{upto}: mean us per wave-step | max us over all waves/steps (100 MHz ticks)")
+    for i, nm in enumerate(names):
+        print(f"  {nm:20s} mean {out[i] / (waves * chunk) / 100.0:9.2f} us   max {out[NP + i] / 100.0:9.2f} us")
