@@ -86,7 +86,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, 2 * PROF_PHASES * sizeof(unsigned long long));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, (2 * PROF_PHASES + 4) * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
@@ -137,7 +137,7 @@ static StepCfg step_cfg(const catan_env_t* e) {
 }
 // One env step = k_step (fused: apply + tier-1 longest road + done/reward + auto-reset + next masks) followed by the
 // two tier-2 kernels, which are no-ops unless some game's longest-road search overflowed its budget.
-constexpr int LR_HEAVY_GRID = 512;
+constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x LR_SPLIT parts are strided over them
 static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
     StepCfg sc = step_cfg(e);
     HIPCHK(hipMemsetAsync(e->pend.count, 0, sizeof(u32), st));
@@ -260,14 +260,14 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
 int catan_profile_enable(catan_env_t* e, int on) {
     if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(e->prof, 0, 2 * PROF_PHASES * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->prof, 0, (2 * PROF_PHASES + 4) * sizeof(unsigned long long)));
     e->prof_on = on;
     return CATAN_OK;
 }
 int catan_profile_read(catan_env_t* e, uint64_t* out16) {
     if (!e || !out16) return fail(CATAN_EINVAL, "catan_profile_read: bad arguments");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out16, e->prof, 2 * PROF_PHASES * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out16, e->prof, (2 * PROF_PHASES + 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 

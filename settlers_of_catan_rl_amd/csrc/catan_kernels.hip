@@ -25,6 +25,8 @@
 #include "catan_state.h"
 
 #define CATAN_TABLE static __device__ __constant__ const
+#define CATAN_FN static __device__ __forceinline__
+#define CATAN_TOPOLOGY_CODE
 #include "catan_topology.inc"
 
 namespace catan {
@@ -278,52 +280,57 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
-constexpr int LR_BUDGET = 160;      // tier-1 iterations per lane before the game is handed to tier 2
-constexpr int LR_HEAVY_THREADS = 512;
-constexpr int LR_POOL = 4096;       // tier-2 workgroup pool entries
+constexpr int LR_BUDGET = 96;       // tier-1 double-iterations per lane before the game is handed to tier 2
+constexpr int LR_HEAVY_THREADS = 1024;
+constexpr int LR_POOL = 3072;       // tier-2 workgroup pool entries
 constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round
 
 struct Dfs { bool active; int cur, d, base, best; u64 seen, cand; };
 struct DfsQueue { u64* seen; unsigned short* cd; int* n; int cap; };
+typedef unsigned short lrstk_t;   // stack entry: vertex | sibling << 6 | mode << 12 (0 none left, 1 one sibling, 2 re-derive)
 
-// One DFS step of one lane.  adj[v]: bitmask of road neighbours of v (0 if v is blocked).  path: this lane's column
-// (element for level d at path[d * stride]).
-DEVI void dfs_iter(Dfs& t, const u64* adj, u8* path, int stride, bool donate, const DfsQueue& q) {
+// One DFS step of one lane: (at most) one backtrack followed by one descend attempt.  adj[v]: bitmask of road
+// neighbours of v (0 if v is blocked).  path: this lane's column (entry for level d at path[d * stride]).
+DEVI void dfs_iter(Dfs& t, const u64* adj, lrstk_t* path, int stride, bool donate, const DfsQueue& q) {
     if (!t.active) return;
-    if (t.cand) {
-        const int v = __ffsll((long long)t.cand) - 1;
-        t.cand &= t.cand - 1;
-        t.best = max(t.best, t.d + 1);
-        const u64 a = adj[v] & ~t.seen & ~(1ull << v);
-        if (a) {
-            int donated = 0;
-            if (t.cand && donate) {                       // give the untaken siblings (<= 2) away
-                donated = 1;
-                u64 cc = t.cand;
-                while (cc) {
-                    const int sb = __ffsll((long long)cc) - 1;
-                    cc &= cc - 1;
-                    t.best = max(t.best, t.d + 1);
-                    if (adj[sb] & ~t.seen & ~(1ull << sb)) {
-                        const int qi = atomicAdd(q.n, 1);
-                        if (qi < q.cap) { q.seen[qi] = t.seen | (1ull << sb); q.cd[qi] = (unsigned short)(sb | ((t.d + 1) << 8)); }
-                        else { atomicSub(q.n, 1); donated = 0; }   // pool full: keep (an already pushed sibling is re-explored; harmless)
-                    }
-                }
-                if (donated) t.cand = 0;
-            }
-            path[t.d * stride] = (u8)(t.cur | (donated << 6));
-            t.cur = v; t.seen |= 1ull << v; t.d++; t.cand = a;
-        }
-    } else if (t.d == t.base) {
-        t.active = false;
-    } else {
+    if (t.cand == 0) {
+        if (t.d == t.base) { t.active = false; return; }
         t.seen &= ~(1ull << t.cur);
         const int child = t.cur;
         t.d--;
         const int pk = path[t.d * stride];
         t.cur = pk & 63;
-        t.cand = (pk >> 6) ? 0ull : (adj[t.cur] & ~t.seen & ~((2ull << child) - 1));
+        const int mode = pk >> 12;
+        t.cand = mode == 0 ? 0ull : (mode == 1 ? (1ull << ((pk >> 6) & 63)) : (adj[t.cur] & ~t.seen & ~((2ull << child) - 1)));
+        if (t.cand == 0) return;
+    }
+    const int v = __ffsll((long long)t.cand) - 1;
+    t.cand &= t.cand - 1;
+    t.best = max(t.best, t.d + 1);
+    const u64 a = adj[v] & ~t.seen & ~(1ull << v);
+    if (a) {
+        if (t.cand && donate) {                       // give the untaken siblings (<= 2) away
+            bool all = true;
+            u64 cc = t.cand;
+            while (cc) {
+                const int sb = __ffsll((long long)cc) - 1;
+                cc &= cc - 1;
+                t.best = max(t.best, t.d + 1);
+                if (adj[sb] & ~t.seen & ~(1ull << sb)) {
+                    const int qi = atomicAdd(q.n, 1);
+                    if (qi < q.cap) { q.seen[qi] = t.seen | (1ull << sb); q.cd[qi] = (unsigned short)(sb | ((t.d + 1) << 8)); }
+                    else { atomicSub(q.n, 1); all = false; }   // pool full: keep (an already pushed sibling is re-explored; harmless)
+                }
+            }
+            if (all) t.cand = 0;
+        }
+        int entry = t.cur;
+        if (t.cand) {
+            const u64 rest = t.cand & (t.cand - 1);
+            entry |= rest ? (2 << 12) : ((1 << 12) | ((__ffsll((long long)t.cand) - 1) << 6));
+        }
+        path[t.d * stride] = (lrstk_t)entry;
+        t.cur = v; t.seen |= 1ull << v; t.d++; t.cand = a;
     }
 }
 DEVI void dfs_take(Dfs& t, const u64* adj, u64 seen, int cd) {
@@ -331,13 +338,21 @@ DEVI void dfs_take(Dfs& t, const u64* adj, u64 seen, int cd) {
     t.cand = adj[t.cur] & ~seen;
     t.active = true;
 }
+// static neighbour tables of corner v packed in two registers (loaded once per kernel): 3 x 8 bit each
+DEVI void lr_load_nbr(int v, u32& nc, u32& ne) {
+    nc = 0xFFFFFFu; ne = 0xFFFFFFu;
+    if (v < 54) {
+        nc = CORNER_NBR_C[v][0] | (CORNER_NBR_C[v][1] << 8) | (CORNER_NBR_C[v][2] << 16);
+        ne = CORNER_NBR_E[v][0] | (CORNER_NBR_E[v][1] << 8) | (CORNER_NBR_E[v][2] << 16);
+    }
+}
 // adjacency bitmask of corner v over road set (R, RH) with blocked corners BL
-DEVI u64 lr_adj_of(int v, u64 R, u32 RH, u64 BL) {
+DEVI u64 lr_adj_of(int v, u32 nc, u32 ne, u64 R, u32 RH, u64 BL) {
     u64 m = 0;
     if (v < 54 && !((BL >> v) & 1)) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            int t = CORNER_NBR_C[v][k], ed = CORNER_NBR_E[v][k];
+            int t = (nc >> (8 * k)) & 255, ed = (ne >> (8 * k)) & 255;
             if (t != 255) {
                 bool has = ed < 64 ? ((R >> ed) & 1) : ((RH >> (ed - 64)) & 1);
                 if (has) m |= 1ull << t;
@@ -352,13 +367,13 @@ struct LrWave {
     u64 q_seen[LR_QN];
     unsigned short q_cd[LR_QN];
     int qn;
-    u8 path[54][64];
+    lrstk_t path[54][64];
 };
 
 // tier 1.  Returns the path length for lanes with want=true, or -1 if the search ran out of budget (budget <= 0:
 // unlimited).  Must be called by all 64 lanes of the wave.
 template <class S>
-DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget) {
+DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget, u32 nbr_c, u32 nbr_e, unsigned long long* stat = nullptr) {
     u64 bal = __ballot(want);
     if (bal == 0) return 0;
     u64 rlo = 0, blocked = 0;
@@ -376,7 +391,7 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
         const u64 R = ((u64)(u32)__shfl((int)(u32)(rlo >> 32), src) << 32) | (u32)__shfl((int)(u32)rlo, src);
         const u32 RH = (u32)__shfl((int)rhi, src);
         const u64 BL = ((u64)(u32)__shfl((int)(u32)(blocked >> 32), src) << 32) | (u32)__shfl((int)(u32)blocked, src);
-        const u64 myadj = lr_adj_of(lane, R, RH, BL);
+        const u64 myadj = lr_adj_of(lane, nbr_c, nbr_e, R, RH, BL);
         if (lane < 54) L.adj[lane] = myadj;
         if (lane == 0) L.qn = 0;
         __builtin_amdgcn_wave_barrier();
@@ -388,6 +403,7 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
         bool overflow = false;
         while (true) {
             dfs_iter(t, L.adj, &L.path[0][lane], 64, idle != 0, q);
+            dfs_iter(t, L.adj, &L.path[0][lane], 64, idle != 0, q);
             idle = __ballot(!t.active);
             const int qn = L.qn;
             if (idle == ~0ull && qn <= 0) break;
@@ -398,6 +414,7 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
                 else atomicAdd(&L.qn, 1);
             }
         }
+        if (stat != nullptr && lane == 0) { atomicAdd(&stat[0], 1ull); atomicAdd(&stat[1], (unsigned long long)it); if (overflow) atomicAdd(&stat[2], 1ull); }
         int best = t.best;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
@@ -407,18 +424,23 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
     return result;
 }
 
-// tier 2: one workgroup per request.  req[i] = game | pid0 << 56; out_len[game] receives the path length.
+// tier 2: LR_SPLIT workgroups per request (static partition of the start corners, combined with atomicMax).
+// req[i] = game | pid0 << 56; out_len[game] (zeroed by k_step) receives the path length.
+constexpr int LR_SPLIT = 8;
 __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
                                                               const u64* __restrict__ req, i32* __restrict__ out_len) {
     __shared__ u64 adj[54];
     __shared__ u64 pool_seen[LR_POOL];
     __shared__ unsigned short pool_cd[LR_POOL];
     __shared__ int pool_n, best_all;
-    __shared__ u8 path[54][LR_HEAVY_THREADS];
+    __shared__ lrstk_t path[54][LR_HEAVY_THREADS];
     const int tid = threadIdx.x;
-    const u32 count = *req_count;
+    const u32 count = *req_count * LR_SPLIT;
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(tid < 54 ? tid : 0, nbr_c, nbr_e);
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
-        const u64 rq = req[r];
+        const u64 rq = req[r / LR_SPLIT];
+        const int part = (int)(r % LR_SPLIT);
         const long game = (long)(rq & 0x00FFFFFFFFFFFFFFull);
         const int pid = (int)(rq >> 56);
         St s(c.R, c.N, game);
@@ -426,12 +448,12 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         if (tid < 54) {
             u64 BL = 0;
             for (int o = 0; o < 4; o++) if (o != pid) BL |= s.settle(o) | s.city(o);
-            adj[tid] = lr_adj_of(tid, s.road_lo(pid), s.road_hi(pid), BL);
+            adj[tid] = lr_adj_of(tid, nbr_c, nbr_e, s.road_lo(pid), s.road_hi(pid), BL);
         }
         if (tid == 0) { pool_n = 0; best_all = 0; }
         __syncthreads();
         Dfs t;
-        t.active = tid < 54 && adj[tid < 54 ? tid : 0] != 0;
+        t.active = tid < 54 && (tid % LR_SPLIT) == part && adj[tid < 54 ? tid : 0] != 0;
         t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
@@ -449,7 +471,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         }
         atomicMax(&best_all, t.best);
         __syncthreads();
-        if (tid == 0) out_len[game] = best_all;
+        if (tid == 0 && best_all > 0) atomicMax(&out_len[game], best_all);
     }
 }
 
@@ -582,33 +604,19 @@ DEVI void load_boards(const S& s, int pid, Boards& b) {
 }
 // ref: game/components/corner.py:24-39 over all corners.  initial=true ignores the own-road requirement.
 DEVI u64 settle_spots(const Boards& b, bool initial) {
-    u64 blocked = b.occ, touched = 0;
-    for (int c = 0; c < 54; c++) if (CORNER_NBR_MASK[c] & b.occ) blocked |= 1ull << c;
-    if (!initial) {
-        u64 rl = b.own_rlo; u32 rh = b.own_rhi;
-        for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
-        for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
-        return ~blocked & touched & ALL54;
-    }
+    const u64 blocked = topo_blocked(b.occ);
+    if (!initial) return ~blocked & topo_touched(b.own_rlo, b.own_rhi) & ALL54;
     return ~blocked & ALL54;
 }
 // ref: env/wrapper.py:322-339 + game/components/edge.py:23-42.  Returns 73 bits (lo 64, hi 9; bit 72 = dummy edge).
 template <class S>
 DEVI void road_spots(const S& s, const Boards& b, int pid, int flags, bool road_building, u64& lo, u32& hi) {
-    u64 elo = ~b.all_rlo;
-    u32 ehi = ~b.all_rhi & 0xFFu;
+    const u64 elo = ~b.all_rlo;
+    const u32 ehi = ~b.all_rhi & 0xFFu;
     u64 anchors;
-    if ((flags & F_INITIAL) && s.pb(pid, P_ISET) == 2) {
-        anchors = 1ull << s.pb(pid, P_ISECOND);
-    } else {
-        u64 touched = 0, rl = b.own_rlo; u32 rh = b.own_rhi;
-        for (int e = 0; e < 64; e++) if ((rl >> e) & 1) touched |= EDGE_CORNER_MASK[e];
-        for (int e = 64; e < 72; e++) if ((rh >> (e - 64)) & 1) touched |= EDGE_CORNER_MASK[e];
-        anchors = b.own_bld | (touched & ~b.occ);
-    }
-    lo = 0; hi = 0;
-    for (int e = 0; e < 64; e++) if (EDGE_CORNER_MASK[e] & anchors) lo |= 1ull << e;
-    for (int e = 64; e < 72; e++) if (EDGE_CORNER_MASK[e] & anchors) hi |= 1u << (e - 64);
+    if ((flags & F_INITIAL) && s.pb(pid, P_ISET) == 2) anchors = 1ull << s.pb(pid, P_ISECOND);
+    else anchors = b.own_bld | (topo_touched(b.own_rlo, b.own_rhi) & ~b.occ);
+    topo_edges_at(anchors, lo, hi);
     lo &= elo; hi &= ehi;
     if (road_building && lo == 0 && hi == 0) hi = 1u << 8;
 }
@@ -668,7 +676,7 @@ DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
     }
     if (flags & F_JUST_ROBBER) {                                           // wrapper.py:210-213, 341-351
         int seatof = s.b(B_SEATOF);
-        u64 tm = TILE_CORNER_MASK[s.b(B_ROBBER)];
+        const u64 tm = topo_tile_corners(s.b(B_ROBBER));
         u32 tg = 0;
         for (int o = 0; o < 4; o++) if (o != pid && ((s.settle(o) | s.city(o)) & tm)) tg |= 1u << label_of(seatof, pid, o);
         setr<M0, 13>(m, 1u << T_STEAL);
@@ -744,9 +752,7 @@ DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
         if (give && bank_bits) { types |= 1u << T_EXCHANGE; setr<M9, 5>(m, give); setr<M10, 5>(m, bank_bits); }
     }
     if (flags & F_CAN_ROBBER) {                                                            // :278-281, 308-320
-        u32 tv = 0;
-        for (int t = 0; t < 19; t++) if (TILE_CORNER_MASK[t] & b.occ) tv |= 1u << t;
-        types |= 1u << T_ROBBER; setr<M3, 19>(m, tv);
+        types |= 1u << T_ROBBER; setr<M3, 19>(m, topo_tiles_at(b.occ));
     }
     {                                                                                      // :283-289
         int tot = res[0] + res[1] + res[2] + res[3] + res[4];
@@ -839,11 +845,18 @@ DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof) {
     u32 alloc[5] = { 0, 0, 0, 0, 0 };     // per resource: one byte per pid0
     u64 st[4], ct[4];
     for (int p = 0; p < 4; p++) { st[p] = s.settle(p); ct[p] = s.city(p); }
+    int hit[2] = { -1, -1 }, hitres[2] = { 0, 0 };   // at most two tiles carry any number token
+#pragma unroll
     for (int t = 0; t < 19; t++) {
-        int tb = s.b(B_TILE + t);
-        if ((tb >> 4) != roll || t == robber) continue;
-        int r0 = (tb & 15) - 1;
-        u64 tm = TILE_CORNER_MASK[t];
+        const int tb = s.b(B_TILE + t);
+        const bool m = (tb >> 4) == roll && t != robber;
+        if (m) { if (hit[0] < 0) { hit[0] = t; hitres[0] = (tb & 15) - 1; } else { hit[1] = t; hitres[1] = (tb & 15) - 1; } }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (hit[h] < 0) continue;
+        const int r0 = hitres[h];
+        const u64 tm = topo_tile_corners(hit[h]);
         u32 add = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) add |= (u32)(__popcll(st[p] & tm) + 2 * __popcll(ct[p] & tm)) << (8 * p);
@@ -936,12 +949,12 @@ struct StepScratch { LrWave lr; ResetScratch rs; };
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof);
+                      long long& tprof, u32 nbr_c, u32 nbr_e);
 
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof) {
+                      long long& tprof, u32 nbr_c, u32 nbr_e) {
     const long e = s.e;
     const bool doit_or_pad = doit || e >= c.n;       // padding games keep valid masks too
     {
@@ -964,7 +977,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
             int max_len = len, player = lr_who;
             bool tied = false;
             for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
-                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch.lr, 0);
+                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch.lr, 0, nbr_c, nbr_e);
                 if (cut && o != lr_who) {
                     if (pl == max_len) tied = true;
                     else if (pl > max_len) { max_len = pl; tied = false; player = o; }
@@ -1049,6 +1062,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int lane = threadIdx.x;
     const long e = (long)blockIdx.x * 64 + lane;
     long long tprof = cfg.prof ? wall_clock64() : 0;
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(lane, nbr_c, nbr_e);
     {
         const u32* __restrict__ src = c.R + e;
 #pragma unroll 16
@@ -1182,7 +1197,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     case T_ROBBER: {                                                       // game.py:623-634
         s.sb(B_ROBBER, a[3]);
         flags &= ~F_CAN_ROBBER;
-        u64 tm = TILE_CORNER_MASK[a[3]], opp = 0;
+        u64 tm = topo_tile_corners(a[3]), opp = 0;
         for (int o = 0; o < 4; o++) if (o != pid) opp |= s.settle(o) | s.city(o);
         if (opp & tm) flags |= F_JUST_ROBBER;
         s.sb(B_FLAGS, flags);
@@ -1352,16 +1367,17 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
 
     prof_mark(cfg, 1, tprof);
     // ---- update_longest_road (game.py:864-919): tier-1 path length, or hand the game to tier 2
-    int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L, LR_BUDGET);
+    int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L, LR_BUDGET, nbr_c, nbr_e, cfg.prof ? cfg.prof + 2 * PROF_PHASES : nullptr);
     const bool pending = lr_who >= 0 && len < 0;
     if (pending) {                                   // finished later by k_lr_heavy + k_step_finish
         const u32 slot = atomicAdd(pend.count, 1u);
         pend.req[slot] = (u64)e | ((u64)lr_who << 56);
         pend.type[e] = (u8)(type + 1);
         pend.who[e] = (u8)lr_who;
+        pend.len[e] = 0;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof);
+    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e);
     // ---- write the tile back
     {
         u32* __restrict__ dst = c.R + e;
@@ -1395,7 +1411,9 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     const int len = doit ? pend.len[e] : 0;
     if (doit) pend.type[e] = 0;
     // finish_step refreshes masks for `doit` and padding lanes only; the other lanes keep the masks k_step wrote
-    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof);
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(lane, nbr_c, nbr_e);
+    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e);
     {
         u32* __restrict__ dst = c.R + e;
 #pragma unroll 16

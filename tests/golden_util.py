@@ -1,0 +1,37 @@
+"""Decoding helpers for the fixtures written by tools/gen_golden.py."""
+import os
+import zlib
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def unpack_masks(packed):
+    return np.unpackbits(packed, bitorder="little")[:325].astype(np.float32)
+
+
+def decode_obs(traj):
+    """-> list of float32[1787] observations at traj['sample_idx'] (stored as zero pattern + non-zero values)."""
+    pat = np.unpackbits(traj["sample_obs"], axis=1)[:, :1787].astype(bool)
+    vals = traj["sample_obs_nz"]
+    out, k = [], 0
+    for row in pat:
+        o = np.zeros(1787, dtype=np.float32)
+        n = int(row.sum())
+        o[row] = vals[k:k + n]
+        k += n
+        out.append(o)
+    assert k == len(vals)
+    return out
+
+
+TRAJS = ["traj_s3_e0.npz", "traj_s3_e1.npz", "traj_s17_e4.npz"]

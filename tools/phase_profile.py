@@ -16,10 +16,11 @@ for upto, chunk in [(128, 128), (3000, 256)]:
     env.random_rollout(done, upto - chunk - done); done = upto - chunk
     L.catan_profile_enable(env.h, 1)
     env.random_rollout(done, chunk); done = upto
-    out = (C.c_uint64 * (2 * NP))()
+    out = (C.c_uint64 * (2 * NP + 4))()
     L.catan_profile_read(env.h, out)
     L.catan_profile_enable(env.h, 0)
     waves = (n + 63) // 64
     print(f"--- steps {upto-chunk}..{upto}: mean us per wave-step | max us over all waves/steps (100 MHz ticks)")
     for i, nm in enumerate(names):
         print(f"  {nm:20s} mean {out[i] / (waves * chunk) / 100.0:9.2f} us   max {out[NP + i] / 100.0:9.2f} us")
+    print(f"  tier-1 requests {out[2*NP]} ({out[2*NP]/(waves*chunk):.2f}/wave-step), loop iterations {out[2*NP+1]} ({out[2*NP+1]/max(1,out[2*NP]):.1f}/request), overflows {out[2*NP+2]} ({out[2*NP+2]/chunk:.1f}/step)")
