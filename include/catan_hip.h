@@ -99,6 +99,35 @@ int catan_random_rollout(catan_env_t* env, uint32_t step_idx0, int64_t steps, ca
  * float[4] receiving the summed milliseconds of k_sample_random, k_step, k_lr_heavy, k_step_finish (bench.py roofline). */
 int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms);
 
+/* EnvWrapper._get_obs(): env/wrapper.py:52-83 (+ _get_tile_features :491-524, _get_player_inputs :526-709), batched.
+ * out_f: float32 [n][1787] in the order proposed_trade[12] current_resources[6] tile_representations[19][60]
+ * current_player_main[152] next/next_next/next_next_next_player_main[159]; out_lists: int32 [n][5][25] card-id lists
+ * (current played, current hidden, next x3 played; ids = card+1, zero padded); out_lens: int32 [n][5] (1 when empty,
+ * like the reference's [0]).  The deciding player of each game is catan_deciding_seat(). */
+int catan_obs(catan_env_t* env, float* out_f, int32_t* out_lists, int32_t* out_lens, catan_stream_t stream);
+
+/* Game.get_longest_path(player): game/game.py:843-862 for players[i] (PlayerId) in game i -> out[i].  Diagnostic/test
+ * entry; inside catan_step the same search runs as part of update_longest_road. */
+int catan_longest_path(catan_env_t* env, const int32_t* players, int32_t* out, catan_stream_t stream);
+
+/* BatchProcessor.compute_advantages_alt: RL/ppo/process_batch.py:134-141.  rewards [T][N], values [T+1][N]
+ * (denormalised), masks [T+1][N] -> returns [T][N], adv_raw [T][N] = returns - values[:-1], and
+ * stats3 (device double[3]) = (sum, sum of squares, count) of adv_raw for the global normalisation.
+ * workspace: device double[catan_gae_workspace_doubles(N)]. */
+int64_t catan_gae_workspace_doubles(int64_t N);
+int catan_gae(const float* rewards, const float* values, const float* masks, int64_t T, int64_t N, double gamma, double lam,
+              float* returns, float* adv_raw, double* workspace, double* stats3, catan_stream_t stream);
+/* process_batch.py:142: adv = (adv - mean) / (std_unbiased + 1e-5) with (sum, sumsq, count) in stats3 - all-reduce
+ * the three doubles over ranks first when games are sharded over GPUs. */
+int catan_adv_normalise(float* adv, int64_t total, const double* stats3, catan_stream_t stream);
+
+/* PPO.update loss: RL/ppo/ppo.py:46-48 (value normaliser, when use_norm) and :54-66.  All arrays float32 [B] on device.
+ * losses2 = (action_loss, value_loss); d_logp, d_values = gradient of value_coef*value_loss + action_loss w.r.t.
+ * action_log_probs and values (the entropy term stays in the network's autograd graph). */
+int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, const float* values, const float* old_values,
+                   const float* returns, int64_t B, float clip, float value_coef, int use_norm, float norm_mean, float norm_std,
+                   float* losses2, float* d_logp, float* d_values, catan_stream_t stream);
+
 /* k_step phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums over waves then 8
  * per-wave maxima, in 100 MHz wall-clock ticks, for the phases stage-in, validate+apply, tier-1 longest road,
  * holder logic (+cut), done/reward, reset, masks, write-back. */

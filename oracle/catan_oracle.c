@@ -1215,9 +1215,9 @@ int64_t orc_batch_run_random(OrcEnv* envs, int64_t n, uint64_t seed, uint64_t en
 /* ====================================================================== GAE + PPO loss */
 /* ref: RL/ppo/process_batch.py:134-142.  fp32 recurrences in the reference's evaluation order; the global
  * mean / unbiased std are accumulated in fp64 (torch reduces in fp32 with a different order: tolerance 1e-5). */
-void orc_gae(const float* rewards, const float* values, const float* masks, int64_t T, int64_t N, float gamma,
-             float lam, float* returns, float* adv_norm) {
-    float gl = (float)((double)gamma * (double)lam);
+void orc_gae(const float* rewards, const float* values, const float* masks, int64_t T, int64_t N, double gamma_d,
+             double lam_d, float* returns, float* adv_norm) {
+    float gamma = (float)gamma_d, gl = (float)(gamma_d * lam_d);   /* python doubles, cast where they meet an fp32 tensor */
     double sum = 0.0, sumsq = 0.0;
     for (int64_t n = 0; n < N; n++) {
         float gae = 0.0f;

@@ -9,6 +9,8 @@
 
 #include "../../include/catan_hip.h"
 #include "catan_kernels.hip"
+#include "catan_obs.hip"
+#include "catan_ppo.hip"
 
 using namespace catan;
 
@@ -252,6 +254,55 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
             kernel_ms[k] += ms;
         }
     for (auto& x : ev) hipEventDestroy(x);
+    return CATAN_OK;
+}
+
+int catan_obs(catan_env_t* e, float* out_f, int32_t* out_lists, int32_t* out_lens, catan_stream_t stream) {
+    if (!e || !out_f || !out_lists || !out_lens) return fail(CATAN_EINVAL, "catan_obs: null argument");
+    hipLaunchKernelGGL(k_obs, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_longest_path(catan_env_t* e, const int32_t* players, int32_t* out, catan_stream_t stream) {
+    if (!e || !players || !out) return fail(CATAN_EINVAL, "catan_longest_path: null argument");
+    hipLaunchKernelGGL(k_longest_path, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, players, out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int64_t catan_gae_workspace_doubles(int64_t N) { return 2 * ((N + GAE_BLOCK - 1) / GAE_BLOCK) + 4; }
+
+int catan_gae(const float* rewards, const float* values, const float* masks, int64_t T, int64_t N, double gamma, double lam,
+              float* returns, float* adv_raw, double* workspace, double* stats3, catan_stream_t stream) {
+    if (!rewards || !values || !masks || !returns || !adv_raw || !workspace || !stats3 || T <= 0 || N <= 0)
+        return fail(CATAN_EINVAL, "catan_gae: bad arguments");
+    const int nb = (int)((N + GAE_BLOCK - 1) / GAE_BLOCK);
+    // python-scalar semantics of the reference: gamma and gamma*lambda are doubles, cast to fp32 where they meet a tensor
+    const float gl = (float)(gamma * lam);
+    hipLaunchKernelGGL(k_gae, dim3(nb), dim3(GAE_BLOCK), 0, S(stream), rewards, values, masks, (long)T, (long)N, (float)gamma, gl, returns, adv_raw, workspace);
+    hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(GAE_BLOCK), 0, S(stream), (const double*)workspace, nb, (double)T * (double)N, stats3);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_adv_normalise(float* adv, int64_t total, const double* stats3, catan_stream_t stream) {
+    if (!adv || !stats3 || total <= 0) return fail(CATAN_EINVAL, "catan_adv_normalise: bad arguments");
+    long nb = (total + GAE_BLOCK - 1) / GAE_BLOCK;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_adv_normalise, dim3((unsigned)nb), dim3(GAE_BLOCK), 0, S(stream), adv, (long)total, stats3);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, const float* values, const float* old_values,
+                   const float* returns, int64_t B, float clip, float value_coef, int use_norm, float norm_mean, float norm_std,
+                   float* losses2, float* d_logp, float* d_values, catan_stream_t stream) {
+    if (!logp || !old_logp || !adv || !values || !old_values || !returns || !losses2 || !d_logp || !d_values || B <= 0)
+        return fail(CATAN_EINVAL, "catan_ppo_loss: bad arguments");
+    PpoArgs a{ clip, value_coef, norm_mean, norm_std, use_norm };
+    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, S(stream), logp, old_logp, adv, values, old_values, returns, (long)B, a, losses2, d_logp, d_values);
+    HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
 

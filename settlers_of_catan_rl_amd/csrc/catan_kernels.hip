@@ -1686,4 +1686,18 @@ __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict_
     s.sw(W_RNG, (u32)in.get());
 }
 
+// test/diagnostic entry: longest path of player players[i] (PlayerId 1..4) in game i, unbudgeted tier-1 search
+__global__ __launch_bounds__(64) void k_longest_path(Ctx c, const i32* __restrict__ players, i32* __restrict__ out) {
+    __shared__ LrWave L;
+    const int lane = threadIdx.x;
+    const long e = (long)blockIdx.x * 64 + lane;
+    St s(c.R, c.N, e);
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(lane, nbr_c, nbr_e);
+    const bool want = e < c.n;
+    const int pid = want ? players[e] - 1 : 0;
+    const int len = coop_longest_path(want, s, pid, L, 0, nbr_c, nbr_e);
+    if (want) out[e] = len;
+}
+
 }  // namespace catan

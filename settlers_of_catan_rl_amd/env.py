@@ -127,6 +127,17 @@ class VecCatanEnv(object):
         bt = b.t().contiguous()
         _lib.check(self.L.catan_state_import(self.h, _ptr(bt), _ptr(idx), cnt, _stream()))
 
+    def get_obs(self, out=None):
+        from . import obs as _obs
+        return _obs.get_obs(self, out)
+
+    def longest_path(self, players):
+        """Game.get_longest_path for PlayerId players[i] of game i (diagnostic/test entry)."""
+        p = torch.as_tensor(players, dtype=torch.int32, device=self.device).contiguous()
+        out = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_longest_path(self.h, _ptr(p), _ptr(out), _stream()))
+        return out
+
     def invalid_action_count(self):
         return int(self.L.catan_invalid_action_count(self.h, _stream()))
 
@@ -183,6 +194,7 @@ class EnvWrapper(object):
         self.validate_actions = validate_actions
         self.game = _GameView(self)
         self._cache = None
+        self._fresh = True          # catan_create already reset the game: the first reset() must not draw again
         self._reward_annealing_factor = 1.0
 
     @property
@@ -200,7 +212,10 @@ class EnvWrapper(object):
         return self._cache
 
     def reset(self):
-        self.vec.reset()
+        if self._fresh:
+            self._fresh = False
+        else:
+            self.vec.reset()
         self._cache = None
         return self._get_obs()
 

@@ -48,7 +48,7 @@ def lib():
         L.orc_batch_create.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64]
         L.orc_batch_run_random.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, i32p, i64p, C.c_int]
         L.orc_batch_run_random.restype = C.c_int64
-        L.orc_gae.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_float, C.c_float, f32p, f32p]
+        L.orc_gae.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_double, C.c_double, f32p, f32p]
         L.orc_ppo_loss.argtypes = [f32p] * 6 + [C.c_int64, C.c_float, f32p, f32p, f32p, f32p, C.c_float]
         _lib = L
     return _lib
