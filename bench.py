@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path over one batch: for every game of this rank, one uniform-random legal
 action (device sampler standing in for the policy), EnvWrapper.step semantics (apply + done/reward + auto-reset)
-and the next legal-action masks - i.e. k_sample_random -> k_step -> k_reset -> k_masks, all inputs resident in HBM.
+and the next legal-action masks - i.e. k_sample_random -> k_step (fused) -> k_lr_heavy -> k_step_finish, all inputs
+resident in HBM.
 
     python bench.py --gpus 1 --steps 4096 --warmup 256
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -72,38 +73,24 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from settlers_of_catan_rl_amd import dist as cdist
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world = cdist.init_from_env()          # backend "nccl" == RCCL over xGMI
 
     from settlers_of_catan_rl_amd.env import VecCatanEnv
 
-    n = args.envs
-    env = VecCatanEnv(n, seed=args.seed, env_id0=rank * n, validate_actions=not args.no_validate, auto_reset=True)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    env_id0, n = cdist.shard(rank, args.envs)                # global game ids: results do not depend on `world`
+    env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0, validate_actions=not args.no_validate, auto_reset=True)
 
     env.random_rollout(0, args.warmup)
-    barrier()
+    cdist.barrier()
     t0 = time.perf_counter()
     env.random_rollout(args.warmup, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    cdist.barrier()
+    dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
     bad = env.invalid_action_count()
 
     out = None
@@ -142,8 +129,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        cdist.finalize()
     if rank == 0:
         print(json.dumps(out))
 

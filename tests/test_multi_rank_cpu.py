@@ -1,0 +1,83 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: game sharding by global id is invariant to the number of ranks,
+the 3-scalar advantage-statistics all-reduce reproduces the global normalisation, the flat gradient bucket averages,
+and the bench timing reduction takes the max over ranks.  The per-game engine here is the CPU oracle (test
+infrastructure); on the GPU box the same dist helpers run over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from settlers_of_catan_rl_amd import dist as cdist
+    r, lr, w = cdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    n_per, seed, steps = 48, 5, 300
+    env_id0, n = cdist.shard(r, n_per)
+    b = oracle_lib.OracleBatch(n, seed, env_id0=env_id0)
+    blobs = torch.from_numpy(b.run_random(steps, n_threads=1))
+    gathered = [torch.empty_like(blobs) for _ in range(w)]
+    dist.all_gather(gathered, blobs)
+    # (1) advantage statistics: local (sum, sumsq, count) -> all-reduce -> global mean / unbiased std
+    g = torch.Generator().manual_seed(100 + r)
+    adv = torch.randn(40, n, generator=g, dtype=torch.float32) * (1 + r) + 0.3 * r
+    stats = torch.tensor([adv.double().sum(), (adv.double() ** 2).sum(), adv.numel()], dtype=torch.float64)
+    dist.all_reduce(stats)
+    cnt, mean = stats[2], stats[0] / stats[2]
+    std = torch.sqrt((stats[1] - cnt * mean * mean) / (cnt - 1))
+    all_adv = [torch.empty_like(adv) for _ in range(w)]
+    dist.all_gather(all_adv, adv)
+    # (2) flat gradient bucket
+    lin = torch.nn.Linear(4, 3)
+    for i, p in enumerate(lin.parameters()):
+        p.grad = torch.full_like(p, float(r + 1 + i))
+    cdist.allreduce_flat_grads(list(lin.parameters()))
+    grads = [p.grad.clone() for p in lin.parameters()]
+    # (3) timing reduction
+    tmax = cdist.max_over_ranks(1.0 + r)
+    tsum = cdist.sum_over_ranks(1.0 + r)
+    cdist.barrier(sync_cuda=False)
+    if r == 0:
+        q.put(dict(blobs=torch.cat(gathered).numpy(), mean=float(mean), std=float(std),
+                   ref_mean=float(torch.cat(all_adv, 1).double().mean()), ref_std=float(torch.cat(all_adv, 1).double().std()),
+                   grads=[g.numpy() for g in grads], tmax=tmax, tsum=tsum, n_per=n_per, seed=seed, steps=steps))
+    cdist.finalize()
+
+
+def test_two_rank_sharding_and_reductions():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    single = oracle_lib.OracleBatch(world * out["n_per"], out["seed"]).run_random(out["steps"], n_threads=1)
+    assert np.array_equal(out["blobs"], single), "sharded games differ from the single-process run"
+    assert abs(out["mean"] - out["ref_mean"]) < 1e-9 and abs(out["std"] - out["ref_std"]) < 1e-9
+    for i, g in enumerate(out["grads"]):
+        assert np.allclose(g, (1 + i + 2 + i) / 2.0)
+    assert out["tmax"] == 2.0 and out["tsum"] == 3.0
