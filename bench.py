@@ -64,7 +64,7 @@ def cpu_baseline(sample_envs=2048, sample_steps=1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=65536, help="games per GPU")
     ap.add_argument("--seed", type=int, default=0)
