@@ -1,0 +1,375 @@
+"""Policy / value network of the reference, restated for batched fixed-shape execution on MI355X (PyTorch-ROCm).
+
+Architecture and semantics follow the reference (paths relative to the upstream repo):
+  RL/models/build_agent_model.py:8-33,36-155   sizes, autoregressive map, type-conditional masks, log-prob masks
+  RL/models/observation_module.py:47-61        tile encoder + player modules -> 987 -> 512 trunk
+  RL/models/tile_encoder.py:67-91              60 -> 64, LN, ReLU, 2 pre-LN encoder layers (4 heads, FFN x2), 64 -> 25, LN, ReLU
+  RL/models/player_modules.py:12-157           current / other player MLPs + masked dev-card attention, summed
+  RL/models/multi_headed_attention.py:12-54    attention with a key mask
+  RL/models/policy.py:52-111                   value MLP 512-256-128-1 with LayerNorm; act / evaluate_actions / get_value
+  RL/models/action_heads_module.py:25-329      12 autoregressive heads, masked categoricals, recurrent resource heads
+  RL/distributions.py:10-40                    logits = linear(x) + log(mask); entropy with p<=0 -> 1
+
+Nothing here is copied: it is a from-scratch module tree whose *parameter names and shapes* equal the reference's
+`state_dict` (the names are the checkpoint interface), so `load_state_dict(reference_sd, strict=False)` works and the
+parity test can compare against the reference net with identical weights.  Differences by design:
+  * inputs are the flat tensors the HIP encoder writes (obs float[B,1787], card-id lists int[B,5,25] + lengths, masks
+    float[B,325]) instead of per-game Python dicts/lists; dev-card lists are fixed-pad 25 with a length mask;
+  * actions are one int64 tensor [B,18] (heads 7/8 are 4-long sequences), see spec.ACTION_HEAD_SLICES;
+  * the linears run under bf16 autocast on the GPU (MFMA via hipBLASLt); softmax/log-prob math stays fp32.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import spec
+
+T_SETTLE, T_ROAD, T_CITY, T_BUYDEV, T_PLAYDEV, T_EXCHANGE, T_PROPOSE, T_RESPOND, T_ROBBER, T_ROLL, T_ENDTURN, T_STEAL, T_DISCARD = range(13)
+C_YOP, C_MONO = 2, 4
+MO = spec.MASK_OFFSETS
+
+
+def _ortho_linear(i, o, gain=math.sqrt(2)):
+    lin = nn.Linear(i, o)
+    nn.init.orthogonal_(lin.weight, gain=gain)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+class _MHA(nn.Module):
+    """qkv_nets.{0,1,2} + out_proj_net (reference multi_headed_attention.py:21-22)."""
+
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads, self.hd = heads, dim // heads
+        self.qkv_nets = nn.ModuleList([nn.Linear(dim, dim) for _ in range(3)])
+        self.out_proj_net = nn.Linear(dim, dim)
+
+    def forward(self, x, key_mask=None):
+        B, L, D = x.shape
+        w = torch.cat([n.weight for n in self.qkv_nets], 0)
+        b = torch.cat([n.bias for n in self.qkv_nets], 0)
+        q, k, v = F.linear(x, w, b).view(B, L, 3, self.heads, self.hd).permute(2, 0, 3, 1, 4)
+        am = None if key_mask is None else key_mask[:, None, None, :]
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=am)
+        return self.out_proj_net(o.transpose(1, 2).reshape(B, L, D))
+
+
+class _FFN(nn.Module):
+    def __init__(self, dim, mult):
+        super().__init__()
+        self.linear1 = _ortho_linear(dim, mult * dim)
+        self.linear2 = _ortho_linear(mult * dim, dim)
+
+    def forward(self, x):
+        return self.linear2(F.relu(self.linear1(x)))
+
+
+class _SubLayer(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.sublayers = nn.ModuleList([_SubLayer(dim), _SubLayer(dim)])
+        self.multi_headed_attention = _MHA(dim, heads)
+        self.pointwise_net = _FFN(dim, 2)
+
+    def forward(self, x):
+        x = x + self.multi_headed_attention(self.sublayers[0].norm(x))
+        return x + self.pointwise_net(self.sublayers[1].norm(x))
+
+
+class _TileEncoder(nn.Module):
+    def __init__(self, in_dim=60, dim=64, heads=4, layers=2, out_dim=25):
+        super().__init__()
+        self.first_layer = _ortho_linear(in_dim, dim)
+        self.encoder_layers = nn.ModuleList([_EncoderLayer(dim, heads) for _ in range(layers)])
+        self.norm = nn.LayerNorm(out_dim)
+        self.norm_2 = nn.LayerNorm(dim)
+        self.out_proj = _ortho_linear(dim, out_dim)
+
+    def forward(self, tiles):
+        x = F.relu(self.norm_2(self.first_layer(tiles)))
+        for layer in self.encoder_layers:
+            x = layer(x)
+        return F.relu(self.norm(self.out_proj(x)).reshape(tiles.shape[0], -1))
+
+
+def _card_summary(ids, lens, embedding, mha, norm):
+    """masked attention over a padded card-id list, zero the padding, sum (player_modules.py:55-69)."""
+    L = ids.shape[1]
+    valid = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
+    rep = norm(mha(embedding(ids), key_mask=valid))
+    return (rep * valid[..., None].to(rep.dtype)).sum(1)
+
+
+class _CurrentPlayer(nn.Module):
+    def __init__(self, in_dim=152, card_dim=16, proj=25):
+        super().__init__()
+        self.main_input_layer_1 = _ortho_linear(in_dim, 256)
+        self.norm = nn.LayerNorm(card_dim)
+        self.norm_1 = nn.LayerNorm(256)
+        self.norm_2 = nn.LayerNorm(proj)
+        self.norm_3 = nn.LayerNorm(proj)
+        self.norm_4 = nn.LayerNorm(128)
+        self.proj_hidden_dev_card = _ortho_linear(card_dim, proj)
+        self.proj_played_dev_card = _ortho_linear(card_dim, proj)
+        self.final_linear_layer = _ortho_linear(2 * proj + 256, 128)
+
+    def forward(self, main, hid, hid_len, played, played_len, emb, hid_mha, played_mha):
+        h = F.relu(self.norm_2(self.proj_hidden_dev_card(_card_summary(hid, hid_len, emb, hid_mha, self.norm))))
+        p = F.relu(self.norm_3(self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm))))
+        m = F.relu(self.norm_1(self.main_input_layer_1(main)))
+        return F.relu(self.norm_4(self.final_linear_layer(torch.cat((m, p, h), -1))))
+
+
+class _OtherPlayers(nn.Module):
+    def __init__(self, in_dim=159, card_dim=16, proj=25):
+        super().__init__()
+        self.main_input_layer_1 = _ortho_linear(in_dim, 256)
+        self.proj_played_dev_card = _ortho_linear(card_dim, proj)
+        self.final_linear_layer = _ortho_linear(proj + 256, 128)
+        self.norm = nn.LayerNorm(card_dim)
+        self.norm_1 = nn.LayerNorm(256)
+        self.norm_2 = nn.LayerNorm(proj)
+        self.norm_3 = nn.LayerNorm(128)
+
+    def forward(self, main, played, played_len, emb, played_mha):
+        p = F.relu(self.norm_2(self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm))))
+        m = F.relu(self.norm_1(self.main_input_layer_1(main)))
+        return F.relu(self.norm_3(self.final_linear_layer(torch.cat((m, p), -1))))
+
+
+class _ObservationModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.dev_card_embedding = nn.Embedding(6, 16)
+        self.hidden_card_mha = _MHA(16, 4)
+        self.played_card_mha = _MHA(16, 4)
+        self.tile_encoder = _TileEncoder()
+        self.current_player_module = _CurrentPlayer()
+        self.other_players_module = _OtherPlayers()
+        self.final_layer = _ortho_linear(19 * 25 + 4 * 128, 512)
+        self.norm = nn.LayerNorm(512)
+
+    def forward(self, obs_f, lists, lens):
+        o = spec.OBS_FLOAT_OFFSETS
+        B = obs_f.shape[0]
+        tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
+        cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
+        lists = lists.long()
+        parts = [self.tile_encoder(tiles),
+                 self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
+                                            self.hidden_card_mha, self.played_card_mha)]
+        # the three opponents share one module: run them as one batch of 3B rows
+        k0 = o["next_player_main"]
+        others = obs_f[:, k0:k0 + 3 * 159].reshape(B * 3, 159)
+        op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
+                                       self.dev_card_embedding, self.played_card_mha)
+        parts.append(op.reshape(B, 3 * 128))
+        return F.relu(self.norm(self.final_layer(torch.cat(parts, -1))))
+
+
+class _Dist(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.linear = _ortho_linear(i, o, gain=0.01)
+
+
+class _Head(nn.Module):
+    """mlp_1 -> LayerNorm -> ReLU -> mlp_2 -> distribution.linear (action_heads_module.py:202-228)."""
+
+    def __init__(self, in_dim, out_dim, custom_in=0, custom_out=0):
+        super().__init__()
+        if custom_in:
+            self.custom_mlp = nn.Linear(custom_in, custom_out)
+            self.custom_norm = nn.LayerNorm(custom_out)
+        self.mlp_1 = nn.Linear(in_dim + custom_out, 128)
+        self.mlp_2 = nn.Linear(128, 128)
+        self.norm = nn.LayerNorm(128)
+        self.distribution = _Dist(128, out_dim)
+
+    def logits(self, x, custom=None):
+        if custom is not None:
+            x = torch.cat((x, F.relu(self.custom_norm(self.custom_mlp(custom)))), -1)
+        return self.distribution.linear(self.mlp_2(F.relu(self.norm(self.mlp_1(x))))).float()
+
+
+def _masked_logp(logits, mask):
+    """log-softmax of logits + log(mask) (distributions.py:35-38)."""
+    return F.log_softmax(logits + torch.log(mask), dim=-1)
+
+
+def _entropy(logp):
+    p = logp.exp()
+    return -(p * torch.where(p > 0, logp, torch.zeros_like(logp))).sum(-1)      # p <= 0 -> contributes 0 (distributions.py:18-20)
+
+
+def _choose(logp, given, deterministic, generator):
+    if given is not None:
+        return given
+    if deterministic:
+        return logp.argmax(-1)
+    return torch.multinomial(logp.exp(), 1, generator=generator).squeeze(-1)
+
+
+class _ActionHeads(nn.Module):
+    def __init__(self):
+        super().__init__()
+        D = 512
+        self.action_heads = nn.ModuleList([
+            _Head(D, 13), _Head(D + 2, 54), _Head(D, 73), _Head(D, 19), _Head(D, 5),
+            _Head(D, 2, custom_in=12, custom_out=32), _Head(D + 2, 3), _Head(D + 6, 6), _Head(D + 6 + 6, 6),
+            _Head(D + 4, 5), _Head(D + 4 + 5, 5), _Head(D, 5)])
+
+    def _recurrent(self, head, x, cur_res, from_hand, acts, deterministic, generator):
+        """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask."""
+        B = x.shape[0]
+        out = torch.zeros(B, 6, device=x.device, dtype=torch.float32)
+        res = cur_res.clone()
+        mask = (res > 0).float() if from_hand else torch.ones_like(res)
+        mask[:, 0] = (res.sum(-1) == 0).float()
+        logp_sum = torch.zeros(B, device=x.device)
+        ent_sum = torch.zeros(B, device=x.device)
+        chosen = []
+        for i in range(4):
+            lp = _masked_logp(head.logits(torch.cat((x, out.to(x.dtype)), -1)), mask)
+            a = _choose(lp, None if acts is None else acts[:, i], deterministic, generator)
+            step_lp = lp.gather(-1, a[:, None]).squeeze(-1)
+            ent = _entropy(lp)
+            onehot = F.one_hot(a, 6).float()
+            out = out + onehot
+            res = torch.clamp(res - onehot, min=0)
+            mask = (res > 0).float() if from_hand else torch.ones_like(res)
+            mask[:, 0] = 1.0
+            if i > 0:
+                keep = (chosen[-1] > 0).float()
+                step_lp, ent = step_lp * keep, ent * keep
+            logp_sum, ent_sum = logp_sum + step_lp, ent_sum + ent
+            chosen.append(a)
+            out = out * torch.tensor([0., 1, 1, 1, 1, 1], device=x.device)
+        return out, torch.stack(chosen, 1), logp_sum, ent_sum
+
+    def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None):
+        """main [B,512]; masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.
+        -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
+        B, dev = main.shape[0], main.device
+        H = self.action_heads
+        given = (lambda i: None) if actions is None else (lambda i: actions[:, i])
+        m = masks
+        out = torch.zeros(B, 18, dtype=torch.int64, device=dev)
+        one = torch.ones(B, device=dev)
+
+        def run(head, x, mask, idx, count, custom=None):
+            lp = _masked_logp(head.logits(x, custom), mask)
+            a = _choose(lp, given(idx), deterministic, generator)
+            return a, lp.gather(-1, a[:, None]).squeeze(-1) * count, (count * _entropy(lp)).mean()
+
+        # head 0: action type
+        typ, logp, entropy = run(H[0], main, m[:, MO[0]:MO[0] + 13], 0, one)
+        out[:, 0] = typ
+        is_ = lambda t: (typ == t).float()
+        # head 1: corner, conditioned on (settlement, city); mask row by type (build_agent_model.py:113-115)
+        row = torch.where(typ == T_SETTLE, 0, torch.where(typ == T_CITY, 1, 2))
+        cm = m[:, MO[1]:MO[1] + 162].reshape(B, 3, 54).gather(1, row[:, None, None].expand(B, 1, 54)).squeeze(1)
+        x = torch.cat((main, torch.stack((is_(T_SETTLE), is_(T_CITY)), -1).to(main.dtype)), -1)
+        a, lp, e = run(H[1], x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); out[:, 1] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(H[2], main, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); out[:, 2] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(H[3], main, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); out[:, 3] = a; logp = logp + lp; entropy = entropy + e
+        card, lp, e = run(H[4], main, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); out[:, 4] = card; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(H[5], main, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); out[:, 5] = a; logp = logp + lp; entropy = entropy + e
+        # head 6: relative player, conditioned on (propose, steal)
+        row = torch.where(typ == T_PROPOSE, 0, torch.where(typ == T_STEAL, 1, 2))
+        pm = m[:, MO[6]:MO[6] + 9].reshape(B, 3, 3).gather(1, row[:, None, None].expand(B, 1, 3)).squeeze(1)
+        x = torch.cat((main, torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1).to(main.dtype)), -1)
+        a, lp, e = run(H[6], x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); out[:, 6] = a; logp = logp + lp; entropy = entropy + e
+        # heads 7 / 8: recurrent give / receive resource lists
+        prop = is_(T_PROPOSE)
+        give_out, give_a, lp7, e7 = self._recurrent(H[7], main, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
+        lp7 = lp7 * prop
+        out[:, 7:11] = give_a; logp = logp + lp7; entropy = entropy + (e7 * prop).mean()
+        filt7 = (lp7 == 0).float()                                               # action_heads_module.py:175
+        x8 = torch.cat((main, (give_out * (1 - filt7)[:, None]).to(main.dtype)), -1)
+        _, recv_a, lp8, e8 = self._recurrent(H[8], x8, cur_res, False, None if actions is None else actions[:, 11:15], deterministic, generator)
+        out[:, 11:15] = recv_a; logp = logp + lp8 * prop; entropy = entropy + (e8 * prop).mean()
+        # heads 9 / 10: resource A / B, conditioned on (play dev, exchange) and on the card (YoP, Monopoly)
+        playdev = typ == T_PLAYDEV
+        tcond = torch.stack((is_(T_PLAYDEV), is_(T_EXCHANGE)), -1)
+        ccond = torch.stack(((card == C_YOP).float(), (card == C_MONO).float()), -1) * playdev.float()[:, None]   # filtered when head 4 is masked out
+        m9 = m[:, MO[9]:MO[9] + 20].reshape(B, 4, 5)
+        row_t = torch.where(typ == T_EXCHANGE, 0, 1)
+        row_c = torch.where(card == C_MONO, 2, torch.where(card == C_YOP, 3, 1))
+        mask_t = m9.gather(1, row_t[:, None, None].expand(B, 1, 5)).squeeze(1)
+        mask_c = m9.gather(1, row_c[:, None, None].expand(B, 1, 5)).squeeze(1)
+        mask9 = mask_t * torch.where(playdev[:, None], mask_c, torch.ones_like(mask_c))
+        cnt9 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, ((card == C_YOP) | (card == C_MONO)).float(), one)
+        x = torch.cat((main, tcond.to(main.dtype), ccond.to(main.dtype)), -1)
+        ra, lp, e = run(H[9], x, mask9, 15, cnt9); out[:, 15] = ra; logp = logp + lp; entropy = entropy + e
+        cnt10 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, (card == C_YOP).float(), one)
+        x = torch.cat((x, (F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]).to(main.dtype)), -1)
+        a, lp, e = run(H[10], x, m[:, MO[10]:MO[10] + 5], 16, cnt10); out[:, 16] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(H[11], main, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); out[:, 17] = a; logp = logp + lp; entropy = entropy + e
+        return out, logp, entropy
+
+
+class CatanPolicy(nn.Module):
+    """SettlersAgentPolicy (RL/models/policy.py:12-111) for flat batched inputs."""
+
+    VALUE_MEAN, VALUE_STD = 150.0, 150.0          # ValueFunctionNormaliser(mean=150, std=150), policy.py:23
+    include_lstm = False
+    use_value_normalisation = True
+
+    def __init__(self):
+        super().__init__()
+        self.observation_module = _ObservationModule()
+        self.action_head_module = _ActionHeads()
+        self.value_network_fc_1 = nn.Linear(512, 256)
+        self.value_network_fc_2 = nn.Linear(256, 128)
+        self.value_out = nn.Linear(128, 1)
+        self.v_norm_1 = nn.LayerNorm(256)
+        self.v_norm_2 = nn.LayerNorm(128)
+
+    # ---- pieces
+    def base(self, obs_f, lists, lens):
+        main = self.observation_module(obs_f, lists, lens)
+        v = self.value_out(F.relu(self.v_norm_2(self.value_network_fc_2(F.relu(self.v_norm_1(self.value_network_fc_1(main)))))))
+        return v.float(), main
+
+    @staticmethod
+    def _custom(obs_f):
+        return obs_f[:, 12:18].float(), obs_f[:, 0:12].float()      # current_resources, proposed_trade
+
+    # ---- reference-shaped API
+    def act(self, obs_f, lists, lens, masks, deterministic=False, generator=None):
+        value, main = self.base(obs_f, lists, lens)
+        cur_res, trade = self._custom(obs_f)
+        actions, logp, _ = self.action_head_module(main, masks.float(), cur_res, trade, None, deterministic, generator)
+        return value, actions, logp[:, None]
+
+    def evaluate_actions(self, obs_f, lists, lens, masks, actions):
+        value, main = self.base(obs_f, lists, lens)
+        cur_res, trade = self._custom(obs_f)
+        _, logp, entropy = self.action_head_module(main, masks.float(), cur_res, trade, actions)
+        return value, logp[:, None], entropy
+
+    def get_value(self, obs_f, lists, lens):
+        return self.base(obs_f, lists, lens)[0]
+
+    def denormalise(self, v):
+        return self.VALUE_MEAN + v * self.VALUE_STD          # RL/models/utils.py:20-21
+
+    def load_reference_state_dict(self, sd):
+        """Loads a reference `SettlersAgentPolicy.state_dict()` (same parameter names; the reference's empty
+        `dummy_param` entries and the value normaliser constants are ignored)."""
+        own = self.state_dict()
+        filt = {k: v for k, v in sd.items() if k in own}
+        missing = [k for k in own if k not in filt]
+        if missing:
+            raise KeyError(f"reference state_dict lacks {missing[:5]} ...")
+        self.load_state_dict(filt, strict=True)
