@@ -1,0 +1,197 @@
+"""Batched on-device rollout collection with the reference's active-seat bookkeeping.
+
+Replaces `GamesAndPoliciesManager.gather_rollouts` / `_after_rollouts` / `reset` (reference RL/ppo/game_manager.py:35-59,
+69-150) and the worker/pipe layer above it (RL/ppo/vec_gather_experience.py) by one lock-step device loop over all games:
+every iteration encodes the observation of each game's deciding player (k_obs), runs the policy of that seat, steps
+all games (k_step) and updates the per-game bookkeeping with vectorised tensor ops.  Only the decisions of each game's
+ACTIVE seat (the seat mapped to the central policy) are stored; rewards are accumulated across the other seats' moves.
+
+The bookkeeping restates game_manager.py line by line (including its quirks, see comments) with four per-game counters
+instead of Python lists: n_obs (observations), n_msk (terminal masks), n_act (actions / log-probs / action masks) and
+n_rew (rewards).  A game is frozen (no-op actions) once it holds T+1 observations, until the slowest game catches up.
+Storage is written directly in the `(T+1, N, ...)` layout of `BatchProcessor.process_rollouts`
+(RL/ppo/process_batch.py:37-104), so no restacking is needed.
+
+The env is duck-typed (`n`, `device`, `deciding_player`, `get_obs`, `get_action_masks`, `step` with auto-reset and
+no-op for type < 0): `env.VecCatanEnv` on the GPU; the CPU tests use an oracle-backed stand-in.
+"""
+import torch
+
+from . import spec
+
+
+class RolloutStorage(object):
+    """The tensors `BatchProcessor` holds after `process_rollouts` (process_batch.py:37-104), device resident."""
+
+    def __init__(self, T, N, device, obs_dtype=torch.float32):
+        self.T, self.N = T, N
+        self.obs_f = torch.zeros((T + 1, N, spec.OBS_FLOATS), dtype=obs_dtype, device=device)
+        self.lists = torch.zeros((T + 1, N, 5, spec.OBS_LIST_PAD), dtype=torch.int8, device=device)
+        self.lens = torch.ones((T + 1, N, 5), dtype=torch.int8, device=device)
+        self.masks = torch.ones((T + 2, N), dtype=torch.float32, device=device)      # terminal masks (one spare slot, see reset quirk)
+        self.rewards = torch.zeros((T + 2, N), dtype=torch.float32, device=device)
+        self.actions = torch.zeros((T, N, spec.ACTION_WORDS), dtype=torch.int64, device=device)
+        self.action_log_probs = torch.zeros((T, N), dtype=torch.float32, device=device)
+        self.action_masks = torch.zeros((T, N, 11), dtype=torch.int32, device=device)   # packed 325-bit masks
+        self.games_complete = 0
+
+    def unpack_action_masks(self, packed):
+        """int32 [..., 11] -> float32 [..., 325]"""
+        bits = (packed[..., None] >> torch.arange(32, device=packed.device, dtype=torch.int32)) & 1
+        return bits.reshape(packed.shape[:-1] + (352,))[..., :spec.MASK_WORDS].float()
+
+
+def pack_action_masks(m):
+    """float [N,325] -> int32 [N,11] (bit i of the flat mask -> word i>>5, bit i&31)"""
+    N = m.shape[0]
+    b = torch.zeros((N, 352), dtype=torch.int64, device=m.device)
+    b[:, :spec.MASK_WORDS] = (m > 0).long()
+    w = (b.reshape(N, 11, 32) << torch.arange(32, device=m.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).int()
+
+
+class RolloutCollector(object):
+    def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None):
+        """policy: central net (policy 0); opponents: list of up to 3 nets for policies 1..3 (None = every seat plays
+        the central policy, i.e. true self-play - a documented deviation from the reference's league opponents)."""
+        self.env, self.policy, self.T = env, policy, num_steps
+        self.opponents = opponents or []
+        self.N, self.device = env.n, env.device
+        self.autocast_dtype = autocast_dtype
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        # game_manager.py:24-31: a random seat order per game; order[0] is the active player, order[j] plays policy j
+        perm = torch.stack([torch.randperm(4, generator=g) for _ in range(self.N)])        # [N,4] pid0 per policy slot
+        self.policy_of_pid = torch.empty((self.N, 4), dtype=torch.int64)
+        self.policy_of_pid.scatter_(1, perm, torch.arange(4).expand(self.N, 4))
+        self.policy_of_pid = self.policy_of_pid.to(self.device)
+        self.active_pid = (perm[:, 0] + 1).to(self.device)                                  # PlayerId 1..4
+        self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
+        self.storage = RolloutStorage(num_steps, self.N, self.device)
+        self.reset()
+
+    # game_manager.py:35-59 (the env itself is already reset: EnvWrapper.reset() happened in catan_create / env.reset())
+    def reset(self):
+        N, dev, st = self.N, self.device, self.storage
+        self.n_obs = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.n_msk = torch.ones(N, dtype=torch.int64, device=dev)                           # terminal_masks = [1.0]
+        self.n_act = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.n_rew = torch.zeros(N, dtype=torch.int64, device=dev)
+        st.masks[0] = 1.0
+        self.pending_obs = self.env.deciding_player().long() == self.active_pid             # observations = [obs] iff the active seat moves first
+        self.done_since = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.racc = torch.zeros((N, 4), dtype=torch.float32, device=dev)
+
+    def _store_obs(self, sel, f, lists, lens):
+        st = self.storage
+        idx = sel.nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
+            return
+        t = self.n_obs[idx]
+        st.obs_f[t, idx] = f[idx].to(st.obs_f.dtype)
+        st.lists[t, idx] = lists[idx].to(torch.int8)
+        st.lens[t, idx] = lens[idx].to(torch.int8)
+        self.n_obs[idx] += 1
+
+    @torch.no_grad()
+    def gather_rollouts(self, max_iters=None):
+        """game_manager.py:69-140.  Returns the storage (first T(+1) entries per game are the rollout)."""
+        env, st, T, N, dev = self.env, self.storage, self.T, self.N, self.device
+        ar = torch.arange(N, device=dev)
+        self.racc.zero_()                        # `rewards = {...: 0}` at the start of every gather call (:76)
+        self.done_since.zero_()                  # `done_since_prev_turn = [False ...]` (:77)
+        iters = 0
+        while True:
+            f, lists, lens = env.get_obs()
+            # an observation produced by the previous step for the active seat (:126-133) - or the carried one
+            self._store_obs(self.pending_obs & (self.n_obs < T + 1), f, lists, lens)
+            self.pending_obs = torch.zeros(N, dtype=torch.bool, device=dev)
+            frozen = self.n_obs >= T + 1                                                    # while len(observations) < T+1 (:78)
+            if bool(frozen.all()) or (max_iters is not None and iters >= max_iters):
+                break
+            iters += 1
+            deciding = env.deciding_player().long()                                         # :79
+            masks = env.get_action_masks()                                                  # :83
+            pol = self.policy_of_pid[ar, deciding - 1]
+            actions, logp = self._act(f, lists, lens, masks, pol)                           # :85
+            a_env = actions.t().contiguous().to(torch.int32)
+            a_env[0] = torch.where(frozen, torch.full_like(a_env[0], -1), a_env[0])         # frozen games: no-op
+            reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
+            live = ~frozen
+            done = done.bool() & live
+            self.racc += reward.t() * live[:, None]                                         # :94-95
+            was_active = (deciding == self.active_pid) & live
+            idx = was_active.nonzero(as_tuple=True)[0]                                      # :102-105
+            if idx.numel():
+                t = self.n_act[idx]
+                st.actions[t, idx] = actions[idx]
+                st.action_log_probs[t, idx] = logp[idx]
+                st.action_masks[t, idx] = pack_action_masks(masks[idx])
+                self.n_act[idx] += 1
+            n_deciding = env.deciding_player().long()                                       # after the step (and the reset)
+            next_active = (n_deciding == self.active_pid) & live
+            r_active = self.racc[ar, self.active_pid - 1]
+            # :106-110 (not done: uses the post-step deciding player) and :112-118 (done: exactly one reward is appended)
+            app = torch.where(done, torch.ones_like(done), next_active & (self.n_act > 0) & ~self.done_since) & live
+            idx = app.nonzero(as_tuple=True)[0]
+            if idx.numel():
+                st.rewards[self.n_rew[idx].clamp(max=T + 1), idx] = r_active[idx]
+                self.n_rew[idx] += 1
+                self.racc[idx, self.active_pid[idx] - 1] = 0.0
+            idx = done.nonzero(as_tuple=True)[0]                                            # :112-124
+            if idx.numel():
+                st.masks[self.n_msk[idx].clamp(max=T + 1), idx] = 0.0
+                self.n_msk[idx] += 1
+                self.done_since[idx] = False
+                self.racc[idx] = 0.0
+                st.games_complete += int(idx.numel())
+            # :128-136
+            add_mask = next_active & ~done & ~self.done_since
+            idx = add_mask.nonzero(as_tuple=True)[0]
+            if idx.numel():
+                st.masks[self.n_msk[idx].clamp(max=T + 1), idx] = 1.0
+                self.n_msk[idx] += 1
+            self.done_since = torch.where(next_active, torch.zeros_like(self.done_since),
+                                          torch.where(done & live, torch.ones_like(self.done_since), self.done_since))
+            self.pending_obs = next_active
+        self.iters = iters
+        return st
+
+    def _act(self, f, lists, lens, masks, pol):
+        nets = [self.policy] + list(self.opponents)
+        N = f.shape[0]
+        actions = torch.zeros((N, spec.ACTION_WORDS), dtype=torch.int64, device=f.device)
+        logp = torch.zeros((N,), dtype=torch.float32, device=f.device)
+        if len(nets) == 1:
+            groups = [(None, nets[0])]
+        else:
+            groups = [((pol == k).nonzero(as_tuple=True)[0], nets[min(k, len(nets) - 1)]) for k in range(4)]
+        for idx, net in groups:
+            if idx is not None and idx.numel() == 0:
+                continue
+            args = (f, lists, lens, masks) if idx is None else (f[idx], lists[idx], lens[idx], masks[idx])
+            if self.autocast_dtype is not None:
+                with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+                    _, a, lp = net.act(*args, generator=self.sample_gen)
+            else:
+                _, a, lp = net.act(*args, generator=self.sample_gen)
+            if idx is None:
+                actions, logp = a, lp[:, 0]
+            else:
+                actions[idx] = a
+                logp[idx] = lp[:, 0]
+        return actions, logp
+
+    # game_manager.py:142-150
+    def after_rollouts(self):
+        st, T, N = self.storage, self.T, self.N
+        ar = torch.arange(N, device=self.device)
+        last_t = (self.n_obs - 1).clamp(min=0)
+        st.obs_f[0] = st.obs_f[last_t, ar]
+        st.lists[0] = st.lists[last_t, ar]
+        st.lens[0] = st.lens[last_t, ar]
+        st.masks[0] = st.masks[(self.n_msk - 1).clamp(min=0, max=T + 1), ar]
+        had_obs = self.n_obs > 0
+        self.n_obs = had_obs.long()
+        self.n_msk = torch.ones_like(self.n_msk)
+        self.n_act.zero_()
+        self.n_rew.zero_()

@@ -1,0 +1,106 @@
+"""PPO update on device: the loop of `PPO.update` (reference RL/ppo/ppo.py:25-79) over the storage written by
+`rollout.RolloutCollector`, with the reference's defaults (RL/ppo/arguments.py:4-116).
+
+Per epoch (ppo.py:30-32, recompute_returns): values of all (T+1)*N stored observations are re-evaluated in chunks
+(process_batch.py:108-132), GAE + advantage normalisation run on the HIP kernels (ppo.compute_gae; global statistics
+over ranks), then `num_mini_batch` random minibatches of T*N // num_mini_batch rows (process_batch.py:169-200):
+evaluate_actions -> fused PPO loss kernel (fwd+bwd) -> gradient all-reduce (one flat bucket over RCCL when N>1 ranks)
+-> clip_grad_norm_(0.5) -> Adam.  The network runs under bf16 autocast on the GPU.
+"""
+import time
+
+import torch
+
+from . import dist as cdist
+from . import ppo as ppo_kernels
+
+
+class PPOConfig(object):
+    # RL/ppo/arguments.py defaults
+    lr = 3e-4
+    eps = 1e-5
+    gamma = 0.999
+    gae_lambda = 0.95
+    clip_param = 0.2
+    ppo_epoch = 10
+    num_mini_batch = 64
+    value_loss_coef = 1.0
+    entropy_coef = 0.04
+    max_grad_norm = 0.5
+    value_chunk = 262144
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+class PPOTrainer(object):
+    def __init__(self, policy, cfg=None, autocast_dtype=torch.bfloat16, seed=0):
+        self.policy, self.cfg = policy, cfg or PPOConfig()
+        self.autocast_dtype = autocast_dtype
+        self.optimiser = torch.optim.Adam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)   # ppo.py:23
+        dev = next(policy.parameters()).device
+        self.gen = torch.Generator(device=dev).manual_seed(seed + 17 * (1 + (torch.distributed.get_rank()
+                                                                         if torch.distributed.is_initialized() else 0)))
+        self.timings = {}
+
+    def _autocast(self):
+        if self.autocast_dtype is None:
+            return torch.autocast(device_type="cuda", enabled=False)
+        return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
+
+    @torch.no_grad()
+    def compute_values(self, st):
+        """process_batch.py:108-132: V(obs) for all (T+1)*N observations, denormalised (RL/models/utils.py:20-21)."""
+        T1, N = st.obs_f.shape[0], st.obs_f.shape[1]
+        f = st.obs_f.reshape(T1 * N, -1); lists = st.lists.reshape(T1 * N, 5, -1); lens = st.lens.reshape(T1 * N, 5)
+        out = torch.empty((T1 * N,), dtype=torch.float32, device=f.device)
+        ch = self.cfg.value_chunk
+        for s in range(0, T1 * N, ch):
+            with self._autocast():
+                v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long())
+            out[s:s + ch] = v[:, 0]
+        return self.policy.denormalise(out).reshape(T1, N)
+
+    def update(self, st):
+        """-> (value_loss, action_loss, entropy_loss) averaged over the optimiser steps, as ppo.py:70-79."""
+        cfg, pol = self.cfg, self.policy
+        T, N = st.T, st.N
+        dev = st.obs_f.device
+        total = T * N
+        mbs = total // cfg.num_mini_batch
+        f_all = st.obs_f[:T].reshape(total, -1); lists_all = st.lists[:T].reshape(total, 5, -1); lens_all = st.lens[:T].reshape(total, 5)
+        acts_all = st.actions.reshape(total, -1); amask_all = st.action_masks.reshape(total, -1)
+        old_lp_all = st.action_log_probs.reshape(total)
+        rewards = st.rewards[:T].contiguous(); masks = st.masks[:T + 1].contiguous()
+        vl_sum = al_sum = ent_sum = 0.0
+        t_val = t_gae = t_opt = 0.0
+        for _ in range(cfg.ppo_epoch):
+            t0 = time.perf_counter()
+            values = self.compute_values(st)                                               # ppo.py:31-32
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            returns, adv = ppo_kernels.compute_gae(rewards, values, masks, cfg.gamma, cfg.gae_lambda)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            vpred = values[:T].reshape(total); ret = returns.reshape(total); advf = adv.reshape(total)
+            perm = torch.randperm(total, generator=self.gen, device=dev)                   # SubsetRandomSampler
+            for mb in range(cfg.num_mini_batch):                                           # BatchSampler(drop_last=True)
+                idx = perm[mb * mbs:(mb + 1) * mbs]
+                with self._autocast():
+                    v, lp, ent = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
+                                                      st.unpack_action_masks(amask_all[idx]), acts_all[idx])
+                loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
+                                                   cfg.clip_param, cfg.value_loss_coef,
+                                                   value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
+                self.optimiser.zero_grad(set_to_none=True)
+                (loss - ent * cfg.entropy_coef).backward()                                 # ppo.py:66
+                cdist.allreduce_flat_grads([p for p in pol.parameters()])                  # one RCCL all-reduce per step
+                torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
+                self.optimiser.step()
+                al_sum += float(parts[0]); vl_sum += float(parts[1]) * cfg.value_loss_coef; ent_sum += float(ent) * cfg.entropy_coef
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2
+        n = cfg.ppo_epoch * cfg.num_mini_batch
+        self.timings = {"values_s": t_val, "gae_s": t_gae, "minibatches_s": t_opt}
+        return vl_sum / n, al_sum / n, ent_sum / n

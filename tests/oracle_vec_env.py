@@ -1,0 +1,71 @@
+"""CPU stand-in for VecCatanEnv over the oracle (test infrastructure): same duck-typed interface, torch CPU tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_lib
+
+
+class OracleVecEnv(object):
+    def __init__(self, n, seed=0, env_id0=0):
+        self.n, self.seed, self.env_id0 = n, seed, env_id0
+        self.device = torch.device("cpu")
+        self.b = oracle_lib.OracleBatch(n, seed, env_id0)
+        self.L = self.b.L
+        self.steps_taken = np.zeros(n, dtype=np.int64)
+
+    def advance_random(self, steps):
+        self.b.run_random(steps, want_blobs=False)
+
+    def deciding_player(self):
+        return torch.tensor([self.L.orc_deciding_player(self.b.env_ptr(i)) for i in range(self.n)], dtype=torch.int32)
+
+    def get_obs(self):
+        n = self.n
+        f = np.zeros((n, 1787), dtype=np.float32); lists = np.zeros((n, 5, 25), dtype=np.int32)
+        lens = np.zeros((n, 5), dtype=np.int32); pid = np.zeros((1,), dtype=np.int32)
+        for i in range(n):
+            self.L.orc_obs(self.b.env_ptr(i), f[i].ctypes.data_as(C.POINTER(C.c_float)), lists[i].ctypes.data_as(C.POINTER(C.c_int32)),
+                           lens[i].ctypes.data_as(C.POINTER(C.c_int32)), pid.ctypes.data_as(C.POINTER(C.c_int32)))
+        return torch.from_numpy(f), torch.from_numpy(lists), torch.from_numpy(lens)
+
+    def get_action_masks(self):
+        return torch.from_numpy(self.b.masks())
+
+    def step(self, actions):
+        a = actions.numpy().astype(np.int32)
+        rew = np.zeros((4, self.n), dtype=np.float32); done = np.zeros((self.n,), dtype=np.uint8)
+        for i in range(self.n):
+            if a[0, i] < 0:
+                continue
+            ai = np.ascontiguousarray(a[:, i]); r = np.zeros(4, dtype=np.float32); d = C.c_int(0)
+            assert self.L.orc_action_is_legal(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32))), (i, ai)
+            self.L.orc_step(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32)), r.ctypes.data_as(C.POINTER(C.c_float)), C.byref(d))
+            rew[:, i] = r; done[i] = d.value
+            self.steps_taken[i] += 1
+            if d.value:
+                self.L.orc_game_reset(self.b.env_ptr(i))
+        return torch.from_numpy(rew), torch.from_numpy(done)
+
+
+class ScriptedPolicy(object):
+    """Uniform-random legal policy keyed by (game, number of decisions that game has taken): independent of the order in
+    which games are evaluated, so a lock-step collector and a sequential one make identical decisions."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def act(self, f, lists, lens, masks, generator=None, deterministic=False, idx=None):
+        env = self.env
+        n = f.shape[0]
+        assert n == env.n
+        a = np.zeros((n, 18), dtype=np.int64)
+        for i in range(n):
+            m = np.ascontiguousarray(masks[i].numpy(), dtype=np.float32)
+            out = np.zeros(18, dtype=np.int32)
+            env.L.orc_sample_action(env.b.env_ptr(i), env.seed + 99, env.env_id0 + i, int(env.steps_taken[i]),
+                                    m.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_int32)))
+            a[i] = out
+        logp = torch.from_numpy(-(a.sum(1) % 7).astype(np.float32))[:, None]     # any deterministic stand-in for log-probs
+        return torch.zeros(n, 1), torch.from_numpy(a), logp
