@@ -65,6 +65,7 @@ int64_t catan_num_envs(const catan_env_t* env);
 int catan_reset(catan_env_t* env, const uint8_t* reset_mask, catan_stream_t stream);
 
 /* EnvWrapper.step(action): env/wrapper.py:36-50 (translate + apply + done/reward); then, per cfg, auto-reset of
+ * (a game whose action type is negative is left untouched: explicit no-op, reward 0, done 0)
  * finished games; then the next legal-action masks are refreshed (kept packed inside the handle). */
 int catan_step(catan_env_t* env, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream);
 
@@ -127,6 +128,20 @@ int catan_adv_normalise(float* adv, int64_t total, const double* stats3, catan_s
 int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, const float* values, const float* old_values,
                    const float* returns, int64_t B, float clip, float value_coef, int use_norm, float norm_mean, float norm_std,
                    float* losses2, float* d_logp, float* d_values, catan_stream_t stream);
+
+/* Fused small-sequence multi-head attention of the policy net (RL/models/multi_headed_attention.py:25-54 as used by
+ * tile_encoder.py:41-60 with L=19, 4 heads x 16 and by player_modules.py:55-69 with L<=25, 4 heads x 4).
+ * qkv [B][L][3][H][HD] (fused Q/K/V projection), out [B][L][H*HD]; float32 or bfloat16 storage (is_bf16), fp32 math;
+ * lens (int32 [B], may be NULL): keys >= lens[b] are masked.  bwd recomputes the probabilities. */
+int catan_attention_fwd(const void* qkv, const int32_t* lens, void* out, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream);
+int catan_attention_bwd(const void* qkv, const int32_t* lens, const void* dout, void* dqkv, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream);
+
+/* LayerNorm over a small last dimension D in {16, 25, 32, 64} with optional fused ReLU (the nn.LayerNorm + ReLU pairs of
+ * RL/models/tile_encoder.py:83-91, player_modules.py:26-30,114-117).  x, y, dy, dx: [rows][D] float32 or bfloat16;
+ * w, b, dw, db float32 [D]; dw/db are ACCUMULATED into (zero them first). */
+int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y, int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream);
+int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
+                         float eps, int relu, int is_bf16, catan_stream_t stream);
 
 /* k_step phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums over waves then 8
  * per-wave maxima, in 100 MHz wall-clock ticks, for the phases stage-in, validate+apply, tier-1 longest road,

@@ -11,6 +11,7 @@
 #include "catan_kernels.hip"
 #include "catan_obs.hip"
 #include "catan_ppo.hip"
+#include "catan_nn.hip"
 
 using namespace catan;
 
@@ -38,6 +39,44 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         hipError_t e_ = (x);                                                                         \
         if (e_ != hipSuccess) return fail(CATAN_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+template <class T>
+static int attn_dispatch(bool bwd, const void* qkv, const int* lens, const void* dout, void* out, long B, int L, int H, int HD, hipStream_t st) {
+    const T* q = (const T*)qkv;
+    if (L == 19 && H == 4 && HD == 16) {
+        unsigned nb = (unsigned)((B + 2) / 3);
+        if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
+        else hipLaunchKernelGGL((k_attn_bwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
+    } else if (L == 25 && H == 4 && HD == 4) {
+        unsigned nb = (unsigned)((B + 1) / 2);
+        if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
+        else hipLaunchKernelGGL((k_attn_bwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
+    } else return fail(CATAN_EINVAL, "catan_attention: unsupported (L, heads, head_dim); built for (19,4,16) and (25,4,4)");
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+template <class T, int D, int GL>
+static int ln_launch(bool bwd, const void* x, const float* w, const float* b, const void* dy, void* out, float* dw, float* db,
+                     long rows, float eps, int relu, hipStream_t st) {
+    long nb = (rows + (256 / GL) - 1) / (256 / GL);
+    const long cap = bwd ? 2048 : 8192;          // bwd ends with 2*D atomics per block: keep the grid moderate
+    if (nb > cap) nb = cap;
+    if (!bwd) hipLaunchKernelGGL((k_ln_fwd<T, D, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (T*)out, rows, eps, relu);
+    else hipLaunchKernelGGL((k_ln_bwd<T, D, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (const T*)dy, (T*)out, dw, db, rows, eps, relu);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+template <class T>
+static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, const void* dy, void* out, float* dw, float* db,
+                       long rows, int D, float eps, int relu, hipStream_t st) {
+    switch (D) {
+    case 16: return ln_launch<T, 16, 16>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 25: return ln_launch<T, 25, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 32: return ln_launch<T, 32, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 64: return ln_launch<T, 64, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    default: return fail(CATAN_EINVAL, "catan_layer_norm: unsupported width (built for 16, 25, 32, 64)");
+    }
+}
 
 extern "C" {
 
@@ -304,6 +343,29 @@ int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, c
     hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, S(stream), logp, old_logp, adv, values, old_values, returns, (long)B, a, losses2, d_logp, d_values);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
+}
+
+int catan_attention_fwd(const void* qkv, const int32_t* lens, void* out, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream) {
+    if (!qkv || !out || B <= 0) return fail(CATAN_EINVAL, "catan_attention_fwd: bad arguments");
+    return is_bf16 ? attn_dispatch<__hip_bfloat16>(false, qkv, lens, nullptr, out, B, L, H, HD, S(stream))
+                   : attn_dispatch<float>(false, qkv, lens, nullptr, out, B, L, H, HD, S(stream));
+}
+int catan_attention_bwd(const void* qkv, const int32_t* lens, const void* dout, void* dqkv, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream) {
+    if (!qkv || !dout || !dqkv || B <= 0) return fail(CATAN_EINVAL, "catan_attention_bwd: bad arguments");
+    return is_bf16 ? attn_dispatch<__hip_bfloat16>(true, qkv, lens, dout, dqkv, B, L, H, HD, S(stream))
+                   : attn_dispatch<float>(true, qkv, lens, dout, dqkv, B, L, H, HD, S(stream));
+}
+
+int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y, int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream) {
+    if (!x || !w || !b || !y || rows <= 0) return fail(CATAN_EINVAL, "catan_layer_norm_fwd: bad arguments");
+    return is_bf16 ? ln_dispatch<__hip_bfloat16>(false, x, w, b, nullptr, y, nullptr, nullptr, rows, D, eps, relu, S(stream))
+                   : ln_dispatch<float>(false, x, w, b, nullptr, y, nullptr, nullptr, rows, D, eps, relu, S(stream));
+}
+int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
+                         float eps, int relu, int is_bf16, catan_stream_t stream) {
+    if (!x || !w || !b || !dy || !dx || !dw || !db || rows <= 0) return fail(CATAN_EINVAL, "catan_layer_norm_bwd: bad arguments");
+    return is_bf16 ? ln_dispatch<__hip_bfloat16>(true, x, w, b, dy, dx, dw, db, rows, D, eps, relu, S(stream))
+                   : ln_dispatch<float>(true, x, w, b, dy, dx, dw, db, rows, D, eps, relu, S(stream));
 }
 
 // k_step phase profile (100 MHz wall_clock64 ticks): enable/zero, then read [8] sums over waves + [8] maxima.

@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
 #pragma unroll
     for (int i = 0; i < ACTION_WORDS; i++) a[i] = live ? actions[(long)i * c.n + s.e] : 0;
     int type = live ? a[0] : -1;
-    if (live && cfg.validate) {
+    if (live && cfg.validate && type >= 0) {          // a negative type is an explicit no-op (frozen game), not an error
         u32 m[MASK_WORDS];
 #pragma unroll
         for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[(long)i * c.N + s.e];

@@ -1,0 +1,235 @@
+// catan_nn.hip - fused small-sequence multi-head attention (forward + backward) for the policy net.
+//
+// The reference net attends over 19 hex tiles (4 heads x 16) and over <= 25 development cards (4 heads x 4)
+// (RL/models/tile_encoder.py:41-60, player_modules.py:55-69, multi_headed_attention.py:25-54).  As library batched GEMMs
+// these are 65 536 x 4 products of 19x16 matrices - 55-60 % of the net's time on MI355X (rocprof/torch profiler).
+// Here one wave handles G = 64 / L sequences: lane = (sequence, query row); K and V of the G sequences sit in LDS
+// (fp32), scores / softmax / PV stay in registers.  The arithmetic is a few kFLOP per sequence, so the kernels are
+// HBM-bound on the qkv read and the output write; plain VALU FMAs (no MFMA: the tiles are 19x16).
+// Layout: qkv [B][L][3][H][HD] (the fused QKV projection output), out [B][L][H*HD]; T = float or bf16 storage, fp32 math.
+// lens (optional): keys j >= lens[b] are masked (the reference's key mask); rows are computed for every query position
+// (the caller zeroes padded rows, as the reference does).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+namespace catan {
+
+template <class T> __device__ __forceinline__ float ld_f(const T* p);
+template <> __device__ __forceinline__ float ld_f<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_f<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <class T> __device__ __forceinline__ void st_f(T* p, float v);
+template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+template <class T, int L, int H, int HD>
+__global__ __launch_bounds__(64) void k_attn_fwd(const T* __restrict__ qkv, const int* __restrict__ lens, T* __restrict__ out, long B) {
+    constexpr int G = 64 / L, D = H * HD;
+    __shared__ float Ks[G][L][D + 1], Vs[G][L][D + 1];
+    const int lane = threadIdx.x, g = lane / L, i = lane % L;
+    const long b0 = (long)blockIdx.x * G;
+    // stage K, V (coalesced over the contiguous [L][3][D] block of each sequence)
+    for (int gg = 0; gg < G; gg++) {
+        const long b = b0 + gg;
+        if (b >= B) break;
+        const T* base = qkv + b * (long)(L * 3 * D);
+        for (int x = lane; x < L * D; x += 64) {
+            const int l = x / D, d = x % D;
+            Ks[gg][l][d] = ld_f(base + (l * 3 + 1) * D + d);
+            Vs[gg][l][d] = ld_f(base + (l * 3 + 2) * D + d);
+        }
+    }
+    __syncthreads();
+    const long b = b0 + g;
+    if (g >= G || b >= B) return;
+    const int len = lens ? lens[b] : L;
+    const T* qp = qkv + (b * L + i) * (long)(3 * D);
+    const float scale = rsqrtf((float)HD);
+    T* op = out + (b * L + i) * (long)D;
+    for (int h = 0; h < H; h++) {
+        float q[HD];
+#pragma unroll
+        for (int d = 0; d < HD; d++) q[d] = ld_f(qp + h * HD + d) * scale;
+        float s[L], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < HD; d++) a += q[d] * Ks[g][j][h * HD + d];
+            s[j] = j < len ? a : -INFINITY;
+            mx = fmaxf(mx, s[j]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < L; j++) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+        const float inv = 1.0f / sum;
+        float o[HD];
+#pragma unroll
+        for (int d = 0; d < HD; d++) o[d] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const float p = s[j] * inv;
+#pragma unroll
+            for (int d = 0; d < HD; d++) o[d] += p * Vs[g][j][h * HD + d];
+        }
+#pragma unroll
+        for (int d = 0; d < HD; d++) st_f(op + h * HD + d, o[d]);
+    }
+}
+
+// dqkv [B][L][3][H][HD] from dout [B][L][D]; probabilities are recomputed (no saved attention matrix)
+template <class T, int L, int H, int HD>
+__global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, const int* __restrict__ lens, const T* __restrict__ dout,
+                                                 T* __restrict__ dqkv, long B) {
+    constexpr int G = 64 / L, D = H * HD;
+    __shared__ float Qs[G][L][D + 1], Ks[G][L][D + 1], Vs[G][L][D + 1], Os[G][L][D + 1];
+    __shared__ float Ps[G][L][L + 1], Ss[G][L][L + 1];
+    const int lane = threadIdx.x, g = lane / L, i = lane % L;
+    const long b0 = (long)blockIdx.x * G;
+    for (int gg = 0; gg < G; gg++) {
+        const long b = b0 + gg;
+        if (b >= B) break;
+        const T* base = qkv + b * (long)(L * 3 * D);
+        const T* dob = dout + b * (long)(L * D);
+        for (int x = lane; x < L * D; x += 64) {
+            const int l = x / D, d = x % D;
+            Qs[gg][l][d] = ld_f(base + (l * 3 + 0) * D + d);
+            Ks[gg][l][d] = ld_f(base + (l * 3 + 1) * D + d);
+            Vs[gg][l][d] = ld_f(base + (l * 3 + 2) * D + d);
+            Os[gg][l][d] = ld_f(dob + l * D + d);
+        }
+    }
+    __syncthreads();
+    const long b = b0 + g;
+    const bool act = g < G && b < B;
+    const int len = act ? (lens ? lens[b] : L) : 0;
+    const float scale = rsqrtf((float)HD);
+    T* dp = dqkv + (b * L + i) * (long)(3 * D);
+    for (int h = 0; h < H; h++) {
+        if (act) {
+            float s[L], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < HD; d++) a += Qs[g][i][h * HD + d] * Ks[g][j][h * HD + d];
+                s[j] = j < len ? a * scale : -INFINITY;
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < L; j++) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+            const float inv = 1.0f / sum;
+            float dP[L], delta = 0.0f;
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                s[j] *= inv;
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < HD; d++) a += Os[g][i][h * HD + d] * Vs[g][j][h * HD + d];
+                dP[j] = a;
+                delta += s[j] * a;
+            }
+            float dq[HD];
+#pragma unroll
+            for (int d = 0; d < HD; d++) dq[d] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                const float ds = s[j] * (dP[j] - delta) * scale;       // d(scores)/ ... includes the 1/sqrt(hd)
+                Ps[g][i][j] = s[j];
+                Ss[g][i][j] = ds;
+#pragma unroll
+                for (int d = 0; d < HD; d++) dq[d] += ds * Ks[g][j][h * HD + d];
+            }
+#pragma unroll
+            for (int d = 0; d < HD; d++) st_f(dp + 0 * D + h * HD + d, dq[d]);
+        }
+        __syncthreads();
+        if (act) {                                   // lane (g, j = i): column sums
+            float dk[HD], dv[HD];
+#pragma unroll
+            for (int d = 0; d < HD; d++) { dk[d] = 0.0f; dv[d] = 0.0f; }
+#pragma unroll
+            for (int r = 0; r < L; r++) {
+                const float ds = Ss[g][r][i], p = Ps[g][r][i];
+#pragma unroll
+                for (int d = 0; d < HD; d++) { dk[d] += ds * Qs[g][r][h * HD + d]; dv[d] += p * Os[g][r][h * HD + d]; }
+            }
+#pragma unroll
+            for (int d = 0; d < HD; d++) { st_f(dp + 1 * D + h * HD + d, dk[d]); st_f(dp + 2 * D + h * HD + d, dv[d]); }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace catan
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over a small last dimension D <= 64 (+ optional fused ReLU), forward and backward.
+// The net normalises millions of short rows (19 tiles x 64, 25 cards x 16, 19 x 25 per game); a library LayerNorm
+// spends a workgroup per row.  Here GL = 16 / 32 / 64 lanes own one row at a time (element j of the row in lane j of the
+// group: fully coalesced, group-local shuffles for the moments) and every lane always works on the same column, so the
+// weight/bias gradients accumulate in registers and leave with one atomicAdd per lane per kernel.
+namespace catan {
+
+template <int GL>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = GL / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, GL);
+    return v;
+}
+
+template <class T, int D, int GL>
+__global__ __launch_bounds__(256) void k_ln_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                T* __restrict__ y, long rows, float eps, int relu) {
+    constexpr int RPB = 256 / GL;
+    const int j = threadIdx.x % GL, r = threadIdx.x / GL;
+    const bool col = j < D;
+    const float wj = col ? w[j] : 0.0f, bj = col ? bvec[j] : 0.0f;
+    for (long row = (long)blockIdx.x * RPB + r; row < rows; row += (long)gridDim.x * RPB) {
+        const float v = col ? ld_f(x + row * D + j) : 0.0f;
+        const float mean = group_sum<GL>(v) * (1.0f / D);
+        const float c = col ? v - mean : 0.0f;
+        const float rstd = rsqrtf(group_sum<GL>(c * c) * (1.0f / D) + eps);
+        float o = c * rstd * wj + bj;
+        if (relu) o = fmaxf(o, 0.0f);
+        if (col) st_f(y + row * D + j, o);
+    }
+}
+
+// dx, and dw/db accumulated with atomics into fp32 buffers (zeroed by the caller)
+template <class T, int D, int GL>
+__global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dw,
+                                                float* __restrict__ db, long rows, float eps, int relu) {
+    constexpr int RPB = 256 / GL;
+    const int j = threadIdx.x % GL, r = threadIdx.x / GL;
+    const bool col = j < D;
+    const float wj = col ? w[j] : 0.0f, bj = col ? bvec[j] : 0.0f;
+    float aw = 0.0f, ab = 0.0f;
+    for (long row = (long)blockIdx.x * RPB + r; row < rows; row += (long)gridDim.x * RPB) {
+        const float v = col ? ld_f(x + row * D + j) : 0.0f;
+        const float mean = group_sum<GL>(v) * (1.0f / D);
+        const float c = col ? v - mean : 0.0f;
+        const float rstd = rsqrtf(group_sum<GL>(c * c) * (1.0f / D) + eps);
+        const float xh = c * rstd;
+        float g = col ? ld_f(dy + row * D + j) : 0.0f;
+        if (relu && xh * wj + bj <= 0.0f) g = 0.0f;
+        aw += g * xh; ab += g;
+        const float gw = g * wj;
+        const float m1 = group_sum<GL>(gw) * (1.0f / D);
+        const float m2 = group_sum<GL>(gw * xh) * (1.0f / D);
+        if (col) st_f(dx + row * D + j, rstd * (gw - m1 - xh * m2));
+    }
+    // block-level reduction over the RPB row groups, then one atomic per column per block
+    __shared__ float sw[256], sb[256];
+    sw[threadIdx.x] = aw; sb[threadIdx.x] = ab;
+    __syncthreads();
+    if (threadIdx.x < GL && threadIdx.x < D) {
+        float tw = 0.0f, tb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RPB; q++) { tw += sw[q * GL + threadIdx.x]; tb += sb[q * GL + threadIdx.x]; }
+        atomicAdd(dw + threadIdx.x, tw); atomicAdd(db + threadIdx.x, tb);
+    }
+}
+
+}  // namespace catan

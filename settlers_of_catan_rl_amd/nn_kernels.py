@@ -1,0 +1,91 @@
+"""Hand-written HIP kernels used inside the (otherwise PyTorch) policy net: fused small-sequence attention
+(csrc/catan_nn.hip).  torch is plumbing: tensors, streams, autograd registration."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+SUPPORTED = {(19, 4, 16), (25, 4, 4)}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _SmallAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, lens):
+        B, L, three, H, HD = qkv.shape
+        qkv = qkv.contiguous()
+        out = torch.empty((B, L, H * HD), dtype=qkv.dtype, device=qkv.device)
+        _lib.check(_lib.lib().catan_attention_fwd(_ptr(qkv), _ptr(lens), _ptr(out), B, L, H, HD,
+                                                  int(qkv.dtype == torch.bfloat16), _stream()))
+        ctx.save_for_backward(qkv, lens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, lens = ctx.saved_tensors
+        B, L, three, H, HD = qkv.shape
+        dout = dout.contiguous().to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), _ptr(lens), _ptr(dout), _ptr(dqkv), B, L, H, HD,
+                                                  int(qkv.dtype == torch.bfloat16), _stream()))
+        return dqkv, None
+
+
+def small_attention(qkv, lens=None):
+    """qkv [B, L, 3, H, HD] (float32 or bfloat16, CUDA) -> [B, L, H*HD]; lens int32 [B] masks keys >= len."""
+    assert qkv.is_cuda and qkv.dtype in (torch.float32, torch.bfloat16) and tuple(qkv.shape[1:2] + qkv.shape[3:]) in SUPPORTED
+    if lens is not None:
+        lens = lens.to(torch.int32).contiguous()
+    return _SmallAttention.apply(qkv, lens)
+
+
+def supported(L, H, HD):
+    return (L, H, HD) in SUPPORTED
+
+
+LN_WIDTHS = {16, 25, 32, 64}
+
+
+class _SmallLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, relu):
+        D = x.shape[-1]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        rows = x.numel() // D
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        _lib.check(_lib.lib().catan_layer_norm_fwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(y), rows, D, float(eps), int(relu),
+                                                   int(x.dtype == torch.bfloat16), _stream()))
+        ctx.save_for_backward(x, wf, bf)
+        ctx.eps, ctx.relu = eps, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf, bf = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        dw = torch.zeros(D, dtype=torch.float32, device=x.device)
+        db = torch.zeros(D, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().catan_layer_norm_bwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), rows, D,
+                                                   float(ctx.eps), int(ctx.relu), int(x.dtype == torch.bfloat16), _stream()))
+        return dx, dw, db, None, None
+
+
+def small_layer_norm(x, ln, relu=False):
+    """nn.LayerNorm `ln` (normalised dim in LN_WIDTHS) applied to CUDA tensor x (float32 / bfloat16), optional fused ReLU."""
+    return _SmallLayerNorm.apply(x, ln.weight, ln.bias, ln.eps, relu)
+
+
+def ln_supported(x, ln):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and len(ln.normalized_shape) == 1 and ln.normalized_shape[0] in LN_WIDTHS

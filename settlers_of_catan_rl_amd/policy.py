@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import spec
+from . import nn_kernels, spec
 
 T_SETTLE, T_ROAD, T_CITY, T_BUYDEV, T_PLAYDEV, T_EXCHANGE, T_PROPOSE, T_RESPOND, T_ROBBER, T_ROLL, T_ENDTURN, T_STEAL, T_DISCARD = range(13)
 C_YOP, C_MONO = 2, 4
@@ -38,6 +38,14 @@ def _ortho_linear(i, o, gain=math.sqrt(2)):
     return lin
 
 
+def _ln(ln, x, relu=False):
+    """LayerNorm (+ optional ReLU): the fused HIP kernel for the small widths on the GPU, torch otherwise."""
+    if nn_kernels.ln_supported(x, ln):
+        return nn_kernels.small_layer_norm(x, ln, relu)
+    y = ln(x)
+    return F.relu(y) if relu else y
+
+
 class _MHA(nn.Module):
     """qkv_nets.{0,1,2} + out_proj_net (reference multi_headed_attention.py:21-22)."""
 
@@ -47,13 +55,22 @@ class _MHA(nn.Module):
         self.qkv_nets = nn.ModuleList([nn.Linear(dim, dim) for _ in range(3)])
         self.out_proj_net = nn.Linear(dim, dim)
 
-    def forward(self, x, key_mask=None):
+    def forward(self, x, lens=None):
+        """x [B, L, D]; lens [B] (keys >= len are masked, reference key mask) or None."""
         B, L, D = x.shape
         w = torch.cat([n.weight for n in self.qkv_nets], 0)
         b = torch.cat([n.bias for n in self.qkv_nets], 0)
-        q, k, v = F.linear(x, w, b).view(B, L, 3, self.heads, self.hd).permute(2, 0, 3, 1, 4)
-        am = None if key_mask is None else key_mask[:, None, None, :]
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=am)
+        qkv = F.linear(x, w, b).view(B, L, 3, self.heads, self.hd)
+        if x.is_cuda and nn_kernels.supported(L, self.heads, self.hd) and qkv.dtype in (torch.float32, torch.bfloat16):
+            o = nn_kernels.small_attention(qkv, lens)             # fused HIP kernel (csrc/catan_nn.hip)
+            return self.out_proj_net(o)
+        # reference formulation in plain torch ops (CPU parity tests, unsupported shapes)
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
+        scores = torch.matmul(q, k.transpose(-2, -1)) * (1.0 / math.sqrt(self.hd))
+        if lens is not None:
+            key_mask = torch.arange(L, device=x.device)[None, :] < lens[:, None]
+            scores = scores.masked_fill(~key_mask[:, None, None, :], float("-inf"))
+        o = torch.matmul(torch.softmax(scores.float(), -1).to(v.dtype), v)
         return self.out_proj_net(o.transpose(1, 2).reshape(B, L, D))
 
 
@@ -81,8 +98,8 @@ class _EncoderLayer(nn.Module):
         self.pointwise_net = _FFN(dim, 2)
 
     def forward(self, x):
-        x = x + self.multi_headed_attention(self.sublayers[0].norm(x))
-        return x + self.pointwise_net(self.sublayers[1].norm(x))
+        x = x + self.multi_headed_attention(_ln(self.sublayers[0].norm, x))
+        return x + self.pointwise_net(_ln(self.sublayers[1].norm, x))
 
 
 class _TileEncoder(nn.Module):
@@ -95,17 +112,19 @@ class _TileEncoder(nn.Module):
         self.out_proj = _ortho_linear(dim, out_dim)
 
     def forward(self, tiles):
-        x = F.relu(self.norm_2(self.first_layer(tiles)))
+        x = _ln(self.norm_2, self.first_layer(tiles), relu=True)
         for layer in self.encoder_layers:
             x = layer(x)
-        return F.relu(self.norm(self.out_proj(x)).reshape(tiles.shape[0], -1))
+        return _ln(self.norm, self.out_proj(x), relu=True).reshape(tiles.shape[0], -1)   # relu(norm(.)).reshape == relu(norm(.).reshape)
 
 
 def _card_summary(ids, lens, embedding, mha, norm):
     """masked attention over a padded card-id list, zero the padding, sum (player_modules.py:55-69)."""
     L = ids.shape[1]
     valid = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
-    rep = norm(mha(embedding(ids), key_mask=valid))
+    # 6-row embedding as a one-hot matmul: its backward is a GEMM instead of a 6-way atomic scatter
+    emb = F.one_hot(ids, embedding.num_embeddings).to(embedding.weight.dtype) @ embedding.weight
+    rep = _ln(norm, mha(emb, lens))
     return (rep * valid[..., None].to(rep.dtype)).sum(1)
 
 
@@ -123,8 +142,8 @@ class _CurrentPlayer(nn.Module):
         self.final_linear_layer = _ortho_linear(2 * proj + 256, 128)
 
     def forward(self, main, hid, hid_len, played, played_len, emb, hid_mha, played_mha):
-        h = F.relu(self.norm_2(self.proj_hidden_dev_card(_card_summary(hid, hid_len, emb, hid_mha, self.norm))))
-        p = F.relu(self.norm_3(self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm))))
+        h = _ln(self.norm_2, self.proj_hidden_dev_card(_card_summary(hid, hid_len, emb, hid_mha, self.norm)), relu=True)
+        p = _ln(self.norm_3, self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm)), relu=True)
         m = F.relu(self.norm_1(self.main_input_layer_1(main)))
         return F.relu(self.norm_4(self.final_linear_layer(torch.cat((m, p, h), -1))))
 
@@ -141,7 +160,7 @@ class _OtherPlayers(nn.Module):
         self.norm_3 = nn.LayerNorm(128)
 
     def forward(self, main, played, played_len, emb, played_mha):
-        p = F.relu(self.norm_2(self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm))))
+        p = _ln(self.norm_2, self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm)), relu=True)
         m = F.relu(self.norm_1(self.main_input_layer_1(main)))
         return F.relu(self.norm_3(self.final_linear_layer(torch.cat((m, p), -1))))
 

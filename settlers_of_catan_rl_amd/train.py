@@ -75,7 +75,7 @@ class PPOTrainer(object):
         acts_all = st.actions.reshape(total, -1); amask_all = st.action_masks.reshape(total, -1)
         old_lp_all = st.action_log_probs.reshape(total)
         rewards = st.rewards[:T].contiguous(); masks = st.masks[:T + 1].contiguous()
-        vl_sum = al_sum = ent_sum = 0.0
+        sums = torch.zeros(3, device=dev)                 # action loss, value loss, entropy (accumulated on device)
         t_val = t_gae = t_opt = 0.0
         for _ in range(cfg.ppo_epoch):
             t0 = time.perf_counter()
@@ -98,9 +98,10 @@ class PPOTrainer(object):
                 cdist.allreduce_flat_grads([p for p in pol.parameters()])                  # one RCCL all-reduce per step
                 torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
                 self.optimiser.step()
-                al_sum += float(parts[0]); vl_sum += float(parts[1]) * cfg.value_loss_coef; ent_sum += float(ent) * cfg.entropy_coef
+                sums += torch.stack((parts[0], parts[1], ent.detach().float()))
             torch.cuda.synchronize(); t3 = time.perf_counter()
             t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2
         n = cfg.ppo_epoch * cfg.num_mini_batch
         self.timings = {"values_s": t_val, "gae_s": t_gae, "minibatches_s": t_opt}
-        return vl_sum / n, al_sum / n, ent_sum / n
+        al, vl, en = (sums / n).tolist()
+        return vl * cfg.value_loss_coef, al, en * cfg.entropy_coef

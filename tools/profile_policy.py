@@ -1,0 +1,43 @@
+"""Diagnostics (GPU box): where the policy's time goes at rollout width (act, B=65536) and in a minibatch step."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd.policy import CatanPolicy
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+env = VecCatanEnv(B, seed=0); env.random_rollout(0, 500)
+f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+net = CatanPolicy().cuda()
+gen = torch.Generator(device="cuda").manual_seed(0)
+
+def act():
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        return net.act(f, lists, lens, masks, generator=gen)
+
+for _ in range(3): act()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): act()
+torch.cuda.synchronize(); print(f"act B={B}: {(time.perf_counter()-t0)/5*1e3:.1f} ms")
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    act(); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
+ev = prof.key_averages()
+print("total kernels launched:", sum(e.count for e in ev if e.device_type is not None and "cuda" in str(e.device_type).lower()))
+# minibatch step
+Bm = 16384
+_, a, _ = act()
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+def step():
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v, lp, ent = net.evaluate_actions(f[:Bm], lists[:Bm], lens[:Bm], masks[:Bm], a[:Bm])
+    loss = v.float().mean() + lp.float().mean() - 0.01 * ent
+    opt.zero_grad(); loss.backward(); opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): step()
+torch.cuda.synchronize(); print(f"train step B={Bm}: {(time.perf_counter()-t0)/5*1e3:.1f} ms")
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=60))
