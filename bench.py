@@ -31,8 +31,9 @@ ALGO_BYTES = {
     # (112 rows x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
     # one bitboard word: ~40 rows x 4 B = 160)
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
-    "k_lr_heavy": 0,                                # tier-2 longest road: LDS/ALU only (3 bitboard words per request)
-    "k_step_finish": 1,                             # pending flag; finishes the few games tier 2 handled
+    "k_classify": 4 + 4,                            # action type in, permutation out
+    "k_lr": 0,                                      # longest-road tiers: LDS/ALU only (3 bitboard words per request)
+    "k_step_finish": 0,                             # completes the ~3 % of games that placed a road / settlement
 }
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 

@@ -10,12 +10,12 @@
  *    .data_ptr()); calls are asynchronous on the given HIP stream (pass NULL for the default stream);
  *    one handle per GPU / per thread.
  *  - return 0 on success, negative CATAN_E* otherwise; catan_last_error() gives the message (thread local).
- *  - n = number of games of the handle.  Batched layouts are head-major / field-major so that the lane-per-game
- *    kernels read and write them coalesced:
- *        actions  int32 [18][n]   the 12-head composite action of env/wrapper.py:114-166 flattened
+ *  - n = number of games of the handle.  Batched layouts are game-major (one contiguous record per game: the step kernel
+ *    gathers games sorted by action type, so everything belonging to a game sits in as few cache lines as possible):
+ *        actions  int32 [n][18]   the 12-head composite action of env/wrapper.py:114-166 flattened
  *                                 ([0]type [1]corner [2]edge(72=dummy) [3]tile [4]dev card [5]accept0/reject1
  *                                  [6]relative player [7..10]give seq [11..14]receive seq [15]res A [16]res B [17]discard)
- *        reward   float [4][n]    index = PlayerId-1 (White, Blue, Orange, Red; game/enums.py:8-12)
+ *        reward   float [n][4]    index = PlayerId-1 (White, Blue, Orange, Red; game/enums.py:8-12)
  *        done     uint8 [n]
  *        masks    float [n][325]  the 12 arrays of get_action_masks (env/wrapper.py:172-185) concatenated
  *        blob     int32 [736][cnt] canonical full state (settlers_of_catan_rl_amd/spec.py STATE_FIELDS)
@@ -71,14 +71,14 @@ int catan_step(catan_env_t* env, const int32_t* actions, float* reward, uint8_t*
 
 /* EnvWrapper.get_action_masks(): env/wrapper.py:168-290, batched float32 [n][325]. */
 int catan_masks(catan_env_t* env, float* out_masks, catan_stream_t stream);
-/* the same masks as 325-bit strings: uint32 [11][pitch] (bit i of the flat mask = word i>>5, bit i&31) */
+/* the same masks as 325-bit strings: uint32 [n][pitch], pitch = 16 words (bit i of the flat mask = word i>>5, bit i&31) */
 int catan_masks_packed(catan_env_t* env, const uint32_t** out_ptr, int64_t* out_pitch);
 
 /* deciding player (discarder > trade target > players_go): env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.
  * out: int32 [n], PlayerId 1..4 */
 int catan_deciding_seat(catan_env_t* env, int32_t* out, catan_stream_t stream);
 
-/* uniform-random legal policy used by bench config 2 (DESIGN.md "random policy"); writes int32 [18][n] */
+/* uniform-random legal policy used by bench config 2 (DESIGN.md "random policy"); writes int32 [n][18] */
 int catan_sample_random_actions(catan_env_t* env, uint32_t step_idx, int32_t* actions, catan_stream_t stream);
 
 /* EnvWrapper.save_state()/restore_state(): env/wrapper.py:711-721 -> game/game.py:1013-1205.
@@ -97,7 +97,8 @@ int64_t catan_invalid_action_count(catan_env_t* env, catan_stream_t stream);
 int catan_random_rollout(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream);
 
 /* the same loop with a hipEvent pair around every kernel launch (recorded on `stream`); kernel_ms is a HOST
- * float[4] receiving the summed milliseconds of k_sample_random, k_step, k_lr_heavy, k_step_finish (bench.py roofline). */
+ * float[5] receiving the summed milliseconds of k_sample_random, the action-type sort (k_classify_*), k_step,
+ * k_lr + k_lr_heavy, k_step_finish (bench.py roofline). */
 int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms);
 
 /* EnvWrapper._get_obs(): env/wrapper.py:52-83 (+ _get_tile_features :491-524, _get_player_inputs :526-709), batched.

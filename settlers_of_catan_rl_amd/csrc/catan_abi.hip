@@ -21,11 +21,11 @@ struct catan_env {
     Ctx ctx;
     catan_cfg_t cfg;
     void* state;          // W rows then B rows
-    u32* mpk;             // packed masks [11][N]
+    u32* mpk;             // packed masks [N][16]
     u32* err;             // invalid-action counter
     // scratch for catan_random_rollout
-    i32* scratch_actions; // [18][n]
-    float* scratch_reward;// [4][n]
+    i32* scratch_actions; // [n][18]
+    float* scratch_reward;// [n][4]
     u8* scratch_done;     // [n]
     Pending pend;         // tier-2 longest-road hand-off (device arrays)
     unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
@@ -117,13 +117,16 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (cfg) e->cfg = *cfg; else catan_cfg_default(&e->cfg);
     size_t bytes = (size_t)e->N * STATE_BYTES_PER_GAME;
     hipError_t rc = hipMalloc(&e->state, bytes);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->mpk, (size_t)e->N * MASK_WORDS * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->mpk, (size_t)e->N * MPK_STRIDE * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->err, 64);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_actions, (size_t)e->n * ACTION_WORDS * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_done, (size_t)e->n);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.count, 64);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ctr, CTR_WORDS * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req, (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.heavy, (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
@@ -131,7 +134,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
-    HIPCHK(hipMemset(e->pend.count, 0, 64));
+    HIPCHK(hipMemset(e->pend.ctr, 0, CTR_WORDS * sizeof(u32)));
     HIPCHK(hipMemset(e->pend.type, 0, (size_t)e->N));
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
@@ -154,8 +157,11 @@ void catan_destroy(catan_env_t* e) {
     if (e->scratch_reward) hipFree(e->scratch_reward);
     if (e->scratch_done) hipFree(e->scratch_done);
     if (e->prof) hipFree(e->prof);
-    if (e->pend.count) hipFree(e->pend.count);
+    if (e->pend.ctr) hipFree(e->pend.ctr);
     if (e->pend.req) hipFree(e->pend.req);
+    if (e->pend.heavy) hipFree(e->pend.heavy);
+    if (e->pend.perm) hipFree(e->pend.perm);
+    if (e->pend.resets) hipFree(e->pend.resets);
     if (e->pend.type) hipFree(e->pend.type);
     if (e->pend.who) hipFree(e->pend.who);
     if (e->pend.len) hipFree(e->pend.len);
@@ -164,7 +170,7 @@ void catan_destroy(catan_env_t* e) {
 
 int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
     if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
-    hipLaunchKernelGGL(k_reset, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, reset_mask);
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)(e->N < 16384 ? e->N : 16384)), dim3(64), 0, S(stream), e->ctx, reset_mask);
     HIPCHK(hipGetLastError());
     return launch_masks(e, S(stream));
 }
@@ -176,17 +182,34 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.prof = e->prof_on ? e->prof : nullptr;
     return sc;
 }
-// One env step = k_step (fused: apply + tier-1 longest road + done/reward + auto-reset + next masks) followed by the
-// two tier-2 kernels, which are no-ops unless some game's longest-road search overflowed its budget.
+// One env step = counting sort of the games by action type (k_classify_*), k_step (fused: apply + done/reward +
+// auto-reset + next masks for every game that needs no longest-road update), then for the road/settlement placements:
+// k_lr (tier-1 path search, one request per wave), k_lr_heavy (tier 2), k_step_finish (compact completion), and
+// k_reset_list for the games that ended (one wave per game).
 constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x LR_SPLIT parts are strided over them
-static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
+constexpr int LR_GRID = 2048;
+constexpr int RESET_GRID = 512;
+static int enqueue_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev) {
     StepCfg sc = step_cfg(e);
-    HIPCHK(hipMemsetAsync(e->pend.count, 0, sizeof(u32), st));
+    HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
+    hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.perm);
+    if (ev) HIPCHK(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
-    hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)e->pend.count, (const u64*)e->pend.req, e->pend.len);
+    if (ev) HIPCHK(hipEventRecord(ev[2], st));
+    hipLaunchKernelGGL(k_lr, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->pend, sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
+    hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)(e->pend.ctr + 1), (const u64*)e->pend.heavy, e->pend.len);
+    if (ev) HIPCHK(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
+    if (e->cfg.auto_reset)
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn, e->pend);
+    if (ev) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
+}
+static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
+    return enqueue_step(e, actions, reward, done, st, nullptr);
 }
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
@@ -204,7 +227,7 @@ int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
 
 int catan_masks_packed(catan_env_t* e, const uint32_t** out_ptr, int64_t* out_pitch) {
     if (!e || !out_ptr || !out_pitch) return fail(CATAN_EINVAL, "catan_masks_packed: null argument");
-    *out_ptr = e->mpk; *out_pitch = e->N;
+    *out_ptr = e->mpk; *out_pitch = MPK_STRIDE;
     return CATAN_OK;
 }
 
@@ -263,35 +286,31 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 
 // Same loop as catan_random_rollout but with a hipEvent pair around every kernel launch (events recorded on
 // `stream`, the stream the kernels run on).  kernel_ms (host, float[4]) receives the summed elapsed
-// milliseconds of: [0] k_sample_random  [1] k_step  [2] k_lr_heavy  [3] k_step_finish.
+// milliseconds of: [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr + k_lr_heavy  [4] k_step_finish.
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
-    const int K = 4;
+    const int K = 5;                       // events per step: before sort | before k_step | after k_step | after k_lr* | after finish
     std::vector<hipEvent_t> ev((size_t)steps * (K + 1));
     for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableSystemFence));   // no L2 flush between kernels
-    StepCfg sc = step_cfg(e);
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * (K + 1)];
-        HIPCHK(hipMemsetAsync(e->pend.count, 0, sizeof(u32), st));
-        HIPCHK(hipEventRecord(v[0], st));
+        HIPCHK(hipEventRecord(v[5], st));
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s, e->scratch_actions);
-        HIPCHK(hipEventRecord(v[1], st));
-        hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, (const i32*)e->scratch_actions, e->mpk, e->scratch_reward, e->scratch_done, e->err, sc, e->pend);
-        HIPCHK(hipEventRecord(v[2], st));
-        hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)e->pend.count, (const u64*)e->pend.req, e->pend.len);
-        HIPCHK(hipEventRecord(v[3], st));
-        hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, e->scratch_reward, e->scratch_done, sc, e->pend);
-        HIPCHK(hipEventRecord(v[4], st));
+        int r = enqueue_step(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v);
+        if (r != CATAN_OK) return r;
     }
     HIPCHK(hipStreamSynchronize(st));
-    for (int k = 0; k < 4; k++) kernel_ms[k] = 0.0f;
-    for (int64_t s = 0; s < steps; s++)
-        for (int k = 0; k < K; k++) {
-            float ms = 0.0f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[(size_t)s * (K + 1) + k], ev[(size_t)s * (K + 1) + k + 1]));
-            kernel_ms[k] += ms;
-        }
+    for (int k = 0; k < 5; k++) kernel_ms[k] = 0.0f;
+    for (int64_t s = 0; s < steps; s++) {
+        hipEvent_t* v = &ev[(size_t)s * (K + 1)];
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (+ counter memset)
+        HIPCHK(hipEventElapsedTime(&ms, v[0], v[1])); kernel_ms[1] += ms;      // k_classify_hist + k_classify_scatter
+        HIPCHK(hipEventElapsedTime(&ms, v[1], v[2])); kernel_ms[2] += ms;      // k_step
+        HIPCHK(hipEventElapsedTime(&ms, v[2], v[3])); kernel_ms[3] += ms;      // k_lr + k_lr_heavy
+        HIPCHK(hipEventElapsedTime(&ms, v[3], v[4])); kernel_ms[4] += ms;      // k_step_finish
+    }
     for (auto& x : ev) hipEventDestroy(x);
     return CATAN_OK;
 }

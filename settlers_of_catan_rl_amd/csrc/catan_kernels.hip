@@ -38,7 +38,7 @@ constexpr u64 ALL54 = (1ull << 54) - 1;
 
 // ------------------------------------------------------------------------------------------------ state view
 struct Ctx {          // launch-invariant handle fields
-    u32* R;           // [NROWS][N]
+    u32* R;           // game records, REC words each
     long N;           // padded number of games (row pitch)
     long n;           // real number of games
     u32 key0, key1;   // philox key = seed
@@ -68,31 +68,62 @@ struct StOps {
     DEVI int pile(int i) const { return self().cold(B_PILE + i); }
     DEVI void set_pile(int i, int v) const { self().scold(B_PILE + i, v); }
 };
-// view 1: everything in HBM (k_masks, k_reset, k_sample_random, export/import)
+// view 1: the game's record in HBM (k_masks, k_reset, k_sample_random, export/import, k_obs, tier-2 longest road)
 struct St : StOps<St> {
-    u32* R;
-    long N, e;
-    DEVI St(u32* R_, long N_, long e_) : R(R_), N(N_), e(e_) {}
-    DEVI u32 w(int r) const { return R[(long)r * N + e]; }
-    DEVI void sw(int r, u32 v) const { R[(long)r * N + e] = v; }
-    DEVI int cold(int f) const { return ((const u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3]; }
-    DEVI void scold(int f, int v) const { ((u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3] = (u8)v; }
+    u32* P;           // the game's record
+    long e;
+    DEVI St(u32* R_, long /*N*/, long e_) : P(R_ + e_ * REC), e(e_) {}
+    DEVI u32 w(int r) const { return P[r]; }
+    DEVI void sw(int r, u32 v) const { P[r] = v; }
+    DEVI int cold(int f) const { return ((const u8*)(P + NW))[f]; }
+    DEVI void scold(int f, int v) const { ((u8*)(P + NW))[f] = (u8)v; }
     DEVI int b(int f) const { return cold(f); }
     DEVI void sb(int f, int v) const { scold(f, v); }
 };
-// view 2: the wave's HOT rows staged in LDS as tile[row][lane] (k_step); cold fields stay in HBM
-struct StL : StOps<StL> {
-    u32* T;           // LDS tile base, already offset by the lane: element (row) at T[row * 64]
-    u32* R;
-    long N, e;
-    DEVI StL(u32* T_, u32* R_, long N_, long e_) : T(T_), R(R_), N(N_), e(e_) {}
-    DEVI u32 w(int r) const { return T[r * 64]; }
-    DEVI void sw(int r, u32 v) const { T[r * 64] = v; }
-    DEVI int b(int f) const { return ((const u8*)(T + (NW + (f >> 2)) * 64))[f & 3]; }
-    DEVI void sb(int f, int v) const { ((u8*)(T + (NW + (f >> 2)) * 64))[f & 3] = (u8)v; }
-    DEVI int cold(int f) const { return ((const u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3]; }
-    DEVI void scold(int f, int v) const { ((u8*)(R + (long)(NW + (f >> 2)) * N + e))[f & 3] = (u8)v; }
+// view 2: the HOT words staged in LDS as tile[word][slot] with row stride TS (k_step); cold fields stay in HBM
+template <int STRIDE>
+struct StLT : StOps<StLT<STRIDE>> {
+    u32* T;           // LDS tile base, already offset by the slot (lane): word r at T[r * STRIDE]
+    u32* P;           // the game's record in HBM (cold fields)
+    long e;
+    DEVI StLT(u32* T_, u32* R_, long /*N*/, long e_) : T(T_), P(R_ + e_ * REC), e(e_) {}
+    DEVI u32 w(int r) const { return T[r * STRIDE]; }
+    DEVI void sw(int r, u32 v) const { T[r * STRIDE] = v; }
+    DEVI int b(int f) const { return ((const u8*)(T + (NW + (f >> 2)) * STRIDE))[f & 3]; }
+    DEVI void sb(int f, int v) const { ((u8*)(T + (NW + (f >> 2)) * STRIDE))[f & 3] = (u8)v; }
+    DEVI int cold(int f) const { return ((const u8*)(P + NW))[f]; }
+    DEVI void scold(int f, int v) const { ((u8*)(P + NW))[f] = (u8)v; }
 };
+typedef StLT<TS> StL;     // k_step / k_step_finish: 64 games per tile
+typedef StLT<1> StL1;     // k_reset_list: one game per wave, its hot record linear in LDS
+// Transposing stage-in / stage-out of the HOT words of the 64 games whose ids sit one per lane in `e` (-1 = empty slot).
+// 28 x 16 B per game, two games per pass (lanes 0..55): every load/store instruction moves 2 x 448 contiguous bytes.
+DEVI void stage_in(u32* tile, const u32* __restrict__ R, int e, int lane) {
+    const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
+#pragma unroll 8
+    for (int p = 0; p < 32; p++) {
+        const int g = 2 * p + half;
+        const int eg = __shfl(e, g & 63);
+        if (lane < 56 && eg >= 0) {
+            const uint4 v = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+            u32* t = tile + (4 * q) * TS + g;
+            t[0] = v.x; t[TS] = v.y; t[2 * TS] = v.z; t[3 * TS] = v.w;
+        }
+    }
+}
+DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
+    const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
+#pragma unroll 8
+    for (int p = 0; p < 32; p++) {
+        const int g = 2 * p + half;
+        const int eg = __shfl(e, g & 63);
+        if (lane < 56 && eg >= 0) {
+            const u32* t = tile + (4 * q) * TS + g;
+            uint4 v; v.x = t[0]; v.y = t[TS]; v.z = t[2 * TS]; v.w = t[3 * TS];
+            reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v;
+        }
+    }
+}
 
 DEVI int seat_of(int seatof, int p) { return (seatof >> (2 * p)) & 3; }
 DEVI int pid_at(int order, int seat) { return (order >> (2 * (seat & 3))) & 3; }
@@ -280,7 +311,7 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
-constexpr int LR_BUDGET = 96;       // tier-1 double-iterations per lane before the game is handed to tier 2
+constexpr int LR_BUDGET = 12;       // tier-1 double-iterations per lane before the game is handed to tier 2
 constexpr int LR_HEAVY_THREADS = 1024;
 constexpr int LR_POOL = 3072;       // tier-2 workgroup pool entries
 constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round
@@ -499,79 +530,95 @@ struct Packed {
         }
     }
 };
-struct ResetScratch { int unused; };
-// ref: game/components/board.py:67-100, game/game.py:39-136, game/components/player.py:9-58, env/wrapper.py:30-34.
-// `hot_rows` rows of the state view are zeroed through s.sw (all of them for the HBM view, the LDS tile for StL).
-template <class S>
-DEVI void reset_game(const S& s, Rng& rng, ResetScratch&, int, int hot_rows) {
-    for (int r = 0; r < hot_rows; r++) if (r != W_RNG) s.sw(r, 0);
-    // terrain: Desert, 3 Hills, 4 Fields, 4 Forest, 3 Mountains, 4 Pastures (board.py:27-28; Terrain == Resource value)
-    Packed<3, 21> terr; terr.lo = 0; terr.hi = 0;
-#pragma unroll
-    for (int i = 0; i < 19; i++) terr.set(i, i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4)))));
-    terr.shuffle(19, rng);                                     // board.py:72
-    // number tokens (board.py:25), reshuffled until no 6/8 are adjacent (board.py:79-81, 50-65)
-    Packed<4, 16> nums; nums.lo = 0; nums.hi = 0;
-    {
-        const int nv[18] = { 5, 2, 6, 3, 8, 10, 9, 12, 11, 4, 8, 10, 9, 4, 5, 6, 3, 11 };
-#pragma unroll
-        for (int i = 0; i < 18; i++) nums.set(i, nv[i]);
+// scratch of the wave-cooperative reset used inside k_step / k_step_finish: the game's Philox stream is generated in bulk
+// by all 64 lanes (RND_WORDS consecutive draws), then the resetting lane walks it; its shuffle arrays are LDS bytes.
+constexpr int RND_WORDS = 768;
+struct ResetScratch { u32 rnd[RND_WORDS]; u8 arr[32]; u8 terr[32]; };
+// RNG view over the pre-generated words, falling back to inline Philox beyond them (p99.9 of a reset is ~1250 draws)
+struct RngBuf {
+    const u32* buf; u32 base, avail;      // buf[i] = draw number base + i
+    Rng slow;
+    DEVI u32 next() {
+        const u32 i = slow.draws - base;
+        if (i < avail) { slow.draws++; return buf[i]; }
+        return slow.next();
     }
+    DEVI u32 bounded(u32 mx) {
+        if (mx == 0) return 0;
+        const u32 mask = 0xFFFFFFFFu >> __clz(mx);
+        u32 v;
+        do { v = next() & mask; } while (v > mx);
+        return v;
+    }
+};
+DEVI void shuffle_bytes(u8* a, int n, RngBuf& rng) {     // np.random.shuffle on a list
+    for (int i = n - 1; i >= 1; i--) {
+        const int j = (int)rng.bounded((u32)i);
+        const u8 t = a[i]; a[i] = a[j]; a[j] = t;
+    }
+}
+// Same reset as reset_game<> (board.py:67-100, game.py:39-136), executed by ONE lane on LDS byte arrays and the
+// pre-generated random words.
+template <class S>
+DEVI void reset_game_lds(const S& s, RngBuf& rng, ResetScratch& sc, int hot_rows) {
+    u8* arr = sc.arr; u8* terr = sc.terr;
+    for (int r = 0; r < hot_rows; r++) if (r != W_RNG) s.sw(r, 0);
+    for (int i = 0; i < 19; i++) terr[i] = (u8)(i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4)))));
+    shuffle_bytes(terr, 19, rng);                              // board.py:72
+    {   // board.py:25: 5 2 6 3 8 10 9 12 11 4 8 10 9 4 5 6 3 11, packed as nibbles (no constant-memory table)
+        for (int i = 0; i < 16; i++) arr[i] = (u8)((0x6549A84BC9A83625ull >> (4 * i)) & 15);   // entry i in bits 4i..4i+3
+        arr[16] = 3; arr[17] = 11;
+    }
+    // tile terrains in registers, indexed by constants below
+    int tr[19];
+#pragma unroll
+    for (int t = 0; t < 19; t++) tr[t] = terr[t];
     bool ok = false;
-    do {
-        nums.shuffle(18, rng);
+    do {                                                       // board.py:79-81, 50-65
+        shuffle_bytes(arr, 18, rng);
         u32 reds = 0;
         int n = 0;
+#pragma unroll
         for (int i = 0; i < 19; i++) {
-            const int t = PLACEMENT[i];
-            const int tr = terr.get(t);
-            const int v = tr == 0 ? 7 : nums.get(n);
-            if (tr != 0) n++;
+            const int t = topo_placement(i);
+            const int v = tr[t] == 0 ? 7 : arr[n];
+            if (tr[t] != 0) n++;
             if (v == 6 || v == 8) reds |= 1u << t;
         }
         ok = true;
-        for (int t = 0; t < 19; t++) if (((reds >> t) & 1) && (TILE_NBR_MASK[t] & reds)) ok = false;
+#pragma unroll
+        for (int t = 0; t < 19; t++) if (((reds >> t) & 1) && (topo_tile_nbr_mask(t) & reds)) ok = false;
     } while (!ok);
     {
         int n = 0;
+#pragma unroll
         for (int i = 0; i < 19; i++) {                        // board.py:91-100
-            const int t = PLACEMENT[i], tr = terr.get(t);
+            const int t = topo_placement(i);
             int v;
-            if (tr == 0) { v = 7; s.sb(B_ROBBER, t); } else { v = nums.get(n); n++; }
-            s.sb(B_TILE + t, tr | (v << 4));
+            if (tr[t] == 0) { v = 7; s.sb(B_ROBBER, t); } else { v = arr[n]; n++; }
+            s.sb(B_TILE + t, tr[t] | (v << 4));
         }
     }
-    Packed<4, 16> harb; harb.lo = 0x876543210ull; harb.hi = 0;
-    harb.shuffle(9, rng);                                      // board.py:84
-    for (int i = 0; i < 9; i++) s.sb(B_HARB + i, harb.get(i));
-    Packed<2, 32> ord; ord.lo = 0xE4ull; ord.hi = 0;          // game.py:41 [White, Blue, Orange, Red] as pid0 = 0,1,2,3
-    ord.shuffle(4, rng);                                       // game.py:42
+    for (int i = 0; i < 9; i++) arr[i] = (u8)i;
+    shuffle_bytes(arr, 9, rng);                                // board.py:84
+    for (int i = 0; i < 9; i++) s.sb(B_HARB + i, arr[i]);
+    for (int i = 0; i < 4; i++) arr[i] = (u8)i;                // game.py:41
+    shuffle_bytes(arr, 4, rng);                                // game.py:42
     {
-        int order = (int)(ord.lo & 0xFF), seatof = 0;
-        for (int i = 0; i < 4; i++) seatof |= i << (2 * ord.get(i));
+        int order = 0, seatof = 0;
+        for (int i = 0; i < 4; i++) { const int p = arr[i]; order |= p << (2 * i); seatof |= i << (2 * p); }
         s.sb(B_ORDER, order); s.sb(B_SEATOF, seatof);
         s.sb(B_GO, order & 3); s.sb(B_ORDER_ID, 0);
     }
     for (int r = 0; r < 5; r++) s.sb(B_BANK + r, 19);         // game.py:48-54
     for (int p = 0; p < 4; p++) { s.spb(p, P_SLEFT, 5); s.spb(p, P_CLEFT, 4); s.spb(p, P_ISECOND, 255); }
-    Packed<3, 21> deck; deck.lo = 0; deck.hi = 0;             // game.py:75-76
-#pragma unroll
-    for (int i = 0; i < 25; i++) deck.set(i, i < 14 ? C_KNIGHT : (i < 19 ? C_VP : (i < 21 ? C_YOP : (i < 23 ? C_RB : C_MONO))));
-    deck.shuffle(25, rng);                                     // game.py:77
-    for (int i = 0; i < 25; i++) s.set_pile(i, deck.get(i));  // card lists need no clearing: their lengths are 0
+    for (int i = 0; i < 25; i++) arr[i] = (u8)(i < 14 ? C_KNIGHT : (i < 19 ? C_VP : (i < 21 ? C_YOP : (i < 23 ? C_RB : C_MONO))));
+    shuffle_bytes(arr, 25, rng);                               // game.py:77
+    for (int i = 0; i < 25; i++) s.set_pile(i, arr[i]);
     s.sb(B_PILE_LEN, 25);
     s.sb(B_FLAGS, F_INITIAL);
-    s.sw(W_RNG, rng.draws);
+    s.sw(W_RNG, rng.slow.draws);
 }
-__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
-    ResetScratch sc;
-    St s(c.R, c.N, (long)blockIdx.x * 64 + threadIdx.x);
-    if (s.e >= c.N) return;
-    if (sel != nullptr && (s.e >= c.n || sel[s.e] == 0)) return;
-    Rng rng = rng_load(c, s);
-    reset_game(s, rng, sc, threadIdx.x, NROWS);
-}
-
 // ------------------------------------------------------------------------------------------------ masks
 template <int OFF, int NBITS>
 DEVI void setr(u32 (&m)[MASK_WORDS], u64 v) {      // overwrite bit range [OFF, OFF+NBITS) with the low NBITS of v
@@ -767,16 +814,16 @@ __global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, i
     u32 m[MASK_WORDS];
     compute_masks(s, m, max_trades);
 #pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) mpk[(long)i * c.N + s.e] = m[i];
+    for (int i = 0; i < MASK_WORDS; i++) mpk[s.e * MPK_STRIDE + i] = m[i];
 }
 
-// packed [11][Npad] -> float32 [n][325] row-major (what EnvWrapper.get_action_masks returns, batched)
+// packed [N][16] -> float32 [n][325] row-major (what EnvWrapper.get_action_masks returns, batched)
 __global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ mpk, long N, long n, float* __restrict__ out) {
     long i = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n * MASK_BITS) return;
     long e = i / MASK_BITS;
     int j = (int)(i - e * MASK_BITS);
-    out[i] = (float)((mpk[(long)(j >> 5) * N + e] >> (j & 31)) & 1u);
+    out[i] = (float)((mpk[e * MPK_STRIDE + (j >> 5)] >> (j & 31)) & 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ step
@@ -938,7 +985,11 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     t_prev = wall_clock64();
 }
 
-struct Pending { u32* count; u64* req; u8* type; u8* who; i32* len; };   // games handed to tier 2 (all device arrays)
+// Per-step hand-off buffers (all device arrays).  ctr: [0] number of longest-road requests (= games whose step is
+// completed by k_step_finish), [1] number of tier-2 requests, [2] number of finished games to reset (k_reset_list),
+// [16..29] games per action-type bin, [32..45] bin cursors.
+struct Pending { u32* ctr; u64* req; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets; };
+constexpr int CTR_WORDS = 64;
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
 struct StepScratch { LrWave lr; ResetScratch rs; };
@@ -949,12 +1000,12 @@ struct StepScratch { LrWave lr; ResetScratch rs; };
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e);
+                      long long& tprof, u32 nbr_c, u32 nbr_e, u32* reset_count, i32* resets);
 
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e) {
+                      long long& tprof, u32 nbr_c, u32 nbr_e, u32* reset_count, i32* resets) {
     const long e = s.e;
     const bool doit_or_pad = doit || e >= c.n;       // padding games keep valid masks too
     {
@@ -1024,24 +1075,23 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
                 s.sb(B_CURVP + p, vps[p]);
                 if (dn && winner == p + 1) r += cfg.win_reward;
             }
-            reward[(long)p * c.n + s.e] = r;
+            reward[s.e * 4 + p] = r;
         }
         if (dn) s.sb(B_WINNER, winner);
         done[s.e] = dn ? 1 : 0;
         want_reset = dn && cfg.auto_reset;
+        // RL/ppo/game_manager.py:112-113: the finished game is reset by k_reset_list (one wave per game: winning moves
+        // cluster in a few action-type bins, inline resets would serialise inside those waves), which also writes its masks
+        if (want_reset) resets[atomicAdd(reset_count, 1u)] = (i32)s.e;
     }
     prof_mark(cfg, 4, tprof);
-    if (want_reset) {                                                      // RL/ppo/game_manager.py:112-113
-        Rng rng = rng_load(c, s);
-        reset_game(s, rng, scratch.rs, lane, ROWS_HOT);
-    }
     prof_mark(cfg, 5, tprof);
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
-    if (doit_or_pad) {
+    if (doit_or_pad && !want_reset) {
         u32 m[MASK_WORDS];
         compute_masks(s, m, cfg.max_trades);
 #pragma unroll
-        for (int i = 0; i < MASK_WORDS; i++) mpk[(long)i * c.N + e] = m[i];
+        for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
     }
     prof_mark(cfg, 6, tprof);
 }
@@ -1051,35 +1101,31 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
 // apply_action, longest road (wave-cooperative), done/rewards, auto-reset of finished games, next legal-action
 // masks - and the tile is written back once.  With 65 536 games there is exactly one wave per SIMD, so the launch
 // time is the dependent-latency chain of a single wave: LDS (~64 cycles) instead of HBM/L2 (~200-900 cycles) per hop.
-// actions: int32 [18][n] head-major; reward: float [4][n] (PlayerId-1 major); done: u8 [n]; err: [1] invalid-action
-// counter; mpk: packed masks [11][N], read for validation, rewritten with the masks of the new state.
+// actions: int32 [n][18]; reward: float [n][4] (index PlayerId-1); done: u8 [n]; err: [1] invalid-action
+// counter; mpk: packed masks [N][16], read for validation, rewritten with the masks of the new state.
 __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend) {
-    __shared__ u32 tile[ROWS_HOT * 64];
+    __shared__ u32 tile[ROWS_HOT * TS];
     __shared__ StepScratch scratch;
-    LrWave& L = scratch.lr;
     const int lane = threadIdx.x;
-    const long e = (long)blockIdx.x * 64 + lane;
+    const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
     long long tprof = cfg.prof ? wall_clock64() : 0;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    {
-        const u32* __restrict__ src = c.R + e;
-#pragma unroll 16
-        for (int r = 0; r < ROWS_HOT; r++) tile[r * 64 + lane] = src[(long)r * c.N];
-    }
+    stage_in(tile, c.R, (int)e, lane);
+    __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
     const bool live = s.e < c.n;
     int a[ACTION_WORDS];
 #pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = live ? actions[(long)i * c.n + s.e] : 0;
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = live ? actions[s.e * ACTION_WORDS + i] : 0;
     int type = live ? a[0] : -1;
     if (live && cfg.validate && type >= 0) {          // a negative type is an explicit no-op (frozen game), not an error
         u32 m[MASK_WORDS];
 #pragma unroll
-        for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[(long)i * c.N + s.e];
+        for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
         if (!action_legal(s, m, a)) { atomicAdd(err, 1u); type = -1; }
     }
     if (type < 0 || type > 12) type = -1;
@@ -1366,59 +1412,157 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
 
     prof_mark(cfg, 1, tprof);
-    // ---- update_longest_road (game.py:864-919): tier-1 path length, or hand the game to tier 2
-    int len = coop_longest_path(lr_who >= 0, s, lr_who < 0 ? 0 : lr_who, L, LR_BUDGET, nbr_c, nbr_e, cfg.prof ? cfg.prof + 2 * PROF_PHASES : nullptr);
-    const bool pending = lr_who >= 0 && len < 0;
-    if (pending) {                                   // finished later by k_lr_heavy + k_step_finish
-        const u32 slot = atomicAdd(pend.count, 1u);
+    // ---- update_longest_road (game.py:864-919): the path search runs in k_lr / k_lr_heavy; k_step_finish completes
+    // the step of these games (sorted waves would otherwise serialise up to 64 searches in the road-placement waves)
+    const int len = 0;
+    const bool pending = lr_who >= 0;
+    if (pending) {
+        const u32 slot = atomicAdd(&pend.ctr[0], 1u);
         pend.req[slot] = (u64)e | ((u64)lr_who << 56);
         pend.type[e] = (u8)(type + 1);
         pend.who[e] = (u8)lr_who;
-        pend.len[e] = 0;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e);
+    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e, &pend.ctr[2], pend.resets);
     // ---- write the tile back
-    {
-        u32* __restrict__ dst = c.R + e;
-#pragma unroll 16
-        for (int r = 0; r < ROWS_HOT; r++) dst[(long)r * c.N] = tile[r * 64 + lane];
-    }
+    __builtin_amdgcn_wave_barrier();
+    stage_out(tile, c.R, (int)e, lane);
     prof_mark(cfg, 7, tprof);
 }
 
-// Completes the games k_step handed to tier 2 (their longest-road length now sits in pend.len).  A wave with no
-// pending game exits after one load.
+// tier 1 of the longest road, one request per wave (all 64 lanes cooperate); overflow goes to the tier-2 list.
+__global__ __launch_bounds__(64) void k_lr(Ctx c, Pending pend, unsigned long long* stat) {
+    __shared__ LrWave L;
+    const int lane = threadIdx.x;
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(lane, nbr_c, nbr_e);
+    const u32 count = pend.ctr[0];
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        const u64 rq = pend.req[r];
+        const long e = (long)(rq & 0x00FFFFFFFFFFFFFFull);
+        const int who = (int)(rq >> 56);
+        St s(c.R, c.N, e);
+        const int len = coop_longest_path(lane == 0, s, who, L, LR_BUDGET, nbr_c, nbr_e, stat);
+        if (lane == 0) {
+            if (len < 0) { const u32 slot = atomicAdd(&pend.ctr[1], 1u); pend.heavy[slot] = rq; pend.len[e] = 0; }
+            else pend.len[e] = len;
+        }
+    }
+}
+
+// Completes the step of the games in the request list (their longest-road length now sits in pend.len): holder logic,
+// done/rewards, auto-reset, next masks.  Compact: wave w gathers requests 64w .. 64w+63, whatever games they are.
 __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward,
                                                     u8* __restrict__ done, StepCfg cfg, Pending pend) {
-    __shared__ u32 tile[ROWS_HOT * 64];
+    __shared__ u32 tile[ROWS_HOT * TS];
     __shared__ StepScratch scratch;
     const int lane = threadIdx.x;
-    const long e = (long)blockIdx.x * 64 + lane;
-    const int pt = e < c.n ? pend.type[e] : 0;
-    if (__ballot(pt != 0) == 0) return;
-    {
-        const u32* __restrict__ src = c.R + e;
-#pragma unroll 16
-        for (int r = 0; r < ROWS_HOT; r++) tile[r * 64 + lane] = src[(long)r * c.N];
-    }
-    StL s(tile + lane, c.R, c.N, e);
+    const u32 count = pend.ctr[0];
+    if ((u32)blockIdx.x * 64u >= count) return;
+    const u32 r = blockIdx.x * 64u + lane;
+    const bool doit = r < count;
+    const long e = doit ? (long)(pend.req[r] & 0x00FFFFFFFFFFFFFFull) : -1;
+    stage_in(tile, c.R, (int)e, lane);
+    __builtin_amdgcn_wave_barrier();
+    StL s(tile + lane, c.R, c.N, doit ? e : 0);
     long long tprof = 0;
     StepCfg cfg2 = cfg;
     cfg2.prof = nullptr;
-    const bool doit = pt != 0;
+    const int pt = doit ? pend.type[e] : 0;
     const int who = doit ? pend.who[e] : -1;
     const int len = doit ? pend.len[e] : 0;
-    if (doit) pend.type[e] = 0;
-    // finish_step refreshes masks for `doit` and padding lanes only; the other lanes keep the masks k_step wrote
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e);
-    {
-        u32* __restrict__ dst = c.R + e;
-#pragma unroll 16
-        for (int r = 0; r < ROWS_HOT; r++) dst[(long)r * c.N] = tile[r * 64 + lane];
+    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, &pend.ctr[2], pend.resets);
+    __builtin_amdgcn_wave_barrier();
+    stage_out(tile, c.R, (int)e, lane);
+}
+
+// One wave resets one game: the 64 lanes generate the game's next RND_WORDS Philox draws into LDS, lane 0 runs the
+// (inherently serial) shuffles of Board.reset / Game.reset on the game's hot record held linearly in LDS, then computes
+// the masks of the fresh game.
+DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, int max_trades) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
+    __builtin_amdgcn_wave_barrier();
+    StL1 s(rec, c.R, c.N, e);
+    Rng mine = rng_load(c, s);
+    const u32 blk0 = mine.draws >> 2;
+#pragma unroll
+    for (int b = 0; b < RND_WORDS / 256; b++) {
+        u32 o[4];
+        philox4x32_10(blk0 + b * 64 + lane, 0u, mine.e0, mine.e1, c.key0, c.key1, o);
+        const int at = (b * 64 + lane) * 4;
+        sc.rnd[at] = o[0]; sc.rnd[at + 1] = o[1]; sc.rnd[at + 2] = o[2]; sc.rnd[at + 3] = o[3];
     }
+    for (int r = ROWS_HOT + lane; r < REC; r += 64) c.R[e * REC + r] = 0;     // cold part: empty card lists
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        RngBuf rb;
+        rb.buf = sc.rnd; rb.base = blk0 * 4; rb.avail = RND_WORDS; rb.slow = mine;
+        reset_game_lds(s, rb, sc, ROWS_HOT);
+        if (mpk != nullptr) {
+            u32 m[MASK_WORDS];
+            compute_masks(s, m, max_trades);
+#pragma unroll
+            for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+}
+// Resets the games this step finished (RL/ppo/game_manager.py:112-113), one wave per game.
+__global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, Pending pend) {
+    __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
+    __shared__ ResetScratch sc;
+    const u32 count = pend.ctr[2];
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) wave_reset_game(c, pend.resets[r], rec, sc, threadIdx.x, mpk, max_trades);
+}
+// catan_reset: every game (sel == nullptr) or the selected ones.
+__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
+    __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
+    __shared__ ResetScratch sc;
+    for (long e = blockIdx.x; e < c.N; e += gridDim.x) {
+        if (sel != nullptr && (e >= c.n || sel[e] == 0)) continue;
+        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sort by action type
+// Counting sort of the games by the type of the action they are about to take (14 bins: 13 types + no-op/padding), so
+// that k_step's waves are type-homogeneous: the 13-way `switch` no longer serialises inside a wave.  The order inside
+// a bin is irrelevant (games are independent), so block ranges are reserved with atomics.
+DEVI int action_bin(const Ctx& c, const i32* __restrict__ actions, long e) {
+    if (e >= c.n) return 13;
+    const int t = actions[e * ACTION_WORDS];
+    return (t < 0 || t > 12) ? 13 : t;
+}
+__global__ __launch_bounds__(BLOCK) void k_classify_hist(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr) {
+    __shared__ u32 hist[16];
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e < c.N) atomicAdd(&hist[action_bin(c, actions, e)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&ctr[16 + threadIdx.x], hist[threadIdx.x]);
+}
+__global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr,
+                                                           i32* __restrict__ perm) {
+    __shared__ u32 hist[16], base[16];
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    int bin = 0;
+    u32 rank = 0;
+    if (e < c.N) { bin = action_bin(c, actions, e); rank = atomicAdd(&hist[bin], 1u); }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+        u32 start = 0;
+        for (int b = 0; b < (int)threadIdx.x; b++) start += ctr[16 + b];
+        base[threadIdx.x] = start + (hist[threadIdx.x] ? atomicAdd(&ctr[32 + threadIdx.x], hist[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (e < c.N) perm[base[bin] + rank] = (i32)e;
 }
 
 // ------------------------------------------------------------------------------------------------ random policy
@@ -1437,7 +1581,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     if (s.e >= c.n) return;
     u32 m[MASK_WORDS];
 #pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[(long)i * c.N + s.e];
+    for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
     u64 id = c.env_id0 + (u64)s.e;
     u32 w[8];
     {
@@ -1502,7 +1646,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     default: break;
     }
 #pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) actions[(long)i * c.n + s.e] = a[i];
+    for (int i = 0; i < ACTION_WORDS; i++) actions[s.e * ACTION_WORDS + i] = a[i];
 }
 
 // ------------------------------------------------------------------------------------------------ deciding seat

@@ -1,14 +1,17 @@
-// catan_state.h - packed struct-of-arrays game state in HBM (one game per lane).
+// catan_state.h - packed per-game state records in HBM.
 //
-// Layout: one allocation per handle, `N` = number of games padded to a multiple of 256.
-//   u32 rows  R[NROWS][N]
-//     rows 0 .. NW-1            : 32-bit fields (bitboards: corners 54 bit, edges 72 bit; packed estimates; counters)
-//     rows NW .. NW+NB/4-1      : byte fields, four per word: byte field b of game e lives at byte (b&3) of word
-//                                 row NW + (b>>2)  ->  byte address ((NW + (b>>2))*N + e)*4 + (b&3)
-// The 64 lanes of a wave therefore touch one 256 B segment per row access, and a whole wave-tile of the HOT rows
-// (rows 0 .. ROWS_HOT-1, everything but the ordered dev-card lists and the pile) is 112 coalesced 256 B loads -
-// that tile is what k_step stages in LDS ([row][lane], conflict-free) for the duration of a step.
-// 676 B per game in total (the reference-like int32 form of the same state is 736 words = 2944 B, spec.py).
+// Layout: one allocation per handle, game-major ("array of records"): game e owns the REC = 176 words
+// R[e*REC .. e*REC+175] = 704 B = exactly 11 cache lines (64 B), 64 B aligned.
+//     words 0 .. NW-1           : 32-bit fields (bitboards: corners 54 bit, edges 72 bit; packed estimates; counters)
+//     bytes from word NW on     : byte fields, byte field b at byte offset 4*NW + b of the record
+//     words 0 .. ROWS_HOT-1     : the HOT part = the first 7 cache lines (448 B): everything but the ordered dev-card
+//                                 lists and the pile
+// A record being contiguous is what lets a wave gather 64 ARBITRARY games at full line efficiency - k_step processes
+// games sorted by action type (type-homogeneous waves) and stages their hot parts into an LDS tile transposed to
+// tile[word][slot] (row stride 65 words: odd, so both the transposing writes and the lane-per-game reads are bank
+// conflict free).  Lane-per-game kernels that touch little state (masks, sampler, export) address the records directly.
+// 676 B of the 704 are used (the reference-like int32 form of the same state is 736 words = 2944 B, spec.py).
+// The per-game side buffers are game-major too: actions int32 [n][18], rewards float [n][4], packed masks u32 [N][16].
 //
 // Players are indexed by pid0 = PlayerId-1 (0 White, 1 Blue, 2 Orange, 3 Red; reference game/enums.py:8-12).
 // Resources r0 = Resource-1 (0 Brick, 1 Wood, 2 Ore, 3 Sheep, 4 Wheat; game/enums.py:22-28).
@@ -92,10 +95,14 @@ constexpr int B_CARDS = 208;      // + p*50 : hidden_cards[25] (ordered) then vi
 constexpr int NB = B_CARDS + 4 * 50;        // 408
 static_assert(B_HOT % 4 == 0 && NB % 4 == 0, "byte fields are packed four per word row");
 
-constexpr int ROWS_HOT = NW + B_HOT / 4;    // 112
-constexpr int NROWS = NW + NB / 4;          // 169
-constexpr int STATE_BYTES_PER_GAME = NROWS * 4;
-static_assert(STATE_BYTES_PER_GAME == 676 && ROWS_HOT == 112, "restate DESIGN.md byte table when the layout changes");
+constexpr int ROWS_HOT = NW + B_HOT / 4;    // 112 words = 7 cache lines
+constexpr int NROWS = NW + NB / 4;          // 169 words used
+constexpr int REC = 176;                    // words per game record (704 B = 11 cache lines)
+constexpr int TS = 65;                      // LDS tile row stride in words (odd: conflict-free transposition)
+constexpr int MPK_STRIDE = 16;              // packed masks: 11 words used of a 64 B line per game
+constexpr int STATE_BYTES_PER_GAME = REC * 4;
+static_assert(NROWS * 4 == 676 && ROWS_HOT == 112 && ROWS_HOT * 4 % 64 == 0 && REC >= NROWS && REC * 4 % 64 == 0,
+              "restate DESIGN.md byte table when the layout changes");
 
 // B_FLAGS bits
 constexpr int F_INITIAL = 1, F_ROLLED = 2, F_PLAYED_DEV = 4, F_MUST_USE_DEV = 8, F_MUST_RESPOND = 16,

@@ -43,7 +43,7 @@ class VecCatanEnv(object):
         with torch.cuda.device(self.device):
             _lib.check(self.L.catan_create(C.byref(h), self.device.index or 0, self.n, seed, env_id0, C.byref(cfg)))
         self.h = h
-        self.reward = torch.zeros((4, self.n), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros((self.n, 4), dtype=torch.float32, device=self.device)
         self.done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
 
     def close(self):
@@ -65,10 +65,10 @@ class VecCatanEnv(object):
         _lib.check(self.L.catan_reset(self.h, _ptr(m), _stream()))
 
     def step(self, actions):
-        """actions: int32 [18][n] (head-major).  Returns (reward [4][n] float32, done [n] uint8) - views of
-        buffers owned by the env, overwritten by the next step."""
+        """actions: int32 [n][18] (a negative type = no-op).  Returns (reward [n][4] float32 indexed by PlayerId-1,
+        done [n] uint8) - views of buffers owned by the env, overwritten by the next step."""
         a = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        assert a.shape == (spec.ACTION_WORDS, self.n), a.shape
+        assert a.shape == (self.n, spec.ACTION_WORDS), a.shape
         _lib.check(self.L.catan_step(self.h, _ptr(a), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.reward, self.done
 
@@ -91,7 +91,7 @@ class VecCatanEnv(object):
 
     def sample_random_actions(self, step_idx, out=None):
         if out is None:
-            out = torch.empty((spec.ACTION_WORDS, self.n), dtype=torch.int32, device=self.device)
+            out = torch.empty((self.n, spec.ACTION_WORDS), dtype=torch.int32, device=self.device)
         _lib.check(self.L.catan_sample_random_actions(self.h, int(step_idx), _ptr(out), _stream()))
         return out
 
@@ -100,9 +100,9 @@ class VecCatanEnv(object):
 
     def random_rollout_timed(self, step_idx0, steps):
         """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream)."""
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 5)()
         _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), _stream(), ms))
-        return dict(zip(("k_sample_random", "k_step", "k_lr_heavy", "k_step_finish"), [float(x) for x in ms]))
+        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr", "k_step_finish"), [float(x) for x in ms]))
 
     def export_state(self, env_idx=None):
         """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""
@@ -230,11 +230,11 @@ class EnvWrapper(object):
             v = np.asarray(action[h]).reshape(-1)
             flat[off:off + min(ln, len(v))] = v[:ln]
         bad0 = self.vec.invalid_action_count() if self.validate_actions else 0
-        reward, done = self.vec.step(torch.from_numpy(flat).view(spec.ACTION_WORDS, 1))
+        reward, done = self.vec.step(torch.from_numpy(flat).view(1, spec.ACTION_WORDS))
         self._cache = None
         if self.validate_actions and self.vec.invalid_action_count() != bad0:
             raise RuntimeError("invalid action (its legal-action mask bit is clear)")   # reference env/wrapper.py:38-41
-        r = reward[:, 0].cpu().numpy()
+        r = reward[0].cpu().numpy()
         rew = {pid: float(r[pid - 1]) for pid in (1, 2, 3, 4)}
         return self._get_obs(), rew, bool(done[0].item()), {"log": None}
 

@@ -113,12 +113,12 @@ class RolloutCollector(object):
             masks = env.get_action_masks()                                                  # :83
             pol = self.policy_of_pid[ar, deciding - 1]
             actions, logp = self._act(f, lists, lens, masks, pol)                           # :85
-            a_env = actions.t().contiguous().to(torch.int32)
-            a_env[0] = torch.where(frozen, torch.full_like(a_env[0], -1), a_env[0])         # frozen games: no-op
+            a_env = actions.to(torch.int32)
+            a_env[:, 0] = torch.where(frozen, torch.full_like(a_env[:, 0], -1), a_env[:, 0])   # frozen games: no-op
             reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
             live = ~frozen
             done = done.bool() & live
-            self.racc += reward.t() * live[:, None]                                         # :94-95
+            self.racc += reward * live[:, None]                                         # :94-95
             was_active = (deciding == self.active_pid) & live
             idx = was_active.nonzero(as_tuple=True)[0]                                      # :102-105
             if idx.numel():

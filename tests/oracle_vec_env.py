@@ -35,14 +35,14 @@ class OracleVecEnv(object):
 
     def step(self, actions):
         a = actions.numpy().astype(np.int32)
-        rew = np.zeros((4, self.n), dtype=np.float32); done = np.zeros((self.n,), dtype=np.uint8)
+        rew = np.zeros((self.n, 4), dtype=np.float32); done = np.zeros((self.n,), dtype=np.uint8)
         for i in range(self.n):
-            if a[0, i] < 0:
+            if a[i, 0] < 0:
                 continue
-            ai = np.ascontiguousarray(a[:, i]); r = np.zeros(4, dtype=np.float32); d = C.c_int(0)
+            ai = np.ascontiguousarray(a[i]); r = np.zeros(4, dtype=np.float32); d = C.c_int(0)
             assert self.L.orc_action_is_legal(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32))), (i, ai)
             self.L.orc_step(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32)), r.ctypes.data_as(C.POINTER(C.c_float)), C.byref(d))
-            rew[:, i] = r; done[i] = d.value
+            rew[i] = r; done[i] = d.value
             self.steps_taken[i] += 1
             if d.value:
                 self.L.orc_game_reset(self.b.env_ptr(i))

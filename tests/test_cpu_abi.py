@@ -25,7 +25,7 @@ def test_layout_constants_agree():
     assert L.catan_mask_words() == spec.MASK_WORDS
     assert L.catan_action_words() == spec.ACTION_WORDS
     assert L.catan_obs_floats() == spec.OBS_FLOATS
-    assert L.catan_state_bytes_per_game() == 676
+    assert L.catan_state_bytes_per_game() == 704
 
 
 def test_no_device_fails_loudly():

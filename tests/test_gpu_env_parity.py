@@ -72,10 +72,10 @@ def test_step_api_rewards_and_done(oracle, hip_lib):
         import ctypes as C
         for i in range(n):
             e = ob.env_ptr(i)
-            ai = np.ascontiguousarray(acts[:, i])
+            ai = np.ascontiguousarray(acts[i])
             orew = np.zeros(4, dtype=np.float32); od = C.c_int(0)
             ob.L.orc_step(e, ai.ctypes.data_as(C.POINTER(C.c_int32)), orew.ctypes.data_as(C.POINTER(C.c_float)), C.byref(od))
-            assert np.array_equal(orew, rew[:, i]) and bool(od.value) == bool(done[i]), (t, i, orew, rew[:, i])
+            assert np.array_equal(orew, rew[i]) and bool(od.value) == bool(done[i]), (t, i, orew, rew[i])
             if od.value:
                 ndone += 1
                 ob.L.orc_game_reset(e)
@@ -104,8 +104,8 @@ def test_export_import_roundtrip(oracle, hip_lib):
 def test_validate_rejects_illegal_action(hip_lib):
     import torch
     env = _env(8, 1)
-    a = torch.zeros((spec.ACTION_WORDS, 8), dtype=torch.int32)
-    a[0] = 9          # RollDice during initial placement is illegal
+    a = torch.zeros((8, spec.ACTION_WORDS), dtype=torch.int32)
+    a[:, 0] = 9          # RollDice during initial placement is illegal
     before = env.export_state().cpu().numpy()
     env.step(a)
     assert env.invalid_action_count() == 8

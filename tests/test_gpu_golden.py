@@ -38,9 +38,9 @@ def test_trajectory_vs_reference(hip_lib, name):
         if step in sample:
             assert int(env.deciding_player()[0].item()) == int(t["deciding"][step])
             assert np.array_equal(blob, t["sample_blob"][sample[step]].astype(np.int32))
-        a = torch.from_numpy(t["actions"][step].astype(np.int32)).view(spec.ACTION_WORDS, 1)
+        a = torch.from_numpy(t["actions"][step].astype(np.int32)).view(1, spec.ACTION_WORDS)
         rew, done = env.step(a)
-        assert np.array_equal(rew[:, 0].cpu().numpy(), t["rewards"][step]) and bool(done[0].item()) == bool(t["dones"][step]), step
+        assert np.array_equal(rew[0].cpu().numpy(), t["rewards"][step]) and bool(done[0].item()) == bool(t["dones"][step]), step
     assert env.invalid_action_count() == 0
     assert np.array_equal(env.export_state()[0].cpu().numpy(), t["final_blob"])
 

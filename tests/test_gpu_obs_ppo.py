@@ -122,7 +122,6 @@ def test_longest_road_heavy_tier_matches_oracle(oracle, hip_lib):
     base.run_random(40)                                  # past initial placement for most games
     blobs = base.export()
     po = spec.STATE_OFFSETS
-    acts = np.zeros((spec.ACTION_WORDS, n), dtype=np.int32)
     keep = []
     for i in range(n):
         b = blobs[i]
@@ -145,24 +144,24 @@ def test_longest_road_heavy_tier_matches_oracle(oracle, hip_lib):
     env = _env(len(keep), 0, auto_reset=False)
     env.import_state(blobs)
     masks = env.get_action_masks().cpu().numpy()
-    acts = np.zeros((spec.ACTION_WORDS, len(keep)), dtype=np.int32)
+    acts = np.zeros((len(keep), spec.ACTION_WORDS), dtype=np.int32)
     orcs = []
     for j in range(len(keep)):
         o = oracle.OracleEnv(0, j); o.import_(blobs[j]); orcs.append(o)
         assert np.array_equal(o.masks(), masks[j])
         road = np.flatnonzero(masks[j][spec.MASK_OFFSETS[2]:spec.MASK_OFFSETS[2] + 72])
         if masks[j][1] > 0 and len(road):
-            acts[0, j] = 1; acts[2, j] = road[0]
+            acts[j, 0] = 1; acts[j, 2] = road[0]
         else:
-            acts[0, j] = 10                                                   # EndTurn
+            acts[j, 0] = 10                                                   # EndTurn
     rew, done = env.step(torch.from_numpy(acts))
     got = env.export_state().cpu().numpy()
     nroad = 0
     for j, o in enumerate(orcs):
-        orew, odone = o.step(acts[:, j])
-        nroad += int(acts[0, j] == 1)
+        orew, odone = o.step(acts[j])
+        nroad += int(acts[j, 0] == 1)
         assert np.array_equal(got[j], o.export()), spec.describe_state_diff(o.export(), got[j])
-        assert np.array_equal(rew[:, j].cpu().numpy(), orew) and bool(done[j].item()) == odone
+        assert np.array_equal(rew[j].cpu().numpy(), orew) and bool(done[j].item()) == odone
     assert nroad >= 8 and env.invalid_action_count() == 0
 
 

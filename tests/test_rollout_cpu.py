@@ -34,17 +34,17 @@ def _sequential_manager(env, policy, active_pid, T, state):
         dec = env.deciding_player(); f, lists, lens = env.get_obs(); masks = env.get_action_masks()
         _, a, lp = policy.act(f, lists, lens, masks)
         frozen = [len(state["obs"][i]) >= T + 1 for i in range(n)]
-        a_env = a.t().contiguous().to(torch.int32)
+        a_env = a.to(torch.int32)
         for i in range(n):
             if frozen[i]:
-                a_env[0, i] = -1
+                a_env[i, 0] = -1
         rew, done = env.step(a_env)
         ndec = env.deciding_player(); nf, nlists, nlens = env.get_obs()
         for i in range(n):
             if frozen[i]:
                 continue
             act = active_pid[i]
-            racc[i] += rew[:, i].numpy()
+            racc[i] += rew[i].numpy()
             d = bool(done[i])
             reward_updated = False
             if int(dec[i]) == act:
