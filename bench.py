@@ -33,7 +33,9 @@ ALGO_BYTES = {
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
     "k_classify": 4 + 4,                            # action type in, permutation out
     "k_lr": 0,                                      # longest-road tiers: LDS/ALU only (3 bitboard words per request)
+    "k_lr_heavy": 0,
     "k_step_finish": 0,                             # completes the ~3 % of games that placed a road / settlement
+    "k_reset_list": 0,                              # ~0.1 % of games per step end and are re-dealt
 }
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -71,6 +73,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true", help="skip the mask-bit legality check in k_step")
+    ap.add_argument("--window", type=int, default=0,
+                    help="0: lock-step loop; W > 0: deferred loop, slow path (longest road, re-deal) once per W iterations")
     args = ap.parse_args()
 
     import torch
@@ -86,20 +90,33 @@ def main():
     env_id0, n = cdist.shard(rank, args.envs)                # global game ids: results do not depend on `world`
     env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0, validate_actions=not args.no_validate, auto_reset=True)
 
-    env.random_rollout(0, args.warmup)
-    cdist.barrier()
-    t0 = time.perf_counter()
-    env.random_rollout(args.warmup, args.steps)
-    cdist.barrier()
-    dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
+    if args.window > 0:
+        env.random_rollout_deferred(args.warmup, args.window)
+        c0 = int(env.policy_counters().sum())
+        cdist.barrier()
+        t0 = time.perf_counter()
+        env.random_rollout_deferred(args.steps, args.window)
+        cdist.barrier()
+        dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
+        env_steps = cdist.sum_over_ranks(int(env.policy_counters().sum()) - c0)   # decisions actually executed
+    else:
+        env.random_rollout(0, args.warmup)
+        cdist.barrier()
+        t0 = time.perf_counter()
+        env.random_rollout(args.warmup, args.steps)
+        cdist.barrier()
+        dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
+        env_steps = world * n * args.steps
     bad = env.invalid_action_count()
 
     out = None
     if rank == 0:
         # per-kernel durations: HIP events on the launch stream, a separate short pass right after the timed region
         prof_steps = min(args.steps, 512)
-        kms = env.random_rollout_timed(args.warmup + args.steps, prof_steps)
-        per_launch_us = {k: v * 1e3 / prof_steps for k, v in kms.items() if k in ALGO_BYTES}
+        kms = env.random_rollout_timed(args.warmup + args.steps, prof_steps, args.window)
+        slow_launches = prof_steps if args.window <= 0 else -(-prof_steps // args.window)
+        launches = {k: (slow_launches if k in ("k_lr", "k_lr_heavy", "k_step_finish", "k_reset_list") else prof_steps) for k in kms}
+        per_launch_us = {k: v * 1e3 / launches[k] for k, v in kms.items() if k in ALGO_BYTES}
         dom = max(per_launch_us, key=per_launch_us.get)
         achieved = ALGO_BYTES[dom] * n / (per_launch_us[dom] * 1e-6) / 1e9
         total_us = sum(per_launch_us.values())
@@ -114,7 +131,7 @@ def main():
             "note": "integer/byte rules engine: latency- and divergence-bound, far below the HBM roofline by nature "
                     "(SURVEY.md 8(d)); frac is reported for the dominant kernel as the contract asks",
         }
-        value = world * n * args.steps / dt
+        value = env_steps / dt
         out = {
             "metric": "Catan env-steps/sec at 65k parallel games", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -96,10 +96,25 @@ int64_t catan_invalid_action_count(catan_env_t* env, catan_stream_t stream);
  * total_done (int64 device scalar, may be NULL) accumulates finished games. */
 int catan_random_rollout(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream);
 
-/* the same loop with a hipEvent pair around every kernel launch (recorded on `stream`); kernel_ms is a HOST
- * float[5] receiving the summed milliseconds of k_sample_random, the action-type sort (k_classify_*), k_step,
- * k_lr + k_lr_heavy, k_step_finish (bench.py roofline). */
-int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms);
+/* Deferred rollout: `iters` iterations of sample + step in which a game whose step needs the slow path (longest-road
+ * recomputation after a road / settlement, re-deal after a win) stays BUSY - takes no action and draws nothing from its
+ * policy stream - until the end of the current window of `window` iterations, when the slow path runs once for all of
+ * them.  Each game draws its policy words with its OWN decision counter (catan_policy_counters) instead of a global step
+ * index, so every game's trajectory is exactly the one the lock-step loop produces for that game after the same number of
+ * decisions (tests/test_gpu_env_parity.py); only the interleaving between games differs.  Returns with every game idle
+ * (the last window is closed).  Env-steps executed = sum of the counter increments. */
+int catan_random_rollout_deferred(catan_env_t* env, int64_t iters, int32_t window, catan_stream_t stream);
+/* per-game decision counters of the deferred rollout: read into / set from a DEVICE uint32[n] (in == NULL: zero them) */
+int catan_policy_counters(catan_env_t* env, uint32_t* out, catan_stream_t stream);
+int catan_set_policy_counters(catan_env_t* env, const uint32_t* in, catan_stream_t stream);
+/* tier-1 longest-road search budget (iterations) before a request is handed to tier 2: lock-step / deferred mode */
+int catan_set_lr_budgets(catan_env_t* env, int32_t lockstep, int32_t deferred);
+
+/* the rollout loops with a hipEvent around every kernel launch (recorded on `stream`); window <= 0: the lock-step
+ * loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST
+ * float[7] receiving the summed milliseconds of k_sample_random, the action-type sort (k_classify_*), k_step,
+ * k_lr, k_lr_heavy, k_step_finish, k_reset_list (bench.py roofline). */
+int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms);
 
 /* EnvWrapper._get_obs(): env/wrapper.py:52-83 (+ _get_tile_features :491-524, _get_player_inputs :526-709), batched.
  * out_f: float32 [n][1787] in the order proposed_trade[12] current_resources[6] tile_representations[19][60]

@@ -1212,6 +1212,36 @@ int64_t orc_batch_run_random(OrcEnv* envs, int64_t n, uint64_t seed, uint64_t en
     return n * steps;
 }
 
+/* The same loop with a per-game number of decisions: game i takes counts[i] steps, its policy stream indexed by its own
+ * decision number start[i] + s (start == NULL: 0).  Checker of the deferred rollout (catan_random_rollout_deferred),
+ * where games advance at different rates but each along the lock-step trajectory. */
+int64_t orc_batch_run_random_counts(OrcEnv* envs, int64_t n, uint64_t seed, uint64_t env_id0, const uint32_t* start,
+                                    const uint32_t* counts, int32_t* blobs, int64_t* n_games, int n_threads) {
+    int64_t games = 0, total = 0;
+    orc_topology();
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : games, total)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        float m[ORC_MASK_WORDS], rew[4];
+        int32_t a[ORC_ACTION_WORDS];
+        int done;
+        uint32_t s0 = start ? start[i] : 0u;
+        for (uint32_t s = 0; s < counts[i]; s++) {
+            orc_masks(&envs[i], m);
+            orc_sample_action(&envs[i], seed, env_id0 + (uint64_t)i, s0 + s, m, a);
+            orc_step(&envs[i], a, rew, &done);
+            if (done) { games++; orc_game_reset(&envs[i]); }
+        }
+        total += counts[i];
+        if (blobs) orc_export(&envs[i], blobs + i * ORC_STATE_WORDS);
+    }
+    (void)n_threads;
+    if (n_games) *n_games += games;
+    return total;
+}
+
 /* ====================================================================== GAE + PPO loss */
 /* ref: RL/ppo/process_batch.py:134-142.  fp32 recurrences in the reference's evaluation order; the global
  * mean / unbiased std are accumulated in fp64 (torch reduces in fp32 with a different order: tolerance 1e-5). */

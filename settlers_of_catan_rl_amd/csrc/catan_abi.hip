@@ -30,8 +30,13 @@ struct catan_env {
     Pending pend;         // tier-2 longest-road hand-off (device arrays)
     unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
     int prof_on;
+    u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
+    int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
+    hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
+    hipEvent_t ev_fork, ev_join;
 };
 
+constexpr int LR_BUDGET_DEFERRED = 96;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                    \
@@ -126,16 +131,25 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.heavy, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)e->N * sizeof(i32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[0], (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[1], (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, (2 * PROF_PHASES + 4) * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
     HIPCHK(hipMemset(e->pend.ctr, 0, CTR_WORDS * sizeof(u32)));
     HIPCHK(hipMemset(e->pend.type, 0, (size_t)e->N));
+    HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
+    HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
+    e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
     e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
@@ -161,10 +175,16 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.req) hipFree(e->pend.req);
     if (e->pend.heavy) hipFree(e->pend.heavy);
     if (e->pend.perm) hipFree(e->pend.perm);
-    if (e->pend.resets) hipFree(e->pend.resets);
+    if (e->pend.resets[0]) hipFree(e->pend.resets[0]);
+    if (e->pend.resets[1]) hipFree(e->pend.resets[1]);
+    if (e->side) hipStreamDestroy(e->side);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->pend.type) hipFree(e->pend.type);
     if (e->pend.who) hipFree(e->pend.who);
     if (e->pend.len) hipFree(e->pend.len);
+    if (e->pend.busy) hipFree(e->pend.busy);
+    if (e->pctr) hipFree(e->pctr);
     delete e;
 }
 
@@ -182,34 +202,73 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.prof = e->prof_on ? e->prof : nullptr;
     return sc;
 }
-// One env step = counting sort of the games by action type (k_classify_*), k_step (fused: apply + done/reward +
-// auto-reset + next masks for every game that needs no longest-road update), then for the road/settlement placements:
-// k_lr (tier-1 path search, one request per wave), k_lr_heavy (tier 2), k_step_finish (compact completion), and
-// k_reset_list for the games that ended (one wave per game).
+// One env step = counting sort of the games by action type (k_classify_*), k_step (fused: apply + done/reward + next
+// masks for every game that needs no longest-road update) - the FAST path - then the SLOW path for the few games
+// that placed a road / settlement or ended: k_lr (tier-1 path search, one request per wave), k_lr_heavy (tier 2),
+// k_step_finish (compact completion), k_reset_list (one wave per finished game).  The slow path's launch times are
+// the latency tails of a handful of serial searches / re-deals.  Lock-step mode (catan_step, catan_random_rollout) runs
+// it inside every step.  Deferred mode (catan_random_rollout_deferred) runs it once per window of W steps: a game that
+// needs it stays busy (no action, no policy draw) until the window closes, so the tails are amortised over W steps;
+// every game's own trajectory is unchanged because its policy stream is indexed by its own decision counter.
 constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x LR_SPLIT parts are strided over them
-constexpr int LR_GRID = 2048;
-constexpr int RESET_GRID = 512;
-static int enqueue_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev) {
+constexpr int LR_GRID = 4096;
+constexpr int RESET_GRID = 2048;
+// ev (optional, 8 events): [0] before the sort, [1] after it, [2] after k_step
+static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev,
+                        bool new_window, bool carry) {
     StepCfg sc = step_cfg(e);
-    HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    if (new_window && !carry) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    else {
+        if (new_window) {
+            // deferred mode: the games that ended in k_step_finish wait in list ra^1; it becomes this window's list
+            HIPCHK(hipMemsetAsync(e->pend.ctr, 0, 2 * sizeof(u32), st));
+            HIPCHK(hipMemsetAsync(e->pend.ctr + 2 + e->pend.ra, 0, sizeof(u32), st));
+            e->pend.ra ^= 1;
+        }
+        HIPCHK(hipMemsetAsync(e->pend.ctr + 16, 0, (CTR_WORDS - 16) * sizeof(u32), st));      // the sort's bins only
+    }
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
     hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.perm);
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_lr, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->pend, sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+// ev (optional): [2] before k_lr, [6] after it, [3] after k_lr_heavy, [7] after k_step_finish, [4] after k_reset_list
+// The games that ended in k_step (list ra) are re-dealt on the side stream while the longest-road kernels run; those that
+// end in k_step_finish (list ra^1) are re-dealt afterwards (lock-step) or carried into the next window (carry).
+static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int lr_budget, bool carry) {
+    StepCfg sc = step_cfg(e);
+    const int ra = e->pend.ra, max_trades = e->cfg.max_proposed_trades_per_turn;
+    if (e->cfg.auto_reset) {
+        HIPCHK(hipEventRecord(e->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(e->pend.ctr + 2 + ra),
+                           (const i32*)e->pend.resets[ra], e->pend.busy, sc.prof);
+        HIPCHK(hipEventRecord(e->ev_join, e->side));
+    }
+    hipLaunchKernelGGL(k_lr, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->pend, lr_budget, sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
+    if (ev) HIPCHK(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)(e->pend.ctr + 1), (const u64*)e->pend.heavy, e->pend.len);
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
-    if (e->cfg.auto_reset)
-        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn, e->pend);
+    if (ev) HIPCHK(hipEventRecord(ev[7], st));
+    if (e->cfg.auto_reset) {
+        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
+        if (!carry)
+            hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(e->pend.ctr + 2 + (ra ^ 1)),
+                               (const i32*)e->pend.resets[ra ^ 1], e->pend.busy, sc.prof);
+    }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
 static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
-    return enqueue_step(e, actions, reward, done, st, nullptr);
+    int r = enqueue_fast(e, actions, reward, done, st, nullptr, true, false);
+    if (r != CATAN_OK) return r;
+    return enqueue_slow(e, reward, done, st, nullptr, e->lr_budget[0], false);
 }
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
@@ -240,7 +299,8 @@ int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
 
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
-    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions);
+    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
+                       (u32*)nullptr, (const u8*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -284,32 +344,87 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
     return CATAN_OK;
 }
 
-// Same loop as catan_random_rollout but with a hipEvent pair around every kernel launch (events recorded on
-// `stream`, the stream the kernels run on).  kernel_ms (host, float[4]) receives the summed elapsed
-// milliseconds of: [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr + k_lr_heavy  [4] k_step_finish.
-int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream, float* kernel_ms) {
+// One iteration of the deferred rollout: policy draw (per-game counters), fast path; the slow path when a window closes.
+static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
+    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
+                       e->pctr, (const u8*)e->pend.busy);
+    // the last window of a call also re-deals the games that ended in k_step_finish: the call returns with no busy game
+    const bool last = it + 1 == iters;
+    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, it % window == 0, it != 0);
+    if (r != CATAN_OK) return r;
+    if ((it + 1) % window == 0 || last) r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, ev, e->lr_budget[1], !last);
+    return r;
+}
+
+int catan_random_rollout_deferred(catan_env_t* e, int64_t iters, int32_t window, catan_stream_t stream) {
+    if (!e || iters < 0 || window <= 0) return fail(CATAN_EINVAL, "catan_random_rollout_deferred: bad arguments");
+    for (int64_t it = 0; it < iters; it++) {
+        int r = deferred_iter(e, it, iters, window, S(stream), nullptr);
+        if (r != CATAN_OK) return r;
+    }
+    return CATAN_OK;
+}
+
+int catan_policy_counters(catan_env_t* e, uint32_t* out, catan_stream_t stream) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_policy_counters: null argument");
+    HIPCHK(hipMemcpyAsync(out, e->pctr, (size_t)e->n * sizeof(u32), hipMemcpyDeviceToDevice, S(stream)));
+    return CATAN_OK;
+}
+
+int catan_set_policy_counters(catan_env_t* e, const uint32_t* in, catan_stream_t stream) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_policy_counters: null handle");
+    if (in) HIPCHK(hipMemcpyAsync(e->pctr, in, (size_t)e->n * sizeof(u32), hipMemcpyDeviceToDevice, S(stream)));
+    else HIPCHK(hipMemsetAsync(e->pctr, 0, (size_t)e->N * sizeof(u32), S(stream)));
+    return CATAN_OK;
+}
+
+int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
+    if (!e || lockstep < 1 || deferred < 1) return fail(CATAN_EINVAL, "catan_set_lr_budgets: bad arguments");
+    e->lr_budget[0] = lockstep; e->lr_budget[1] = deferred;
+    return CATAN_OK;
+}
+
+// The rollout loops with a hipEvent around every kernel launch (events recorded on `stream`, the stream the kernels
+// run on).  window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host,
+// float[7]) receives the summed elapsed milliseconds of:
+// [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
+int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
-    const int K = 5;                       // events per step: before sort | before k_step | after k_step | after k_lr* | after finish
-    std::vector<hipEvent_t> ev((size_t)steps * (K + 1));
+    const int K = 8;                       // events per step, see enqueue_fast / enqueue_slow; [5] = before the sampler
+    std::vector<hipEvent_t> ev((size_t)steps * K);
     for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableSystemFence));   // no L2 flush between kernels
+    std::vector<char> slow((size_t)steps, 0);
     for (int64_t s = 0; s < steps; s++) {
-        hipEvent_t* v = &ev[(size_t)s * (K + 1)];
-        HIPCHK(hipEventRecord(v[5], st));
-        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s, e->scratch_actions);
-        int r = enqueue_step(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v);
+        hipEvent_t* v = &ev[(size_t)s * K];
+        int r;
+        if (window > 0) {
+            r = deferred_iter(e, s, steps, window, st, v);
+            slow[s] = ((s + 1) % window == 0 || s + 1 == steps);
+        } else {
+            HIPCHK(hipEventRecord(v[5], st));
+            hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s,
+                               e->scratch_actions, (u32*)nullptr, (const u8*)nullptr);
+            r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v, true, false);
+            if (r == CATAN_OK) r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, v, e->lr_budget[0], false);
+            slow[s] = 1;
+        }
         if (r != CATAN_OK) return r;
     }
     HIPCHK(hipStreamSynchronize(st));
-    for (int k = 0; k < 5; k++) kernel_ms[k] = 0.0f;
+    for (int k = 0; k < 7; k++) kernel_ms[k] = 0.0f;
     for (int64_t s = 0; s < steps; s++) {
-        hipEvent_t* v = &ev[(size_t)s * (K + 1)];
+        hipEvent_t* v = &ev[(size_t)s * K];
         float ms = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (+ counter memset)
         HIPCHK(hipEventElapsedTime(&ms, v[0], v[1])); kernel_ms[1] += ms;      // k_classify_hist + k_classify_scatter
         HIPCHK(hipEventElapsedTime(&ms, v[1], v[2])); kernel_ms[2] += ms;      // k_step
-        HIPCHK(hipEventElapsedTime(&ms, v[2], v[3])); kernel_ms[3] += ms;      // k_lr + k_lr_heavy
-        HIPCHK(hipEventElapsedTime(&ms, v[3], v[4])); kernel_ms[4] += ms;      // k_step_finish
+        if (!slow[s]) continue;
+        HIPCHK(hipEventElapsedTime(&ms, v[2], v[6])); kernel_ms[3] += ms;      // k_lr
+        HIPCHK(hipEventElapsedTime(&ms, v[6], v[3])); kernel_ms[4] += ms;      // k_lr_heavy
+        HIPCHK(hipEventElapsedTime(&ms, v[3], v[7])); kernel_ms[5] += ms;      // k_step_finish
+        HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[6] += ms;      // k_reset_list
     }
     for (auto& x : ev) hipEventDestroy(x);
     return CATAN_OK;

@@ -973,7 +973,8 @@ DEVI void update_largest_army(const S& s) {
 
 struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; int auto_reset;
                  unsigned long long* prof; };   // optional phase profile: [6] cycle sums then [6] per-wave maxima
-constexpr int PROF_PHASES = 8;    // stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back
+constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
+                                  // k_reset_list: 3 philox draws per re-deal, 4 re-deals, 5 serial shuffle time
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     if (cfg.prof == nullptr) return;
     long long t = wall_clock64();
@@ -986,9 +987,13 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 }
 
 // Per-step hand-off buffers (all device arrays).  ctr: [0] number of longest-road requests (= games whose step is
-// completed by k_step_finish), [1] number of tier-2 requests, [2] number of finished games to reset (k_reset_list),
+// completed by k_step_finish), [1] number of tier-2 requests, [2], [3] lengths of the two re-deal lists (k_reset_list),
 // [16..29] games per action-type bin, [32..45] bin cursors.
-struct Pending { u32* ctr; u64* req; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets; };
+// busy[e] != 0: game e is waiting for the slow path (longest-road completion or re-deal); it takes no action until the
+// slow path has run (same step in lock-step mode, end of the window in deferred mode).
+// Finished games go to one of two re-deal lists: k_step appends to list `ra`, k_step_finish to the other one, so that
+// list `ra` can be re-dealt (k_reset_list) concurrently with the longest-road kernels.
+struct Pending { u32* ctr; u64* req; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets[2]; u8* busy; int ra; };
 constexpr int CTR_WORDS = 64;
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
@@ -1000,14 +1005,13 @@ struct StepScratch { LrWave lr; ResetScratch rs; };
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e, u32* reset_count, i32* resets);
+                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist);
 
 template <class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e, u32* reset_count, i32* resets) {
+                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist) {
     const long e = s.e;
-    const bool doit_or_pad = doit || e >= c.n;       // padding games keep valid masks too
     {
         bool cut = false;
         int holder = 0, hcount = 0;
@@ -1048,7 +1052,6 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
             }
         }
     }
-    prof_mark(cfg, 3, tprof);
     // ---- done / rewards (wrapper.py:85-112)
     bool want_reset = false;
     if (doit) {
@@ -1082,12 +1085,11 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
         want_reset = dn && cfg.auto_reset;
         // RL/ppo/game_manager.py:112-113: the finished game is reset by k_reset_list (one wave per game: winning moves
         // cluster in a few action-type bins, inline resets would serialise inside those waves), which also writes its masks
-        if (want_reset) resets[atomicAdd(reset_count, 1u)] = (i32)s.e;
+        if (want_reset) pend.resets[rlist][atomicAdd(&pend.ctr[2 + rlist], 1u)] = (i32)s.e;
+        if (want_reset || lr_who >= 0) pend.busy[s.e] = want_reset ? 1 : 0;
     }
-    prof_mark(cfg, 4, tprof);
-    prof_mark(cfg, 5, tprof);
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
-    if (doit_or_pad && !want_reset) {
+    if (doit && !want_reset) {
         u32 m[MASK_WORDS];
         compute_masks(s, m, cfg.max_trades);
 #pragma unroll
@@ -1111,24 +1113,37 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int lane = threadIdx.x;
     const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
     long long tprof = cfg.prof ? wall_clock64() : 0;
+    const bool live = e < c.n;
+    // a negative type is an explicit no-op (frozen game), a busy game ignores its action: neither touches its record
+    int type = live ? actions[e * ACTION_WORDS] : -1;
+    if (type < 0 || type > 12 || pend.busy[e]) type = -1;
+    if (live && type < 0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) reward[e * 4 + p] = 0.0f;
+        done[e] = 0;
+    }
+    if (__ballot(type >= 0) == 0) return;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    stage_in(tile, c.R, (int)e, lane);
+    stage_in(tile, c.R, type >= 0 ? (int)e : -1, lane);
     __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
-    const bool live = s.e < c.n;
     int a[ACTION_WORDS];
 #pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = live ? actions[s.e * ACTION_WORDS + i] : 0;
-    int type = live ? a[0] : -1;
-    if (live && cfg.validate && type >= 0) {          // a negative type is an explicit no-op (frozen game), not an error
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = type >= 0 ? actions[e * ACTION_WORDS + i] : 0;
+    bool rejected = false;
+    if (cfg.validate && type >= 0) {
         u32 m[MASK_WORDS];
 #pragma unroll
         for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
-        if (!action_legal(s, m, a)) { atomicAdd(err, 1u); type = -1; }
+        if (!action_legal(s, m, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
     }
-    if (type < 0 || type > 12) type = -1;
+    if (rejected) {                                   // an illegal action leaves the game untouched (reward 0, not done)
+#pragma unroll
+        for (int p = 0; p < 4; p++) reward[e * 4 + p] = 0.0f;
+        done[e] = 0;
+    }
     // clamp indices so that an unvalidated bad action cannot touch memory outside the game's rows
     a[1] = min(max(a[1], 0), 53); a[2] = min(max(a[2], 0), 72); a[3] = min(max(a[3], 0), 18);
     a[4] = min(max(a[4], 0), 4); a[6] = min(max(a[6], 0), 2);
@@ -1421,17 +1436,18 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         pend.req[slot] = (u64)e | ((u64)lr_who << 56);
         pend.type[e] = (u8)(type + 1);
         pend.who[e] = (u8)lr_who;
+        pend.busy[e] = 1;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step(c, s, scratch, cfg, lane, live && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e, &pend.ctr[2], pend.resets);
+    finish_step(c, s, scratch, cfg, lane, type >= 0 && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra);
     // ---- write the tile back
     __builtin_amdgcn_wave_barrier();
-    stage_out(tile, c.R, (int)e, lane);
+    stage_out(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     prof_mark(cfg, 7, tprof);
 }
 
 // tier 1 of the longest road, one request per wave (all 64 lanes cooperate); overflow goes to the tier-2 list.
-__global__ __launch_bounds__(64) void k_lr(Ctx c, Pending pend, unsigned long long* stat) {
+__global__ __launch_bounds__(64) void k_lr(Ctx c, Pending pend, int budget, unsigned long long* stat) {
     __shared__ LrWave L;
     const int lane = threadIdx.x;
     u32 nbr_c, nbr_e;
@@ -1442,7 +1458,7 @@ __global__ __launch_bounds__(64) void k_lr(Ctx c, Pending pend, unsigned long lo
         const long e = (long)(rq & 0x00FFFFFFFFFFFFFFull);
         const int who = (int)(rq >> 56);
         St s(c.R, c.N, e);
-        const int len = coop_longest_path(lane == 0, s, who, L, LR_BUDGET, nbr_c, nbr_e, stat);
+        const int len = coop_longest_path(lane == 0, s, who, L, budget, nbr_c, nbr_e, stat);
         if (lane == 0) {
             if (len < 0) { const u32 slot = atomicAdd(&pend.ctr[1], 1u); pend.heavy[slot] = rq; pend.len[e] = 0; }
             else pend.len[e] = len;
@@ -1473,7 +1489,7 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     const int len = doit ? pend.len[e] : 0;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, &pend.ctr[2], pend.resets);
+    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra ^ 1);
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (int)e, lane);
 }
@@ -1481,7 +1497,8 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
 // One wave resets one game: the 64 lanes generate the game's next RND_WORDS Philox draws into LDS, lane 0 runs the
 // (inherently serial) shuffles of Board.reset / Game.reset on the game's hot record held linearly in LDS, then computes
 // the masks of the fresh game.
-DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, int max_trades) {
+DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, int max_trades, u8* busy,
+                           unsigned long long* prof = nullptr) {
     __builtin_amdgcn_wave_barrier();
     if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
     __builtin_amdgcn_wave_barrier();
@@ -1500,7 +1517,14 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
     if (lane == 0) {
         RngBuf rb;
         rb.buf = sc.rnd; rb.base = blk0 * 4; rb.avail = RND_WORDS; rb.slow = mine;
+        const long long t0 = prof ? wall_clock64() : 0;
         reset_game_lds(s, rb, sc, ROWS_HOT);
+        if (prof) {
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
+            atomicAdd(&prof[5], dt); atomicMax(&prof[PROF_PHASES + 5], dt);
+            atomicAdd(&prof[3], (unsigned long long)(rb.slow.draws - mine.draws)); atomicMax(&prof[PROF_PHASES + 3], (unsigned long long)(rb.slow.draws - mine.draws));
+            atomicAdd(&prof[4], 1ull);
+        }
         if (mpk != nullptr) {
             u32 m[MASK_WORDS];
             compute_masks(s, m, max_trades);
@@ -1510,13 +1534,15 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+    if (lane == 0 && busy != nullptr) busy[e] = 0;
 }
 // Resets the games this step finished (RL/ppo/game_manager.py:112-113), one wave per game.
-__global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, Pending pend) {
+__global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
+                                                   const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     __shared__ ResetScratch sc;
-    const u32 count = pend.ctr[2];
-    for (u32 r = blockIdx.x; r < count; r += gridDim.x) wave_reset_game(c, pend.resets[r], rec, sc, threadIdx.x, mpk, max_trades);
+    const u32 count = *count_p;
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, max_trades, busy, prof);
 }
 // catan_reset: every game (sel == nullptr) or the selected ones.
 __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
@@ -1524,7 +1550,7 @@ __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel)
     __shared__ ResetScratch sc;
     for (long e = blockIdx.x; e < c.N; e += gridDim.x) {
         if (sel != nullptr && (e >= c.n || sel[e] == 0)) continue;
-        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, 0);
+        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, 0, nullptr);
     }
 }
 
@@ -1576,9 +1602,18 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
     return nth_set(v, (int)__umulhi(w, (u32)k));
 }
 // DESIGN.md "random policy": philox stream 1, blocks 2*step_idx and 2*step_idx+1 -> words w0..w7
-__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions) {
+// pctr == nullptr: every game draws with the caller's step_idx (lock-step rollouts).  Otherwise game e draws with its own
+// decision counter pctr[e] (advanced here) and a busy game gets the no-op action: its trajectory does not depend on when
+// it is scheduled (deferred rollouts).
+__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
+                                                        u32* __restrict__ pctr, const u8* __restrict__ busy) {
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.n) return;
+    if (pctr != nullptr) {
+        if (busy[s.e]) { actions[s.e * ACTION_WORDS] = -1; return; }
+        step_idx = pctr[s.e];
+        pctr[s.e] = step_idx + 1;
+    }
     u32 m[MASK_WORDS];
 #pragma unroll
     for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];

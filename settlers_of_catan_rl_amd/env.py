@@ -98,11 +98,29 @@ class VecCatanEnv(object):
     def random_rollout(self, step_idx0, steps):
         _lib.check(self.L.catan_random_rollout(self.h, int(step_idx0), int(steps), _stream()))
 
-    def random_rollout_timed(self, step_idx0, steps):
-        """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream)."""
-        ms = (C.c_float * 5)()
-        _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), _stream(), ms))
-        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr", "k_step_finish"), [float(x) for x in ms]))
+    def random_rollout_deferred(self, iters, window):
+        """`iters` iterations of the deferred loop (include/catan_hip.h): games that need the slow path (longest road,
+        re-deal) sit out until their window of `window` iterations closes; per-game trajectories are the lock-step ones."""
+        _lib.check(self.L.catan_random_rollout_deferred(self.h, int(iters), int(window), _stream()))
+
+    def policy_counters(self):
+        """-> int64 [n]: decisions taken by every game in deferred rollouts (its policy-stream index)"""
+        out = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_policy_counters(self.h, _ptr(out), _stream()))
+        return out.long() & 0xFFFFFFFF
+
+    def set_policy_counters(self, counters=None):
+        c = None if counters is None else torch.as_tensor(counters, device=self.device).to(torch.int32).contiguous()
+        _lib.check(self.L.catan_set_policy_counters(self.h, _ptr(c), _stream()))
+
+    def set_lr_budgets(self, lockstep, deferred):
+        _lib.check(self.L.catan_set_lr_budgets(self.h, int(lockstep), int(deferred)))
+
+    def random_rollout_timed(self, step_idx0, steps, window=0):
+        """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream); window > 0: the deferred loop."""
+        ms = (C.c_float * 7)()
+        _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), int(window), _stream(), ms))
+        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr", "k_lr_heavy", "k_step_finish", "k_reset_list"), [float(x) for x in ms]))
 
     def export_state(self, env_idx=None):
         """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""

@@ -48,6 +48,9 @@ def lib():
         L.orc_batch_create.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64]
         L.orc_batch_run_random.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, i32p, i64p, C.c_int]
         L.orc_batch_run_random.restype = C.c_int64
+        u32p = C.POINTER(C.c_uint32)
+        L.orc_batch_run_random_counts.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, u32p, u32p, i32p, i64p, C.c_int]
+        L.orc_batch_run_random_counts.restype = C.c_int64
         L.orc_gae.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_double, C.c_double, f32p, f32p]
         L.orc_ppo_loss.argtypes = [f32p] * 6 + [C.c_int64, C.c_float, f32p, f32p, f32p, f32p, C.c_float]
         _lib = L
@@ -154,6 +157,16 @@ class OracleBatch(object):
         self.L.orc_batch_run_random(self.p, self.n, self.seed, self.env_id0, self.step_idx, steps,
                                     _p(blobs, C.c_int32) if want_blobs else None, C.byref(self.games), n_threads)
         self.step_idx += steps
+        return blobs
+
+    def run_random_counts(self, counts, start=None, n_threads=0):
+        """game i takes counts[i] decisions, its policy stream indexed by its own decision number (start[i] + s)"""
+        blobs = np.zeros((self.n, STATE_WORDS), dtype=np.int32)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        start = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
+        self.L.orc_batch_run_random_counts(self.p, self.n, self.seed, self.env_id0,
+                                           _p(start, C.c_uint32) if start is not None else None, _p(counts, C.c_uint32),
+                                           _p(blobs, C.c_int32), C.byref(self.games), n_threads)
         return blobs
 
     def export(self):

@@ -54,6 +54,32 @@ def test_random_rollout_state_parity(oracle, hip_lib, n, steps, seed):
     assert ob.games.value > 0 or steps < 1500
 
 
+@pytest.mark.parametrize("n,iters,window,seed", [(1024, 3000, 8, 0), (300, 1500, 1, 5), (4096, 2500, 32, 9)])
+def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, seed):
+    """The deferred loop lets games that need the slow path sit out until their window closes.  Every game must still
+    follow its lock-step trajectory: after the rollout, game i has taken counters[i] decisions and its state (and masks)
+    must equal the oracle's after exactly that many decisions of the same policy stream."""
+    env = _env(n, seed)
+    ob = oracle.OracleBatch(n, seed)
+    total = np.zeros(n, dtype=np.int64)
+    for chunk in (window + 3, iters - window - 3):              # two calls: the counters continue across calls
+        env.random_rollout_deferred(chunk, window)
+        cnt = env.policy_counters().cpu().numpy()
+        step = cnt - total
+        assert step.min() >= 0 and step.max() <= chunk
+        o = ob.run_random_counts(step, start=total)
+        total = cnt
+        _assert_blobs_equal(env.export_state().cpu().numpy(), o, f"state after {chunk} deferred iterations")
+        assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+    assert env.invalid_action_count() == 0
+    if window == 1:
+        # window 1 is the lock-step schedule, except that a game won through the longest road sits out one iteration
+        assert total.max() == iters and total.min() >= iters - 16
+    else:
+        assert total.max() <= iters and total.mean() > 0.5 * iters
+    assert ob.games.value > 0
+
+
 def test_step_api_rewards_and_done(oracle, hip_lib):
     """Per-step API: device sampler -> catan_step; rewards/done/deciding player against the oracle."""
     import torch

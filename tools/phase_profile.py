@@ -9,7 +9,7 @@ from settlers_of_catan_rl_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
-names = ["stage-in", "validate+apply", "tier-1 longest road", "holder logic (+cut)", "done/reward", "reset", "masks", "write-back"]
+names = ["stage-in", "validate+apply", "LR request push", None, None, None, "holder+done/reward+masks", "write-back"]
 NP = len(names)
 done = 0
 for upto, chunk in [(128, 128), (3000, 256)]:
@@ -22,5 +22,9 @@ for upto, chunk in [(128, 128), (3000, 256)]:
     waves = (n + 63) // 64
     print(f"--- steps {upto-chunk}..{upto}: mean us per wave-step | max us over all waves/steps (100 MHz ticks)")
     for i, nm in enumerate(names):
+        if nm is None:
+            continue
         print(f"  {nm:20s} mean {out[i] / (waves * chunk) / 100.0:9.2f} us   max {out[NP + i] / 100.0:9.2f} us")
+    nres = max(1, out[4])
+    print(f"  re-deals {out[4]} ({out[4]/chunk:.1f}/step): philox draws mean {out[3]/nres:.0f} max {out[NP+3]}; serial shuffle time mean {out[5]/nres/100.0:.1f} us max {out[NP+5]/100.0:.1f} us")
     print(f"  tier-1 requests {out[2*NP]} ({out[2*NP]/(waves*chunk):.2f}/wave-step), loop iterations {out[2*NP+1]} ({out[2*NP+1]/max(1,out[2*NP]):.1f}/request), overflows {out[2*NP+2]} ({out[2*NP+2]/chunk:.1f}/step)")
