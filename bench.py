@@ -32,7 +32,7 @@ ALGO_BYTES = {
     # one bitboard word: ~40 rows x 4 B = 160)
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
     "k_classify": 4 + 4,                            # action type in, permutation out
-    "k_lr": 0,                                      # longest-road tiers: LDS/ALU only (3 bitboard words per request)
+    "k_lr_finish": 0,                                    # longest-road tiers: LDS/ALU only (3 bitboard words per request)
     "k_lr_heavy": 0,
     "k_step_finish": 0,                             # completes the ~3 % of games that placed a road / settlement
     "k_reset_list": 0,                              # ~0.1 % of games per step end and are re-dealt
@@ -115,7 +115,7 @@ def main():
         prof_steps = min(args.steps, 512)
         kms = env.random_rollout_timed(args.warmup + args.steps, prof_steps, args.window)
         slow_launches = prof_steps if args.window <= 0 else -(-prof_steps // args.window)
-        launches = {k: (slow_launches if k in ("k_lr", "k_lr_heavy", "k_step_finish", "k_reset_list") else prof_steps) for k in kms}
+        launches = {k: (slow_launches if k in ("k_lr_heavy", "k_step_finish", "k_reset_list") else prof_steps) for k in kms}
         per_launch_us = {k: v * 1e3 / launches[k] for k, v in kms.items() if k in ALGO_BYTES}
         dom = max(per_launch_us, key=per_launch_us.get)
         achieved = ALGO_BYTES[dom] * n / (per_launch_us[dom] * 1e-6) / 1e9

@@ -34,9 +34,13 @@ struct catan_env {
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
     hipEvent_t ev_fork, ev_join;
+    hipStream_t fstream[2];  // deferred rollouts: tier-1 longest road + completion of iteration t run on fstream[t & 1] during t+1
+    hipEvent_t ev_fready[2], ev_fdone[2];
+    float* f_reward;      // [n][4] / [n]: outputs of the completions that run on fstream (scratch)
+    u8* f_done;
 };
 
-constexpr int LR_BUDGET_DEFERRED = 96;
+constexpr int LR_BUDGET_DEFERRED = 48;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                    \
@@ -128,7 +132,15 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_done, (size_t)e->n);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ctr, CTR_WORDS * sizeof(u32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req, (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[0], (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[1], (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_reward, (size_t)e->n * 4 * sizeof(float));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_done, (size_t)e->n);
+    for (int i = 0; i < 2 && rc == hipSuccess; i++) {
+        rc = hipStreamCreateWithFlags(&e->fstream[i], hipStreamNonBlocking);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fready[i], hipEventDisableTiming);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fdone[i], hipEventDisableTiming);
+    }
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.heavy, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[0], (size_t)e->N * sizeof(i32));
@@ -150,6 +162,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
+    e->pend.ra = 0; e->pend.fa = 0; e->pend.ftag = 1;
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
     e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
@@ -172,7 +185,11 @@ void catan_destroy(catan_env_t* e) {
     if (e->scratch_done) hipFree(e->scratch_done);
     if (e->prof) hipFree(e->prof);
     if (e->pend.ctr) hipFree(e->pend.ctr);
-    if (e->pend.req) hipFree(e->pend.req);
+    if (e->pend.req[0]) hipFree(e->pend.req[0]);
+    if (e->pend.req[1]) hipFree(e->pend.req[1]);
+    if (e->f_reward) hipFree(e->f_reward);
+    if (e->f_done) hipFree(e->f_done);
+    for (int i = 0; i < 2; i++) { if (e->fstream[i]) hipStreamDestroy(e->fstream[i]); if (e->ev_fready[i]) hipEventDestroy(e->ev_fready[i]); if (e->ev_fdone[i]) hipEventDestroy(e->ev_fdone[i]); }
     if (e->pend.heavy) hipFree(e->pend.heavy);
     if (e->pend.perm) hipFree(e->pend.perm);
     if (e->pend.resets[0]) hipFree(e->pend.resets[0]);
@@ -202,31 +219,34 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.prof = e->prof_on ? e->prof : nullptr;
     return sc;
 }
-// One env step = counting sort of the games by action type (k_classify_*), k_step (fused: apply + done/reward + next
-// masks for every game that needs no longest-road update) - the FAST path - then the SLOW path for the few games
-// that placed a road / settlement or ended: k_lr (tier-1 path search, one request per wave), k_lr_heavy (tier 2),
-// k_step_finish (compact completion), k_reset_list (one wave per finished game).  The slow path's launch times are
-// the latency tails of a handful of serial searches / re-deals.  Lock-step mode (catan_step, catan_random_rollout) runs
-// it inside every step.  Deferred mode (catan_random_rollout_deferred) runs it once per window of W steps: a game that
-// needs it stays busy (no action, no policy draw) until the window closes, so the tails are amortised over W steps;
-// every game's own trajectory is unchanged because its policy stream is indexed by its own decision counter.
-constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x LR_SPLIT parts are strided over them
+// One env step = counting sort of the games by action type (k_classify_*), then k_step (fused: apply + done/reward + next
+// masks for every game that needs no longest-road update) - the FAST path.  The few games that placed a road / settlement
+// or ended take the SLOW path: k_lr_finish (tier-1 path search + completion, one game per wave), k_lr_heavy (tier 2) +
+// k_step_finish, k_reset_list (re-deal, one wave per finished game).  Its launch times are the latency tails of a handful
+// of serial searches / re-deals.
+//   lock-step (catan_step, catan_random_rollout): the slow path runs inside every step, on the caller's stream.
+//   deferred (catan_random_rollout_deferred): a game on the slow path is BUSY (no action, no policy draw).  Tier 1 of
+//     iteration t runs on a side stream during iteration t+1 and its games play again at t+2; tier 2 and the re-deals run
+//     once per window of W iterations.  Every game's own trajectory is unchanged because its policy stream is indexed by
+//     its own decision counter; release points are fixed by the schedule, never by kernel timing.
+constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x split parts are strided over them
 constexpr int LR_GRID = 4096;
 constexpr int RESET_GRID = 2048;
-// ev (optional, 8 events): [0] before the sort, [1] after it, [2] after k_step
-static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev,
-                        bool new_window, bool carry) {
-    StepCfg sc = step_cfg(e);
-    if (new_window && !carry) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
-    else {
-        if (new_window) {
-            // deferred mode: the games that ended in k_step_finish wait in list ra^1; it becomes this window's list
-            HIPCHK(hipMemsetAsync(e->pend.ctr, 0, 2 * sizeof(u32), st));
-            HIPCHK(hipMemsetAsync(e->pend.ctr + 2 + e->pend.ra, 0, sizeof(u32), st));
-            e->pend.ra ^= 1;
-        }
-        HIPCHK(hipMemsetAsync(e->pend.ctr + 16, 0, (CTR_WORDS - 16) * sizeof(u32), st));      // the sort's bins only
+// counter zeroing before the sort of an iteration.  mode 0: everything (lock-step step / first iteration of a deferred
+// call); 1: a new deferred window (tier-2 list, the consumed re-deal list; the other one carries over); 2: inside a window
+static int zero_counters(catan_env_t* e, hipStream_t st, int mode) {
+    if (mode == 0) { HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st)); return CATAN_OK; }
+    if (mode == 1) {
+        // the games that ended in k_step_finish wait in list ra^1; it becomes this window's list
+        HIPCHK(hipMemsetAsync(e->pend.ctr, 0, 2 * sizeof(u32), st));
+        HIPCHK(hipMemsetAsync(e->pend.ctr + 2 + e->pend.ra, 0, sizeof(u32), st));
+        e->pend.ra ^= 1;
     }
+    return CATAN_OK;      // the tier-1 list counter is cleared by the sampler, the sort's bins by k_step
+}
+// ev (optional): [0] before the sort, [1] after it, [2] after k_step
+static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev) {
+    StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
     hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.perm);
@@ -236,10 +256,20 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-// ev (optional): [2] before k_lr, [6] after it, [3] after k_lr_heavy, [7] after k_step_finish, [4] after k_reset_list
-// The games that ended in k_step (list ra) are re-dealt on the side stream while the longest-road kernels run; those that
-// end in k_step_finish (list ra^1) are re-dealt afterwards (lock-step) or carried into the next window (carry).
-static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int lr_budget, bool carry) {
+// tier 1 + completion of request list `fl` on stream `st`.  ev (optional): recorded on st: [8] before, [6] after
+static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
+    StepCfg sc = step_cfg(e);
+    if (ev) HIPCHK(hipEventRecord(ev[8], st));
+    hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+                       sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
+    if (ev) HIPCHK(hipEventRecord(ev[6], st));
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+// tier 2 + re-deals.  The games that ended in k_step / k_lr_finish (list ra) are re-dealt on the side stream while the
+// tier-2 kernels run; those that end in k_step_finish (list ra^1) are re-dealt afterwards (lock-step) or carried into the
+// next window (carry).  ev (optional): [9] before k_lr_heavy, [3] after it, [7] after k_step_finish, [4] at the end
+static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, bool carry) {
     StepCfg sc = step_cfg(e);
     const int ra = e->pend.ra, max_trades = e->cfg.max_proposed_trades_per_turn;
     if (e->cfg.auto_reset) {
@@ -249,8 +279,7 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
                            (const i32*)e->pend.resets[ra], e->pend.busy, sc.prof);
         HIPCHK(hipEventRecord(e->ev_join, e->side));
     }
-    hipLaunchKernelGGL(k_lr, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->pend, lr_budget, sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
-    if (ev) HIPCHK(hipEventRecord(ev[6], st));
+    if (ev) HIPCHK(hipEventRecord(ev[9], st));
     hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)(e->pend.ctr + 1), (const u64*)e->pend.heavy, e->pend.len);
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
@@ -265,10 +294,14 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st) {
-    int r = enqueue_fast(e, actions, reward, done, st, nullptr, true, false);
-    if (r != CATAN_OK) return r;
-    return enqueue_slow(e, reward, done, st, nullptr, e->lr_budget[0], false);
+constexpr int EV_PER_STEP = 10;
+static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr) {
+    e->pend.fa = 0; e->pend.ftag = 1;
+    int r = zero_counters(e, st, 0);
+    if (r == CATAN_OK) r = enqueue_fast(e, actions, reward, done, st, ev);
+    if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
+    if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, false);
+    return r;
 }
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
@@ -300,7 +333,7 @@ int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (const u8*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, (u32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -344,16 +377,35 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
     return CATAN_OK;
 }
 
-// One iteration of the deferred rollout: policy draw (per-game counters), fast path; the slow path when a window closes.
+// One iteration of the deferred rollout (see enqueue_* above).  Iteration `it` uses request list it & 1 and tag 2 + (it & 1).
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+    const int fa = (int)(it & 1);
+    const bool last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
+    if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-2 is complete
+    e->pend.fa = fa; e->pend.ftag = 2 + fa;
+    int r = zero_counters(e, st, it == 0 ? 0 : (it % window == 0 ? 1 : 2));
+    if (r != CATAN_OK) return r;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
-                       e->pctr, (const u8*)e->pend.busy);
-    // the last window of a call also re-deals the games that ended in k_step_finish: the call returns with no busy game
-    const bool last = it + 1 == iters;
-    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, it % window == 0, it != 0);
+                       e->pctr, e->pend.busy, 2 + fa, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa);
+    r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev);
     if (r != CATAN_OK) return r;
-    if ((it + 1) % window == 0 || last) r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, ev, e->lr_budget[1], !last);
+    HIPCHK(hipEventRecord(e->ev_fready[fa], st));
+    HIPCHK(hipStreamWaitEvent(e->fstream[fa], e->ev_fready[fa], 0));
+    r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[fa], ev, fa, e->lr_budget[1]);
+    if (r != CATAN_OK) return r;
+    HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[fa]));
+    if (closes) {
+        // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
+        HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));
+        if (it >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa ^ 1], 0));
+        // the last window of a call also re-deals the games that ended in k_step_finish: the call returns with no busy game
+        r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, ev, !last);
+        if (r == CATAN_OK && last) {
+            hipLaunchKernelGGL(k_release_tags, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy);
+            e->pend.fa = 0; e->pend.ftag = 1;
+        }
+    }
     return r;
 }
 
@@ -385,14 +437,14 @@ int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
     return CATAN_OK;
 }
 
-// The rollout loops with a hipEvent around every kernel launch (events recorded on `stream`, the stream the kernels
-// run on).  window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host,
-// float[7]) receives the summed elapsed milliseconds of:
-// [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
+// The rollout loops with a hipEvent around every kernel launch (recorded on the stream the kernel runs on).
+// window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host, float[7])
+// receives the summed elapsed milliseconds of:
+// [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr_finish  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
-    const int K = 8;                       // events per step, see enqueue_fast / enqueue_slow; [5] = before the sampler
+    const int K = EV_PER_STEP;             // see enqueue_fast / enqueue_tier1 / enqueue_slow; [5] = before the sampler
     std::vector<hipEvent_t> ev((size_t)steps * K);
     for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableSystemFence));   // no L2 flush between kernels
     std::vector<char> slow((size_t)steps, 0);
@@ -405,26 +457,27 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
         } else {
             HIPCHK(hipEventRecord(v[5], st));
             hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s,
-                               e->scratch_actions, (u32*)nullptr, (const u8*)nullptr);
-            r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v, true, false);
-            if (r == CATAN_OK) r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, v, e->lr_budget[0], false);
+                               e->scratch_actions, (u32*)nullptr, (u8*)nullptr, 0, (u32*)nullptr);
+            r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v);
             slow[s] = 1;
         }
         if (r != CATAN_OK) return r;
     }
     HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(e->fstream[0]));
+    HIPCHK(hipStreamSynchronize(e->fstream[1]));
     for (int k = 0; k < 7; k++) kernel_ms[k] = 0.0f;
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * K];
         float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (+ counter memset)
+        HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random
         HIPCHK(hipEventElapsedTime(&ms, v[0], v[1])); kernel_ms[1] += ms;      // k_classify_hist + k_classify_scatter
         HIPCHK(hipEventElapsedTime(&ms, v[1], v[2])); kernel_ms[2] += ms;      // k_step
+        HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[3] += ms;      // k_lr_finish
         if (!slow[s]) continue;
-        HIPCHK(hipEventElapsedTime(&ms, v[2], v[6])); kernel_ms[3] += ms;      // k_lr
-        HIPCHK(hipEventElapsedTime(&ms, v[6], v[3])); kernel_ms[4] += ms;      // k_lr_heavy
+        HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[4] += ms;      // k_lr_heavy
         HIPCHK(hipEventElapsedTime(&ms, v[3], v[7])); kernel_ms[5] += ms;      // k_step_finish
-        HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[6] += ms;      // k_reset_list
+        HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[6] += ms;      // k_reset_list (wait for the side stream + second pass)
     }
     for (auto& x : ev) hipEventDestroy(x);
     return CATAN_OK;

@@ -311,7 +311,7 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
-constexpr int LR_BUDGET = 12;       // tier-1 double-iterations per lane before the game is handed to tier 2
+constexpr int LR_BUDGET = 48;       // tier-1 double-iterations per lane before the game is handed to tier 2
 constexpr int LR_HEAVY_THREADS = 1024;
 constexpr int LR_POOL = 3072;       // tier-2 workgroup pool entries
 constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round
@@ -455,9 +455,9 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
     return result;
 }
 
-// tier 2: LR_SPLIT workgroups per request (static partition of the start corners, combined with atomicMax).
+// tier 2: `split` workgroups per request (static partition of the start corners, combined with atomicMax); few requests
+// (lock-step) get 8 workgroups each for latency, many (a deferred window) share the grid for throughput.
 // req[i] = game | pid0 << 56; out_len[game] (zeroed by k_step) receives the path length.
-constexpr int LR_SPLIT = 8;
 __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
                                                               const u64* __restrict__ req, i32* __restrict__ out_len) {
     __shared__ u64 adj[54];
@@ -466,7 +466,9 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
     __shared__ int pool_n, best_all;
     __shared__ lrstk_t path[54][LR_HEAVY_THREADS];
     const int tid = threadIdx.x;
-    const u32 count = *req_count * LR_SPLIT;
+    const u32 nreq = *req_count;
+    const u32 LR_SPLIT = nreq * 8 <= gridDim.x ? 8u : (nreq * 4 <= gridDim.x ? 4u : (nreq * 2 <= gridDim.x ? 2u : 1u));
+    const u32 count = nreq * LR_SPLIT;
     u32 nbr_c, nbr_e;
     lr_load_nbr(tid < 54 ? tid : 0, nbr_c, nbr_e);
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         if (tid == 0) { pool_n = 0; best_all = 0; }
         __syncthreads();
         Dfs t;
-        t.active = tid < 54 && (tid % LR_SPLIT) == part && adj[tid < 54 ? tid : 0] != 0;
+        t.active = tid < 54 && ((u32)tid % LR_SPLIT) == (u32)part && adj[tid < 54 ? tid : 0] != 0;
         t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
@@ -986,33 +988,33 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     t_prev = wall_clock64();
 }
 
-// Per-step hand-off buffers (all device arrays).  ctr: [0] number of longest-road requests (= games whose step is
-// completed by k_step_finish), [1] number of tier-2 requests, [2], [3] lengths of the two re-deal lists (k_reset_list),
-// [16..29] games per action-type bin, [32..45] bin cursors.
+// Per-step hand-off buffers (all device arrays).  ctr: [1] number of tier-2 longest-road requests (completed by
+// k_lr_heavy + k_step_finish), [2], [3] lengths of the two re-deal lists (k_reset_list), [4], [5] lengths of the two
+// tier-1 request lists (k_lr_finish), [16..29] games per action-type bin, [32..45] bin cursors.
 // busy[e] != 0: game e is waiting for the slow path (longest-road completion or re-deal); it takes no action until the
 // slow path has run (same step in lock-step mode, end of the window in deferred mode).
 // Finished games go to one of two re-deal lists: k_step appends to list `ra`, k_step_finish to the other one, so that
 // list `ra` can be re-dealt (k_reset_list) concurrently with the longest-road kernels.
-struct Pending { u32* ctr; u64* req; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets[2]; u8* busy; int ra; };
+// Longest-road requests go to request list `fa` (two lists, so that the list of one iteration can be worked off on a side
+// stream while the next iteration fills the other); k_step marks those games busy with `ftag`: 1 = cleared by the kernel
+// that completes the game (everything on one stream), 2 + fa = cleared by the sampler two iterations later (deferred
+// rollouts: the release point must not depend on when the side stream happens to finish).
+struct Pending { u32* ctr; u64* req[2]; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets[2]; u8* busy; int ra; int fa; int ftag; };
 constexpr int CTR_WORDS = 64;
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
-struct StepScratch { LrWave lr; ResetScratch rs; };
+struct StepScratch { LrWave lr; };
 
 // Everything of a step that needs the longest-road length: the holder logic of game/game.py:864-919, done/rewards
 // (env/wrapper.py:85-112), auto-reset (RL/ppo/game_manager.py:112-113) and the next legal-action masks.
 // Must be called by all 64 lanes; `doit` selects the lanes it applies to.
-template <class S>
-DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
+// LR = false: no lane has a longest-road update (k_step: those games take the slow path); scratch may be null then.
+template <bool LR, class S>
+DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist);
-
-template <class S>
-DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const StepCfg& cfg, int lane, bool doit, int type,
-                      int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist) {
+                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist, bool clear_busy) {
     const long e = s.e;
-    {
+    if constexpr (LR) {
         bool cut = false;
         int holder = 0, hcount = 0;
         if (doit && lr_who >= 0) {
@@ -1032,7 +1034,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
             int max_len = len, player = lr_who;
             bool tied = false;
             for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
-                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch.lr, 0, nbr_c, nbr_e);
+                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch->lr, 0, nbr_c, nbr_e);
                 if (cut && o != lr_who) {
                     if (pl == max_len) tied = true;
                     else if (pl > max_len) { max_len = pl; tied = false; player = o; }
@@ -1086,7 +1088,8 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch& scratch, const Step
         // RL/ppo/game_manager.py:112-113: the finished game is reset by k_reset_list (one wave per game: winning moves
         // cluster in a few action-type bins, inline resets would serialise inside those waves), which also writes its masks
         if (want_reset) pend.resets[rlist][atomicAdd(&pend.ctr[2 + rlist], 1u)] = (i32)s.e;
-        if (want_reset || lr_who >= 0) pend.busy[s.e] = want_reset ? 1 : 0;
+        if (want_reset) pend.busy[s.e] = 1;
+        else if (lr_who >= 0 && clear_busy) pend.busy[s.e] = 0;
     }
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
     if (doit && !want_reset) {
@@ -1109,8 +1112,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend) {
     __shared__ u32 tile[ROWS_HOT * TS];
-    __shared__ StepScratch scratch;
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane < CTR_WORDS - 16) pend.ctr[16 + lane] = 0;     // the sort is done with its bins: clear them for the next one
     const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
     long long tprof = cfg.prof ? wall_clock64() : 0;
     const bool live = e < c.n;
@@ -1432,52 +1435,67 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int len = 0;
     const bool pending = lr_who >= 0;
     if (pending) {
-        const u32 slot = atomicAdd(&pend.ctr[0], 1u);
-        pend.req[slot] = (u64)e | ((u64)lr_who << 56);
+        const u32 slot = atomicAdd(&pend.ctr[4 + pend.fa], 1u);
+        pend.req[pend.fa][slot] = (u64)e | ((u64)lr_who << 56);
         pend.type[e] = (u8)(type + 1);
         pend.who[e] = (u8)lr_who;
-        pend.busy[e] = 1;
+        pend.busy[e] = (u8)pend.ftag;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step(c, s, scratch, cfg, lane, type >= 0 && !pending, type, lr_who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra);
+    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra, false);
     // ---- write the tile back
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     prof_mark(cfg, 7, tprof);
 }
 
-// tier 1 of the longest road, one request per wave (all 64 lanes cooperate); overflow goes to the tier-2 list.
-__global__ __launch_bounds__(64) void k_lr(Ctx c, Pending pend, int budget, unsigned long long* stat) {
-    __shared__ LrWave L;
+// Tier 1 of the longest road and the completion of the step, one request per wave: all 64 lanes cooperate on the path
+// search (budgeted; overflow hands the game to the tier-2 list), then the game's hot record is staged linearly in LDS and
+// lane 0 completes the step (holder logic, done/reward, next masks).  `fl` selects the request list.
+__global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
+                                                  StepCfg cfg, Pending pend, int fl, int budget, unsigned long long* stat) {
+    __shared__ StepScratch scratch;
+    __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     const int lane = threadIdx.x;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    const u32 count = pend.ctr[0];
+    const u32 count = pend.ctr[4 + fl];
+    StepCfg cfg2 = cfg;
+    cfg2.prof = nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
-        const u64 rq = pend.req[r];
+        const u64 rq = pend.req[fl][r];
         const long e = (long)(rq & 0x00FFFFFFFFFFFFFFull);
         const int who = (int)(rq >> 56);
-        St s(c.R, c.N, e);
-        const int len = coop_longest_path(lane == 0, s, who, L, budget, nbr_c, nbr_e, stat);
-        if (lane == 0) {
-            if (len < 0) { const u32 slot = atomicAdd(&pend.ctr[1], 1u); pend.heavy[slot] = rq; pend.len[e] = 0; }
-            else pend.len[e] = len;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
+        __builtin_amdgcn_wave_barrier();
+        StL1 s(rec, c.R, c.N, e);
+        int len = coop_longest_path(lane == 0, s, who, scratch.lr, budget, nbr_c, nbr_e, stat);
+        len = __shfl(len, 0);
+        if (len < 0) {                                   // tier 2 takes over; the record is untouched
+            if (lane == 0) { const u32 slot = atomicAdd(&pend.ctr[1], 1u); pend.heavy[slot] = rq; pend.len[e] = 0; pend.busy[e] = 1; }
+            continue;
         }
+        long long tprof = 0;
+        finish_step<true>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
+                    pend.ra, pend.ftag < 2);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
     }
 }
 
-// Completes the step of the games in the request list (their longest-road length now sits in pend.len): holder logic,
-// done/rewards, auto-reset, next masks.  Compact: wave w gathers requests 64w .. 64w+63, whatever games they are.
+// Completes the step of the games in the tier-2 list (their longest-road length now sits in pend.len): holder logic,
+// done/rewards, next masks.  Compact: wave w gathers requests 64w .. 64w+63, whatever games they are.
 __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward,
                                                     u8* __restrict__ done, StepCfg cfg, Pending pend) {
     __shared__ u32 tile[ROWS_HOT * TS];
     __shared__ StepScratch scratch;
     const int lane = threadIdx.x;
-    const u32 count = pend.ctr[0];
+    const u32 count = pend.ctr[1];
     if ((u32)blockIdx.x * 64u >= count) return;
     const u32 r = blockIdx.x * 64u + lane;
     const bool doit = r < count;
-    const long e = doit ? (long)(pend.req[r] & 0x00FFFFFFFFFFFFFFull) : -1;
+    const long e = doit ? (long)(pend.heavy[r] & 0x00FFFFFFFFFFFFFFull) : -1;
     stage_in(tile, c.R, (int)e, lane);
     __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, doit ? e : 0);
@@ -1489,9 +1507,15 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     const int len = doit ? pend.len[e] : 0;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    finish_step(c, s, scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra ^ 1);
+    finish_step<true>(c, s, &scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra ^ 1, true);
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (int)e, lane);
+}
+
+// Deferred rollouts: frees the games that still carry a release tag when a call ends (their steps are complete).
+__global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ busy) {
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e < c.N && busy[e] >= 2) busy[e] = 0;
 }
 
 // One wave resets one game: the 64 lanes generate the game's next RND_WORDS Philox draws into LDS, lane 0 runs the
@@ -1605,12 +1629,17 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
 // pctr == nullptr: every game draws with the caller's step_idx (lock-step rollouts).  Otherwise game e draws with its own
 // decision counter pctr[e] (advanced here) and a busy game gets the no-op action: its trajectory does not depend on when
 // it is scheduled (deferred rollouts).
+// A busy game whose tag equals tag_now (>= 2) is released here: its step was completed on the side stream, which the
+// caller has joined before this launch.
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
-                                                        u32* __restrict__ pctr, const u8* __restrict__ busy) {
+                                                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, u32* __restrict__ zero_me) {
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
+    if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
     if (s.e >= c.n) return;
     if (pctr != nullptr) {
-        if (busy[s.e]) { actions[s.e * ACTION_WORDS] = -1; return; }
+        int b = busy[s.e];
+        if (b >= 2 && b == tag_now) { busy[s.e] = 0; b = 0; }
+        if (b) { actions[s.e * ACTION_WORDS] = -1; return; }
         step_idx = pctr[s.e];
         pctr[s.e] = step_idx + 1;
     }

@@ -120,7 +120,7 @@ class VecCatanEnv(object):
         """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream); window > 0: the deferred loop."""
         ms = (C.c_float * 7)()
         _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), int(window), _stream(), ms))
-        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr", "k_lr_heavy", "k_step_finish", "k_reset_list"), [float(x) for x in ms]))
+        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr_finish", "k_lr_heavy", "k_step_finish", "k_reset_list"), [float(x) for x in ms]))
 
     def export_state(self, env_idx=None):
         """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""

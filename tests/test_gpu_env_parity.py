@@ -72,11 +72,7 @@ def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, s
         _assert_blobs_equal(env.export_state().cpu().numpy(), o, f"state after {chunk} deferred iterations")
         assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
     assert env.invalid_action_count() == 0
-    if window == 1:
-        # window 1 is the lock-step schedule, except that a game won through the longest road sits out one iteration
-        assert total.max() == iters and total.min() >= iters - 16
-    else:
-        assert total.max() <= iters and total.mean() > 0.5 * iters
+    assert total.max() <= iters and total.mean() > 0.5 * iters
     assert ob.games.value > 0
 
 
