@@ -38,9 +38,15 @@ struct catan_env {
     hipEvent_t ev_fready[2], ev_fdone[2];
     float* f_reward;      // [n][4] / [n]: outputs of the completions that run on fstream (scratch)
     u8* f_done;
+    hipStream_t sstream;  // deferred rollouts: tier 2 + re-deals of window w run here during window w+1
+    hipEvent_t ev_sdone[2];
+    float* s_reward;      // outputs of the completions that run on sstream (scratch)
+    u8* s_done;
 };
 
-constexpr int LR_BUDGET_DEFERRED = 48;
+constexpr int LR_BUDGET_DEFERRED = 24;
+// cross-stream ordering inside one device: no timing, no system-scope release (which would flush L2 at every record)
+constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                    \
@@ -136,18 +142,27 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[1], (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_done, (size_t)e->n);
+    // HIP multiplexes streams onto 4 hardware queues; streams that share a queue serialise.  Caller's stream + side +
+    // fstream + sstream = 4, so the two tier-1 slots share one stream (tier 1 of an iteration must fit in one iteration).
+    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->fstream[0], hipStreamNonBlocking);
+    e->fstream[1] = e->fstream[0];
     for (int i = 0; i < 2 && rc == hipSuccess; i++) {
-        rc = hipStreamCreateWithFlags(&e->fstream[i], hipStreamNonBlocking);
-        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fready[i], hipEventDisableTiming);
-        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fdone[i], hipEventDisableTiming);
+        rc = hipEventCreateWithFlags(&e->ev_fready[i], EV_SYNC);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fdone[i], EV_SYNC);
     }
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.heavy, (size_t)e->N * sizeof(u64));
+    for (int i = 0; i < 2 && rc == hipSuccess; i++) {
+        rc = hipMalloc((void**)&e->pend.heavy[i], (size_t)e->N * sizeof(u64));
+        if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][0], (size_t)e->N * sizeof(i32));
+        if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][1], (size_t)e->N * sizeof(i32));
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_sdone[i], EV_SYNC);
+    }
+    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)e->N * sizeof(i32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[0], (size_t)e->N * sizeof(i32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[1], (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, EV_SYNC);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
@@ -162,7 +177,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
-    e->pend.ra = 0; e->pend.fa = 0; e->pend.ftag = 1;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
     e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
@@ -189,11 +204,18 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.req[1]) hipFree(e->pend.req[1]);
     if (e->f_reward) hipFree(e->f_reward);
     if (e->f_done) hipFree(e->f_done);
-    for (int i = 0; i < 2; i++) { if (e->fstream[i]) hipStreamDestroy(e->fstream[i]); if (e->ev_fready[i]) hipEventDestroy(e->ev_fready[i]); if (e->ev_fdone[i]) hipEventDestroy(e->ev_fdone[i]); }
-    if (e->pend.heavy) hipFree(e->pend.heavy);
+    if (e->fstream[0]) hipStreamDestroy(e->fstream[0]);
+    for (int i = 0; i < 2; i++) { if (e->ev_fready[i]) hipEventDestroy(e->ev_fready[i]); if (e->ev_fdone[i]) hipEventDestroy(e->ev_fdone[i]); }
+    for (int i = 0; i < 2; i++) {
+        if (e->pend.heavy[i]) hipFree(e->pend.heavy[i]);
+        if (e->pend.resets[i][0]) hipFree(e->pend.resets[i][0]);
+        if (e->pend.resets[i][1]) hipFree(e->pend.resets[i][1]);
+        if (e->ev_sdone[i]) hipEventDestroy(e->ev_sdone[i]);
+    }
+    if (e->sstream) hipStreamDestroy(e->sstream);
+    if (e->s_reward) hipFree(e->s_reward);
+    if (e->s_done) hipFree(e->s_done);
     if (e->pend.perm) hipFree(e->pend.perm);
-    if (e->pend.resets[0]) hipFree(e->pend.resets[0]);
-    if (e->pend.resets[1]) hipFree(e->pend.resets[1]);
     if (e->side) hipStreamDestroy(e->side);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -224,26 +246,17 @@ static StepCfg step_cfg(const catan_env_t* e) {
 // or ended take the SLOW path: k_lr_finish (tier-1 path search + completion, one game per wave), k_lr_heavy (tier 2) +
 // k_step_finish, k_reset_list (re-deal, one wave per finished game).  Its launch times are the latency tails of a handful
 // of serial searches / re-deals.
-//   lock-step (catan_step, catan_random_rollout): the slow path runs inside every step, on the caller's stream.
+//   lock-step (catan_step, catan_random_rollout): the slow path runs inside every step (re-deals next to the tier-2
+//     kernels, on a side stream).
 //   deferred (catan_random_rollout_deferred): a game on the slow path is BUSY (no action, no policy draw).  Tier 1 of
-//     iteration t runs on a side stream during iteration t+1 and its games play again at t+2; tier 2 and the re-deals run
-//     once per window of W iterations.  Every game's own trajectory is unchanged because its policy stream is indexed by
-//     its own decision counter; release points are fixed by the schedule, never by kernel timing.
+//     iteration t runs on a side stream during iteration t+1 and its games play again at t+2; tier 2 and the re-deals of
+//     window w (W iterations) run on another stream during window w+1 and their games play again in window w+2.  Every
+//     game's own trajectory is unchanged because its policy stream is indexed by its own decision counter; the release
+//     points are fixed by this schedule (the main stream waits for the side work there), never by kernel timing.
 constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x split parts are strided over them
+constexpr int LR_HEAVY_GRID_DEFERRED = 128;  // next to the fast path: leave most CUs (and their LDS) to k_step
 constexpr int LR_GRID = 4096;
 constexpr int RESET_GRID = 2048;
-// counter zeroing before the sort of an iteration.  mode 0: everything (lock-step step / first iteration of a deferred
-// call); 1: a new deferred window (tier-2 list, the consumed re-deal list; the other one carries over); 2: inside a window
-static int zero_counters(catan_env_t* e, hipStream_t st, int mode) {
-    if (mode == 0) { HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st)); return CATAN_OK; }
-    if (mode == 1) {
-        // the games that ended in k_step_finish wait in list ra^1; it becomes this window's list
-        HIPCHK(hipMemsetAsync(e->pend.ctr, 0, 2 * sizeof(u32), st));
-        HIPCHK(hipMemsetAsync(e->pend.ctr + 2 + e->pend.ra, 0, sizeof(u32), st));
-        e->pend.ra ^= 1;
-    }
-    return CATAN_OK;      // the tier-1 list counter is cleared by the sampler, the sort's bins by k_step
-}
 // ev (optional): [0] before the sort, [1] after it, [2] after k_step
 static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev) {
     StepCfg sc = step_cfg(e);
@@ -266,29 +279,30 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-// tier 2 + re-deals.  The games that ended in k_step / k_lr_finish (list ra) are re-dealt on the side stream while the
-// tier-2 kernels run; those that end in k_step_finish (list ra^1) are re-dealt afterwards (lock-step) or carried into the
-// next window (carry).  ev (optional): [9] before k_lr_heavy, [3] after it, [7] after k_step_finish, [4] at the end
-static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, bool carry) {
+// tier 2 + re-deals of window slot pend.sa on stream st.  The games that ended in k_step / k_lr_finish (list 0) are re-dealt
+// on the side stream while the tier-2 kernels run, those that end in k_step_finish (list 1) afterwards.
+// ev (optional): [9] before k_lr_heavy, [3] after it, [7] after k_step_finish, [4] at the end
+static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int heavy_grid) {
     StepCfg sc = step_cfg(e);
-    const int ra = e->pend.ra, max_trades = e->cfg.max_proposed_trades_per_turn;
+    const int sa = e->pend.sa, max_trades = e->cfg.max_proposed_trades_per_turn;
+    u32* sctr = e->pend.ctr + 8 + 4 * sa;
+    u8* busy = e->pend.stag < 2 ? e->pend.busy : nullptr;       // tagged games are released by the sampler, not here
     if (e->cfg.auto_reset) {
         HIPCHK(hipEventRecord(e->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(e->pend.ctr + 2 + ra),
-                           (const i32*)e->pend.resets[ra], e->pend.busy, sc.prof);
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 1),
+                           (const i32*)e->pend.resets[sa][0], busy, sc.prof);
         HIPCHK(hipEventRecord(e->ev_join, e->side));
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
-    hipLaunchKernelGGL(k_lr_heavy, dim3(LR_HEAVY_GRID), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)(e->pend.ctr + 1), (const u64*)e->pend.heavy, e->pend.len);
+    hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len);
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[7], st));
     if (e->cfg.auto_reset) {
         HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
-        if (!carry)
-            hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(e->pend.ctr + 2 + (ra ^ 1)),
-                               (const i32*)e->pend.resets[ra ^ 1], e->pend.busy, sc.prof);
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2),
+                           (const i32*)e->pend.resets[sa][1], busy, sc.prof);
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(hipGetLastError());
@@ -296,11 +310,11 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
 }
 constexpr int EV_PER_STEP = 10;
 static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr) {
-    e->pend.fa = 0; e->pend.ftag = 1;
-    int r = zero_counters(e, st, 0);
-    if (r == CATAN_OK) r = enqueue_fast(e, actions, reward, done, st, ev);
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+    HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    int r = enqueue_fast(e, actions, reward, done, st, ev);
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
-    if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, false);
+    if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, LR_HEAVY_GRID);
     return r;
 }
 
@@ -333,7 +347,7 @@ int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (u8*)nullptr, 0, (u32*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -377,18 +391,24 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
     return CATAN_OK;
 }
 
-// One iteration of the deferred rollout (see enqueue_* above).  Iteration `it` uses request list it & 1 and tag 2 + (it & 1).
+// One iteration of the deferred rollout (schedule above).  Iteration `it` uses tier-1 request list it & 1 with tag
+// 2 + (it & 1); window w = it / window uses slot w & 1 with tag 4 + (w & 1).
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
     const int fa = (int)(it & 1);
-    const bool last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
+    const int64_t w = it / window;
+    const int sa = (int)(w & 1);
+    const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
     if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-2 is complete
-    e->pend.fa = fa; e->pend.ftag = 2 + fa;
-    int r = zero_counters(e, st, it == 0 ? 0 : (it % window == 0 ? 1 : 2));
-    if (r != CATAN_OK) return r;
+    if (it == 0) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    else if (opens) {
+        if (w >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));     // the slow path of window w-2 is complete
+        HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
+    }
+    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
-                       e->pctr, e->pend.busy, 2 + fa, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa);
-    r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev);
+                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa);
+    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
     HIPCHK(hipStreamWaitEvent(e->fstream[fa], e->ev_fready[fa], 0));
@@ -397,13 +417,16 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[fa]));
     if (closes) {
         // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
-        HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));
-        if (it >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa ^ 1], 0));
-        // the last window of a call also re-deals the games that ended in k_step_finish: the call returns with no busy game
-        r = enqueue_slow(e, e->scratch_reward, e->scratch_done, st, ev, !last);
-        if (r == CATAN_OK && last) {
+        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa], 0));
+        if (it >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa ^ 1], 0));
+        r = enqueue_slow(e, e->s_reward, e->s_done, e->sstream, ev, LR_HEAVY_GRID_DEFERRED);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_sdone[sa], e->sstream));
+        if (last) {                                   // the call returns with every step complete and no busy game
+            HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));
+            if (w >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa ^ 1], 0));
             hipLaunchKernelGGL(k_release_tags, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy);
-            e->pend.fa = 0; e->pend.ftag = 1;
+            e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
         }
     }
     return r;
@@ -457,7 +480,7 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
         } else {
             HIPCHK(hipEventRecord(v[5], st));
             hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s,
-                               e->scratch_actions, (u32*)nullptr, (u8*)nullptr, 0, (u32*)nullptr);
+                               e->scratch_actions, (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr);
             r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v);
             slow[s] = 1;
         }
@@ -465,7 +488,7 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
     }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipStreamSynchronize(e->fstream[0]));
-    HIPCHK(hipStreamSynchronize(e->fstream[1]));
+    HIPCHK(hipStreamSynchronize(e->sstream));
     for (int k = 0; k < 7; k++) kernel_ms[k] = 0.0f;
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * K];

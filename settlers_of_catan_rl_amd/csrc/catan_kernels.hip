@@ -988,18 +988,21 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     t_prev = wall_clock64();
 }
 
-// Per-step hand-off buffers (all device arrays).  ctr: [1] number of tier-2 longest-road requests (completed by
-// k_lr_heavy + k_step_finish), [2], [3] lengths of the two re-deal lists (k_reset_list), [4], [5] lengths of the two
-// tier-1 request lists (k_lr_finish), [16..29] games per action-type bin, [32..45] bin cursors.
+// ctr: [4], [5] lengths of the two tier-1 request lists (k_lr_finish); [8 + 4 sa]: tier-2 requests of slot sa (k_lr_heavy +
+// k_step_finish), [9 + 4 sa], [10 + 4 sa]: its two re-deal lists (k_reset_list); [16..29] games per action-type bin,
+// [32..45] bin cursors.
 // busy[e] != 0: game e is waiting for the slow path (longest-road completion or re-deal); it takes no action until the
 // slow path has run (same step in lock-step mode, end of the window in deferred mode).
-// Finished games go to one of two re-deal lists: k_step appends to list `ra`, k_step_finish to the other one, so that
-// list `ra` can be re-dealt (k_reset_list) concurrently with the longest-road kernels.
-// Longest-road requests go to request list `fa` (two lists, so that the list of one iteration can be worked off on a side
-// stream while the next iteration fills the other); k_step marks those games busy with `ftag`: 1 = cleared by the kernel
-// that completes the game (everything on one stream), 2 + fa = cleared by the sampler two iterations later (deferred
-// rollouts: the release point must not depend on when the side stream happens to finish).
-struct Pending { u32* ctr; u64* req[2]; u64* heavy; u8* type; u8* who; i32* len; i32* perm; i32* resets[2]; u8* busy; int ra; int fa; int ftag; };
+// Slow-path hand-off (all device arrays).
+//   tier-1 longest-road requests go to request list `fa` (two lists, so that the list of one iteration can be worked off on
+//   a side stream while the next iteration fills the other); k_step marks those games busy with `ftag`;
+//   tier-2 requests and finished games go to the lists of window slot `sa`: heavy[sa], resets[sa][0] (games that ended in
+//   k_step / k_lr_finish) and resets[sa][1] (games that ended in k_step_finish); those games are marked busy with `stag`.
+//   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
+//   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
+//   later), never by when a side stream happens to finish.
+struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; i32* perm; i32* resets[2][2]; u8* busy;
+                 int fa, ftag, sa, stag; };
 constexpr int CTR_WORDS = 64;
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
@@ -1087,8 +1090,8 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
         want_reset = dn && cfg.auto_reset;
         // RL/ppo/game_manager.py:112-113: the finished game is reset by k_reset_list (one wave per game: winning moves
         // cluster in a few action-type bins, inline resets would serialise inside those waves), which also writes its masks
-        if (want_reset) pend.resets[rlist][atomicAdd(&pend.ctr[2 + rlist], 1u)] = (i32)s.e;
-        if (want_reset) pend.busy[s.e] = 1;
+        if (want_reset) pend.resets[pend.sa][rlist][atomicAdd(&pend.ctr[9 + 4 * pend.sa + rlist], 1u)] = (i32)s.e;
+        if (want_reset) pend.busy[s.e] = (u8)pend.stag;
         else if (lr_who >= 0 && clear_busy) pend.busy[s.e] = 0;
     }
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
@@ -1442,7 +1445,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         pend.busy[e] = (u8)pend.ftag;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra, false);
+    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 0, false);
     // ---- write the tile back
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
@@ -1473,12 +1476,15 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         int len = coop_longest_path(lane == 0, s, who, scratch.lr, budget, nbr_c, nbr_e, stat);
         len = __shfl(len, 0);
         if (len < 0) {                                   // tier 2 takes over; the record is untouched
-            if (lane == 0) { const u32 slot = atomicAdd(&pend.ctr[1], 1u); pend.heavy[slot] = rq; pend.len[e] = 0; pend.busy[e] = 1; }
+            if (lane == 0) {
+                const u32 slot = atomicAdd(&pend.ctr[8 + 4 * pend.sa], 1u);
+                pend.heavy[pend.sa][slot] = rq; pend.len[e] = 0; pend.busy[e] = (u8)pend.stag;
+            }
             continue;
         }
         long long tprof = 0;
         finish_step<true>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
-                    pend.ra, pend.ftag < 2);
+                    0, pend.ftag < 2);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
     }
@@ -1491,11 +1497,11 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     __shared__ u32 tile[ROWS_HOT * TS];
     __shared__ StepScratch scratch;
     const int lane = threadIdx.x;
-    const u32 count = pend.ctr[1];
+    const u32 count = pend.ctr[8 + 4 * pend.sa];
     if ((u32)blockIdx.x * 64u >= count) return;
     const u32 r = blockIdx.x * 64u + lane;
     const bool doit = r < count;
-    const long e = doit ? (long)(pend.heavy[r] & 0x00FFFFFFFFFFFFFFull) : -1;
+    const long e = doit ? (long)(pend.heavy[pend.sa][r] & 0x00FFFFFFFFFFFFFFull) : -1;
     stage_in(tile, c.R, (int)e, lane);
     __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, doit ? e : 0);
@@ -1507,7 +1513,7 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     const int len = doit ? pend.len[e] : 0;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    finish_step<true>(c, s, &scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, pend.ra ^ 1, true);
+    finish_step<true>(c, s, &scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 1, pend.stag < 2);
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (int)e, lane);
 }
@@ -1629,16 +1635,17 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
 // pctr == nullptr: every game draws with the caller's step_idx (lock-step rollouts).  Otherwise game e draws with its own
 // decision counter pctr[e] (advanced here) and a busy game gets the no-op action: its trajectory does not depend on when
 // it is scheduled (deferred rollouts).
-// A busy game whose tag equals tag_now (>= 2) is released here: its step was completed on the side stream, which the
-// caller has joined before this launch.
+// A busy game whose tag equals tag_now or tag_now2 (>= 2) is released here: its step was completed on a side stream, which
+// the caller has joined before this launch.
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
-                                                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, u32* __restrict__ zero_me) {
+                                                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
+                                                        u32* __restrict__ zero_me) {
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
     if (s.e >= c.n) return;
     if (pctr != nullptr) {
         int b = busy[s.e];
-        if (b >= 2 && b == tag_now) { busy[s.e] = 0; b = 0; }
+        if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
         if (b) { actions[s.e * ACTION_WORDS] = -1; return; }
         step_idx = pctr[s.e];
         pctr[s.e] = step_idx + 1;
