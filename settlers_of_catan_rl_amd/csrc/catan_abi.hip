@@ -258,10 +258,11 @@ constexpr int LR_HEAVY_GRID_DEFERRED = 128;  // next to the fast path: leave mos
 constexpr int LR_GRID = 4096;
 constexpr int RESET_GRID = 2048;
 // ev (optional): [0] before the sort, [1] after it, [2] after k_step
-static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev) {
+static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev,
+                        bool have_hist = false) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
+    if (!have_hist) hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
     hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.perm);
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
@@ -309,10 +310,16 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
     return CATAN_OK;
 }
 constexpr int EV_PER_STEP = 10;
-static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr) {
+// sample_step != nullptr: the random policy draws the actions first (into `actions`), fused with the sort's histogram
+static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr,
+                     const uint32_t* sample_step = nullptr) {
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
     HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
-    int r = enqueue_fast(e, actions, reward, done, st, ev);
+    if (sample_step)
+        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
+                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16);
+    int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
     if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, LR_HEAVY_GRID);
     return r;
@@ -320,7 +327,7 @@ static int step_impl(catan_env_t* e, const int32_t* actions, float* reward, uint
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
     if (!e || !actions || !reward || !done) return fail(CATAN_EINVAL, "catan_step: null argument");
-    return step_impl(e, actions, reward, done, S(stream));
+    return step_impl(e, const_cast<int32_t*>(actions), reward, done, S(stream));
 }
 
 int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
@@ -347,7 +354,7 @@ int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -383,9 +390,8 @@ int64_t catan_invalid_action_count(catan_env_t* e, catan_stream_t stream) {
 int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream) {
     if (!e || steps < 0) return fail(CATAN_EINVAL, "catan_random_rollout: bad arguments");
     for (int64_t s = 0; s < steps; s++) {
-        int r = catan_sample_random_actions(e, step_idx0 + (uint32_t)s, e->scratch_actions, stream);
-        if (r != CATAN_OK) return r;
-        r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, S(stream));
+        const uint32_t step_idx = step_idx0 + (uint32_t)s;
+        int r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, S(stream), nullptr, &step_idx);
         if (r != CATAN_OK) return r;
     }
     return CATAN_OK;
@@ -407,8 +413,9 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
-                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa);
-    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev);
+                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa,
+                       e->pend.ctr + 16);
+    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
     HIPCHK(hipStreamWaitEvent(e->fstream[fa], e->ev_fready[fa], 0));
@@ -478,10 +485,8 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
             r = deferred_iter(e, s, steps, window, st, v);
             slow[s] = ((s + 1) % window == 0 || s + 1 == steps);
         } else {
-            HIPCHK(hipEventRecord(v[5], st));
-            hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, step_idx0 + (uint32_t)s,
-                               e->scratch_actions, (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr);
-            r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v);
+            const uint32_t step_idx = step_idx0 + (uint32_t)s;
+            r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, v, &step_idx);
             slow[s] = 1;
         }
         if (r != CATAN_OK) return r;

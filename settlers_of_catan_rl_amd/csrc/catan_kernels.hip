@@ -100,28 +100,37 @@ typedef StLT<1> StL1;     // k_reset_list: one game per wave, its hot record lin
 // 28 x 16 B per game, two games per pass (lanes 0..55): every load/store instruction moves 2 x 448 contiguous bytes.
 DEVI void stage_in(u32* tile, const u32* __restrict__ R, int e, int lane) {
     const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
-#pragma unroll 8
+    // all 32 loads are issued before the first LDS store: one HBM round trip instead of several (VGPRs are plentiful at
+    // one wave per SIMD)
+    uint4 v[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const int eg = __shfl(e, (2 * p + half) & 63);
+        v[p] = make_uint4(0, 0, 0, 0);
+        if (lane < 56 && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+    }
+#pragma unroll
     for (int p = 0; p < 32; p++) {
         const int g = 2 * p + half;
-        const int eg = __shfl(e, g & 63);
-        if (lane < 56 && eg >= 0) {
-            const uint4 v = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+        if (lane < 56) {
             u32* t = tile + (4 * q) * TS + g;
-            t[0] = v.x; t[TS] = v.y; t[2 * TS] = v.z; t[3 * TS] = v.w;
+            t[0] = v[p].x; t[TS] = v[p].y; t[2 * TS] = v[p].z; t[3 * TS] = v[p].w;
         }
     }
 }
 DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
     const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
-#pragma unroll 8
+    uint4 v[32];
+#pragma unroll
     for (int p = 0; p < 32; p++) {
         const int g = 2 * p + half;
-        const int eg = __shfl(e, g & 63);
-        if (lane < 56 && eg >= 0) {
-            const u32* t = tile + (4 * q) * TS + g;
-            uint4 v; v.x = t[0]; v.y = t[TS]; v.z = t[2 * TS]; v.w = t[3 * TS];
-            reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v;
-        }
+        const u32* t = tile + (4 * (lane < 56 ? q : 0)) * TS + g;
+        v[p].x = t[0]; v[p].y = t[TS]; v[p].z = t[2 * TS]; v[p].w = t[3 * TS];
+    }
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const int eg = __shfl(e, (2 * p + half) & 63);
+        if (lane < 56 && eg >= 0) reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v[p];
     }
 }
 
@@ -1637,16 +1646,13 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
 // it is scheduled (deferred rollouts).
 // A busy game whose tag equals tag_now or tag_now2 (>= 2) is released here: its step was completed on a side stream, which
 // the caller has joined before this launch.
-__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
-                                                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
-                                                        u32* __restrict__ zero_me) {
-    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
-    if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
-    if (s.e >= c.n) return;
+// Returns the sampled action type (-1: busy game, no action).
+DEVI int sample_random(const Ctx& c, const St& s, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
+                       u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2) {
     if (pctr != nullptr) {
         int b = busy[s.e];
         if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
-        if (b) { actions[s.e * ACTION_WORDS] = -1; return; }
+        if (b) { actions[s.e * ACTION_WORDS] = -1; return -1; }
         step_idx = pctr[s.e];
         pctr[s.e] = step_idx + 1;
     }
@@ -1718,6 +1724,29 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     }
 #pragma unroll
     for (int i = 0; i < ACTION_WORDS; i++) actions[s.e * ACTION_WORDS + i] = a[i];
+    return t;
+}
+// bins != nullptr: also the histogram of the counting sort (k_classify_hist fused in; rollout loops)
+__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
+                                                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
+                                                        u32* __restrict__ zero_me, u32* __restrict__ bins) {
+    __shared__ u32 hist[16];
+    if (bins != nullptr) {
+        if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
+    if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
+    int t = 13;                                             // padding games: the no-op bin
+    if (s.e < c.n) {
+        t = sample_random(c, s, mpk, step_idx, actions, pctr, busy, tag_now, tag_now2);
+        if (t < 0 || t > 12) t = 13;
+    }
+    if (bins != nullptr) {
+        if (s.e < c.N) atomicAdd(&hist[t], 1u);
+        __syncthreads();
+        if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ deciding seat
