@@ -159,9 +159,14 @@ int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y,
 int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
                          float eps, int relu, int is_bf16, catan_stream_t stream);
 
-/* k_step phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums over waves then 8
- * per-wave maxima, in 100 MHz wall-clock ticks, for the phases stage-in, validate+apply, tier-1 longest road,
- * holder logic (+cut), done/reward, reset, masks, write-back. */
+/* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
+ * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
+int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);
+
+/* phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums then 8 maxima (+ 4 tier-1 counters).
+ * Slots 0, 1, 2, 6, 7: k_step phases per wave in 100 MHz wall-clock ticks (stage-in, validate+apply, request push,
+ * done/reward+masks, write-back); slots 3, 4, 5: k_reset_list (philox draws, re-deals, serial shuffle ticks);
+ * tools/phase_profile.py prints them. */
 int catan_profile_enable(catan_env_t* env, int on);
 int catan_profile_read(catan_env_t* env, uint64_t* out16);
 

@@ -585,6 +585,13 @@ int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const vo
 
 // k_step phase profile (100 MHz wall_clock64 ticks): enable/zero, then read [8] sums over waves + [8] maxima.
 // phases: stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back.
+int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {
+    if (!dst || !src || bytes <= 0 || bytes % 16) return fail(CATAN_EINVAL, "catan_calib_copy: bad arguments");
+    hipLaunchKernelGGL(k_calib_copy, dim3(4096), dim3(BLOCK), 0, S(stream), (const uint4*)src, (uint4*)dst, (long)(bytes / 16));
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int catan_profile_enable(catan_env_t* e, int on) {
     if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
     HIPCHK(hipDeviceSynchronize());

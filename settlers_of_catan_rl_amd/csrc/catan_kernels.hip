@@ -1749,6 +1749,13 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ PMC calibration
+// Streams n16 x 16 B from src to dst: a launch with exactly known HBM bytes, used to calibrate the rocprofv3
+// FETCH_SIZE / WRITE_SIZE counters on this GPU (profiles/README.md).
+__global__ __launch_bounds__(BLOCK) void k_calib_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (long)gridDim.x * BLOCK) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------ deciding seat
 // ref: env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.  out = PlayerId 1..4
 __global__ __launch_bounds__(BLOCK) void k_deciding(Ctx c, i32* __restrict__ out) {
