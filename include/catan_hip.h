@@ -159,6 +159,14 @@ int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y,
 int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
                          float eps, int relu, int is_bf16, catan_stream_t stream);
 
+/* Weight / bias gradient of a Linear layer with a huge row count and small widths (the tile / card / player modules of
+ * RL/models: rows = 19 B .. 75 B, widths 6..256): dw[out][in] += sum_r dy[r][out] * x[r][in], db[out] += sum_r dy[r][out].
+ * x [rows][in], dy [rows][out] bfloat16 row-major, 16-byte aligned; dw, db float32, ACCUMULATED into (zero them first);
+ * db may be NULL.  MFMA (v_mfma_f32_16x16x32_bf16) with the rows split over the grid; in + 1 <= 160, out <= 256. */
+int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features);
+int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
+                       catan_stream_t stream);
+
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);

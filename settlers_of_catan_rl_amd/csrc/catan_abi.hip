@@ -93,6 +93,24 @@ static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, 
     }
 }
 
+template <int OTW, int IT>
+static int wgrad_launch(const void* x, const void* dy, float* dw, float* db, long R, int I, int O, hipStream_t st) {
+    long stages = (R + WG_KT - 1) / WG_KT;
+    long nb = stages < 1024 ? stages : 1024;                // 4 workgroups per CU at most; every block >= 1 stage
+    long per = (stages + nb - 1) / nb * WG_KT;
+    nb = (R + per - 1) / per;
+    hipLaunchKernelGGL((k_wgrad<OTW, IT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, I, O, per);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+template <int OTW>
+static int wgrad_dispatch_it(int it, const void* x, const void* dy, float* dw, float* db, long R, int I, int O, hipStream_t st) {
+    if (it <= 2) return wgrad_launch<OTW, 2>(x, dy, dw, db, R, I, O, st);
+    if (it <= 5) return wgrad_launch<OTW, 5>(x, dy, dw, db, R, I, O, st);
+    if (it <= 10) return wgrad_launch<OTW, 10>(x, dy, dw, db, R, I, O, st);
+    return fail(CATAN_EINVAL, "catan_linear_wgrad: in_features + 1 > 160");
+}
+
 extern "C" {
 
 const char* catan_last_error(void) { return g_err.c_str(); }
@@ -585,6 +603,24 @@ int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const vo
 
 // k_step phase profile (100 MHz wall_clock64 ticks): enable/zero, then read [8] sums over waves + [8] maxima.
 // phases: stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back.
+int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features) {
+    return rows >= 1 && in_features >= 1 && out_features >= 1 && in_features + 1 <= 160 && out_features <= 256;
+}
+
+int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
+                       catan_stream_t stream) {
+    if (!x || !dy || !dw || !catan_linear_wgrad_supported(rows, in_features, out_features))
+        return fail(CATAN_EINVAL, "catan_linear_wgrad: bad arguments / unsupported widths (in + 1 <= 160, out <= 256)");
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return fail(CATAN_EINVAL, "catan_linear_wgrad: x and dy must be 16-byte aligned");
+    const int it = (in_features + 1 + 15) / 16, otw = ((out_features + 15) / 16 + 3) / 4;
+    switch (otw) {
+    case 1: return wgrad_dispatch_it<1>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
+    case 2: return wgrad_dispatch_it<2>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
+    case 3: return wgrad_dispatch_it<3>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
+    default: return wgrad_dispatch_it<4>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
+    }
+}
+
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {
     if (!dst || !src || bytes <= 0 || bytes % 16) return fail(CATAN_EINVAL, "catan_calib_copy: bad arguments");
     hipLaunchKernelGGL(k_calib_copy, dim3(4096), dim3(BLOCK), 0, S(stream), (const uint4*)src, (uint4*)dst, (long)(bytes / 16));

@@ -232,4 +232,120 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ x, const f
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ tall-skinny weight gradient
+// dW[o][i] = sum_r dY[r][o] * X[r][i],  db[o] = sum_r dY[r][o]   for the Linear layers of the net whose row count is
+// huge and whose widths are small (tile encoder: R = 19 B rows, widths 25..192; card attention: R = 25 B..75 B, widths
+// 6..48; player modules: R = B..3 B, widths 152..256).  As library GEMMs (M x N = O x I tiny, K = R ~ 10^6) these took
+// 0.9-1.6 ms each - 40 % of a training step - because a 64 x 64 output offers a library kernel only a handful of tiles.
+// Here the ROWS are split over the grid: a 256-thread workgroup streams its slice of X and dY through LDS (transposed on
+// the way in, so that an MFMA fragment - 8 consecutive k of one column - is one 16 B LDS read), keeps the whole O x (I+1)
+// result in MFMA accumulators (v_mfma_f32_16x16x32_bf16; column I of the X tile is all ones, which yields db for free)
+// and adds it to dW / db with fp32 atomics at the end.  HBM-bound: R x (I + O) x 2 B read once.
+// Wave w owns o-tiles [w*OTW, (w+1)*OTW); IT i-tiles cover I+1 columns.  bf16 inputs, fp32 outputs (zeroed by the caller).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int WG_KT = 64;            // rows per stage
+constexpr int WG_LD = WG_KT + 8;     // LDS row pitch in elements (144 B: 16 B aligned fragments)
+
+// stage one operand tile: the 64 x W row-major span starting at element `base` (of `total` elements), transposed into
+// T[col][k].  NV = number of 16 B vectors per thread.
+template <int NV>
+__device__ __forceinline__ void wg_load(const unsigned short* __restrict__ src, long base, long total, int W, uint4 (&v)[NV], int tid) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const long f0 = (long)(tid + 256 * j) * 8;
+        v[j] = make_uint4(0, 0, 0, 0);
+        if (f0 < (long)WG_KT * W) {
+            const long g = base + f0;
+            if (g + 8 <= total) v[j] = *reinterpret_cast<const uint4*>(src + g);
+            else {
+                unsigned short e[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) e[q] = g + q < total ? src[g + q] : (unsigned short)0;
+                v[j] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+        }
+    }
+}
+template <int NV>
+__device__ __forceinline__ void wg_store(unsigned short* T, int W, const uint4 (&v)[NV], int tid) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const unsigned f0 = (unsigned)(tid + 256 * j) * 8u;
+        if (f0 < (unsigned)(WG_KT * W)) {
+            unsigned row = f0 / (unsigned)W, col = f0 - row * (unsigned)W;
+            const unsigned w4[4] = { v[j].x, v[j].y, v[j].z, v[j].w };
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (row < (unsigned)WG_KT) T[col * WG_LD + row] = (unsigned short)(w4[q >> 1] >> (16 * (q & 1)));
+                if (++col == (unsigned)W) { col = 0; row++; }
+            }
+        }
+    }
+}
+
+template <int OTW, int IT>
+__global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                               float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block) {
+    constexpr int XC = IT * 16, YC = OTW * 4 * 16;           // padded column counts
+    constexpr int NX = (WG_KT * XC / 8 + 255) / 256, NY = (WG_KT * YC / 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[XC * WG_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Yt[YC * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = r_begin + rows_per_block < R ? r_begin + rows_per_block : R;
+    if (r_begin >= R) return;
+    for (int x = tid; x < XC * WG_LD; x += 256) Xt[x] = 0;
+    for (int x = tid; x < YC * WG_LD; x += 256) Yt[x] = 0;
+    f32x4_t acc[OTW][IT];
+#pragma unroll
+    for (int a = 0; a < OTW; a++)
+#pragma unroll
+        for (int b = 0; b < IT; b++) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 vx[NX], vy[NY];
+    wg_load<NX>(X, r_begin * I, R * (long)I, I, vx, tid);
+    wg_load<NY>(dY, r_begin * O, R * (long)O, O, vy, tid);
+    __syncthreads();                                         // zero fill complete
+    for (long r0 = r_begin; r0 < r_end; r0 += WG_KT) {
+        wg_store<NX>(Xt, I, vx, tid);
+        wg_store<NY>(Yt, O, vy, tid);
+        if (tid < WG_KT) Xt[I * WG_LD + tid] = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;   // bf16 1.0: the bias column
+        __syncthreads();
+        if (r0 + WG_KT < r_end) {                            // next stage's loads fly during the MFMAs
+            wg_load<NX>(X, (r0 + WG_KT) * I, R * (long)I, I, vx, tid);
+            wg_load<NY>(dY, (r0 + WG_KT) * O, R * (long)O, O, vy, tid);
+        }
+        // rows_per_block is a multiple of WG_KT, so only the last block has a partial stage, and its missing rows were
+        // loaded as zeros
+#pragma unroll
+        for (int ks = 0; ks < WG_KT / 32; ks++) {
+            const int koff = ks * 32 + 8 * (lane >> 4);
+            bf16x8_t bfrag[IT];
+#pragma unroll
+            for (int b = 0; b < IT; b++) bfrag[b] = *reinterpret_cast<const bf16x8_t*>(&Xt[(b * 16 + (lane & 15)) * WG_LD + koff]);
+#pragma unroll
+            for (int a = 0; a < OTW; a++) {
+                bf16x8_t afrag = *reinterpret_cast<const bf16x8_t*>(&Yt[((wave * OTW + a) * 16 + (lane & 15)) * WG_LD + koff]);
+#pragma unroll
+                for (int b = 0; b < IT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < OTW; a++)
+#pragma unroll
+        for (int b = 0; b < IT; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (wave * OTW + a) * 16 + 4 * (lane >> 4) + r, i = b * 16 + (lane & 15);
+                const float v = acc[a][b][r];
+                if (o < O && v != 0.0f) {
+                    if (i < I) atomicAdd(&dW[(long)o * I + i], v);
+                    else if (i == I && db != nullptr) atomicAdd(&db[o], v);
+                }
+            }
+}
+
 }  // namespace catan

@@ -89,3 +89,48 @@ def small_layer_norm(x, ln, relu=False):
 
 def ln_supported(x, ln):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and len(ln.normalized_shape) == 1 and ln.normalized_shape[0] in LN_WIDTHS
+
+
+class _LinearTallSkinny(torch.autograd.Function):
+    """y = x @ w.T + b in bf16 (fp32 accumulate, library GEMM); backward: dx by the library, dw / db by the hand-written
+    MFMA kernel k_wgrad (csrc/catan_nn.hip) which splits the huge row dimension over the grid."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        with torch.autocast("cuda", enabled=False):
+            xb = x.to(torch.bfloat16)
+            wb = w.to(torch.bfloat16)
+            y = torch.nn.functional.linear(xb, wb, None if b is None else b.to(torch.bfloat16))
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        O, I = wb.shape
+        dy2 = dy.reshape(-1, O).to(torch.bfloat16).contiguous()
+        x2 = xb.reshape(-1, I).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ wb).reshape(xb.shape)
+        dw = torch.zeros((O, I), dtype=torch.float32, device=dy.device)
+        db = torch.zeros((O,), dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+        _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))
+        return dx, dw, db
+
+
+def linear_supported(x, w):
+    """bf16 compute on the GPU (autocast or bf16 input), widths the kernel is built for, and enough rows to be worth it."""
+    if not x.is_cuda or w.dim() != 2:
+        return False
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+        return False
+    O, I = w.shape
+    rows = x.numel() // I
+    return rows >= 4096 and bool(_lib.lib().catan_linear_wgrad_supported(rows, I, O))
+
+
+def linear(x, w, b=None):
+    """Linear layer for tall-skinny shapes (see linear_supported); same values as F.linear under bf16 autocast."""
+    return _LinearTallSkinny.apply(x, w, b)

@@ -38,6 +38,14 @@ def _ortho_linear(i, o, gain=math.sqrt(2)):
     return lin
 
 
+def _lin(x, w, b=None):
+    """F.linear; tall-skinny shapes (huge row count, small widths) take the path whose weight gradient is the hand-written
+    MFMA kernel (nn_kernels.linear) when training - as library GEMMs those gradients were 40 % of a step."""
+    if torch.is_grad_enabled() and nn_kernels.linear_supported(x, w):
+        return nn_kernels.linear(x, w, b)
+    return F.linear(x, w, b)
+
+
 def _ln(ln, x, relu=False):
     """LayerNorm (+ optional ReLU): the fused HIP kernel for the small widths on the GPU, torch otherwise."""
     if nn_kernels.ln_supported(x, ln):
@@ -60,10 +68,10 @@ class _MHA(nn.Module):
         B, L, D = x.shape
         w = torch.cat([n.weight for n in self.qkv_nets], 0)
         b = torch.cat([n.bias for n in self.qkv_nets], 0)
-        qkv = F.linear(x, w, b).view(B, L, 3, self.heads, self.hd)
+        qkv = _lin(x, w, b).view(B, L, 3, self.heads, self.hd)
         if x.is_cuda and nn_kernels.supported(L, self.heads, self.hd) and qkv.dtype in (torch.float32, torch.bfloat16):
             o = nn_kernels.small_attention(qkv, lens)             # fused HIP kernel (csrc/catan_nn.hip)
-            return self.out_proj_net(o)
+            return _lin(o, self.out_proj_net.weight, self.out_proj_net.bias)
         # reference formulation in plain torch ops (CPU parity tests, unsupported shapes)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
         scores = torch.matmul(q, k.transpose(-2, -1)) * (1.0 / math.sqrt(self.hd))
@@ -81,7 +89,7 @@ class _FFN(nn.Module):
         self.linear2 = _ortho_linear(mult * dim, dim)
 
     def forward(self, x):
-        return self.linear2(F.relu(self.linear1(x)))
+        return _lin(F.relu(_lin(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
 
 
 class _SubLayer(nn.Module):
@@ -112,10 +120,10 @@ class _TileEncoder(nn.Module):
         self.out_proj = _ortho_linear(dim, out_dim)
 
     def forward(self, tiles):
-        x = _ln(self.norm_2, self.first_layer(tiles), relu=True)
+        x = _ln(self.norm_2, _lin(tiles, self.first_layer.weight, self.first_layer.bias), relu=True)
         for layer in self.encoder_layers:
             x = layer(x)
-        return _ln(self.norm, self.out_proj(x), relu=True).reshape(tiles.shape[0], -1)   # relu(norm(.)).reshape == relu(norm(.).reshape)
+        return _ln(self.norm, _lin(x, self.out_proj.weight, self.out_proj.bias), relu=True).reshape(tiles.shape[0], -1)   # relu(norm(.)).reshape == relu(norm(.).reshape)
 
 
 def _card_summary(ids, lens, embedding, mha, norm):
@@ -123,7 +131,7 @@ def _card_summary(ids, lens, embedding, mha, norm):
     L = ids.shape[1]
     valid = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
     # 6-row embedding as a one-hot matmul: its backward is a GEMM instead of a 6-way atomic scatter
-    emb = F.one_hot(ids, embedding.num_embeddings).to(embedding.weight.dtype) @ embedding.weight
+    emb = _lin(F.one_hot(ids, embedding.num_embeddings).to(embedding.weight.dtype), embedding.weight.t())
     rep = _ln(norm, mha(emb, lens))
     return (rep * valid[..., None].to(rep.dtype)).sum(1)
 
@@ -142,9 +150,9 @@ class _CurrentPlayer(nn.Module):
         self.final_linear_layer = _ortho_linear(2 * proj + 256, 128)
 
     def forward(self, main, hid, hid_len, played, played_len, emb, hid_mha, played_mha):
-        h = _ln(self.norm_2, self.proj_hidden_dev_card(_card_summary(hid, hid_len, emb, hid_mha, self.norm)), relu=True)
-        p = _ln(self.norm_3, self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm)), relu=True)
-        m = F.relu(self.norm_1(self.main_input_layer_1(main)))
+        h = _ln(self.norm_2, _lin(_card_summary(hid, hid_len, emb, hid_mha, self.norm), self.proj_hidden_dev_card.weight, self.proj_hidden_dev_card.bias), relu=True)
+        p = _ln(self.norm_3, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
+        m = F.relu(self.norm_1(_lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias)))
         return F.relu(self.norm_4(self.final_linear_layer(torch.cat((m, p, h), -1))))
 
 
@@ -160,8 +168,8 @@ class _OtherPlayers(nn.Module):
         self.norm_3 = nn.LayerNorm(128)
 
     def forward(self, main, played, played_len, emb, played_mha):
-        p = _ln(self.norm_2, self.proj_played_dev_card(_card_summary(played, played_len, emb, played_mha, self.norm)), relu=True)
-        m = F.relu(self.norm_1(self.main_input_layer_1(main)))
+        p = _ln(self.norm_2, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
+        m = F.relu(self.norm_1(_lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias)))
         return F.relu(self.norm_3(self.final_linear_layer(torch.cat((m, p), -1))))
 
 

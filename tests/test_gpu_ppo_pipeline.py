@@ -123,3 +123,60 @@ def test_small_layer_norm_kernel_vs_torch(hip_lib, D, dtype, relu):
         n = x.numel() // D
         assert torch.allclose(gw, ln.weight.grad, atol=tol * 4 * max(1, n ** 0.5), rtol=2e-2)
         assert torch.allclose(gb, ln.bias.grad, atol=tol * 4 * max(1, n ** 0.5), rtol=2e-2)
+
+
+@pytest.mark.parametrize("R,I,O", [(100003, 60, 64), (5000, 6, 16), (70001, 64, 192), (33333, 152, 256), (4097, 16, 25),
+                                   (20000, 128, 64), (64, 16, 48), (130, 159, 256)])
+def test_linear_wgrad_kernel_vs_torch(hip_lib, R, I, O):
+    """k_wgrad (MFMA, rows split over the grid): dw = dy^T x, db = column sums of dy, against fp32 torch on the same bf16
+    inputs.  Asymmetric random data (a transposed or row/column-swapped result cannot pass)."""
+    import ctypes as C
+    from settlers_of_catan_rl_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(R + I)
+    x = (torch.randn((R, I), device="cuda", generator=g) * torch.linspace(0.5, 2.0, I, device="cuda")).to(torch.bfloat16)
+    dy = (torch.randn((R, O), device="cuda", generator=g) * torch.linspace(2.0, 0.25, O, device="cuda") + 0.1).to(torch.bfloat16)
+    dw = torch.zeros((O, I), device="cuda")
+    db = torch.zeros((O,), device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.catan_linear_wgrad_supported(R, I, O)
+    _lib.check(L.catan_linear_wgrad(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), C.c_void_p(db.data_ptr()),
+                                    R, I, O, st))
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    tol = 2e-5 * float(ref_w.abs().max()) + 1e-3        # fp32 accumulation of exact bf16 products, different order
+    assert float((dw.double() - ref_w).abs().max()) < tol
+    assert float((db.double() - ref_b).abs().max()) < 2e-5 * float(ref_b.abs().max()) + 1e-3
+
+
+def test_policy_grads_with_wgrad_kernel_match_library_path(hip_lib, monkeypatch):
+    """The net's parameter gradients under bf16 autocast: tall-skinny Linear layers through k_wgrad vs through F.linear."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd import nn_kernels
+    torch.manual_seed(1)
+    B = 4096
+    env = VecCatanEnv(B, seed=3)
+    env.random_rollout(0, 400)
+    f, lists, lens = env.get_obs()
+    masks = env.get_action_masks()
+    lens = lens.long()
+    net = CatanPolicy().cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, a, _ = net.act(f, lists, lens, masks, generator=torch.Generator(device="cuda").manual_seed(0))
+
+    def grads(use_kernel):
+        if not use_kernel:
+            monkeypatch.setattr(nn_kernels, "linear_supported", lambda x, w: False)
+        net.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            v, lp, ent = net.evaluate_actions(f, lists, lens, masks, a)
+        (v.float().mean() + lp.float().mean() - 0.01 * ent).backward()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    g1 = grads(True)
+    g0 = grads(False)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        den = float(g0[k].norm()) + 1e-6
+        assert float((g1[k] - g0[k]).norm()) / den < 5e-2, k     # bf16 activations; the kernel path keeps dw in fp32

@@ -26,7 +26,7 @@ print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_nam
 ev = prof.key_averages()
 print("total kernels launched:", sum(e.count for e in ev if e.device_type is not None and "cuda" in str(e.device_type).lower()))
 # minibatch step
-Bm = 16384
+Bm = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 _, a, _ = act()
 opt = torch.optim.Adam(net.parameters(), lr=1e-4)
 def step():
@@ -40,4 +40,4 @@ for _ in range(5): step()
 torch.cuda.synchronize(); print(f"train step B={Bm}: {(time.perf_counter()-t0)/5*1e3:.1f} ms")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=70))
