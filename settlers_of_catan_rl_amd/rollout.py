@@ -52,11 +52,14 @@ def pack_action_masks(m):
 
 class RolloutCollector(object):
     def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None):
-        """policy: central net (policy 0); opponents: list of up to 3 nets for policies 1..3 (None = every seat plays
-        the central policy, i.e. true self-play - a documented deviation from the reference's league opponents)."""
+        """policy: central net (policy 0); opponents: list of up to 3 nets for policy slots 1..3 of every game (None =
+        every seat plays the central policy).  A league (league.League.assign) installs per-game opponents instead."""
         self.env, self.policy, self.T = env, policy, num_steps
-        self.opponents = opponents or []
         self.N, self.device = env.n, env.device
+        self.opponent_nets, self.opp_index = [], None
+        if opponents:
+            nets = list(opponents)
+            self.set_opponents(nets, torch.tensor([[min(j, len(nets) - 1) for j in range(3)]]).expand(self.N, 3))
         self.autocast_dtype = autocast_dtype
         g = torch.Generator(device="cpu").manual_seed(seed)
         # game_manager.py:24-31: a random seat order per game; order[0] is the active player, order[j] plays policy j
@@ -68,6 +71,12 @@ class RolloutCollector(object):
         self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
         self.storage = RolloutStorage(num_steps, self.N, self.device)
         self.reset()
+
+    def set_opponents(self, nets, opp_index):
+        """nets: the distinct opponent nets in play; opp_index int64 [N,3]: which of them plays policy slots 1..3 of
+        each game (game_manager.py:15,28-31: the slot -> seat map of a game stays fixed)."""
+        self.opponent_nets = list(nets)
+        self.opp_index = opp_index.to(self.device).long().contiguous() if len(self.opponent_nets) else None
 
     # game_manager.py:35-59 (the env itself is already reset: EnvWrapper.reset() happened in catan_create / env.reset())
     def reset(self):
@@ -157,17 +166,18 @@ class RolloutCollector(object):
         return st
 
     def _act(self, f, lists, lens, masks, pol):
-        nets = [self.policy] + list(self.opponents)
+        """One batched forward per distinct net in play: net 0 = central policy, net 1 + k = opponent_nets[k]."""
         N = f.shape[0]
+        if not self.opponent_nets:
+            groups = [(None, self.policy)]
+        else:
+            ar = torch.arange(N, device=f.device)
+            net_id = torch.where(pol == 0, torch.zeros_like(pol), 1 + self.opp_index[ar, (pol - 1).clamp(min=0)])
+            groups = [((net_id == int(k)).nonzero(as_tuple=True)[0], self.policy if int(k) == 0 else self.opponent_nets[int(k) - 1])
+                      for k in torch.unique(net_id).tolist()]
         actions = torch.zeros((N, spec.ACTION_WORDS), dtype=torch.int64, device=f.device)
         logp = torch.zeros((N,), dtype=torch.float32, device=f.device)
-        if len(nets) == 1:
-            groups = [(None, nets[0])]
-        else:
-            groups = [((pol == k).nonzero(as_tuple=True)[0], nets[min(k, len(nets) - 1)]) for k in range(4)]
         for idx, net in groups:
-            if idx is not None and idx.numel() == 0:
-                continue
             args = (f, lists, lens, masks) if idx is None else (f[idx], lists[idx], lens[idx], masks[idx])
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):

@@ -180,3 +180,36 @@ def test_policy_grads_with_wgrad_kernel_match_library_path(hip_lib, monkeypatch)
     for k in g0:
         den = float(g0[k].norm()) + 1e-6
         assert float((g1[k] - g0[k]).norm()) / den < 5e-2, k     # bf16 activations; the kernel path keeps dw in fp32
+
+
+def test_rollout_with_league_opponents(hip_lib):
+    """Per-worker league opponents (league.League.assign -> grouped inference in the collector): a rollout + update runs,
+    no illegal action reaches the env, and with snapshots identical to the central policy the stored log-probs are those
+    of the central policy on the stored observations."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.league import League
+    torch.manual_seed(0)
+    N, T = 200, 6
+    env = VecCatanEnv(N, seed=9)
+    env.random_rollout(0, 300)
+    net = CatanPolicy().cuda()
+    col = RolloutCollector(env, net, T, seed=1)
+    lg = League(envs_per_worker=5, seed=2)
+    lg.add(net)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    lg.add(net)                                              # two distinct snapshots in the deque
+    distinct = lg.assign(col, lambda: CatanPolicy().cuda())
+    assert 1 <= len(distinct) <= 2 and col.opp_index.shape == (N, 3)
+    st = col.gather_rollouts()
+    assert env.invalid_action_count() == 0
+    assert int(col.n_act.min()) == T
+    # the stored decisions belong to the central policy: re-evaluating them reproduces the stored log-probs
+    f = st.obs_f[:T].reshape(T * N, -1); lists = st.lists[:T].reshape(T * N, 5, -1); lens = st.lens[:T].reshape(T * N, 5)
+    with torch.no_grad():
+        _, lp, _ = net.evaluate_actions(f.float(), lists, lens.long(), st.unpack_action_masks(st.action_masks.reshape(T * N, -1)),
+                                        st.actions.reshape(T * N, -1))
+    assert torch.allclose(lp[:, 0], st.action_log_probs.reshape(T * N), atol=2e-4)

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--warm-games", type=int, default=600, help="random-policy steps before the first rollout (mixes game ages)")
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--league", type=int, default=0,
+                    help="K > 0: opponents from the snapshot league, at most K distinct nets in play (league.League, bounded "
+                         "variant); 0: every seat plays the central policy")
     args = ap.parse_args()
     import torch
     from settlers_of_catan_rl_amd import dist as cdist
@@ -43,6 +46,12 @@ def main():
     ac = None if args.fp32 else torch.bfloat16
     col = RolloutCollector(env, net, args.num_steps, seed=rank, autocast_dtype=ac)
     tr = PPOTrainer(net, PPOConfig(ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch), autocast_dtype=ac, seed=rank)
+    lg = None
+    if args.league > 0:
+        from settlers_of_catan_rl_amd.league import League
+        lg = League(max_distinct=args.league, seed=rank)
+        lg.add(net)                                          # robust_train.py:62-64: the deque starts with the initial policy
+        lg.assign(col, lambda: CatanPolicy().cuda())
     res = []
     for u in range(args.updates):
         cdist.barrier()
@@ -54,6 +63,8 @@ def main():
         cdist.barrier()
         t2 = time.perf_counter()
         col.after_rollouts()
+        if lg is not None and lg.after_update(u, net):
+            lg.assign(col, lambda: CatanPolicy().cuda())
         res.append(dict(rollout_s=cdist.max_over_ranks(t1 - t0), update_s=cdist.max_over_ranks(t2 - t1), env_iters=col.iters,
                         value_loss=vl, action_loss=al, entropy_loss=el, **tr.timings))
     if rank == 0:
@@ -63,7 +74,7 @@ def main():
             "metric": "PPO wall-clock per update", "value": last["rollout_s"] + last["update_s"], "unit": "s/update",
             "higher_is_better": False, "n_gpus": world, "dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 params/softmax)",
             "config": {"workload": "configs[2]: self-play PPO, RL/models net", "games_per_gpu": n, "num_steps": args.num_steps,
-                       "ppo_epoch": args.ppo_epoch, "num_mini_batch": args.num_mini_batch,
+                       "ppo_epoch": args.ppo_epoch, "num_mini_batch": args.num_mini_batch, "league_max_distinct": args.league,
                        "active_seat_decisions_per_update": dec, "minibatch_rows": dec // world // args.num_mini_batch},
             "split": last, "decisions_per_s": dec / (last["rollout_s"] + last["update_s"]),
             "env_steps_per_s_in_rollout": world * n * last["env_iters"] / last["rollout_s"],

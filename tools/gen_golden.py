@@ -231,7 +231,38 @@ def gen_gae_ppo():
     np.savez_compressed(os.path.join(OUT, "gae_ppo.npz"), **out)
 
 
+def gen_league():
+    """RL/ppo/update_opponent_policies.py: the probability vector for several deque lengths, and the draws of
+    update_opponent_policies for a fake rollout manager (numpy global RandomState seeded)."""
+    from RL.ppo.update_opponent_policies import get_prob_dist, update_opponent_policies
+    out = {}
+    sizes = [1, 2, 5, 37, 500, 800, 801, 1000]
+    for n in sizes:
+        out[f"p_{n}"] = get_prob_dist(n)
+    out["sizes"] = np.array(sizes)
+
+    class FakeManager(object):
+        def __init__(self, nproc):
+            self.processes = list(range(nproc))
+            self.calls = []
+
+        def update_policy(self, sd, process_id, policy_id):
+            self.calls.append((process_id, policy_id, sd["id"]))
+
+    for (seed, nproc, npol) in [(0, 7, 40), (5, 128, 500), (9, 3, 1)]:
+        np.random.seed(seed)
+        mgr = FakeManager(nproc)
+        update_opponent_policies([{"id": i} for i in range(npol)], mgr, None)
+        idx = np.zeros((nproc, 3), dtype=np.int64)
+        for (pi, pol, sid) in mgr.calls:
+            idx[pi, pol - 1] = sid
+        out[f"draw_{seed}_{nproc}_{npol}"] = idx
+    np.savez_compressed(os.path.join(OUT, "league.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "league":
+        gen_league(); print("league"); sys.exit(0)
     gen_topology(); print("topology")
     gen_resets(); print("resets")
     for (s, eid, steps) in [(3, 0, 2600), (3, 1, 2600), (17, 4, 1800)]:
@@ -239,4 +270,5 @@ if __name__ == "__main__":
     gen_mt_kat(); print("mt kat")
     gen_longest_road(); print("longest road")
     gen_gae_ppo(); print("gae/ppo")
+    gen_league(); print("league")
     os.system(f"ls -la {OUT}; du -sh {OUT}")
