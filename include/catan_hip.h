@@ -159,6 +159,16 @@ int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y,
 int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
                          float eps, int relu, int is_bf16, catan_stream_t stream);
 
+/* Game.randomise_uncertainty(controlling_player_id): game/game.py:1207-1282 (forward search, worker.py:46): re-deals
+ * the dev-card pile + the other players' hidden cards and the other players' resource hands, consistently with what the
+ * controlling player knows (his opponent_min_res / opponent_max_res bounds, hand sizes, the bank).  controlling_player:
+ * DEVICE int32[n], PlayerId 1..4 per game, 0 = leave that game alone.  Draws from the game's own RNG stream; the packed
+ * masks are recomputed.  The reference's rejection loop does not terminate on a state whose bounds admit no consistent
+ * deal (it only ever calls this on freshly restored states); here the loop is capped at 100 000 attempts and such games
+ * are counted by catan_inconsistent_deal_count. */
+int catan_randomise_uncertainty(catan_env_t* env, const int32_t* controlling_player, catan_stream_t stream);
+int64_t catan_inconsistent_deal_count(catan_env_t* env, catan_stream_t stream);
+
 /* Weight / bias gradient of a Linear layer with a huge row count and small widths (the tile / card / player modules of
  * RL/models: rows = 19 B .. 75 B, widths 6..256): dw[out][in] += sum_r dy[r][out] * x[r][in], db[out] += sum_r dy[r][out].
  * x [rows][in], dy [rows][out] bfloat16 row-major, 16-byte aligned; dw, db float32, ACCUMULATED into (zero them first);

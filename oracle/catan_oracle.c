@@ -1242,6 +1242,80 @@ int64_t orc_batch_run_random_counts(OrcEnv* envs, int64_t n, uint64_t seed, uint
     return total;
 }
 
+/* ====================================================================== forward search: randomise_uncertainty */
+/* ref: game/game.py:1207-1282.  Re-deals everything the controlling player cannot see: the dev-card pile and the other
+ * players' hidden cards are pooled, shuffled (np.random.shuffle) and dealt back (popped from the right end, players in dict
+ * order Blue, Red, Orange, White); the other players' resources are reset to the controlling player's lower bounds and the
+ * unaccounted cards are handed out in a random order (random.shuffle) to random players (random.shuffle of the four
+ * players per card) subject to the upper bounds and the players' true hand sizes, retried until all five resources add
+ * up to 19 with the bank.  Philox mode only: both shuffles are Fisher-Yates from the top on the game stream.
+ * Returns the number of attempts of the rejection loop, or -1 in MT mode. */
+int orc_randomise_uncertainty(OrcEnv* e, int ctrl) {
+    static const int dict_order[4] = { P_BLUE, P_RED, P_ORANGE, P_WHITE };      /* game.py:18-23 */
+    static const int res_order[5] = { 4, 1, 3, 5, 2 };                           /* Sheep, Brick, Ore, Wheat, Wood (:1232) */
+    if (e->rng.mode != ORC_RNG_PHILOX) return -1;
+    int pool[32], n = 0;
+    for (int i = 0; i < e->pile_len; i++) pool[n++] = e->pile[i];                /* :1210 */
+    for (int k = 0; k < 4; k++) {
+        int p = dict_order[k];
+        if (p == ctrl) continue;
+        for (int j = 0; j < e->pl[p].n_hidden; j++) pool[n++] = e->pl[p].hidden[j];
+    }
+    rng_shuffle(e, pool, n);                                                     /* :1214 */
+    for (int k = 0; k < 4; k++) {                                                /* :1217-1220 */
+        int p = dict_order[k];
+        if (p == ctrl) continue;
+        for (int j = 0; j < e->pl[p].n_hidden; j++) e->pl[p].hidden[j] = pool[--n];
+    }
+    e->pile_len = n;
+    for (int i = 0; i < n; i++) e->pile[i] = pool[i];
+
+    int total_before[5], unacc[6];
+    for (int p = 1; p <= 4; p++) { total_before[p] = 0; for (int r = 1; r <= 5; r++) total_before[p] += e->pl[p].res[r]; }
+    for (int q = 0; q < 5; q++) {                                                /* :1230-1243 */
+        int r = res_order[q], acc = e->bank[r];
+        for (int k = 0; k < 4; k++) {
+            int p = dict_order[k];
+            if (p != ctrl) {
+                int d = e->pl[ctrl].opp_min[label_of(e, ctrl, p)][r];
+                acc += d;
+                e->pl[p].res[r] = d;
+            } else acc += e->pl[p].res[r];
+        }
+        unacc[r] = 19 - acc;
+    }
+    int attempts = 0;
+    int prop[5][6];
+    for (;;) {                                                                   /* :1245-1276 */
+        attempts++;
+        for (int p = 1; p <= 4; p++) for (int r = 1; r <= 5; r++) prop[p][r] = e->pl[p].res[r];
+        int list[128], len = 0;
+        for (int q = 0; q < 5; q++) for (int c = 0; c < unacc[res_order[q]]; c++) list[len++] = res_order[q];
+        rng_shuffle(e, list, len);                                               /* random.shuffle(res_list) */
+        while (len > 0) {
+            int r = list[--len];
+            int keys[4] = { dict_order[0], dict_order[1], dict_order[2], dict_order[3] };
+            rng_shuffle(e, keys, 4);                                             /* random.shuffle(player_keys) */
+            for (int k = 0; k < 4; k++) {
+                int p = keys[k];
+                if (p == ctrl) continue;
+                int tot = 0;
+                for (int x = 1; x <= 5; x++) tot += prop[p][x];
+                if (tot < total_before[p] && e->pl[ctrl].opp_max[label_of(e, ctrl, p)][r] > prop[p][r]) { prop[p][r]++; break; }
+            }
+        }
+        int ok = 0;
+        for (int r = 1; r <= 5; r++) {
+            int in_hand = 0;
+            for (int p = 1; p <= 4; p++) in_hand += prop[p][r];
+            if (in_hand + e->bank[r] == 19) ok++;
+        }
+        if (ok == 5) break;
+    }
+    for (int p = 1; p <= 4; p++) for (int r = 1; r <= 5; r++) e->pl[p].res[r] = prop[p][r];
+    return attempts;
+}
+
 /* ====================================================================== GAE + PPO loss */
 /* ref: RL/ppo/process_batch.py:134-142.  fp32 recurrences in the reference's evaluation order; the global
  * mean / unbiased std are accumulated in fp64 (torch reduces in fp32 with a different order: tolerance 1e-5). */

@@ -621,6 +621,22 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
     }
 }
 
+int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
+    if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
+    hipLaunchKernelGGL(k_randomise_uncertainty, dim3(blocks(e->n, 64)), dim3(64), 0, S(stream), e->ctx, controlling_player, e->mpk, e->err,
+                       100000, e->cfg.max_proposed_trades_per_turn);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int64_t catan_inconsistent_deal_count(catan_env_t* e, catan_stream_t stream) {
+    if (!e) return -1;
+    u32 v = 0;
+    if (hipMemcpyAsync(&v, e->err + 1, sizeof v, hipMemcpyDeviceToHost, S(stream)) != hipSuccess) return -1;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {
     if (!dst || !src || bytes <= 0 || bytes % 16) return fail(CATAN_EINVAL, "catan_calib_copy: bad arguments");
     hipLaunchKernelGGL(k_calib_copy, dim3(4096), dim3(BLOCK), 0, S(stream), (const uint4*)src, (uint4*)dst, (long)(bytes / 16));

@@ -1749,6 +1749,131 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward search
+// Game.randomise_uncertainty (game/game.py:1207-1282): re-deal everything the controlling player cannot see.  The pile and
+// the other players' hidden dev cards are pooled, shuffled and dealt back (popped from the right end, players in dict
+// order Blue, Red, Orange, White); the other players' hands are reset to the controlling player's lower bounds and the
+// unaccounted resource cards are handed out in a shuffled order, each to the first player of a freshly shuffled player
+// order who is below his true hand size and below the controlling player's upper bound for that resource; the hand-out
+// is retried until every resource adds up to 19 with the bank.  Lane = game; the per-game scratch arrays live in LDS as
+// [index][lane].  ctrl[e] = controlling PlayerId 1..4 (0: leave game e alone).  The reference loops forever on states
+// whose estimates admit no consistent deal; here the loop is capped (max_attempts) and such games are counted in err[1].
+__global__ __launch_bounds__(64) void k_randomise_uncertainty(Ctx c, const i32* __restrict__ ctrl, u32* __restrict__ mpk, u32* __restrict__ err,
+                                                              int max_attempts, int max_trades) {
+    __shared__ u8 pool[32][64];
+    __shared__ u8 lst[96][64];
+    __shared__ u8 prop[20][64], hand[20][64], emx[20][64];
+    const int lane = threadIdx.x;
+    const long e = (long)blockIdx.x * 64 + lane;
+    if (e >= c.n) return;
+    const int cp = ctrl[e] - 1;
+    if (cp < 0 || cp > 3) return;
+    St s(c.R, c.N, e);
+    Rng rng = rng_load(c, s);
+    const int seatof = s.b(B_SEATOF);
+    const u32 DICT = 1u | (3u << 8) | (2u << 16) | (0u << 24);           // Blue, Red, Orange, White as pid0 (game.py:18-23)
+    // ---- development cards (:1210-1221)
+    int n = 0;
+    const int plen = s.b(B_PILE_LEN);
+    for (int i = 0; i < plen; i++) pool[n++][lane] = (u8)s.pile(i);
+    for (int k = 0; k < 4; k++) {
+        const int p = (DICT >> (8 * k)) & 255;
+        if (p == cp) continue;
+        const int nh = s.pb(p, P_NHID);
+        for (int j = 0; j < nh; j++) pool[n++][lane] = (u8)s.hidden(p, j);
+    }
+    for (int i = n - 1; i >= 1; i--) {                                   // np.random.shuffle
+        const int j = (int)rng.bounded((u32)i);
+        const u8 t = pool[i][lane]; pool[i][lane] = pool[j][lane]; pool[j][lane] = t;
+    }
+    for (int k = 0; k < 4; k++) {
+        const int p = (DICT >> (8 * k)) & 255;
+        if (p == cp) continue;
+        const int nh = s.pb(p, P_NHID);
+        u32 cnt = 0;                                                     // 5 counters of 6 bits
+        for (int j = 0; j < nh; j++) { const int v = pool[--n][lane]; s.set_hidden(p, j, v); cnt += 1u << (6 * v); }
+        for (int t = 0; t < 5; t++) s.spb(p, P_HCNT + t, (cnt >> (6 * t)) & 63);
+    }
+    s.sb(B_PILE_LEN, n);
+    for (int i = 0; i < n; i++) s.set_pile(i, pool[i][lane]);
+    // ---- resources (:1224-1243); r0: 0 Brick, 1 Wood, 2 Ore, 3 Sheep, 4 Wheat; reference order Sheep, Brick, Ore, Wheat, Wood
+    const u32 RORD = 3u | (0u << 4) | (2u << 8) | (4u << 12) | (1u << 16);
+    int total_before[4], unacc[5], bank[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) bank[r] = s.b(B_BANK + r);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { const int v = s.res(p, r); hand[p * 5 + r][lane] = (u8)v; t += v; }
+        total_before[p] = t;
+        if (p != cp) {
+            Est E;
+            est_load(s, cp, label_of(seatof, cp, p), E);
+#pragma unroll
+            for (int r = 0; r < 5; r++) { hand[p * 5 + r][lane] = (u8)E.mn[r]; emx[p * 5 + r][lane] = (u8)E.mx[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        int acc = bank[r];
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc += hand[p * 5 + r][lane];
+        unacc[r] = 19 - acc;
+    }
+    int attempts = 0;
+    bool ok = false;
+    while (!ok) {                                                        // :1245-1276
+        for (int x = 0; x < 20; x++) prop[x][lane] = hand[x][lane];
+        int len = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int r = (RORD >> (4 * q)) & 15;
+            for (int k = 0; k < unacc[r] && len < 96; k++) lst[len++][lane] = (u8)r;
+        }
+        for (int i = len - 1; i >= 1; i--) {                             // random.shuffle(res_list)
+            const int j = (int)rng.bounded((u32)i);
+            const u8 t = lst[i][lane]; lst[i][lane] = lst[j][lane]; lst[j][lane] = t;
+        }
+        while (len > 0) {
+            const int r = lst[--len][lane];
+            u32 keys = DICT;                                             // random.shuffle(player_keys)
+#pragma unroll
+            for (int i = 3; i >= 1; i--) {
+                const int j = (int)rng.bounded((u32)i);
+                const u32 a = (keys >> (8 * i)) & 255, b = (keys >> (8 * j)) & 255;
+                keys = (keys & ~(255u << (8 * i)) & ~(255u << (8 * j))) | (b << (8 * i)) | (a << (8 * j));
+            }
+            for (int k = 0; k < 4; k++) {
+                const int p = (keys >> (8 * k)) & 255;
+                if (p == cp) continue;
+                int tot = 0;
+#pragma unroll
+                for (int x = 0; x < 5; x++) tot += prop[p * 5 + x][lane];
+                if (tot < total_before[p] && emx[p * 5 + r][lane] > prop[p * 5 + r][lane]) { prop[p * 5 + r][lane]++; break; }
+            }
+        }
+        ok = true;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            int in_hand = bank[r];
+#pragma unroll
+            for (int p = 0; p < 4; p++) in_hand += prop[p * 5 + r][lane];
+            if (in_hand != 19) ok = false;
+        }
+        if (!ok && ++attempts >= max_attempts) { atomicAdd(&err[1], 1u); break; }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int r = 0; r < 5; r++) s.spb(p, P_RES + r, prop[p * 5 + r][lane]);
+    s.sw(W_RNG, rng.draws);
+    u32 m[MASK_WORDS];
+    compute_masks(s, m, max_trades);
+#pragma unroll
+    for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
+}
+
 // ------------------------------------------------------------------------------------------------ PMC calibration
 // Streams n16 x 16 B from src to dst: a launch with exactly known HBM bytes, used to calibrate the rocprofv3
 // FETCH_SIZE / WRITE_SIZE counters on this GPU (profiles/README.md).

@@ -98,6 +98,15 @@ class VecCatanEnv(object):
     def random_rollout(self, step_idx0, steps):
         _lib.check(self.L.catan_random_rollout(self.h, int(step_idx0), int(steps), _stream()))
 
+    def randomise_uncertainty(self, controlling_player):
+        """Game.randomise_uncertainty for every game with controlling_player[i] in 1..4 (0: untouched), game.py:1207-1282"""
+        cp = torch.as_tensor(controlling_player, device=self.device).to(torch.int32).contiguous()
+        assert cp.shape == (self.n,)
+        _lib.check(self.L.catan_randomise_uncertainty(self.h, _ptr(cp), _stream()))
+
+    def inconsistent_deal_count(self):
+        return int(self.L.catan_inconsistent_deal_count(self.h, _stream()))
+
     def random_rollout_deferred(self, iters, window):
         """`iters` iterations of the deferred loop (include/catan_hip.h): games that need the slow path (longest road,
         re-deal) sit out until their window of `window` iterations closes; per-game trajectories are the lock-step ones."""

@@ -51,6 +51,8 @@ def lib():
         u32p = C.POINTER(C.c_uint32)
         L.orc_batch_run_random_counts.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, u32p, u32p, i32p, i64p, C.c_int]
         L.orc_batch_run_random_counts.restype = C.c_int64
+        L.orc_randomise_uncertainty.argtypes = [vp, C.c_int]
+        L.orc_randomise_uncertainty.restype = C.c_int
         L.orc_gae.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_double, C.c_double, f32p, f32p]
         L.orc_ppo_loss.argtypes = [f32p] * 6 + [C.c_int64, C.c_float, f32p, f32p, f32p, f32p, C.c_float]
         _lib = L
@@ -110,6 +112,12 @@ class OracleEnv(object):
         rc = self.L.orc_step(self.p, _p(a, C.c_int32), _p(rew, C.c_float), C.byref(done))
         assert rc == 0
         return rew, bool(done.value)
+
+    def randomise_uncertainty(self, controlling_player):
+        """Game.randomise_uncertainty (game.py:1207-1282); returns the attempts of its rejection loop"""
+        r = self.L.orc_randomise_uncertainty(self.p, int(controlling_player))
+        assert r >= 1
+        return r
 
     def deciding_player(self):
         return self.L.orc_deciding_player(self.p)

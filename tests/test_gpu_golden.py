@@ -56,3 +56,42 @@ def test_reference_states_masks(hip_lib):
     env.import_state(np.array(blobs))
     assert np.array_equal(env.export_state().cpu().numpy(), np.array(blobs))
     assert np.array_equal(env.get_action_masks().cpu().numpy(), np.array(masks))
+
+
+def test_randomise_uncertainty_golden_and_oracle(oracle, hip_lib):
+    """k_randomise_uncertainty against the reference's before/after states (tests/golden/randomise.npz) and, on a larger
+    batch of mid-game states, against the CPU oracle (state incl. card orders, hands, pile, RNG draw count; masks)."""
+    import torch
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    g = gu.load("randomise.npz")
+    seed = int(g["seed"])
+    n_games = int(g["env_id"].max()) + 1
+    per = len(g["ctrl"]) // n_games
+    env = VecCatanEnv(n_games, seed=seed, auto_reset=False)
+    for k in range(per):                                    # one case per game per round: game e uses the stream of env id e
+        sel = [e * per + k for e in range(n_games)]
+        assert [int(g["env_id"][i]) for i in sel] == list(range(n_games))
+        env.import_state(g["before"][sel])
+        env.randomise_uncertainty(torch.tensor(g["ctrl"][sel]))
+        out = env.export_state().cpu().numpy()
+        for j, i in enumerate(sel):
+            assert np.array_equal(out[j], g["after"][i]), f"case {i}:\n" + spec.describe_state_diff(g["after"][i], out[j])
+    assert env.inconsistent_deal_count() == 0
+    # larger batch vs the oracle: 512 games at various ages, a random controlling player each (0 = untouched)
+    n, seed = 512, 77
+    env = VecCatanEnv(n, seed=seed)
+    ob = oracle.OracleBatch(n, seed)
+    env.random_rollout(0, 900)
+    ob.run_random(900, want_blobs=False)
+    rng = np.random.default_rng(5)
+    ctrl = rng.integers(0, 5, size=n)
+    env.randomise_uncertainty(torch.tensor(ctrl))
+    for i in range(n):
+        if ctrl[i]:
+            ob.L.orc_randomise_uncertainty(ob.env_ptr(i), int(ctrl[i]))
+    out = env.export_state().cpu().numpy()
+    want = ob.export()
+    bad = np.flatnonzero((out != want).any(axis=1))
+    assert len(bad) == 0, f"{len(bad)} games differ; game {bad[0]} ctrl {ctrl[bad[0]]}:\n" + spec.describe_state_diff(want[bad[0]], out[bad[0]])
+    assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+    assert env.inconsistent_deal_count() == 0

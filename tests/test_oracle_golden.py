@@ -147,3 +147,15 @@ def test_resource_conservation_property(oracle):
             tot = tot + spec.state_field(blobs, f"p{p}_res")
         assert (tot == 19).all()
         assert (spec.state_field(blobs, "p1_res") >= 0).all()
+
+
+def test_randomise_uncertainty_golden(oracle):
+    """Game.randomise_uncertainty (game.py:1207-1282): states before / after from the reference (tools/gen_golden.py)."""
+    g = gu.load("randomise.npz")
+    seed = int(g["seed"])
+    for before, after, ctrl, env_id in zip(g["before"], g["after"], g["ctrl"], g["env_id"]):
+        e = oracle.OracleEnv(seed, int(env_id))
+        e.import_(before)
+        e.randomise_uncertainty(int(ctrl))
+        out = e.export()
+        assert np.array_equal(out, after), spec.describe_state_diff(after, out)

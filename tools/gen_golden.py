@@ -260,7 +260,38 @@ def gen_league():
     np.savez_compressed(os.path.join(OUT, "league.npz"), **out)
 
 
+def gen_randomise(n_games=6, steps=1800, every=37):
+    """Game.randomise_uncertainty (game.py:1207-1282) on states along random games: (blob before, controlling player, blob
+    after), generated by the reference with its shuffles routed to the game's philox stream; the game itself continues from
+    the un-randomised state (restore_state), as in the forward search."""
+    before, after, ctrl_list = [], [], []
+    for env_id in range(n_games):
+        rng = np.random.default_rng(4242 + env_id)
+        ref = rh.RefEnv(21, env_id)
+        ref.reset()
+        for s in range(steps):
+            if s % every == every - 1:
+                ctrl = int(rng.integers(1, 5))
+                saved, draws = ref.env.save_state(), ref.stream.draws
+                before.append(ref.state_blob())
+                with rh.patched_rng(ref.stream):
+                    ref.env.game.randomise_uncertainty(rh.PIDS[ctrl - 1])
+                after.append(ref.state_blob())
+                ctrl_list.append(ctrl)
+                ref.env.restore_state(saved); ref.stream.draws = draws
+            a = rh.random_legal_action(ref.masks(), ref.env, rng)
+            _, _, done = ref.step(a)
+            if done:
+                ref.reset()
+    np.savez_compressed(os.path.join(OUT, "randomise.npz"), seed=21, before=np.array(before, dtype=np.int32),
+                        after=np.array(after, dtype=np.int32), ctrl=np.array(ctrl_list, dtype=np.int32),
+                        env_id=np.repeat(np.arange(n_games), len(before) // n_games).astype(np.int64))
+    return len(before)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "randomise":
+        print("randomise", gen_randomise()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
         gen_league(); print("league"); sys.exit(0)
     gen_topology(); print("topology")
@@ -271,4 +302,5 @@ if __name__ == "__main__":
     gen_longest_road(); print("longest road")
     gen_gae_ppo(); print("gae/ppo")
     gen_league(); print("league")
+    print("randomise", gen_randomise())
     os.system(f"ls -la {OUT}; du -sh {OUT}")

@@ -97,16 +97,17 @@ _CURRENT = [None]
 @contextlib.contextmanager
 def patched_rng(stream):
     """Route the reference's RNG call sites to `stream` while inside the context."""
-    saved = (np.random.shuffle, np.random.randint, _py_random.choice)
+    saved = (np.random.shuffle, np.random.randint, _py_random.choice, _py_random.shuffle)
     prev = _CURRENT[0]
     _CURRENT[0] = stream
     np.random.shuffle = lambda x: stream.shuffle(x)
     np.random.randint = lambda lo, hi=None: stream.randint(lo, hi)
     _py_random.choice = lambda seq: stream.choice(seq)
+    _py_random.shuffle = lambda x: stream.shuffle(x)       # only Game.randomise_uncertainty (game.py:1250,1255) uses it
     try:
         yield stream
     finally:
-        np.random.shuffle, np.random.randint, _py_random.choice = saved
+        np.random.shuffle, np.random.randint, _py_random.choice, _py_random.shuffle = saved
         _CURRENT[0] = prev
 
 
