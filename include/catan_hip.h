@@ -77,6 +77,9 @@ int catan_masks_packed(catan_env_t* env, const uint32_t** out_ptr, int64_t* out_
 /* deciding player (discarder > trade target > players_go): env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.
  * out: int32 [n], PlayerId 1..4 */
 int catan_deciding_seat(catan_env_t* env, int32_t* out, catan_stream_t stream);
+/* the forward-search simulator's notion of whose turn it is (trade target > players_go; the discard phase is NOT
+ * looked at): RL/forward_search_policy/worker.py:146-151.  out: int32 [n], PlayerId 1..4 */
+int catan_players_turn_sim(catan_env_t* env, int32_t* out, catan_stream_t stream);
 
 /* uniform-random legal policy used by bench config 2 (DESIGN.md "random policy"); writes int32 [n][18] */
 int catan_sample_random_actions(catan_env_t* env, uint32_t step_idx, int32_t* actions, catan_stream_t stream);

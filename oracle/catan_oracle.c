@@ -245,6 +245,11 @@ static int harbour_resource(int id) {
     return r[id];
 }
 
+/* EnvWrapper(max_proposed_trades_per_turn, win_reward, dense_reward) + reward_annealing_factor (env/wrapper.py:12-22) */
+void orc_set_config(OrcEnv* e, int max_trades_per_turn, float win_reward, int dense_reward, float reward_annealing_factor) {
+    e->max_trades_per_turn = max_trades_per_turn; e->win_reward = win_reward; e->dense_reward = dense_reward;
+    e->reward_annealing_factor = reward_annealing_factor;
+}
 void orc_config_default(OrcEnv* e) {
     e->max_trades_per_turn = 4; e->win_reward = 500.0f; e->dense_reward = 0; e->reward_annealing_factor = 1.0f;
 }
@@ -960,6 +965,12 @@ int orc_step(OrcEnv* e, const int32_t* a, float* reward4, int* done) {
 /* ref: wrapper.py:53-58, RL/ppo/game_manager.py:152-159 */
 int orc_deciding_player(const OrcEnv* e) {
     if (e->need_discard) return e->to_discard[0];
+    if (e->must_respond) return e->trade_target;
+    return e->players_go;
+}
+
+/* ref: RL/forward_search_policy/worker.py:146-151 (the simulator ignores the discard phase) */
+int orc_players_turn_sim(const OrcEnv* e) {
     if (e->must_respond) return e->trade_target;
     return e->players_go;
 }

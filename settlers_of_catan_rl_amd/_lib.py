@@ -83,6 +83,7 @@ _SIGS = {
     "catan_set_lr_budgets": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "catan_calib_copy": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "catan_randomise_uncertainty": (C.c_int, [_vp, _vp, _vp]),
+    "catan_players_turn_sim": (C.c_int, [_vp, _vp, _vp]),
     "catan_inconsistent_deal_count": (C.c_int64, [_vp, _vp]),
     "catan_linear_wgrad_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "catan_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),

@@ -364,7 +364,14 @@ int catan_masks_packed(catan_env_t* e, const uint32_t** out_ptr, int64_t* out_pi
 
 int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
     if (!e || !out) return fail(CATAN_EINVAL, "catan_deciding_seat: null argument");
-    hipLaunchKernelGGL(k_deciding, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, out);
+    hipLaunchKernelGGL(k_deciding, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, out, 0);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_players_turn_sim: null argument");
+    hipLaunchKernelGGL(k_deciding, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, out, 1);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

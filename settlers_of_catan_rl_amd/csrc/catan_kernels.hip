@@ -1883,11 +1883,13 @@ __global__ __launch_bounds__(BLOCK) void k_calib_copy(const uint4* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------ deciding seat
 // ref: env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.  out = PlayerId 1..4
-__global__ __launch_bounds__(BLOCK) void k_deciding(Ctx c, i32* __restrict__ out) {
+// ignore_discard: the forward-search simulator's get_players_turn (RL/forward_search_policy/worker.py:146-151), which does
+// not look at the discard phase
+__global__ __launch_bounds__(BLOCK) void k_deciding(Ctx c, i32* __restrict__ out, int ignore_discard) {
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.n) return;
     int p;
-    if (s.b(B_NDISC) > 0) p = s.b(B_DISC);
+    if (!ignore_discard && s.b(B_NDISC) > 0) p = s.b(B_DISC);
     else if (s.flags() & F_MUST_RESPOND) p = s.b(B_TRADE_TGT);
     else p = s.b(B_GO);
     out[s.e] = p + 1;

@@ -89,6 +89,12 @@ class VecCatanEnv(object):
         _lib.check(self.L.catan_deciding_seat(self.h, _ptr(out), _stream()))
         return out
 
+    def players_turn_sim(self):
+        """worker.py:146-151: trade target > players_go, ignoring the discard phase (forward-search simulations)"""
+        out = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_players_turn_sim(self.h, _ptr(out), _stream()))
+        return out
+
     def sample_random_actions(self, step_idx, out=None):
         if out is None:
             out = torch.empty((self.n, spec.ACTION_WORDS), dtype=torch.int32, device=self.device)
@@ -143,7 +149,8 @@ class VecCatanEnv(object):
         return blob.t().contiguous()
 
     def import_state(self, blobs, env_idx=None):
-        b = torch.as_tensor(np.asarray(blobs), dtype=torch.int32).to(self.device)
+        b = blobs if torch.is_tensor(blobs) else torch.as_tensor(np.asarray(blobs))
+        b = b.to(device=self.device, dtype=torch.int32)
         if b.dim() == 1:
             b = b[None]
         cnt = b.shape[0]

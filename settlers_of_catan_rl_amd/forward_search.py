@@ -1,0 +1,370 @@
+"""Batched forward search (reference RL/forward_search_policy/*; BASELINE.json configs[4]).
+
+The reference planner decides ONE move of ONE game: it proposes <= 10 root actions with the policy
+(`default_sample_actions`, sample_actions_fn.py:55-328), then for a wall-clock budget lets 11 CPU worker processes run
+simulations - restore the root state, `randomise_uncertainty`, play the proposed action, then up to `max_depth` further
+decisions of the searching player with the policy acting for every seat, and score the line with a GAE-style estimate
+(worker.py:39-143) - allocating simulations to root actions with a UCB rule (policy.py:151-177).
+
+Here R root games are searched at once.  Every piece keeps the reference's arithmetic and quirks:
+  * `propose_actions`  - default_sample_actions for all roots: one batched, type-conditioned policy call per step of the
+                         procedure (13 first-pass types + <= max_actions refinement draws) instead of one call per root.
+  * `simulate`         - run_simulation_forward for n simulations in lock-step on a VecCatanEnv (dense rewards, no
+                         auto-reset): incl. the simulator's get_players_turn that ignores the discard phase and the
+                         `elif done` reward rule.
+  * `gae_estimate`     - worker.gae, vectorised over simulations (the unused final value, the `len(values) <= 1` shortcut).
+  * `UCBStats`         - _select_action / _update_stats / MovingAvgCalculator, vectorised over roots (host, float64).
+  * `ForwardSearch`    - the act() loop with a fixed simulation budget instead of a wall-clock one (the reference's own
+                         "deterministic testing" variant, policy.py:112): rounds of K simulations per root; inside a round
+                         simulations are allocated one after the other exactly as the reference hands them to free workers.
+State broadcast = catan_state_export / catan_state_import; every simulation gets its own Philox substream.
+"""
+import math
+import random as _py_random
+
+import numpy as np
+import torch
+
+from . import spec
+
+MAX_PROP_TRADE_ACTIONS = 3                                   # sample_actions_fn.py:6
+PRIORITIES = [["settlement", "city", "move_robber", "steal", "discard"], ["road"], ["play_dev"], ["exchange_res", "prop_trade"]]
+TYPE_TO_IND = {"settlement": 0, "road": 1, "city": 2, "buy_dev": 3, "play_dev": 4, "exchange_res": 5, "prop_trade": 6,
+               "respond_trade": 7, "move_robber": 8, "roll_dice": 9, "end_turn": 10, "steal": 11, "discard": 12}
+MO = spec.MASK_OFFSETS
+
+
+# ---------------------------------------------------------------------------------------------------- worker.gae
+def gae_estimate(values, n_values, rewards, n_rewards, gamma, done, gae_lambda=0.95):
+    """worker.py:117-143 for a batch: values [n, *] / rewards [n, *] hold n_values[i] / n_rewards[i] valid entries.
+    -> float64 [n]."""
+    values = np.asarray(values, dtype=np.float64); rewards = np.asarray(rewards, dtype=np.float64)
+    n_values = np.asarray(n_values); n_rewards = np.asarray(n_rewards); done = np.asarray(done, dtype=bool)
+    n = values.shape[0]
+    out = np.zeros(n, dtype=np.float64)
+    short = n_values <= 1                                     # `return rewards[0] + gamma * rewards[1]`
+    if short.any():
+        assert (n_rewards[short] >= 2).all(), "worker.gae indexes rewards[1] here (IndexError in the reference)"
+        out[short] = rewards[short, 0] + gamma * rewards[short, 1]
+    idx = np.flatnonzero(~short)
+    if idx.size:
+        v = values[idx]; r = rewards[idx]; nv = n_values[idx]; d = done[idx]
+        num_steps = nv - 2                                    # len(values[:-1]) - 1
+        g = np.zeros(idx.size, dtype=np.float64)
+        for step in range(int(num_steps.max()) - 1, -1, -1):
+            live = step < num_steps
+            delta = r[:, 1 + step] + gamma * v[:, step + 1] - v[:, step]      # rewards_for_gae = rewards[1:-1]
+            last = live & (step == num_steps - 1) & d
+            g = np.where(last, delta, np.where(live, delta + gamma * gae_lambda * g, g))
+        out[idx] = r[:, 0] + gamma * (g + v[:, 0])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- UCB bookkeeping
+class UCBStats(object):
+    """policy.py:151-177 + utils.MovingAvgCalculator for R roots; root i has n_actions[i] proposed actions."""
+
+    def __init__(self, n_roots, max_actions, window=500):
+        R, A = n_roots, max_actions
+        self.R, self.A = R, A
+        self.window = np.zeros((R, window)); self.window_size = window
+        self.num_added = np.zeros(R, dtype=np.int64)
+        self.avg = np.zeros(R); self.var = np.zeros(R); self.last_std = np.zeros(R)
+        self.new_decision(np.zeros(R, dtype=np.int64))
+
+    def new_decision(self, n_actions):
+        """act(): the per-decision counters restart, the value moving average persists (policy.py:48,96-100)."""
+        self.n_actions = np.asarray(n_actions)
+        self.finished = np.zeros(self.R, dtype=np.int64)
+        self.finished_each = np.zeros((self.R, self.A)); self.started_each = np.zeros((self.R, self.A))
+        self.exploit = np.zeros((self.R, self.A))
+
+    def select(self, explore=True):
+        """_select_action for every root (first best index wins ties, `score > best_score`)."""
+        exploit = self.exploit / (self.finished_each + 1e-5)
+        score = exploit
+        if explore:
+            explore_score = np.sqrt(2.0 * np.log(self.finished + 2)[:, None] / (self.finished_each + self.started_each + 1e-10))
+            score = exploit + 2.0 * np.maximum(self.last_std, 1.0)[:, None] * explore_score
+        score = np.where(np.arange(self.A)[None, :] < self.n_actions[:, None], score, -np.inf)
+        return np.argmax(score, axis=1)
+
+    def start(self, action_id, sel=None):
+        rows = np.arange(self.R) if sel is None else sel
+        self.started_each[rows, action_id] += 1
+
+    def update(self, val, action_id, sel=None):
+        """_update_stats + MovingAvgCalculator.update for one finished simulation per selected root."""
+        rows = np.arange(self.R) if sel is None else np.asarray(sel)
+        val = np.asarray(val, dtype=np.float64)
+        self.started_each[rows, action_id] -= 1
+        self.finished[rows] += 1
+        self.finished_each[rows, action_id] += 1
+        self.exploit[rows, action_id] += val
+        # utils.py:14-46
+        k = self.num_added[rows] % self.window_size
+        old_value = self.window[rows, k]
+        self.window[rows, k] = val
+        self.num_added[rows] += 1
+        na = self.num_added[rows]
+        old_avg = self.avg[rows].copy()
+        filling = na <= self.window_size
+        delta = np.where(filling, val - old_avg, val - old_value)
+        avg = old_avg + np.where(filling, delta / na, delta / self.window_size)
+        var = self.var[rows] + np.where(filling, delta * (val - avg), delta * ((val - avg) + (old_value - old_avg)))
+        self.avg[rows] = avg; self.var[rows] = var
+        variance = np.where(filling, np.where(na == 1, 1.0, var / np.maximum(na - 1, 1)), var / self.window_size)
+        with np.errstate(invalid="ignore"):
+            std = np.sqrt(variance)
+        self.last_std[rows] = np.where(np.isnan(std), 0.1, std)       # `except: std = 0.1` / isnan
+
+
+# ---------------------------------------------------------------------------------------------------- simulations
+@torch.no_grad()
+def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, deterministic=False, generator=None, autocast_dtype=None):
+    """run_simulation_forward (worker.py:61-114) for all env.n simulations in lock-step.  env: dense-reward, no auto-reset,
+    already holding the (randomised) start states; ctrl int [n] PlayerId of the searching player; init_actions [n,18].
+    -> float64 numpy [n] value estimates."""
+    n, dev = env.n, env.device
+    ar = torch.arange(n, device=dev)
+    ctrl = torch.as_tensor(ctrl, device=dev).long()
+    D = max_depth
+    rewards = torch.zeros((n, D + 2), dtype=torch.float64, device=dev); n_rew = torch.zeros(n, dtype=torch.long, device=dev)
+    values = torch.zeros((n, D + 1), dtype=torch.float64, device=dev); n_val = torch.zeros(n, dtype=torch.long, device=dev)
+
+    def push(buf, cnt, sel, x):
+        idx = sel.nonzero(as_tuple=True)[0]
+        if idx.numel():
+            buf[idx, cnt[idx]] = x[idx].double()
+            cnt[idx] += 1
+
+    reward, done = env.step(torch.as_tensor(init_actions, device=dev).to(torch.int32))      # worker.py:71
+    reward = reward.clone(); first_done = done.bool().clone()
+    push(rewards, n_rew, torch.ones(n, dtype=torch.bool, device=dev), reward[ar, ctrl - 1])
+    agent_actions = torch.ones(n, dtype=torch.long, device=dev)
+    active = ~first_done                                                                    # `if done: return actual_rewards[0]`
+    finished = torch.zeros(n, dtype=torch.bool, device=dev)
+    while True:
+        live = active & (agent_actions < D)                                                 # worker.py:81
+        if not bool(live.any()):
+            break
+        players_go = env.players_turn_sim().long()                                          # :82, 146-151
+        f, lists, lens = env.get_obs()
+        masks = env.get_action_masks()
+        if autocast_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=autocast_dtype):
+                value, action, _ = policy.act(f, lists, lens.long(), masks, deterministic=deterministic, generator=generator)
+        else:
+            value, action, _ = policy.act(f, lists, lens.long(), masks, deterministic=deterministic, generator=generator)
+        value = policy.denormalise(value.float()[:, 0])                                     # :92-93
+        a_env = action.to(torch.int32)
+        a_env[:, 0] = torch.where(live, a_env[:, 0], torch.full_like(a_env[:, 0], -1))     # finished simulations idle
+        reward, done = env.step(a_env)
+        done = done.bool() & live
+        r_ctrl = reward[ar, ctrl - 1]
+        is_agent = live & (players_go == ctrl)                                              # :99-104
+        agent_actions += is_agent.long()
+        push(rewards, n_rew, is_agent | (live & ~is_agent & done), r_ctrl)
+        push(values, n_val, is_agent, value)
+        finished |= done                                                                    # :109-111
+        active &= ~done
+    fd = first_done.cpu().numpy()
+    rewards_h = rewards.cpu().numpy()
+    out = rewards_h[:, 0].copy()                                                            # `if done: return actual_rewards[0]`
+    rest = np.flatnonzero(~fd)
+    if rest.size:
+        out[rest] = gae_estimate(values.cpu().numpy()[rest], n_val.cpu().numpy()[rest], rewards_h[rest], n_rew.cpu().numpy()[rest],
+                                 gamma, finished.cpu().numpy()[rest])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- proposals
+def _update_action_masks(action, m):
+    """sample_actions_fn.py:31-53 on one flat mask row (numpy float [325]) - removes the proposed target from its head."""
+    t = int(action[0])
+    if t == 0:
+        if m[MO[1]:MO[1] + 54].sum() > 1: m[MO[1] + action[1]] = 0
+    elif t == 1:
+        if m[MO[2]:MO[2] + 73].sum() > 1: m[MO[2] + action[2]] = 0
+    elif t == 2:
+        if m[MO[1] + 54:MO[1] + 108].sum() > 1: m[MO[1] + 54 + action[1]] = 0
+    elif t == 4:
+        if m[MO[4]:MO[4] + 5].sum() > 1: m[MO[4] + action[4]] = 0
+    elif t == 8:
+        if m[MO[3]:MO[3] + 19].sum() > 0: m[MO[3] + action[3]] = 0
+    elif t == 11:
+        if m[MO[6] + 3:MO[6] + 6].sum() > 0: m[MO[6] + 3 + action[6]] = 0
+    elif t == 12:
+        if m[MO[11]:MO[11] + 5].sum() > 1: m[MO[11] + action[17]] = 0
+
+
+@torch.no_grad()
+def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settlement_phase=None,
+                    consider_all_initial_settlements=False, rngs=None, deterministic=False, generator=None, autocast_dtype=None):
+    """default_sample_actions (sample_actions_fn.py:55-328, with dont_propose_devcards = dont_propose_trades = False) for R
+    roots.  f/lists/lens/masks: the roots' observations and masks (device tensors); rngs: one `random.Random` per root for
+    the procedure's random.choice calls.  -> (actions int64 numpy [R, A, 18], counts [R]) in proposal order."""
+    R, dev = f.shape[0], f.device
+    m = masks.detach().cpu().numpy().astype(np.float32).copy()            # working copies, updated as targets are used up
+    type_masks = m[:, MO[0]:MO[0] + 13].copy()
+    rngs = rngs or [_py_random.Random(i) for i in range(R)]
+    init_phase = np.zeros(R, dtype=bool) if initial_settlement_phase is None else np.asarray(initial_settlement_phase, dtype=bool)
+    proposed = [[] for _ in range(R)]
+    avail = [dict() for _ in range(R)]
+    effective = np.zeros(R)
+    exchanges = [[] for _ in range(R)]
+    trades = np.zeros(R, dtype=np.int64)
+
+    def act(rows, types):
+        idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+        forced = torch.as_tensor(types, device=dev, dtype=torch.long)
+        mk = torch.from_numpy(m[rows]).to(dev)
+        args = (f[idx], lists[idx], lens[idx].long(), mk)
+        if autocast_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=autocast_dtype):
+                _, a, _ = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced)
+        else:
+            _, a, _ = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced)
+        return a.cpu().numpy()
+
+    count_of = {0: lambda r: m[r, MO[1]:MO[1] + 54].sum() - 1, 1: lambda r: m[r, MO[2]:MO[2] + 73].sum() - 1,
+                2: lambda r: m[r, MO[1] + 54:MO[1] + 108].sum() - 1, 4: lambda r: m[r, MO[4]:MO[4] + 5].sum() - 1,
+                5: lambda r: m[r, MO[10]:MO[10] + 5].sum() * m[r, MO[9]:MO[9] + 5].sum() - 1,
+                6: lambda r: MAX_PROP_TRADE_ACTIONS - 1, 8: lambda r: m[r, MO[3]:MO[3] + 19].sum() - 1,
+                11: lambda r: m[r, MO[6] + 3:MO[6] + 6].sum() - 1, 12: lambda r: m[r, MO[11]:MO[11] + 5].sum() - 1}
+    name_of = {v: k for k, v in TYPE_TO_IND.items()}
+    for t in range(13):                                                   # first pass: one proposal per available type
+        rows = np.flatnonzero(type_masks[:, t] == 1)
+        if rows.size == 0:
+            continue
+        for r in rows:
+            if t in count_of:
+                c = float(count_of[t](r))
+                avail[r][name_of[t]] = c
+                effective[r] += c
+            elif t == 7:
+                effective[r] += m[r, MO[5]:MO[5] + 2].sum() - 1            # respond: counted but not refinable (:198)
+        a = act(rows, np.full(rows.size, t))
+        for j, r in enumerate(rows):
+            assert a[j, 0] == t
+            proposed[r].append(a[j])
+            if t == 5:
+                exchanges[r].append((int(a[j, 15]), int(a[j, 16])))
+            if t == 6:
+                trades[r] += 1
+            if t in (0, 1, 2, 4, 8, 11, 12):
+                _update_action_masks(a[j], m[r])
+    # refinement draws (:286-328)
+    n_more = np.zeros(R, dtype=np.int64)
+    for r in range(R):
+        if init_phase[r] and consider_all_initial_settlements:
+            n_more[r] = int(avail[r]["settlement"])
+        else:
+            n_more[r] = int(min(max_actions - len(proposed[r]), effective[r]))
+    alive = n_more > 0
+    for i in range(int(n_more.max()) if R else 0):
+        rows, types = [], []
+        for r in range(R):
+            if not alive[r] or i >= n_more[r]:
+                continue
+            ac_type = None
+            for pr in PRIORITIES:
+                av = [x for x in pr if avail[r].get(x, 0) > 0]
+                if trades[r] >= MAX_PROP_TRADE_ACTIONS and "prop_trade" in av:
+                    av.remove("prop_trade")
+                if av:
+                    ac_type = rngs[r].choice(av)
+                    avail[r][ac_type] -= 1
+                    break
+            if ac_type is None:
+                alive[r] = False                                          # "something gone wrong - just return what we have"
+                continue
+            rows.append(r); types.append(TYPE_TO_IND[ac_type])
+        if not rows:
+            break
+        a = act(np.asarray(rows), np.asarray(types))
+        for j, r in enumerate(rows):
+            act_j = a[j]
+            if types[j] == 6:
+                proposed[r].append(act_j); trades[r] += 1
+            elif types[j] == 5:
+                # the reference re-draws the pair `while prop_exchange not in exchanges_proposed` (:316-320): a NEW pair is
+                # replaced by random legal picks until it coincides with one proposed before
+                pair = (int(act_j[15]), int(act_j[16]))
+                give_ok = np.flatnonzero(m[r, MO[9]:MO[9] + 5]); recv_ok = np.flatnonzero(m[r, MO[10]:MO[10] + 5])
+                while pair not in exchanges[r]:
+                    act_j[15] = rngs[r].choice(list(give_ok)); act_j[16] = rngs[r].choice(list(recv_ok))
+                    pair = (int(act_j[15]), int(act_j[16]))
+                proposed[r].append(act_j); exchanges[r].append(pair)
+            else:
+                proposed[r].append(act_j)
+                _update_action_masks(act_j, m[r])
+    A = max(len(p) for p in proposed) if R else 0
+    out = np.zeros((R, A, spec.ACTION_WORDS), dtype=np.int64)
+    counts = np.zeros(R, dtype=np.int64)
+    for r in range(R):
+        counts[r] = len(proposed[r])
+        for j, a in enumerate(proposed[r]):
+            out[r, j] = a
+    return out, counts
+
+
+# ---------------------------------------------------------------------------------------------------- the planner
+class ForwardSearch(object):
+    """ForwardSearchPolicy.act (policy.py:72-149) for all games of `root_env` at once, each searched by its deciding
+    player.  make_sim_env(n) -> an env of n games with dense rewards and no auto-reset (VecCatanEnv on the GPU)."""
+
+    def __init__(self, policy, make_sim_env, n_roots, max_init_actions=10, max_depth=20, gamma=0.999, sims_per_root=64,
+                 sims_per_round=16, consider_all_moves_for_opening_placement=False, seed=0, autocast_dtype=None):
+        assert sims_per_root % sims_per_round == 0
+        self.policy, self.R = policy, n_roots
+        self.max_init_actions, self.max_depth, self.gamma = max_init_actions, max_depth, gamma
+        self.S, self.K = sims_per_root, sims_per_round
+        self.consider_all = consider_all_moves_for_opening_placement
+        self.sim_env = make_sim_env(n_roots * sims_per_round)
+        self.stats = UCBStats(n_roots, 54 if consider_all_moves_for_opening_placement else max_init_actions)
+        self.rngs = [_py_random.Random(seed * 1000003 + i) for i in range(n_roots)]
+        self.gen = None
+        self.autocast_dtype = autocast_dtype
+        self.sims_run = 0
+        self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]
+
+    @torch.no_grad()
+    def act(self, root_env, initial_settlement=None, deterministic=False):
+        """-> (actions int64 numpy [R,18], info dict).  Roots with a single proposal skip the search (policy.py:88-89)."""
+        R, K = self.R, self.K
+        assert root_env.n == R
+        ctrl = root_env.deciding_player().long()
+        f, lists, lens = root_env.get_obs()
+        masks = root_env.get_action_masks()
+        props, counts = propose_actions(self.policy, f, lists, lens, masks, self.max_init_actions, initial_settlement, self.consider_all,
+                                        self.rngs, deterministic, self.gen, self.autocast_dtype)
+        self.stats.new_decision(counts)
+        blobs = root_env.export_state()                                             # [R, 736] int32 (state broadcast)
+        blobs = blobs.repeat_interleave(K, dim=0).clone()
+        ctrl_sim = ctrl.repeat_interleave(K)
+        base_draws = blobs[:, self._rng_word].long() & 0xFFFFFFFF
+        props_t = torch.from_numpy(props).to(root_env.device)
+        ar_sim = torch.arange(R * K, device=root_env.device)
+        for rnd in range(self.S // K):
+            ids = np.zeros((R, K), dtype=np.int64)
+            for k in range(K):                                                      # one simulation after the other (:118-125)
+                a = self.stats.select(explore=True)
+                self.stats.start(a)
+                ids[:, k] = a
+            # every simulation its own philox substream: offset the game stream's draw counter by a large stride
+            sub = (base_draws + (1 + rnd * K + (ar_sim % K)) * (1 << 22)) & 0xFFFFFFFF
+            blobs[:, self._rng_word] = torch.where(sub >= 2 ** 31, sub - 2 ** 32, sub).to(torch.int32)
+            self.sim_env.import_state(blobs)                                        # worker.py:44-45
+            self.sim_env.randomise_uncertainty(ctrl_sim)                            # :46
+            init = props_t[torch.arange(R, device=props_t.device).repeat_interleave(K), torch.from_numpy(ids.reshape(-1)).to(props_t.device)]
+            vals = simulate(self.sim_env, self.policy, ctrl_sim, init, self.max_depth, self.gamma, deterministic, self.gen,
+                            self.autocast_dtype).reshape(R, K)
+            for k in range(K):
+                self.stats.update(vals[:, k], ids[:, k])
+            self.sims_run += R * K
+        best = self.stats.select(explore=False)
+        best = np.where(counts == 1, 0, best)
+        chosen = props[np.arange(R), best]
+        return chosen, {"n_proposed": counts, "best": best, "finished_each": self.stats.finished_each.copy(),
+                        "mean_value": self.stats.exploit / np.maximum(self.stats.finished_each, 1)}

@@ -283,8 +283,10 @@ class _ActionHeads(nn.Module):
             out = out * torch.tensor([0., 1, 1, 1, 1, 1], device=x.device)
         return out, torch.stack(chosen, 1), logp_sum, ent_sum
 
-    def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None):
+    def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None):
         """main [B,512]; masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.
+        forced_type int64 [B] or None: rows with a value >= 0 take that action type instead of sampling the type head
+        (`condition_on_action_type`, action_heads_module.py:37-48: the type head is skipped, its output is the one-hot).
         -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
         B, dev = main.shape[0], main.device
         H = self.action_heads
@@ -300,6 +302,10 @@ class _ActionHeads(nn.Module):
 
         # head 0: action type
         typ, logp, entropy = run(H[0], main, m[:, MO[0]:MO[0] + 13], 0, one)
+        if forced_type is not None:
+            forced = forced_type >= 0
+            typ = torch.where(forced, forced_type, typ)
+            logp = torch.where(forced, torch.zeros_like(logp), logp)
         out[:, 0] = typ
         is_ = lambda t: (typ == t).float()
         # head 1: corner, conditioned on (settlement, city); mask row by type (build_agent_model.py:113-115)
@@ -373,10 +379,12 @@ class CatanPolicy(nn.Module):
         return obs_f[:, 12:18].float(), obs_f[:, 0:12].float()      # current_resources, proposed_trade
 
     # ---- reference-shaped API
-    def act(self, obs_f, lists, lens, masks, deterministic=False, generator=None):
+    def act(self, obs_f, lists, lens, masks, deterministic=False, generator=None, condition_on_action_type=None):
+        """condition_on_action_type: int64 [B] (entries < 0 = free) or None (RL/models/policy.py:72-82)."""
         value, main = self.base(obs_f, lists, lens)
         cur_res, trade = self._custom(obs_f)
-        actions, logp, _ = self.action_head_module(main, masks.float(), cur_res, trade, None, deterministic, generator)
+        actions, logp, _ = self.action_head_module(main, masks.float(), cur_res, trade, None, deterministic, generator,
+                                                   forced_type=condition_on_action_type)
         return value, actions, logp[:, None]
 
     def evaluate_actions(self, obs_f, lists, lens, masks, actions):

@@ -34,6 +34,7 @@ def lib():
         L.orc_seed_mt.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.orc_rng_draws.argtypes = [vp]; L.orc_rng_draws.restype = C.c_uint32
         L.orc_config_default.argtypes = [vp]
+        L.orc_set_config.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_float]
         L.orc_board_reset.argtypes = [vp]
         L.orc_game_reset.argtypes = [vp]
         L.orc_masks.argtypes = [vp, f32p]
@@ -182,6 +183,16 @@ class OracleBatch(object):
         for i in range(self.n):
             self.L.orc_export(self.env_ptr(i), _p(blobs[i], C.c_int32))
         return blobs
+
+    def import_all(self, blobs):
+        blobs = np.ascontiguousarray(blobs, dtype=np.int32)
+        assert blobs.shape == (self.n, STATE_WORDS)
+        for i in range(self.n):
+            self.L.orc_import(self.env_ptr(i), _p(blobs[i], C.c_int32))
+
+    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0):
+        for i in range(self.n):
+            self.L.orc_set_config(self.env_ptr(i), int(max_trades_per_turn), float(win_reward), int(dense_reward), float(reward_annealing_factor))
 
     def masks(self):
         m = np.zeros((self.n, MASK_WORDS), dtype=np.float32)

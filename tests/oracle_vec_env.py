@@ -8,18 +8,35 @@ import oracle_lib
 
 
 class OracleVecEnv(object):
-    def __init__(self, n, seed=0, env_id0=0):
+    def __init__(self, n, seed=0, env_id0=0, dense_reward=False, auto_reset=True):
         self.n, self.seed, self.env_id0 = n, seed, env_id0
         self.device = torch.device("cpu")
         self.b = oracle_lib.OracleBatch(n, seed, env_id0)
         self.L = self.b.L
         self.steps_taken = np.zeros(n, dtype=np.int64)
+        self.auto_reset = auto_reset
+        if dense_reward:
+            self.b.set_config(dense_reward=True)
+
+    def export_state(self):
+        return torch.from_numpy(self.b.export())
+
+    def import_state(self, blobs):
+        self.b.import_all(np.asarray(blobs))
 
     def advance_random(self, steps):
         self.b.run_random(steps, want_blobs=False)
 
     def deciding_player(self):
         return torch.tensor([self.L.orc_deciding_player(self.b.env_ptr(i)) for i in range(self.n)], dtype=torch.int32)
+
+    def players_turn_sim(self):
+        return torch.tensor([self.L.orc_players_turn_sim(self.b.env_ptr(i)) for i in range(self.n)], dtype=torch.int32)
+
+    def randomise_uncertainty(self, ctrl):
+        for i, c in enumerate(np.asarray(ctrl).tolist()):
+            if c:
+                self.L.orc_randomise_uncertainty(self.b.env_ptr(i), int(c))
 
     def get_obs(self):
         n = self.n
@@ -44,7 +61,7 @@ class OracleVecEnv(object):
             self.L.orc_step(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32)), r.ctypes.data_as(C.POINTER(C.c_float)), C.byref(d))
             rew[i] = r; done[i] = d.value
             self.steps_taken[i] += 1
-            if d.value:
+            if d.value and self.auto_reset:
                 self.L.orc_game_reset(self.b.env_ptr(i))
         return torch.from_numpy(rew), torch.from_numpy(done)
 

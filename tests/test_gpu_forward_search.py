@@ -1,0 +1,55 @@
+"""GPU: the batched forward search on the HIP env (config 5 shape, tiny sizes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_search_on_device(hip_lib, oracle):
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd import forward_search as fs
+    torch.manual_seed(0)
+    R, S, K = 64, 8, 4
+    root = VecCatanEnv(R, seed=3)
+    root.random_rollout(0, 600)
+    before = root.export_state().clone()
+    net = CatanPolicy().cuda().eval()
+    search = fs.ForwardSearch(net, lambda n: VecCatanEnv(n, seed=4, env_id0=1 << 20, dense_reward=True, auto_reset=False), R, max_depth=4,
+                              sims_per_root=S, sims_per_round=K)
+    chosen, info = search.act(root)
+    assert torch.equal(root.export_state(), before)                     # roots are only read
+    assert search.sims_run == R * S and (info["finished_each"].sum(1) == S).all()
+    assert search.sim_env.invalid_action_count() == 0 and search.sim_env.inconsistent_deal_count() == 0
+    root.step(torch.from_numpy(chosen).cuda().to(torch.int32))
+    assert root.invalid_action_count() == 0                            # every chosen move is legal in its root
+
+
+def test_simulate_on_device_matches_oracle_env(hip_lib, oracle):
+    """simulate() on the HIP env against the same simulation on the oracle-backed env: identical (arg-max) policy
+    decisions need identical observations, masks, rewards and turn bookkeeping at every step."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_vec_env import OracleVecEnv
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd import forward_search as fs
+    torch.manual_seed(1)
+    n, seed = 48, 6
+    src = VecCatanEnv(n, seed=seed)
+    src.random_rollout(0, 800)
+    blobs = src.export_state()
+    ctrl = src.deciding_player().long()
+    init = src.sample_random_actions(12345).long()
+    net = CatanPolicy().eval()
+    dev_env = VecCatanEnv(n, seed=seed, dense_reward=True, auto_reset=False)
+    dev_env.import_state(blobs.cpu().numpy())
+    cpu_env = OracleVecEnv(n, seed, dense_reward=True, auto_reset=False)
+    cpu_env.import_state(blobs.cpu().numpy())
+    dev_env.randomise_uncertainty(ctrl)
+    cpu_env.randomise_uncertainty(ctrl.cpu())
+    want = fs.simulate(cpu_env, net, ctrl.cpu(), init.cpu(), max_depth=6, deterministic=True)
+    got = fs.simulate(dev_env, net.cuda(), ctrl, init, max_depth=6, deterministic=True)
+    assert np.allclose(got, want, rtol=2e-3, atol=2e-2), np.abs(got - want).max()
+    assert np.array_equal(dev_env.export_state().cpu().numpy(), cpu_env.b.export())
