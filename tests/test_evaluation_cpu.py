@@ -1,0 +1,123 @@
+"""Evaluation protocol (reference RL/ppo/evaluation_manager.py) on CPU: the batched episode runner against the reference's
+EvaluationManager.run_evaluation_game with identical nets (arg-max actions), seat orders and game streams."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_bootstrap  # noqa: E402
+
+from settlers_of_catan_rl_amd import evaluation as ev  # noqa: E402
+from settlers_of_catan_rl_amd.policy import CatanPolicy  # noqa: E402
+from oracle_vec_env import OracleVecEnv  # noqa: E402
+
+HAVE_REF = ref_bootstrap.have_reference()
+if HAVE_REF:
+    ref_bootstrap.bootstrap()
+
+
+def test_sample_orders_is_the_reference_shuffle():
+    random.seed(5)
+    want = []
+    for _ in range(6):
+        o = [2, 4, 3, 1]
+        random.shuffle(o)
+        want.append(o)
+    assert np.array_equal(ev.sample_orders(6, random.Random(5)), np.array(want))
+
+
+def _scripted_action(L, env_ptr, seed, env_id, step, masks_flat):
+    import ctypes as C
+    m = np.ascontiguousarray(masks_flat, dtype=np.float32)
+    out = np.zeros(18, dtype=np.int32)
+    L.orc_sample_action(env_ptr, seed + 99, env_id, int(step), m.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="upstream reference not mounted")
+def test_episodes_match_reference_evaluation_manager():
+    """Full games: the reference EvaluationManager.run_evaluation_game (its env routed to the game's philox stream, its four
+    policies replaced by a scripted uniform-random legal policy keyed by (game, decision number)) against the batched
+    runner on the oracle-backed env with the same scripted policy: winner index, policy-0 victory points, game length and
+    policy-0 decisions per game, for random seat orders."""
+    import ctypes as C
+    import ref_harness as rh
+    import oracle_lib
+    from RL.ppo.evaluation_manager import EvaluationManager
+    seed, n = 31, 4
+
+    class EnvAdapter(object):
+        def __init__(self, env_id):
+            self.r = rh.RefEnv(seed, env_id)
+            self.env_id, self.steps = env_id, 0
+            self.mirror = oracle_lib.OracleEnv(seed, env_id)        # supplies the scripted policy with its hand-dependent draws
+
+        @property
+        def game(self): return self.r.env.game
+
+        @property
+        def winner(self): return self.r.env.winner
+
+        @property
+        def curr_vps(self): return self.r.env.curr_vps
+
+        def reset(self):
+            self.mirror.reset()
+            return self.r.reset()
+
+        def get_action_masks(self):
+            return self.r.env.get_action_masks()
+
+        def step(self, a):
+            flat = np.concatenate([np.asarray(h).reshape(-1) for h in a]).astype(np.int32)
+            with rh.patched_rng(self.r.stream):
+                out = self.r.env.step(a)
+            self.mirror.step(flat)
+            self.steps += 1
+            return out
+
+    class FakePolicy(object):
+        lstm_size = 4
+        dummy_param = torch.empty(1)
+
+        def __init__(self, mgr): self.mgr = mgr
+        def eval(self): pass
+        def obs_to_torch(self, obs): return obs
+        def act_masks_to_torch(self, masks): return masks
+        def torch_act_to_np(self, a): return a
+
+        def act(self, obs, hs, tm, masks, deterministic=False):
+            ad = self.mgr.env
+            a = _scripted_action(ad.mirror.L, ad.mirror.p, seed, ad.env_id, ad.steps, rh.masks_flat(masks))
+            return None, rh.action_to_heads(a), None, hs
+
+    mgr = EvaluationManager.__new__(EvaluationManager)
+    mgr.policies = [FakePolicy(mgr) for _ in range(4)]
+    mgr.device = torch.device("cpu")
+    want, orders = [], []
+    random.seed(77)
+    for g in range(n):
+        mgr.env = EnvAdapter(g)
+        want.append(mgr.run_evaluation_game())
+        orders.append([int(p) for p in mgr.order])
+        assert np.array_equal(mgr.env.r.state_blob(), mgr.env.mirror.export())
+    env = OracleVecEnv(n, seed, auto_reset=False)
+
+    def act_fn(net, idx, f, lists, lens, masks):
+        return torch.tensor(np.stack([_scripted_action(env.L, env.b.env_ptr(int(i)), seed, int(i), env.steps_taken[int(i)], masks[j].numpy())
+                                      for j, i in enumerate(idx)]), dtype=torch.int64)
+
+    class Tag(object):
+        pass
+    central, opp = Tag(), Tag()
+    got = ev.run_evaluation_episodes(env, [central, opp, opp, opp], np.array(orders), act_fn=act_fn)
+    for g in range(n):
+        winner, vps, steps, decisions = want[g]
+        assert (got["winner"][g], got["victory_points"][g], got["game_steps"][g], got["policy_decisions"][g]) == \
+               (winner, vps, steps, decisions), (g, want[g], {k: v[g] for k, v in got.items()})
+    assert len({tuple(o) for o in orders}) > 1

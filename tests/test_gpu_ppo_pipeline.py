@@ -213,3 +213,27 @@ def test_rollout_with_league_opponents(hip_lib):
         _, lp, _ = net.evaluate_actions(f.float(), lists, lens.long(), st.unpack_action_masks(st.action_masks.reshape(T * N, -1)),
                                         st.actions.reshape(T * N, -1))
     assert torch.allclose(lp[:, 0], st.action_log_probs.reshape(T * N), atol=2e-4)
+
+
+def test_evaluation_protocol_on_device(hip_lib):
+    """run_evaluation_protocol on the HIP env (two random-init nets, sampled actions, the offline evaluator's draw cap to
+    bound the run): every action legal, statistics well-formed, capped games reported as draws."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd import evaluation as ev
+    import random
+    torch.manual_seed(0)
+    central, opp = CatanPolicy().cuda().eval(), CatanPolicy().cuda().eval()
+    envs = []
+
+    def make_env(n):
+        envs.append(VecCatanEnv(n, seed=8, auto_reset=False))
+        return envs[-1]
+
+    log, summary = ev.run_evaluation_protocol(make_env, central, opp, 96, update_num=3, rng=random.Random(1), max_steps=400)
+    assert envs[0].invalid_action_count() == 0
+    r = log["random"]
+    assert log["update"] == 3 and 0.0 <= r["policy_win_frac"] <= 1.0
+    assert 400 < r["avg_game_length"] <= 401.0001 or r["policy_win_frac"] > 0      # capped games stop right after step 401
+    assert 0 < r["avg_policy_decisions"] < r["avg_game_length"] and 0 <= r["avg_victory_points"] <= 12
+    assert "EVALUATION (after 3 updates)" in summary
