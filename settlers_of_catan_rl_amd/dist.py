@@ -77,6 +77,15 @@ def allreduce_flat_grads(params, world=None):
         off += n
 
 
+def broadcast_parameters(module, src=0):
+    """Replicates rank `src`'s parameters and buffers (the reference's central policy is a single object; here every rank
+    holds a replica that must start identical and stays identical through the all-reduced gradients)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
 def finalize():
     if dist.is_initialized():
         dist.barrier()
