@@ -184,12 +184,16 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);
 
-/* phase profile (diagnostics): enable (zeroes the counters) / read.  out16 = 8 sums then 8 maxima (+ 4 tier-1 counters).
+/* phase profile (diagnostics): enable (zeroes the counters) / read.  out16 (62 words) = 8 sums then 8 maxima, 4 tier-1
+ * counters, then per action type (14) the sum / count / maximum of k_step's validate+apply time.
  * Slots 0, 1, 2, 6, 7: k_step phases per wave in 100 MHz wall-clock ticks (stage-in, validate+apply, request push,
  * done/reward+masks, write-back); slots 3, 4, 5: k_reset_list (philox draws, re-deals, serial shuffle ticks);
  * tools/phase_profile.py prints them. */
 int catan_profile_enable(catan_env_t* env, int on);
 int catan_profile_read(catan_env_t* env, uint64_t* out16);
+/* catan_profile_enable(env, 2): contention-free variant for k_step - every wave stores its own phase durations of the LAST
+ * launch; out: HOST uint32 [ceil(n/256)*4][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = action type + 1) */
+int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ struct catan_env {
     Pending pend;         // tier-2 longest-road hand-off (device arrays)
     unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
     int prof_on;
+    u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
@@ -186,7 +187,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, (2 * PROF_PHASES + 4) * sizeof(unsigned long long));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64) * 8 * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
@@ -242,6 +244,7 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.len) hipFree(e->pend.len);
     if (e->pend.busy) hipFree(e->pend.busy);
     if (e->pctr) hipFree(e->pctr);
+    if (e->prof_wave) hipFree(e->prof_wave);
     delete e;
 }
 
@@ -257,6 +260,7 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
     sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn; sc.auto_reset = e->cfg.auto_reset;
     sc.prof = e->prof_on ? e->prof : nullptr;
+    sc.prof_wave = e->prof_on == 2 ? e->prof_wave : nullptr;
     return sc;
 }
 // One env step = counting sort of the games by action type (k_classify_*), then k_step (fused: apply + done/reward + next
@@ -654,14 +658,21 @@ int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t s
 int catan_profile_enable(catan_env_t* e, int on) {
     if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(e->prof, 0, (2 * PROF_PHASES + 4) * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->prof, 0, PROF_WORDS * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(e->prof_wave, 0, (size_t)(e->N / 64) * 8 * sizeof(u32)));
     e->prof_on = on;
+    return CATAN_OK;
+}
+int catan_profile_read_waves(catan_env_t* e, uint32_t* out) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_profile_read_waves: bad arguments");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 64) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 int catan_profile_read(catan_env_t* e, uint64_t* out16) {
     if (!e || !out16) return fail(CATAN_EINVAL, "catan_profile_read: bad arguments");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out16, e->prof, (2 * PROF_PHASES + 4) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out16, e->prof, PROF_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 

@@ -134,6 +134,81 @@ DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
     }
 }
 
+// k_step's stage-in: besides the hot records, the ACTION rows (72 B) and packed MASK rows (44 of 64 B) of the wave's 64
+// arbitrary games.  Read lane-per-game, each of those 29 words is a load instruction that touches 64 different cache
+// lines (measured: 25 us + 8 us per wave, most of k_step); read row-wise - 7 games x 9 lanes x 8 B and 21 games x 3
+// lanes x 16 B per instruction - every line is requested once.  The words go through the (still empty) tile to the
+// owning lane's registers before the state is written into it; all global loads are issued up front.
+DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, const u32* __restrict__ mpk, int e, int lane,
+                       int (&a)[ACTION_WORDS], u32 (&m)[MASK_WORDS]) {
+    const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
+    const int ag = lane / 9, aq = lane - 9 * ag, mg = lane / 3, mq = lane - 3 * mg;
+    uint4 v[32], mv[4];
+    uint2 av[10];
+#pragma unroll
+    for (int p = 0; p < 10; p++) {
+        const int g = p * 7 + ag, eg = __shfl(e, g & 63);
+        av[p] = make_uint2(0, 0);
+        if (lane < 63 && g < 64 && eg >= 0) av[p] = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int g = p * 21 + mg, eg = __shfl(e, g & 63);
+        mv[p] = make_uint4(0, 0, 0, 0);
+        if (lane < 63 && g < 64 && eg >= 0) mv[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq);
+    }
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const int eg = __shfl(e, (2 * p + half) & 63);
+        v[p] = make_uint4(0, 0, 0, 0);
+        if (lane < 56 && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+    }
+#pragma unroll
+    for (int p = 0; p < 10; p++) {
+        const int g = p * 7 + ag;
+        if (lane < 63 && g < 64) { tile[(2 * aq) * TS + g] = av[p].x; tile[(2 * aq + 1) * TS + g] = av[p].y; }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int g = p * 21 + mg;
+        if (lane < 63 && g < 64) {
+            u32* t = tile + (ACTION_WORDS + 4 * mq) * TS + g;
+            t[0] = mv[p].x; t[TS] = mv[p].y; t[2 * TS] = mv[p].z; t[3 * TS] = mv[p].w;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = (int)tile[i * TS + lane];
+#pragma unroll
+    for (int i = 0; i < MASK_WORDS; i++) m[i] = tile[(ACTION_WORDS + i) * TS + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const int g = 2 * p + half;
+        if (lane < 56) {
+            u32* t = tile + (4 * q) * TS + g;
+            t[0] = v[p].x; t[TS] = v[p].y; t[2 * TS] = v[p].z; t[3 * TS] = v[p].w;
+        }
+    }
+}
+// the reverse for the new masks: rows of the games with e >= 0, through the (free again) tile
+DEVI void stage_out_masks(u32* tile, u32* __restrict__ mpk, int e, int lane, const u32 (&m)[MASK_WORDS]) {
+    const int mg = lane / 3, mq = lane - 3 * mg;
+#pragma unroll
+    for (int i = 0; i < MASK_WORDS; i++) tile[i * TS + lane] = m[i];
+    tile[MASK_WORDS * TS + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int g = p * 21 + mg, eg = __shfl(e, g & 63);
+        if (lane < 63 && g < 64 && eg >= 0) {
+            const u32* t = tile + (4 * mq) * TS + g;
+            uint4 val; val.x = t[0]; val.y = t[TS]; val.z = t[2 * TS]; val.w = t[3 * TS];
+            *reinterpret_cast<uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq) = val;
+        }
+    }
+}
+
 DEVI int seat_of(int seatof, int p) { return (seatof >> (2 * p)) & 3; }
 DEVI int pid_at(int order, int seat) { return (order >> (2 * (seat & 3))) & 3; }
 // ref: game/components/player.py:12-20
@@ -983,10 +1058,19 @@ DEVI void update_largest_army(const S& s) {
 }
 
 struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; int auto_reset;
-                 unsigned long long* prof; };   // optional phase profile: [6] cycle sums then [6] per-wave maxima
+                 unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
+                 u32* prof_wave; };             // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
 constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
                                   // k_reset_list: 3 philox draws per re-deal, 4 re-deals, 5 serial shuffle time
+constexpr int PROF_TOTAL = 2 * PROF_PHASES + 4;   // then 14 sums, 14 counts, 14 maxima of validate+apply per action type
+constexpr int PROF_WORDS = PROF_TOTAL + 42;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
+    if (cfg.prof_wave != nullptr) {                 // contention-free variant (k_step only): one slot per wave and phase
+        const long long t = wall_clock64();
+        if ((threadIdx.x & 63) == 0) cfg.prof_wave[(long)blockIdx.x * 8 + phase] = (u32)(t - t_prev);
+        t_prev = wall_clock64();
+        return;
+    }
     if (cfg.prof == nullptr) return;
     long long t = wall_clock64();
     if ((threadIdx.x & 63) == 0) {
@@ -1024,7 +1108,8 @@ struct StepScratch { LrWave lr; };
 template <bool LR, class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
-                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist, bool clear_busy) {
+                      long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist, bool clear_busy,
+                      u32* m_out = nullptr, bool* m_valid = nullptr) {
     const long e = s.e;
     if constexpr (LR) {
         bool cut = false;
@@ -1077,6 +1162,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 #pragma unroll
         for (int i = 0; i < 4; i++) if (vps[dict_order[i]] >= 10) winner = dict_order[i] + 1;
         bool dn = winner != 0 && type >= 0;
+        float rw[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             float r = 0.0f;
@@ -1092,8 +1178,9 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
                 s.sb(B_CURVP + p, vps[p]);
                 if (dn && winner == p + 1) r += cfg.win_reward;
             }
-            reward[s.e * 4 + p] = r;
+            rw[p] = r;
         }
+        *reinterpret_cast<float4*>(reward + s.e * 4) = make_float4(rw[0], rw[1], rw[2], rw[3]);      // one 16 B store per game
         if (dn) s.sb(B_WINNER, winner);
         done[s.e] = dn ? 1 : 0;
         want_reset = dn && cfg.auto_reset;
@@ -1107,8 +1194,14 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
     if (doit && !want_reset) {
         u32 m[MASK_WORDS];
         compute_masks(s, m, cfg.max_trades);
+        if (m_out != nullptr) {                       // the caller stores the rows (k_step: row-wise through LDS)
 #pragma unroll
-        for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
+            for (int i = 0; i < MASK_WORDS; i++) m_out[i] = m[i];
+            *m_valid = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
+        }
     }
     prof_mark(cfg, 6, tprof);
 }
@@ -1127,36 +1220,28 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < CTR_WORDS - 16) pend.ctr[16 + lane] = 0;     // the sort is done with its bins: clear them for the next one
     const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
-    long long tprof = cfg.prof ? wall_clock64() : 0;
+    long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     const bool live = e < c.n;
     // a negative type is an explicit no-op (frozen game), a busy game ignores its action: neither touches its record
     int type = live ? actions[e * ACTION_WORDS] : -1;
     if (type < 0 || type > 12 || pend.busy[e]) type = -1;
     if (live && type < 0) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) reward[e * 4 + p] = 0.0f;
+        *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         done[e] = 0;
     }
     if (__ballot(type >= 0) == 0) return;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    stage_in(tile, c.R, type >= 0 ? (int)e : -1, lane);
+    int a[ACTION_WORDS];
+    u32 m_in[MASK_WORDS];
+    stage_in_all(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
     __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
-    int a[ACTION_WORDS];
-#pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = type >= 0 ? actions[e * ACTION_WORDS + i] : 0;
     bool rejected = false;
-    if (cfg.validate && type >= 0) {
-        u32 m[MASK_WORDS];
-#pragma unroll
-        for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
-        if (!action_legal(s, m, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
-    }
+    if (cfg.validate && type >= 0 && !action_legal(s, m_in, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
     if (rejected) {                                   // an illegal action leaves the game untouched (reward 0, not done)
-#pragma unroll
-        for (int p = 0; p < 4; p++) reward[e * 4 + p] = 0.0f;
+        *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         done[e] = 0;
     }
     // clamp indices so that an unvalidated bad action cannot touch memory outside the game's rows
@@ -1164,6 +1249,9 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     a[4] = min(max(a[4], 0), 4); a[6] = min(max(a[6], 0), 2);
     a[15] = min(max(a[15], 0), 4); a[16] = min(max(a[16], 0), 4); a[17] = min(max(a[17], 0), 4);
 
+#ifdef CATAN_FINE_PROF
+    prof_mark(cfg, 4, tprof);
+#endif
     const int order = s.b(B_ORDER), seatof = s.b(B_SEATOF);
     const int pid = s.b(B_GO);
     int flags = s.flags();
@@ -1439,8 +1527,19 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     }
     default: break;
     }
+#ifdef CATAN_FINE_PROF
+    prof_mark(cfg, 3, tprof);
+#endif
     if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
 
+    if (cfg.prof_wave != nullptr && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 5] = (u32)(type + 1);   // slot 5: action type + 1
+    if (cfg.prof != nullptr && cfg.prof_wave == nullptr && lane == 0) {   // per action type: time of validate+apply
+        const int t0 = live ? actions[e * ACTION_WORDS] : 13;
+        const int tb = (t0 < 0 || t0 > 12) ? 13 : t0;
+        const unsigned long long dt = (unsigned long long)(wall_clock64() - tprof);
+        atomicAdd(&cfg.prof[PROF_TOTAL + tb], dt); atomicAdd(&cfg.prof[PROF_TOTAL + 14 + tb], 1ull);
+        atomicMax(&cfg.prof[PROF_TOTAL + 28 + tb], dt);
+    }
     prof_mark(cfg, 1, tprof);
     // ---- update_longest_road (game.py:864-919): the path search runs in k_lr / k_lr_heavy; k_step_finish completes
     // the step of these games (sorted waves would otherwise serialise up to 64 searches in the road-placement waves)
@@ -1454,10 +1553,15 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         pend.busy[e] = (u8)pend.ftag;
     }
     prof_mark(cfg, 2, tprof);
-    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 0, false);
-    // ---- write the tile back
+    u32 m_new[MASK_WORDS];
+    bool have_masks = false;
+    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 0, false,
+                       m_new, &have_masks);
+    // ---- write the tile back, then the new mask rows through the tile
     __builtin_amdgcn_wave_barrier();
     stage_out(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    __builtin_amdgcn_wave_barrier();
+    stage_out_masks(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
 }
 
@@ -1473,7 +1577,7 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
     lr_load_nbr(lane, nbr_c, nbr_e);
     const u32 count = pend.ctr[4 + fl];
     StepCfg cfg2 = cfg;
-    cfg2.prof = nullptr;
+    cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
         const u64 rq = pend.req[fl][r];
         const long e = (long)(rq & 0x00FFFFFFFFFFFFFFull);
@@ -1516,7 +1620,7 @@ __global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk
     StL s(tile + lane, c.R, c.N, doit ? e : 0);
     long long tprof = 0;
     StepCfg cfg2 = cfg;
-    cfg2.prof = nullptr;
+    cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
     const int pt = doit ? pend.type[e] : 0;
     const int who = doit ? pend.who[e] : -1;
     const int len = doit ? pend.len[e] : 0;

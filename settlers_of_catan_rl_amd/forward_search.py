@@ -151,11 +151,20 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
         players_go = env.players_turn_sim().long()                                          # :82, 146-151
         f, lists, lens = env.get_obs()
         masks = env.get_action_masks()
+        # only the simulations still running need a decision (the batch thins out as lines reach max_depth or end)
+        idx = live.nonzero(as_tuple=True)[0]
+        sub = idx.numel() < n
+        args = (f[idx], lists[idx], lens[idx].long(), masks[idx]) if sub else (f, lists, lens.long(), masks)
         if autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=autocast_dtype):
-                value, action, _ = policy.act(f, lists, lens.long(), masks, deterministic=deterministic, generator=generator)
+                value_s, action_s, _ = policy.act(*args, deterministic=deterministic, generator=generator)
         else:
-            value, action, _ = policy.act(f, lists, lens.long(), masks, deterministic=deterministic, generator=generator)
+            value_s, action_s, _ = policy.act(*args, deterministic=deterministic, generator=generator)
+        if sub:
+            value = torch.zeros((n, 1), dtype=value_s.dtype, device=dev); value[idx] = value_s
+            action = torch.zeros((n, spec.ACTION_WORDS), dtype=action_s.dtype, device=dev); action[idx] = action_s
+        else:
+            value, action = value_s, action_s
         value = policy.denormalise(value.float()[:, 0])                                     # :92-93
         a_env = action.to(torch.int32)
         a_env[:, 0] = torch.where(live, a_env[:, 0], torch.full_like(a_env[:, 0], -1))     # finished simulations idle
