@@ -1,23 +1,25 @@
-// catan_kernels.hip - hand-written gfx950 kernels for the batched Catan env (one game per lane).
+// catan_kernels.hip - hand-written gfx950 kernels for the batched Catan env.
 //
 // What each kernel replaces in the reference (henrycharlesworth/settlers_of_catan_RL):
-//   k_reset         Board.reset + Game.reset + EnvWrapper.reset      game/components/board.py:67-100, game/game.py:39-136, env/wrapper.py:30-34
-//   k_step          EnvWrapper.step = _translate_action + Game.apply_action + _get_done_and_rewards
-//                                                                      env/wrapper.py:36-50,114-166,85-112, game/game.py:527-815
-//   k_masks         EnvWrapper.get_action_masks                        env/wrapper.py:168-412
-//   k_sample_random uniform-random legal policy (bench config 2)       (reference: none; rule in DESIGN.md)
-//   k_export/import Game.save_current_state / restore_state            game/game.py:1013-1205
-//   k_expand_masks  packed 325-bit masks -> float32 [N][325]           (wrapper returns float arrays)
+//   k_reset, k_reset_list    Board.reset + Game.reset + EnvWrapper.reset   game/components/board.py:67-100, game/game.py:39-136, env/wrapper.py:30-34
+//   k_step                   EnvWrapper.step = _translate_action + Game.apply_action + _get_done_and_rewards, and the next masks
+//                                                                          env/wrapper.py:36-50,114-166,85-112, game/game.py:527-815
+//   k_lr_finish, k_lr_heavy, k_step_finish   update_longest_road / get_longest_path + the rest of those steps   game/game.py:843-919
+//   k_masks                  EnvWrapper.get_action_masks                   env/wrapper.py:168-412
+//   k_sample_random          uniform-random legal policy (bench config 2)  (reference: none; rule in DESIGN.md)
+//   k_classify_*             counting sort of the games by action type     (enables type-homogeneous waves)
+//   k_export/import          Game.save_current_state / restore_state       game/game.py:1013-1205
+//   k_expand_masks           packed 325-bit masks -> float32 [n][325]      (wrapper returns float arrays)
+//   k_randomise_uncertainty  Game.randomise_uncertainty                    game/game.py:1207-1282
 //
-// Design notes (gfx950 / wave64):
-//  * lane = game.  All state accesses are row accesses of a [row][N] array -> the 64 lanes of a wave
-//    read/write 64 consecutive elements (coalesced 64 B / 256 B segments).
+// Design notes (gfx950 / wave64; measurements and history in DESIGN.md 4):
+//  * game-major 704 B records (catan_state.h).  k_step: one wave = 64 games of ONE action type (the games are sorted by
+//    type every pass), their hot 448 B staged transposed in LDS so that lane = game runs the step out of LDS columns.
 //  * board occupancy is kept as bitboards (54-bit corners, 72-bit edges) so placement legality, production and
 //    the robber/steal masks are a handful of 64-bit and/popcount ops instead of graph walks.
-//  * longest road (vertex-simple longest path, game/game.py:843-862 + game/utils.py:3-15) is the one genuinely
-//    divergent graph walk; it is executed wave-cooperatively: lanes that need it are found with a ballot, their
-//    bitboards are broadcast one at a time, and the 64 lanes each run the DFS from a different start corner,
-//    followed by a wave max-reduction.
+//  * the rare serial work gets its own kernels, one game per wave: longest road (vertex-simple longest path: lanes run
+//    the DFS from different start corners and share work through an LDS queue; tier 2 = 1 024-thread workgroups) and the
+//    re-deal of a finished game (64 lanes generate the Philox words, one lane runs the shuffles).
 //  * integer/byte work only - no MFMA, by design (HBM/latency-bound; see DESIGN.md roofline section).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -387,11 +389,10 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 // roads exist iff u holds no opponent building; a path may END on an opponent's corner but not start on or pass it.
 // The number of simple paths is heavy-tailed under random play (mean ~150 DFS expansions per call, p99.9 > 10^4,
 // extremes > 10^6), so the search is two-tiered:
-//   tier 1 (inside k_step, one wave): lane v enumerates the simple paths that start at corner v; busy lanes hand
-//           untaken sibling subtrees to an LDS task queue whenever other lanes are idle; iteration budget LR_BUDGET.
-//   tier 2 (k_lr_heavy, one 512-thread workgroup per overflowed game): the same DFS, bulk-synchronous work sharing
-//           through a workgroup pool, so a dense road network gets a whole CU (and different heavy games get
-//           different CUs) instead of stalling one wave of k_step; k_step_finish then completes those games.
+//   tier 1 (k_lr_finish, one wave per game): lane v enumerates the simple paths that start at corner v; busy lanes hand
+//           untaken sibling subtrees to an LDS task queue whenever other lanes are idle; iteration budget (LR_BUDGET).
+//   tier 2 (k_lr_heavy, 1 024-thread workgroups, 1..8 per overflowed game): the same DFS, bulk-synchronous work sharing
+//           through a workgroup pool, so a dense road network gets whole CUs; k_step_finish then completes those games.
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
@@ -592,32 +593,8 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
     }
 }
 
-// Small integer arrays packed in a register pair: field i holds BITS bits; fields 0..PER-1 live in lo, the rest in hi.
-// The reset shuffles run entirely in registers (no LDS/HBM round trips between dependent draws).
-template <int BITS, int PER>
-struct Packed {
-    u64 lo, hi;
-    DEVI int get(int i) const {
-        const u64 w = i < PER ? lo : hi;
-        const int sh = BITS * (i < PER ? i : i - PER);
-        return (int)((w >> sh) & ((1u << BITS) - 1));
-    }
-    DEVI void set(int i, int v) {
-        const int sh = BITS * (i < PER ? i : i - PER);
-        const u64 m = (u64)((1u << BITS) - 1) << sh, x = (u64)v << sh;
-        if (i < PER) lo = (lo & ~m) | x; else hi = (hi & ~m) | x;
-    }
-    // Fisher-Yates from the top (np.random.shuffle on a list)
-    DEVI void shuffle(int n, Rng& rng) {
-        for (int i = n - 1; i >= 1; i--) {
-            const int j = (int)rng.bounded((u32)i);
-            const int a = get(i), b = get(j);
-            set(i, b); set(j, a);
-        }
-    }
-};
-// scratch of the wave-cooperative reset used inside k_step / k_step_finish: the game's Philox stream is generated in bulk
-// by all 64 lanes (RND_WORDS consecutive draws), then the resetting lane walks it; its shuffle arrays are LDS bytes.
+// scratch of the one-wave-per-game re-deal (wave_reset_game): the game's Philox stream is generated in bulk by all 64 lanes
+// (RND_WORDS consecutive draws), then one lane walks it; its shuffle arrays are LDS bytes.
 constexpr int RND_WORDS = 768;
 struct ResetScratch { u32 rnd[RND_WORDS]; u8 arr[32]; u8 terr[32]; };
 // RNG view over the pre-generated words, falling back to inline Philox beyond them (p99.9 of a reset is ~1250 draws)
@@ -643,8 +620,8 @@ DEVI void shuffle_bytes(u8* a, int n, RngBuf& rng) {     // np.random.shuffle on
         const u8 t = a[i]; a[i] = a[j]; a[j] = t;
     }
 }
-// Same reset as reset_game<> (board.py:67-100, game.py:39-136), executed by ONE lane on LDS byte arrays and the
-// pre-generated random words.
+// Board.reset + Game.reset (board.py:67-100, game.py:39-136), executed by ONE lane on LDS byte arrays and the pre-generated
+// random words.
 template <class S>
 DEVI void reset_game_lds(const S& s, RngBuf& rng, ResetScratch& sc, int hot_rows) {
     u8* arr = sc.arr; u8* terr = sc.terr;

@@ -132,3 +132,36 @@ def test_validate_rejects_illegal_action(hip_lib):
     env.step(a)
     assert env.invalid_action_count() == 8
     assert np.array_equal(env.export_state().cpu().numpy(), before)
+
+
+def test_full_size_invariants_and_sampled_parity(oracle, hip_lib):
+    """BASELINE.json's full size (65 536 games, the bench's deferred schedule): size-independent properties of every game
+    - cards are conserved (bank + hands = 19 per resource; pile + hidden + played = 25 development cards), buildings
+    and roads are owned consistently, no busy game is left behind - and bit-exact state parity with the oracle for a sample
+    of the games (each after exactly its own number of decisions)."""
+    n, seed, iters = 65536, 4, 2200
+    env = _env(n, seed)
+    env.random_rollout_deferred(iters, 32)
+    cnt = env.policy_counters().cpu().numpy()
+    blobs = env.export_state().cpu().numpy()
+    assert env.invalid_action_count() == 0
+    assert cnt.max() <= iters and cnt.mean() > 0.8 * iters
+    f = lambda name: spec.state_field(blobs, name)
+    tot = f("bank_res").astype(np.int64)
+    for p in (1, 2, 3, 4):
+        tot = tot + f(f"p{p}_res")
+        assert (f(f"p{p}_res") >= 0).all() and (f(f"p{p}_vp") >= 0).all() and (f(f"p{p}_vp") <= 12).all()
+    assert (tot == 19).all()
+    cards = f("pile_len")[:, 0].astype(np.int64)
+    for p in (1, 2, 3, 4):
+        cards = cards + f(f"p{p}_n_hidden")[:, 0] + f(f"p{p}_n_played")[:, 0]
+    assert (cards == 25).all()
+    bld, own = f("corner_bld"), f("corner_owner")
+    assert ((bld > 0) == (own > 0)).all() and (own <= 4).all() and (f("edge_owner") <= 4).all()
+    assert (f("winner")[:, 0] == 0).all()                      # auto-reset: no finished game is left standing
+    # sampled parity: every 257th game against the oracle after exactly its own number of decisions
+    idx = np.arange(0, n, 257)
+    for i in idx[:: max(1, len(idx) // 64)]:
+        ob = oracle.OracleBatch(1, seed, env_id0=int(i))
+        want = ob.run_random_counts(np.array([cnt[i]]))
+        assert np.array_equal(blobs[i], want[0]), f"game {i} after {cnt[i]} decisions:\n" + spec.describe_state_diff(want[0], blobs[i])
