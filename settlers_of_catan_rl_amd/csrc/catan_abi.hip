@@ -186,6 +186,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.atype, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ptype, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64) * 8 * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
@@ -243,6 +245,8 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.who) hipFree(e->pend.who);
     if (e->pend.len) hipFree(e->pend.len);
     if (e->pend.busy) hipFree(e->pend.busy);
+    if (e->pend.atype) hipFree(e->pend.atype);
+    if (e->pend.ptype) hipFree(e->pend.ptype);
     if (e->pctr) hipFree(e->pctr);
     if (e->prof_wave) hipFree(e->prof_wave);
     delete e;
@@ -284,8 +288,9 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
                         bool have_hist = false) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    if (!have_hist) hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr);
-    hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.perm);
+    if (!have_hist) hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.atype);
+    hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u8*)e->pend.atype, e->pend.ctr,
+                       e->pend.perm, e->pend.ptype);
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
@@ -340,7 +345,7 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
     HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
     if (sample_step)
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
-                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16);
+                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16, e->pend.atype);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
     if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, LR_HEAVY_GRID);
@@ -383,7 +388,7 @@ int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) 
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr, (u8*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -443,7 +448,7 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
                        e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa,
-                       e->pend.ctr + 16);
+                       e->pend.ctr + 16, e->pend.atype);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));

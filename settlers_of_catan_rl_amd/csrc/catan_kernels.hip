@@ -1072,6 +1072,7 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
 struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; i32* perm; i32* resets[2][2]; u8* busy;
+                 u8* atype; u8* ptype;      // action-type bin per game / per sorted slot (13 = no-op, padding or busy)
                  int fa, ftag, sa, stag; };
 constexpr int CTR_WORDS = 64;
 struct StepCfg;
@@ -1199,9 +1200,10 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     const bool live = e < c.n;
-    // a negative type is an explicit no-op (frozen game), a busy game ignores its action: neither touches its record
-    int type = live ? actions[e * ACTION_WORDS] : -1;
-    if (type < 0 || type > 12 || pend.busy[e]) type = -1;
+    // bin 13 = explicit no-op (negative type: frozen game), padding, or a busy game (the sampler gives those the no-op):
+    // none of them touches its record
+    int type = pend.ptype[(long)blockIdx.x * 64 + lane];
+    if (type > 12 || !live) type = -1;
     if (live && type < 0) {
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         done[e] = 0;
@@ -1683,24 +1685,25 @@ DEVI int action_bin(const Ctx& c, const i32* __restrict__ actions, long e) {
     const int t = actions[e * ACTION_WORDS];
     return (t < 0 || t > 12) ? 13 : t;
 }
-__global__ __launch_bounds__(BLOCK) void k_classify_hist(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr) {
+__global__ __launch_bounds__(BLOCK) void k_classify_hist(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr, u8* __restrict__ atype) {
     __shared__ u32 hist[16];
     if (threadIdx.x < 16) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
-    if (e < c.N) atomicAdd(&hist[action_bin(c, actions, e)], 1u);
+    if (e < c.N) { const int bin = action_bin(c, actions, e); atomicAdd(&hist[bin], 1u); atype[e] = (u8)bin; }
     __syncthreads();
     if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&ctr[16 + threadIdx.x], hist[threadIdx.x]);
 }
-__global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr,
-                                                           i32* __restrict__ perm) {
+// atype: the games' bins (written by the histogram pass); ptype: the bins in sorted order, next to perm
+__global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const u8* __restrict__ atype, u32* __restrict__ ctr,
+                                                           i32* __restrict__ perm, u8* __restrict__ ptype) {
     __shared__ u32 hist[16], base[16];
     if (threadIdx.x < 16) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
     int bin = 0;
     u32 rank = 0;
-    if (e < c.N) { bin = action_bin(c, actions, e); rank = atomicAdd(&hist[bin], 1u); }
+    if (e < c.N) { bin = atype[e]; rank = atomicAdd(&hist[bin], 1u); }
     __syncthreads();
     if (threadIdx.x < 14) {
         u32 start = 0;
@@ -1708,7 +1711,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const i32* __
         base[threadIdx.x] = start + (hist[threadIdx.x] ? atomicAdd(&ctr[32 + threadIdx.x], hist[threadIdx.x]) : 0u);
     }
     __syncthreads();
-    if (e < c.N) perm[base[bin] + rank] = (i32)e;
+    if (e < c.N) { perm[base[bin] + rank] = (i32)e; ptype[base[bin] + rank] = (u8)bin; }
 }
 
 // ------------------------------------------------------------------------------------------------ random policy
@@ -1728,18 +1731,17 @@ DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * 
 // A busy game whose tag equals tag_now or tag_now2 (>= 2) is released here: its step was completed on a side stream, which
 // the caller has joined before this launch.
 // Returns the sampled action type (-1: busy game, no action).
-DEVI int sample_random(const Ctx& c, const St& s, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
+DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u32 step_idx, int (&a)[ACTION_WORDS],
                        u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2) {
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
     if (pctr != nullptr) {
         int b = busy[s.e];
         if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
-        if (b) { actions[s.e * ACTION_WORDS] = -1; return -1; }
+        if (b) { a[0] = -1; return -1; }
         step_idx = pctr[s.e];
         pctr[s.e] = step_idx + 1;
     }
-    u32 m[MASK_WORDS];
-#pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
     u64 id = c.env_id0 + (u64)s.e;
     u32 w[8];
     {
@@ -1747,9 +1749,6 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32* __restrict__ mpk, u
         philox4x32_10(2 * step_idx, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
         w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
     }
-    int a[ACTION_WORDS];
-#pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
     int t = pick64(getr<M0, 13>(m), w[0]);
     a[0] = t;
     switch (t) {
@@ -1803,14 +1802,14 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32* __restrict__ mpk, u
     case T_DISCARD: a[17] = pick64(getr<M11, 5>(m), w[1]); break;
     default: break;
     }
-#pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) actions[s.e * ACTION_WORDS + i] = a[i];
     return t;
 }
-// bins != nullptr: also the histogram of the counting sort (k_classify_hist fused in; rollout loops)
+// bins != nullptr: also the histogram of the counting sort (k_classify_hist fused in; rollout loops) and the per-game
+// action types for k_classify_scatter.  (Staging the mask / action rows through LDS with coalesced transfers was tried:
+// 2.5 us slower - the kernel is bound by its divergent sampling chain, not by the row accesses.)
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
                                                         u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
-                                                        u32* __restrict__ zero_me, u32* __restrict__ bins) {
+                                                        u32* __restrict__ zero_me, u32* __restrict__ bins, u8* __restrict__ atype) {
     __shared__ u32 hist[16];
     if (bins != nullptr) {
         if (threadIdx.x < 16) hist[threadIdx.x] = 0;
@@ -1820,11 +1819,18 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
     int t = 13;                                             // padding games: the no-op bin
     if (s.e < c.n) {
-        t = sample_random(c, s, mpk, step_idx, actions, pctr, busy, tag_now, tag_now2);
+        u32 m[MASK_WORDS];
+#pragma unroll
+        for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
+        int a[ACTION_WORDS];
+        t = sample_random(c, s, m, step_idx, a, pctr, busy, tag_now, tag_now2);
         if (t < 0 || t > 12) t = 13;
+        uint2* row = reinterpret_cast<uint2*>(actions + s.e * ACTION_WORDS);         // 72 B rows: 8 B aligned
+#pragma unroll
+        for (int i = 0; i < ACTION_WORDS / 2; i++) row[i] = make_uint2((u32)a[2 * i], (u32)a[2 * i + 1]);
     }
     if (bins != nullptr) {
-        if (s.e < c.N) atomicAdd(&hist[t], 1u);
+        if (s.e < c.N) { atomicAdd(&hist[t], 1u); atype[s.e] = (u8)t; }
         __syncthreads();
         if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]);
     }
