@@ -181,7 +181,9 @@ class VecCatanEnv(object):
 
 class _GameView(object):
     """The `env.game.*` attributes the reference's callers read: players_need_to_discard,
-    players_to_discard, must_respond_to_trade, proposed_trade["target_player"], players_go."""
+    players_to_discard, must_respond_to_trade, proposed_trade["target_player"], players_go (game_manager.py:152-159),
+    initial_settlements_placed / initial_roads_placed (evaluation/evaluation_manager.py:84-88) and
+    randomise_uncertainty(player_id) (forward_search_policy/worker.py:46)."""
 
     def __init__(self, wrapper):
         self._w = wrapper
@@ -215,6 +217,24 @@ class _GameView(object):
     @property
     def players_go(self):
         return int(self._field("players_go")[0])
+
+    @property
+    def initial_placement_phase(self):
+        return bool(self._field("initial_phase")[0])
+
+    @property
+    def initial_settlements_placed(self):
+        v = self._field("init_settlements")
+        return {pid: int(v[pid - 1]) for pid in (1, 2, 3, 4)}
+
+    @property
+    def initial_roads_placed(self):
+        v = self._field("init_roads")
+        return {pid: int(v[pid - 1]) for pid in (1, 2, 3, 4)}
+
+    def randomise_uncertainty(self, controlling_player_id):
+        self._w.vec.randomise_uncertainty(torch.tensor([int(controlling_player_id)]))
+        self._w._cache = None
 
 
 class EnvWrapper(object):

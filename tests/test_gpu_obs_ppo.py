@@ -90,6 +90,16 @@ def test_env_wrapper_shim_signatures(oracle, hip_lib):
     assert not np.array_equal(env.save_state()["blob"], st["blob"])
     env.restore_state(st)
     assert np.array_equal(env.save_state()["blob"], st["blob"]) and legal_type >= 0
+    # the remaining attributes the reference's callers read: evaluation + forward search
+    ob = o.export()
+    assert env.curr_vps == {p: int(spec.state_field(ob, "curr_vps")[p - 1]) for p in (1, 2, 3, 4)}
+    assert env.game.initial_settlements_placed == {p: int(spec.state_field(ob, "init_settlements")[p - 1]) for p in (1, 2, 3, 4)}
+    assert env.game.initial_roads_placed == {p: int(spec.state_field(ob, "init_roads")[p - 1]) for p in (1, 2, 3, 4)}
+    assert (env.winner is None) == (int(spec.state_field(ob, "winner")[0]) == 0)
+    ctrl = env.game.players_go
+    env.game.randomise_uncertainty(ctrl)                     # forward_search_policy/worker.py:46
+    o.randomise_uncertainty(ctrl)
+    assert np.array_equal(env.save_state()["blob"], o.export())
 
 
 def test_longest_path_cases_vs_reference(hip_lib):
