@@ -21,9 +21,9 @@ def main():
     ap.add_argument("--roots", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=64)
     ap.add_argument("--round", type=int, default=16)
-    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--depth", type=int, default=15, help="max_depth of a simulation (SURVEY 8(d) config 5: 15; the reference class default is 20)")
     ap.add_argument("--decisions", type=int, default=2, help="timed planner decisions per root (after one warm-up)")
-    ap.add_argument("--warm-games", type=int, default=700)
+    ap.add_argument("--warm-games", type=int, default=500, help="random-policy steps before the roots are taken (config 5: step 500)")
     ap.add_argument("--fp32", action="store_true")
     args = ap.parse_args()
     import torch
