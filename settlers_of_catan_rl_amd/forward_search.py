@@ -119,9 +119,66 @@ class UCBStats(object):
         self.last_std[rows] = np.where(np.isnan(std), 0.1, std)       # `except: std = 0.1` / isnan
 
 
+# ---------------------------------------------------------------------------------------------------- small-batch inference
+class GraphedAct(object):
+    """policy.act for SMALL batches as hipGraph replays.  Towards the end of a round only a few simulations are still
+    running, and a policy pass is then ~1 300 tiny kernels - launch-bound at ~10 ms whatever the batch.  For a few bucket
+    sizes the pass is captured once (torch.cuda.CUDAGraph: the library GEMMs and the hand-written attention / LayerNorm
+    launches alike, all on the capture stream) with static input buffers and replayed; rows beyond the live ones are
+    padding and ignored.  Sampling uses torch's default CUDA generator, which graphs advance correctly.  Falls back to the
+    eager call if capture is unavailable."""
+
+    def __init__(self, policy, buckets=(512, 4096), autocast_dtype=None, deterministic=False):
+        self.policy, self.buckets, self.autocast_dtype, self.deterministic = policy, tuple(sorted(buckets)), autocast_dtype, deterministic
+        self.graphs = {}
+        self.failed = False
+
+    def _run(self, f, lists, lens, masks):
+        if self.autocast_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+                return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic)
+        return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic)
+
+    def _capture(self, B, f, lists, lens, masks):
+        st = {"f": f[:1].expand(B, -1).clone(), "lists": lists[:1].expand(B, -1, -1).clone(),
+              "lens": lens[:1].expand(B, -1).clone(), "masks": masks[:1].expand(B, -1).clone()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._run(st["f"], st["lists"], st["lens"], st["masks"])
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            v, a, _ = self._run(st["f"], st["lists"], st["lens"], st["masks"])
+        st["g"], st["v"], st["a"] = g, v, a
+        return st
+
+    def __call__(self, f, lists, lens, masks):
+        """-> (value [n,1], actions [n,18]) for n rows; eager when n exceeds the largest bucket."""
+        n = f.shape[0]
+        B = next((b for b in self.buckets if n <= b), None)
+        if B is None or self.failed or not f.is_cuda:
+            v, a, _ = self._run(f, lists, lens, masks)
+            return v, a
+        if B not in self.graphs:
+            try:
+                self.graphs[B] = self._capture(B, f, lists, lens, masks)
+            except Exception:                                   # capture not available: stay eager
+                self.failed = True
+                torch.cuda.synchronize()
+                v, a, _ = self._run(f, lists, lens, masks)
+                return v, a
+        st = self.graphs[B]
+        st["f"][:n] = f; st["lists"][:n] = lists; st["lens"][:n] = lens; st["masks"][:n] = masks
+        st["g"].replay()
+        return st["v"][:n].clone(), st["a"][:n].clone()
+
+
 # ---------------------------------------------------------------------------------------------------- simulations
 @torch.no_grad()
-def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, deterministic=False, generator=None, autocast_dtype=None):
+def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, deterministic=False, generator=None, autocast_dtype=None,
+             graphed=None):
     """run_simulation_forward (worker.py:61-114) for all env.n simulations in lock-step.  env: dense-reward, no auto-reset,
     already holding the (randomised) start states; ctrl int [n] PlayerId of the searching player; init_actions [n,18].
     -> float64 numpy [n] value estimates."""
@@ -155,7 +212,9 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
         idx = live.nonzero(as_tuple=True)[0]
         sub = idx.numel() < n
         args = (f[idx], lists[idx], lens[idx].long(), masks[idx]) if sub else (f, lists, lens.long(), masks)
-        if autocast_dtype is not None:
+        if graphed is not None and sub:
+            value_s, action_s = graphed(*args)                                             # small batch: hipGraph replay
+        elif autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=autocast_dtype):
                 value_s, action_s, _ = policy.act(*args, deterministic=deterministic, generator=generator)
         else:
@@ -324,7 +383,7 @@ class ForwardSearch(object):
     player.  make_sim_env(n) -> an env of n games with dense rewards and no auto-reset (VecCatanEnv on the GPU)."""
 
     def __init__(self, policy, make_sim_env, n_roots, max_init_actions=10, max_depth=20, gamma=0.999, sims_per_root=64,
-                 sims_per_round=16, consider_all_moves_for_opening_placement=False, seed=0, autocast_dtype=None):
+                 sims_per_round=16, consider_all_moves_for_opening_placement=False, seed=0, autocast_dtype=None, use_graphs=False):
         assert sims_per_root % sims_per_round == 0
         self.policy, self.R = policy, n_roots
         self.max_init_actions, self.max_depth, self.gamma = max_init_actions, max_depth, gamma
@@ -335,6 +394,7 @@ class ForwardSearch(object):
         self.rngs = [_py_random.Random(seed * 1000003 + i) for i in range(n_roots)]
         self.gen = None
         self.autocast_dtype = autocast_dtype
+        self.graphed = GraphedAct(policy, autocast_dtype=autocast_dtype) if use_graphs else None
         self.sims_run = 0
         self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]
 
@@ -368,7 +428,7 @@ class ForwardSearch(object):
             self.sim_env.randomise_uncertainty(ctrl_sim)                            # :46
             init = props_t[torch.arange(R, device=props_t.device).repeat_interleave(K), torch.from_numpy(ids.reshape(-1)).to(props_t.device)]
             vals = simulate(self.sim_env, self.policy, ctrl_sim, init, self.max_depth, self.gamma, deterministic, self.gen,
-                            self.autocast_dtype).reshape(R, K)
+                            self.autocast_dtype, None if deterministic else self.graphed).reshape(R, K)
             for k in range(K):
                 self.stats.update(vals[:, k], ids[:, k])
             self.sims_run += R * K

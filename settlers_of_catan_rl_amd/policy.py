@@ -280,7 +280,7 @@ class _ActionHeads(nn.Module):
                 step_lp, ent = step_lp * keep, ent * keep
             logp_sum, ent_sum = logp_sum + step_lp, ent_sum + ent
             chosen.append(a)
-            out = out * torch.tensor([0., 1, 1, 1, 1, 1], device=x.device)
+            out = torch.cat((torch.zeros_like(out[:, :1]), out[:, 1:]), 1)     # column 0 ("stop") never feeds back; no host constant
         return out, torch.stack(chosen, 1), logp_sum, ent_sum
 
     def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None):
