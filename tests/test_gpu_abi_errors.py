@@ -1,0 +1,39 @@
+"""GPU: error behaviour of the C ABI (return codes + catan_last_error, no exceptions across the boundary)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments_are_reported_not_crashed(hip_lib):
+    from settlers_of_catan_rl_amd import _lib
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    L = _lib.lib()
+    env = VecCatanEnv(64, seed=0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def err(rc):
+        assert rc != 0
+        return L.catan_last_error().decode()
+
+    assert "null" in err(L.catan_step(env.h, None, None, None, st))
+    assert "bad arguments" in err(L.catan_random_rollout_deferred(env.h, 10, 0, st))
+    assert "bad arguments" in err(L.catan_random_rollout(env.h, 0, -1, st))
+    h = C.c_void_p()
+    assert "bad arguments" in err(L.catan_create(C.byref(h), 0, 0, 0, 0, None))
+    assert "bad device" in err(L.catan_create(C.byref(h), 99, 8, 0, 0, None))
+    x = torch.zeros((128, 16), device="cuda", dtype=torch.bfloat16)
+    dw = torch.zeros((300, 16), device="cuda")
+    assert not L.catan_linear_wgrad_supported(128, 16, 300) and not L.catan_linear_wgrad_supported(128, 200, 16)
+    assert "unsupported" in err(L.catan_linear_wgrad(C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(dw.data_ptr()), None, 128, 16, 300, st))
+    q = torch.zeros((4, 7, 3, 2, 8), device="cuda")
+    assert "unsupported" in err(L.catan_attention_fwd(C.c_void_p(q.data_ptr()), None, C.c_void_p(q.data_ptr()), 4, 7, 2, 8, 0, st))
+    assert "unsupported" in err(L.catan_layer_norm_fwd(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()),
+                                                       C.c_void_p(q.data_ptr()), 4, 48, 1e-5, 0, 0, st))
+    with pytest.raises(_lib.CatanHipError):
+        _lib.check(L.catan_random_rollout_deferred(env.h, 10, -3, st))
+    # the handle is still usable after the failed calls
+    env.random_rollout_deferred(40, 8)
+    assert env.invalid_action_count() == 0
