@@ -1,0 +1,24 @@
+"""Workload for the learner-side rocprofv3 passes (tools/profile_policy_round.sh): three PPO-style training steps of the
+policy net at 65 536 rows (bf16 autocast) after a warm-up, so that the kernel-trace statistics and the MFMA counters
+describe the steady-state step."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd.policy import CatanPolicy
+
+B = 65536
+env = VecCatanEnv(B, seed=0); env.random_rollout(0, 500)
+f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+net = CatanPolicy().cuda()
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+    _, a, _ = net.act(f, lists, lens, masks)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+for _ in range(int(os.environ.get("STEPS", "4"))):
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v, lp, ent = net.evaluate_actions(f, lists, lens, masks, a)
+    loss = v.float().mean() + lp.float().mean() - 0.01 * ent
+    opt.zero_grad(); loss.backward(); opt.step()
+torch.cuda.synchronize()
+print("policy workload done")
