@@ -223,9 +223,11 @@ class _Head(nn.Module):
         self.distribution = _Dist(128, out_dim)
 
     def logits(self, x, custom=None):
+        # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
         if custom is not None:
-            x = torch.cat((x, F.relu(self.custom_norm(self.custom_mlp(custom)))), -1)
-        return self.distribution.linear(self.mlp_2(F.relu(self.norm(self.mlp_1(x))))).float()
+            x = torch.cat((x, F.relu(self.custom_norm(_lin(custom, self.custom_mlp.weight, self.custom_mlp.bias)))), -1)
+        h = _lin(F.relu(self.norm(self.mlp_1(x))), self.mlp_2.weight, self.mlp_2.bias)
+        return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
 
 
 def _masked_logp(logits, mask):
@@ -371,7 +373,8 @@ class CatanPolicy(nn.Module):
     # ---- pieces
     def base(self, obs_f, lists, lens):
         main = self.observation_module(obs_f, lists, lens)
-        v = self.value_out(F.relu(self.v_norm_2(self.value_network_fc_2(F.relu(self.v_norm_1(self.value_network_fc_1(main)))))))
+        v = _lin(F.relu(self.v_norm_2(self.value_network_fc_2(F.relu(self.v_norm_1(self.value_network_fc_1(main)))))),
+                 self.value_out.weight, self.value_out.bias)
         return v.float(), main
 
     @staticmethod
