@@ -24,7 +24,7 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 template <class T, int L, int H, int HD>
 __global__ __launch_bounds__(64) void k_attn_fwd(const T* __restrict__ qkv, const int* __restrict__ lens, T* __restrict__ out, long B) {
     constexpr int G = 64 / L, D = H * HD;
-    __shared__ float Ks[G][L][D + 1], Vs[G][L][D + 1];
+    __shared__ __attribute__((aligned(16))) float Ks[G][L][D + 4], Vs[G][L][D + 4];   // 16 B aligned rows: a head slice is read with ds_read_b128
     const int lane = threadIdx.x, g = lane / L, i = lane % L;
     const long b0 = (long)blockIdx.x * G;
     // stage K, V (coalesced over the contiguous [L][3][D] block of each sequence)
@@ -81,7 +81,7 @@ template <class T, int L, int H, int HD>
 __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, const int* __restrict__ lens, const T* __restrict__ dout,
                                                  T* __restrict__ dqkv, long B) {
     constexpr int G = 64 / L, D = H * HD;
-    __shared__ float Qs[G][L][D + 1], Ks[G][L][D + 1], Vs[G][L][D + 1], Os[G][L][D + 1];
+    __shared__ __attribute__((aligned(16))) float Qs[G][L][D + 4], Ks[G][L][D + 4], Vs[G][L][D + 4], Os[G][L][D + 4];   // 16 B aligned rows
     __shared__ float Ps[G][L][L + 1], Ss[G][L][L + 1];
     const int lane = threadIdx.x, g = lane / L, i = lane % L;
     const long b0 = (long)blockIdx.x * G;
