@@ -155,7 +155,7 @@ int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, c
 int catan_attention_fwd(const void* qkv, const int32_t* lens, void* out, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream);
 int catan_attention_bwd(const void* qkv, const int32_t* lens, const void* dout, void* dqkv, int64_t B, int L, int H, int HD, int is_bf16, catan_stream_t stream);
 
-/* LayerNorm over a small last dimension D in {16, 25, 32, 64} with optional fused ReLU (the nn.LayerNorm + ReLU pairs of
+/* LayerNorm over the last dimension D in {16, 25, 32, 64, 128, 256, 512} (x, y, dy, dx 16-byte aligned for D >= 128) with optional fused ReLU (the nn.LayerNorm + ReLU pairs of
  * RL/models/tile_encoder.py:83-91, player_modules.py:26-30,114-117).  x, y, dy, dx: [rows][D] float32 or bfloat16;
  * w, b, dw, db float32 [D]; dw/db are ACCUMULATED into (zero them first). */
 int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y, int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream);

@@ -233,6 +233,116 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ x, const f
 }
 
 
+// ------------------------------------------------------------------------------------------------ LayerNorm, wide rows
+// D = 64 * EPL (128, 256, 512: the player / head / value modules, RL/models/player_modules.py:26-30,114-117,
+// action_heads_module.py, policy.py): one wave per row, lane j owns the EPL contiguous elements j*EPL .. j*EPL+EPL-1 (one
+// 4 / 8 / 16 B access per lane, fully coalesced), moments by a 64-lane butterfly; in the backward every lane always works on
+// the same columns, so dw / db accumulate in registers and leave through one LDS reduction + EPL atomics per lane per block.
+template <class T, int EPL> struct RowVec;
+template <int EPL> struct RowVec<float, EPL> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[EPL]) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) { const float4 u = *reinterpret_cast<const float4*>(p + e); v[e] = u.x; v[e + 1] = u.y; v[e + 2] = u.z; v[e + 3] = u.w; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[EPL]) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(p + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+    }
+};
+template <> struct RowVec<float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) { const float2 u = *reinterpret_cast<const float2*>(p); v[0] = u.x; v[1] = u.y; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <int EPL> struct RowVec<__hip_bfloat16, EPL> {
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+        return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+    }
+    static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[EPL]) {
+        unsigned w[EPL / 2];
+        if constexpr (EPL == 2) w[0] = *reinterpret_cast<const unsigned*>(p);
+        else if constexpr (EPL == 4) { const uint2 u = *reinterpret_cast<const uint2*>(p); w[0] = u.x; w[1] = u.y; }
+        else { const uint4 u = *reinterpret_cast<const uint4*>(p); w[0] = u.x; w[1] = u.y; w[2] = u.z; w[3] = u.w; }
+#pragma unroll
+        for (int k = 0; k < EPL / 2; k++) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u); }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[EPL]) {
+        if constexpr (EPL == 2) *reinterpret_cast<unsigned*>(p) = pack(v[0], v[1]);
+        else if constexpr (EPL == 4) *reinterpret_cast<uint2*>(p) = make_uint2(pack(v[0], v[1]), pack(v[2], v[3]));
+        else *reinterpret_cast<uint4*>(p) = make_uint4(pack(v[0], v[1]), pack(v[2], v[3]), pack(v[4], v[5]), pack(v[6], v[7]));
+    }
+};
+
+template <class T, int EPL>
+__global__ __launch_bounds__(256) void k_lnw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                 T* __restrict__ y, long rows, float eps, int relu) {
+    constexpr int D = 64 * EPL;
+    const int j = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float wj[EPL], bj[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) { wj[e] = w[j * EPL + e]; bj[e] = bvec[j * EPL + e]; }
+    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+        float v[EPL];
+        RowVec<T, EPL>::load(x + row * D + j * EPL, v);
+        float sum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) sum += v[e];
+        const float mean = group_sum<64>(sum) * (1.0f / D);
+        float sq = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { v[e] -= mean; sq += v[e] * v[e]; }
+        const float rstd = rsqrtf(group_sum<64>(sq) * (1.0f / D) + eps);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { v[e] = v[e] * rstd * wj[e] + bj[e]; if (relu) v[e] = fmaxf(v[e], 0.0f); }
+        RowVec<T, EPL>::store(y + row * D + j * EPL, v);
+    }
+}
+
+template <class T, int EPL>
+__global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                 const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dw,
+                                                 float* __restrict__ db, long rows, float eps, int relu) {
+    constexpr int D = 64 * EPL;
+    const int j = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float wj[EPL], bj[EPL], aw[EPL], ab[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) { wj[e] = w[j * EPL + e]; bj[e] = bvec[j * EPL + e]; aw[e] = 0.0f; ab[e] = 0.0f; }
+    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+        float v[EPL], g[EPL];
+        RowVec<T, EPL>::load(x + row * D + j * EPL, v);
+        RowVec<T, EPL>::load(dy + row * D + j * EPL, g);
+        float sum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) sum += v[e];
+        const float mean = group_sum<64>(sum) * (1.0f / D);
+        float sq = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { v[e] -= mean; sq += v[e] * v[e]; }
+        const float rstd = rsqrtf(group_sum<64>(sq) * (1.0f / D) + eps);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            v[e] *= rstd;                                          // x_hat
+            if (relu && v[e] * wj[e] + bj[e] <= 0.0f) g[e] = 0.0f;
+            aw[e] += g[e] * v[e]; ab[e] += g[e];
+            g[e] *= wj[e];
+            s1 += g[e]; s2 += g[e] * v[e];
+        }
+        const float m1 = group_sum<64>(s1) * (1.0f / D), m2 = group_sum<64>(s2) * (1.0f / D);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) v[e] = rstd * (g[e] - m1 - v[e] * m2);
+        RowVec<T, EPL>::store(dx + row * D + j * EPL, v);
+    }
+    __shared__ float sw[4][D], sb[4][D];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) { sw[wv][j * EPL + e] = aw[e]; sb[wv][j * EPL + e] = ab[e]; }
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < D; cidx += 256) {
+        atomicAdd(dw + cidx, sw[0][cidx] + sw[1][cidx] + sw[2][cidx] + sw[3][cidx]);
+        atomicAdd(db + cidx, sb[0][cidx] + sb[1][cidx] + sb[2][cidx] + sb[3][cidx]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ tall-skinny weight gradient
 // dW[o][i] = sum_r dY[r][o] * X[r][i],  db[o] = sum_r dY[r][o]   for the Linear layers of the net whose row count is
 // huge and whose widths are small (tile encoder: R = 19 B rows, widths 25..192; card attention: R = 25 B..75 B, widths

@@ -17,6 +17,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _aligned(t):
+    """contiguous and 16-byte aligned (the wide LayerNorm uses 16 B global accesses; a contiguous view may start anywhere)"""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 class _SmallAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, lens):
@@ -51,14 +57,14 @@ def supported(L, H, HD):
     return (L, H, HD) in SUPPORTED
 
 
-LN_WIDTHS = {16, 25, 32, 64}
+LN_WIDTHS = {16, 25, 32, 64, 128, 256, 512}
 
 
 class _SmallLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, relu):
         D = x.shape[-1]
-        x = x.contiguous()
+        x = _aligned(x)
         y = torch.empty_like(x)
         rows = x.numel() // D
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
@@ -73,7 +79,7 @@ class _SmallLayerNorm(torch.autograd.Function):
         x, wf, bf = ctx.saved_tensors
         D = x.shape[-1]
         rows = x.numel() // D
-        dy = dy.contiguous().to(x.dtype)
+        dy = _aligned(dy.to(x.dtype))
         dx = torch.empty_like(x)
         dw = torch.zeros(D, dtype=torch.float32, device=x.device)
         db = torch.zeros(D, dtype=torch.float32, device=x.device)

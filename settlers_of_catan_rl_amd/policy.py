@@ -152,8 +152,8 @@ class _CurrentPlayer(nn.Module):
     def forward(self, main, hid, hid_len, played, played_len, emb, hid_mha, played_mha):
         h = _ln(self.norm_2, _lin(_card_summary(hid, hid_len, emb, hid_mha, self.norm), self.proj_hidden_dev_card.weight, self.proj_hidden_dev_card.bias), relu=True)
         p = _ln(self.norm_3, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
-        m = F.relu(self.norm_1(_lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias)))
-        return F.relu(self.norm_4(self.final_linear_layer(torch.cat((m, p, h), -1))))
+        m = _ln(self.norm_1, _lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias), relu=True)
+        return _ln(self.norm_4, self.final_linear_layer(torch.cat((m, p, h), -1)), relu=True)
 
 
 class _OtherPlayers(nn.Module):
@@ -169,8 +169,8 @@ class _OtherPlayers(nn.Module):
 
     def forward(self, main, played, played_len, emb, played_mha):
         p = _ln(self.norm_2, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
-        m = F.relu(self.norm_1(_lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias)))
-        return F.relu(self.norm_3(self.final_linear_layer(torch.cat((m, p), -1))))
+        m = _ln(self.norm_1, _lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias), relu=True)
+        return _ln(self.norm_3, self.final_linear_layer(torch.cat((m, p), -1)), relu=True)
 
 
 class _ObservationModule(nn.Module):
@@ -200,7 +200,7 @@ class _ObservationModule(nn.Module):
         op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
                                        self.dev_card_embedding, self.played_card_mha)
         parts.append(op.reshape(B, 3 * 128))
-        return F.relu(self.norm(self.final_layer(torch.cat(parts, -1))))
+        return _ln(self.norm, self.final_layer(torch.cat(parts, -1)), relu=True)
 
 
 class _Dist(nn.Module):
@@ -225,8 +225,8 @@ class _Head(nn.Module):
     def logits(self, x, custom=None):
         # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
         if custom is not None:
-            x = torch.cat((x, F.relu(self.custom_norm(_lin(custom, self.custom_mlp.weight, self.custom_mlp.bias)))), -1)
-        h = _lin(F.relu(self.norm(self.mlp_1(x))), self.mlp_2.weight, self.mlp_2.bias)
+            x = torch.cat((x, _ln(self.custom_norm, _lin(custom, self.custom_mlp.weight, self.custom_mlp.bias), relu=True)), -1)
+        h = _lin(_ln(self.norm, self.mlp_1(x), relu=True), self.mlp_2.weight, self.mlp_2.bias)
         return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
 
 
@@ -373,7 +373,7 @@ class CatanPolicy(nn.Module):
     # ---- pieces
     def base(self, obs_f, lists, lens):
         main = self.observation_module(obs_f, lists, lens)
-        v = _lin(F.relu(self.v_norm_2(self.value_network_fc_2(F.relu(self.v_norm_1(self.value_network_fc_1(main)))))),
+        v = _lin(_ln(self.v_norm_2, self.value_network_fc_2(_ln(self.v_norm_1, self.value_network_fc_1(main), relu=True)), relu=True),
                  self.value_out.weight, self.value_out.bias)
         return v.float(), main
 

@@ -95,7 +95,7 @@ def test_fused_attention_kernel_vs_torch(hip_lib, L, H, HD, dtype):
         assert torch.allclose(g1, x.grad, atol=tol * 4, rtol=tol * 4), float((g1 - x.grad).abs().max())
 
 
-@pytest.mark.parametrize("D", [16, 25, 64])
+@pytest.mark.parametrize("D", [16, 25, 64, 128, 256, 512])
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 @pytest.mark.parametrize("relu", [False, True])
 def test_small_layer_norm_kernel_vs_torch(hip_lib, D, dtype, relu):
@@ -119,7 +119,10 @@ def test_small_layer_norm_kernel_vs_torch(hip_lib, D, dtype, relu):
         yr.backward(go.float())
         tol = 2e-5 if dtype == "float32" else 4e-2
         assert torch.allclose(y.float(), yr, atol=tol, rtol=tol)
-        assert torch.allclose(gx, xr.grad, atol=tol * 4, rtol=tol * 4)
+        bad = ~torch.isclose(gx, xr.grad, atol=tol * 4, rtol=tol * 4)
+        # with the fused ReLU an output within rounding of 0 can fall on the other side of the threshold than in torch's
+        # summation order, which changes that row's gradient: allow a vanishing fraction of such rows
+        assert float(bad.float().mean()) <= (2e-5 if relu else 0.0)
         n = x.numel() // D
         assert torch.allclose(gw, ln.weight.grad, atol=tol * 4 * max(1, n ** 0.5), rtol=2e-2)
         assert torch.allclose(gb, ln.bias.grad, atol=tol * 4 * max(1, n ** 0.5), rtol=2e-2)
