@@ -82,14 +82,15 @@ static int ln_launch(bool bwd, const void* x, const float* w, const float* b, co
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-template <class T, int EPL>
+template <class T, int EPL, int GL>
 static int lnw_launch(bool bwd, const void* x, const float* w, const float* b, const void* dy, void* out, float* dw, float* db,
                       long rows, float eps, int relu, hipStream_t st) {
-    long nb = (rows + 3) / 4;
+    constexpr int RPB = 256 / GL;
+    long nb = (rows + RPB - 1) / RPB;
     const long cap = bwd ? 1024 : 8192;          // bwd ends with 2*D atomics per block
     if (nb > cap) nb = cap;
-    if (!bwd) hipLaunchKernelGGL((k_lnw_fwd<T, EPL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (T*)out, rows, eps, relu);
-    else hipLaunchKernelGGL((k_lnw_bwd<T, EPL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (const T*)dy, (T*)out, dw, db, rows, eps, relu);
+    if (!bwd) hipLaunchKernelGGL((k_lnw_fwd<T, EPL, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (T*)out, rows, eps, relu);
+    else hipLaunchKernelGGL((k_lnw_bwd<T, EPL, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (const T*)dy, (T*)out, dw, db, rows, eps, relu);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -100,10 +101,12 @@ static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, 
     case 16: return ln_launch<T, 16, 16>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     case 25: return ln_launch<T, 25, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     case 32: return ln_launch<T, 32, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 64: return ln_launch<T, 64, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 128: return lnw_launch<T, 2>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 256: return lnw_launch<T, 4>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 512: return lnw_launch<T, 8>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 64:
+        if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) return lnw_launch<T, 8, 8>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+        return ln_launch<T, 64, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 128: return lnw_launch<T, 2, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 256: return lnw_launch<T, 4, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 512: return lnw_launch<T, 8, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     default: return fail(CATAN_EINVAL, "catan_layer_norm: unsupported width (built for 16, 25, 32, 64, 128, 256, 512)");
     }
 }

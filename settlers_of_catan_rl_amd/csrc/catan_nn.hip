@@ -234,10 +234,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ x, const f
 
 
 // ------------------------------------------------------------------------------------------------ LayerNorm, wide rows
-// D = 64 * EPL (128, 256, 512: the player / head / value modules, RL/models/player_modules.py:26-30,114-117,
-// action_heads_module.py, policy.py): one wave per row, lane j owns the EPL contiguous elements j*EPL .. j*EPL+EPL-1 (one
-// 4 / 8 / 16 B access per lane, fully coalesced), moments by a 64-lane butterfly; in the backward every lane always works on
-// the same columns, so dw / db accumulate in registers and leave through one LDS reduction + EPL atomics per lane per block.
+// D = GL * EPL: GL lanes per row, lane j owns the EPL contiguous elements j*EPL .. j*EPL+EPL-1 (one 4 / 8 / 16 B access per
+// lane, fully coalesced), moments by a GL-lane butterfly.  GL = 64 for D = 128, 256, 512 (the player / head / value modules,
+// RL/models/player_modules.py:26-30,114-117, action_heads_module.py, policy.py); GL = 8, EPL = 8 for D = 64 (the tile
+// encoder's 1.2 M rows per pass: eight rows per wave, three shuffle steps instead of six).  In the backward every lane always
+// works on the same columns, so dw / db accumulate in registers and leave through one LDS reduction + atomics per block.
 template <class T, int EPL> struct RowVec;
 template <int EPL> struct RowVec<float, EPL> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[EPL]) {
@@ -273,52 +274,52 @@ template <int EPL> struct RowVec<__hip_bfloat16, EPL> {
     }
 };
 
-template <class T, int EPL>
+template <class T, int EPL, int GL>
 __global__ __launch_bounds__(256) void k_lnw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
                                                  T* __restrict__ y, long rows, float eps, int relu) {
-    constexpr int D = 64 * EPL;
-    const int j = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int D = GL * EPL, RPB = 256 / GL;
+    const int j = threadIdx.x % GL, wv = threadIdx.x / GL;
     float wj[EPL], bj[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) { wj[e] = w[j * EPL + e]; bj[e] = bvec[j * EPL + e]; }
-    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    for (long row = (long)blockIdx.x * RPB + wv; row < rows; row += (long)gridDim.x * RPB) {
         float v[EPL];
         RowVec<T, EPL>::load(x + row * D + j * EPL, v);
         float sum = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; e++) sum += v[e];
-        const float mean = group_sum<64>(sum) * (1.0f / D);
+        const float mean = group_sum<GL>(sum) * (1.0f / D);
         float sq = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; e++) { v[e] -= mean; sq += v[e] * v[e]; }
-        const float rstd = rsqrtf(group_sum<64>(sq) * (1.0f / D) + eps);
+        const float rstd = rsqrtf(group_sum<GL>(sq) * (1.0f / D) + eps);
 #pragma unroll
         for (int e = 0; e < EPL; e++) { v[e] = v[e] * rstd * wj[e] + bj[e]; if (relu) v[e] = fmaxf(v[e], 0.0f); }
         RowVec<T, EPL>::store(y + row * D + j * EPL, v);
     }
 }
 
-template <class T, int EPL>
+template <class T, int EPL, int GL>
 __global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
                                                  const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dw,
                                                  float* __restrict__ db, long rows, float eps, int relu) {
-    constexpr int D = 64 * EPL;
-    const int j = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int D = GL * EPL, RPB = 256 / GL;
+    const int j = threadIdx.x % GL, wv = threadIdx.x / GL;
     float wj[EPL], bj[EPL], aw[EPL], ab[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) { wj[e] = w[j * EPL + e]; bj[e] = bvec[j * EPL + e]; aw[e] = 0.0f; ab[e] = 0.0f; }
-    for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    for (long row = (long)blockIdx.x * RPB + wv; row < rows; row += (long)gridDim.x * RPB) {
         float v[EPL], g[EPL];
         RowVec<T, EPL>::load(x + row * D + j * EPL, v);
         RowVec<T, EPL>::load(dy + row * D + j * EPL, g);
         float sum = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; e++) sum += v[e];
-        const float mean = group_sum<64>(sum) * (1.0f / D);
+        const float mean = group_sum<GL>(sum) * (1.0f / D);
         float sq = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; e++) { v[e] -= mean; sq += v[e] * v[e]; }
-        const float rstd = rsqrtf(group_sum<64>(sq) * (1.0f / D) + eps);
+        const float rstd = rsqrtf(group_sum<GL>(sq) * (1.0f / D) + eps);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
@@ -328,18 +329,20 @@ __global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const 
             g[e] *= wj[e];
             s1 += g[e]; s2 += g[e] * v[e];
         }
-        const float m1 = group_sum<64>(s1) * (1.0f / D), m2 = group_sum<64>(s2) * (1.0f / D);
+        const float m1 = group_sum<GL>(s1) * (1.0f / D), m2 = group_sum<GL>(s2) * (1.0f / D);
 #pragma unroll
         for (int e = 0; e < EPL; e++) v[e] = rstd * (g[e] - m1 - v[e] * m2);
         RowVec<T, EPL>::store(dx + row * D + j * EPL, v);
     }
-    __shared__ float sw[4][D], sb[4][D];
+    __shared__ float sw[RPB][D + 1], sb[RPB][D + 1];
 #pragma unroll
     for (int e = 0; e < EPL; e++) { sw[wv][j * EPL + e] = aw[e]; sb[wv][j * EPL + e] = ab[e]; }
     __syncthreads();
     for (int cidx = threadIdx.x; cidx < D; cidx += 256) {
-        atomicAdd(dw + cidx, sw[0][cidx] + sw[1][cidx] + sw[2][cidx] + sw[3][cidx]);
-        atomicAdd(db + cidx, sb[0][cidx] + sb[1][cidx] + sb[2][cidx] + sb[3][cidx]);
+        float tw = 0.0f, tb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RPB; q++) { tw += sw[q][cidx]; tb += sb[q][cidx]; }
+        atomicAdd(dw + cidx, tw); atomicAdd(db + cidx, tb);
     }
 }
 
