@@ -119,6 +119,33 @@ class TrainingLoop(object):
                     "eval_logs": self.eval_logs, "update_num": self.update_num, "args": copy.copy(self.args.__dict__),
                     "entropy_coef": self.entropy_coef, "reward_weight": self.reward_weight}, path)
 
+    def save_reference_tuple(self, path):
+        """The reference's own checkpoint layout (robust_train.py:155-156): the 5-tuple (central state-dict, deque of
+        earlier state-dicts, eval logs, update number, args).  State-dict keys are the reference's (CatanPolicy keeps its
+        parameter names); the reference's two extra entries (`dummy_param`, the value normaliser's constants) are added so
+        that `central_policy.load_state_dict` on the reference side accepts it."""
+        import argparse
+        from collections import deque
+        sd = {k: v.detach().cpu() for k, v in self.policy.state_dict().items()}
+        sd.setdefault("dummy_param", torch.empty(0))
+        earlier = deque(self.league.earlier if self.league is not None else [], maxlen=(self.league.earlier.maxlen if self.league is not None else 500))
+        torch.save((sd, earlier, self.eval_logs, self.update_num, argparse.Namespace(**self.args.__dict__)), path)
+
+    def load_reference_tuple(self, path):
+        """robust_train.py:55: accepts the reference's 5-tuple (or its 7-tuple variant with entropy coefficient and reward weight)."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        sd, earlier, self.eval_logs, self.update_num = ck[0], ck[1], ck[2], ck[3]
+        own = self.policy.state_dict()
+        self.policy.load_state_dict({k: v for k, v in sd.items() if k in own})
+        if self.league is not None:
+            self.league.earlier.clear()
+            self.league.earlier.extend({k: v for k, v in e.items() if k in own} for e in earlier)
+            self.league.assign(self.collector, self.make_net)
+        if len(ck) >= 7:
+            self.entropy_coef, self.reward_weight = ck[5], ck[6]
+            self.trainer.cfg.entropy_coef = self.entropy_coef
+            self.env.set_reward_annealing_factor(self.reward_weight)
+
     def load(self, path):
         ck = torch.load(path, map_location="cpu", weights_only=False)
         self.policy.load_state_dict(ck["central_policy"])

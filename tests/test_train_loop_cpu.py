@@ -78,3 +78,11 @@ def test_loop_bookkeeping(tmp_path):
     loop2.load(str(tmp_path / "ck.pt"))
     assert loop2.update_num == 13 and len(loop2.league.earlier) == 4
     assert torch.equal(loop2.policy.weight, net.weight)
+    # the reference's 5-tuple layout (robust_train.py:55,155)
+    loop.save_reference_tuple(str(tmp_path / "ref.pt"))
+    tup = torch.load(str(tmp_path / "ref.pt"), weights_only=False)
+    assert len(tup) == 5 and tup[3] == 13 and len(tup[1]) == 4 and "weight" in tup[0] and tup[4].num_steps == 4
+    loop3 = tl.TrainingLoop(_Env(), torch.nn.Linear(3, 3), _Collector(), _Trainer(net), args, league=League(envs_per_worker=5),
+                            make_net=lambda: torch.nn.Linear(3, 3))
+    loop3.load_reference_tuple(str(tmp_path / "ref.pt"))
+    assert loop3.update_num == 13 and len(loop3.league.earlier) == 4 and torch.equal(loop3.policy.weight, net.weight)
