@@ -180,6 +180,14 @@ int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features
 int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
                        catan_stream_t stream);
 
+/* y[r][n] = sum_k x[r][k] * w[n][k] (+ bias[n]) for huge row counts and small widths (forward and input-gradient GEMMs of
+ * the same layers as catan_linear_wgrad): x [rows][in], w [out][in], bias [out] or NULL, y [rows][out], all bfloat16
+ * row-major, x / w / y 16-byte aligned; in a multiple of 8 and <= 192, out <= 192, and W small enough for the register file (catan_linear_rows_supported).  MFMA with the rows split over the
+ * grid and W resident in registers; HBM-bound. */
+int catan_linear_rows_supported(int64_t rows, int in_features, int out_features);
+int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
+                      catan_stream_t stream);
+
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);

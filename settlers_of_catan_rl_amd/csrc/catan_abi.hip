@@ -131,6 +131,22 @@ static int wgrad_dispatch_it(int it, const void* x, const void* dy, float* dw, f
     return fail(CATAN_EINVAL, "catan_linear_wgrad: in_features + 1 > 160");
 }
 
+template <int KS>
+static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void* b, void* y, long R, int K, int N, hipStream_t st) {
+    long nb = ((R + 15) / 16 + 3) / 4;
+    if (nb > 2048) nb = 2048;
+#define CATAN_LINROWS(NT) hipLaunchKernelGGL((k_linear_rows<KS, NT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, \
+                                             (const unsigned short*)w, (const unsigned short*)b, (unsigned short*)y, R, K, N)
+    if (nt <= 1) CATAN_LINROWS(1);
+    else if (nt <= 2) CATAN_LINROWS(2);
+    else if (nt <= 4) CATAN_LINROWS(4);
+    else if (nt <= 8) CATAN_LINROWS(8);
+    else CATAN_LINROWS(12);
+#undef CATAN_LINROWS
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 extern "C" {
 
 const char* catan_last_error(void) { return g_err.c_str(); }
@@ -670,6 +686,28 @@ int64_t catan_inconsistent_deal_count(catan_env_t* e, catan_stream_t stream) {
     if (hipMemcpyAsync(&v, e->err + 1, sizeof v, hipMemcpyDeviceToHost, S(stream)) != hipSuccess) return -1;
     if (hipStreamSynchronize(S(stream)) != hipSuccess) return -1;
     return (int64_t)v;
+}
+
+int catan_linear_rows_supported(int64_t rows, int in_features, int out_features) {
+    if (!(rows >= 1 && in_features >= 8 && in_features <= 192 && (in_features & 7) == 0 && out_features >= 1 && out_features <= 192)) return 0;
+    const int ks = (in_features + 31) / 32, nt = (out_features + 15) / 16;
+    const int ks_i = ks <= 4 ? ks : 6, nt_i = nt <= 1 ? 1 : (nt <= 2 ? 2 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 12)));   // instantiated sizes
+    return ks_i * nt_i <= 32;                                // W fragments (4 VGPRs each) must fit the register file
+}
+
+int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
+                      catan_stream_t stream) {
+    if (!x || !w || !y || !catan_linear_rows_supported(rows, in_features, out_features))
+        return fail(CATAN_EINVAL, "catan_linear_rows: bad arguments / unsupported widths (in multiple of 8 and <= 192, out <= 192, ceil(in/32)*ceil(out/16) <= 24)");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return fail(CATAN_EINVAL, "catan_linear_rows: x, w, y must be 16-byte aligned");
+    const int ks = (in_features + 31) / 32, nt = (out_features + 15) / 16;
+    switch (ks) {
+    case 1: return linrows_dispatch_nt<1>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    case 2: return linrows_dispatch_nt<2>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    case 3: return linrows_dispatch_nt<3>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    case 4: return linrows_dispatch_nt<4>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    default: return linrows_dispatch_nt<6>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    }
 }
 
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {

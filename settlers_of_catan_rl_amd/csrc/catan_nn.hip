@@ -461,4 +461,79 @@ __global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict_
             }
 }
 
+
+// ------------------------------------------------------------------------------------------------ tall-skinny linear (forward / dX)
+// y[r][n] = sum_k x[r][k] * W[n][k] (+ b[n]) for huge row counts and small widths (K = in <= 128 and a multiple of 8,
+// N = out <= 192): the per-tile / per-card layers of the net have 10^6 rows and 16..192 columns, where a library GEMM reaches
+// ~40 % of the HBM roofline.  Rows are split over the grid; a wave owns 16-row tiles: its A fragments (8 consecutive k of a
+// row) are 16 B global loads straight from x, the whole W sits in B-fragment registers for the kernel's lifetime
+// (v_mfma_f32_16x16x32_bf16), and the 16 x N result goes through a small LDS tile so that it leaves as 16 B row stores.
+// HBM-bound by construction: R x (K + N) x 2 B moved once.  bf16 in / out, fp32 accumulate; bias optional.
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void k_linear_rows(const unsigned short* __restrict__ x, const unsigned short* __restrict__ W,
+                                                     const unsigned short* __restrict__ bias, unsigned short* __restrict__ y,
+                                                     long R, int K, int N) {
+    constexpr int NP = NT * 16 + 8;                              // LDS row pitch (elements): 16 B aligned, conflict-light
+    __shared__ __attribute__((aligned(16))) unsigned short ot[4][16 * NP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lr = lane & 15, lk = (lane >> 4) * 8;
+    // B fragments: lane holds W[n = nt*16 + lr][k = ks*32 + lk .. +7] (zero beyond N / K)
+    bf16x8_t bfrag[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            const int n = nt * 16 + lr, k = ks * 32 + lk;
+            if (n < N && k < K) u = *reinterpret_cast<const uint4*>(W + (long)n * K + k);
+            bfrag[nt][ks] = *reinterpret_cast<const bf16x8_t*>(&u);
+        }
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int n = nt * 16 + lr;
+        bv[nt] = (bias != nullptr && n < N) ? __uint_as_float((unsigned)bias[n] << 16) : 0.0f;
+    }
+    const long tiles = (R + 15) / 16;
+    for (long t = (long)blockIdx.x * 4 + wv; t < tiles; t += (long)gridDim.x * 4) {
+        const long r0 = t * 16;
+        f32x4_t acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            const int k = ks * 32 + lk;
+            if (r0 + lr < R && k < K) u = *reinterpret_cast<const uint4*>(x + (r0 + lr) * (long)K + k);
+            const bf16x8_t afrag = *reinterpret_cast<const bf16x8_t*>(&u);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[nt][ks], acc[nt], 0, 0, 0);
+        }
+        // C layout: lane holds rows 4*(lane>>4)+r (r = 0..3), column lane&15 of every n-tile
+        unsigned short* o = ot[wv];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const __hip_bfloat16 h = __float2bfloat16(acc[nt][r] + bv[nt]);
+                o[(4 * (lane >> 4) + r) * NP + nt * 16 + lr] = *reinterpret_cast<const unsigned short*>(&h);
+            }
+        __builtin_amdgcn_wave_barrier();
+        // row stores: 16 rows x N elements; 8-element (16 B) chunks where the row pitch allows, else element-wise
+        if ((N & 7) == 0) {
+            const int cpr = N / 8;                               // chunks per row
+            for (int c = lane; c < 16 * cpr; c += 64) {
+                const int row = c / cpr, ch = c - row * cpr;
+                if (r0 + row < R) *reinterpret_cast<uint4*>(y + (r0 + row) * (long)N + ch * 8) = *reinterpret_cast<const uint4*>(o + row * NP + ch * 8);
+            }
+        } else {
+            for (int c = lane; c < 16 * N; c += 64) {
+                const int row = c / N, col = c - row * N;
+                if (r0 + row < R) y[(r0 + row) * (long)N + col] = o[row * NP + col];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace catan

@@ -41,8 +41,12 @@ def _ortho_linear(i, o, gain=math.sqrt(2)):
 def _lin(x, w, b=None):
     """F.linear; tall-skinny shapes (huge row count, small widths) take the path whose weight gradient is the hand-written
     MFMA kernel (nn_kernels.linear) when training - as library GEMMs those gradients were 40 % of a step."""
-    if torch.is_grad_enabled() and nn_kernels.linear_supported(x, w):
-        return nn_kernels.linear(x, w, b)
+    if nn_kernels.linear_supported(x, w):
+        if torch.is_grad_enabled():
+            return nn_kernels.linear(x, w, b)
+        y = nn_kernels.linear_inference(x, w, b)          # inference: the forward kernel alone (10^6-row layers)
+        if y is not None:
+            return y
     return F.linear(x, w, b)
 
 

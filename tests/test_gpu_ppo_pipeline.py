@@ -240,3 +240,24 @@ def test_evaluation_protocol_on_device(hip_lib):
     assert 400 < r["avg_game_length"] <= 401.0001 or r["policy_win_frac"] > 0      # capped games stop right after step 401
     assert 0 < r["avg_policy_decisions"] < r["avg_game_length"] and 0 <= r["avg_victory_points"] <= 12
     assert "EVALUATION (after 3 updates)" in summary
+
+
+@pytest.mark.parametrize("R,K,N,bias", [(100003, 64, 192, True), (70000, 64, 25, True), (33333, 128, 64, False), (50001, 16, 48, True),
+                                        (4099, 48, 16, False), (17, 64, 64, True), (65536, 128, 128, True), (20000, 8, 16, True)])
+def test_linear_rows_kernel_vs_torch(hip_lib, R, K, N, bias):
+    """k_linear_rows (MFMA, rows split over the grid, W in registers) against fp32 torch on the same bf16 inputs; asymmetric
+    data, ragged row tails, partial k-steps and n-tiles."""
+    import ctypes as C
+    from settlers_of_catan_rl_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(R + K + N)
+    x = (torch.randn((R, K), device="cuda", generator=g) * torch.linspace(0.5, 2.0, K, device="cuda")).to(torch.bfloat16)
+    w = (torch.randn((N, K), device="cuda", generator=g) * 0.3 + torch.linspace(-0.2, 0.2, N, device="cuda")[:, None]).to(torch.bfloat16)
+    b = (torch.randn((N,), device="cuda", generator=g)).to(torch.bfloat16) if bias else None
+    y = torch.empty((R, N), device="cuda", dtype=torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.catan_linear_rows_supported(R, K, N)
+    _lib.check(L.catan_linear_rows(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()) if bias else None,
+                                   C.c_void_p(y.data_ptr()), R, K, N, st))
+    ref = x.float() @ w.float().t() + (b.float() if bias else 0.0)
+    assert torch.allclose(y.float(), ref, atol=2e-2 * float(ref.abs().max()) / 4 + 1e-2, rtol=1e-2)
