@@ -165,3 +165,20 @@ def linear_supported(x, w):
 def linear(x, w, b=None):
     """Linear layer for tall-skinny shapes (see linear_supported); same values as F.linear under bf16 autocast."""
     return _LinearTallSkinny.apply(x, w, b)
+
+
+def use_tuned_gemms():
+    """Library GEMMs with the solutions PyTorch TunableOp found for this net's shapes on gfx950 (tools/tune_gemms.py ->
+    tunableop_gfx950.csv: rocBLAS / hipBLASLt solution indices per (transposes, m, n, k) at the rollout, minibatch and value-
+    chunk widths).  Tuning itself stays off: shapes that are not in the file use the library default.  The file carries
+    the library versions it was made with; TunableOp ignores it when they differ."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+    if not (torch.cuda.is_available() and os.path.exists(path)):
+        return False
+    import torch.cuda.tunable as tun
+    tun.enable(True)
+    tun.tuning_enable(False)
+    tun.write_file_on_exit(False)
+    tun.set_filename(path)
+    return True

@@ -40,6 +40,9 @@ class PPOTrainer(object):
     def __init__(self, policy, cfg=None, autocast_dtype=torch.bfloat16, seed=0):
         self.policy, self.cfg = policy, cfg or PPOConfig()
         self.autocast_dtype = autocast_dtype
+        if next(policy.parameters()).is_cuda:
+            from . import nn_kernels
+            nn_kernels.use_tuned_gemms()           # library GEMMs: tuned solution per shape (tunableop_gfx950.csv)
         self.optimiser = torch.optim.Adam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)   # ppo.py:23
         dev = next(policy.parameters()).device
         self.gen = torch.Generator(device=dev).manual_seed(seed + 17 * (1 + (torch.distributed.get_rank()
