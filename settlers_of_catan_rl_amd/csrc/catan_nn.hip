@@ -21,10 +21,40 @@ template <class T> __device__ __forceinline__ void st_f(T* p, float v);
 template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
 
+// LDS rows are kept in the storage type (bf16 inputs: half the LDS, twice the blocks per CU) with a 16 B aligned pitch; a head
+// slice (HD = 4 or 16 consecutive elements) is fetched with 8 / 16 B LDS reads and widened in registers.
+template <class T> struct LdsRow;
+template <> struct LdsRow<float> {
+    static constexpr int PAD = 4;
+    template <int HD> static __device__ __forceinline__ void load(const float* p, float (&v)[HD]) {
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) { const float4 u = *reinterpret_cast<const float4*>(p + d); v[d] = u.x; v[d + 1] = u.y; v[d + 2] = u.z; v[d + 3] = u.w; }
+    }
+};
+template <> struct LdsRow<__hip_bfloat16> {
+    static constexpr int PAD = 8;
+    template <int HD> static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[HD]) {
+        if constexpr (HD == 4) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; d += 8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(p + d);
+                const unsigned w[4] = { u.x, u.y, u.z, u.w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) { v[d + 2 * k] = __uint_as_float(w[k] << 16); v[d + 2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u); }
+            }
+        }
+    }
+};
+
 template <class T, int L, int H, int HD>
 __global__ __launch_bounds__(64) void k_attn_fwd(const T* __restrict__ qkv, const int* __restrict__ lens, T* __restrict__ out, long B) {
     constexpr int G = 64 / L, D = H * HD;
-    __shared__ __attribute__((aligned(16))) float Ks[G][L][D + 4], Vs[G][L][D + 4];   // 16 B aligned rows: a head slice is read with ds_read_b128
+    constexpr int P = D + LdsRow<float>::PAD;              // forward: fp32 rows (half-width rows measured slower here)
+    __shared__ __attribute__((aligned(16))) float Ks[G][L][P], Vs[G][L][P];
     const int lane = threadIdx.x, g = lane / L, i = lane % L;
     const long b0 = (long)blockIdx.x * G;
     // stage K, V (coalesced over the contiguous [L][3][D] block of each sequence)
@@ -52,9 +82,11 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const T* __restrict__ qkv, cons
         float s[L], mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < L; j++) {
+            float kr[HD];
+            LdsRow<float>::template load<HD>(&Ks[g][j][h * HD], kr);
             float a = 0.0f;
 #pragma unroll
-            for (int d = 0; d < HD; d++) a += q[d] * Ks[g][j][h * HD + d];
+            for (int d = 0; d < HD; d++) a += q[d] * kr[d];
             s[j] = j < len ? a : -INFINITY;
             mx = fmaxf(mx, s[j]);
         }
@@ -68,8 +100,10 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const T* __restrict__ qkv, cons
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const float p = s[j] * inv;
+            float vr[HD];
+            LdsRow<float>::template load<HD>(&Vs[g][j][h * HD], vr);
 #pragma unroll
-            for (int d = 0; d < HD; d++) o[d] += p * Vs[g][j][h * HD + d];
+            for (int d = 0; d < HD; d++) o[d] += p * vr[d];
         }
 #pragma unroll
         for (int d = 0; d < HD; d++) st_f(op + h * HD + d, o[d]);
@@ -81,7 +115,8 @@ template <class T, int L, int H, int HD>
 __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, const int* __restrict__ lens, const T* __restrict__ dout,
                                                  T* __restrict__ dqkv, long B) {
     constexpr int G = 64 / L, D = H * HD;
-    __shared__ __attribute__((aligned(16))) float Qs[G][L][D + 4], Ks[G][L][D + 4], Vs[G][L][D + 4], Os[G][L][D + 4];   // 16 B aligned rows
+    constexpr int P = D + LdsRow<T>::PAD;
+    __shared__ __attribute__((aligned(16))) T Qs[G][L][P], Ks[G][L][P], Vs[G][L][P], Os[G][L][P];
     __shared__ float Ps[G][L][L + 1], Ss[G][L][L + 1];
     const int lane = threadIdx.x, g = lane / L, i = lane % L;
     const long b0 = (long)blockIdx.x * G;
@@ -92,10 +127,10 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, cons
         const T* dob = dout + b * (long)(L * D);
         for (int x = lane; x < L * D; x += 64) {
             const int l = x / D, d = x % D;
-            Qs[gg][l][d] = ld_f(base + (l * 3 + 0) * D + d);
-            Ks[gg][l][d] = ld_f(base + (l * 3 + 1) * D + d);
-            Vs[gg][l][d] = ld_f(base + (l * 3 + 2) * D + d);
-            Os[gg][l][d] = ld_f(dob + l * D + d);
+            Qs[gg][l][d] = base[(l * 3 + 0) * D + d];
+            Ks[gg][l][d] = base[(l * 3 + 1) * D + d];
+            Vs[gg][l][d] = base[(l * 3 + 2) * D + d];
+            Os[gg][l][d] = dob[l * D + d];
         }
     }
     __syncthreads();
@@ -107,11 +142,16 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, cons
     for (int h = 0; h < H; h++) {
         if (act) {
             float s[L], mx = -INFINITY;
+            float qi[HD], oi[HD];
+            LdsRow<T>::template load<HD>(&Qs[g][i][h * HD], qi);
+            LdsRow<T>::template load<HD>(&Os[g][i][h * HD], oi);
 #pragma unroll
             for (int j = 0; j < L; j++) {
+                float kr[HD];
+                LdsRow<T>::template load<HD>(&Ks[g][j][h * HD], kr);
                 float a = 0.0f;
 #pragma unroll
-                for (int d = 0; d < HD; d++) a += Qs[g][i][h * HD + d] * Ks[g][j][h * HD + d];
+                for (int d = 0; d < HD; d++) a += qi[d] * kr[d];
                 s[j] = j < len ? a * scale : -INFINITY;
                 mx = fmaxf(mx, s[j]);
             }
@@ -123,9 +163,11 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, cons
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 s[j] *= inv;
+                float vr[HD];
+                LdsRow<T>::template load<HD>(&Vs[g][j][h * HD], vr);
                 float a = 0.0f;
 #pragma unroll
-                for (int d = 0; d < HD; d++) a += Os[g][i][h * HD + d] * Vs[g][j][h * HD + d];
+                for (int d = 0; d < HD; d++) a += oi[d] * vr[d];
                 dP[j] = a;
                 delta += s[j] * a;
             }
@@ -137,8 +179,10 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, cons
                 const float ds = s[j] * (dP[j] - delta) * scale;       // d(scores)/ ... includes the 1/sqrt(hd)
                 Ps[g][i][j] = s[j];
                 Ss[g][i][j] = ds;
+                float kr[HD];
+                LdsRow<T>::template load<HD>(&Ks[g][j][h * HD], kr);
 #pragma unroll
-                for (int d = 0; d < HD; d++) dq[d] += ds * Ks[g][j][h * HD + d];
+                for (int d = 0; d < HD; d++) dq[d] += ds * kr[d];
             }
 #pragma unroll
             for (int d = 0; d < HD; d++) st_f(dp + 0 * D + h * HD + d, dq[d]);
@@ -151,8 +195,11 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const T* __restrict__ qkv, cons
 #pragma unroll
             for (int r = 0; r < L; r++) {
                 const float ds = Ss[g][r][i], p = Ps[g][r][i];
+                float qr[HD], orow[HD];
+                LdsRow<T>::template load<HD>(&Qs[g][r][h * HD], qr);
+                LdsRow<T>::template load<HD>(&Os[g][r][h * HD], orow);
 #pragma unroll
-                for (int d = 0; d < HD; d++) { dk[d] += ds * Qs[g][r][h * HD + d]; dv[d] += p * Os[g][r][h * HD + d]; }
+                for (int d = 0; d < HD; d++) { dk[d] += ds * qr[d]; dv[d] += p * orow[d]; }
             }
 #pragma unroll
             for (int d = 0; d < HD; d++) { st_f(dp + 1 * D + h * HD + d, dk[d]); st_f(dp + 2 * D + h * HD + d, dv[d]); }
