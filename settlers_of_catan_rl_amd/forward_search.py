@@ -394,6 +394,9 @@ class ForwardSearch(object):
         self.rngs = [_py_random.Random(seed * 1000003 + i) for i in range(n_roots)]
         self.gen = None
         self.autocast_dtype = autocast_dtype
+        if torch.cuda.is_available() and next(policy.parameters()).is_cuda:
+            from . import nn_kernels
+            nn_kernels.use_tuned_gemms()
         self.graphed = GraphedAct(policy, autocast_dtype=autocast_dtype) if use_graphs else None
         self.sims_run = 0
         self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]

@@ -56,6 +56,9 @@ class RolloutCollector(object):
         every seat plays the central policy).  A league (league.League.assign) installs per-game opponents instead."""
         self.env, self.policy, self.T = env, policy, num_steps
         self.N, self.device = env.n, env.device
+        if torch.device(self.device).type == "cuda":
+            from . import nn_kernels
+            nn_kernels.use_tuned_gemms()
         self.opponent_nets, self.opp_index = [], None
         if opponents:
             nets = list(opponents)
