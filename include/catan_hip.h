@@ -188,6 +188,18 @@ int catan_linear_rows_supported(int64_t rows, int in_features, int out_features)
 int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
                       catan_stream_t stream);
 
+/* One step of the optional LSTM policy (`include_lstm`, RL/models/policy.py:36-45,113-166: torch.nn.LSTM(512, 256), gate
+ * order i, f, g, o): the arithmetic between the step's two GEMMs.  gx = x W_ih^T + b_ih + b_hh and gh = (h_prev*mask) W_hh^T,
+ * both [rows][4*hidden] (fp32 or bf16); c_prev, h_out, c_out, dh, dc, dc_prev fp32 [rows][hidden]; mask fp32 [rows] or NULL
+ * (the terminal mask that multiplies the incoming cell state, policy.py:119,149).
+ *   c = sigmoid(f) * (c_prev * mask) + sigmoid(i) * tanh(g);  h = sigmoid(o) * tanh(c)
+ * The backward recomputes the activations and writes the gradient of the pre-activation gates (= gradient of gx and of gh)
+ * in the dtype of gx, and dc_prev.  hidden must be a multiple of 4, all buffers 16-byte aligned. */
+int catan_lstm_cell_fwd(const void* gx, const void* gh, const float* c_prev, const float* mask, float* h_out, float* c_out, int64_t rows,
+                        int hidden, int is_bf16, catan_stream_t stream);
+int catan_lstm_cell_bwd(const void* gx, const void* gh, const float* c_prev, const float* mask, const float* dh, const float* dc, void* dgates,
+                        float* dc_prev, int64_t rows, int hidden, int is_bf16, catan_stream_t stream);
+
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);

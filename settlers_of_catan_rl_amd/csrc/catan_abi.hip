@@ -111,6 +111,17 @@ static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, 
     }
 }
 
+template <class T>
+static int lstm_cell_launch(bool bwd, const void* gx, const void* gh, const float* c_prev, const float* mask, const float* dh, const float* dc,
+                            void* o0, float* o1, long n, int L, hipStream_t st) {
+    long nb = (n * (L / 4) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (!bwd) hipLaunchKernelGGL((k_lstm_cell_fwd<T>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)gx, (const T*)gh, c_prev, mask, (float*)o0, o1, n, L);
+    else hipLaunchKernelGGL((k_lstm_cell_bwd<T>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)gx, (const T*)gh, c_prev, mask, dh, dc, (T*)o0, o1, n, L);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 template <int OTW, int IT>
 static int wgrad_launch(const void* x, const void* dy, float* dw, float* db, long R, int I, int O, hipStream_t st) {
     long stages = (R + WG_KT - 1) / WG_KT;
@@ -708,6 +719,26 @@ int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, i
     case 4: return linrows_dispatch_nt<4>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
     default: return linrows_dispatch_nt<6>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
     }
+}
+
+int catan_lstm_cell_fwd(const void* gx, const void* gh, const float* c_prev, const float* mask, float* h_out, float* c_out, int64_t rows,
+                        int hidden, int is_bf16, catan_stream_t stream) {
+    if (!gx || !gh || !c_prev || !h_out || !c_out || rows <= 0 || hidden <= 0 || (hidden & 3))
+        return fail(CATAN_EINVAL, "catan_lstm_cell_fwd: bad arguments (hidden must be a multiple of 4)");
+    if (((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)c_prev | (uintptr_t)h_out | (uintptr_t)c_out) & 15)
+        return fail(CATAN_EINVAL, "catan_lstm_cell_fwd: buffers must be 16-byte aligned");
+    return is_bf16 ? lstm_cell_launch<__hip_bfloat16>(false, gx, gh, c_prev, mask, nullptr, nullptr, h_out, c_out, rows, hidden, S(stream))
+                   : lstm_cell_launch<float>(false, gx, gh, c_prev, mask, nullptr, nullptr, h_out, c_out, rows, hidden, S(stream));
+}
+
+int catan_lstm_cell_bwd(const void* gx, const void* gh, const float* c_prev, const float* mask, const float* dh, const float* dc, void* dgates,
+                        float* dc_prev, int64_t rows, int hidden, int is_bf16, catan_stream_t stream) {
+    if (!gx || !gh || !c_prev || !dh || !dc || !dgates || !dc_prev || rows <= 0 || hidden <= 0 || (hidden & 3))
+        return fail(CATAN_EINVAL, "catan_lstm_cell_bwd: bad arguments (hidden must be a multiple of 4)");
+    if (((uintptr_t)gx | (uintptr_t)gh | (uintptr_t)c_prev | (uintptr_t)dh | (uintptr_t)dc | (uintptr_t)dgates | (uintptr_t)dc_prev) & 15)
+        return fail(CATAN_EINVAL, "catan_lstm_cell_bwd: buffers must be 16-byte aligned");
+    return is_bf16 ? lstm_cell_launch<__hip_bfloat16>(true, gx, gh, c_prev, mask, dh, dc, dgates, dc_prev, rows, hidden, S(stream))
+                   : lstm_cell_launch<float>(true, gx, gh, c_prev, mask, dh, dc, dgates, dc_prev, rows, hidden, S(stream));
 }
 
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {

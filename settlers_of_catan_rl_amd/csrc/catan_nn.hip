@@ -583,4 +583,89 @@ __global__ __launch_bounds__(256) void k_linear_rows(const unsigned short* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LSTM cell (the optional `include_lstm` path: RL/models/policy.py:36-45,113-166 uses torch.nn.LSTM, gate order i, f, g, o).
+// The two GEMMs of a step (x W_ih^T over all steps at once, h W_hh^T per step) stay library GEMMs; everything between them
+// is this one pass: gates = gx + gh, c = sigmoid(f) * (c_prev * mask) + sigmoid(i) * tanh(g), h = sigmoid(o) * tanh(c).
+// A thread owns 4 consecutive hidden units of one row: four 8 B (bf16) / 16 B (fp32) loads per gate tensor, all coalesced.
+// HBM-bound: (2 * 4L * sizeof(T) + 3 * 4L) bytes per row forward.  The backward recomputes the activations from the same
+// inputs and writes the pre-activation gate gradient (it is the gradient of gx and of gh alike) and dc_prev.
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+
+template <class T>
+__global__ __launch_bounds__(256) void k_lstm_cell_fwd(const T* __restrict__ gx, const T* __restrict__ gh, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ mask, float* __restrict__ h_out,
+                                                       float* __restrict__ c_out, long n, int L) {
+    const int q = L / 4;
+    const long items = n * q;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long row = it / q;
+        const int j = (int)(it - row * q) * 4;
+        const T* px = gx + row * 4 * L + j;
+        const T* ph = gh + row * 4 * L + j;
+        float a[4][4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            RowVec<T, 4>::load(px + k * L, a[k]);
+            RowVec<T, 4>::load(ph + k * L, b);
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[k][e] += b[e];
+        }
+        float cp[4], h[4], c[4];
+        RowVec<float, 4>::load(c_prev + row * L + j, cp);
+        const float mm = mask ? mask[row] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            c[e] = sigmoid_f(a[1][e]) * (cp[e] * mm) + sigmoid_f(a[0][e]) * tanh_f(a[2][e]);
+            h[e] = sigmoid_f(a[3][e]) * tanh_f(c[e]);
+        }
+        RowVec<float, 4>::store(c_out + row * L + j, c);
+        RowVec<float, 4>::store(h_out + row * L + j, h);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_lstm_cell_bwd(const T* __restrict__ gx, const T* __restrict__ gh, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ mask, const float* __restrict__ dh,
+                                                       const float* __restrict__ dc_out, T* __restrict__ dgates,
+                                                       float* __restrict__ dc_prev, long n, int L) {
+    const int q = L / 4;
+    const long items = n * q;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long row = it / q;
+        const int j = (int)(it - row * q) * 4;
+        const T* px = gx + row * 4 * L + j;
+        const T* ph = gh + row * 4 * L + j;
+        float a[4][4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            RowVec<T, 4>::load(px + k * L, a[k]);
+            RowVec<T, 4>::load(ph + k * L, b);
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[k][e] += b[e];
+        }
+        float cp[4], gh_[4], gc[4], dcp[4];
+        RowVec<float, 4>::load(c_prev + row * L + j, cp);
+        RowVec<float, 4>::load(dh + row * L + j, gh_);
+        RowVec<float, 4>::load(dc_out + row * L + j, gc);
+        const float mm = mask ? mask[row] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float i = sigmoid_f(a[0][e]), f = sigmoid_f(a[1][e]), g = tanh_f(a[2][e]), o = sigmoid_f(a[3][e]);
+            const float cin = cp[e] * mm;
+            const float tc = tanh_f(f * cin + i * g);
+            const float dc = gc[e] + gh_[e] * o * (1.0f - tc * tc);
+            a[0][e] = dc * g * i * (1.0f - i);
+            a[1][e] = dc * cin * f * (1.0f - f);
+            a[2][e] = dc * i * (1.0f - g * g);
+            a[3][e] = gh_[e] * tc * o * (1.0f - o);
+            dcp[e] = dc * f * mm;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) RowVec<T, 4>::store(dgates + row * 4 * L + j + k * L, a[k]);
+        RowVec<float, 4>::store(dc_prev + row * L + j, dcp);
+    }
+}
+
 }  // namespace catan

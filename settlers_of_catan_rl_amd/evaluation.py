@@ -49,6 +49,10 @@ def run_evaluation_episodes(env, nets, orders, max_steps=None, deterministic=Fal
     decisions = torch.zeros(n, dtype=torch.long, device=dev)
     running = torch.ones(n, dtype=torch.bool, device=dev)
     draw = torch.zeros(n, dtype=torch.bool, device=dev)
+    # LSTM policies: one (h, c) per seat, zero at the start of the game (evaluation_manager.py:20-26,50-59); a net without
+    # an LSTM ignores its seats' entries.  The terminal mask stays 1: a finished evaluation game takes no further step.
+    sizes = [int(net.lstm_size) for net in distinct if getattr(net, "include_lstm", False)]
+    hid = torch.zeros((2, n, 4, max(sizes)), dtype=torch.float32, device=dev) if sizes else None
     while bool(running.any()):
         deciding = env.deciding_player().long()
         pol = policy_of_pid[ar, deciding - 1]
@@ -64,12 +68,19 @@ def run_evaluation_episodes(env, nets, orders, max_steps=None, deterministic=Fal
             if act_fn is not None:
                 actions[idx] = act_fn(net, idx, *args)
                 continue
+            kw = {"deterministic": deterministic, "generator": generator}
+            rec = getattr(net, "include_lstm", False)
+            if rec:
+                L, seat = int(net.lstm_size), deciding[idx] - 1
+                kw.update(hidden=(hid[0, idx, seat, :L], hid[1, idx, seat, :L]), nonterminal=torch.ones(idx.numel(), device=dev))
             if autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=autocast_dtype):
-                    _, a, _ = net.act(*args, deterministic=deterministic, generator=generator)
+                    res = net.act(*args, **kw)
             else:
-                _, a, _ = net.act(*args, deterministic=deterministic, generator=generator)
-            actions[idx] = a
+                res = net.act(*args, **kw)
+            actions[idx] = res[1]
+            if rec:
+                hid[0, idx, seat, :L], hid[1, idx, seat, :L] = res[3][0].float(), res[3][1].float()
         a_env = actions.to(torch.int32)
         a_env[:, 0] = torch.where(running, a_env[:, 0], torch.full_like(a_env[:, 0], -1))
         _, done = env.step(a_env)

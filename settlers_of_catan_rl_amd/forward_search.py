@@ -385,6 +385,10 @@ class ForwardSearch(object):
     def __init__(self, policy, make_sim_env, n_roots, max_init_actions=10, max_depth=20, gamma=0.999, sims_per_root=64,
                  sims_per_round=16, consider_all_moves_for_opening_placement=False, seed=0, autocast_dtype=None, use_graphs=False):
         assert sims_per_root % sims_per_round == 0
+        if getattr(policy, "include_lstm", False):
+            # the reference threads (h, c) of every seat through proposals and simulations (forward_search_policy/policy.py:72-106,
+            # zero_opponent_hidden_states); that is not restated here - refuse instead of searching with stale states
+            raise NotImplementedError("ForwardSearch does not carry LSTM states; use a feed-forward CatanPolicy")
         self.policy, self.R = policy, n_roots
         self.max_init_actions, self.max_depth, self.gamma = max_init_actions, max_depth, gamma
         self.S, self.K = sims_per_root, sims_per_round

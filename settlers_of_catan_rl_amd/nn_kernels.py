@@ -181,3 +181,41 @@ def use_tuned_gemms():
     tun.tuning_enable(False)
     tun.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "catan_tunableop_unused.csv"))   # never write into the package
     return bool(tun.read_file(path))
+
+
+class _LSTMCell(torch.autograd.Function):
+    """One LSTM step between its two GEMMs (csrc/catan_nn.hip k_lstm_cell_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, gx, gh, c_prev, mask):
+        n, L = c_prev.shape
+        gx, gh, c_prev = _aligned(gx), _aligned(gh), _aligned(c_prev)
+        mask = None if mask is None else mask.contiguous()
+        h = torch.empty((n, L), dtype=torch.float32, device=gx.device)
+        c = torch.empty_like(h)
+        _lib.check(_lib.lib().catan_lstm_cell_fwd(_ptr(gx), _ptr(gh), _ptr(c_prev), _ptr(mask), _ptr(h), _ptr(c), n, L,
+                                                  int(gx.dtype == torch.bfloat16), _stream()))
+        ctx.save_for_backward(gx, gh, c_prev, mask)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gx, gh, c_prev, mask = ctx.saved_tensors
+        n, L = c_prev.shape
+        dh, dc = _aligned(dh.float()), _aligned(dc.float())
+        dg = torch.empty_like(gx)
+        dcp = torch.empty_like(c_prev)
+        _lib.check(_lib.lib().catan_lstm_cell_bwd(_ptr(gx), _ptr(gh), _ptr(c_prev), _ptr(mask), _ptr(dh), _ptr(dc), _ptr(dg), _ptr(dcp),
+                                                  n, L, int(gx.dtype == torch.bfloat16), _stream()))
+        return dg, dg, dcp, None
+
+
+def lstm_cell_supported(gx, c_prev):
+    return gx.is_cuda and gx.dtype in (torch.float32, torch.bfloat16) and c_prev.dtype == torch.float32 and c_prev.shape[-1] % 4 == 0
+
+
+def lstm_cell(gx, gh, c_prev, mask=None):
+    """gx, gh [n, 4L] (same dtype, fp32 or bf16; gate order i, f, g, o), c_prev fp32 [n, L], mask fp32 [n] or None
+    -> (h, c) fp32 [n, L] with c = sigmoid(f) * (c_prev * mask) + sigmoid(i) * tanh(g), h = sigmoid(o) * tanh(c)."""
+    assert gx.shape == gh.shape and gx.dtype == gh.dtype and gx.shape[-1] == 4 * c_prev.shape[-1]
+    return _LSTMCell.apply(gx, gh, c_prev, None if mask is None else mask.float().reshape(-1))

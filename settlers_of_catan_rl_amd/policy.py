@@ -253,9 +253,8 @@ def _choose(logp, given, deterministic, generator):
 
 
 class _ActionHeads(nn.Module):
-    def __init__(self):
+    def __init__(self, D=512):
         super().__init__()
-        D = 512
         self.action_heads = nn.ModuleList([
             _Head(D, 13), _Head(D + 2, 54), _Head(D, 73), _Head(D, 19), _Head(D, 5),
             _Head(D, 2, custom_in=12, custom_out=32), _Head(D + 2, 3), _Head(D + 6, 6), _Head(D + 6 + 6, 6),
@@ -290,7 +289,7 @@ class _ActionHeads(nn.Module):
         return out, torch.stack(chosen, 1), logp_sum, ent_sum
 
     def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None):
-        """main [B,512]; masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.
+        """main [B,512] (+ lstm_size with the LSTM); masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.
         forced_type int64 [B] or None: rows with a value >= 0 take that action type instead of sampling the type head
         (`condition_on_action_type`, action_heads_module.py:37-48: the type head is skipped, its output is the one-hot).
         -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
@@ -358,50 +357,111 @@ class _ActionHeads(nn.Module):
 
 
 class CatanPolicy(nn.Module):
-    """SettlersAgentPolicy (RL/models/policy.py:12-111) for flat batched inputs."""
+    """SettlersAgentPolicy (RL/models/policy.py:12-111) for flat batched inputs.
+
+    include_lstm (off in the reference's defaults, build_agent_model.py:26): a one-layer LSTM(512 -> lstm_size) over each
+    seat's successive decisions; its output is concatenated to the 512-wide trunk for the value MLP and every action head
+    (policy.py:36-45,59-66).  `hidden` = (h, c), each [rows, lstm_size]; `nonterminal` [rows] or [rows,1] multiplies the
+    incoming state (policy.py:113-166)."""
 
     VALUE_MEAN, VALUE_STD = 150.0, 150.0          # ValueFunctionNormaliser(mean=150, std=150), policy.py:23
-    include_lstm = False
     use_value_normalisation = True
 
-    def __init__(self):
+    def __init__(self, include_lstm=False, lstm_size=256):
         super().__init__()
+        self.include_lstm, self.lstm_size = bool(include_lstm), int(lstm_size)
         self.observation_module = _ObservationModule()
-        self.action_head_module = _ActionHeads()
-        self.value_network_fc_1 = nn.Linear(512, 256)
+        D = 512
+        if self.include_lstm:
+            self.lstm = nn.LSTM(num_layers=1, hidden_size=self.lstm_size, input_size=D, batch_first=False)   # policy.py:38-43
+            for name, prm in self.lstm.named_parameters():
+                if "bias" in name:
+                    nn.init.zeros_(prm)
+                else:
+                    nn.init.orthogonal_(prm)
+            D += self.lstm_size
+        self.action_head_module = _ActionHeads(D)
+        self.value_network_fc_1 = nn.Linear(D, 256)
         self.value_network_fc_2 = nn.Linear(256, 128)
         self.value_out = nn.Linear(128, 1)
         self.v_norm_1 = nn.LayerNorm(256)
         self.v_norm_2 = nn.LayerNorm(128)
 
     # ---- pieces
-    def base(self, obs_f, lists, lens):
+    def initial_hidden(self, rows, device=None):
+        """The zero state a seat starts a game with (game_manager.py:54-59,121-124)."""
+        dev = self.value_out.weight.device if device is None else device
+        return (torch.zeros(rows, self.lstm_size, device=dev), torch.zeros(rows, self.lstm_size, device=dev))
+
+    def _forward_lstm(self, x, hidden, nonterminal):
+        """`_forward_lstm` (policy.py:113-166).  x [R,512]; hidden (h, c) with R rows -> one step per row; with B < R rows
+        -> x is T = R/B steps of B sequences, time-major (row t*B + b), and the state entering step t is multiplied by
+        nonterminal[t*B + b].  (The reference runs the stretches between zero masks through one nn.LSTM call each and
+        multiplies by the mask at their first step only: the same recurrence, since the other masks are 1.)
+        The input projection of all steps is one GEMM; the recurrence is h @ W_hh^T plus the gate arithmetic per step."""
+        h, c = hidden
+        L = self.lstm_size
+        R, B = x.shape[0], h.shape[0]
+        if R % B != 0:
+            raise ValueError(f"LSTM input rows ({R}) are not a multiple of the hidden-state rows ({B})")
+        T = R // B
+        m = nonterminal.reshape(T, B, 1).to(torch.float32)
+        w_ih, w_hh = self.lstm.weight_ih_l0, self.lstm.weight_hh_l0
+        gx = F.linear(x, w_ih, self.lstm.bias_ih_l0 + self.lstm.bias_hh_l0).reshape(T, B, 4 * L)
+        h, c = h.float(), c.float()
+        outs = []
+        fused = nn_kernels.lstm_cell_supported(gx, c)            # GPU: the gate arithmetic of a step is one HIP kernel
+        gxs = gx.unbind(0)                                       # (one stack in the backward instead of T zero-padded slices)
+        for t in range(T):
+            h = h * m[t]
+            gh = F.linear(h.to(x.dtype), w_hh)
+            if fused:
+                h, c = nn_kernels.lstm_cell(gxs[t], gh.to(gx.dtype), c, m[t])
+            else:
+                g = gxs[t].float() + gh.float()
+                i, f, gg, o = g[:, :L], g[:, L:2 * L], g[:, 2 * L:3 * L], g[:, 3 * L:]    # torch.nn.LSTM gate order i, f, g, o
+                c = torch.sigmoid(f) * (c * m[t]) + torch.sigmoid(i) * torch.tanh(gg)
+                h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        out = outs[0] if T == 1 else torch.stack(outs, 0).reshape(R, L)
+        return out.to(x.dtype), (h, c)
+
+    def base(self, obs_f, lists, lens, hidden=None, nonterminal=None):
+        """-> (value [B,1] fp32, main [B,512(+lstm_size)], hidden or None)   (policy.py:59-66)"""
         main = self.observation_module(obs_f, lists, lens)
+        if self.include_lstm:
+            if hidden is None:
+                raise ValueError("include_lstm: hidden=(h, c) and nonterminal are required")
+            if nonterminal is None:
+                nonterminal = torch.ones(main.shape[0], device=main.device)
+            out, hidden = self._forward_lstm(main, hidden, nonterminal)
+            main = torch.cat((main, out), -1)
         v = _lin(_ln(self.v_norm_2, self.value_network_fc_2(_ln(self.v_norm_1, self.value_network_fc_1(main), relu=True)), relu=True),
                  self.value_out.weight, self.value_out.bias)
-        return v.float(), main
+        return v.float(), main, hidden
 
     @staticmethod
     def _custom(obs_f):
         return obs_f[:, 12:18].float(), obs_f[:, 0:12].float()      # current_resources, proposed_trade
 
-    # ---- reference-shaped API
-    def act(self, obs_f, lists, lens, masks, deterministic=False, generator=None, condition_on_action_type=None):
+    # ---- reference-shaped API (with include_lstm the new hidden state is returned as a last extra item)
+    def act(self, obs_f, lists, lens, masks, deterministic=False, generator=None, condition_on_action_type=None,
+            hidden=None, nonterminal=None):
         """condition_on_action_type: int64 [B] (entries < 0 = free) or None (RL/models/policy.py:72-82)."""
-        value, main = self.base(obs_f, lists, lens)
+        value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal)
         cur_res, trade = self._custom(obs_f)
         actions, logp, _ = self.action_head_module(main, masks.float(), cur_res, trade, None, deterministic, generator,
                                                    forced_type=condition_on_action_type)
-        return value, actions, logp[:, None]
+        return (value, actions, logp[:, None], hidden) if self.include_lstm else (value, actions, logp[:, None])
 
-    def evaluate_actions(self, obs_f, lists, lens, masks, actions):
-        value, main = self.base(obs_f, lists, lens)
+    def evaluate_actions(self, obs_f, lists, lens, masks, actions, hidden=None, nonterminal=None):
+        value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal)
         cur_res, trade = self._custom(obs_f)
         _, logp, entropy = self.action_head_module(main, masks.float(), cur_res, trade, actions)
-        return value, logp[:, None], entropy
+        return (value, logp[:, None], entropy, hidden) if self.include_lstm else (value, logp[:, None], entropy)
 
-    def get_value(self, obs_f, lists, lens):
-        return self.base(obs_f, lists, lens)[0]
+    def get_value(self, obs_f, lists, lens, hidden=None, nonterminal=None):
+        return self.base(obs_f, lists, lens, hidden, nonterminal)[0]
 
     def denormalise(self, v):
         return self.VALUE_MEAN + v * self.VALUE_STD          # RL/models/utils.py:20-21

@@ -23,8 +23,10 @@ from . import spec
 class RolloutStorage(object):
     """The tensors `BatchProcessor` holds after `process_rollouts` (process_batch.py:37-104), device resident."""
 
-    def __init__(self, T, N, device, obs_dtype=torch.float32):
+    def __init__(self, T, N, device, obs_dtype=torch.float32, lstm_size=0):
         self.T, self.N = T, N
+        # process_batch.py:53-59: the active seat's LSTM state (h, c) entering each of its stored decisions
+        self.hidden = torch.zeros((2, T + 1, N, lstm_size), dtype=torch.float32, device=device) if lstm_size else None
         self.obs_f = torch.zeros((T + 1, N, spec.OBS_FLOATS), dtype=obs_dtype, device=device)
         self.lists = torch.zeros((T + 1, N, 5, spec.OBS_LIST_PAD), dtype=torch.int8, device=device)
         self.lens = torch.ones((T + 1, N, 5), dtype=torch.int8, device=device)
@@ -72,7 +74,9 @@ class RolloutCollector(object):
         self.policy_of_pid = self.policy_of_pid.to(self.device)
         self.active_pid = (perm[:, 0] + 1).to(self.device)                                  # PlayerId 1..4
         self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
-        self.storage = RolloutStorage(num_steps, self.N, self.device)
+        self.recurrent = bool(getattr(policy, "include_lstm", False))
+        self.lstm_size = int(policy.lstm_size) if self.recurrent else 0
+        self.storage = RolloutStorage(num_steps, self.N, self.device, lstm_size=self.lstm_size)
         self.reset()
 
     def set_opponents(self, nets, opp_index):
@@ -92,6 +96,8 @@ class RolloutCollector(object):
         self.pending_obs = self.env.deciding_player().long() == self.active_pid             # observations = [obs] iff the active seat moves first
         self.done_since = torch.zeros(N, dtype=torch.bool, device=dev)
         self.racc = torch.zeros((N, 4), dtype=torch.float32, device=dev)
+        if self.recurrent:            # game_manager.py:54-59: every seat of every game starts from the zero state
+            self.hid = torch.zeros((2, N, 4, self.lstm_size), dtype=torch.float32, device=dev)
 
     def _store_obs(self, sel, f, lists, lens):
         st = self.storage
@@ -102,6 +108,8 @@ class RolloutCollector(object):
         st.obs_f[t, idx] = f[idx].to(st.obs_f.dtype)
         st.lists[t, idx] = lists[idx].to(torch.int8)
         st.lens[t, idx] = lens[idx].to(torch.int8)
+        if self.recurrent:            # game_manager.py:55,133: the state the active seat will enter this decision with
+            st.hidden[:, t, idx] = self.hid[:, idx, self.active_pid[idx] - 1]
         self.n_obs[idx] += 1
 
     @torch.no_grad()
@@ -111,6 +119,7 @@ class RolloutCollector(object):
         ar = torch.arange(N, device=dev)
         self.racc.zero_()                        # `rewards = {...: 0}` at the start of every gather call (:76)
         self.done_since.zero_()                  # `done_since_prev_turn = [False ...]` (:77)
+        term = st.masks[0].clone()               # `terminal_mask = terminal_masks[env_num][0]` (:74-75)
         iters = 0
         while True:
             f, lists, lens = env.get_obs()
@@ -124,12 +133,13 @@ class RolloutCollector(object):
             deciding = env.deciding_player().long()                                         # :79
             masks = env.get_action_masks()                                                  # :83
             pol = self.policy_of_pid[ar, deciding - 1]
-            actions, logp = self._act(f, lists, lens, masks, pol)                           # :85
+            actions, logp = self._act(f, lists, lens, masks, pol, deciding, term, ~frozen)  # :85-89
             a_env = actions.to(torch.int32)
             a_env[:, 0] = torch.where(frozen, torch.full_like(a_env[:, 0], -1), a_env[:, 0])   # frozen games: no-op
             reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
             live = ~frozen
             done = done.bool() & live
+            term = torch.where(live, 1.0 - done.float(), term)                              # :97
             self.racc += reward * live[:, None]                                         # :94-95
             was_active = (deciding == self.active_pid) & live
             idx = was_active.nonzero(as_tuple=True)[0]                                      # :102-105
@@ -155,6 +165,8 @@ class RolloutCollector(object):
                 self.n_msk[idx] += 1
                 self.done_since[idx] = False
                 self.racc[idx] = 0.0
+                if self.recurrent:
+                    self.hid[:, idx] = 0.0                                                  # :121-124
                 st.games_complete += int(idx.numel())
             # :128-136
             add_mask = next_active & ~done & ~self.done_since
@@ -168,8 +180,10 @@ class RolloutCollector(object):
         self.iters = iters
         return st
 
-    def _act(self, f, lists, lens, masks, pol):
-        """One batched forward per distinct net in play: net 0 = central policy, net 1 + k = opponent_nets[k]."""
+    def _act(self, f, lists, lens, masks, pol, deciding=None, term=None, live=None):
+        """One batched forward per distinct net in play: net 0 = central policy, net 1 + k = opponent_nets[k].
+        With an LSTM policy the deciding seat's state goes in (multiplied by the previous step's terminal mask, :81,85-89)
+        and its new state is kept for the games that really step."""
         N = f.shape[0]
         if not self.opponent_nets:
             groups = [(None, self.policy)]
@@ -180,18 +194,34 @@ class RolloutCollector(object):
                       for k in torch.unique(net_id).tolist()]
         actions = torch.zeros((N, spec.ACTION_WORDS), dtype=torch.int64, device=f.device)
         logp = torch.zeros((N,), dtype=torch.float32, device=f.device)
+        if self.recurrent:
+            ar_all = torch.arange(N, device=f.device)
+            seat = deciding - 1
+            h_in, c_in = self.hid[0, ar_all, seat], self.hid[1, ar_all, seat]
+            new_h, new_c = h_in.clone(), c_in.clone()
         for idx, net in groups:
             args = (f, lists, lens, masks) if idx is None else (f[idx], lists[idx], lens[idx], masks[idx])
+            kw = {"generator": self.sample_gen}
+            if self.recurrent:
+                sel = slice(None) if idx is None else idx
+                kw.update(hidden=(h_in[sel], c_in[sel]), nonterminal=term[sel])
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
-                    _, a, lp = net.act(*args, generator=self.sample_gen)
+                    res = net.act(*args, **kw)
             else:
-                _, a, lp = net.act(*args, generator=self.sample_gen)
+                res = net.act(*args, **kw)
+            a, lp = res[1], res[2]
+            if self.recurrent:
+                new_h[sel], new_c[sel] = res[3][0].float(), res[3][1].float()
             if idx is None:
                 actions, logp = a, lp[:, 0]
             else:
                 actions[idx] = a
                 logp[idx] = lp[:, 0]
+        if self.recurrent:
+            keep = live[:, None]
+            self.hid[0, ar_all, seat] = torch.where(keep, new_h, h_in)                     # :89
+            self.hid[1, ar_all, seat] = torch.where(keep, new_c, c_in)
         return actions, logp
 
     # game_manager.py:142-150
@@ -203,6 +233,8 @@ class RolloutCollector(object):
         st.lists[0] = st.lists[last_t, ar]
         st.lens[0] = st.lens[last_t, ar]
         st.masks[0] = st.masks[(self.n_msk - 1).clamp(min=0, max=T + 1), ar]
+        if self.recurrent:
+            st.hidden[:, 0] = st.hidden[:, last_t, ar]
         had_obs = self.n_obs > 0
         self.n_obs = had_obs.long()
         self.n_msk = torch.ones_like(self.n_msk)

@@ -6,6 +6,12 @@ Per epoch (ppo.py:30-32, recompute_returns): values of all (T+1)*N stored observ
 over ranks), then `num_mini_batch` random minibatches of T*N // num_mini_batch rows (process_batch.py:169-200):
 evaluate_actions -> fused PPO loss kernel (fwd+bwd) -> gradient all-reduce (one flat bucket over RCCL when N>1 ranks)
 -> clip_grad_norm_(0.5) -> Adam.  The network runs under bf16 autocast on the GPU.
+
+With an LSTM policy (`include_lstm`, off in the reference's defaults) the minibatches are the truncated-BPTT sequences of
+`generator_lstm` (process_batch.py:203-293): every game's T stored decisions are cut into T / truncated_seq_len
+consecutive pieces, a minibatch is a random set of pieces laid out time-major, entered with the LSTM state stored at the
+piece's first decision and carrying the terminal masks inside; the value re-evaluation is one LSTM step per stored
+decision from its stored state (process_batch.py:117-121, the `x.size(0) == hxs.size(0)` branch of policy.py:117-123).
 """
 import time
 
@@ -27,6 +33,7 @@ class PPOConfig(object):
     value_loss_coef = 1.0
     entropy_coef = 0.04
     max_grad_norm = 0.5
+    truncated_seq_len = 10            # arguments.py:57-59 (LSTM policies only)
     value_chunk = 262144
 
     def __init__(self, **kw):
@@ -34,6 +41,24 @@ class PPOConfig(object):
             if not hasattr(self, k):
                 raise AttributeError(k)
             setattr(self, k, v)
+
+
+def lstm_minibatches(T, N, seq_len, num_mini_batch, perm):
+    """The index arithmetic of `generator_lstm` (process_batch.py:203-241).  Pieces are numbered game-major
+    (piece k = game k // (T/seq_len), first decision (k % (T/seq_len)) * seq_len, :211-215); `perm` is the random
+    permutation of the pieces (:216).  Yields per minibatch (t [seq_len, n], game [n]): decision (t[l, j], game[j]) is row
+    l*n + j of the flattened batch (`_flatten_helper`, :274-291); the LSTM state going in is the one stored at (t[0, j], game[j])."""
+    if T % seq_len != 0:
+        raise ValueError("num_steps must be a multiple of truncated_seq_len (process_batch.py:206)")
+    pieces = T // seq_len
+    n = (T * N) // num_mini_batch // seq_len                                  # num_sequences_per_minibatch (:208)
+    if n < 1 or (N * pieces) % n != 0:
+        raise ValueError("the sequences do not divide into equal minibatches (the reference's .view(N, -1) at :257 needs that)")
+    steps = torch.arange(seq_len, device=perm.device)
+    for s in range(0, N * pieces, n):
+        k = perm[s:s + n]
+        game, t0 = k // pieces, (k % pieces) * seq_len
+        yield t0[None, :] + steps[:, None], game
 
 
 class PPOTrainer(object):
@@ -61,9 +86,16 @@ class PPOTrainer(object):
         f = st.obs_f.reshape(T1 * N, -1); lists = st.lists.reshape(T1 * N, 5, -1); lens = st.lens.reshape(T1 * N, 5)
         out = torch.empty((T1 * N,), dtype=torch.float32, device=f.device)
         ch = self.cfg.value_chunk
+        rec = getattr(self.policy, "include_lstm", False)
+        if rec:
+            hid = st.hidden[:, :T1].reshape(2, T1 * N, -1); nt = st.masks[:T1].reshape(T1 * N)
         for s in range(0, T1 * N, ch):
             with self._autocast():
-                v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long())
+                if rec:
+                    v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long(),
+                                              (hid[0, s:s + ch], hid[1, s:s + ch]), nt[s:s + ch])
+                else:
+                    v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long())
             out[s:s + ch] = v[:, 0]
         return self.policy.denormalise(out).reshape(T1, N)
 
@@ -78,6 +110,8 @@ class PPOTrainer(object):
         acts_all = st.actions.reshape(total, -1); amask_all = st.action_masks.reshape(total, -1)
         old_lp_all = st.action_log_probs.reshape(total)
         rewards = st.rewards[:T].contiguous(); masks = st.masks[:T + 1].contiguous()
+        rec = getattr(pol, "include_lstm", False)
+        nt_all = masks[:T].reshape(total)                 # masks_batch of generator_lstm (process_batch.py:249)
         sums = torch.zeros(3, device=dev)                 # action loss, value loss, entropy (accumulated on device)
         t_val = t_gae = t_opt = 0.0
         for _ in range(cfg.ppo_epoch):
@@ -87,12 +121,22 @@ class PPOTrainer(object):
             returns, adv = ppo_kernels.compute_gae(rewards, values, masks, cfg.gamma, cfg.gae_lambda)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             vpred = values[:T].reshape(total); ret = returns.reshape(total); advf = adv.reshape(total)
-            perm = torch.randperm(total, generator=self.gen, device=dev)                   # SubsetRandomSampler
-            for mb in range(cfg.num_mini_batch):                                           # BatchSampler(drop_last=True)
-                idx = perm[mb * mbs:(mb + 1) * mbs]
+            if rec:
+                seqs = lstm_minibatches(T, N, cfg.truncated_seq_len, cfg.num_mini_batch,
+                                        torch.randperm(total // cfg.truncated_seq_len, generator=self.gen, device=dev))
+                batches = [((t * N + g[None, :]).reshape(-1), (st.hidden[0, t[0], g], st.hidden[1, t[0], g])) for t, g in seqs]
+            else:
+                perm = torch.randperm(total, generator=self.gen, device=dev)               # SubsetRandomSampler
+                batches = [(perm[mb * mbs:(mb + 1) * mbs], None) for mb in range(cfg.num_mini_batch)]   # BatchSampler(drop_last=True)
+            for idx, hidden in batches:
                 with self._autocast():
-                    v, lp, ent = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
-                                                      st.unpack_action_masks(amask_all[idx]), acts_all[idx])
+                    if rec:
+                        v, lp, ent, _ = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
+                                                             st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                             hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
+                    else:
+                        v, lp, ent = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
+                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx])
                 loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
                                                    cfg.clip_param, cfg.value_loss_coef,
                                                    value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
@@ -104,7 +148,7 @@ class PPOTrainer(object):
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))
             torch.cuda.synchronize(); t3 = time.perf_counter()
             t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2
-        n = cfg.ppo_epoch * cfg.num_mini_batch
+        n = cfg.ppo_epoch * len(batches)
         self.timings = {"values_s": t_val, "gae_s": t_gae, "minibatches_s": t_opt}
         al, vl, en = (sums / n).tolist()
         return vl * cfg.value_loss_coef, al, en * cfg.entropy_coef

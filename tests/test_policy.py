@@ -101,3 +101,73 @@ def test_parity_with_reference_net(oracle):
         assert torch.allclose(v_m, v_r, atol=1e-5)
         assert torch.allclose(lp_m, lp_r, atol=1e-5), float((lp_m - lp_r).abs().max())
         assert abs(float(ent_m) - float(ent_r)) < 1e-5
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="upstream reference not mounted")
+def test_lstm_path_parity_with_reference_net(oracle):
+    """include_lstm (build_agent_model.py:26 switched on): one step per row, and the truncated-BPTT form (T steps of B
+    sequences with terminal masks inside), against the reference net with identical weights."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from ref_bootstrap import bootstrap
+    bootstrap()
+    import RL.models.build_agent_model as bam
+    old = bam.include_lstm
+    bam.include_lstm = True
+    try:
+        torch.manual_seed(3)
+        ref = bam.build_agent_model()
+    finally:
+        bam.include_lstm = old
+    _perturb(ref, seed=4)
+    ref.eval()
+    mine = CatanPolicy(include_lstm=True)
+    mine.load_reference_state_dict(ref.state_dict())
+    mine.eval()
+    assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for p in ref.parameters()) - 2
+    T, Bs = 5, 8
+    x = {k: v[:T * Bs] for k, v in policy_util.oracle_batch_inputs(oracle, n=T * Bs, seed=9).items()}
+    B = x["obs_f"].shape[0]
+    assert B == T * Bs
+    o = spec.OBS_FLOAT_OFFSETS
+    obs = {k: x["obs_f"][:, o[k]:o[k] + int(np.prod(shp))].reshape((B,) + shp).clone() for k, shp in spec.OBS_FLOAT_KEYS.items()}
+    for i, k in enumerate(spec.OBS_LIST_KEYS):
+        obs[k] = x["lists"][:, i].long()
+    masks = []
+    for hi, (off, sz, shp) in enumerate(zip(spec.MASK_OFFSETS, spec.MASK_SIZES, spec.MASK_SHAPES)):
+        mk = x["masks"][:, off:off + sz].reshape((B,) + shp).clone()
+        masks.append(mk.transpose(0, 1).contiguous() if hi in (1, 6, 9) else mk)
+    g = torch.Generator().manual_seed(21)
+    cp = lambda d: {k: v.clone() for k, v in d.items()}
+    with torch.no_grad():
+        # (1) one step per row, random incoming state, some rows with a zero terminal mask
+        h0 = torch.randn(B, 256, generator=g) * 0.5; c0 = torch.randn(B, 256, generator=g) * 0.5
+        nt = (torch.rand(B, 1, generator=g) > 0.3).float()
+        v_m, a_m, lp_m, (h_m, c_m) = mine.act(x["obs_f"], x["lists"], x["lens"], x["masks"], deterministic=True, hidden=(h0, c0), nonterminal=nt)
+        v_r, a_r, lp_r, (h_r, c_r) = ref.act(cp(obs), (h0.clone(), c0.clone()), nt.clone(), [mk.clone() for mk in masks], deterministic=True)
+        a_r_flat = torch.cat([torch.stack([t.view(-1) for t in h], 1) if isinstance(h, list) else h.view(B, -1) for h in a_r], 1)
+        assert torch.allclose(h_m, h_r, atol=1e-5) and torch.allclose(c_m, c_r, atol=1e-5)
+        assert torch.allclose(v_m, v_r, atol=1e-5), float((v_m - v_r).abs().max())
+        assert torch.equal(a_m, a_r_flat)
+        assert torch.allclose(lp_m, lp_r, atol=1e-5)
+        assert torch.allclose(mine.get_value(x["obs_f"], x["lists"], x["lens"], (h0, c0), nt), ref.get_value(cp(obs), (h0.clone(), c0.clone()), nt.clone()), atol=1e-5)
+        # (2) T steps of Bs sequences, zeros inside the mask (incl. at t = 0 and two in the same step)
+        hs = torch.randn(Bs, 256, generator=g) * 0.5; cs = torch.randn(Bs, 256, generator=g) * 0.5
+        nts = torch.ones(T, Bs); nts[0, 1] = 0; nts[2, 3] = 0; nts[2, 5] = 0; nts[4, 0] = 0
+        nts = nts.reshape(T * Bs, 1)
+        _, a_s, _, _ = mine.act(x["obs_f"], x["lists"], x["lens"], x["masks"], generator=g, hidden=(h0, c0), nonterminal=nt)
+        acts_ref = [a_s[:, off:off + ln].clone() for off, ln in spec.ACTION_HEAD_SLICES]
+        v_r, lp_r, ent_r, (h_r, c_r) = ref.evaluate_actions(cp(obs), (hs.clone(), cs.clone()), nts.clone(), acts_ref, [mk.clone() for mk in masks])
+        v_m, lp_m, ent_m, (h_m, c_m) = mine.evaluate_actions(x["obs_f"], x["lists"], x["lens"], x["masks"], a_s, hidden=(hs, cs), nonterminal=nts)
+        assert torch.allclose(v_m, v_r, atol=2e-5), float((v_m - v_r).abs().max())
+        assert torch.allclose(lp_m, lp_r, atol=2e-5), float((lp_m - lp_r).abs().max())
+        assert abs(float(ent_m) - float(ent_r)) < 1e-5
+        assert torch.allclose(h_m, h_r, atol=1e-5) and torch.allclose(c_m, c_r, atol=1e-5)
+        # all-ones masks (the reference's scalar `has_zeros` branch)
+        ones = torch.ones(T * Bs, 1)
+        v_r, _, _, _ = ref.evaluate_actions(cp(obs), (hs.clone(), cs.clone()), ones.clone(), acts_ref, [mk.clone() for mk in masks])
+        v_m, _, _, _ = mine.evaluate_actions(x["obs_f"], x["lists"], x["lens"], x["masks"], a_s, hidden=(hs, cs), nonterminal=ones)
+        assert torch.allclose(v_m, v_r, atol=2e-5)
+    # gradients flow through time into the LSTM weights
+    v, lp, ent, _ = mine.evaluate_actions(x["obs_f"], x["lists"], x["lens"], x["masks"], a_s, hidden=(hs, cs), nonterminal=nts)
+    (v.mean() + lp.mean() + ent).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in mine.lstm.parameters())

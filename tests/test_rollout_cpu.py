@@ -12,28 +12,39 @@ import torch
 from settlers_of_catan_rl_amd import spec
 from settlers_of_catan_rl_amd.rollout import RolloutCollector
 from settlers_of_catan_rl_amd.policy import CatanPolicy
-from oracle_vec_env import OracleVecEnv, ScriptedPolicy
+from oracle_vec_env import OracleVecEnv, ScriptedPolicy, RecurrentScriptedPolicy
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HAVE_REF = os.path.isdir("/root/reference/RL/ppo")
 
 
-def _sequential_manager(env, policy, active_pid, T, state):
+def _sequential_manager(env, policy, active_pid, T, state, L=0):
     """game_manager.py:69-140 for every game of `env`, one game at a time is impossible with a lock-step env object, so the
     restatement keeps per-game Python lists and walks all games step by step - the list logic per game is the reference's."""
     n = env.n
     if state is None:                                      # game_manager.py:35-59
         state = dict(obs=[[] for _ in range(n)], masks=[[1.0] for _ in range(n)], acts=[[] for _ in range(n)],
-                     lps=[[] for _ in range(n)], rews=[[] for _ in range(n)])
+                     lps=[[] for _ in range(n)], rews=[[] for _ in range(n)], hid=[[] for _ in range(n)],
+                     cur=[{p: (torch.zeros(L), torch.zeros(L)) for p in (1, 2, 3, 4)} for _ in range(n)])
         f, lists, lens = env.get_obs(); dec = env.deciding_player()
         for i in range(n):
             if int(dec[i]) == active_pid[i]:
                 state["obs"][i].append((f[i].clone(), lists[i].clone(), lens[i].clone()))
+                state["hid"][i].append(state["cur"][i][active_pid[i]])
     racc = np.zeros((n, 4)); done_since = [False] * n
+    term = [state["masks"][i][0] for i in range(n)]                  # game_manager.py:74-75
     while any(len(state["obs"][i]) < T + 1 for i in range(n)):
         dec = env.deciding_player(); f, lists, lens = env.get_obs(); masks = env.get_action_masks()
-        _, a, lp = policy.act(f, lists, lens, masks)
         frozen = [len(state["obs"][i]) >= T + 1 for i in range(n)]
+        if L:
+            h = torch.stack([state["cur"][i][int(dec[i])][0] for i in range(n)])
+            c = torch.stack([state["cur"][i][int(dec[i])][1] for i in range(n)])
+            _, a, lp, (nh, nc) = policy.act(f, lists, lens, masks, hidden=(h, c), nonterminal=torch.tensor(term))
+            for i in range(n):
+                if not frozen[i]:
+                    state["cur"][i][int(dec[i])] = (nh[i].clone(), nc[i].clone())       # :89
+        else:
+            _, a, lp = policy.act(f, lists, lens, masks)
         a_env = a.to(torch.int32)
         for i in range(n):
             if frozen[i]:
@@ -46,6 +57,7 @@ def _sequential_manager(env, policy, active_pid, T, state):
             act = active_pid[i]
             racc[i] += rew[i].numpy()
             d = bool(done[i])
+            term[i] = 1.0 - float(d)                                 # :97
             reward_updated = False
             if int(dec[i]) == act:
                 state["acts"][i].append(a[i].clone()); state["lps"][i].append(float(lp[i, 0]))
@@ -57,11 +69,13 @@ def _sequential_manager(env, policy, active_pid, T, state):
                 state["rews"][i].append(racc[i, act - 1]); racc[i, act - 1] = 0.0; reward_updated = True
             if d:
                 state["masks"][i].append(0.0); done_since[i] = False; racc[i] = 0.0
+                state["cur"][i] = {p: (torch.zeros(L), torch.zeros(L)) for p in (1, 2, 3, 4)}    # :121-124
             if int(ndec[i]) == act:
                 if not d and not done_since[i]:
                     state["masks"][i].append(1.0)
                 done_since[i] = False
                 state["obs"][i].append((nf[i].clone(), nlists[i].clone(), nlens[i].clone()))
+                state["hid"][i].append(state["cur"][i][act])                                     # :133
             elif d:
                 done_since[i] = True
     return state
@@ -71,27 +85,33 @@ def _after(state):                                        # game_manager.py:142-
     for k in ("acts", "lps", "rews"):
         state[k] = [[] for _ in state[k]]
     state["obs"] = [[o[-1]] for o in state["obs"]]
+    state["hid"] = [[h[-1]] for h in state["hid"]]
     state["masks"] = [[m[-1]] for m in state["masks"]]
 
 
-def test_collector_matches_sequential_restatement():
+@pytest.mark.parametrize("recurrent", [False, True])
+def test_collector_matches_sequential_restatement(recurrent):
     n, T, seed = 20, 24, 13
     envA, envB = OracleVecEnv(n, seed), OracleVecEnv(n, seed)
     envA.advance_random(1750); envB.advance_random(1750)             # late game: several games end inside the rollouts
-    col = RolloutCollector(envA, ScriptedPolicy(envA), T, seed=4)
+    Pol = RecurrentScriptedPolicy if recurrent else ScriptedPolicy
+    L = Pol.lstm_size if recurrent else 0
+    col = RolloutCollector(envA, Pol(envA), T, seed=4)
     active = [int(x) for x in col.active_pid]
     state = None
-    polB = ScriptedPolicy(envB)
+    polB = Pol(envB)
     ends = 0
     for r in range(3):
         st = col.gather_rollouts()
-        state = _sequential_manager(envB, polB, active, T, state)
+        state = _sequential_manager(envB, polB, active, T, state, L)
         for i in range(n):
             assert len(state["obs"][i]) == T + 1 and len(state["acts"][i]) == T
             for t in range(T + 1):
                 assert torch.equal(st.obs_f[t, i], state["obs"][i][t][0]), (r, i, t)
                 assert torch.equal(st.lists[t, i].int(), state["obs"][i][t][1]) and torch.equal(st.lens[t, i].int(), state["obs"][i][t][2])
                 assert float(st.masks[t, i]) == state["masks"][i][t], (r, i, t)
+                if recurrent:
+                    assert torch.equal(st.hidden[0, t, i], state["hid"][i][t][0]) and torch.equal(st.hidden[1, t, i], state["hid"][i][t][1]), (r, i, t)
             for t in range(T):
                 assert torch.equal(st.actions[t, i], state["acts"][i][t])
                 assert float(st.action_log_probs[t, i]) == state["lps"][i][t]
@@ -111,15 +131,24 @@ def test_action_mask_packing_roundtrip():
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="upstream reference not mounted")
-def test_collector_vs_reference_manager():
+@pytest.mark.parametrize("lstm", [False, True])
+def test_collector_vs_reference_manager(lstm):
+    """lstm=True: `include_lstm` of build_agent_model.py:26 switched on - the per-seat LSTM states, their reset at a game
+    end and the stored `active_hidden_states` (game_manager.py:54-59,81-89,121-124,133)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ref_harness as rh
     from RL.ppo.game_manager import GamesAndPoliciesManager
-    T, seed = 14, 21
+    import RL.models.build_agent_model as bam
+    T, seed = (40, 23) if lstm else (14, 21)
     torch.manual_seed(3)
     stream = rh.PhiloxStream(seed, 0)
-    with rh.patched_rng(rh.PhiloxStream(seed ^ 0xABC, 0)):             # constructor draws are discarded (as in RefEnv)
-        mgr = GamesAndPoliciesManager(num_envs=1, num_steps=T)
+    old_flag = bam.include_lstm
+    bam.include_lstm = lstm
+    try:
+        with rh.patched_rng(rh.PhiloxStream(seed ^ 0xABC, 0)):         # constructor draws are discarded (as in RefEnv)
+            mgr = GamesAndPoliciesManager(num_envs=1, num_steps=T)
+    finally:
+        bam.include_lstm = old_flag
     sd = mgr.policies[0].state_dict()
     g = torch.Generator().manual_seed(9)
     sd = {k: (v + 0.05 * torch.randn(v.shape, generator=g) if v.numel() and v.dtype == torch.float32 else v) for k, v in sd.items()}
@@ -137,13 +166,19 @@ def test_collector_vs_reference_manager():
         def __init__(self, net): self.net = net
         def act(self, *a, **kw):
             kw.pop("generator", None)
-            return self.net.act(*a, deterministic=True)
-    net = CatanPolicy(); net.load_reference_state_dict(sd); net.eval()
+            return self.net.act(*a, deterministic=True, **kw)
+        include_lstm, lstm_size = lstm, 256
+    net = CatanPolicy(include_lstm=lstm); net.load_reference_state_dict(sd); net.eval()
     col = RolloutCollector(env, Det(net), T, seed=0)
     col.active_pid[:] = int(mgr.active_player_ids[0])
     col.reset()
     st = col.gather_rollouts()
-    obs_ref, _, rew_ref, act_ref, amask_ref, lp_ref, tm_ref = ref
+    obs_ref, hid_ref, rew_ref, act_ref, amask_ref, lp_ref, tm_ref = ref
+    if lstm:
+        for t in range(T + 1):
+            for j in range(2):
+                assert torch.allclose(st.hidden[j, t, 0], hid_ref[0][t][j][0], atol=2e-5), (t, j)
+        assert float(st.hidden[:, 1:].abs().max()) > 0.01
     o = spec.OBS_FLOAT_OFFSETS
     for t in range(T + 1):
         ro = obs_ref[0][t]

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--updates", type=int, default=1)
     ap.add_argument("--warm-games", type=int, default=600, help="random-policy steps before the first rollout (mixes game ages)")
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--lstm", action="store_true", help="include_lstm: LSTM(512 -> 256) policy, truncated-BPTT minibatches (seq len 10)")
     ap.add_argument("--league", type=int, default=0,
                     help="K > 0: opponents from the snapshot league, at most K distinct nets in play (league.League, bounded "
                          "variant); 0: every seat plays the central policy")
@@ -42,7 +43,8 @@ def main():
     env_id0, n = cdist.shard(rank, args.envs)
     env = VecCatanEnv(n, seed=0, env_id0=env_id0)
     env.random_rollout(0, args.warm_games)
-    net = CatanPolicy().cuda()
+    make_net = lambda: CatanPolicy(include_lstm=args.lstm).cuda()
+    net = make_net()
     ac = None if args.fp32 else torch.bfloat16
     col = RolloutCollector(env, net, args.num_steps, seed=rank, autocast_dtype=ac)
     tr = PPOTrainer(net, PPOConfig(ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch), autocast_dtype=ac, seed=rank)
@@ -51,7 +53,7 @@ def main():
         from settlers_of_catan_rl_amd.league import League
         lg = League(max_distinct=args.league, seed=rank)
         lg.add(net)                                          # robust_train.py:62-64: the deque starts with the initial policy
-        lg.assign(col, lambda: CatanPolicy().cuda())
+        lg.assign(col, make_net)
     res = []
     for u in range(args.updates):
         cdist.barrier()
@@ -64,7 +66,7 @@ def main():
         t2 = time.perf_counter()
         col.after_rollouts()
         if lg is not None and lg.after_update(u, net):
-            lg.assign(col, lambda: CatanPolicy().cuda())
+            lg.assign(col, make_net)
         res.append(dict(rollout_s=cdist.max_over_ranks(t1 - t0), update_s=cdist.max_over_ranks(t2 - t1), env_iters=col.iters,
                         value_loss=vl, action_loss=al, entropy_loss=el, **tr.timings))
     if rank == 0:

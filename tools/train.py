@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--eval-max-steps", type=int, default=2500)
     ap.add_argument("--checkpoint", type=str, default="")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lstm", action="store_true", help="include_lstm (build_agent_model.py:26): LSTM policy + truncated BPTT")
     args = ap.parse_args()
     import torch
     from settlers_of_catan_rl_amd import dist as cdist
@@ -40,11 +41,11 @@ def main():
     torch.manual_seed(args.seed)
     env_id0, n = cdist.shard(rank, args.envs)
     env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0)          # game_manager.py:16: EnvWrapper() defaults (sparse win reward)
-    net = CatanPolicy().cuda()
+    net = CatanPolicy(include_lstm=args.lstm).cuda()
     cdist.broadcast_parameters(net)
     col = RolloutCollector(env, net, args.num_steps, seed=rank, autocast_dtype=torch.bfloat16)
     tr = PPOTrainer(net, PPOConfig(ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch), seed=rank)
-    random_net = CatanPolicy().cuda().eval()                                   # robust_train.py:76-78: the evaluation opponent
+    random_net = CatanPolicy(include_lstm=args.lstm).cuda().eval()                                   # robust_train.py:76-78: the evaluation opponent
 
     def evaluate(policy, update_num):
         return evaluation.run_evaluation_protocol(lambda m: VecCatanEnv(m, seed=args.seed + 1000 + update_num, env_id0=1 << 40, auto_reset=False),
@@ -53,7 +54,7 @@ def main():
 
     lg = League(max_distinct=args.league, seed=rank) if args.league > 0 else None
     targs = train_loop.TrainArgs(num_steps=args.num_steps, eval_every=args.eval_every, num_eval_episodes=args.num_eval_episodes)
-    loop = train_loop.TrainingLoop(env, net, col, tr, targs, league=lg, make_net=lambda: CatanPolicy().cuda(),
+    loop = train_loop.TrainingLoop(env, net, col, tr, targs, league=lg, make_net=lambda: CatanPolicy(include_lstm=args.lstm).cuda(),
                                    evaluate=evaluate if rank == 0 else None, checkpoint_path=args.checkpoint or None)
     for _ in range(args.updates):
         out = loop.run_update()
