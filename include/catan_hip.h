@@ -212,7 +212,8 @@ int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t s
 int catan_profile_enable(catan_env_t* env, int on);
 int catan_profile_read(catan_env_t* env, uint64_t* out16);
 /* catan_profile_enable(env, 2): contention-free variant for k_step - every wave stores its own phase durations of the LAST
- * launch; out: HOST uint32 [ceil(n/256)*4][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = action type + 1) */
+ * launch; out: HOST uint32 [ceil(n/256)*4 + 17][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = sort bin + 1: bins
+ * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort) */
 int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
 
 #ifdef __cplusplus

@@ -224,7 +224,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)(e->N + SORT_PAD) * sizeof(i32));
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, EV_SYNC);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
@@ -233,9 +233,9 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.atype, (size_t)e->N);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ptype, (size_t)e->N);
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ptype, (size_t)(e->N + SORT_PAD));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64) * 8 * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
@@ -338,7 +338,7 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u8*)e->pend.atype, e->pend.ctr,
                        e->pend.perm, e->pend.ptype);
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
+    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -752,14 +752,14 @@ int catan_profile_enable(catan_env_t* e, int on) {
     if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(e->prof, 0, PROF_WORDS * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(e->prof_wave, 0, (size_t)(e->N / 64) * 8 * sizeof(u32)));
+    HIPCHK(hipMemset(e->prof_wave, 0, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32)));
     e->prof_on = on;
     return CATAN_OK;
 }
 int catan_profile_read_waves(catan_env_t* e, uint32_t* out) {
     if (!e || !out) return fail(CATAN_EINVAL, "catan_profile_read_waves: bad arguments");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 64) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 int catan_profile_read(catan_env_t* e, uint64_t* out16) {

@@ -280,6 +280,51 @@ DEVI void est_store(const S& s, int o, int l, const Est& E) {
     for (int r = 0; r < 4; r++) { a |= (u32)(E.mn[r] & 255) << (8 * r); b |= (u32)(E.mx[r] & 255) << (8 * r); }
     s.sw(base, a); s.sw(base + 1, b); s.sw(base + 2, (u32)(E.mn[4] & 255) | ((u32)(E.mx[4] & 255) << 8));
 }
+// The visible-exchange update of one estimate entry, field = clip(field + delta, 0, total) for the selected resources
+// (game.py:938-944), on the packed words directly: the ten fields are bytes of three words, and per byte
+//   clip(x + d, 0, T) = min(satsub(x + max(d, 0), max(-d, 0)), T)            (x, T >= 0)
+// costs a handful of word instructions as long as every byte stays below 128 (hands total <= 95; checked, with the
+// field-by-field form as the fall-back).  k_step is bound by its instruction count: unpacked, an entry took ~150
+// instructions and a dice roll updates twelve of them.
+// Packed operands: words 0/1 (mn / mx of resources 0..3) share pw/nw/tw/mw, word 2 (mn[4] | mx[4] << 8) uses pc/nc/tc/mc;
+// p = positive part of delta, n = magnitude of its negative part, t = clip bound, m = 0xFF per selected byte.
+constexpr u32 H4 = 0x80808080u;
+DEVI u32 swar_clip(u32 x, u32 p, u32 n, u32 t, u32 m) {
+    u32 v = x + p;
+    u32 d = (v | H4) - n;                                  // per byte 128 + v - n: bit 7 = (v >= n), no borrow across bytes
+    v = d & ~H4 & (((d & H4) >> 7) * 255u);                // saturating v - n
+    d = (v | H4) - t;
+    const u32 ge = ((d & H4) >> 7) * 255u;                 // 0xFF where v >= t
+    v = (t & ge) | (v & ~ge);
+    return (v & m) | (x & ~m);
+}
+// the same for delta >= 0: min(x + p, t) per selected byte
+DEVI u32 swar_addmin(u32 x, u32 p, u32 t, u32 m) {
+    const u32 v = x + p;
+    const u32 ge = ((((v | H4) - t) & H4) >> 7) * 255u;   // 0xFF where v >= t
+    const u32 r = (t & ge) | (v & ~ge);
+    return (r & m) | (x & ~m);
+}
+template <class S>
+DEVI void est_apply(const S& s, int o, int l, u32 pw, u32 nw, u32 tw, u32 mw, u32 pc, u32 nc, u32 tc, u32 mc) {
+    const int base = W_EST + (o * 3 + l) * 3;
+    const u32 a = s.w(base), b = s.w(base + 1), c = s.w(base + 2);
+    if ((((a + pw) | (b + pw) | (c + pc) | a | b | c | pw | pc | tw | tc | nw | nc) & H4) == 0) {
+        s.sw(base, swar_clip(a, pw, nw, tw, mw)); s.sw(base + 1, swar_clip(b, pw, nw, tw, mw)); s.sw(base + 2, swar_clip(c, pc, nc, tc, mc));
+        return;
+    }
+    Est E; est_load(s, o, l, E);                            // some byte >= 128: field by field
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int sh = 8 * (r & 3);
+        const bool sel = r < 4 ? ((mw >> sh) & 1) : (mc & 1);
+        if (!sel) continue;
+        const int d = r < 4 ? (int)((pw >> sh) & 255) - (int)((nw >> sh) & 255) : (int)(pc & 255) - (int)(nc & 255);
+        const int t = r < 4 ? (int)((tw >> sh) & 255) : (int)(tc & 255);
+        E.mx[r] = clipi(E.mx[r] + d, 0, t); E.mn[r] = clipi(E.mn[r] + d, 0, t);
+    }
+    est_store(s, o, l, E);
+}
 struct D5 { int v[5]; };
 DEVI D5 d5_zero() { D5 d; d.v[0] = d.v[1] = d.v[2] = d.v[3] = d.v[4] = 0; return d; }
 DEVI void d5_add(D5& d, int r0, int x) {
@@ -290,6 +335,19 @@ DEVI void d5_add(D5& d, int r0, int x) {
 template <class S>
 DEVI void update_estimates(const S& s, int seatof, const D5& delta, int touched, int upd, int thief) {
     int total = s.total(upd);
+    if (thief < 0) {                                       // visible exchange: every other player clips (game.py:936-944)
+        u32 pw = 0, nw = 0, mw = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int d = delta.v[r];
+            pw |= (u32)max(d, 0) << (8 * r); nw |= (u32)max(-d, 0) << (8 * r); mw |= ((touched >> r) & 1) ? 0xFFu << (8 * r) : 0u;
+        }
+        const u32 p4 = (u32)max(delta.v[4], 0), n4 = (u32)max(-delta.v[4], 0), t1 = (u32)total;
+        const u32 mc = ((touched >> 4) & 1) ? 0xFFFFu : 0u;
+        for (int o = 0; o < 4; o++)
+            if (o != upd) est_apply(s, o, label_of(seatof, o, upd), pw, nw, t1 * 0x01010101u, mw, p4 * 0x0101u, n4 * 0x0101u, t1 * 0x0101u, mc);
+        return;
+    }
     int total_thief = thief >= 0 ? s.total(thief) : 0;
     for (int o = 0; o < 4; o++) {
         Est E;
@@ -936,10 +994,30 @@ DEVI bool action_legal(const S& s, const u32 (&m)[MASK_WORDS], const int (&a)[AC
 }
 
 // ref: game/game.py:138-177
+// clock read that neither the scheduler nor outstanding memory operations can move work across (diagnostics only)
+DEVI long long clock_fenced() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long long t = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+// ref: game/game.py:138-177.  `roll` waves are a fifth of all k_step waves and were its slowest (2 300 VALU instructions,
+// 8.6 us): the kernel is bound by the instruction count of its slowest wave, so this function is written for few
+// instructions - one generator call site for both dice, the 19 tile bytes scanned four per word, the corner masks of the
+// hit tiles from an LDS table (tct) instead of a 19-way select, the twelve estimate entries loaded together and clipped on
+// the packed words.
 template <class S>
-DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof) {
-    int d1 = 1 + (int)rng.bounded(5), d2 = 1 + (int)rng.bounded(5);
+DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof, const u64* tct, u32* tk = nullptr) {
+    long long t0 = tk ? clock_fenced() : 0;
+    // np.random.randint(1, 7) twice = two masked-rejection draws on 3 bits (Rng::bounded(5)), same draw order
+    int d1 = 0, d2 = 0;
+    for (int have = 0; have < 2;) {
+        const u32 v = rng.next() & 7u;
+        if (v <= 5u) { if (have == 0) d1 = 1 + (int)v; else d2 = 1 + (int)v; have++; }
+    }
     s.sb(B_DIE1, d1); s.sb(B_DIE2, d2);
+    if (tk) { const long long t1 = clock_fenced(); tk[0] = (u32)(t1 - t0); t0 = t1; }
     int roll = d1 + d2;
     if (roll == 7) {
         int n = 0;
@@ -950,28 +1028,38 @@ DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof) {
         s.sb(B_NDISC, n);
         return roll;
     }
-    // at most two tiles carry any number token
-    int robber = s.b(B_ROBBER);
-    u32 alloc[5] = { 0, 0, 0, 0, 0 };     // per resource: one byte per pid0
-    u64 st[4], ct[4];
-    for (int p = 0; p < 4; p++) { st[p] = s.settle(p); ct[p] = s.city(p); }
-    int hit[2] = { -1, -1 }, hitres[2] = { 0, 0 };   // at most two tiles carry any number token
+    // tiles whose number token equals the roll (at most two carry any number), robber tile excluded: the tile bytes
+    // (resource | value << 4) are bytes 0..18 of five words
+    static_assert(B_TILE == 0, "tile bytes start a word");
+    const int robber = s.b(B_ROBBER);
+    u32 tmask = 0;
 #pragma unroll
-    for (int t = 0; t < 19; t++) {
-        const int tb = s.b(B_TILE + t);
-        const bool m = (tb >> 4) == roll && t != robber;
-        if (m) { if (hit[0] < 0) { hit[0] = t; hitres[0] = (tb & 15) - 1; } else { hit[1] = t; hitres[1] = (tb & 15) - 1; } }
+    for (int w = 0; w < 5; w++) {
+        const u32 x = s.w(NW + w);
+        const u32 eq = ((x >> 4) & 0x0F0F0F0Fu) ^ ((u32)roll * 0x01010101u);          // byte == 0  <=>  value == roll
+        u32 z = (((eq + 0x7F7F7F7Fu) & 0x80808080u) ^ 0x80808080u) >> 7;             // 1 per matching byte (bytes <= 15: no carry)
+        if (w == 4) z &= 0x00010101u;                                                 // byte 19 is not a tile
+        tmask |= ((z | (z >> 7) | (z >> 14) | (z >> 21)) & 15u) << (4 * w);
     }
+    tmask &= ~(1u << robber);
+    u32 alloc[5] = { 0, 0, 0, 0, 0 };     // per resource: one byte per pid0
+    if (tmask) {
+        u64 st[4], ct[4];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if (hit[h] < 0) continue;
-        const int r0 = hitres[h];
-        const u64 tm = topo_tile_corners(hit[h]);
-        u32 add = 0;
+        for (int p = 0; p < 4; p++) { st[p] = s.settle(p); ct[p] = s.city(p); }
 #pragma unroll
-        for (int p = 0; p < 4; p++) add |= (u32)(__popcll(st[p] & tm) + 2 * __popcll(ct[p] & tm)) << (8 * p);
+        for (int h = 0; h < 2; h++) {
+            if (tmask == 0) break;
+            const int t = __ffs((int)tmask) - 1;
+            tmask &= tmask - 1;
+            const int r0 = (s.b(B_TILE + t) & 15) - 1;
+            const u64 tm = tct[t];
+            u32 add = 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) alloc[k] += (k == r0) ? add : 0u;
+            for (int p = 0; p < 4; p++) add |= (u32)(__popcll(st[p] & tm) + 2 * __popcll(ct[p] & tm)) << (8 * p);
+#pragma unroll
+            for (int k = 0; k < 5; k++) alloc[k] += (k == r0) ? add : 0u;
+        }
     }
     // game.py:170-175: per resource all-or-nothing, in dict order Wood, Ore, Brick, Wheat, Sheep
     const int res_order[5] = { R_WOOD, R_ORE, R_BRICK, R_WHEAT, R_SHEEP };
@@ -984,32 +1072,57 @@ DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof) {
         int bank = s.b(B_BANK + r0);
         if (tot <= bank) { okbits |= 1u << r0; if (tot) s.sb(B_BANK + r0, bank - tot); }
     }
+    if (tk) { const long long t1 = clock_fenced(); tk[1] = (u32)(t1 - t0); t0 = t1; }
     // hands + estimates.  For a fixed receiving player X the five per-resource updates are sequential (the clip bound
     // is X's running hand total); different X touch disjoint estimate entries, so the player order is free.
+    // Every player's estimates of X are clipped for every resource the bank could pay (game.py:172-175 calls the update
+    // with zero amounts too), so all twelve entries are touched: new = min(old + add, bound) per byte.
+    u32 mw = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) mw |= ((okbits >> r) & 1) ? 0xFFu << (8 * r) : 0u;
+    const u32 mc = ((okbits >> 4) & 1) ? 0xFFFFu : 0u;
+    u32 pw[4], tw[4], pc[4], tc[4];
+#pragma unroll
     for (int X = 0; X < 4; X++) {
-        int base_total = s.total(X);
-        int add[5];
+        int tot = s.total(X);
+        int add[5], bound[5];
 #pragma unroll
-        for (int r = 0; r < 5; r++) add[r] = (alloc[r] >> (8 * X)) & 255;
+        for (int r = 0; r < 5; r++) add[r] = ((okbits >> r) & 1) ? (int)((alloc[r] >> (8 * X)) & 255) : 0;
 #pragma unroll
-        for (int r = 0; r < 5; r++) if (((okbits >> r) & 1) && add[r]) s.spb(X, P_RES + r, s.pb(X, P_RES + r) + add[r]);
-        for (int o = 0; o < 4; o++) {
-            if (o == X) continue;
-            int l = label_of(seatof, o, X);
-            Est E; est_load(s, o, l, E);
-            int tot = base_total;
+        for (int i = 0; i < 5; i++) { const int r = res_order[i]; tot += add[r]; bound[r] = tot; }   // the running hand total is the clip bound
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                int r = res_order[i];
-                if ((okbits >> r) & 1) {
-                    tot += add[r];
-                    E.mx[r] = clipi(E.mx[r] + add[r], 0, tot);
-                    E.mn[r] = clipi(E.mn[r] + add[r], 0, tot);
-                }
-            }
-            est_store(s, o, l, E);
-        }
+        for (int r = 0; r < 5; r++) if (add[r]) s.spb(X, P_RES + r, s.pb(X, P_RES + r) + add[r]);
+        pw[X] = (u32)add[0] | ((u32)add[1] << 8) | ((u32)add[2] << 16) | ((u32)add[3] << 24);
+        tw[X] = (u32)bound[0] | ((u32)bound[1] << 8) | ((u32)bound[2] << 16) | ((u32)bound[3] << 24);
+        pc[X] = (u32)add[4] * 0x0101u; tc[X] = (u32)bound[4] * 0x0101u;
     }
+    int base[12];
+    u32 ea[12], eb[12], ec[12], guard = 0;
+#pragma unroll
+    for (int X = 0; X < 4; X++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int o = j + (j >= X ? 1 : 0), k = X * 3 + j;
+            base[k] = W_EST + (o * 3 + label_of(seatof, o, X)) * 3;
+            ea[k] = s.w(base[k]); eb[k] = s.w(base[k] + 1); ec[k] = s.w(base[k] + 2);
+            guard |= ea[k] | eb[k] | ec[k] | (ea[k] + pw[X]) | (eb[k] + pw[X]) | (ec[k] + pc[X]) | pw[X] | pc[X] | tw[X] | tc[X];
+        }
+    if ((guard & H4) == 0) {                               // every byte below 128 (always, in practice): clip on the packed words
+#pragma unroll
+        for (int X = 0; X < 4; X++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int k = X * 3 + j;
+                s.sw(base[k], swar_addmin(ea[k], pw[X], tw[X], mw));
+                s.sw(base[k] + 1, swar_addmin(eb[k], pw[X], tw[X], mw));
+                s.sw(base[k] + 2, swar_addmin(ec[k], pc[X], tc[X], mc));
+            }
+    } else {
+        for (int X = 0; X < 4; X++)
+            for (int o = 0; o < 4; o++)
+                if (o != X) est_apply(s, o, label_of(seatof, o, X), pw[X], 0u, tw[X], mw, pc[X], 0u, tc[X], mc);
+    }
+    if (tk) tk[2] = (u32)(clock_fenced() - t0);
     return roll;
 }
 
@@ -1075,6 +1188,15 @@ struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* l
                  u8* atype; u8* ptype;      // action-type bin per game / per sorted slot (13 = no-op, padding or busy)
                  int fa, ftag, sa, stag; };
 constexpr int CTR_WORDS = 64;
+// Sort bins: 0..12 = the action types, 13..16 = play_dev with card 1..4 (card 0 stays in bin T_PLAYDEV: the five cards run
+// five different code paths, and the launch lasts as long as its slowest wave), NBINS-1 = no-op / busy / padding.
+constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
+DEVI int bin_of(int t, int card) {
+    if (t < 0 || t > 12) return BIN_NOOP;
+    return (t == T_PLAYDEV && card >= 1 && card <= 4) ? 12 + card : t;
+}
+DEVI int type_of_bin(int bin) { return bin <= 12 ? bin : (bin < BIN_NOOP ? T_PLAYDEV : -1); }
+
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
 struct StepScratch { LrWave lr; };
@@ -1195,6 +1317,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend) {
     __shared__ u32 tile[ROWS_HOT * TS];
+    __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < CTR_WORDS - 16) pend.ctr[16 + lane] = 0;     // the sort is done with its bins: clear them for the next one
     const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
@@ -1202,13 +1325,14 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const bool live = e < c.n;
     // bin 13 = explicit no-op (negative type: frozen game), padding, or a busy game (the sampler gives those the no-op):
     // none of them touches its record
-    int type = pend.ptype[(long)blockIdx.x * 64 + lane];
-    if (type > 12 || !live) type = -1;
+    const int bin = pend.ptype[(long)blockIdx.x * 64 + lane];
+    int type = live ? type_of_bin(bin) : -1;
     if (live && type < 0) {
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         done[e] = 0;
     }
     if (__ballot(type >= 0) == 0) return;
+    if (__ballot(type == T_ROLL) != 0 && lane < 19) tct[lane] = topo_tile_corners(lane);
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
     int a[ACTION_WORDS];
@@ -1235,6 +1359,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int pid = s.b(B_GO);
     int flags = s.flags();
     int lr_who = -1;
+    const long long t_sw0 = cfg.prof_wave ? clock_fenced() : 0;
 
     switch (type) {
     case T_SETTLE: {                                                       // game.py:530-555, 195-212
@@ -1320,7 +1445,10 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     }
     case T_ROLL: {                                                         // game.py:605-611
         Rng rng = rng_load(c, s);
-        int roll = roll_dice(s, rng, order, seatof);
+        u32 tk[3] = { 0, 0, 0 };
+        int roll = roll_dice(s, rng, order, seatof, tct, cfg.prof_wave ? tk : nullptr);
+        if (cfg.prof_wave != nullptr && lane == 0)          // slot 4: dice draws | tile scan + bank << 10 | hands + estimates << 20
+            cfg.prof_wave[(long)blockIdx.x * 8 + 4] = (tk[0] & 1023u) | ((tk[1] & 1023u) << 10) | ((tk[2] & 1023u) << 20);
         s.sw(W_RNG, rng.draws);
         flags |= F_ROLLED;
         if (roll == 7) flags |= F_CAN_ROBBER;
@@ -1506,12 +1634,13 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     }
     default: break;
     }
-#ifdef CATAN_FINE_PROF
-    prof_mark(cfg, 3, tprof);
-#endif
+    if (cfg.prof_wave != nullptr) {                         // slot 3: before the switch (validate, clamps) | the switch << 16; slot 4: unused
+        const long long t_sw1 = clock_fenced();
+        if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 3] = ((u32)(t_sw0 - tprof) & 0xFFFFu) | ((u32)(t_sw1 - t_sw0) << 16);
+    }
     if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
 
-    if (cfg.prof_wave != nullptr && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 5] = (u32)(type + 1);   // slot 5: action type + 1
+    if (cfg.prof_wave != nullptr && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 5] = (u32)(type >= 0 ? bin + 1 : 0);   // slot 5: sort bin + 1
     if (cfg.prof != nullptr && cfg.prof_wave == nullptr && lane == 0) {   // per action type: time of validate+apply
         const int t0 = live ? actions[e * ACTION_WORDS] : 13;
         const int tb = (t0 < 0 || t0 > 12) ? 13 : t0;
@@ -1677,47 +1806,73 @@ __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel)
 }
 
 // ------------------------------------------------------------------------------------------------ sort by action type
-// Counting sort of the games by the type of the action they are about to take (14 bins: 13 types + no-op/padding), so
+// Counting sort of the games by the type of the action they are about to take (18 bins: 13 types, play_dev split by card, no-op/padding), so
 // that k_step's waves are type-homogeneous: the 13-way `switch` no longer serialises inside a wave.  The order inside
 // a bin is irrelevant (games are independent), so block ranges are reserved with atomics.
 DEVI int action_bin(const Ctx& c, const i32* __restrict__ actions, long e) {
-    if (e >= c.n) return 13;
-    const int t = actions[e * ACTION_WORDS];
-    return (t < 0 || t > 12) ? 13 : t;
+    if (e >= c.n) return BIN_NOOP;
+    return bin_of(actions[e * ACTION_WORDS], actions[e * ACTION_WORDS + 4]);
 }
 __global__ __launch_bounds__(BLOCK) void k_classify_hist(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr, u8* __restrict__ atype) {
-    __shared__ u32 hist[16];
-    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __shared__ u32 hist[NBINS];
+    if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (e < c.N) { const int bin = action_bin(c, actions, e); atomicAdd(&hist[bin], 1u); atype[e] = (u8)bin; }
     __syncthreads();
-    if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&ctr[16 + threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x < NBINS && hist[threadIdx.x]) atomicAdd(&ctr[16 + threadIdx.x], hist[threadIdx.x]);
 }
-// atype: the games' bins (written by the histogram pass); ptype: the bins in sorted order, next to perm
+// atype: the games' bins (written by the histogram pass); ptype: the bins in sorted order, next to perm.
+// Every action-type bin starts at a multiple of 64 so that no k_step wave holds two types (a straddling wave would run both
+// types' code, and the launch lasts as long as its slowest wave): perm has SORT_PAD extra slots, the gap behind each bin
+// and the unused tail hold a not-a-game id.
+constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
+constexpr int SORT_PAD = SORT_PAD_WAVES * 64;
 __global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const u8* __restrict__ atype, u32* __restrict__ ctr,
                                                            i32* __restrict__ perm, u8* __restrict__ ptype) {
-    __shared__ u32 hist[16], base[16];
-    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __shared__ u32 hist[NBINS], base[NBINS], start[NBINS + 1], cnt[NBINS];
+    if (threadIdx.x < NBINS) { hist[threadIdx.x] = 0; cnt[threadIdx.x] = ctr[16 + threadIdx.x]; }   // one global round trip
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
     int bin = 0;
     u32 rank = 0;
     if (e < c.N) { bin = atype[e]; rank = atomicAdd(&hist[bin], 1u); }
     __syncthreads();
-    if (threadIdx.x < 14) {
-        u32 start = 0;
-        for (int b = 0; b < (int)threadIdx.x; b++) start += ctr[16 + b];
-        base[threadIdx.x] = start + (hist[threadIdx.x] ? atomicAdd(&ctr[32 + threadIdx.x], hist[threadIdx.x]) : 0u);
+    if (threadIdx.x < NBINS) {
+        u32 st = 0;
+        for (int b = 0; b < (int)threadIdx.x; b++) st += (cnt[b] + 63u) & ~63u;
+        start[threadIdx.x] = st;
+        base[threadIdx.x] = st + (hist[threadIdx.x] ? atomicAdd(&ctr[16 + NBINS + threadIdx.x], hist[threadIdx.x]) : 0u);
     }
     __syncthreads();
     if (e < c.N) { perm[base[bin] + rank] = (i32)e; ptype[base[bin] + rank] = (u8)bin; }
+    if (blockIdx.x == gridDim.x - 1) {                     // (the last block: it is dispatched last and has the fewest games)
+        for (int i = threadIdx.x; i < NBINS * 64; i += BLOCK) {
+            const int b = i >> 6;
+            const u32 slot = start[b] + cnt[b] + (u32)(i & 63);          // gap behind bin b; behind the last bin: the tail
+            const u32 lim = b < NBINS - 1 ? start[b + 1] : (u32)(c.N + SORT_PAD);
+            if (slot < lim) perm[slot] = 0x7fffffff;
+        }
+        // the rest of the tail behind the last bin (at most SORT_PAD slots in all)
+        for (u32 slot = start[NBINS - 1] + cnt[NBINS - 1] + 64u + threadIdx.x; slot < (u32)(c.N + SORT_PAD); slot += BLOCK) perm[slot] = 0x7fffffff;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ random policy
+// position of the nth (0-based) set bit of v, -1 if there is none: branch-free rank search by halves (the peel-off loop
+// `v &= v - 1` ran max-over-lanes(nth) times per wave - up to 70 for an edge pick - in a kernel bound by exactly that)
 DEVI int nth_set(u64 v, int nth) {
-    for (int i = 0; i < nth; i++) v &= v - 1;
-    return __ffsll((long long)v) - 1;
+    if (nth >= __popcll(v)) return -1;
+    int pos = 0;
+    u32 w = (u32)v;
+    int c = __popc(w);
+    if (nth >= c) { nth -= c; w = (u32)(v >> 32); pos = 32; }
+    c = __popc(w & 0xFFFFu); if (nth >= c) { nth -= c; w >>= 16; pos += 16; }
+    c = __popc(w & 0xFFu);   if (nth >= c) { nth -= c; w >>= 8;  pos += 8; }
+    c = __popc(w & 0xFu);    if (nth >= c) { nth -= c; w >>= 4;  pos += 4; }
+    c = __popc(w & 0x3u);    if (nth >= c) { nth -= c; w >>= 2;  pos += 2; }
+    if (nth >= (int)(w & 1u)) pos += 1;
+    return pos;
 }
 DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * k) >> 32)-th
     int k = __popcll(v);
@@ -1810,21 +1965,21 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u3
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
                                                         u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
                                                         u32* __restrict__ zero_me, u32* __restrict__ bins, u8* __restrict__ atype) {
-    __shared__ u32 hist[16];
+    __shared__ u32 hist[NBINS];
     if (bins != nullptr) {
-        if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+        if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
         __syncthreads();
     }
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
-    int t = 13;                                             // padding games: the no-op bin
+    int t = BIN_NOOP;                                       // padding games: the no-op bin
     if (s.e < c.n) {
         u32 m[MASK_WORDS];
 #pragma unroll
         for (int i = 0; i < MASK_WORDS; i++) m[i] = mpk[s.e * MPK_STRIDE + i];
         int a[ACTION_WORDS];
         t = sample_random(c, s, m, step_idx, a, pctr, busy, tag_now, tag_now2);
-        if (t < 0 || t > 12) t = 13;
+        t = bin_of(t, a[4]);
         uint2* row = reinterpret_cast<uint2*>(actions + s.e * ACTION_WORDS);         // 72 B rows: 8 B aligned
 #pragma unroll
         for (int i = 0; i < ACTION_WORDS / 2; i++) row[i] = make_uint2((u32)a[2 * i], (u32)a[2 * i + 1]);
@@ -1832,7 +1987,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
     if (bins != nullptr) {
         if (s.e < c.N) { atomicAdd(&hist[t], 1u); atype[s.e] = (u8)t; }
         __syncthreads();
-        if (threadIdx.x < 14 && hist[threadIdx.x]) atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]);
+        if (threadIdx.x < NBINS && hist[threadIdx.x]) atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]);
     }
 }
 
