@@ -120,19 +120,26 @@ DEVI void stage_in(u32* tile, const u32* __restrict__ R, int e, int lane) {
         }
     }
 }
+// chunks [FIRST, FIRST + NCH) of the 28 16-byte chunks of the hot record, GP = 64 / NCH games per pass: k_step writes back
+// only what its wave's action type can have changed (the type is wave-uniform: sorted, padded bins) - the bitboards
+// (chunks 0..6) change with settle / road / city only, the estimates (7..15) with the resource-moving types.
+template <int NCH = 28, int FIRST = 0>
 DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
-    const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
-    uint4 v[32];
+    constexpr int GP = 64 / NCH, NP = (64 + GP - 1) / GP;
+    const int gi = lane / NCH, q = FIRST + lane - NCH * gi;
+    const bool act = lane < GP * NCH;
+    uint4 v[NP];
 #pragma unroll
-    for (int p = 0; p < 32; p++) {
-        const int g = 2 * p + half;
-        const u32* t = tile + (4 * (lane < 56 ? q : 0)) * TS + g;
+    for (int p = 0; p < NP; p++) {
+        const int g = p * GP + gi;
+        const u32* t = tile + (4 * (act ? q : FIRST)) * TS + (g & 63);
         v[p].x = t[0]; v[p].y = t[TS]; v[p].z = t[2 * TS]; v[p].w = t[3 * TS];
     }
 #pragma unroll
-    for (int p = 0; p < 32; p++) {
-        const int eg = __shfl(e, (2 * p + half) & 63);
-        if (lane < 56 && eg >= 0) reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v[p];
+    for (int p = 0; p < NP; p++) {
+        const int g = p * GP + gi;
+        const int eg = __shfl(e, g & 63);
+        if (act && g < 64 && eg >= 0) reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v[p];
     }
 }
 
@@ -141,11 +148,16 @@ DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
 // lines (measured: 25 us + 8 us per wave, most of k_step); read row-wise - 7 games x 9 lanes x 8 B and 21 games x 3
 // lanes x 16 B per instruction - every line is requested once.  The words go through the (still empty) tile to the
 // owning lane's registers before the state is written into it; all global loads are issued up front.
+// EST = false: the nine estimate chunks (7..15) are left out - the wave's action type neither reads nor writes them
+// (propose, end_turn, robber, knight / victory point / road building cards: 40 % of the waves) - 19 chunks, 3 games per pass.
+template <bool EST>
 DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, const u32* __restrict__ mpk, int e, int lane,
                        int (&a)[ACTION_WORDS], u32 (&m)[MASK_WORDS]) {
-    const int half = lane >= 28 ? 1 : 0, q = lane - 28 * half;
+    constexpr int NCH = EST ? 28 : 19, GP = 64 / NCH, NP = (64 + GP - 1) / GP;
+    const int gi = lane / NCH, q0 = lane - NCH * gi, q = (EST || q0 < 7) ? q0 : q0 + 9;
+    const bool act = lane < GP * NCH;
     const int ag = lane / 9, aq = lane - 9 * ag, mg = lane / 3, mq = lane - 3 * mg;
-    uint4 v[32], mv[4];
+    uint4 v[NP], mv[4];
     uint2 av[10];
 #pragma unroll
     for (int p = 0; p < 10; p++) {
@@ -160,10 +172,10 @@ DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restri
         if (lane < 63 && g < 64 && eg >= 0) mv[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq);
     }
 #pragma unroll
-    for (int p = 0; p < 32; p++) {
-        const int eg = __shfl(e, (2 * p + half) & 63);
+    for (int p = 0; p < NP; p++) {
+        const int g = p * GP + gi, eg = __shfl(e, g & 63);
         v[p] = make_uint4(0, 0, 0, 0);
-        if (lane < 56 && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+        if (act && g < 64 && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
     }
 #pragma unroll
     for (int p = 0; p < 10; p++) {
@@ -185,9 +197,9 @@ DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restri
     for (int i = 0; i < MASK_WORDS; i++) m[i] = tile[(ACTION_WORDS + i) * TS + lane];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < 32; p++) {
-        const int g = 2 * p + half;
-        if (lane < 56) {
+    for (int p = 0; p < NP; p++) {
+        const int g = p * GP + gi;
+        if (act && g < 64) {
             u32* t = tile + (4 * q) * TS + g;
             t[0] = v[p].x; t[TS] = v[p].y; t[2 * TS] = v[p].z; t[3 * TS] = v[p].w;
         }
@@ -1193,7 +1205,9 @@ constexpr int CTR_WORDS = 64;
 constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
 DEVI int bin_of(int t, int card) {
     if (t < 0 || t > 12) return BIN_NOOP;
-    return (t == T_PLAYDEV && card >= 1 && card <= 4) ? 12 + card : t;
+    if (t != T_PLAYDEV) return t;
+    card = min(max(card, 0), 4);                           // the clamp k_step applies to an unvalidated card index
+    return card >= 1 ? 12 + card : t;
 }
 DEVI int type_of_bin(int bin) { return bin <= 12 ? bin : (bin < BIN_NOOP ? T_PLAYDEV : -1); }
 
@@ -1337,7 +1351,14 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     lr_load_nbr(lane, nbr_c, nbr_e);
     int a[ACTION_WORDS];
     u32 m_in[MASK_WORDS];
-    stage_in_all(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
+    // what the wave's action type can touch (wave-uniform: sorted, padded bins): bitboards are written by settle / road /
+    // city only; the estimates are read and written by the resource-moving types only
+    const bool t_board = type == T_SETTLE || type == T_ROAD || type == T_CITY;
+    const bool t_est = t_board || type == T_BUYDEV || bin == 12 + C_YOP || bin == 12 + C_MONO || type == T_EXCHANGE || type == T_RESPOND ||
+                       type == T_ROLL || type == T_STEAL || type == T_DISCARD;
+    const bool w_board = __ballot(type >= 0 && t_board) != 0, w_est = __ballot(type >= 0 && t_est) != 0;
+    if (w_est) stage_in_all<true>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
+    else stage_in_all<false>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
     __builtin_amdgcn_wave_barrier();
     StL s(tile + lane, c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
@@ -1667,7 +1688,9 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
                        m_new, &have_masks);
     // ---- write the tile back, then the new mask rows through the tile
     __builtin_amdgcn_wave_barrier();
-    stage_out(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    if (w_board) stage_out<28, 0>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    else if (w_est) stage_out<21, 7>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    else stage_out<12, 16>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     __builtin_amdgcn_wave_barrier();
     stage_out_masks(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
@@ -1891,10 +1914,11 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u3
 #pragma unroll
     for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
     if (pctr != nullptr) {
+        const u32 own = pctr[s.e];                          // loaded next to the busy byte: one memory round trip, not two
         int b = busy[s.e];
         if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
         if (b) { a[0] = -1; return -1; }
-        step_idx = pctr[s.e];
+        step_idx = own;
         pctr[s.e] = step_idx + 1;
     }
     u64 id = c.env_id0 + (u64)s.e;
