@@ -32,12 +32,12 @@ sys.path.insert(0, ROOT)
 # Algorithmic HBM bytes per game per launch of each kernel (game-major layout of csrc/catan_state.h; derivation in
 # DESIGN.md "Roofline"): the minimum live set an ideal kernel must move, not what the kernel happens to touch.
 ALGO_BYTES = {
-    "k_sample_random": 44 + 5 + 72,                 # packed masks + own hand + action out
+    "k_sample_random": 44 + 5 + 72 + 4,             # packed masks + own hand + action out + the sort's list entry
     # fused step: action in (72) + packed masks in/out (44 + 44) + reward/done out (17) + the HOT record read
     # (112 words x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
     # one bitboard word: ~40 words x 4 B = 160)
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
-    "k_classify": 4 + 4,                            # action type in, permutation out
+    "k_classify": 0,                                # (the sort for caller-supplied actions; the rollout loops sort in the sampler)
     "k_lr_finish": 0,                               # slow path (a few % of the games): latency-bound searches / re-deals,
     "k_lr_heavy": 0,                                # no meaningful byte roofline
     "k_step_finish": 0,

@@ -209,6 +209,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_done, (size_t)e->n);
     // HIP multiplexes streams onto 4 hardware queues; streams that share a queue serialise.  Caller's stream + side +
     // fstream + sstream = 4, so the two tier-1 slots share one stream (tier 1 of an iteration must fit in one iteration).
+    // (A second tier-1 stream was measured with GPU_MAX_HW_QUEUES=4 and 8: 883 M and 447 M env-steps/s against 1 015 M -
+    // two tier-1 launches in flight take the SIMDs from k_step.)
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->fstream[0], hipStreamNonBlocking);
     e->fstream[1] = e->fstream[0];
     for (int i = 0; i < 2 && rc == hipSuccess; i++) {
@@ -224,7 +226,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.perm, (size_t)(e->N + SORT_PAD) * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.lists, (size_t)NBINS * e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, EV_SYNC);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
@@ -232,8 +234,6 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.atype, (size_t)e->N);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ptype, (size_t)(e->N + SORT_PAD));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
@@ -283,7 +283,7 @@ void catan_destroy(catan_env_t* e) {
     if (e->sstream) hipStreamDestroy(e->sstream);
     if (e->s_reward) hipFree(e->s_reward);
     if (e->s_done) hipFree(e->s_done);
-    if (e->pend.perm) hipFree(e->pend.perm);
+    if (e->pend.lists) hipFree(e->pend.lists);
     if (e->side) hipStreamDestroy(e->side);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -291,8 +291,6 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.who) hipFree(e->pend.who);
     if (e->pend.len) hipFree(e->pend.len);
     if (e->pend.busy) hipFree(e->pend.busy);
-    if (e->pend.atype) hipFree(e->pend.atype);
-    if (e->pend.ptype) hipFree(e->pend.ptype);
     if (e->pctr) hipFree(e->pctr);
     if (e->prof_wave) hipFree(e->prof_wave);
     delete e;
@@ -334,11 +332,12 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
                         bool have_hist = false) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    if (!have_hist) hipLaunchKernelGGL(k_classify_hist, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, e->pend.ctr, e->pend.atype);
-    hipLaunchKernelGGL(k_classify_scatter, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u8*)e->pend.atype, e->pend.ctr,
-                       e->pend.perm, e->pend.ptype);
-    if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend);
+    u32* bins = e->pend.ctr + 16 + NBINS * e->pend.bsel;
+    if (!have_hist) {                                     // (the rollout loops sort inside k_sample_random)
+        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists);
+        if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    }
+    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -386,12 +385,12 @@ constexpr int EV_PER_STEP = 10;
 // sample_step != nullptr: the random policy draws the actions first (into `actions`), fused with the sort's histogram
 static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr,
                      const uint32_t* sample_step = nullptr) {
-    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.bsel = 0;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
     if (sample_step)
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
-                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16, e->pend.atype);
+                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16, e->pend.lists);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
     if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, LR_HEAVY_GRID);
@@ -434,7 +433,7 @@ int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) 
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr, (u8*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr, (i32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -490,11 +489,11 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         if (w >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));     // the slow path of window w-2 is complete
         HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
     }
-    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa;
+    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
                        e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa,
-                       e->pend.ctr + 16, e->pend.atype);
+                       e->pend.ctr + 16 + NBINS * fa, e->pend.lists);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
@@ -550,7 +549,8 @@ int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
 // The rollout loops with a hipEvent around every kernel launch (recorded on the stream the kernel runs on).
 // window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host, float[7])
 // receives the summed elapsed milliseconds of:
-// [0] k_sample_random  [1] k_classify_*  [2] k_step  [3] k_lr_finish  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
+// [0] k_sample_random (incl. the sort by action type)  [1] 0 (k_classify only runs for caller-supplied actions)  [2] k_step
+// [3] k_lr_finish  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
@@ -578,9 +578,8 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * K];
         float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random
-        HIPCHK(hipEventElapsedTime(&ms, v[0], v[1])); kernel_ms[1] += ms;      // k_classify_hist + k_classify_scatter
-        HIPCHK(hipEventElapsedTime(&ms, v[1], v[2])); kernel_ms[2] += ms;      // k_step
+        HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (sampling + sort lists)
+        HIPCHK(hipEventElapsedTime(&ms, v[0], v[2])); kernel_ms[2] += ms;      // k_step
         HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[3] += ms;      // k_lr_finish
         if (!slow[s]) continue;
         HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[4] += ms;      // k_lr_heavy

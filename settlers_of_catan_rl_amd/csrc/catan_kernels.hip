@@ -1196,13 +1196,15 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
-struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; i32* perm; i32* resets[2][2]; u8* busy;
-                 u8* atype; u8* ptype;      // action-type bin per game / per sorted slot (13 = no-op, padding or busy)
+struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; i32* resets[2][2]; u8* busy;
+                 i32* lists;                // the sort: game ids per action-type bin, [NBINS][N] (bin b, rank r at b * N + r)
+                 int bsel;                  // which of the two bin-count sets (ctr[16 + NBINS * bsel ..]) this pass uses
                  int fa, ftag, sa, stag; };
 constexpr int CTR_WORDS = 64;
 // Sort bins: 0..12 = the action types, 13..16 = play_dev with card 1..4 (card 0 stays in bin T_PLAYDEV: the five cards run
 // five different code paths, and the launch lasts as long as its slowest wave), NBINS-1 = no-op / busy / padding.
 constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
+static_assert(16 + 2 * NBINS <= CTR_WORDS, "two sets of bin counts live in ctr[16 ..]");
 DEVI int bin_of(int t, int card) {
     if (t < 0 || t > 12) return BIN_NOOP;
     if (t != T_PLAYDEV) return t;
@@ -1329,17 +1331,32 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // counter; mpk: packed masks [N][16], read for validation, rewritten with the masks of the new state.
 __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
-                                             u32* __restrict__ err, StepCfg cfg, Pending pend) {
+                                             u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
     __shared__ u32 tile[ROWS_HOT * TS];
     __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane < CTR_WORDS - 16) pend.ctr[16 + lane] = 0;     // the sort is done with its bins: clear them for the next one
-    const long e = pend.perm[(long)blockIdx.x * 64 + lane];      // games sorted by action type: type-homogeneous waves
+    if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * (pend.bsel ^ 1) + lane] = 0;     // the next pass's bin counts
+    // Wave w takes the sorted positions 64w .. 64w+63.  The sort is never materialised: the sampler / k_classify left the
+    // game ids in one list per bin, every bin occupies ceil(count / 64) waves (type-pure waves), and a wave finds its bin
+    // and offset from the 18 counts.
+    int bin = -1, cnt = 0, first = 0;
+    {
+        const int pos = (int)blockIdx.x * 64;
+        int start = 0;
+#pragma unroll
+        for (int k = 0; k < NBINS; k++) {
+            const int ck = (int)bins[k], len = (ck + 63) & ~63;
+            if (bin < 0 && pos < start + len) { bin = k; cnt = ck; first = pos - start; }
+            start += len;
+        }
+    }
+    if (bin < 0) return;                                   // behind the last bin
+    const int rnk = first + lane;
+    const long e = rnk < cnt ? (long)pend.lists[(long)bin * c.N + rnk] : 0x7fffffffL;
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     const bool live = e < c.n;
-    // bin 13 = explicit no-op (negative type: frozen game), padding, or a busy game (the sampler gives those the no-op):
-    // none of them touches its record
-    const int bin = pend.ptype[(long)blockIdx.x * 64 + lane];
+    // the last bin = explicit no-op (negative type: frozen game) or a busy game (the sampler gives those the no-op): none
+    // of them touches its record
     int type = live ? type_of_bin(bin) : -1;
     if (live && type < 0) {
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1836,50 +1853,25 @@ DEVI int action_bin(const Ctx& c, const i32* __restrict__ actions, long e) {
     if (e >= c.n) return BIN_NOOP;
     return bin_of(actions[e * ACTION_WORDS], actions[e * ACTION_WORDS + 4]);
 }
-__global__ __launch_bounds__(BLOCK) void k_classify_hist(Ctx c, const i32* __restrict__ actions, u32* __restrict__ ctr, u8* __restrict__ atype) {
-    __shared__ u32 hist[NBINS];
+// Appends the block's games to the per-bin lists: rank inside the block from an LDS counter, the block's range in each
+// bin reserved with one global atomic per (block, bin).  bins: this pass's NBINS counts (zero before the first block).
+DEVI void sort_append(long e, bool valid, int bin, u32* hist, u32* base, u32* __restrict__ bins, i32* __restrict__ lists, long N) {
+    u32 rank = 0;
+    if (valid) rank = atomicAdd(&hist[bin], 1u);
+    __syncthreads();
+    if (threadIdx.x < NBINS) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (valid) lists[(long)bin * N + base[bin] + rank] = (i32)e;
+}
+// the sort for caller-supplied actions (catan_step); the rollout loops do it inside k_sample_random
+__global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict__ actions, u32* __restrict__ bins, i32* __restrict__ lists) {
+    __shared__ u32 hist[NBINS], base[NBINS];
     if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
-    if (e < c.N) { const int bin = action_bin(c, actions, e); atomicAdd(&hist[bin], 1u); atype[e] = (u8)bin; }
-    __syncthreads();
-    if (threadIdx.x < NBINS && hist[threadIdx.x]) atomicAdd(&ctr[16 + threadIdx.x], hist[threadIdx.x]);
+    sort_append(e, e < c.n, e < c.n ? action_bin(c, actions, e) : BIN_NOOP, hist, base, bins, lists, c.N);
 }
-// atype: the games' bins (written by the histogram pass); ptype: the bins in sorted order, next to perm.
-// Every action-type bin starts at a multiple of 64 so that no k_step wave holds two types (a straddling wave would run both
-// types' code, and the launch lasts as long as its slowest wave): perm has SORT_PAD extra slots, the gap behind each bin
-// and the unused tail hold a not-a-game id.
 constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
-constexpr int SORT_PAD = SORT_PAD_WAVES * 64;
-__global__ __launch_bounds__(BLOCK) void k_classify_scatter(Ctx c, const u8* __restrict__ atype, u32* __restrict__ ctr,
-                                                           i32* __restrict__ perm, u8* __restrict__ ptype) {
-    __shared__ u32 hist[NBINS], base[NBINS], start[NBINS + 1], cnt[NBINS];
-    if (threadIdx.x < NBINS) { hist[threadIdx.x] = 0; cnt[threadIdx.x] = ctr[16 + threadIdx.x]; }   // one global round trip
-    __syncthreads();
-    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
-    int bin = 0;
-    u32 rank = 0;
-    if (e < c.N) { bin = atype[e]; rank = atomicAdd(&hist[bin], 1u); }
-    __syncthreads();
-    if (threadIdx.x < NBINS) {
-        u32 st = 0;
-        for (int b = 0; b < (int)threadIdx.x; b++) st += (cnt[b] + 63u) & ~63u;
-        start[threadIdx.x] = st;
-        base[threadIdx.x] = st + (hist[threadIdx.x] ? atomicAdd(&ctr[16 + NBINS + threadIdx.x], hist[threadIdx.x]) : 0u);
-    }
-    __syncthreads();
-    if (e < c.N) { perm[base[bin] + rank] = (i32)e; ptype[base[bin] + rank] = (u8)bin; }
-    if (blockIdx.x == gridDim.x - 1) {                     // (the last block: it is dispatched last and has the fewest games)
-        for (int i = threadIdx.x; i < NBINS * 64; i += BLOCK) {
-            const int b = i >> 6;
-            const u32 slot = start[b] + cnt[b] + (u32)(i & 63);          // gap behind bin b; behind the last bin: the tail
-            const u32 lim = b < NBINS - 1 ? start[b + 1] : (u32)(c.N + SORT_PAD);
-            if (slot < lim) perm[slot] = 0x7fffffff;
-        }
-        // the rest of the tail behind the last bin (at most SORT_PAD slots in all)
-        for (u32 slot = start[NBINS - 1] + cnt[NBINS - 1] + 64u + threadIdx.x; slot < (u32)(c.N + SORT_PAD); slot += BLOCK) perm[slot] = 0x7fffffff;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ random policy
 // position of the nth (0-based) set bit of v, -1 if there is none: branch-free rank search by halves (the peel-off loop
@@ -1988,8 +1980,8 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u3
 // 2.5 us slower - the kernel is bound by its divergent sampling chain, not by the row accesses.)
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
                                                         u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
-                                                        u32* __restrict__ zero_me, u32* __restrict__ bins, u8* __restrict__ atype) {
-    __shared__ u32 hist[NBINS];
+                                                        u32* __restrict__ zero_me, u32* __restrict__ bins, i32* __restrict__ lists) {
+    __shared__ u32 hist[NBINS], base[NBINS];
     if (bins != nullptr) {
         if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
         __syncthreads();
@@ -2008,11 +2000,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
 #pragma unroll
         for (int i = 0; i < ACTION_WORDS / 2; i++) row[i] = make_uint2((u32)a[2 * i], (u32)a[2 * i + 1]);
     }
-    if (bins != nullptr) {
-        if (s.e < c.N) { atomicAdd(&hist[t], 1u); atype[s.e] = (u8)t; }
-        __syncthreads();
-        if (threadIdx.x < NBINS && hist[threadIdx.x]) atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]);
-    }
+    if (bins != nullptr) sort_append(s.e, s.e < c.n, t, hist, base, bins, lists, c.N);
 }
 
 // ------------------------------------------------------------------------------------------------ forward search

@@ -5,12 +5,12 @@ import torch
 from settlers_of_catan_rl_amd.env import VecCatanEnv
 env = VecCatanEnv(65536, seed=0)
 env.random_rollout_deferred(3000, 16)
-for budget in (16, 24, 32):
-    for w in (16, 24, 32, 48, 64):
+for budget in (8, 12, 16, 24):
+    for w in (24, 32, 48):
         env.set_lr_budgets(48, budget)
         env.random_rollout_deferred(2 * w, w)
         c0 = int(env.policy_counters().sum()); torch.cuda.synchronize(); t0 = time.perf_counter()
-        env.random_rollout_deferred(2048, w)
+        env.random_rollout_deferred(4096, w)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         c1 = int(env.policy_counters().sum())
-        print(f"budget {budget:3d} window {w:2d}: {(c1-c0)/dt/1e6:7.1f} M/s  {dt/2048*1e6:6.1f} us/iter  active {(c1-c0)/2048/65536:.3f}", flush=True)
+        print(f"budget {budget:3d} window {w:2d}: {(c1-c0)/dt/1e6:7.1f} M/s  {dt/4096*1e6:6.1f} us/iter  active {(c1-c0)/4096/65536:.3f}", flush=True)
