@@ -165,3 +165,32 @@ def test_full_size_invariants_and_sampled_parity(oracle, hip_lib):
         ob = oracle.OracleBatch(1, seed, env_id0=int(i))
         want = ob.run_random_counts(np.array([cnt[i]]))
         assert np.array_equal(blobs[i], want[0]), f"game {i} after {cnt[i]} decisions:\n" + spec.describe_state_diff(want[0], blobs[i])
+
+
+def test_estimate_bytes_above_127_take_the_fieldwise_path(oracle, hip_lib):
+    """The opponent-hand estimates are clipped on packed words while every byte is below 128 (always, in real games);
+    the field-by-field fall-back must give the same result.  States with estimates of 130..220 are imported into both
+    sides and played on: the first visible exchange clips them to the hand total (game.py:938-944) on both."""
+    n, seed = 256, 3
+    env = _env(n, seed)
+    ob = oracle.OracleBatch(n, seed)
+    env.random_rollout(0, 600)
+    ob.run_random(600, n_threads=0)
+    blobs = ob.export()
+    _assert_blobs_equal(env.export_state().cpu().numpy(), blobs, "state before the edit")
+    rng = np.random.default_rng(1)
+    for p in (1, 2, 3, 4):
+        for name in (f"p{p}_opp_max", f"p{p}_opp_min"):
+            off, ln = spec.STATE_OFFSETS[name]
+            hit = rng.random((n, ln)) < 0.3
+            blobs[:, off:off + ln] = np.where(hit, rng.integers(130, 221, (n, ln)), blobs[:, off:off + ln])
+    env.import_state(blobs)
+    ob.import_all(blobs)
+    _assert_blobs_equal(env.export_state().cpu().numpy(), ob.export(), "state after the edit")
+    done_steps = 600
+    for chunk in (1, 3, 40, 400):
+        env.random_rollout(done_steps, chunk)
+        o = ob.run_random(chunk, n_threads=0)
+        done_steps += chunk
+        _assert_blobs_equal(env.export_state().cpu().numpy(), o, f"state {done_steps - 600} steps after the edit")
+    assert env.invalid_action_count() == 0
