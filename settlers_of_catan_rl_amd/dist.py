@@ -35,10 +35,13 @@ def shard(rank, games_per_rank):
 
 
 def barrier(sync_cuda=True):
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    """Device work of this rank done -> all ranks arrived -> (the barrier's own collective done)."""
     if sync_cuda and torch.cuda.is_available():
         torch.cuda.synchronize()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+        if sync_cuda and torch.cuda.is_available():
+            torch.cuda.synchronize()
 
 
 def _reduce(value, op, device=None):
