@@ -201,6 +201,17 @@ int catan_lstm_cell_fwd(const void* gx, const void* gh, const float* c_prev, con
 int catan_lstm_cell_bwd(const void* gx, const void* gh, const float* c_prev, const float* mask, const float* dh, const float* dc, void* dgates,
                         float* dc_prev, int64_t rows, int hidden, int is_bf16, catan_stream_t stream);
 
+/* Masked categorical action head (RL/distributions.py:10-40; sampled / evaluated in RL/models/action_heads_module.py:202-256):
+ * logp = log_softmax(logits + log(mask)) per row.  logits fp32 [rows][K] contiguous; mask fp32 rows of pitch mask_ld (> 0 =
+ * legal; may be a column window of the [rows][325] mask matrix); given int64 [rows] or NULL (evaluate those actions);
+ * u fp32 [rows] uniform in [0,1) or NULL: inverse-CDF sample; both NULL: arg-max.  Outputs: action int64, its log-prob,
+ * the row entropy -sum p logp over p > 0, and the row's log-sum-exp (kept for the backward).
+ * backward: dlogits = dlogp * (onehot(action) - p) - dent * p * (logp + entropy), 0 on masked entries. */
+int catan_categorical_fwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* given, const float* u, int64_t* action,
+                          float* logp, float* entropy, float* lse, int64_t rows, int K, catan_stream_t stream);
+int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* action, const float* lse, const float* entropy,
+                          const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream);
+
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);

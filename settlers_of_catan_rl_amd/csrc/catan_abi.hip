@@ -740,6 +740,26 @@ int catan_lstm_cell_bwd(const void* gx, const void* gh, const float* c_prev, con
                    : lstm_cell_launch<float>(true, gx, gh, c_prev, mask, dh, dc, dgates, dc_prev, rows, hidden, S(stream));
 }
 
+int catan_categorical_fwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* given, const float* u, int64_t* action,
+                          float* logp, float* entropy, float* lse, int64_t rows, int K, catan_stream_t stream) {
+    if (!logits || !mask || !action || !logp || !entropy || !lse || rows <= 0 || K <= 0 || mask_ld < K)
+        return fail(CATAN_EINVAL, "catan_categorical_fwd: bad arguments");
+    hipLaunchKernelGGL(k_categorical_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), logits, mask, (long)mask_ld,
+                       (const long long*)given, u, (long long*)action, logp, entropy, lse, (long)rows, K);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* action, const float* lse, const float* entropy,
+                          const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream) {
+    if (!logits || !mask || !action || !lse || !entropy || !dlogp || !dent || !dlogits || rows <= 0 || K <= 0 || mask_ld < K)
+        return fail(CATAN_EINVAL, "catan_categorical_bwd: bad arguments");
+    hipLaunchKernelGGL(k_categorical_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), logits, mask, (long)mask_ld,
+                       (const long long*)action, lse, entropy, dlogp, dent, dlogits, (long)rows, K);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {
     if (!dst || !src || bytes <= 0 || bytes % 16) return fail(CATAN_EINVAL, "catan_calib_copy: bad arguments");
     hipLaunchKernelGGL(k_calib_copy, dim3(4096), dim3(BLOCK), 0, S(stream), (const uint4*)src, (uint4*)dst, (long)(bytes / 16));

@@ -668,4 +668,66 @@ __global__ __launch_bounds__(256) void k_lstm_cell_bwd(const T* __restrict__ gx,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Masked categorical head (RL/distributions.py:10-40 + the sampling / log-prob / entropy calls of
+// RL/models/action_heads_module.py:202-256): logp = log_softmax(logits + log(mask)); action = given | arg-max | inverse-CDF
+// sample with the caller's uniform u; outputs the action, its log-prob and the row entropy (-sum p logp over p > 0).
+// As torch ops this was a dozen launches per head, twenty head evaluations per policy call - a quarter of the launches of a
+// call that is launch-bound at rollout width.  One lane per row, three passes over the K <= 73 logits of the row (the rows
+// of neighbouring lanes are adjacent, so every cache line is used completely over the k loop).
+__global__ __launch_bounds__(256) void k_categorical_fwd(const float* __restrict__ logits, const float* __restrict__ mask, long mask_ld,
+                                                         const long long* __restrict__ given, const float* __restrict__ u,
+                                                         long long* __restrict__ action, float* __restrict__ logp,
+                                                         float* __restrict__ entropy, float* __restrict__ lse_out, long B, int K) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    const float* z = logits + row * K;
+    const float* m = mask + row * mask_ld;
+    float mx = -INFINITY;
+    int amax = 0;
+    for (int k = 0; k < K; k++) if (m[k] > 0.0f && z[k] > mx) { mx = z[k]; amax = k; }
+    float sum = 0.0f;
+    for (int k = 0; k < K; k++) if (m[k] > 0.0f) sum += __expf(z[k] - mx);
+    const float lse = mx + __logf(sum);
+    const float thr = u ? u[row] : 0.0f;
+    float cdf = 0.0f, ent = 0.0f;
+    int pick = -1, last = amax;
+    for (int k = 0; k < K; k++) {
+        if (!(m[k] > 0.0f)) continue;
+        const float lp = z[k] - lse, p = __expf(lp);
+        if (p > 0.0f) ent -= p * lp;
+        cdf += p;
+        last = k;
+        if (pick < 0 && cdf > thr) pick = k;
+    }
+    int a = given ? (int)given[row] : (u ? (pick >= 0 ? pick : last) : amax);
+    a = min(max(a, 0), K - 1);
+    action[row] = a;
+    logp[row] = (m[a] > 0.0f ? z[a] : -INFINITY) - lse;
+    entropy[row] = ent;
+    lse_out[row] = lse;
+}
+// d logits = dlogp * (onehot(a) - p) - dent * p * (logp + H)
+__global__ __launch_bounds__(256) void k_categorical_bwd(const float* __restrict__ logits, const float* __restrict__ mask, long mask_ld,
+                                                         const long long* __restrict__ action, const float* __restrict__ lse,
+                                                         const float* __restrict__ entropy, const float* __restrict__ dlogp,
+                                                         const float* __restrict__ dent, float* __restrict__ dlogits, long B, int K) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    const float* z = logits + row * K;
+    const float* m = mask + row * mask_ld;
+    float* dz = dlogits + row * K;
+    const int a = (int)action[row];
+    const float l = lse[row], H = entropy[row], gl = dlogp[row], ge = dent[row];
+    for (int k = 0; k < K; k++) {
+        float g = 0.0f;
+        if (m[k] > 0.0f) {
+            const float lp = z[k] - l, p = __expf(lp);
+            g = gl * ((k == a ? 1.0f : 0.0f) - p);
+            if (p > 0.0f) g -= ge * p * (lp + H);
+        }
+        dz[k] = g;
+    }
+}
+
 }  // namespace catan

@@ -39,6 +39,10 @@ def run_evaluation_episodes(env, nets, orders, max_steps=None, deterministic=Fal
     orders_t = torch.as_tensor(orders, device=dev).long()
     policy_of_pid = torch.empty((n, 4), dtype=torch.long, device=dev)
     policy_of_pid.scatter_(1, orders_t - 1, torch.arange(4, device=dev).expand(n, 4))
+    if autocast_dtype is not None:        # weights in the autocast dtype: no per-call casts (policy.inference_copy)
+        cache = {}
+        nets = [cache.setdefault(id(n), n.inference_copy(autocast_dtype)) if (hasattr(n, "inference_copy") and getattr(n, "_inference_dtype", None) is None)
+                else n for n in nets]
     distinct = []
     for net in nets:
         if not any(net is d for d in distinct):

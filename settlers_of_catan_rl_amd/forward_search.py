@@ -389,6 +389,8 @@ class ForwardSearch(object):
             # the reference threads (h, c) of every seat through proposals and simulations (forward_search_policy/policy.py:72-106,
             # zero_opponent_hidden_states); that is not restated here - refuse instead of searching with stale states
             raise NotImplementedError("ForwardSearch does not carry LSTM states; use a feed-forward CatanPolicy")
+        if autocast_dtype is not None and hasattr(policy, "inference_copy") and getattr(policy, "_inference_dtype", None) is None:
+            policy = policy.inference_copy(autocast_dtype)      # weights in the autocast dtype: no per-call casts
         self.policy, self.R = policy, n_roots
         self.max_init_actions, self.max_depth, self.gamma = max_init_actions, max_depth, gamma
         self.S, self.K = sims_per_root, sims_per_round

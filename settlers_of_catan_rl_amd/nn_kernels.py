@@ -219,3 +219,48 @@ def lstm_cell(gx, gh, c_prev, mask=None):
     -> (h, c) fp32 [n, L] with c = sigmoid(f) * (c_prev * mask) + sigmoid(i) * tanh(g), h = sigmoid(o) * tanh(c)."""
     assert gx.shape == gh.shape and gx.dtype == gh.dtype and gx.shape[-1] == 4 * c_prev.shape[-1]
     return _LSTMCell.apply(gx, gh, c_prev, None if mask is None else mask.float().reshape(-1))
+
+
+class _MaskedCategorical(torch.autograd.Function):
+    """csrc/catan_nn.hip k_categorical_fwd / _bwd: one launch for log_softmax(logits + log(mask)), the action (given /
+    arg-max / inverse-CDF sample), its log-prob and the entropy."""
+
+    @staticmethod
+    def forward(ctx, logits, mask, given, u):
+        B, K = logits.shape
+        logits = logits.contiguous()
+        if mask.stride(-1) != 1 or mask.dtype != torch.float32:
+            mask = mask.float().contiguous()
+        action = torch.empty(B, dtype=torch.int64, device=logits.device)
+        logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+        ent, lse = torch.empty_like(logp), torch.empty_like(logp)
+        _lib.check(_lib.lib().catan_categorical_fwd(_ptr(logits), _ptr(mask), mask.stride(0), _ptr(given), _ptr(u), _ptr(action), _ptr(logp),
+                                                    _ptr(ent), _ptr(lse), B, K, _stream()))
+        ctx.save_for_backward(logits, mask, action, lse, ent)
+        ctx.mark_non_differentiable(action)
+        return action, logp, ent
+
+    @staticmethod
+    def backward(ctx, _da, dlogp, dent):
+        logits, mask, action, lse, ent = ctx.saved_tensors
+        B, K = logits.shape
+        dlogits = torch.empty_like(logits)
+        _lib.check(_lib.lib().catan_categorical_bwd(_ptr(logits), _ptr(mask), mask.stride(0), _ptr(action), _ptr(lse), _ptr(ent),
+                                                    _ptr(dlogp.float().contiguous()), _ptr(dent.float().contiguous()), _ptr(dlogits), B, K, _stream()))
+        return dlogits, None, None, None
+
+
+def categorical_supported(logits):
+    return logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+
+
+def masked_categorical(logits, mask, given=None, deterministic=False, generator=None):
+    """logits fp32 [B,K]; mask [B,K] (a column window of the mask matrix is fine); given int64 [B] or None.
+    -> (action int64 [B], log-prob of the action [B], entropy [B])."""
+    B = logits.shape[0]
+    u = None
+    if given is None and not deterministic:
+        u = torch.rand(B, device=logits.device, generator=generator)
+    if given is not None:
+        given = given.contiguous()
+    return _MaskedCategorical.apply(logits, mask, given, u)

@@ -226,11 +226,19 @@ class _Head(nn.Module):
         self.norm = nn.LayerNorm(128)
         self.distribution = _Dist(128, out_dim)
 
-    def logits(self, x, custom=None):
-        # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
+    def logits(self, pre, extra=None, custom=None):
+        """pre [B,128]: mlp_1 applied to the trunk columns of its input, bias included - `_ActionHeads` computes it for all
+        twelve heads in ONE GEMM (the trunk is the same for every head and for every step of the recurrent heads; as
+        separate layers that was 18 GEMMs over a [B, 512+] input plus a concatenation of the trunk with a few conditioning
+        columns each).  extra [B,e] / custom: the conditioning columns that follow the trunk in mlp_1's input."""
+        parts = [] if extra is None else [extra]
         if custom is not None:
-            x = torch.cat((x, _ln(self.custom_norm, _lin(custom, self.custom_mlp.weight, self.custom_mlp.bias), relu=True)), -1)
-        h = _lin(_ln(self.norm, self.mlp_1(x), relu=True), self.mlp_2.weight, self.mlp_2.bias)
+            parts.append(_ln(self.custom_norm, _lin(custom, self.custom_mlp.weight, self.custom_mlp.bias), relu=True))
+        if parts:
+            e = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
+            pre = pre + F.linear(e.to(pre.dtype), self.mlp_1.weight[:, self.mlp_1.in_features - e.shape[-1]:])
+        # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
+        h = _lin(_ln(self.norm, pre, relu=True), self.mlp_2.weight, self.mlp_2.bias)
         return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
 
 
@@ -244,6 +252,16 @@ def _entropy(logp):
     return -(p * torch.where(p > 0, logp, torch.zeros_like(logp))).sum(-1)      # p <= 0 -> contributes 0 (distributions.py:18-20)
 
 
+def _categorical(logits, mask, given, deterministic, generator):
+    """-> (action [B], log-prob of the action [B], entropy [B]) of the masked categorical (distributions.py:10-40): one HIP
+    kernel on the GPU (nn_kernels.masked_categorical), the torch formulation otherwise."""
+    if nn_kernels.categorical_supported(logits):
+        return nn_kernels.masked_categorical(logits, mask, given, deterministic, generator)
+    lp = _masked_logp(logits, mask)
+    a = _choose(lp, given, deterministic, generator)
+    return a, lp.gather(-1, a[:, None]).squeeze(-1), _entropy(lp)
+
+
 def _choose(logp, given, deterministic, generator):
     if given is not None:
         return given
@@ -255,14 +273,16 @@ def _choose(logp, given, deterministic, generator):
 class _ActionHeads(nn.Module):
     def __init__(self, D=512):
         super().__init__()
+        self.D = D
         self.action_heads = nn.ModuleList([
             _Head(D, 13), _Head(D + 2, 54), _Head(D, 73), _Head(D, 19), _Head(D, 5),
             _Head(D, 2, custom_in=12, custom_out=32), _Head(D + 2, 3), _Head(D + 6, 6), _Head(D + 6 + 6, 6),
             _Head(D + 4, 5), _Head(D + 4 + 5, 5), _Head(D, 5)])
 
-    def _recurrent(self, head, x, cur_res, from_hand, acts, deterministic, generator):
-        """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask."""
-        B = x.shape[0]
+    def _recurrent(self, head, pre, fixed, cur_res, from_hand, acts, deterministic, generator):
+        """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask.
+        pre: the head's trunk contribution (constant over the four steps); fixed: conditioning columns before `out` or None."""
+        B, x = pre.shape[0], pre
         out = torch.zeros(B, 6, device=x.device, dtype=torch.float32)
         res = cur_res.clone()
         mask = (res > 0).float() if from_hand else torch.ones_like(res)
@@ -271,10 +291,8 @@ class _ActionHeads(nn.Module):
         ent_sum = torch.zeros(B, device=x.device)
         chosen = []
         for i in range(4):
-            lp = _masked_logp(head.logits(torch.cat((x, out.to(x.dtype)), -1)), mask)
-            a = _choose(lp, None if acts is None else acts[:, i], deterministic, generator)
-            step_lp = lp.gather(-1, a[:, None]).squeeze(-1)
-            ent = _entropy(lp)
+            a, step_lp, ent = _categorical(head.logits(pre, out if fixed is None else torch.cat((fixed, out), -1)), mask,
+                                           None if acts is None else acts[:, i], deterministic, generator)
             onehot = F.one_hot(a, 6).float()
             out = out + onehot
             res = torch.clamp(res - onehot, min=0)
@@ -300,13 +318,17 @@ class _ActionHeads(nn.Module):
         out = torch.zeros(B, 18, dtype=torch.int64, device=dev)
         one = torch.ones(B, device=dev)
 
-        def run(head, x, mask, idx, count, custom=None):
-            lp = _masked_logp(head.logits(x, custom), mask)
-            a = _choose(lp, given(idx), deterministic, generator)
-            return a, lp.gather(-1, a[:, None]).squeeze(-1) * count, (count * _entropy(lp)).mean()
+        # mlp_1 of all twelve heads over the trunk: one [B, D] x [D, 12*128] GEMM (each head's weight columns 0..D-1)
+        D = self.D
+        pre_all = F.linear(main, torch.cat([h.mlp_1.weight[:, :D] for h in H], 0), torch.cat([h.mlp_1.bias for h in H], 0))
+        pre = lambda i: pre_all[:, 128 * i:128 * (i + 1)]
+
+        def run(i, extra, mask, idx, count, custom=None):
+            a, lpa, ent = _categorical(H[i].logits(pre(i), extra, custom), mask, given(idx), deterministic, generator)
+            return a, lpa * count, (count * ent).mean()
 
         # head 0: action type
-        typ, logp, entropy = run(H[0], main, m[:, MO[0]:MO[0] + 13], 0, one)
+        typ, logp, entropy = run(0, None, m[:, MO[0]:MO[0] + 13], 0, one)
         if forced_type is not None:
             forced = forced_type >= 0
             typ = torch.where(forced, forced_type, typ)
@@ -316,25 +338,25 @@ class _ActionHeads(nn.Module):
         # head 1: corner, conditioned on (settlement, city); mask row by type (build_agent_model.py:113-115)
         row = torch.where(typ == T_SETTLE, 0, torch.where(typ == T_CITY, 1, 2))
         cm = m[:, MO[1]:MO[1] + 162].reshape(B, 3, 54).gather(1, row[:, None, None].expand(B, 1, 54)).squeeze(1)
-        x = torch.cat((main, torch.stack((is_(T_SETTLE), is_(T_CITY)), -1).to(main.dtype)), -1)
-        a, lp, e = run(H[1], x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); out[:, 1] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(H[2], main, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); out[:, 2] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(H[3], main, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); out[:, 3] = a; logp = logp + lp; entropy = entropy + e
-        card, lp, e = run(H[4], main, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); out[:, 4] = card; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(H[5], main, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); out[:, 5] = a; logp = logp + lp; entropy = entropy + e
+        x = torch.stack((is_(T_SETTLE), is_(T_CITY)), -1)
+        a, lp, e = run(1, x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); out[:, 1] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(2, None, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); out[:, 2] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(3, None, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); out[:, 3] = a; logp = logp + lp; entropy = entropy + e
+        card, lp, e = run(4, None, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); out[:, 4] = card; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(5, None, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); out[:, 5] = a; logp = logp + lp; entropy = entropy + e
         # head 6: relative player, conditioned on (propose, steal)
         row = torch.where(typ == T_PROPOSE, 0, torch.where(typ == T_STEAL, 1, 2))
         pm = m[:, MO[6]:MO[6] + 9].reshape(B, 3, 3).gather(1, row[:, None, None].expand(B, 1, 3)).squeeze(1)
-        x = torch.cat((main, torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1).to(main.dtype)), -1)
-        a, lp, e = run(H[6], x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); out[:, 6] = a; logp = logp + lp; entropy = entropy + e
+        x = torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1)
+        a, lp, e = run(6, x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); out[:, 6] = a; logp = logp + lp; entropy = entropy + e
         # heads 7 / 8: recurrent give / receive resource lists
         prop = is_(T_PROPOSE)
-        give_out, give_a, lp7, e7 = self._recurrent(H[7], main, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
+        give_out, give_a, lp7, e7 = self._recurrent(H[7], pre(7), None, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
         lp7 = lp7 * prop
         out[:, 7:11] = give_a; logp = logp + lp7; entropy = entropy + (e7 * prop).mean()
         filt7 = (lp7 == 0).float()                                               # action_heads_module.py:175
-        x8 = torch.cat((main, (give_out * (1 - filt7)[:, None]).to(main.dtype)), -1)
-        _, recv_a, lp8, e8 = self._recurrent(H[8], x8, cur_res, False, None if actions is None else actions[:, 11:15], deterministic, generator)
+        _, recv_a, lp8, e8 = self._recurrent(H[8], pre(8), give_out * (1 - filt7)[:, None], cur_res, False,
+                                             None if actions is None else actions[:, 11:15], deterministic, generator)
         out[:, 11:15] = recv_a; logp = logp + lp8 * prop; entropy = entropy + (e8 * prop).mean()
         # heads 9 / 10: resource A / B, conditioned on (play dev, exchange) and on the card (YoP, Monopoly)
         playdev = typ == T_PLAYDEV
@@ -347,12 +369,12 @@ class _ActionHeads(nn.Module):
         mask_c = m9.gather(1, row_c[:, None, None].expand(B, 1, 5)).squeeze(1)
         mask9 = mask_t * torch.where(playdev[:, None], mask_c, torch.ones_like(mask_c))
         cnt9 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, ((card == C_YOP) | (card == C_MONO)).float(), one)
-        x = torch.cat((main, tcond.to(main.dtype), ccond.to(main.dtype)), -1)
-        ra, lp, e = run(H[9], x, mask9, 15, cnt9); out[:, 15] = ra; logp = logp + lp; entropy = entropy + e
+        x = torch.cat((tcond, ccond), -1)
+        ra, lp, e = run(9, x, mask9, 15, cnt9); out[:, 15] = ra; logp = logp + lp; entropy = entropy + e
         cnt10 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, (card == C_YOP).float(), one)
-        x = torch.cat((x, (F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]).to(main.dtype)), -1)
-        a, lp, e = run(H[10], x, m[:, MO[10]:MO[10] + 5], 16, cnt10); out[:, 16] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(H[11], main, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); out[:, 17] = a; logp = logp + lp; entropy = entropy + e
+        x = torch.cat((x, F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]), -1)
+        a, lp, e = run(10, x, m[:, MO[10]:MO[10] + 5], 16, cnt10); out[:, 16] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(11, None, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); out[:, 17] = a; logp = logp + lp; entropy = entropy + e
         return out, logp, entropy
 
 
@@ -462,6 +484,30 @@ class CatanPolicy(nn.Module):
 
     def get_value(self, obs_f, lists, lens, hidden=None, nonterminal=None):
         return self.base(obs_f, lists, lens, hidden, nonterminal)[0]
+
+    def inference_copy(self, dtype=torch.bfloat16):
+        """A no-grad copy for acting under `torch.autocast(dtype)`: the Linear / LSTM / embedding parameters are stored in
+        `dtype` already, so autocast has nothing to cast (with fp32 masters it re-casts every weight and bias on every call:
+        ~200 tiny launches of the ~800 of an `act`, which is launch-bound).  LayerNorm parameters stay fp32 (the HIP
+        LayerNorm kernels read them as fp32).  Refresh with `load_from(master)` after an optimiser step."""
+        import copy
+        c = copy.deepcopy(self).eval().requires_grad_(False)
+        c._inference_dtype = dtype
+        for mod in c.modules():
+            if isinstance(mod, (nn.Linear, nn.Embedding)):
+                mod.to(dtype)
+            elif isinstance(mod, nn.LSTM):         # its two bias vectors are added in fp32 before the cast (_forward_lstm)
+                for name, prm in mod.named_parameters():
+                    if name.startswith("weight"):
+                        prm.data = prm.data.to(dtype)
+        return c
+
+    @torch.no_grad()
+    def load_from(self, master):
+        """Copies (and casts) the parameters of `master` into this copy."""
+        for (k, dst), (k2, src) in zip(self.state_dict().items(), master.state_dict().items()):
+            assert k == k2
+            dst.copy_(src)
 
     def denormalise(self, v):
         return self.VALUE_MEAN + v * self.VALUE_STD          # RL/models/utils.py:20-21

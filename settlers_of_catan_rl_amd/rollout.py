@@ -61,11 +61,13 @@ class RolloutCollector(object):
         if torch.device(self.device).type == "cuda":
             from . import nn_kernels
             nn_kernels.use_tuned_gemms()
+        self.autocast_dtype = autocast_dtype
         self.opponent_nets, self.opp_index = [], None
         if opponents:
             nets = list(opponents)
             self.set_opponents(nets, torch.tensor([[min(j, len(nets) - 1) for j in range(3)]]).expand(self.N, 3))
-        self.autocast_dtype = autocast_dtype
+        # acting nets under autocast hold their weights in the autocast dtype (policy.inference_copy): no per-call casts
+        self._shadow = policy.inference_copy(autocast_dtype) if (autocast_dtype is not None and hasattr(policy, "inference_copy")) else None
         g = torch.Generator(device="cpu").manual_seed(seed)
         # game_manager.py:24-31: a random seat order per game; order[0] is the active player, order[j] plays policy j
         perm = torch.stack([torch.randperm(4, generator=g) for _ in range(self.N)])        # [N,4] pid0 per policy slot
@@ -82,7 +84,8 @@ class RolloutCollector(object):
     def set_opponents(self, nets, opp_index):
         """nets: the distinct opponent nets in play; opp_index int64 [N,3]: which of them plays policy slots 1..3 of
         each game (game_manager.py:15,28-31: the slot -> seat map of a game stays fixed)."""
-        self.opponent_nets = list(nets)
+        self.opponent_nets = [n.inference_copy(self.autocast_dtype) if (getattr(self, "autocast_dtype", None) is not None and hasattr(n, "inference_copy")
+                                                                        and getattr(n, "_inference_dtype", None) is None) else n for n in nets]
         self.opp_index = opp_index.to(self.device).long().contiguous() if len(self.opponent_nets) else None
 
     # game_manager.py:35-59 (the env itself is already reset: EnvWrapper.reset() happened in catan_create / env.reset())
@@ -117,6 +120,8 @@ class RolloutCollector(object):
         """game_manager.py:69-140.  Returns the storage (first T(+1) entries per game are the rollout)."""
         env, st, T, N, dev = self.env, self.storage, self.T, self.N, self.device
         ar = torch.arange(N, device=dev)
+        if self._shadow is not None:
+            self._shadow.load_from(self.policy)  # the central policy as of this rollout (game_manager.py:161-162 `_update_policy`)
         self.racc.zero_()                        # `rewards = {...: 0}` at the start of every gather call (:76)
         self.done_since.zero_()                  # `done_since_prev_turn = [False ...]` (:77)
         term = st.masks[0].clone()               # `terminal_mask = terminal_masks[env_num][0]` (:74-75)
@@ -186,11 +191,11 @@ class RolloutCollector(object):
         and its new state is kept for the games that really step."""
         N = f.shape[0]
         if not self.opponent_nets:
-            groups = [(None, self.policy)]
+            groups = [(None, self.policy if self._shadow is None else self._shadow)]
         else:
             ar = torch.arange(N, device=f.device)
             net_id = torch.where(pol == 0, torch.zeros_like(pol), 1 + self.opp_index[ar, (pol - 1).clamp(min=0)])
-            groups = [((net_id == int(k)).nonzero(as_tuple=True)[0], self.policy if int(k) == 0 else self.opponent_nets[int(k) - 1])
+            groups = [((net_id == int(k)).nonzero(as_tuple=True)[0], (self.policy if self._shadow is None else self._shadow) if int(k) == 0 else self.opponent_nets[int(k) - 1])
                       for k in torch.unique(net_id).tolist()]
         actions = torch.zeros((N, spec.ACTION_WORDS), dtype=torch.int64, device=f.device)
         logp = torch.zeros((N,), dtype=torch.float32, device=f.device)

@@ -332,3 +332,76 @@ def test_lstm_cell_kernel_vs_torch(hip_lib, n, L, masked, dtype):
         assert float(err.max()) < tol, float(err.max())
     assert float((c0.grad.double() - c64.grad).abs().max()) < 1e-5
     assert torch.equal(gx.grad, gh.grad)
+
+
+@pytest.mark.parametrize("B,K,window", [(5000, 13, True), (777, 73, False), (4096, 2, True), (1, 54, False)])
+def test_masked_categorical_kernel_vs_torch(hip_lib, B, K, window):
+    """k_categorical_fwd / _bwd against log_softmax(logits + log(mask)) / gather / entropy in torch (fp64): log-probs and
+    entropies within 2e-6, gradients within 2e-6, arg-max actions equal, sampled actions legal and distributed like p."""
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator(device="cuda").manual_seed(B + K)
+    logits = (torch.randn(B, K, generator=g, device="cuda") * 2).requires_grad_(True)
+    full = (torch.rand(B, 325, generator=g, device="cuda") > 0.4).float()
+    full[:, 7] = 1.0                                                  # at least one legal entry per row
+    mask = full[:, 5:5 + K] if window else full[:, 5:5 + K].contiguous()
+    if K == 2:
+        mask = full[:, 6:8]
+    given = torch.multinomial(mask + 1e-9, 1, generator=g).squeeze(-1)
+    wl, we = torch.randn(B, generator=g, device="cuda"), torch.randn(B, generator=g, device="cuda")
+    a, lp, ent = nn_kernels.masked_categorical(logits, mask, given)
+    assert torch.equal(a, given)
+    (lp * wl + ent * we).sum().backward()
+    z = logits.detach().double().requires_grad_(True)
+    lp_all = torch.log_softmax(z + torch.log(mask.double()), -1)
+    p = lp_all.exp()
+    ent_ref = -(p * torch.where(p > 0, lp_all, torch.zeros_like(lp_all))).sum(-1)
+    lp_ref = lp_all.gather(-1, given[:, None]).squeeze(-1)
+    (lp_ref * wl.double() + ent_ref * we.double()).sum().backward()
+    assert float((lp.double() - lp_ref).abs().max()) < 2e-6 and float((ent.double() - ent_ref).abs().max()) < 2e-6
+    assert float((logits.grad.double() - z.grad).abs().max()) < 2e-6
+    with torch.no_grad():
+        a_det, lp_det, _ = nn_kernels.masked_categorical(logits, mask, None, deterministic=True)
+        assert torch.equal(a_det, lp_all.argmax(-1)) and torch.allclose(lp_det.double(), lp_all.max(-1).values, atol=2e-6)
+        # a given action that the mask forbids has log-prob -inf (as logits + log(0) gives)
+        bad = (mask == 0).float().argmax(-1)
+        has_bad = (mask == 0).any(-1)
+        if bool(has_bad.any()):
+            _, lp_bad, _ = nn_kernels.masked_categorical(logits, mask, bad)
+            assert bool(torch.isinf(lp_bad[has_bad]).all())
+        # sampling: legal, reproducible with the generator, frequencies follow p (row 0 repeated)
+        g2 = torch.Generator(device="cuda").manual_seed(1)
+        a_s, lp_s, _ = nn_kernels.masked_categorical(logits, mask, None, generator=g2)
+        assert bool((mask.gather(-1, a_s[:, None]) > 0).all())
+        assert torch.allclose(lp_s.double(), lp_all.gather(-1, a_s[:, None]).squeeze(-1), atol=2e-6)
+        g3 = torch.Generator(device="cuda").manual_seed(1)
+        assert torch.equal(nn_kernels.masked_categorical(logits, mask, None, generator=g3)[0], a_s)
+        n = 200000
+        rep_l, rep_m = logits[:1].expand(n, K).contiguous(), mask[:1].expand(n, K).contiguous()
+        a_r, _, _ = nn_kernels.masked_categorical(rep_l, rep_m, None, generator=g2)
+        freq = torch.bincount(a_r, minlength=K).double() / n
+        assert float((freq - p[0].detach()).abs().max()) < 0.01
+
+
+def test_inference_copy_acts_like_the_master_under_autocast(hip_lib):
+    """policy.inference_copy: Linear / LSTM / embedding weights stored in bf16 (nothing left for autocast to cast) - the same
+    decisions, values and log-probs as the fp32 master under bf16 autocast, before and after a refresh."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(0)
+    env = VecCatanEnv(512, seed=2); env.random_rollout(0, 400)
+    f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+    for lstm in (False, True):
+        net = CatanPolicy(include_lstm=lstm).cuda()
+        inf = net.inference_copy(torch.bfloat16)
+        assert inf.value_out.weight.dtype == torch.bfloat16 and inf.v_norm_1.weight.dtype == torch.float32
+        assert not any(p.requires_grad for p in inf.parameters())
+        kw = dict(hidden=net.initial_hidden(512), nonterminal=torch.ones(512, device="cuda")) if lstm else {}
+        for rnd in range(2):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                a = net.act(f, lists, lens, masks, deterministic=True, **kw)
+                b = inf.act(f, lists, lens, masks, deterministic=True, **kw)
+            assert torch.equal(a[1], b[1]) and torch.allclose(a[0], b[0], atol=1e-6) and torch.allclose(a[2], b[2], atol=1e-6)
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.01 * torch.randn_like(p))
+            inf.load_from(net)

@@ -66,7 +66,7 @@ def test_grouped_inference_routes_each_seat_to_its_net():
     from settlers_of_catan_rl_amd.rollout import RolloutCollector
     N = 37
     col = RolloutCollector.__new__(RolloutCollector)     # only the routing is under test
-    col.policy, col.autocast_dtype, col.sample_gen, col.recurrent = _TagNet(0), None, None, False
+    col.policy, col.autocast_dtype, col.sample_gen, col.recurrent, col._shadow = _TagNet(0), None, None, False, None
     col.N, col.device = N, torch.device("cpu")
     g = torch.Generator().manual_seed(3)
     opp_index = torch.randint(0, 5, (N, 3), generator=g)

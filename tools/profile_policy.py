@@ -19,12 +19,19 @@ def act():
 for _ in range(3): act()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): act()
-torch.cuda.synchronize(); print(f"act B={B}: {(time.perf_counter()-t0)/5*1e3:.1f} ms")
+torch.cuda.synchronize(); print(f"act B={B}: {(time.perf_counter()-t0)/5*1e3:.1f} ms (fp32 master weights under autocast)")
+master = net
+net = master.inference_copy(torch.bfloat16)          # what the rollout collector / evaluation / forward search act with
+for _ in range(3): act()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): act()
+torch.cuda.synchronize(); print(f"act B={B}: {(time.perf_counter()-t0)/5*1e3:.1f} ms (inference copy: bf16 weights)")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     act(); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
 ev = prof.key_averages()
 print("total kernels launched:", sum(e.count for e in ev if e.device_type is not None and "cuda" in str(e.device_type).lower()))
+net = master
 # minibatch step
 Bm = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 _, a, _ = act()
