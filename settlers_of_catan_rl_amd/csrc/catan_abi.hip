@@ -59,13 +59,21 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 template <class T>
 static int attn_dispatch(bool bwd, const void* qkv, const int* lens, const void* dout, void* out, long B, int L, int H, int HD, hipStream_t st) {
     const T* q = (const T*)qkv;
+    // bf16: the MFMA kernels (one wave per sequence); fp32 and unaligned buffers: the VALU kernels
+    const bool mfma = sizeof(T) == 2 && (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0;
+    const unsigned nb4 = (unsigned)((B + 3) / 4);
+    const unsigned short* q16 = (const unsigned short*)qkv;
     if (L == 19 && H == 4 && HD == 16) {
         unsigned nb = (unsigned)((B + 2) / 3);
-        if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
+        if (mfma && !bwd) hipLaunchKernelGGL((k_attn_mfma_fwd<19, 4, 16>), dim3(nb4), dim3(256), 0, st, q16, lens, (unsigned short*)out, B);
+        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<19, 4, 16>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
         else hipLaunchKernelGGL((k_attn_bwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
     } else if (L == 25 && H == 4 && HD == 4) {
         unsigned nb = (unsigned)((B + 1) / 2);
-        if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
+        if (mfma && !bwd) hipLaunchKernelGGL((k_attn_mfma_fwd<25, 4, 4>), dim3(nb4), dim3(256), 0, st, q16, lens, (unsigned short*)out, B);
+        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<25, 4, 4>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
         else hipLaunchKernelGGL((k_attn_bwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
     } else return fail(CATAN_EINVAL, "catan_attention: unsupported (L, heads, head_dim); built for (19,4,16) and (25,4,4)");
     HIPCHK(hipGetLastError());

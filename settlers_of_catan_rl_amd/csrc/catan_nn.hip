@@ -730,4 +730,214 @@ __global__ __launch_bounds__(256) void k_categorical_bwd(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention on MFMA for bf16 (L = 19 tiles x 4 heads x 16; L = 25 cards x 4 heads x 4 with a key-length mask): the VALU
+// kernels above spend 115 k FMAs per tile sequence in the backward and ran 4-5x off the HBM floor (config-3 minibatch: 19 of
+// 86 ms in attention).  One wave = one sequence,
+// one v_mfma_f32_32x32x16_bf16 per product, everything TRANSPOSED so that no operand ever changes lanes:
+//   S^T = K Q^T           A = K rows j, B = Q rows i: both 16-byte global loads (lane = row, 8 of the 16 head dims per half)
+//   C layout of a 32x32 product: lane holds column (lane & 31) and rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15
+//   -> a lane owns query i and sixteen of the 32 (padded) keys: the softmax over keys is in-lane plus ONE xor-32 exchange
+//   O^T = V^T P^T         B = P^T straight from those registers: the contraction index may be permuted freely as long as A
+//                         uses the same permutation - k-step s, half h, element t  <->  key 16 s + 4 h + t (t < 4),
+//                         16 s + 8 + 4 h + (t - 4) (t >= 4), i.e. registers 8 s .. 8 s + 7; A = V^T rows d read from an LDS
+//                         copy of V transposed per head as two 8-byte runs
+//   O^T lands as lane = query i, rows = head dims: two 8-byte stores per head.
+// The backward adds the same products in the other orientation (lane = key j) for dK / dV, exchanging only the per-query
+// softmax statistics through LDS.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int AT_LP = 36;                                   // LDS pitch of a transposed row (32 keys / queries + pad)
+
+__device__ __forceinline__ unsigned short f2bf(float x) { const __hip_bfloat16 h = __float2bfloat16(x); return *reinterpret_cast<const unsigned short*>(&h); }
+__device__ __forceinline__ bf16x8_t pack_bf8(const float* v) {
+    union { bf16x8_t f; unsigned short u[8]; } r;
+#pragma unroll
+    for (int t = 0; t < 8; t++) r.u[t] = f2bf(v[t]);
+    return r.f;
+}
+__device__ __forceinline__ bf16x8_t zero_bf8() { union { bf16x8_t f; uint4 u; } r; r.u = make_uint4(0, 0, 0, 0); return r.f; }
+// the 8 k-elements of this lane half for one head slice of a row: head dims 8 hf .. 8 hf + 7 (HD = 16) or dims 0..3 + zeros (HD = 4)
+template <int HD>
+__device__ __forceinline__ bf16x8_t ld_frag(const unsigned short* head, int hf, bool ok) {
+    union { bf16x8_t f; uint4 u; uint2 v[2]; } r;
+    r.u = make_uint4(0, 0, 0, 0);
+    if constexpr (HD == 16) { if (ok) r.u = *reinterpret_cast<const uint4*>(head + 8 * hf); }
+    else { if (ok && hf == 0) r.v[0] = *reinterpret_cast<const uint2*>(head); }
+    return r.f;
+}
+// A operand from a transposed LDS row: the two 4-element runs of k-step s for this lane half
+__device__ __forceinline__ bf16x8_t ld_runs(const unsigned short* row, int s, int hf) {
+    union { bf16x8_t f; uint2 u[2]; } r;
+    r.u[0] = *reinterpret_cast<const uint2*>(row + 16 * s + 4 * hf);
+    r.u[1] = *reinterpret_cast<const uint2*>(row + 16 * s + 8 + 4 * hf);
+    return r.f;
+}
+// stage one of q / k / v / dout of a sequence transposed: dst[dim][j] (j < L written; the rest stays zero)
+template <int L, int D>
+__device__ __forceinline__ void stage_transposed(unsigned short* dst, const unsigned short* src, int row_stride, int lane) {
+    constexpr int CH = D / 8;
+    for (int x = lane; x < L * CH; x += 64) {
+        const int j = x / CH, c = x - j * CH;                  // row j, 8-element chunk c
+        const uint4 u = *reinterpret_cast<const uint4*>(src + j * row_stride + c * 8);
+        const unsigned w[4] = { u.x, u.y, u.z, u.w };
+#pragma unroll
+        for (int e = 0; e < 8; e++) dst[(c * 8 + e) * AT_LP + j] = (unsigned short)(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu);
+    }
+}
+// rows d < HD of a [d][col] product sit in registers 0..7 (HD = 16: d = 4 hf + r, 8 + 4 hf + (r - 4)) or 0..3 of half 0 (HD = 4)
+template <int HD>
+__device__ __forceinline__ void st_head(unsigned short* head, const f32x16_t& c, int hf) {
+    if constexpr (HD == 16) {
+        *reinterpret_cast<uint2*>(head + 4 * hf) = make_uint2(f2bf(c[0]) | ((unsigned)f2bf(c[1]) << 16), f2bf(c[2]) | ((unsigned)f2bf(c[3]) << 16));
+        *reinterpret_cast<uint2*>(head + 8 + 4 * hf) = make_uint2(f2bf(c[4]) | ((unsigned)f2bf(c[5]) << 16), f2bf(c[6]) | ((unsigned)f2bf(c[7]) << 16));
+    } else {
+        if (hf == 0) *reinterpret_cast<uint2*>(head) = make_uint2(f2bf(c[0]) | ((unsigned)f2bf(c[1]) << 16), f2bf(c[2]) | ((unsigned)f2bf(c[3]) << 16));
+    }
+}
+
+template <int L, int H, int HD>
+__global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
+                                                       unsigned short* __restrict__ out, long B) {
+    constexpr int D = H * HD;
+    static_assert(L <= 32 && D % 8 == 0 && (HD == 16 || HD == 4), "one 32x32 tile per product");
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[4][D * AT_LP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
+    const long b = (long)blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    unsigned short* vt = Vt[wv];
+    for (int x = lane; x < D * AT_LP / 4; x += 64) reinterpret_cast<uint2*>(vt)[x] = make_uint2(0, 0);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned short* base = qkv + b * (long)(L * 3 * D);
+    stage_transposed<L, D>(vt, base + 2 * D, 3 * D, lane);
+    __builtin_amdgcn_wave_barrier();
+    const bool rowok = c31 < L;
+    const int len = lens ? lens[b] : L;
+    const float scale = HD == 16 ? 0.25f : 0.5f;               // 1 / sqrt(HD)
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < H; h++) {
+        const bf16x8_t ka = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
+        const bf16x8_t qb = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);
+        const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);   // S^T[j][i]
+        float p[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            p[r] = j < len ? st[r] * scale : -INFINITY;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; r++) p[r] *= inv;
+        f32x16_t ot = zero16;
+        const unsigned short* vrow = vt + (h * HD + (c31 % HD)) * AT_LP;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(vrow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), ot, 0, 0, 0);   // O^T[d][i]
+        if (rowok) st_head<HD>(out + (b * L + c31) * (long)D + h * HD, ot, hf);
+    }
+}
+
+// dqkv [B][L][3][D] from dout [B][L][D]; the probabilities are recomputed in both orientations (see above)
+template <int L, int H, int HD>
+__global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
+                                                       const unsigned short* __restrict__ dout, unsigned short* __restrict__ dqkv, long B) {
+    constexpr int D = H * HD;
+    __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][D * AT_LP];          // K^T, Q^T, dO^T: [dim][key / query]
+    __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: row max, 1 / row sum, delta
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
+    const long b = (long)blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    unsigned short* kt = Tt[wv][0]; unsigned short* qt = Tt[wv][1]; unsigned short* dot = Tt[wv][2];
+    for (int x = lane; x < 3 * D * AT_LP / 4; x += 64) reinterpret_cast<uint2*>(kt)[x] = make_uint2(0, 0);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned short* base = qkv + b * (long)(L * 3 * D);
+    const unsigned short* dob = dout + b * (long)(L * D);
+    unsigned short* gb = dqkv + b * (long)(L * 3 * D);
+    stage_transposed<L, D>(kt, base + D, 3 * D, lane);
+    stage_transposed<L, D>(qt, base, 3 * D, lane);
+    stage_transposed<L, D>(dot, dob, D, lane);
+    __builtin_amdgcn_wave_barrier();
+    const bool rowok = c31 < L;
+    const int len = lens ? lens[b] : L;
+    const float scale = HD == 16 ? 0.25f : 0.5f;
+    float* stat = &Stat[wv][0][0];
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < H; h++) {
+        const bf16x8_t qr = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);            // row c31 of Q, K, V, dO
+        const bf16x8_t kr = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
+        const bf16x8_t vr = ld_frag<HD>(base + (c31 * 3 + 2) * D + h * HD, hf, rowok);
+        const bf16x8_t gr = ld_frag<HD>(dob + c31 * D + h * HD, hf, rowok);
+        const int trow = (h * HD + (c31 % HD)) * AT_LP;                                            // this lane's transposed row (dim d)
+        // ---- lane = query i, registers = keys j
+        {
+            const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qr, zero16, 0, 0, 0);    // S^T[j][i]
+            const f32x16_t dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr, gr, zero16, 0, 0, 0);   // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+            float p[16], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                p[r] = j < len ? st[r] * scale : -INFINITY;
+                mx = fmaxf(mx, p[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float delta = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { p[r] *= inv; delta += p[r] * dpt[r]; }
+            delta += __shfl_xor(delta, 32);
+            if (hf == 0) { stat[c31] = mx; stat[32 + c31] = inv; stat[64 + c31] = delta; }
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[r] = p[r] * (dpt[r] - delta) * scale;                     // dS^T[j][i]
+            f32x16_t dq = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(kt + trow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
+            if (rowok) st_head<HD>(gb + (c31 * 3 + 0) * D + h * HD, dq, hf);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = key j, registers = queries i
+        {
+            const f32x16_t s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kr, zero16, 0, 0, 0);     // S[i][j]
+            const f32x16_t dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr, vr, zero16, 0, 0, 0);     // dP[i][j] = sum_d dO[i][d] V[j][d]
+            const bool keyok = c31 < len;                       // a masked key has probability 0 for every query
+            float p[16], ds[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {                    // registers 4 q4 .. 4 q4 + 3 <-> queries 8 q4 + 4 hf .. + 3
+                const float4 m4 = *reinterpret_cast<const float4*>(stat + 8 * q4 + 4 * hf);
+                const float4 i4 = *reinterpret_cast<const float4*>(stat + 32 + 8 * q4 + 4 * hf);
+                const float4 d4 = *reinterpret_cast<const float4*>(stat + 64 + 8 * q4 + 4 * hf);
+                const float mm[4] = { m4.x, m4.y, m4.z, m4.w }, ii[4] = { i4.x, i4.y, i4.z, i4.w }, dd[4] = { d4.x, d4.y, d4.z, d4.w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = 4 * q4 + e;
+                    p[r] = keyok ? __expf(s2[r] * scale - mm[e]) * ii[e] : 0.0f;
+                    ds[r] = p[r] * (dp[r] - dd[e]) * scale;
+                }
+            }
+            f32x16_t dk = zero16, dv = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(qt + trow, s, hf) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(dot + trow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
+            }
+            if (rowok) {
+                st_head<HD>(gb + (c31 * 3 + 1) * D + h * HD, dk, hf);
+                st_head<HD>(gb + (c31 * 3 + 2) * D + h * HD, dv, hf);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace catan
