@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
 
 
-def cpu_baseline(sample_envs=2048, sample_steps=1024):
+def cpu_baseline(sample_envs=16384, sample_steps=2048):
     """The CPU oracle (port of the reference algorithm, bit-identical to the reference by the fixtures) on the host
     cores of this box, bounded sample of the same workload (same seeds/sampler)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,7 +60,7 @@ def cpu_baseline(sample_envs=2048, sample_steps=1024):
     t0 = time.perf_counter()
     b.run_random(sample_steps, want_blobs=False, n_threads=cores)
     dt_all = time.perf_counter() - t0
-    one = oracle_lib.OracleBatch(max(64, sample_envs // 16), seed=0)
+    one = oracle_lib.OracleBatch(max(64, sample_envs // 32), seed=0)
     t0 = time.perf_counter()
     one.run_random(sample_steps, want_blobs=False, n_threads=1)
     dt_one = time.perf_counter() - t0
