@@ -91,8 +91,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
     from settlers_of_catan_rl_amd import dist as cdist
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, local_rank, world = cdist.init_from_env()          # backend "nccl" == RCCL over xGMI
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    # backend "nccl" == RCCL over xGMI; CATAN_DIST_BACKEND=gloo lets two ranks share one GPU (smoke test of this code path)
+    rank, local_rank, world = cdist.init_from_env(backend=os.environ.get("CATAN_DIST_BACKEND") or None)
 
     from settlers_of_catan_rl_amd.env import VecCatanEnv
 
