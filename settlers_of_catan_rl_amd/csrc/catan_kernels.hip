@@ -666,7 +666,11 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
 // scratch of the one-wave-per-game re-deal (wave_reset_game): the game's Philox stream is generated in bulk by all 64 lanes
 // (RND_WORDS consecutive draws), then one lane walks it; its shuffle arrays are LDS bytes.
 constexpr int RND_WORDS = 768;
-struct ResetScratch { u32 rnd[RND_WORDS]; u8 arr[32]; u8 terr[32]; };
+constexpr int TOK_HORIZON = 256;    // start offsets examined per round of the parallel number-token loop
+constexpr int TOK_DRAWS = 48;       // draws one shuffle of the 18 tokens may take in that loop (mean 23; longer ones fall back)
+constexpr int TOK_CHAIN = 48;       // consecutive attempts examined per round
+struct ResetScratch { u32 rnd[RND_WORDS]; u8 arr[32]; u8 terr[32];
+                      unsigned short endp[TOK_HORIZON]; unsigned short chain[TOK_CHAIN + 1]; u8 pm[18][64]; int tok_state[4]; };
 // RNG view over the pre-generated words, falling back to inline Philox beyond them (p99.9 of a reset is ~1250 draws)
 struct RngBuf {
     const u32* buf; u32 base, avail;      // buf[i] = draw number base + i
@@ -690,24 +694,103 @@ DEVI void shuffle_bytes(u8* a, int n, RngBuf& rng) {     // np.random.shuffle on
         const u8 t = a[i]; a[i] = a[j]; a[j] = t;
     }
 }
-// Board.reset + Game.reset (board.py:67-100, game.py:39-136), executed by ONE lane on LDS byte arrays and the pre-generated
-// random words.
+// Board.reset + Game.reset (board.py:67-100, game.py:39-136) on LDS byte arrays and the pre-generated random words.
+// The shuffles are serial by nature and run on ONE lane - except the rejection loop of the number tokens (board.py:79-81:
+// re-shuffle the 18 tokens until no two red numbers touch: 8 attempts on average, geometric tail), which made the re-deal the
+// longest pole of a lock-step step (a step waits for the slowest of its ~40 re-deals).  That loop runs on the whole wave:
+//   (1) a shuffle started at stream offset q always reads q, q+1, ... - only HOW MANY words it takes depends on the data - so
+//       every lane finds, for its share of the next TOK_HORIZON start offsets, where a shuffle started there would end;
+//   (2) one lane follows these end offsets: the start offsets of the next TOK_CHAIN attempts;
+//   (3) lane k replays attempt k on an identity array: the permutation that attempt applies;
+//   (4) the attempts are then applied in order - one parallel gather each - until the first board without touching reds.
+// Same draws, same order, same result as the serial loop (which remains the fall-back when a shuffle needs more than
+// TOK_DRAWS words or the pre-generated words run out).
+DEVI u32 fy_mask(int i) { return 0xFFFFFFFFu >> __clz((u32)i); }
 template <class S>
-DEVI void reset_game_lds(const S& s, RngBuf& rng, ResetScratch& sc, int hot_rows) {
+DEVI void reset_part1(const S& s, RngBuf& rng, ResetScratch& sc, int hot_rows) {       // lane 0
     u8* arr = sc.arr; u8* terr = sc.terr;
     for (int r = 0; r < hot_rows; r++) if (r != W_RNG) s.sw(r, 0);
     for (int i = 0; i < 19; i++) terr[i] = (u8)(i == 0 ? 0 : (i < 4 ? 1 : (i < 8 ? 5 : (i < 12 ? 2 : (i < 15 ? 3 : 4)))));
     shuffle_bytes(terr, 19, rng);                              // board.py:72
-    {   // board.py:25: 5 2 6 3 8 10 9 12 11 4 8 10 9 4 5 6 3 11, packed as nibbles (no constant-memory table)
-        for (int i = 0; i < 16; i++) arr[i] = (u8)((0x6549A84BC9A83625ull >> (4 * i)) & 15);   // entry i in bits 4i..4i+3
-        arr[16] = 3; arr[17] = 11;
+    // board.py:25: 5 2 6 3 8 10 9 12 11 4 8 10 9 4 5 6 3 11, packed as nibbles (no constant-memory table)
+    for (int i = 0; i < 16; i++) arr[i] = (u8)((0x6549A84BC9A83625ull >> (4 * i)) & 15);       // entry i in bits 4i..4i+3
+    arr[16] = 3; arr[17] = 11;
+    sc.tok_state[0] = (int)(rng.slow.draws - rng.base);        // stream offset of the first token shuffle
+}
+// all 64 lanes; returns (on every lane) whether the board is complete; sc.tok_state[0] = stream offset behind the loop
+DEVI bool reset_tokens_parallel(ResetScratch& sc, int lane) {
+    // per lane = tile t: its index in the spiral placement order, its neighbours, its terrain
+    int pidx = 0;
+#pragma unroll
+    for (int i = 0; i < 19; i++) if (topo_placement(i) == lane) pidx = i;
+    const u32 nbr = lane < 19 ? topo_tile_nbr_mask(lane) : 0u;
+    const bool desert = lane < 19 && sc.terr[lane] == 0;
+    const int dpos = __shfl(pidx, __ffsll((long long)__ballot(desert)) - 1);      // the desert takes no token
+    const int tok_of_tile = pidx - (pidx > dpos ? 1 : 0);
+    int off = sc.tok_state[0];
+    for (int round = 0; round < 8; round++) {                                      // (bounded; the fall-back finishes)
+        if (off + TOK_HORIZON + TOK_DRAWS > RND_WORDS) return false;
+        // (1) end offset of a shuffle started at off + q
+        for (int q = lane; q < TOK_HORIZON; q += 64) {
+            int i = 17, endq = 0xFFFF;
+#pragma unroll 8
+            for (int t = 0; t < TOK_DRAWS; t++) {
+                const u32 w = sc.rnd[off + q + t];
+                if (i >= 1 && (w & fy_mask(i)) <= (u32)i) { i--; if (i == 0) endq = q + t + 1; }
+            }
+            sc.endp[q] = (unsigned short)endq;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (2) the chain of attempt starts (relative to off)
+        if (lane == 0) {
+            int q = 0, n = 0;
+            while (n < TOK_CHAIN && q < TOK_HORIZON) { sc.chain[n++] = (unsigned short)q; const int e = sc.endp[q]; if (e == 0xFFFF) { q = 0xFFFF; break; } q = e; }
+            sc.chain[n] = (unsigned short)q;                    // where attempt n would start (0xFFFF: attempt n-1 needs the fall-back)
+            sc.tok_state[1] = n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n = sc.tok_state[1];
+        // (3) lane k: the permutation of attempt k (an attempt without an end offset is never applied)
+        if (lane < n && sc.chain[lane + 1] != 0xFFFF) {
+#pragma unroll
+            for (int r = 0; r < 18; r++) sc.pm[r][lane] = (u8)r;
+            const int q = sc.chain[lane];
+            int i = 17;
+            for (int t = 0; t < TOK_DRAWS && i >= 1; t++) {
+                const u32 v = sc.rnd[off + q + t] & fy_mask(i);
+                if (v <= (u32)i) { const u8 x = sc.pm[i][lane]; sc.pm[i][lane] = sc.pm[v][lane]; sc.pm[v][lane] = x; i--; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (4) apply the attempts in order until a board has no two touching reds
+        for (int k = 0; k < n; k++) {
+            if (sc.chain[k + 1] == 0xFFFF) { if (lane == 0) sc.tok_state[0] = off + sc.chain[k]; __builtin_amdgcn_wave_barrier(); return false; }
+            const int nv = lane < 18 ? sc.arr[sc.pm[lane][k]] : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 18) sc.arr[lane] = (u8)nv;
+            __builtin_amdgcn_wave_barrier();
+            const int v = (lane < 19 && !desert) ? sc.arr[tok_of_tile] : 7;
+            const bool red = lane < 19 && (v == 6 || v == 8);
+            const u32 reds = (u32)__ballot(red);
+            const bool clash = __ballot(red && (nbr & reds)) != 0;
+            if (!clash) { if (lane == 0) sc.tok_state[0] = off + sc.chain[k + 1]; __builtin_amdgcn_wave_barrier(); return true; }
+        }
+        off += sc.chain[n];                                     // all examined attempts failed: the next round starts behind them
+        if (lane == 0) sc.tok_state[0] = off;
+        __builtin_amdgcn_wave_barrier();
     }
+    return false;
+}
+template <class S>
+DEVI void reset_part2(const S& s, RngBuf& rng, ResetScratch& sc, bool tokens_done) {   // lane 0
+    u8* arr = sc.arr; u8* terr = sc.terr;
     // tile terrains in registers, indexed by constants below
     int tr[19];
 #pragma unroll
     for (int t = 0; t < 19; t++) tr[t] = terr[t];
-    bool ok = false;
-    do {                                                       // board.py:79-81, 50-65
+    rng.slow.draws = rng.base + (u32)sc.tok_state[0];
+    bool ok = tokens_done;
+    while (!ok) {                                              // board.py:79-81, 50-65 (serial form: the fall-back)
         shuffle_bytes(arr, 18, rng);
         u32 reds = 0;
         int n = 0;
@@ -721,7 +804,7 @@ DEVI void reset_game_lds(const S& s, RngBuf& rng, ResetScratch& sc, int hot_rows
         ok = true;
 #pragma unroll
         for (int t = 0; t < 19; t++) if (((reds >> t) & 1) && (topo_tile_nbr_mask(t) & reds)) ok = false;
-    } while (!ok);
+    }
     {
         int n = 0;
 #pragma unroll
@@ -1805,11 +1888,15 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
     }
     for (int r = ROWS_HOT + lane; r < REC; r += 64) c.R[e * REC + r] = 0;     // cold part: empty card lists
     __builtin_amdgcn_wave_barrier();
+    RngBuf rb;
+    rb.buf = sc.rnd; rb.base = blk0 * 4; rb.avail = RND_WORDS; rb.slow = mine;
+    const long long t0 = prof ? wall_clock64() : 0;
+    if (lane == 0) reset_part1(s, rb, sc, ROWS_HOT);
+    __builtin_amdgcn_wave_barrier();
+    const bool tokens_done = reset_tokens_parallel(sc, lane);
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        RngBuf rb;
-        rb.buf = sc.rnd; rb.base = blk0 * 4; rb.avail = RND_WORDS; rb.slow = mine;
-        const long long t0 = prof ? wall_clock64() : 0;
-        reset_game_lds(s, rb, sc, ROWS_HOT);
+        reset_part2(s, rb, sc, tokens_done);
         if (prof) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
             atomicAdd(&prof[5], dt); atomicMax(&prof[PROF_PHASES + 5], dt);
