@@ -5,8 +5,8 @@ import torch
 from settlers_of_catan_rl_amd.env import VecCatanEnv
 env = VecCatanEnv(65536, seed=0)
 env.random_rollout_deferred(3000, 16)
-for budget in (8, 12, 16, 24):
-    for w in (24, 32, 48):
+for budget in (16, 24, 32):
+    for w in (16, 24, 32, 48):
         env.set_lr_budgets(48, budget)
         env.random_rollout_deferred(2 * w, w)
         c0 = int(env.policy_counters().sum()); torch.cuda.synchronize(); t0 = time.perf_counter()
