@@ -376,7 +376,8 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
         HIPCHK(hipEventRecord(e->ev_join, e->side));
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
-    hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len);
+    hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len,
+                       heavy_grid == LR_HEAVY_GRID ? LR_ROUND_LOCKSTEP : LR_ROUND);
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[7], st));

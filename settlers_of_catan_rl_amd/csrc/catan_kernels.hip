@@ -469,7 +469,8 @@ constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
 constexpr int LR_BUDGET = 48;       // tier-1 double-iterations per lane before the game is handed to tier 2
 constexpr int LR_HEAVY_THREADS = 1024;
 constexpr int LR_POOL = 3072;       // tier-2 workgroup pool entries
-constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round
+constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round: deferred windows (throughput)
+constexpr int LR_ROUND_LOCKSTEP = 8;    // ... inside a lock-step step (latency: the step waits for the deepest search; swept)
 
 struct Dfs { bool active; int cur, d, base, best; u64 seen, cand; };
 struct DfsQueue { u64* seen; unsigned short* cd; int* n; int cap; };
@@ -614,7 +615,7 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
 // (lock-step) get 8 workgroups each for latency, many (a deferred window) share the grid for throughput.
 // req[i] = game | pid0 << 56; out_len[game] (zeroed by k_step) receives the path length.
 __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
-                                                              const u64* __restrict__ req, i32* __restrict__ out_len) {
+                                                              const u64* __restrict__ req, i32* __restrict__ out_len, int round_iters) {
     __shared__ u64 adj[54];
     __shared__ u64 pool_seen[LR_POOL];
     __shared__ unsigned short pool_cd[LR_POOL];
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
         while (true) {
-            for (int it = 0; it < LR_ROUND; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
+            for (int it = 0; it < round_iters; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
             __syncthreads();                       // all pushes of this round are complete
             if (!t.active) {
                 const int qi = atomicSub(&pool_n, 1) - 1;
