@@ -22,6 +22,8 @@ struct catan_env {
     catan_cfg_t cfg;
     void* state;          // W rows then B rows
     u32* mpk;             // packed masks [N][16]
+    u32* spec_state;      // shadow records / masks for speculative re-deals inside a lock-step step (enqueue_slow)
+    u32* spec_mpk;
     u32* err;             // invalid-action counter
     // scratch for catan_random_rollout
     i32* scratch_actions; // [n][18]
@@ -206,6 +208,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     size_t bytes = (size_t)e->N * STATE_BYTES_PER_GAME;
     hipError_t rc = hipMalloc(&e->state, bytes);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->mpk, (size_t)e->N * MPK_STRIDE * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->spec_state, (size_t)e->N * REC * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->spec_mpk, (size_t)e->N * MPK_STRIDE * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->err, 64);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_actions, (size_t)e->n * ACTION_WORDS * sizeof(i32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->scratch_reward, (size_t)e->n * 4 * sizeof(float));
@@ -270,6 +274,8 @@ void catan_destroy(catan_env_t* e) {
     hipSetDevice(e->device);
     if (e->state) hipFree(e->state);
     if (e->mpk) hipFree(e->mpk);
+    if (e->spec_state) hipFree(e->spec_state);
+    if (e->spec_mpk) hipFree(e->spec_mpk);
     if (e->err) hipFree(e->err);
     if (e->scratch_actions) hipFree(e->scratch_actions);
     if (e->scratch_reward) hipFree(e->scratch_reward);
@@ -371,8 +377,11 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
     if (e->cfg.auto_reset) {
         HIPCHK(hipEventRecord(e->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        // lock-step steps also deal, speculatively, a successor for every game on the tier-2 list (k_reset_list)
+        const bool spec = heavy_grid == LR_HEAVY_GRID;
         hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 1),
-                           (const i32*)e->pend.resets[sa][0], busy, sc.prof);
+                           (const i32*)e->pend.resets[sa][0], busy, sc.prof, (const u32*)sctr, spec ? (const u64*)e->pend.heavy[sa] : (const u64*)nullptr,
+                           e->spec_state, e->spec_mpk);
         HIPCHK(hipEventRecord(e->ev_join, e->side));
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
@@ -383,8 +392,12 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
     if (ev) HIPCHK(hipEventRecord(ev[7], st));
     if (e->cfg.auto_reset) {
         HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
-        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2),
-                           (const i32*)e->pend.resets[sa][1], busy, sc.prof);
+        if (heavy_grid == LR_HEAVY_GRID)
+            hipLaunchKernelGGL(k_install_list, dim3(256), dim3(64), 0, st, e->ctx, e->mpk, (const u32*)(sctr + 2), (const i32*)e->pend.resets[sa][1], busy,
+                               (const u32*)e->spec_state, (const u32*)e->spec_mpk);
+        else
+            hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2),
+                               (const i32*)e->pend.resets[sa][1], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr);
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(hipGetLastError());

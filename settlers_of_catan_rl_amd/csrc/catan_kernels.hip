@@ -666,7 +666,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
 
 // scratch of the one-wave-per-game re-deal (wave_reset_game): the game's Philox stream is generated in bulk by all 64 lanes
 // (RND_WORDS consecutive draws), then one lane walks it; its shuffle arrays are LDS bytes.
-constexpr int RND_WORDS = 768;
+constexpr int RND_WORDS = 1536;     // p99.9 of a re-deal is ~1250 draws
 constexpr int TOK_HORIZON = 256;    // start offsets examined per round of the parallel number-token loop
 constexpr int TOK_DRAWS = 48;       // draws one shuffle of the 18 tokens may take in that loop (mean 23; longer ones fall back)
 constexpr int TOK_CHAIN = 48;       // consecutive attempts examined per round
@@ -729,10 +729,11 @@ DEVI bool reset_tokens_parallel(ResetScratch& sc, int lane) {
     const int dpos = __shfl(pidx, __ffsll((long long)__ballot(desert)) - 1);      // the desert takes no token
     const int tok_of_tile = pidx - (pidx > dpos ? 1 : 0);
     int off = sc.tok_state[0];
-    for (int round = 0; round < 8; round++) {                                      // (bounded; the fall-back finishes)
-        if (off + TOK_HORIZON + TOK_DRAWS > RND_WORDS) return false;
+    for (int round = 0; round < 16; round++) {                                     // (bounded; the fall-back finishes)
+        const int hz = min(TOK_HORIZON, RND_WORDS - TOK_DRAWS - off);            // start offsets whose TOK_DRAWS words exist
+        if (hz <= 0) return false;
         // (1) end offset of a shuffle started at off + q
-        for (int q = lane; q < TOK_HORIZON; q += 64) {
+        for (int q = lane; q < hz; q += 64) {
             int i = 17, endq = 0xFFFF;
 #pragma unroll 8
             for (int t = 0; t < TOK_DRAWS; t++) {
@@ -745,7 +746,7 @@ DEVI bool reset_tokens_parallel(ResetScratch& sc, int lane) {
         // (2) the chain of attempt starts (relative to off)
         if (lane == 0) {
             int q = 0, n = 0;
-            while (n < TOK_CHAIN && q < TOK_HORIZON) { sc.chain[n++] = (unsigned short)q; const int e = sc.endp[q]; if (e == 0xFFFF) { q = 0xFFFF; break; } q = e; }
+            while (n < TOK_CHAIN && q < hz) { sc.chain[n++] = (unsigned short)q; const int e = sc.endp[q]; if (e == 0xFFFF) { q = 0xFFFF; break; } q = e; }
             sc.chain[n] = (unsigned short)q;                    // where attempt n would start (0xFFFF: attempt n-1 needs the fall-back)
             sc.tok_state[1] = n;
         }
@@ -1872,12 +1873,15 @@ __global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ 
 // One wave resets one game: the 64 lanes generate the game's next RND_WORDS Philox draws into LDS, lane 0 runs the
 // (inherently serial) shuffles of Board.reset / Game.reset on the game's hot record held linearly in LDS, then computes
 // the masks of the fresh game.
+// dstR != nullptr: a SPECULATIVE re-deal - the fresh record (and its masks, through `mpk`) go to the shadow arrays, the game
+// itself is only read (its stream position).  k_install_list copies the shadow over the game if the game did end.
 DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, int max_trades, u8* busy,
-                           unsigned long long* prof = nullptr) {
+                           unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr) {
+    u32* const outR = dstR ? dstR : c.R;
     __builtin_amdgcn_wave_barrier();
     if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
     __builtin_amdgcn_wave_barrier();
-    StL1 s(rec, c.R, c.N, e);
+    StL1 s(rec, outR, c.N, e);
     Rng mine = rng_load(c, s);
     const u32 blk0 = mine.draws >> 2;
 #pragma unroll
@@ -1887,7 +1891,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
         const int at = (b * 64 + lane) * 4;
         sc.rnd[at] = o[0]; sc.rnd[at + 1] = o[1]; sc.rnd[at + 2] = o[2]; sc.rnd[at + 3] = o[3];
     }
-    for (int r = ROWS_HOT + lane; r < REC; r += 64) c.R[e * REC + r] = 0;     // cold part: empty card lists
+    for (int r = ROWS_HOT + lane; r < REC; r += 64) outR[e * REC + r] = 0;    // cold part: empty card lists
     __builtin_amdgcn_wave_barrier();
     RngBuf rb;
     rb.buf = sc.rnd; rb.base = blk0 * 4; rb.avail = RND_WORDS; rb.slow = mine;
@@ -1912,16 +1916,37 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+    if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(outR + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
     if (lane == 0 && busy != nullptr) busy[e] = 0;
 }
 // Resets the games this step finished (RL/ppo/game_manager.py:112-113), one wave per game.
+// spec_list != nullptr (lock-step steps): the launch also deals, speculatively and into the shadow arrays, a fresh game for
+// every game on the tier-2 list - if such a game turns out to end in k_step_finish, k_install_list copies the shadow over it
+// instead of a second, fully exposed re-deal pass at the end of the step (a re-deal depends only on the game's stream
+// position, which the rest of the step does not move).
 __global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
-                                                   const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof) {
+                                                   const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof,
+                                                   const u32* __restrict__ spec_count_p, const u64* __restrict__ spec_list,
+                                                   u32* __restrict__ specR, u32* __restrict__ spec_mpk) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     __shared__ ResetScratch sc;
+    const u32 count = *count_p, scount = spec_list ? *spec_count_p : 0u;
+    for (u32 r = blockIdx.x; r < count + scount; r += gridDim.x) {
+        if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, max_trades, busy, prof);
+        else wave_reset_game(c, (long)(spec_list[r - count] & 0x00FFFFFFFFFFFFFFull), rec, sc, threadIdx.x, spec_mpk, max_trades, nullptr, nullptr, specR);
+    }
+}
+// the games of `list` take their speculatively dealt successors: record (hot and cold part) and masks
+__global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mpk, const u32* __restrict__ count_p, const i32* __restrict__ list,
+                                                     u8* __restrict__ busy, const u32* __restrict__ specR, const u32* __restrict__ spec_mpk) {
     const u32 count = *count_p;
-    for (u32 r = blockIdx.x; r < count; r += gridDim.x) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, max_trades, busy, prof);
+    const int lane = threadIdx.x;
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        const long e = list[r];
+        if (lane < REC / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(specR + e * REC)[lane];
+        if (lane < MPK_STRIDE / 4) reinterpret_cast<uint4*>(mpk + e * MPK_STRIDE)[lane] = reinterpret_cast<const uint4*>(spec_mpk + e * MPK_STRIDE)[lane];
+        if (lane == 0 && busy != nullptr) busy[e] = 0;
+    }
 }
 // catan_reset: every game (sel == nullptr) or the selected ones.
 __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
