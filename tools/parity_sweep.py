@@ -9,7 +9,8 @@ import oracle_lib
 from settlers_of_catan_rl_amd.env import VecCatanEnv
 
 bad = 0
-for seed, n, steps, kw in [(101, 2048, 1500, {}), (202, 1000, 2500, dict(dense_reward=True)), (303, 3000, 1200, dict(max_proposed_trades_per_turn=1)),
+big = [(606, 65536, 2000, {}), (707, 32768, 4000, dict(dense_reward=True))] if "--big" in sys.argv else []
+for seed, n, steps, kw in big + [(101, 2048, 1500, {}), (202, 1000, 2500, dict(dense_reward=True)), (303, 3000, 1200, dict(max_proposed_trades_per_turn=1)),
                            (404, 513, 3000, dict(validate_actions=False)), (505, 4096, 1000, dict(max_proposed_trades_per_turn=7, dense_reward=True))]:
     okw = {k: v for k, v in kw.items() if k in ("dense_reward", "max_proposed_trades_per_turn")}
     # lock-step
@@ -17,7 +18,7 @@ for seed, n, steps, kw in [(101, 2048, 1500, {}), (202, 1000, 2500, dict(dense_r
     ob = oracle_lib.OracleBatch(n, seed)
     ob.set_config(max_trades_per_turn=okw.get("max_proposed_trades_per_turn", 4), dense_reward=okw.get("dense_reward", False))
     env.random_rollout(0, steps)
-    o = ob.run_random(steps, n_threads=0)
+    o = ob.run_random(steps, n_threads=0 if n < 8192 else (os.cpu_count() or 1))
     same = np.array_equal(env.export_state().cpu().numpy(), o) and np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
     print(f"lock-step seed {seed} n {n} steps {steps} {kw}: {'OK' if same else 'MISMATCH'} (games finished {ob.games.value})", flush=True)
     bad += not same
@@ -28,7 +29,7 @@ for seed, n, steps, kw in [(101, 2048, 1500, {}), (202, 1000, 2500, dict(dense_r
         ob.set_config(max_trades_per_turn=okw.get("max_proposed_trades_per_turn", 4), dense_reward=okw.get("dense_reward", False))
         env.random_rollout_deferred(steps, window)
         cnt = env.policy_counters().cpu().numpy()
-        o = ob.run_random_counts(cnt, n_threads=0)
+        o = ob.run_random_counts(cnt, n_threads=0 if n < 8192 else (os.cpu_count() or 1))
         same = np.array_equal(env.export_state().cpu().numpy(), o) and np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
         print(f"deferred W={window} seed {seed}: {'OK' if same else 'MISMATCH'} ({int(cnt.sum())} decisions)", flush=True)
         bad += not same
