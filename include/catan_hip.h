@@ -172,6 +172,9 @@ int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const vo
  * are counted by catan_inconsistent_deal_count. */
 int catan_randomise_uncertainty(catan_env_t* env, const int32_t* controlling_player, catan_stream_t stream);
 int64_t catan_inconsistent_deal_count(catan_env_t* env, catan_stream_t stream);
+/* diagnostics of the lock-step step: finished games whose speculatively dealt successor was missing and which
+ * were re-dealt on the critical path instead; expected 0 (k_step's may-end filter is a superset of the games a step can end) */
+int64_t catan_missed_speculation_count(catan_env_t* env, catan_stream_t stream);
 
 /* Weight / bias gradient of a Linear layer with a huge row count and small widths (the tile / card / player modules of
  * RL/models: rows = 19 B .. 75 B, widths 6..256): dw[out][in] += sum_r dy[r][out] * x[r][in], db[out] += sum_r dy[r][out].

@@ -92,6 +92,7 @@ _SIGS = {
     "catan_randomise_uncertainty": (C.c_int, [_vp, _vp, _vp]),
     "catan_players_turn_sim": (C.c_int, [_vp, _vp, _vp]),
     "catan_inconsistent_deal_count": (C.c_int64, [_vp, _vp]),
+    "catan_missed_speculation_count": (C.c_int64, [_vp, _vp]),
     "catan_linear_wgrad_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "catan_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
 }

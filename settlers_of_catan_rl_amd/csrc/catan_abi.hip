@@ -24,6 +24,7 @@ struct catan_env {
     u32* mpk;             // packed masks [N][16]
     u32* spec_state;      // shadow records / masks for speculative re-deals inside a lock-step step (enqueue_slow)
     u32* spec_mpk;
+    u32 spec_epoch;       // lock-step step counter: tags the shadows of a step
     u32* err;             // invalid-action counter
     // scratch for catan_random_rollout
     i32* scratch_actions; // [n][18]
@@ -233,6 +234,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
         rc = hipMalloc((void**)&e->pend.heavy[i], (size_t)e->N * sizeof(u64));
         if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][0], (size_t)e->N * sizeof(i32));
         if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][1], (size_t)e->N * sizeof(i32));
+        if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][2], (size_t)e->N * sizeof(i32));
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_sdone[i], EV_SYNC);
     }
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
@@ -245,6 +247,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.arrive, (size_t)e->N * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.spec, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32));
@@ -292,6 +296,7 @@ void catan_destroy(catan_env_t* e) {
         if (e->pend.heavy[i]) hipFree(e->pend.heavy[i]);
         if (e->pend.resets[i][0]) hipFree(e->pend.resets[i][0]);
         if (e->pend.resets[i][1]) hipFree(e->pend.resets[i][1]);
+        if (e->pend.resets[i][2]) hipFree(e->pend.resets[i][2]);
         if (e->ev_sdone[i]) hipEventDestroy(e->ev_sdone[i]);
     }
     if (e->sstream) hipStreamDestroy(e->sstream);
@@ -304,6 +309,8 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.type) hipFree(e->pend.type);
     if (e->pend.who) hipFree(e->pend.who);
     if (e->pend.len) hipFree(e->pend.len);
+    if (e->pend.arrive) hipFree(e->pend.arrive);
+    if (e->pend.spec) hipFree(e->pend.spec);
     if (e->pend.busy) hipFree(e->pend.busy);
     if (e->pctr) hipFree(e->pctr);
     if (e->prof_wave) hipFree(e->prof_wave);
@@ -366,38 +373,46 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-// tier 2 + re-deals of window slot pend.sa on stream st.  The games that ended in k_step / k_lr_finish (list 0) are re-dealt
-// on the side stream while the tier-2 kernels run, those that end in k_step_finish (list 1) afterwards.
-// ev (optional): [9] before k_lr_heavy, [3] after it, [7] after k_step_finish, [4] at the end
+// tier 2 (+ the completion of its games) and the re-deals of window slot pend.sa on stream st.
+//   deferred window: the games that ended in k_step / k_lr_finish (list 0) are re-dealt on the side stream while tier 2 runs,
+//     those that end in the tier-2 completion (list 1) afterwards.
+//   lock-step step: no re-deal is left on the critical path - step_impl started, right behind k_step and on the side stream,
+//     the re-deals of the games that ended in k_step AND a speculative successor (shadow records) for every game on the
+//     longest-road path; the games that then end in k_lr_finish (list 2) or in the tier-2 completion (list 1) only take
+//     their shadow (k_install_list).
+// ev (optional): [9] before k_lr_heavy, [3] / [7] after it, [4] at the end
 static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int heavy_grid) {
     StepCfg sc = step_cfg(e);
     const int sa = e->pend.sa, max_trades = e->cfg.max_proposed_trades_per_turn;
+    const bool lockstep = heavy_grid == LR_HEAVY_GRID;
     u32* sctr = e->pend.ctr + 8 + 4 * sa;
     u8* busy = e->pend.stag < 2 ? e->pend.busy : nullptr;       // tagged games are released by the sampler, not here
     if (e->cfg.auto_reset) {
-        HIPCHK(hipEventRecord(e->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        // lock-step steps also deal, speculatively, a successor for every game on the tier-2 list (k_reset_list)
-        const bool spec = heavy_grid == LR_HEAVY_GRID;
-        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 1),
-                           (const i32*)e->pend.resets[sa][0], busy, sc.prof, (const u32*)sctr, spec ? (const u64*)e->pend.heavy[sa] : (const u64*)nullptr,
-                           e->spec_state, e->spec_mpk);
-        HIPCHK(hipEventRecord(e->ev_join, e->side));
+        if (!lockstep) {
+            HIPCHK(hipEventRecord(e->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 1),
+                               (const i32*)e->pend.resets[sa][0], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u);
+            HIPCHK(hipEventRecord(e->ev_join, e->side));
+        }
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
     hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len,
-                       heavy_grid == LR_HEAVY_GRID ? LR_ROUND_LOCKSTEP : LR_ROUND);
+                       lockstep ? LR_ROUND_LOCKSTEP : LR_ROUND, e->mpk, reward, done, sc, e->pend);   // search + completion
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k_step_finish, dim3(blocks(e->N, 64)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend);
     if (ev) HIPCHK(hipEventRecord(ev[7], st));
     if (e->cfg.auto_reset) {
-        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
-        if (heavy_grid == LR_HEAVY_GRID)
-            hipLaunchKernelGGL(k_install_list, dim3(256), dim3(64), 0, st, e->ctx, e->mpk, (const u32*)(sctr + 2), (const i32*)e->pend.resets[sa][1], busy,
-                               (const u32*)e->spec_state, (const u32*)e->spec_mpk);
-        else
+        if (lockstep) {
+            HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));      // the side stream's launch of step_impl: it had the whole slow path to finish
+            hipLaunchKernelGGL(k_install_list, dim3(256), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 3), (const i32*)e->pend.resets[sa][2], busy,
+                               (const u32*)e->spec_state, (const u32*)e->spec_mpk, e->spec_epoch, e->err);
+            hipLaunchKernelGGL(k_install_list, dim3(256), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2), (const i32*)e->pend.resets[sa][1], busy,
+                               (const u32*)e->spec_state, (const u32*)e->spec_mpk, e->spec_epoch, e->err);
+        } else {
+            HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
             hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2),
-                               (const i32*)e->pend.resets[sa][1], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr);
+                               (const i32*)e->pend.resets[sa][1], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u);
+        }
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(hipGetLastError());
@@ -414,6 +429,16 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
                            (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16, e->pend.lists);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
+    if (r == CATAN_OK && e->cfg.auto_reset) {                    // the games that ended in k_step: re-dealt on the side stream from here on
+        HIPCHK(hipEventRecord(e->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        // ... and every game on the longest-road path that this step may end (k_step's list pend.spec) gets a speculative successor
+        e->spec_epoch++;
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn,
+                           (const u32*)(e->pend.ctr + 8 + 1), (const i32*)e->pend.resets[0][0], e->pend.busy, step_cfg(e).prof,
+                           (const u32*)(e->pend.ctr + 6), (const u64*)e->pend.spec, e->spec_state, e->spec_mpk, e->spec_epoch);
+        HIPCHK(hipEventRecord(e->ev_join, e->side));
+    }
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
     if (r == CATAN_OK) r = enqueue_slow(e, reward, done, st, ev, LR_HEAVY_GRID);
     return r;
@@ -780,6 +805,14 @@ int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_l
                        (const long long*)action, lse, entropy, dlogp, dent, dlogits, (long)rows, K);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
+}
+
+int64_t catan_missed_speculation_count(catan_env_t* e, catan_stream_t stream) {
+    if (!e) return -1;
+    u32 v = 0;
+    if (hipMemcpyAsync(&v, e->err + 2, sizeof v, hipMemcpyDeviceToHost, S(stream)) != hipSuccess) return -1;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return -1;
+    return (int64_t)v;
 }
 
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream) {

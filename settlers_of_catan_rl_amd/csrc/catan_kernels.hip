@@ -611,59 +611,6 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
     return result;
 }
 
-// tier 2: `split` workgroups per request (static partition of the start corners, combined with atomicMax); few requests
-// (lock-step) get 8 workgroups each for latency, many (a deferred window) share the grid for throughput.
-// req[i] = game | pid0 << 56; out_len[game] (zeroed by k_step) receives the path length.
-__global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
-                                                              const u64* __restrict__ req, i32* __restrict__ out_len, int round_iters) {
-    __shared__ u64 adj[54];
-    __shared__ u64 pool_seen[LR_POOL];
-    __shared__ unsigned short pool_cd[LR_POOL];
-    __shared__ int pool_n, best_all;
-    __shared__ lrstk_t path[54][LR_HEAVY_THREADS];
-    const int tid = threadIdx.x;
-    const u32 nreq = *req_count;
-    const u32 LR_SPLIT = nreq * 8 <= gridDim.x ? 8u : (nreq * 4 <= gridDim.x ? 4u : (nreq * 2 <= gridDim.x ? 2u : 1u));
-    const u32 count = nreq * LR_SPLIT;
-    u32 nbr_c, nbr_e;
-    lr_load_nbr(tid < 54 ? tid : 0, nbr_c, nbr_e);
-    for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
-        const u64 rq = req[r / LR_SPLIT];
-        const int part = (int)(r % LR_SPLIT);
-        const long game = (long)(rq & 0x00FFFFFFFFFFFFFFull);
-        const int pid = (int)(rq >> 56);
-        St s(c.R, c.N, game);
-        __syncthreads();
-        if (tid < 54) {
-            u64 BL = 0;
-            for (int o = 0; o < 4; o++) if (o != pid) BL |= s.settle(o) | s.city(o);
-            adj[tid] = lr_adj_of(tid, nbr_c, nbr_e, s.road_lo(pid), s.road_hi(pid), BL);
-        }
-        if (tid == 0) { pool_n = 0; best_all = 0; }
-        __syncthreads();
-        Dfs t;
-        t.active = tid < 54 && ((u32)tid % LR_SPLIT) == (u32)part && adj[tid < 54 ? tid : 0] != 0;
-        t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
-        const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
-        bool hint = true;
-        while (true) {
-            for (int it = 0; it < round_iters; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
-            __syncthreads();                       // all pushes of this round are complete
-            if (!t.active) {
-                const int qi = atomicSub(&pool_n, 1) - 1;
-                if (qi >= 0) dfs_take(t, adj, pool_seen[qi], pool_cd[qi]);
-                else atomicAdd(&pool_n, 1);
-            }
-            const int busy = __syncthreads_count(t.active);   // all pops complete
-            if (busy == 0) break;                  // nobody active -> the pool is empty too (idle threads drained it)
-            hint = busy < LR_HEAVY_THREADS;
-        }
-        atomicMax(&best_all, t.best);
-        __syncthreads();
-        if (tid == 0 && best_all > 0) atomicMax(&out_len[game], best_all);
-    }
-}
-
 // scratch of the one-wave-per-game re-deal (wave_reset_game): the game's Philox stream is generated in bulk by all 64 lanes
 // (RND_WORDS consecutive draws), then one lane walks it; its shuffle arrays are LDS bytes.
 constexpr int RND_WORDS = 1536;     // p99.9 of a re-deal is ~1250 draws
@@ -1277,11 +1224,14 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   tier-1 longest-road requests go to request list `fa` (two lists, so that the list of one iteration can be worked off on
 //   a side stream while the next iteration fills the other); k_step marks those games busy with `ftag`;
 //   tier-2 requests and finished games go to the lists of window slot `sa`: heavy[sa], resets[sa][0] (games that ended in
-//   k_step / k_lr_finish) and resets[sa][1] (games that ended in k_step_finish); those games are marked busy with `stag`.
+//   k_step; in a deferred window also those that ended in k_lr_finish), resets[sa][1] (games that ended in the tier-2
+//   completion) and resets[sa][2] (lock-step steps: games that ended in k_lr_finish - the re-deals of list 0 start right
+//   behind k_step); those games are marked busy with `stag`.
 //   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
-struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; i32* resets[2][2]; u8* busy;
+struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; u32* arrive; i32* resets[2][3]; u8* busy;
+                 u64* spec;                 // lock-step steps: the longest-road requests of games that this step may end (ctr[6])
                  i32* lists;                // the sort: game ids per action-type bin, [NBINS][N] (bin b, rank r at b * N + r)
                  int bsel;                  // which of the two bin-count sets (ctr[16 + NBINS * bsel ..]) this pass uses
                  int fa, ftag, sa, stag; };
@@ -1779,6 +1729,12 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     if (pending) {
         const u32 slot = atomicAdd(&pend.ctr[4 + pend.fa], 1u);
         pend.req[pend.fa][slot] = (u64)e | ((u64)lr_who << 56);
+        if (pend.stag < 2) {                               // lock-step: a game whose completion can end it (longest road: +2 points for
+            bool may_end = false;                          // one player) gets a speculative successor (k_reset_list)
+#pragma unroll
+            for (int p = 0; p < 4; p++) may_end |= s.pb(p, P_VP) >= 8;
+            if (may_end) pend.spec[atomicAdd(&pend.ctr[6], 1u)] = (u64)e;
+        }
         pend.type[e] = (u8)(type + 1);
         pend.who[e] = (u8)lr_who;
         pend.busy[e] = (u8)pend.ftag;
@@ -1824,15 +1780,96 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         if (len < 0) {                                   // tier 2 takes over; the record is untouched
             if (lane == 0) {
                 const u32 slot = atomicAdd(&pend.ctr[8 + 4 * pend.sa], 1u);
-                pend.heavy[pend.sa][slot] = rq; pend.len[e] = 0; pend.busy[e] = (u8)pend.stag;
+                pend.heavy[pend.sa][slot] = rq; pend.len[e] = 0; pend.arrive[e] = 0; pend.busy[e] = (u8)pend.stag;
             }
             continue;
         }
         long long tprof = 0;
         finish_step<true>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
-                    0, pend.ftag < 2);
+                    pend.stag < 2 ? 2 : 0, pend.ftag < 2);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+    }
+}
+
+// tier 2: `split` workgroups per request (static partition of the start corners, combined with atomicMax); few requests
+// (lock-step) get 8 workgroups each for latency, many (a deferred window) share the grid for throughput.
+// req[i] = game | pid0 << 56; out_len[game] (zeroed when the request was pushed) collects the path length.  The workgroup
+// that arrives LAST at a request (pend.arrive[game]) completes the step of that game - holder logic, done / rewards, next
+// masks - on its first wave, as k_lr_finish does for tier 1 (a separate completion kernel cost 28 us of every lock-step step).
+__global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
+                                                              const u64* __restrict__ req, i32* __restrict__ out_len, int round_iters,
+                                                              u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
+                                                              StepCfg cfg, Pending pend) {
+    __shared__ u64 adj[54];
+    __shared__ u64 pool_seen[LR_POOL];
+    __shared__ unsigned short pool_cd[LR_POOL];
+    __shared__ int pool_n, best_all, is_last;
+    __shared__ __attribute__((aligned(16))) lrstk_t path[54][LR_HEAVY_THREADS];
+    static_assert(sizeof(StepScratch) + ROWS_HOT * 4 + 64 <= sizeof(lrstk_t) * 54 * LR_HEAVY_THREADS, "the completion reuses the DFS stacks");
+    const int tid = threadIdx.x;
+    const u32 nreq = *req_count;
+    const u32 LR_SPLIT = nreq * 8 <= gridDim.x ? 8u : (nreq * 4 <= gridDim.x ? 4u : (nreq * 2 <= gridDim.x ? 2u : 1u));
+    const u32 count = nreq * LR_SPLIT;
+    u32 nbr_c, nbr_e;
+    lr_load_nbr(tid < 54 ? tid : 0, nbr_c, nbr_e);
+    StepCfg cfg2 = cfg;
+    cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
+    for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        const u64 rq = req[r / LR_SPLIT];
+        const int part = (int)(r % LR_SPLIT);
+        const long game = (long)(rq & 0x00FFFFFFFFFFFFFFull);
+        const int pid = (int)(rq >> 56);
+        St s(c.R, c.N, game);
+        __syncthreads();
+        if (tid < 54) {
+            u64 BL = 0;
+            for (int o = 0; o < 4; o++) if (o != pid) BL |= s.settle(o) | s.city(o);
+            adj[tid] = lr_adj_of(tid, nbr_c, nbr_e, s.road_lo(pid), s.road_hi(pid), BL);
+        }
+        if (tid == 0) { pool_n = 0; best_all = 0; }
+        __syncthreads();
+        Dfs t;
+        t.active = tid < 54 && ((u32)tid % LR_SPLIT) == (u32)part && adj[tid < 54 ? tid : 0] != 0;
+        t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
+        const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
+        bool hint = true;
+        while (true) {
+            for (int it = 0; it < round_iters; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
+            __syncthreads();                       // all pushes of this round are complete
+            if (!t.active) {
+                const int qi = atomicSub(&pool_n, 1) - 1;
+                if (qi >= 0) dfs_take(t, adj, pool_seen[qi], pool_cd[qi]);
+                else atomicAdd(&pool_n, 1);
+            }
+            const int busy = __syncthreads_count(t.active);   // all pops complete
+            if (busy == 0) break;                  // nobody active -> the pool is empty too (idle threads drained it)
+            hint = busy < LR_HEAVY_THREADS;
+        }
+        atomicMax(&best_all, t.best);
+        __syncthreads();
+        if (tid == 0) {
+            if (best_all > 0) atomicMax(&out_len[game], best_all);
+            __threadfence();                                           // this part's result before its arrival
+            is_last = atomicAdd(&pend.arrive[game], 1u) == LR_SPLIT - 1 ? 1 : 0;
+        }
+        __syncthreads();
+        if (is_last && tid < 64) {                                     // every part has arrived: complete the step of this game
+            StepScratch* scratch = reinterpret_cast<StepScratch*>(&path[0][0]);
+            u32* rec = reinterpret_cast<u32*>(reinterpret_cast<char*>(&path[0][0]) + ((sizeof(StepScratch) + 63) & ~size_t(63)));
+            const int lane = tid;
+            const int len = atomicMax(&out_len[game], 0);              // (device-scope read of the combined length)
+            if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + game * REC)[lane];
+            __builtin_amdgcn_wave_barrier();
+            StL1 sl(rec, c.R, c.N, game);
+            u32 nc, ne;
+            lr_load_nbr(lane, nc, ne);
+            long long tprof = 0;
+            finish_step<true>(c, sl, scratch, cfg2, lane, lane == 0, (int)pend.type[game] - 1, pid, len, reward, done, mpk, tprof, nc, ne, pend,
+                              1, pend.stag < 2);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + game * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+        }
     }
 }
 
@@ -1927,24 +1964,41 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
 __global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
                                                    const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof,
                                                    const u32* __restrict__ spec_count_p, const u64* __restrict__ spec_list,
-                                                   u32* __restrict__ specR, u32* __restrict__ spec_mpk) {
+                                                   u32* __restrict__ specR, u32* __restrict__ spec_mpk, u32 epoch) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     __shared__ ResetScratch sc;
     const u32 count = *count_p, scount = spec_list ? *spec_count_p : 0u;
     for (u32 r = blockIdx.x; r < count + scount; r += gridDim.x) {
         if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, max_trades, busy, prof);
-        else wave_reset_game(c, (long)(spec_list[r - count] & 0x00FFFFFFFFFFFFFFull), rec, sc, threadIdx.x, spec_mpk, max_trades, nullptr, nullptr, specR);
+        else {
+            const long e = (long)(spec_list[r - count] & 0x00FFFFFFFFFFFFFFull);
+            wave_reset_game(c, e, rec, sc, threadIdx.x, spec_mpk, max_trades, nullptr, nullptr, specR);
+            if (threadIdx.x == 0) spec_mpk[e * MPK_STRIDE + MPK_STRIDE - 1] = epoch;      // "this shadow belongs to step `epoch`"
+        }
     }
 }
-// the games of `list` take their speculatively dealt successors: record (hot and cold part) and masks
-__global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mpk, const u32* __restrict__ count_p, const i32* __restrict__ list,
-                                                     u8* __restrict__ busy, const u32* __restrict__ specR, const u32* __restrict__ spec_mpk) {
+// the games of `list` take their speculatively dealt successors: record (hot and cold part) and masks.  A game without a
+// shadow of this step (the may-end filter of k_step is meant to be a superset; this is the safety net) is re-dealt here.
+__global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
+                                                     const i32* __restrict__ list, u8* __restrict__ busy, const u32* __restrict__ specR,
+                                                     const u32* __restrict__ spec_mpk, u32 epoch, u32* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
+    __shared__ ResetScratch sc;
     const u32 count = *count_p;
     const int lane = threadIdx.x;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
         const long e = list[r];
+        if (spec_mpk[e * MPK_STRIDE + MPK_STRIDE - 1] != epoch) {
+            if (lane == 0) atomicAdd(err + 2, 1u);                                       // counted: catan_missed_speculation_count
+            wave_reset_game(c, e, rec, sc, lane, mpk, max_trades, busy, nullptr);
+            continue;
+        }
         if (lane < REC / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(specR + e * REC)[lane];
-        if (lane < MPK_STRIDE / 4) reinterpret_cast<uint4*>(mpk + e * MPK_STRIDE)[lane] = reinterpret_cast<const uint4*>(spec_mpk + e * MPK_STRIDE)[lane];
+        if (lane < MPK_STRIDE / 4) {
+            uint4 v = reinterpret_cast<const uint4*>(spec_mpk + e * MPK_STRIDE)[lane];
+            if (lane == MPK_STRIDE / 4 - 1) v.w = 0;                                      // (the tag word is not part of the masks)
+            reinterpret_cast<uint4*>(mpk + e * MPK_STRIDE)[lane] = v;
+        }
         if (lane == 0 && busy != nullptr) busy[e] = 0;
     }
 }

@@ -110,6 +110,10 @@ class VecCatanEnv(object):
         assert cp.shape == (self.n,)
         _lib.check(self.L.catan_randomise_uncertainty(self.h, _ptr(cp), _stream()))
 
+    def missed_speculation_count(self):
+        """finished games of lock-step steps that had no speculatively dealt successor (expected 0)"""
+        return int(self.L.catan_missed_speculation_count(self.h, _stream()))
+
     def inconsistent_deal_count(self):
         return int(self.L.catan_inconsistent_deal_count(self.h, _stream()))
 

@@ -17,3 +17,5 @@ for auto in (True, False):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 128
     k = e2.random_rollout_timed(3136, 64, 0)
     print(f"auto_reset={auto}: {dt * 1e6:.1f} us per step; " + ", ".join(f"{a} {b / 64 * 1e3:.0f}" for a, b in k.items()))
+e3 = VecCatanEnv(n, seed=0); e3.import_state(blob); e3.random_rollout(3000, 600)
+print("finished games re-dealt on the critical path for lack of a speculative successor:", e3.missed_speculation_count())
