@@ -117,7 +117,7 @@ int catan_set_lr_budgets(catan_env_t* env, int32_t lockstep, int32_t deferred);
  * loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST
  * float[7] receiving the summed milliseconds of k_sample_random (which also sorts the games by action type), 0 (slot of
  * k_classify, the sort for caller-supplied actions: not launched by the rollout loops), k_step, k_lr_finish, k_lr_heavy,
- * k_step_finish, k_reset_list (bench.py roofline). */
+ * 0 (slot of the former completion kernel; tier 2 completes its own games), k_reset_list / k_install_list (bench.py roofline). */
 int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms);
 
 /* EnvWrapper._get_obs(): env/wrapper.py:52-83 (+ _get_tile_features :491-524, _get_player_inputs :526-709), batched.

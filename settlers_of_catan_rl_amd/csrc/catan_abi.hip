@@ -332,13 +332,13 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.prof_wave = e->prof_on == 2 ? e->prof_wave : nullptr;
     return sc;
 }
-// One env step = counting sort of the games by action type (k_classify_*), then k_step (fused: apply + done/reward + next
-// masks for every game that needs no longest-road update) - the FAST path.  The few games that placed a road / settlement
-// or ended take the SLOW path: k_lr_finish (tier-1 path search + completion, one game per wave), k_lr_heavy (tier 2) +
-// k_step_finish, k_reset_list (re-deal, one wave per finished game).  Its launch times are the latency tails of a handful
-// of serial searches / re-deals.
-//   lock-step (catan_step, catan_random_rollout): the slow path runs inside every step (re-deals next to the tier-2
-//     kernels, on a side stream).
+// One env step = the games listed by action type (k_sample_random / k_classify), then k_step (fused: apply + done/reward +
+// next masks for every game that needs no longest-road update) - the FAST path.  The few games that placed a road /
+// settlement or ended take the SLOW path: k_lr_finish (tier-1 path search + completion, one game per wave), k_lr_heavy
+// (tier 2 + completion), k_reset_list (re-deal, one wave per finished game).  Its launch times are the latency tails of a
+// handful of serial searches / re-deals.
+//   lock-step (catan_step, catan_random_rollout): the slow path runs inside every step; the re-deals (real ones and
+//     speculative successors of the games the step may still end) run on a side stream right behind k_step.
 //   deferred (catan_random_rollout_deferred): a game on the slow path is BUSY (no action, no policy draw).  Tier 1 of
 //     iteration t runs on a side stream during iteration t+1 and its games play again at t+2; tier 2 and the re-deals of
 //     window w (W iterations) run on another stream during window w+1 and their games play again in window w+2.  Every
@@ -597,7 +597,7 @@ int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
 // window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host, float[7])
 // receives the summed elapsed milliseconds of:
 // [0] k_sample_random (incl. the sort by action type)  [1] 0 (k_classify only runs for caller-supplied actions)  [2] k_step
-// [3] k_lr_finish  [4] k_lr_heavy  [5] k_step_finish  [6] k_reset_list.
+// [3] k_lr_finish  [4] k_lr_heavy (incl. the completion of its games)  [5] 0 (slot of the former k_step_finish)  [6] re-deals / installs.
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
@@ -630,7 +630,7 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
         HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[3] += ms;      // k_lr_finish
         if (!slow[s]) continue;
         HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[4] += ms;      // k_lr_heavy
-        HIPCHK(hipEventElapsedTime(&ms, v[3], v[7])); kernel_ms[5] += ms;      // k_step_finish
+        HIPCHK(hipEventElapsedTime(&ms, v[3], v[7])); kernel_ms[5] += ms;      // (nothing is launched here any more)
         HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[6] += ms;      // k_reset_list (wait for the side stream + second pass)
     }
     for (auto& x : ev) hipEventDestroy(x);

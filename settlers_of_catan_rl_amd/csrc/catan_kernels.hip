@@ -4,7 +4,7 @@
 //   k_reset, k_reset_list    Board.reset + Game.reset + EnvWrapper.reset   game/components/board.py:67-100, game/game.py:39-136, env/wrapper.py:30-34
 //   k_step                   EnvWrapper.step = _translate_action + Game.apply_action + _get_done_and_rewards, and the next masks
 //                                                                          env/wrapper.py:36-50,114-166,85-112, game/game.py:527-815
-//   k_lr_finish, k_lr_heavy, k_step_finish   update_longest_road / get_longest_path + the rest of those steps   game/game.py:843-919
+//   k_lr_finish, k_lr_heavy                  update_longest_road / get_longest_path + the rest of those steps   game/game.py:843-919
 //   k_masks                  EnvWrapper.get_action_masks                   env/wrapper.py:168-412
 //   k_sample_random          uniform-random legal policy (bench config 2)  (reference: none; rule in DESIGN.md)
 //   k_classify_*             counting sort of the games by action type     (enables type-homogeneous waves)
@@ -96,7 +96,7 @@ struct StLT : StOps<StLT<STRIDE>> {
     DEVI int cold(int f) const { return ((const u8*)(P + NW))[f]; }
     DEVI void scold(int f, int v) const { ((u8*)(P + NW))[f] = (u8)v; }
 };
-typedef StLT<TS> StL;     // k_step / k_step_finish: 64 games per tile
+typedef StLT<TS> StL;     // k_step: 64 games per tile
 typedef StLT<1> StL1;     // k_reset_list: one game per wave, its hot record linear in LDS
 // Transposing stage-in / stage-out of the HOT words of the 64 games whose ids sit one per lane in `e` (-1 = empty slot).
 // 28 x 16 B per game, two games per pass (lanes 0..55): every load/store instruction moves 2 x 448 contiguous bytes.
@@ -462,7 +462,7 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 //   tier 1 (k_lr_finish, one wave per game): lane v enumerates the simple paths that start at corner v; busy lanes hand
 //           untaken sibling subtrees to an LDS task queue whenever other lanes are idle; iteration budget (LR_BUDGET).
 //   tier 2 (k_lr_heavy, 1 024-thread workgroups, 1..8 per overflowed game): the same DFS, bulk-synchronous work sharing
-//           through a workgroup pool, so a dense road network gets whole CUs; k_step_finish then completes those games.
+//           through a workgroup pool, so a dense road network gets whole CUs; the workgroup that arrives last completes the game.
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
@@ -1215,9 +1215,9 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     t_prev = wall_clock64();
 }
 
-// ctr: [4], [5] lengths of the two tier-1 request lists (k_lr_finish); [8 + 4 sa]: tier-2 requests of slot sa (k_lr_heavy +
-// k_step_finish), [9 + 4 sa], [10 + 4 sa]: its two re-deal lists (k_reset_list); [16..29] games per action-type bin,
-// [32..45] bin cursors.
+// ctr: [4], [5] lengths of the two tier-1 request lists (k_lr_finish); [6] the may-end list of a lock-step step (pend.spec);
+// [8 + 4 sa]: tier-2 requests of slot sa (k_lr_heavy), [9 + 4 sa] .. [11 + 4 sa]: its re-deal lists 0..2 (k_reset_list /
+// k_install_list); [16 + 18 b ..]: the two sets of games-per-bin counts of the sort.
 // busy[e] != 0: game e is waiting for the slow path (longest-road completion or re-deal); it takes no action until the
 // slow path has run (same step in lock-step mode, end of the window in deferred mode).
 // Slow-path hand-off (all device arrays).
@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         atomicMax(&cfg.prof[PROF_TOTAL + 28 + tb], dt);
     }
     prof_mark(cfg, 1, tprof);
-    // ---- update_longest_road (game.py:864-919): the path search runs in k_lr / k_lr_heavy; k_step_finish completes
+    // ---- update_longest_road (game.py:864-919): the path search runs in k_lr_finish / k_lr_heavy, which also complete
     // the step of these games (sorted waves would otherwise serialise up to 64 searches in the road-placement waves)
     const int len = 0;
     const bool pending = lr_who >= 0;
@@ -1873,34 +1873,6 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
     }
 }
 
-// Completes the step of the games in the tier-2 list (their longest-road length now sits in pend.len): holder logic,
-// done/rewards, next masks.  Compact: wave w gathers requests 64w .. 64w+63, whatever games they are.
-__global__ __launch_bounds__(64) void k_step_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward,
-                                                    u8* __restrict__ done, StepCfg cfg, Pending pend) {
-    __shared__ u32 tile[ROWS_HOT * TS];
-    __shared__ StepScratch scratch;
-    const int lane = threadIdx.x;
-    const u32 count = pend.ctr[8 + 4 * pend.sa];
-    if ((u32)blockIdx.x * 64u >= count) return;
-    const u32 r = blockIdx.x * 64u + lane;
-    const bool doit = r < count;
-    const long e = doit ? (long)(pend.heavy[pend.sa][r] & 0x00FFFFFFFFFFFFFFull) : -1;
-    stage_in(tile, c.R, (int)e, lane);
-    __builtin_amdgcn_wave_barrier();
-    StL s(tile + lane, c.R, c.N, doit ? e : 0);
-    long long tprof = 0;
-    StepCfg cfg2 = cfg;
-    cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
-    const int pt = doit ? pend.type[e] : 0;
-    const int who = doit ? pend.who[e] : -1;
-    const int len = doit ? pend.len[e] : 0;
-    u32 nbr_c, nbr_e;
-    lr_load_nbr(lane, nbr_c, nbr_e);
-    finish_step<true>(c, s, &scratch, cfg2, lane, doit, pt - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 1, pend.stag < 2);
-    __builtin_amdgcn_wave_barrier();
-    stage_out(tile, c.R, (int)e, lane);
-}
-
 // Deferred rollouts: frees the games that still carry a release tag when a call ends (their steps are complete).
 __global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ busy) {
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1958,7 +1930,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
 }
 // Resets the games this step finished (RL/ppo/game_manager.py:112-113), one wave per game.
 // spec_list != nullptr (lock-step steps): the launch also deals, speculatively and into the shadow arrays, a fresh game for
-// every game on the tier-2 list - if such a game turns out to end in k_step_finish, k_install_list copies the shadow over it
+// every game on the tier-2 list - if such a game turns out to end, k_install_list copies the shadow over it
 // instead of a second, fully exposed re-deal pass at the end of the step (a re-deal depends only on the game's stream
 // position, which the rest of the step does not move).
 __global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
