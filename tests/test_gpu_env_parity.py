@@ -52,6 +52,8 @@ def test_random_rollout_state_parity(oracle, hip_lib, n, steps, seed):
         assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks()), f"masks after {done_steps} steps"
     assert env.invalid_action_count() == 0
     assert ob.games.value > 0 or steps < 1500
+    # every game that ended behind k_step found its speculatively dealt successor (no re-deal on the critical path)
+    assert env.missed_speculation_count() == 0
 
 
 @pytest.mark.parametrize("n,iters,window,seed", [(1024, 3000, 8, 0), (300, 1500, 1, 5), (4096, 2500, 32, 9)])
