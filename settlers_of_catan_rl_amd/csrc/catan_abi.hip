@@ -25,6 +25,8 @@ struct catan_env {
     u32* spec_state;      // shadow records / masks for speculative re-deals inside a lock-step step (enqueue_slow)
     u32* spec_mpk;
     u32 spec_epoch;       // lock-step step counter: tags the shadows of a step
+    int ctr_clean;        // lock-step: the counters are maintained by the kernels themselves (no memset per step) once set
+    int lock_parity;      // ... and the sort alternates between its two count sets
     u32* err;             // invalid-action counter
     // scratch for catan_random_rollout
     i32* scratch_actions; // [n][18]
@@ -355,7 +357,7 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     u32* bins = e->pend.ctr + 16 + NBINS * e->pend.bsel;
     if (!have_hist) {                                     // (the rollout loops sort inside k_sample_random)
-        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists);
+        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists, e->pend.ctr + 4, 12);
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
     }
     hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
@@ -422,12 +424,15 @@ constexpr int EV_PER_STEP = 10;
 // sample_step != nullptr: the random policy draws the actions first (into `actions`), fused with the sort's histogram
 static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr,
                      const uint32_t* sample_step = nullptr) {
-    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.bsel = 0;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
-    HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    // the step's first kernel zeroes the slow-path list counters (ctr[4..15]) and k_step the count set of the NEXT sort, so a
+    // memset is only needed after anything else used the counters (creation, a deferred rollout)
+    if (!e->ctr_clean) { HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st)); e->ctr_clean = 1; e->lock_parity = 0; }
+    e->pend.bsel = e->lock_parity; e->lock_parity ^= 1;
     if (sample_step)
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
-                           (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, e->pend.ctr + 16, e->pend.lists);
+                           (u32*)nullptr, (u8*)nullptr, 0, 0, e->pend.ctr + 4, 12, e->pend.ctr + 16 + NBINS * e->pend.bsel, e->pend.lists);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
     if (r == CATAN_OK && e->cfg.auto_reset) {                    // the games that ended in k_step: re-dealt on the side stream from here on
         HIPCHK(hipEventRecord(e->ev_fork, st));
@@ -480,7 +485,7 @@ int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) 
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
-                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, (u32*)nullptr, (i32*)nullptr);
+                       (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, 0, (u32*)nullptr, (i32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -527,6 +532,7 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 // 2 + (it & 1); window w = it / window uses slot w & 1 with tag 4 + (w & 1).
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
     const int fa = (int)(it & 1);
+    e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
     const int64_t w = it / window;
     const int sa = (int)(w & 1);
     const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
@@ -539,7 +545,7 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
-                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa,
+                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa, 1,
                        e->pend.ctr + 16 + NBINS * fa, e->pend.lists);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;

@@ -2003,11 +2003,13 @@ DEVI void sort_append(long e, bool valid, int bin, u32* hist, u32* base, u32* __
     if (valid) lists[(long)bin * N + base[bin] + rank] = (i32)e;
 }
 // the sort for caller-supplied actions (catan_step); the rollout loops do it inside k_sample_random
-__global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict__ actions, u32* __restrict__ bins, i32* __restrict__ lists) {
+__global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict__ actions, u32* __restrict__ bins, i32* __restrict__ lists,
+                                                    u32* __restrict__ zero_me, int zero_n) {
     __shared__ u32 hist[NBINS], base[NBINS];
     if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (zero_me != nullptr && e < zero_n) zero_me[e] = 0;
     sort_append(e, e < c.n, e < c.n ? action_bin(c, actions, e) : BIN_NOOP, hist, base, bins, lists, c.N);
 }
 constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
@@ -2119,14 +2121,16 @@ DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u3
 // 2.5 us slower - the kernel is bound by its divergent sampling chain, not by the row accesses.)
 __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
                                                         u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
-                                                        u32* __restrict__ zero_me, u32* __restrict__ bins, i32* __restrict__ lists) {
+                                                        u32* __restrict__ zero_me, int zero_n, u32* __restrict__ bins, i32* __restrict__ lists) {
     __shared__ u32 hist[NBINS], base[NBINS];
     if (bins != nullptr) {
         if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
         __syncthreads();
     }
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
-    if (zero_me != nullptr && s.e == 0) *zero_me = 0;       // this iteration's (empty again) tier-1 request counter
+    // the list counters this step / iteration starts from zero with: the tier-1 request counter of the iteration (deferred),
+    // every slow-path list counter (lock-step: ctr[4..15]); nothing else touches them before k_step
+    if (zero_me != nullptr && s.e < zero_n) zero_me[s.e] = 0;
     int t = BIN_NOOP;                                       // padding games: the no-op bin
     if (s.e < c.n) {
         u32 m[MASK_WORDS];
