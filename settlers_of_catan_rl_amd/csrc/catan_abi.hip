@@ -258,6 +258,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
     HIPCHK(hipMemset(e->err, 0, 64));
+    HIPCHK(hipMemset(e->spec_mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));   // no shadow carries the tag of a step yet (epochs start at 1)
     HIPCHK(hipMemset(e->pend.ctr, 0, CTR_WORDS * sizeof(u32)));
     HIPCHK(hipMemset(e->pend.type, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
