@@ -39,11 +39,13 @@ enum { CATAN_OK = 0, CATAN_EINVAL = -1, CATAN_ENOMEM = -2, CATAN_EHIP = -3, CATA
 /* EnvWrapper.__init__ keyword arguments, env/wrapper.py:12-13 */
 typedef struct {
     int32_t max_proposed_trades_per_turn; /* 4; negative = None (unlimited) */
-    float win_reward;                     /* 500 */
     int32_t dense_reward;                 /* 0 */
-    float reward_annealing_factor;        /* 1.0 (env.reward_annealing_factor, RL/ppo/game_manager.py:164-166) */
     int32_t validate_actions;             /* 1: an action whose mask bit is clear is rejected and counted */
     int32_t auto_reset;                   /* 1: a finished game is reset inside catan_step (game_manager.py:112-113) */
+    double win_reward;                    /* 500 */
+    double reward_annealing_factor;       /* 1.0 (env.reward_annealing_factor, RL/ppo/game_manager.py:164-166).  Both are doubles
+                                           * because the reference shapes rewards in Python floats (env/wrapper.py:95-110) and
+                                           * rounds once, when the rollout tensors are built (RL/ppo/process_batch.py:63) */
 } catan_cfg_t;
 
 void catan_cfg_default(catan_cfg_t* cfg);
@@ -90,7 +92,12 @@ int catan_state_export(catan_env_t* env, int32_t* blob, const int64_t* env_idx, 
 int catan_state_import(catan_env_t* env, const int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream);
 
 /* env.reward_annealing_factor = f (RL/ppo/game_manager.py:164-166) */
-int catan_set_reward_annealing(catan_env_t* env, float factor);
+int catan_set_reward_annealing(catan_env_t* env, double factor);
+/* Rewards are computed in double exactly as env/wrapper.py:85-112 does (Python floats) and rounded ONCE to the float
+ * `reward` buffer of catan_step.  A caller that accumulates rewards over several steps before rounding, as
+ * RL/ppo/game_manager.py:94-95 does, registers a DEVICE double [n][4] here: every later step also stores the unrounded
+ * rewards there (NULL: off, the default). */
+int catan_set_reward_f64_buffer(catan_env_t* env, double* reward64);
 /* number of rejected (mask-illegal) actions since creation; synchronises the stream.  The reference raises
  * RuntimeError on the first one (env/wrapper.py:38-41). */
 int64_t catan_invalid_action_count(catan_env_t* env, catan_stream_t stream);

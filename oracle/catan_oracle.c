@@ -246,12 +246,12 @@ static int harbour_resource(int id) {
 }
 
 /* EnvWrapper(max_proposed_trades_per_turn, win_reward, dense_reward) + reward_annealing_factor (env/wrapper.py:12-22) */
-void orc_set_config(OrcEnv* e, int max_trades_per_turn, float win_reward, int dense_reward, float reward_annealing_factor) {
+void orc_set_config(OrcEnv* e, int max_trades_per_turn, double win_reward, int dense_reward, double reward_annealing_factor) {
     e->max_trades_per_turn = max_trades_per_turn; e->win_reward = win_reward; e->dense_reward = dense_reward;
     e->reward_annealing_factor = reward_annealing_factor;
 }
 void orc_config_default(OrcEnv* e) {
-    e->max_trades_per_turn = 4; e->win_reward = 500.0f; e->dense_reward = 0; e->reward_annealing_factor = 1.0f;
+    e->max_trades_per_turn = 4; e->win_reward = 500.0; e->dense_reward = 0; e->reward_annealing_factor = 1.0;
 }
 
 /* ====================================================================== reset */
@@ -944,23 +944,28 @@ int orc_step(OrcEnv* e, const int32_t* a, float* reward4, int* done) {
     static const int dict_order[4] = { P_BLUE, P_RED, P_ORANGE, P_WHITE };   /* game.py:18-23 */
     int d = 0;
     for (int i = 0; i < 4; i++) if (e->pl[dict_order[i]].vp >= 10) { d = 1; e->winner = dict_order[i]; }
+    /* Python floats are doubles: same operations in the same order in double, rounded to fp32 once (the reference rounds
+     * when the rollout tensors are built, RL/ppo/process_batch.py:63); the unrounded values stay in e->last_reward64 */
     for (int p = 1; p <= 4; p++) {
-        float r = 0.0f;
+        double r = 0.0;
         if (e->dense_reward) {
-            r += 5.0f * (float)(e->pl[p].vp - e->curr_vps[p]);
-            if (type == T_PLAYDEV) r += 5.0f;
-            if (type == T_ROBBER) r += 1.0f;
-            if (type == T_DISCARD) r -= 0.3f;
-            if (type == T_CITY) r += 2.5f;
+            r += (double)(5 * (e->pl[p].vp - e->curr_vps[p]));
+            if (type == T_PLAYDEV) r += 5.0;
+            if (type == T_ROBBER) r += 1.0;
+            if (type == T_DISCARD) r -= 0.3;
+            if (type == T_CITY) r += 2.5;
             r *= e->reward_annealing_factor;
         }
         e->curr_vps[p] = e->pl[p].vp;
-        reward4[p - 1] = r;
+        e->last_reward64[p - 1] = r;
     }
-    if (d) reward4[e->winner - 1] += e->win_reward;
+    if (d) e->last_reward64[e->winner - 1] += e->win_reward;
+    for (int p = 0; p < 4; p++) reward4[p] = (float)e->last_reward64[p];
     *done = d;
     return 0;
 }
+
+void orc_last_reward64(const OrcEnv* e, double* out4) { for (int p = 0; p < 4; p++) out4[p] = e->last_reward64[p]; }
 
 /* ref: wrapper.py:53-58, RL/ppo/game_manager.py:152-159 */
 int orc_deciding_player(const OrcEnv* e) {

@@ -16,8 +16,8 @@ class CatanHipError(RuntimeError):
 
 
 class CatanCfg(C.Structure):
-    _fields_ = [("max_proposed_trades_per_turn", C.c_int32), ("win_reward", C.c_float), ("dense_reward", C.c_int32),
-                ("reward_annealing_factor", C.c_float), ("validate_actions", C.c_int32), ("auto_reset", C.c_int32)]
+    _fields_ = [("max_proposed_trades_per_turn", C.c_int32), ("dense_reward", C.c_int32), ("validate_actions", C.c_int32),
+                ("auto_reset", C.c_int32), ("win_reward", C.c_double), ("reward_annealing_factor", C.c_double)]
 
 
 def _sources():
@@ -61,7 +61,8 @@ _SIGS = {
     "catan_sample_random_actions": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "catan_state_export": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "catan_state_import": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
-    "catan_set_reward_annealing": (C.c_int, [_vp, C.c_float]),
+    "catan_set_reward_annealing": (C.c_int, [_vp, C.c_double]),
+    "catan_set_reward_f64_buffer": (C.c_int, [_vp, _vp]),
     "catan_invalid_action_count": (C.c_int64, [_vp, _vp]),
     "catan_random_rollout": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp]),
     "catan_obs": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

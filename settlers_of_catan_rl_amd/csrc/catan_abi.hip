@@ -28,6 +28,7 @@ struct catan_env {
     int ctr_clean;        // lock-step: the counters are maintained by the kernels themselves (no memset per step) once set
     int lock_parity;      // ... and the sort alternates between its two count sets
     u32* err;             // invalid-action counter
+    double* reward64;     // caller-owned [n][4] unrounded rewards of catan_step (catan_set_reward_f64_buffer), or NULL
     // scratch for catan_random_rollout
     i32* scratch_actions; // [n][18]
     float* scratch_reward;// [n][4]
@@ -176,8 +177,8 @@ extern "C" {
 const char* catan_last_error(void) { return g_err.c_str(); }
 
 void catan_cfg_default(catan_cfg_t* c) {
-    c->max_proposed_trades_per_turn = 4; c->win_reward = 500.0f; c->dense_reward = 0;
-    c->reward_annealing_factor = 1.0f; c->validate_actions = 1; c->auto_reset = 1;
+    c->max_proposed_trades_per_turn = 4; c->win_reward = 500.0; c->dense_reward = 0;
+    c->reward_annealing_factor = 1.0; c->validate_actions = 1; c->auto_reset = 1;
 }
 int32_t catan_state_words(void) { return STATE_WORDS; }
 int32_t catan_mask_words(void) { return MASK_BITS; }
@@ -331,6 +332,7 @@ static StepCfg step_cfg(const catan_env_t* e) {
     StepCfg sc;
     sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
     sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn; sc.auto_reset = e->cfg.auto_reset;
+    sc.reward64 = e->reward64;
     sc.prof = e->prof_on ? e->prof : nullptr;
     sc.prof_wave = e->prof_on == 2 ? e->prof_wave : nullptr;
     return sc;
@@ -505,7 +507,13 @@ int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_i
     return launch_masks(e, S(stream));
 }
 
-int catan_set_reward_annealing(catan_env_t* e, float f) {
+int catan_set_reward_f64_buffer(catan_env_t* e, double* reward64) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_reward_f64_buffer: null handle");
+    e->reward64 = reward64;
+    return CATAN_OK;
+}
+
+int catan_set_reward_annealing(catan_env_t* e, double f) {
     if (!e) return fail(CATAN_EINVAL, "catan_set_reward_annealing: null handle");
     e->cfg.reward_annealing_factor = f;
     return CATAN_OK;

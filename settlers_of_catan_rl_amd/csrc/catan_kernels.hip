@@ -1191,7 +1191,8 @@ DEVI void update_largest_army(const S& s) {
     }
 }
 
-struct StepCfg { int validate; int dense_reward; float win_reward; float annealing; int max_trades; int auto_reset;
+struct StepCfg { int validate; int dense_reward; double win_reward; double annealing; int max_trades; int auto_reset;
+                 double* reward64;              // optional unrounded rewards [n][4] (catan_set_reward_f64_buffer)
                  unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
                  u32* prof_wave; };             // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
 constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
@@ -1313,17 +1314,19 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 #pragma unroll
         for (int i = 0; i < 4; i++) if (vps[dict_order[i]] >= 10) winner = dict_order[i] + 1;
         bool dn = winner != 0 && type >= 0;
-        float rw[4];
+        // the reference shapes rewards in Python floats (doubles) and rounds to fp32 once, when the rollout tensors are built
+        // (process_batch.py:63): same operations in the same order in double here, one rounding at the store
+        double rw[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            float r = 0.0f;
+            double r = 0.0;
             if (type >= 0) {
                 if (cfg.dense_reward) {
-                    r += 5.0f * (float)(vps[p] - s.b(B_CURVP + p));
-                    if (type == T_PLAYDEV) r += 5.0f;
-                    if (type == T_ROBBER) r += 1.0f;
-                    if (type == T_DISCARD) r -= 0.3f;
-                    if (type == T_CITY) r += 2.5f;
+                    r += (double)(5 * (vps[p] - s.b(B_CURVP + p)));
+                    if (type == T_PLAYDEV) r += 5.0;
+                    if (type == T_ROBBER) r += 1.0;
+                    if (type == T_DISCARD) r -= 0.3;
+                    if (type == T_CITY) r += 2.5;
                     r *= cfg.annealing;
                 }
                 s.sb(B_CURVP + p, vps[p]);
@@ -1331,7 +1334,11 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
             }
             rw[p] = r;
         }
-        *reinterpret_cast<float4*>(reward + s.e * 4) = make_float4(rw[0], rw[1], rw[2], rw[3]);      // one 16 B store per game
+        *reinterpret_cast<float4*>(reward + s.e * 4) = make_float4((float)rw[0], (float)rw[1], (float)rw[2], (float)rw[3]);   // one 16 B store per game
+        if (cfg.reward64) {
+            *reinterpret_cast<double2*>(cfg.reward64 + s.e * 4) = make_double2(rw[0], rw[1]);
+            *reinterpret_cast<double2*>(cfg.reward64 + s.e * 4 + 2) = make_double2(rw[2], rw[3]);
+        }
         if (dn) s.sb(B_WINNER, winner);
         done[s.e] = dn ? 1 : 0;
         want_reset = dn && cfg.auto_reset;
@@ -1395,6 +1402,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     int type = live ? type_of_bin(bin) : -1;
     if (live && type < 0) {
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cfg.reward64) { double2* r64 = reinterpret_cast<double2*>(cfg.reward64 + e * 4); r64[0] = make_double2(0.0, 0.0); r64[1] = make_double2(0.0, 0.0); }
         done[e] = 0;
     }
     if (__ballot(type >= 0) == 0) return;
@@ -1418,6 +1426,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     if (cfg.validate && type >= 0 && !action_legal(s, m_in, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
     if (rejected) {                                   // an illegal action leaves the game untouched (reward 0, not done)
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cfg.reward64) { double2* r64 = reinterpret_cast<double2*>(cfg.reward64 + e * 4); r64[0] = make_double2(0.0, 0.0); r64[1] = make_double2(0.0, 0.0); }
         done[e] = 0;
     }
     // clamp indices so that an unvalidated bad action cannot touch memory outside the game's rows

@@ -45,6 +45,16 @@ class VecCatanEnv(object):
         self.h = h
         self.reward = torch.zeros((self.n, 4), dtype=torch.float32, device=self.device)
         self.done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+        self.reward64 = None
+
+    def enable_reward64(self):
+        """Every later step also leaves its rewards UNROUNDED (the reference's Python floats, env/wrapper.py:85-112) in
+        `self.reward64` (float64 [n][4]); rollout collection sums those over a turn before rounding, as
+        RL/ppo/game_manager.py:94-95 does."""
+        if self.reward64 is None:
+            self.reward64 = torch.zeros((self.n, 4), dtype=torch.float64, device=self.device)
+            _lib.check(self.L.catan_set_reward_f64_buffer(self.h, _ptr(self.reward64)))
+        return self.reward64
 
     def close(self):
         if getattr(self, "h", None):

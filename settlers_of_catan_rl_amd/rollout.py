@@ -79,6 +79,9 @@ class RolloutCollector(object):
         self.recurrent = bool(getattr(policy, "include_lstm", False))
         self.lstm_size = int(policy.lstm_size) if self.recurrent else 0
         self.storage = RolloutStorage(num_steps, self.N, self.device, lstm_size=self.lstm_size)
+        # game_manager.py:94-95 sums the env's rewards (Python floats) over the other seats' moves and process_batch.py:63
+        # rounds the sum to fp32: the env leaves its unrounded rewards in a float64 buffer for that
+        self.reward64 = env.enable_reward64() if hasattr(env, "enable_reward64") else None
         self.reset()
 
     def set_opponents(self, nets, opp_index):
@@ -98,7 +101,7 @@ class RolloutCollector(object):
         st.masks[0] = 1.0
         self.pending_obs = self.env.deciding_player().long() == self.active_pid             # observations = [obs] iff the active seat moves first
         self.done_since = torch.zeros(N, dtype=torch.bool, device=dev)
-        self.racc = torch.zeros((N, 4), dtype=torch.float32, device=dev)
+        self.racc = torch.zeros((N, 4), dtype=torch.float64, device=dev)
         if self.recurrent:            # game_manager.py:54-59: every seat of every game starts from the zero state
             self.hid = torch.zeros((2, N, 4, self.lstm_size), dtype=torch.float32, device=dev)
 
@@ -145,7 +148,7 @@ class RolloutCollector(object):
             live = ~frozen
             done = done.bool() & live
             term = torch.where(live, 1.0 - done.float(), term)                              # :97
-            self.racc += reward * live[:, None]                                         # :94-95
+            self.racc += (reward.double() if self.reward64 is None else self.reward64) * live[:, None]   # :94-95
             was_active = (deciding == self.active_pid) & live
             idx = was_active.nonzero(as_tuple=True)[0]                                      # :102-105
             if idx.numel():
@@ -161,7 +164,7 @@ class RolloutCollector(object):
             app = torch.where(done, torch.ones_like(done), next_active & (self.n_act > 0) & ~self.done_since) & live
             idx = app.nonzero(as_tuple=True)[0]
             if idx.numel():
-                st.rewards[self.n_rew[idx].clamp(max=T + 1), idx] = r_active[idx]
+                st.rewards[self.n_rew[idx].clamp(max=T + 1), idx] = r_active[idx].float()              # process_batch.py:63
                 self.n_rew[idx] += 1
                 self.racc[idx, self.active_pid[idx] - 1] = 0.0
             idx = done.nonzero(as_tuple=True)[0]                                            # :112-124

@@ -34,4 +34,14 @@ def decode_obs(traj):
     return out
 
 
-TRAJS = ["traj_s3_e0.npz", "traj_s3_e1.npz", "traj_s17_e4.npz"]
+# the last two were generated with EnvWrapper's NON-default keyword arguments (env/wrapper.py:12-13): dense rewards x
+# env.reward_annealing_factor 0.37 with 1 proposed trade per turn; dense rewards with unlimited trades
+TRAJS = ["traj_s3_e0.npz", "traj_s3_e1.npz", "traj_s17_e4.npz", "traj_dense037_t1_s5_e2.npz", "traj_dense_tnone_s5_e3.npz"]
+
+
+def traj_kwargs(t):
+    """-> (dense_reward, reward_annealing_factor, max_proposed_trades_per_turn) a trajectory was generated with"""
+    if "dense" not in t.files:
+        return False, 1.0, 4
+    tr = int(t["trades"])
+    return bool(int(t["dense"])), float(t["anneal"]), (None if tr < 0 else tr)

@@ -34,7 +34,8 @@ def lib():
         L.orc_seed_mt.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.orc_rng_draws.argtypes = [vp]; L.orc_rng_draws.restype = C.c_uint32
         L.orc_config_default.argtypes = [vp]
-        L.orc_set_config.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_float]
+        L.orc_set_config.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double]
+        L.orc_last_reward64.argtypes = [vp, C.POINTER(C.c_double)]
         L.orc_board_reset.argtypes = [vp]
         L.orc_game_reset.argtypes = [vp]
         L.orc_masks.argtypes = [vp, f32p]
@@ -90,6 +91,16 @@ class OracleEnv(object):
             L.orc_seed_mt(self.p, mt_seeds[0], mt_seeds[1])
         else:
             L.orc_seed_philox(self.p, seed, env_id)
+
+    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0):
+        """EnvWrapper keyword arguments (env/wrapper.py:12-13); max_trades_per_turn None = unlimited"""
+        mt = -1 if max_trades_per_turn is None else int(max_trades_per_turn)
+        self.L.orc_set_config(self.p, mt, float(win_reward), int(dense_reward), float(reward_annealing_factor))
+
+    def last_reward64(self):
+        r = np.zeros((4,), dtype=np.float64)
+        self.L.orc_last_reward64(self.p, _p(r, C.c_double))
+        return r
 
     def board_reset(self):
         self.L.orc_board_reset(self.p)
@@ -191,8 +202,9 @@ class OracleBatch(object):
             self.L.orc_import(self.env_ptr(i), _p(blobs[i], C.c_int32))
 
     def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0):
+        mt = -1 if max_trades_per_turn is None else int(max_trades_per_turn)
         for i in range(self.n):
-            self.L.orc_set_config(self.env_ptr(i), int(max_trades_per_turn), float(win_reward), int(dense_reward), float(reward_annealing_factor))
+            self.L.orc_set_config(self.env_ptr(i), mt, float(win_reward), int(dense_reward), float(reward_annealing_factor))
 
     def masks(self):
         m = np.zeros((self.n, MASK_WORDS), dtype=np.float32)

@@ -17,6 +17,12 @@ class OracleVecEnv(object):
         self.auto_reset = auto_reset
         if dense_reward:
             self.b.set_config(dense_reward=True)
+        self.reward64 = None
+
+    def enable_reward64(self):
+        if self.reward64 is None:
+            self.reward64 = torch.zeros((self.n, 4), dtype=torch.float64)
+        return self.reward64
 
     def export_state(self):
         return torch.from_numpy(self.b.export())
@@ -55,11 +61,17 @@ class OracleVecEnv(object):
         rew = np.zeros((self.n, 4), dtype=np.float32); done = np.zeros((self.n,), dtype=np.uint8)
         for i in range(self.n):
             if a[i, 0] < 0:
+                if self.reward64 is not None:
+                    self.reward64[i] = 0.0
                 continue
             ai = np.ascontiguousarray(a[i]); r = np.zeros(4, dtype=np.float32); d = C.c_int(0)
             assert self.L.orc_action_is_legal(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32))), (i, ai)
             self.L.orc_step(self.b.env_ptr(i), ai.ctypes.data_as(C.POINTER(C.c_int32)), r.ctypes.data_as(C.POINTER(C.c_float)), C.byref(d))
             rew[i] = r; done[i] = d.value
+            if self.reward64 is not None:
+                r64 = np.zeros(4, dtype=np.float64)
+                self.L.orc_last_reward64(self.b.env_ptr(i), r64.ctypes.data_as(C.POINTER(C.c_double)))
+                self.reward64[i] = torch.from_numpy(r64)
             self.steps_taken[i] += 1
             if d.value and self.auto_reset:
                 self.L.orc_game_reset(self.b.env_ptr(i))

@@ -27,7 +27,10 @@ def test_reset_states_vs_reference(hip_lib):
 def test_trajectory_vs_reference(hip_lib, name):
     import torch
     t = gu.load(name)
-    env = _env(1, int(t["seed"]), env_id0=int(t["env_id"]), auto_reset=True)
+    dense, anneal, trades = gu.traj_kwargs(t)
+    env = _env(1, int(t["seed"]), env_id0=int(t["env_id"]), auto_reset=True, dense_reward=dense, max_proposed_trades_per_turn=trades)
+    env.set_reward_annealing_factor(anneal)
+    r64 = env.enable_reward64()
     sample = {int(i): k for k, i in enumerate(t["sample_idx"])}
     n = len(t["actions"])
     for step in range(n):
@@ -41,6 +44,8 @@ def test_trajectory_vs_reference(hip_lib, name):
         a = torch.from_numpy(t["actions"][step].astype(np.int32)).view(1, spec.ACTION_WORDS)
         rew, done = env.step(a)
         assert np.array_equal(rew[0].cpu().numpy(), t["rewards"][step]) and bool(done[0].item()) == bool(t["dones"][step]), step
+        if "rewards64" in t.files:      # the reference's Python-float rewards, before the single rounding to fp32
+            assert np.array_equal(r64[0].cpu().numpy(), t["rewards64"][step]), step
     assert env.invalid_action_count() == 0
     assert np.array_equal(env.export_state()[0].cpu().numpy(), t["final_blob"])
 

@@ -64,6 +64,8 @@ def test_reset_states(oracle):
 def test_trajectory(oracle, name):
     t = gu.load(name)
     e = oracle.OracleEnv(int(t["seed"]), int(t["env_id"]))
+    dense, anneal, trades = gu.traj_kwargs(t)
+    e.set_config(max_trades_per_turn=trades, dense_reward=dense, reward_annealing_factor=anneal)
     e.reset()
     sample = {int(i): k for k, i in enumerate(t["sample_idx"])}
     obs_gold = gu.decode_obs(t)
@@ -83,6 +85,8 @@ def test_trajectory(oracle, name):
         assert e.is_legal(a)
         rew, done = e.step(a)
         assert np.array_equal(rew, t["rewards"][step]) and done == bool(t["dones"][step]), step
+        if "rewards64" in t.files:      # the reference's Python-float rewards, before the single rounding to fp32
+            assert np.array_equal(e.last_reward64(), t["rewards64"][step]), step
         if done:
             e.reset()
     assert np.array_equal(e.export(), t["final_blob"])

@@ -3,7 +3,8 @@
 For each env id: drive the reference EnvWrapper (philox-patched RNG) and the oracle with the same
 uniformly-random legal actions; after every step compare masks (325), full state blob (736),
 reward[4], done, deciding player, and every `obs_every` steps the observation (1787 floats + 5 lists).
-Usage: python tools/fuzz_oracle_vs_ref.py [n_envs] [steps_per_env] [seed]
+Usage: python tools/fuzz_oracle_vs_ref.py [n_envs] [steps_per_env] [seed] [--dense] [--anneal F] [--trades K|none]
+(the options are EnvWrapper's non-default keyword arguments, env/wrapper.py:12-13, and env.reward_annealing_factor)
 """
 import sys
 import os
@@ -30,14 +31,16 @@ def compare_obs(ref_obs, orc):
     assert np.array_equal(lists, olists), (lists, olists)
 
 
-def fuzz(n_envs, steps, seed, obs_every=7, verbose=True):
+def fuzz(n_envs, steps, seed, obs_every=7, verbose=True, dense=False, anneal=1.0, trades=4):
     t0 = time.time()
     total = 0
     games = 0
     for env_id in range(n_envs):
         rng = np.random.default_rng(seed * 1000003 + env_id)
-        ref = rh.RefEnv(seed, env_id)
+        ref = rh.RefEnv(seed, env_id, dense_reward=dense, max_proposed_trades_per_turn=trades)
+        ref.env.reward_annealing_factor = anneal
         orc = ol.OracleEnv(seed, env_id)
+        orc.set_config(max_trades_per_turn=trades, dense_reward=dense, reward_annealing_factor=anneal)
         ref_obs = ref.reset()
         orc.reset()
         for s in range(steps):
@@ -57,6 +60,7 @@ def fuzz(n_envs, steps, seed, obs_every=7, verbose=True):
             ref_obs, rrew, rdone = ref.step(a)
             orew, odone = orc.step(a)
             assert rdone == odone and np.array_equal(rrew, orew), (env_id, s, a, rrew, orew, rdone, odone)
+            assert np.array_equal(ref.last_reward64, orc.last_reward64()), (env_id, s, a, ref.last_reward64, orc.last_reward64())
             total += 1
             if rdone:
                 compare_obs(ref_obs, orc)
@@ -72,8 +76,15 @@ def fuzz(n_envs, steps, seed, obs_every=7, verbose=True):
 
 
 if __name__ == "__main__":
-    n_envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    total, games = fuzz(n_envs, steps, seed)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n_envs", type=int, nargs="?", default=4)
+    ap.add_argument("steps", type=int, nargs="?", default=3000)
+    ap.add_argument("seed", type=int, nargs="?", default=1)
+    ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--anneal", type=float, default=1.0)
+    ap.add_argument("--trades", default="4")
+    a = ap.parse_args()
+    total, games = fuzz(a.n_envs, a.steps, a.seed, dense=a.dense, anneal=a.anneal,
+                        trades=None if a.trades.lower() == "none" else int(a.trades))
     print(f"PASS: {total} steps, {games} complete games, zero mismatches")

@@ -67,11 +67,14 @@ def gen_resets(n=192, seed=11):
     np.savez_compressed(os.path.join(OUT, "reset_states.npz"), seed=seed, blobs=np.array(blobs, dtype=np.int32))
 
 
-def gen_traj(seed, env_id, steps, sample_every=97):
+def gen_traj(seed, env_id, steps, sample_every=97, name=None, dense=False, anneal=1.0, trades=4):
+    """name/dense/anneal/trades: EnvWrapper's non-default keyword arguments (env/wrapper.py:12-13: dense shaping :95-106 x
+    env.reward_annealing_factor, trade limit :284-289); `rewards64` holds the reference's Python-float rewards."""
     rng = np.random.default_rng(seed * 7919 + env_id)
-    e = rh.RefEnv(seed, env_id)
+    e = rh.RefEnv(seed, env_id, dense_reward=dense, max_proposed_trades_per_turn=trades)
+    e.env.reward_annealing_factor = anneal
     obs = e.reset()
-    actions, rewards, dones, deciding, masks, crcs = [], [], [], [], [], []
+    actions, rewards, dones, deciding, masks, crcs, rewards64 = [], [], [], [], [], [], []
     s_idx, s_blob, s_obs, s_lists, s_lens, s_pid = [], [], [], [], [], []
     for t in range(steps):
         blob = e.state_blob()
@@ -82,11 +85,12 @@ def gen_traj(seed, env_id, steps, sample_every=97):
             s_idx.append(t); s_blob.append(blob); s_obs.append(f); s_lists.append(lists); s_lens.append(lens); s_pid.append(pid)
         a = rh.random_legal_action(e.masks(), e.env, rng)
         obs, rew, done = e.step(a)
-        actions.append(a); rewards.append(rew); dones.append(done)
+        actions.append(a); rewards.append(rew); dones.append(done); rewards64.append(e.last_reward64)
         if done:
             obs = e.reset()
     np.savez_compressed(
-        os.path.join(OUT, f"traj_s{seed}_e{env_id}.npz"), seed=seed, env_id=env_id,
+        os.path.join(OUT, name or f"traj_s{seed}_e{env_id}.npz"), seed=seed, env_id=env_id,
+        dense=int(dense), anneal=float(anneal), trades=-1 if trades is None else int(trades), rewards64=np.array(rewards64, dtype=np.float64),
         actions=np.array(actions, dtype=np.int8), rewards=np.array(rewards, dtype=np.float32), dones=np.array(dones, dtype=np.uint8),
         deciding=np.array(deciding, dtype=np.int8), masks=np.array(masks, dtype=np.uint8), state_crc=np.array(crcs, dtype=np.uint32),
         sample_idx=np.array(s_idx, dtype=np.int32), sample_blob=np.array(s_blob, dtype=np.int16),
@@ -292,6 +296,10 @@ def gen_randomise(n_games=6, steps=1800, every=37):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "randomise":
         print("randomise", gen_randomise()); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "kwargs":
+        print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
+        print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
         gen_league(); print("league"); sys.exit(0)
     gen_topology(); print("topology")
@@ -303,4 +311,6 @@ if __name__ == "__main__":
     gen_gae_ppo(); print("gae/ppo")
     gen_league(); print("league")
     print("randomise", gen_randomise())
+    print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
+    print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
     os.system(f"ls -la {OUT}; du -sh {OUT}")

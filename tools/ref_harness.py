@@ -139,7 +139,8 @@ class RefEnv(object):
         with patched_rng(self.stream):
             obs, reward, done, info = self.env.step(a)
         self.last_obs = obs
-        rew = np.array([reward[p] for p in PIDS], dtype=np.float32)
+        self.last_reward64 = np.array([reward[p] for p in PIDS], dtype=np.float64)      # the reference's Python floats
+        rew = self.last_reward64.astype(np.float32)                                      # one rounding (process_batch.py:63)
         return obs, rew, bool(done)
 
     def deciding_player(self):
