@@ -37,15 +37,13 @@ ALGO_BYTES = {
     # (112 words x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
     # one bitboard word: ~40 words x 4 B = 160)
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
-    "k_classify": 0,                                # (the sort for caller-supplied actions; the rollout loops sort in the sampler)
     "k_lr_finish": 0,                               # slow path (a few % of the games): latency-bound searches / re-deals,
     "k_lr_heavy": 0,                                # no meaningful byte roofline
-    "k_step_finish": 0,
     "k_reset_list": 0,
 }
-FAST_PATH = ("k_sample_random", "k_classify", "k_step")     # the kernels on the timed loop's critical path
+FAST_PATH = ("k_sample_random", "k_step")     # the kernels on the timed loop's critical path
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
 
 
 def cpu_baseline(sample_envs=16384, sample_steps=2048):
@@ -72,6 +70,49 @@ def cpu_baseline(sample_envs=16384, sample_steps=2048):
     }
 
 
+PREROLL_PASSES = 8192        # untimed deferred passes before --warmup: several game lengths, so that the games' ages are mixed
+MIN_TIMED_S = 0.30           # the timed region is `reps` x --steps passes, reps chosen so that it lasts at least this long
+
+
+def _reps_for(per_pass_s, steps):
+    import math
+    return max(1, int(math.ceil(MIN_TIMED_S / max(per_pass_s * steps, 1e-9))))
+
+
+def ppo_update_record(env, n, rank, world, T, cdist):
+    """The metric's second half (BASELINE.json: "PPO wall-clock/update, 1->8 GPU"; workload RL/ppo/arguments.py:48-56) on the
+    same games: one rollout of T active-seat decisions per game + one PPO update with the reference's 10 epochs x 64
+    minibatches, bf16 autocast, fp32 master weights, flat-bucket gradient all-reduce over RCCL when world > 1.  T is REDUCED
+    from the reference's 200 so that the default bench run stays within minutes (the minibatch count is the reference's;
+    a minibatch has T * n / 64 rows); tools/bench_ppo.py runs the full T = 200."""
+    import torch
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    torch.manual_seed(0)
+    net = CatanPolicy().cuda()
+    cdist.broadcast_parameters(net)
+    col = RolloutCollector(env, net, T, seed=rank, autocast_dtype=torch.bfloat16)
+    tr = PPOTrainer(net, PPOConfig(), autocast_dtype=torch.bfloat16, seed=rank)
+    cdist.barrier()
+    t0 = time.perf_counter()
+    st = col.gather_rollouts()
+    cdist.barrier()
+    t1 = time.perf_counter()
+    vl, al, el = tr.update(st)
+    cdist.barrier()
+    t2 = time.perf_counter()
+    rollout_s, update_s = cdist.max_over_ranks(t1 - t0), cdist.max_over_ranks(t2 - t1)
+    dec = world * n * T
+    return {"value": rollout_s + update_s, "unit": "s/update", "higher_is_better": False, "num_steps": T,
+            "reference_num_steps": 200, "games_per_gpu": n, "ppo_epoch": tr.cfg.ppo_epoch, "num_mini_batch": tr.cfg.num_mini_batch,
+            "minibatch_rows": n * T // tr.cfg.num_mini_batch, "active_seat_decisions_per_update": dec,
+            "rollout_s": rollout_s, "update_s": update_s, "env_passes_in_rollout": col.iters, **tr.timings,
+            "decisions_per_s": dec / (rollout_s + update_s), "dtype": "bf16 autocast, fp32 master weights",
+            "losses": {"value": vl, "action": al, "entropy": el},
+            "note": "T reduced from the reference's 200 (stated); every seat plays the central policy; full T: tools/bench_ppo.py"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +124,10 @@ def main():
     ap.add_argument("--no-validate", action="store_true", help="skip the mask-bit legality check in k_step")
     ap.add_argument("--window", type=int, default=32,
                     help="W > 0: deferred loop, tier-2 longest road + re-deals once per W passes; 0: lock-step loop")
-    ap.add_argument("--no-lockstep", action="store_true", help="skip the short lock-step measurement of a deferred run")
+    ap.add_argument("--no-lockstep", action="store_true", help="skip the lock-step measurement of a deferred run")
+    ap.add_argument("--preroll", type=int, default=PREROLL_PASSES, help="untimed passes before --warmup (mixes the games' ages)")
+    ap.add_argument("--ppo-steps", type=int, default=16,
+                    help="T of the `ppo_update` sub-record (one rollout + one PPO update on the same games); 0: skip")
     args = ap.parse_args()
 
     import torch
@@ -100,87 +144,126 @@ def main():
     env_id0, n = cdist.shard(rank, args.envs)                # global game ids: results do not depend on `world`
     env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0, validate_actions=not args.no_validate, auto_reset=True)
 
+    # ---- pre-roll (untimed, independent of --warmup): all games start a game at pass 0, and the opening phase (initial
+    # placement: every road goes through the longest-road slow path) is not the steady state.  Several game lengths of
+    # deferred passes spread the games' ages; its duration also sizes the timed region.
+    W = args.window if args.window > 0 else 32
+    cdist.barrier()
+    t0 = time.perf_counter()
+    env.random_rollout_deferred(max(args.preroll, 64), W)
+    cdist.barrier()
+    pre_pass_s = cdist.max_over_ranks((time.perf_counter() - t0) / max(args.preroll, 64))
+    step_idx = 1 << 20                                        # lock-step passes index the policy stream by a global step number
+
     if args.window > 0:
+        reps = _reps_for(pre_pass_s, args.steps)
         env.random_rollout_deferred(args.warmup, args.window)
         c0 = int(env.policy_counters().sum())
         cdist.barrier()
         t0 = time.perf_counter()
-        env.random_rollout_deferred(args.steps, args.window)
+        env.random_rollout_deferred(args.steps * reps, args.window)      # reps x EXACTLY --steps passes, one timed region
         cdist.barrier()
         dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
         my_steps = int(env.policy_counters().sum()) - c0        # decisions actually executed by this rank's games
         env_steps = cdist.sum_over_ranks(my_steps)
     else:
-        env.random_rollout(0, args.warmup)
+        reps = _reps_for(pre_pass_s * 4.0, args.steps)          # a lock-step pass is ~4 deferred passes long
+        env.random_rollout(step_idx, args.warmup); step_idx += args.warmup
         cdist.barrier()
         t0 = time.perf_counter()
-        env.random_rollout(args.warmup, args.steps)
+        env.random_rollout(step_idx, args.steps * reps); step_idx += args.steps * reps
         cdist.barrier()
         dt = cdist.max_over_ranks(time.perf_counter() - t0)     # max over ranks
-        my_steps = n * args.steps
-        env_steps = world * n * args.steps
+        my_steps = n * args.steps * reps
+        env_steps = world * my_steps
+    timed_passes = args.steps * reps
     bad = env.invalid_action_count()
 
     lockstep = None
     if args.window > 0 and not args.no_lockstep:
-        # the same games, continued in lock-step for a short stretch (every game steps in every pass)
-        ls_steps = min(args.steps, 512)
-        env.random_rollout(1 << 20, 32)
+        # the same games, continued in lock-step (every game steps in every pass): same rule for the timed region
+        ls_reps = _reps_for(pre_pass_s * 4.0, args.steps)
+        env.random_rollout(step_idx, 32); step_idx += 32
         cdist.barrier()
         t0 = time.perf_counter()
-        env.random_rollout((1 << 20) + 32, ls_steps)
+        env.random_rollout(step_idx, args.steps * ls_reps); step_idx += args.steps * ls_reps
         cdist.barrier()
         ls_dt = cdist.max_over_ranks(time.perf_counter() - t0)
-        lockstep = {"value": world * n * ls_steps / ls_dt, "unit": "env-steps/s", "steps": ls_steps, "ms_per_step": ls_dt / ls_steps * 1e3}
+        ls_passes = args.steps * ls_reps
+        lockstep = {"value": world * n * ls_passes / ls_dt, "unit": "env-steps/s", "steps": args.steps, "reps": ls_reps,
+                    "timed_s": ls_dt, "ms_per_step": ls_dt / ls_passes * 1e3}
 
     out = None
+    kms = None
     if rank == 0:
         # per-kernel durations: HIP events on the stream each kernel is launched on, a separate short pass right after
-        prof_steps = min(args.steps, 512)
-        kms = env.random_rollout_timed(args.warmup + args.steps, prof_steps, args.window)
+        prof_steps = 512
+        kms = env.random_rollout_timed(step_idx, prof_steps, args.window)
+    step_idx += 512
+    ppo = None
+    if args.ppo_steps > 0:
+        ppo = ppo_update_record(env, n, rank, world, args.ppo_steps, cdist)
+    if rank == 0:
         slow_launches = prof_steps if args.window <= 0 else -(-prof_steps // args.window)
-        launches = {k: (slow_launches if k in ("k_lr_heavy", "k_step_finish", "k_reset_list") else prof_steps) for k in kms}
+        launches = {k: (slow_launches if k in ("k_lr_heavy", "k_reset_list") else prof_steps) for k in kms}
         per_launch_us = {k: v * 1e3 / launches[k] for k, v in kms.items() if k in ALGO_BYTES}
         dom = max(FAST_PATH, key=per_launch_us.get)
-        active = my_steps / (n * args.steps)                  # games that take a step in a pass (the others are busy)
+        active = my_steps / (n * timed_passes)                # games that take a step in a pass (the others are busy)
         achieved = ALGO_BYTES[dom] * n * active / (per_launch_us[dom] * 1e-6) / 1e9
         fast_us = sum(per_launch_us[k] for k in FAST_PATH)
-        traffic = None
+        traffic, traffic_src = None, None
         if os.path.exists(PMC_SUMMARY):
             with open(PMC_SUMMARY) as f:
-                traffic = json.load(f).get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                pm = json.load(f)
+            k = pm.get("kernels", {}).get(dom, {})
+            traffic = k.get("hbm_bytes_per_launch")
+            traffic_src = (f"steady-state PMC of the same kernel, NOT collected in this run (counters need rocprofv3): "
+                           f"{os.path.relpath(PMC_SUMMARY, ROOT)}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated, "
+                           f"65 536 games after the same pre-roll")
+        per_step_bytes = sum(ALGO_BYTES[k] for k in FAST_PATH)
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": ("profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated; "
-                               "65 536 games, same kernels)") if traffic is not None else None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_game": ALGO_BYTES[dom],
             "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n * active,
             "avg_launch_us": per_launch_us[dom],
             "all_kernels_avg_launch_us": per_launch_us,
-            "fast_path_algorithmic_bytes_per_game": sum(ALGO_BYTES[k] for k in FAST_PATH),
-            "fast_path_achieved_gbs": sum(ALGO_BYTES[k] for k in FAST_PATH) * n * active / (fast_us * 1e-6) / 1e9,
+            "fast_path_algorithmic_bytes_per_game": per_step_bytes,
+            "fast_path_achieved_gbs": per_step_bytes * n * active / (fast_us * 1e-6) / 1e9,
+            # whole schedules, end to end: algorithmic bytes of one env step x executed steps / wall time
+            "end_to_end": {"algorithmic_bytes_per_env_step": per_step_bytes,
+                           "timed_schedule_gbs": per_step_bytes * env_steps / world / dt / 1e9,
+                           "timed_schedule_frac": per_step_bytes * env_steps / world / dt / 1e9 / HBM_PEAK_GBS},
             "note": "integer/byte rules engine at one wave per SIMD: latency- and divergence-bound, far below the HBM "
                     "roofline by nature (SURVEY.md 8(d)); frac is reported for the dominant kernel of the timed loop; "
-                    "the slow-path kernels (k_lr_*, k_step_finish, k_reset_list) run on side streams in the deferred loop",
+                    "the slow-path kernels (k_lr_*, k_reset_list) are latency-bound path searches / re-deals (LDS + ALU, "
+                    "a few MB per launch) and run on side streams in the deferred loop",
         }
+        if lockstep is not None:
+            g = per_step_bytes * n / (lockstep["ms_per_step"] * 1e-3) / 1e9
+            roofline["end_to_end"].update(lockstep_gbs=g, lockstep_frac=g / HBM_PEAK_GBS)
         value = env_steps / dt
         out = {
             "metric": "Catan env-steps/sec at 65k parallel games", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "reps": reps, "timed_passes": timed_passes,
+            "timed_s": dt, "preroll_passes": max(args.preroll, 64), "ms_per_step": dt / timed_passes * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 (integer bitboards)",
             "data": "synthetic (random-seed boards, uniform-random legal policy on device)",
             "config": {"workload": "configs[1]: 65 536 parallel envs per GPU, random policy, step+mask only, "
                                    "bit-exact vs CPU oracle", "games_per_gpu": n, "validate_actions": not args.no_validate,
                        "auto_reset": True, "parallelism": f"games sharded over {world} GPU(s), no collective",
                        "schedule": (f"deferred, window {args.window}: slow-path games sit out; value = executed env steps / time"
-                                    if args.window > 0 else "lock-step: every game steps in every pass")},
-            "env_steps_executed": env_steps, "active_fraction": env_steps / (world * n * args.steps),
+                                    if args.window > 0 else "lock-step: every game steps in every pass"),
+                       "timed_region": f"{reps} x --steps passes in one region (>= {MIN_TIMED_S} s), after {max(args.preroll, 64)} "
+                                       f"untimed pre-roll passes + --warmup"},
+            "env_steps_executed": env_steps, "active_fraction": env_steps / (world * n * timed_passes),
             "invalid_actions": bad,
             "roofline": roofline,
         }
         if lockstep is not None:
             out["lockstep"] = lockstep
+        if ppo is not None:
+            out["ppo_update"] = ppo
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["value"]

@@ -512,6 +512,32 @@ class CatanPolicy(nn.Module):
     def denormalise(self, v):
         return self.VALUE_MEAN + v * self.VALUE_STD          # RL/models/utils.py:20-21
 
+    # entries of the reference `SettlersAgentPolicy.state_dict()` that hold no learnable state: the empty `dummy_param`
+    # device probes of its sub-modules and the value normaliser's constants (RL/models/utils.py:9-15, policy.py:23)
+    REFERENCE_DUMMY_KEYS = (
+        "dummy_param", "value_normaliser.dummy_param", "observation_module.hidden_card_mha.dummy_param",
+        "observation_module.played_card_mha.dummy_param",
+        "observation_module.tile_encoder.encoder_layers.0.multi_headed_attention.dummy_param",
+        "observation_module.tile_encoder.encoder_layers.1.multi_headed_attention.dummy_param",
+        "observation_module.current_player_module.dummy_param", "observation_module.other_players_module.dummy_param",
+        "action_head_module.dummy_param", "action_head_module.action_heads.7.dummy_param",
+        "action_head_module.action_heads.8.dummy_param")
+
+    @classmethod
+    def to_reference_state_dict(cls, sd):
+        """A `CatanPolicy.state_dict()` completed to the key set of the reference net, so that the reference's strict
+        `central_policy.load_state_dict` / `rollout_manager.update_policy` (robust_train.py:55-59, game_manager.py:161-162)
+        accept it."""
+        out = {k: v.detach().cpu() for k, v in sd.items()}
+        for k in cls.REFERENCE_DUMMY_KEYS:
+            out.setdefault(k, torch.empty(0))
+        out.setdefault("value_normaliser.mean", torch.tensor([cls.VALUE_MEAN], dtype=torch.float32))
+        out.setdefault("value_normaliser.std", torch.tensor([cls.VALUE_STD], dtype=torch.float32))
+        return out
+
+    def reference_state_dict(self):
+        return self.to_reference_state_dict(self.state_dict())
+
     def load_reference_state_dict(self, sd):
         """Loads a reference `SettlersAgentPolicy.state_dict()` (same parameter names; the reference's empty
         `dummy_param` entries and the value normaliser constants are ignored)."""

@@ -122,13 +122,15 @@ class TrainingLoop(object):
     def save_reference_tuple(self, path):
         """The reference's own checkpoint layout (robust_train.py:155-156): the 5-tuple (central state-dict, deque of
         earlier state-dicts, eval logs, update number, args).  State-dict keys are the reference's (CatanPolicy keeps its
-        parameter names); the reference's two extra entries (`dummy_param`, the value normaliser's constants) are added so
-        that `central_policy.load_state_dict` on the reference side accepts it."""
+        parameter names); the reference's entries without learnable state (the empty `dummy_param`s of its sub-modules, the
+        value normaliser's constants) are added to the central state-dict AND to every league entry, so that the reference's
+        strict `load_state_dict` accepts them (`policy.CatanPolicy.to_reference_state_dict`)."""
         import argparse
         from collections import deque
-        sd = {k: v.detach().cpu() for k, v in self.policy.state_dict().items()}
-        sd.setdefault("dummy_param", torch.empty(0))
-        earlier = deque(self.league.earlier if self.league is not None else [], maxlen=(self.league.earlier.maxlen if self.league is not None else 500))
+        complete = getattr(type(self.policy), "to_reference_state_dict", None) or (lambda d: {k: v.detach().cpu() for k, v in d.items()})
+        sd = complete(self.policy.state_dict())
+        earlier = deque((complete(e) for e in (self.league.earlier if self.league is not None else [])),
+                        maxlen=(self.league.earlier.maxlen if self.league is not None else 500))
         torch.save((sd, earlier, self.eval_logs, self.update_num, argparse.Namespace(**self.args.__dict__)), path)
 
     def load_reference_tuple(self, path):

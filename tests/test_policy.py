@@ -171,3 +171,40 @@ def test_lstm_path_parity_with_reference_net(oracle):
     v, lp, ent, _ = mine.evaluate_actions(x["obs_f"], x["lists"], x["lens"], x["masks"], a_s, hidden=(hs, cs), nonterminal=nts)
     (v.mean() + lp.mean() + ent).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in mine.lstm.parameters())
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="upstream reference not mounted")
+def test_reference_state_dict_loads_strictly_into_the_reference_net(tmp_path):
+    """The checkpoint tuple written by train_loop (central state-dict and league entries) must pass the reference's STRICT
+    `load_state_dict` (robust_train.py:55-59, game_manager.py:161-162)."""
+    from settlers_of_catan_rl_amd import train_loop as tl
+    from settlers_of_catan_rl_amd.league import League
+    from RL.models.build_agent_model import build_agent_model
+    net = CatanPolicy()
+    ref = build_agent_model()
+    ref.load_state_dict(net.reference_state_dict(), strict=True)
+    assert set(net.reference_state_dict()) == set(ref.state_dict())
+
+    class _Env(object):
+        n = 4
+        def set_reward_annealing_factor(self, f): pass
+
+    class _Col(object):
+        N = 4
+        def set_opponents(self, nets, idx): pass
+
+    class _Tr(object):
+        optimiser = torch.optim.Adam(net.parameters(), lr=3e-4)
+        class cfg: entropy_coef = 0.0
+
+    lg = League(envs_per_worker=2, seed=0)
+    loop = tl.TrainingLoop(_Env(), net, _Col(), _Tr(), tl.TrainArgs(num_steps=2, total_env_steps=800), league=lg, make_net=CatanPolicy)
+    lg.add(net)
+    loop.save_reference_tuple(str(tmp_path / "ref.pt"))
+    sd, earlier, _, _, _ = torch.load(str(tmp_path / "ref.pt"), weights_only=False)
+    ref.load_state_dict(sd, strict=True)
+    assert len(earlier) == 2
+    for e in earlier:
+        build_agent_model().load_state_dict(e, strict=True)
+    # and the other way round
+    loop.load_reference_tuple(str(tmp_path / "ref.pt"))
