@@ -259,6 +259,7 @@ class EnvWrapper(object):
         self.vec = VecCatanEnv(1, seed=seed, env_id0=env_id, max_proposed_trades_per_turn=max_proposed_trades_per_turn,
                                win_reward=win_reward, dense_reward=dense_reward, validate_actions=validate_actions,
                                auto_reset=False)
+        self.vec.enable_reward64()       # step() hands back the reference's Python floats (unrounded doubles)
         self.validate_actions = validate_actions
         self.game = _GameView(self)
         self._cache = None
@@ -302,7 +303,7 @@ class EnvWrapper(object):
         self._cache = None
         if self.validate_actions and self.vec.invalid_action_count() != bad0:
             raise RuntimeError("invalid action (its legal-action mask bit is clear)")   # reference env/wrapper.py:38-41
-        r = reward[0].cpu().numpy()
+        r = self.vec.reward64[0].cpu().numpy()
         rew = {pid: float(r[pid - 1]) for pid in (1, 2, 3, 4)}
         return self._get_obs(), rew, bool(done[0].item()), {"log": None}
 

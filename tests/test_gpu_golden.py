@@ -51,16 +51,21 @@ def test_trajectory_vs_reference(hip_lib, name):
 
 
 def test_reference_states_masks(hip_lib):
-    """Import every sampled reference state of every golden trajectory into the device and compare the masks."""
-    blobs, masks = [], []
+    """Import every sampled reference state of every golden trajectory into the device and compare the masks (one env per
+    trade limit the trajectories were generated with: the propose-trade mask bit depends on it, wrapper.py:284-289)."""
+    groups = {}
     for name in gu.TRAJS:
         t = gu.load(name)
+        _, _, trades = gu.traj_kwargs(t)
+        blobs, masks = groups.setdefault(trades, ([], []))
         for k, i in enumerate(t["sample_idx"]):
             blobs.append(t["sample_blob"][k].astype(np.int32)); masks.append(gu.unpack_masks(t["masks"][int(i)]))
-    env = _env(len(blobs), 0)
-    env.import_state(np.array(blobs))
-    assert np.array_equal(env.export_state().cpu().numpy(), np.array(blobs))
-    assert np.array_equal(env.get_action_masks().cpu().numpy(), np.array(masks))
+    assert len(groups) >= 3
+    for trades, (blobs, masks) in groups.items():
+        env = _env(len(blobs), 0, max_proposed_trades_per_turn=trades)
+        env.import_state(np.array(blobs))
+        assert np.array_equal(env.export_state().cpu().numpy(), np.array(blobs))
+        assert np.array_equal(env.get_action_masks().cpu().numpy(), np.array(masks)), trades
 
 
 def test_randomise_uncertainty_golden_and_oracle(oracle, hip_lib):
