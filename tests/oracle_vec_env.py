@@ -15,9 +15,15 @@ class OracleVecEnv(object):
         self.L = self.b.L
         self.steps_taken = np.zeros(n, dtype=np.int64)
         self.auto_reset = auto_reset
+        self.dense_reward = bool(dense_reward)
         if dense_reward:
             self.b.set_config(dense_reward=True)
         self.reward64 = None
+        self.annealing_log = []
+
+    def set_reward_annealing_factor(self, f):
+        self.annealing_log.append(float(f))
+        self.b.set_config(dense_reward=self.dense_reward, reward_annealing_factor=float(f))
 
     def enable_reward64(self):
         if self.reward64 is None:

@@ -293,7 +293,133 @@ def gen_randomise(n_games=6, steps=1800, every=37):
     return len(before)
 
 
+def _dry_run_game_length(seed, env_id, rng_seed, limit=6000):
+    """env steps until the first game of (seed, env_id) ends under the scripted policy seeded with rng_seed"""
+    rng = np.random.default_rng(rng_seed)
+    e = rh.RefEnv(seed, env_id)
+    e.reset()
+    for s in range(limit):
+        _, _, done = e.step(rh.weighted_legal_action(e.masks(), e.env, rng))
+        if done:
+            return s + 1
+    raise RuntimeError("no game end")
+
+
+def gen_rollout_small(n_envs=4, T=12, n_rollouts=6, seed=31):
+    """SURVEY 8(c) fixture 5: the reference's OWN `GamesAndPoliciesManager.gather_rollouts` / `_after_rollouts`
+    (RL/ppo/game_manager.py:69-150) and `BatchProcessor.process_rollouts` (RL/ppo/process_batch.py:37-104) on n_envs games
+    x n_rollouts consecutive rollouts of T active-seat decisions, with scripted decisions (ref_harness.ScriptedRefPolicy) and
+    every env on its own Philox stream.  Three of the games are advanced (by the same scripted policy, through env.step
+    directly) to shortly before their end first, so that game ends, the re-deal, reward / terminal-mask bookkeeping across
+    the end and the carry-over into the next rollout are all inside the fixture; the manager's `reset()` then runs with
+    `env.reset` disabled so that it adopts those positions.  Stored: the pre-advance actions, every decision of every seat
+    during the rollouts (replayed by the collector under test), and the reference's rollout tensors verbatim."""
+    import types
+    from RL.ppo.game_manager import GamesAndPoliciesManager
+    from RL.ppo.process_batch import BatchProcessor
+    with rh.patched_rng(rh.PhiloxStream(seed ^ 0xABC, 0)):            # constructor draws (boards, seat orders) from a scratch stream
+        mgr = GamesAndPoliciesManager(num_envs=n_envs, num_steps=T)
+    rng_seeds = [9000 + i for i in range(n_envs)]
+    lengths = [_dry_run_game_length(seed, i, rng_seeds[i]) for i in range(n_envs)]
+    pre = [0] + [max(0, lengths[i] - 25 - 30 * i) for i in range(1, n_envs)]   # env 0 starts fresh (initial placement phase)
+    streams = [rh.PhiloxStream(seed, i) for i in range(n_envs)]
+    ctx = rh.ScriptedContext(mgr.envs, streams, rng_seeds)
+    ctx.hook_manager(mgr)
+    pol = rh.ScriptedRefPolicy(ctx, mgr.policies[0].lstm_size)
+    mgr.policy_maps = [{pid: pol for pid in pm} for pm in mgr.policy_maps]
+    pre_actions = []
+    for i, env in enumerate(mgr.envs):
+        env.reset()
+        acts = []
+        for _ in range(pre[i]):
+            a = rh.weighted_legal_action(env.get_action_masks(), env, ctx.rngs[i])
+            _, _, done, _ = env.step(rh.action_to_heads(a))
+            assert not done
+            acts.append(np.array(a, dtype=np.int8))
+        pre_actions.append(np.array(acts, dtype=np.int8).reshape(-1, 18))
+    saved = [env.reset for env in mgr.envs]
+    for env in mgr.envs:                                              # reset() adopts the current positions
+        env.reset = (lambda e: (lambda: e._get_obs()))(env)
+    mgr.reset()
+    for env, r in zip(mgr.envs, saved):
+        env.reset = r
+    args = types.SimpleNamespace(num_steps=T, num_processes=1, num_envs_per_process=n_envs, gamma=0.999, gae_lambda=0.95)
+    bp = BatchProcessor(args, lstm_dim=mgr.policies[0].lstm_size, device="cpu")
+    out = {"seed": seed, "n_envs": n_envs, "T": T, "n_rollouts": n_rollouts,
+           "active_pid": np.array([int(p) for p in mgr.active_player_ids], dtype=np.int8),
+           "pre_len": np.array(pre, dtype=np.int32), "pre_actions": np.concatenate(pre_actions).astype(np.int8)}
+    trace_mark = [0] * n_envs
+    for r in range(n_rollouts):
+        rollouts = mgr.gather_rollouts()
+        mgr._after_rollouts()
+        bp.process_rollouts([rollouts])
+        for i in range(n_envs):                                       # all-seat decisions taken during this rollout
+            seg = np.array(ctx.trace[i][trace_mark[i]:], dtype=np.int8).reshape(-1, 18)
+            out[f"r{r}_trace_{i}"] = seg
+            trace_mark[i] = len(ctx.trace[i])
+        for k in bp.obs_keys:
+            v = bp.obs_dict[k].numpy()
+            out[f"r{r}_obs_{k}"] = v.astype(np.int8) if v.dtype == np.int64 else v.astype(np.float16)
+            assert np.array_equal(out[f"r{r}_obs_{k}"].astype(v.dtype), v), k          # exactly representable
+        out[f"r{r}_rewards"] = bp.rewards.numpy()
+        out[f"r{r}_masks"] = bp.masks.numpy()
+        out[f"r{r}_action_log_probs"] = bp.action_log_probs.numpy()
+        for i in range(12):
+            out[f"r{r}_actions_{i}"] = bp.actions[i].numpy().astype(np.int8)
+            out[f"r{r}_action_masks_{i}"] = bp.action_masks[i].numpy().astype(np.int8)
+        out[f"r{r}_games_complete"] = bp.games_complete
+        out[f"r{r}_state_crc"] = np.array([crc(rh.state_blob(env, streams[i].draws)) for i, env in enumerate(mgr.envs)], dtype=np.uint32)
+    assert bp.games_complete >= 3, bp.games_complete
+    np.savez_compressed(os.path.join(OUT, "rollout_small.npz"), **out)
+    return bp.games_complete, pre, lengths
+
+
+class _EvalPolicy(object):
+    """scripted `act` + the real net's obs / mask / action converters (the evaluation manager calls those on policies[0])"""
+
+    def __init__(self, scripted, real):
+        self.s, self.real = scripted, real
+        self.lstm_size = real.lstm_size
+
+    def eval(self):
+        return self
+
+    def act(self, *a, **kw):
+        return self.s.act(*a, **kw)
+
+    def __getattr__(self, name):
+        return getattr(self.real, name)
+
+
+def gen_eval_small(n_games=3, seed=41):
+    """The reference's `EvaluationManager.run_evaluation_game` (RL/ppo/evaluation_manager.py:36-74) on n_games full games with
+    scripted decisions: the shuffled seat order, (winner, victory points, game steps, policy decisions) and every decision."""
+    from RL.ppo.evaluation_manager import EvaluationManager
+    out = {"seed": seed, "n_games": n_games}
+    for g in range(n_games):
+        with rh.patched_rng(rh.PhiloxStream(seed ^ 0xABC, g)):
+            mgr = EvaluationManager()
+        stream = rh.PhiloxStream(seed, g)
+        ctx = rh.ScriptedContext([mgr.env], [stream], [7000 + g])
+        ctx.hook_manager(mgr)
+        pol = rh.ScriptedRefPolicy(ctx, mgr.policies[0].lstm_size)
+        real = mgr.policies
+        mgr.policies = [_EvalPolicy(pol, real[0]) for _ in range(4)]
+        random.seed(500 + g)                                          # `random.shuffle(self.order)` (evaluation_manager.py:28)
+        winner, vps, steps, decisions = mgr.run_evaluation_game()
+        out[f"g{g}_order"] = np.array([int(p) for p in mgr.order], dtype=np.int8)
+        out[f"g{g}_result"] = np.array([winner, vps, steps, decisions], dtype=np.int32)
+        out[f"g{g}_trace"] = np.array(ctx.trace[0], dtype=np.int8)
+        out[f"g{g}_final_blob"] = rh.state_blob(mgr.env, stream.draws)
+    np.savez_compressed(os.path.join(OUT, "eval_small.npz"), **out)
+    return [out[f"g{g}_result"].tolist() for g in range(n_games)]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+        print("rollout_small (games complete, pre-advance, first-game lengths):", gen_rollout_small()); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        print("eval_small (winner, vps, steps, decisions):", gen_eval_small()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "randomise":
         print("randomise", gen_randomise()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kwargs":
@@ -313,4 +439,6 @@ if __name__ == "__main__":
     print("randomise", gen_randomise())
     print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
     print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
+    print("rollout_small", gen_rollout_small())
+    print("eval_small", gen_eval_small())
     os.system(f"ls -la {OUT}; du -sh {OUT}")

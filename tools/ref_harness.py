@@ -322,3 +322,74 @@ def random_legal_action(masks, env, rng):
     elif t == 12:
         a[17] = pick(m[11])
     return a
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Scripted stand-ins for the four nets of a reference worker, so that fixtures produced by the reference's own
+# GamesAndPoliciesManager / EvaluationManager do not depend on floating-point details of a network: the decision is a
+# seeded random legal action (build-biased, so that games end sooner), recorded in `trace`.
+TYPE_WEIGHTS = np.array([60, 8, 60, 12, 12, 3, 1, 1, 6, 1, 1, 1, 1], dtype=float)
+
+
+def weighted_legal_action(masks, env, rng):
+    m0 = np.asarray(masks[0])
+    w = TYPE_WEIGHTS * (m0 > 0)
+    t = int(rng.choice(13, p=w / w.sum()))
+    mm = [np.array(x, copy=True) for x in masks]
+    mm[0] = np.zeros(13)
+    mm[0][t] = 1
+    return random_legal_action(mm, env, rng)
+
+
+def scripted_log_prob(a18):
+    """any deterministic function of the action serves as the stored `action_log_probs`"""
+    return -0.25 - float(int(np.sum(a18)) % 7)
+
+
+class ScriptedContext(object):
+    """Which env is deciding right now (set by the hooked `_get_players_turn`), one rng + one Philox stream per env, and the
+    trace of every decision (all seats) per env."""
+
+    def __init__(self, envs, streams, rng_seeds):
+        self.envs, self.streams = list(envs), list(streams)
+        self.rngs = [np.random.default_rng(s) for s in rng_seeds]
+        self.trace = [[] for _ in envs]
+        self.cur = 0
+        for i, env in enumerate(self.envs):          # every draw of env i goes to stream i
+            env.reset = self._wrap(env.reset, i)
+            env.step = self._wrap(env.step, i)
+
+    def _wrap(self, fn, i):
+        def call(*a, **kw):
+            with patched_rng(self.streams[i]):
+                return fn(*a, **kw)
+        return call
+
+    def hook_manager(self, mgr):
+        orig = mgr._get_players_turn
+
+        def hooked(env):
+            self.cur = self.envs.index(env)
+            return orig(env)
+        mgr._get_players_turn = hooked
+
+
+class ScriptedRefPolicy(object):
+    """Has the part of the reference net's surface the managers use (`act`, `eval`); returns actions in the net's output
+    format (12 entries, [1,1] int64 tensors; heads 7 and 8 lists of four)."""
+
+    def __init__(self, ctx, lstm_size=256):
+        self.ctx, self.lstm_size = ctx, lstm_size
+
+    def eval(self):
+        return self
+
+    def act(self, obs, hidden_states, terminal_mask, action_masks, deterministic=False):
+        import torch
+        c = self.ctx
+        env = c.envs[c.cur]
+        a = weighted_legal_action(env.get_action_masks(), env, c.rngs[c.cur])
+        c.trace[c.cur].append(np.array(a, dtype=np.int8))
+        heads = action_to_heads(a)
+        actions = [[torch.tensor([[int(v)]]) for v in h] if isinstance(h, (list, np.ndarray)) else torch.tensor([[int(h)]]) for h in heads]
+        return None, actions, torch.tensor([[scripted_log_prob(a)]], dtype=torch.float32), hidden_states
