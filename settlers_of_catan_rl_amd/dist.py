@@ -62,21 +62,70 @@ def sum_over_ranks(value, device=None):
     return _reduce(value, dist.ReduceOp.SUM, device)
 
 
+class GradBucket(object):
+    """One persistent flat gradient buffer for a FIXED parameter list (1.93 M parameters = 7.7 MB fp32: a single bucket;
+    xGMI rings are per-link bound, so one large message beats many small ones).
+
+    Every parameter's `.grad` is a view into the buffer, so autograd accumulates straight into it (in-place adds), the
+    all-reduce runs on the buffer itself - no concatenation, no copy back - and the layout is identical on every rank by
+    construction: a parameter that received no gradient in a step contributes zeros instead of changing the message size
+    (rank-divergent sets of `grad is None` parameters would otherwise mis-align a concatenated bucket or hang the
+    collective).  Use `zero()` instead of `optimizer.zero_grad()` (which would drop the views)."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("GradBucket needs at least one parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("all parameters of a bucket must share device and dtype")
+        self.group = process_group
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self._views = []
+        off = 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = v
+            self._views.append(v)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self._views):      # re-attach if something replaced or dropped a .grad meanwhile
+            if p.grad is not v:
+                p.grad = v
+
+    def check(self):
+        bad = [i for i, (p, v) in enumerate(zip(self.params, self._views)) if p.grad is None or p.grad.data_ptr() != v.data_ptr()]
+        if bad:
+            raise RuntimeError(f"GradBucket: {len(bad)} parameter gradients are no longer views of the bucket (first: #{bad[0]})")
+
+    def allreduce(self):
+        """sum over ranks -> / world, in place, right after backward (a single collective: at 7.7 MB it takes ~0.1 ms over
+        xGMI against an ~80 ms minibatch step, so it is not overlapped with backward)."""
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        self.check()
+        dist.all_reduce(self.flat, group=self.group)
+        self.flat /= dist.get_world_size(self.group)
+
+
 def allreduce_flat_grads(params, world=None):
-    """One flat-bucket gradient all-reduce per optimiser step (1.93 M parameters = 7.7 MB fp32: a single bucket;
-    xGMI rings are per-link bound, so fewer, larger messages win).  Averages in place."""
+    """Stateless variant for callers without a GradBucket: fixed layout over ALL the given parameters (missing gradients
+    are sent as zeros and left missing).  Averages in place."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat)
     flat /= dist.get_world_size() if world is None else world
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(flat[off:off + n].view_as(p))
         off += n
 
 

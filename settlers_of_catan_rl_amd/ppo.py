@@ -16,25 +16,43 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def compute_gae(rewards, values, masks, gamma=0.999, gae_lambda=0.95, process_group=None, normalise=True):
-    """rewards [T,N], values [T+1,N] (denormalised), masks [T+1,N] float32 CUDA -> (returns [T,N], advantages [T,N]).
-    When torch.distributed is initialised the advantage mean/std are global over all ranks (three doubles
-    all-reduced over `process_group`, default group if None); pass process_group=False to keep them rank-local."""
+def _hip_gae_raw(r, v, m, gamma, gae_lambda):
+    """k_gae + k_adv_stats: -> (returns, adv_raw, stats3 = (sum, sum of squares, count) of adv_raw as float64[3])"""
     L = _lib.lib()
-    T, N = rewards.shape
-    assert values.shape == (T + 1, N) and masks.shape == (T + 1, N)
-    r, v, m = (x.contiguous().float() for x in (rewards, values, masks))
+    T, N = r.shape
     returns = torch.empty_like(r)
     adv = torch.empty_like(r)
     ws = torch.empty((L.catan_gae_workspace_doubles(N),), dtype=torch.float64, device=r.device)
     stats = torch.empty((3,), dtype=torch.float64, device=r.device)
     _lib.check(L.catan_gae(_ptr(r), _ptr(v), _ptr(m), T, N, float(gamma), float(gae_lambda), _ptr(returns), _ptr(adv),
                            _ptr(ws), _ptr(stats), _stream()))
+    return returns, adv, stats
+
+
+def _hip_adv_normalise(adv, stats):
+    """k_adv_normalise, in place"""
+    _lib.check(_lib.lib().catan_adv_normalise(_ptr(adv), adv.numel(), _ptr(stats), _stream()))
+    return adv
+
+
+# the two device back-ends of compute_gae; the world_size-2 gloo test swaps in torch stand-ins so that the function's own
+# distributed logic (what is reduced, over which group, in which order) runs on CPU
+_gae_raw, _adv_normalise = _hip_gae_raw, _hip_adv_normalise
+
+
+def compute_gae(rewards, values, masks, gamma=0.999, gae_lambda=0.95, process_group=None, normalise=True):
+    """rewards [T,N], values [T+1,N] (denormalised), masks [T+1,N] float32 CUDA -> (returns [T,N], advantages [T,N]).
+    When torch.distributed is initialised the advantage mean/std are global over all ranks (three doubles
+    all-reduced over `process_group`, default group if None); pass process_group=False to keep them rank-local."""
+    T, N = rewards.shape
+    assert values.shape == (T + 1, N) and masks.shape == (T + 1, N)
+    r, v, m = (x.contiguous().float() for x in (rewards, values, masks))
+    returns, adv, stats = _gae_raw(r, v, m, gamma, gae_lambda)
     if normalise:
         dist = torch.distributed
         if process_group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             dist.all_reduce(stats, group=process_group)     # (sum, sumsq, count) over all ranks: global mean / std
-        _lib.check(L.catan_adv_normalise(_ptr(adv), T * N, _ptr(stats), _stream()))
+        adv = _adv_normalise(adv, stats)
     return returns, adv
 
 
@@ -62,9 +80,18 @@ class _PpoLoss(torch.autograd.Function):
         return (g_total * d_logp).view(ctx.shapes[0]), (g_total * d_values).view(ctx.shapes[1]), None, None, None, None, None, None, None
 
 
+def _hip_ppo_loss(action_log_probs, values, old_action_log_probs, adv_targets, value_preds, returns, clip_param, value_loss_coef,
+                  value_normaliser):
+    return _PpoLoss.apply(action_log_probs, values, old_action_log_probs, adv_targets, value_preds, returns,
+                          clip_param, value_loss_coef, value_normaliser)
+
+
+_loss_backend = _hip_ppo_loss        # (replaceable like the GAE back-ends above)
+
+
 def ppo_loss(action_log_probs, values, old_action_log_probs, adv_targets, value_preds, returns, clip_param=0.2,
              value_loss_coef=1.0, value_normaliser=None):
     """-> (value_loss_coef * value_loss + action_loss, (action_loss, value_loss)).  `value_normaliser` = (mean, std)
     applies RL/models/utils.py:17-18 to value_preds and returns first, as RL/ppo/ppo.py:46-48 does."""
-    return _PpoLoss.apply(action_log_probs, values, old_action_log_probs, adv_targets, value_preds, returns,
-                          clip_param, value_loss_coef, value_normaliser)
+    return _loss_backend(action_log_probs, values, old_action_log_probs, adv_targets, value_preds, returns,
+                         clip_param, value_loss_coef, value_normaliser)

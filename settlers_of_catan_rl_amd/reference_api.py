@@ -660,13 +660,13 @@ class PPO(object):
         self.max_grad_norm, self.recompute_returns = args.max_grad_norm, getattr(args, "recompute_returns", True)
         self.gamma, self.gae_lambda = args.gamma, args.gae_lambda
         self.optimiser = torch.optim.Adam(actor_critic.parameters(), lr=args.lr, eps=args.eps)
+        self.bucket = cdist.GradBucket(actor_critic.parameters())     # persistent flat gradient buffer (one all-reduce per step)
         self.timings = {}
 
     def update(self, rollout_storage):
         ac = self.actor_critic
         if getattr(ac, "include_lstm", False):
             raise NotImplementedError("truncated-BPTT minibatches: use train.PPOTrainer (generator_lstm lives there)")
-        params = [p for p in ac.parameters()]
         sums = None
         t_adv = t_opt = 0.0
         n_steps = 0
@@ -684,9 +684,9 @@ class PPO(object):
                         if getattr(ac, "use_value_normalisation", False) else None)             # ppo.py:46-48, inside the kernel
                 loss, parts = _LOSS(action_log_probs.float(), values.float(), old_action_log_probs_batch, adv_target,
                                     value_preds_batch, returns_batch, self.clip_param, self.value_loss_coef, value_normaliser=norm)
-                self.optimiser.zero_grad()
+                self.bucket.zero()
                 (loss - entropy * self.entropy_coef).backward()                              # ppo.py:66
-                cdist.allreduce_flat_grads(params)
+                self.bucket.allreduce()
                 nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
                 self.optimiser.step()
                 s = torch.stack((parts[1].detach() * self.value_loss_coef, parts[0].detach(), entropy.detach().float() * self.entropy_coef))

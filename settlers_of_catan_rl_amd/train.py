@@ -69,7 +69,11 @@ class PPOTrainer(object):
             from . import nn_kernels
             nn_kernels.use_tuned_gemms()           # library GEMMs: tuned solution per shape (tunableop_gfx950.csv)
         self.optimiser = torch.optim.Adam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)   # ppo.py:23
+        # gradients live in one persistent flat buffer with a fixed layout (dist.GradBucket): the all-reduce of a step is one
+        # collective on that buffer, and zeroing the gradients is one memset
+        self.bucket = cdist.GradBucket(policy.parameters())
         dev = next(policy.parameters()).device
+        self._sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
         self.gen = torch.Generator(device=dev).manual_seed(seed + 17 * (1 + (torch.distributed.get_rank()
                                                                          if torch.distributed.is_initialized() else 0)))
         self.timings = {}
@@ -117,9 +121,9 @@ class PPOTrainer(object):
         for _ in range(cfg.ppo_epoch):
             t0 = time.perf_counter()
             values = self.compute_values(st)                                               # ppo.py:31-32
-            torch.cuda.synchronize(); t1 = time.perf_counter()
+            self._sync(); t1 = time.perf_counter()
             returns, adv = ppo_kernels.compute_gae(rewards, values, masks, cfg.gamma, cfg.gae_lambda)
-            torch.cuda.synchronize(); t2 = time.perf_counter()
+            self._sync(); t2 = time.perf_counter()
             vpred = values[:T].reshape(total); ret = returns.reshape(total); advf = adv.reshape(total)
             if rec:
                 seqs = lstm_minibatches(T, N, cfg.truncated_seq_len, cfg.num_mini_batch,
@@ -140,13 +144,13 @@ class PPOTrainer(object):
                 loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
                                                    cfg.clip_param, cfg.value_loss_coef,
                                                    value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
-                self.optimiser.zero_grad(set_to_none=True)
+                self.bucket.zero()
                 (loss - ent * cfg.entropy_coef).backward()                                 # ppo.py:66
-                cdist.allreduce_flat_grads([p for p in pol.parameters()])                  # one RCCL all-reduce per step
+                self.bucket.allreduce()                                                    # one RCCL all-reduce per step
                 torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
                 self.optimiser.step()
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))
-            torch.cuda.synchronize(); t3 = time.perf_counter()
+            self._sync(); t3 = time.perf_counter()
             t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2
         n = cfg.ppo_epoch * len(batches)
         self.timings = {"values_s": t_val, "gae_s": t_gae, "minibatches_s": t_opt}

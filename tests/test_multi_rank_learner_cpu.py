@@ -1,0 +1,156 @@
+"""world_size-2 gloo test (CPU) of the PRODUCT's N>1 learner path: `train.PPOTrainer.update` (GradBucket all-reduce per
+optimiser step, broadcast parameters) and `ppo.compute_gae(process_group=...)` (three-double advantage statistics) on two
+shards of one rollout, against the single-process run on the concatenated rollout.
+
+The HIP kernels behind compute_gae / ppo_loss cannot run here, so their torch formulations stand in through the back-end
+hooks of ppo.py (the kernels themselves are pinned against the reference's values in the gpu tests); everything around them -
+what is reduced, over which group, when, with which layout - is the shipped code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T, N_PER, WORLD = 6, 5, 2
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _install_cpu_backends():
+    from settlers_of_catan_rl_amd import ppo
+
+    def gae_raw(r, v, m, gamma, lam):
+        Tn = r.shape[0]
+        ret = torch.zeros_like(r)
+        gae = torch.zeros_like(r[0])
+        for t in reversed(range(Tn)):
+            delta = r[t] + gamma * v[t + 1] * m[t + 1] - v[t]
+            gae = delta + gamma * lam * m[t + 1] * gae
+            ret[t] = gae + v[t]
+        adv = ret - v[:-1]
+        a = adv.double()
+        return ret, adv, torch.stack((a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), dtype=torch.float64)))
+
+    def adv_normalise(adv, stats):
+        cnt, mean = stats[2], stats[0] / stats[2]
+        std = torch.sqrt((stats[1] - cnt * mean * mean) / (cnt - 1))
+        return ((adv.double() - mean) / (std + 1e-5)).float()
+
+    def loss(lp, v, old_lp, adv, v_old, ret, clip, value_coef, norm):
+        lp, v, old_lp, adv, v_old, ret = (x.reshape(-1) for x in (lp, v, old_lp, adv, v_old, ret))
+        if norm is not None:
+            v_old, ret = (v_old - norm[0]) / (norm[1] + 1e-4), (ret - norm[0]) / (norm[1] + 1e-4)
+        ratio = torch.exp(lp - old_lp)
+        al = -torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv).mean()
+        vc = v_old + (v - v_old).clamp(-clip, clip)
+        vl = 0.5 * torch.max((v - ret).pow(2), (vc - ret).pow(2)).mean()
+        return vl * value_coef + al, torch.stack((al.detach(), vl.detach()))
+    ppo._gae_raw, ppo._adv_normalise, ppo._loss_backend = gae_raw, adv_normalise, loss
+
+
+def _make_rollout(n_games, env_id0):
+    """a rollout storage filled by the real collector (oracle-backed env, random-initialised net, fixed seeds)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_vec_env import OracleVecEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    torch.manual_seed(7)
+    actor = CatanPolicy().eval()
+    env = OracleVecEnv(n_games, seed=9, env_id0=env_id0)
+    env.advance_random(900)
+    col = RolloutCollector(env, actor, T, seed=100 + env_id0)
+    st = col.gather_rollouts()
+    for (t, g) in ((2, 1), (4, 6), (1, 8)):                # game ends for the learner's benefit: terminal masks + win rewards
+        st.masks[t + 1, g] = 0.0
+        st.rewards[t, g] = 500.0
+    return st
+
+
+def _slice_storage(st, lo, hi):
+    from settlers_of_catan_rl_amd.rollout import RolloutStorage
+    out = RolloutStorage(st.T, hi - lo, "cpu")
+    for k in ("obs_f", "lists", "lens", "masks", "rewards", "actions", "action_log_probs", "action_masks"):
+        setattr(out, k, getattr(st, k)[:, lo:hi].clone())
+    return out
+
+
+def _train(st, epochs):
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    from settlers_of_catan_rl_amd import dist as cdist, ppo
+    torch.manual_seed(123)
+    net = CatanPolicy()
+    cdist.broadcast_parameters(net)
+    tr = PPOTrainer(net, PPOConfig(ppo_epoch=epochs, num_mini_batch=1), autocast_dtype=None, seed=0)
+    losses = tr.update(st)
+    values = tr.compute_values(st)
+    returns, adv = ppo.compute_gae(st.rewards[:st.T].contiguous(), values, st.masks[:st.T + 1].contiguous(), tr.cfg.gamma, tr.cfg.gae_lambda)
+    tr.bucket.check()
+    return net, losses, returns, adv
+
+
+def _worker(rank, port, path, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(WORLD), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    from settlers_of_catan_rl_amd import dist as cdist
+    _install_cpu_backends()
+    cdist.init_from_env(backend="gloo")
+    full = torch.load(path, weights_only=False)
+    st = _slice_storage(full, rank * N_PER, (rank + 1) * N_PER)
+    net, losses, returns, adv = _train(st, epochs=2)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    q.put((rank, flat.numpy(), losses, returns.numpy(), adv.numpy()))
+    cdist.finalize()
+
+
+def test_two_rank_ppo_update_equals_single_process(tmp_path):
+    sys.path.insert(0, ROOT)
+    _install_cpu_backends()
+    full = _make_rollout(WORLD * N_PER, 0)
+    path = str(tmp_path / "rollout.pt")
+    torch.save(full, path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, path, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(WORLD)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process on the concatenated rollout (one minibatch = the whole rollout, so the two-rank minibatches - each rank's
+    # whole shard - average to exactly the same loss and gradient)
+    net, losses, returns, adv = _train(full, epochs=2)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    assert np.array_equal(got[0][1], got[1][1]), "ranks diverged"
+    assert np.abs(got[0][1] - flat).max() < 1e-5, np.abs(got[0][1] - flat).max()
+    mean_losses = np.mean([g[2] for g in got], axis=0)
+    assert np.abs(mean_losses - np.array(losses)).max() < 1e-5, (mean_losses, losses)
+    two_adv = np.concatenate([g[4] for g in got], axis=1)
+    two_ret = np.concatenate([g[3] for g in got], axis=1)
+    assert np.abs(two_adv - adv.numpy()).max() < 1e-5 and np.allclose(two_ret, returns.numpy(), rtol=1e-5, atol=1e-4)
+    assert abs(float(two_adv.mean())) < 1e-5                # normalised with the GLOBAL statistics
+
+
+def test_grad_bucket_fixed_layout():
+    from settlers_of_catan_rl_amd import dist as cdist
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    b = cdist.GradBucket(lin.parameters())
+    b.zero()
+    lin[0](torch.randn(5, 4)).sum().backward()              # the second layer gets no gradient: zeros, same layout
+    assert all(p.grad is not None for p in lin.parameters()) and float(lin[1].weight.grad.abs().sum()) == 0.0
+    assert float(b.flat[:12].abs().sum()) > 0
+    b.check()
+    opt = torch.optim.Adam(lin.parameters())
+    opt.zero_grad(set_to_none=True)                         # something dropped the views: zero() re-attaches them
+    b.zero(); b.check()
+    lin(torch.randn(5, 4)).sum().backward()
+    assert float(b.flat.abs().sum()) > 0 and lin[1].weight.grad.data_ptr() == b._views[2].data_ptr()
