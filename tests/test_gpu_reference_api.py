@@ -59,7 +59,7 @@ def test_run_update_sequence_on_device(hip_lib):
         vl, al, el = agent.update(storage)
         assert all(np.isfinite(x) for x in (vl, al, el)), (vl, al, el)
         mgr.update_policy(central.state_dict(), policy_id=0)
-        ra.update_opponent_policies([central.state_dict(), central.state_dict()], mgr, args, rng=np.random.RandomState(u))
+        ra.update_opponent_policies([central.state_dict()], mgr, args, rng=np.random.RandomState(u))
     T, N = args.num_steps, 256
     assert storage.values.shape == (T + 1, N, 1) and storage.advantages.shape == (T, N, 1)
     r, v, m = storage.rewards[..., 0].double(), storage.values[..., 0].double(), storage.masks[..., 0].double()
@@ -73,7 +73,7 @@ def test_run_update_sequence_on_device(hip_lib):
     assert torch.allclose(storage.returns[..., 0].double(), ret, rtol=1e-5, atol=1e-3)
     assert torch.allclose(storage.advantages[..., 0].double(), adv, rtol=1e-4, atol=1e-4)
     assert mgr.env.invalid_action_count() == 0
-    assert len(mgr.collector.opponent_nets) == 1            # both league entries are the same dict object -> one net in play
+    assert len(mgr.collector.opponent_nets) == 1            # every group drew the same league entry (one dict object) -> one net in play
 
 
 def test_config3_shape_65536_games_sampled_parity(oracle, hip_lib):
