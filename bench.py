@@ -37,10 +37,14 @@ ALGO_BYTES = {
     # (112 words x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
     # one bitboard word: ~40 words x 4 B = 160)
     "k_step": 72 + 44 + 44 + 17 + 448 + 160,
-    "k_lr_finish": 0,                               # slow path (a few % of the games): latency-bound searches / re-deals,
-    "k_lr_heavy": 0,                                # no meaningful byte roofline
+    "k_lr_finish": 0,                               # slow path: priced per REQUEST below (LR_REQUEST_BYTES), not per game
+    "k_lr_heavy": 0,
     "k_reset_list": 0,
 }
+# a longest-road request (~3 % of the games of a pass): hot record in and out (448 + 448), the longest-path cache (28 + 28),
+# new masks (44), reward / done (17).  The search itself runs in LDS / registers: the kernels are LATENCY-bound (a DFS step
+# is ~1 us of dependent instructions at this occupancy), the byte figure only shows how far from any HBM limit they are.
+LR_REQUEST_BYTES = 448 + 448 + 28 + 28 + 44 + 17
 FAST_PATH = ("k_sample_random", "k_step")     # the kernels on the timed loop's critical path
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
@@ -198,7 +202,9 @@ def main():
     if rank == 0:
         # per-kernel durations: HIP events on the stream each kernel is launched on, a separate short pass right after
         prof_steps = 512
+        sp0 = env.slow_path_counts()
         kms = env.random_rollout_timed(step_idx, prof_steps, args.window)
+        sp1 = env.slow_path_counts()
     step_idx += 512
     ppo = None
     if args.ppo_steps > 0:
@@ -239,6 +245,16 @@ def main():
                     "the slow-path kernels (k_lr_*, k_reset_list) are latency-bound path searches / re-deals (LDS + ALU, "
                     "a few MB per launch) and run on side streams in the deferred loop",
         }
+        t1_req, t2_req, t1_launches = (b - a for a, b in zip(sp0, sp1))
+        lr_us = per_launch_us["k_lr_finish"]
+        roofline["slow_path"] = {
+            "bound": "latency (path search in LDS / registers; not an HBM- or MFMA-bound kernel)",
+            "tier1_requests_per_launch": t1_req / max(1, t1_launches), "tier2_requests_per_launch": t2_req / max(1, slow_launches),
+            "algorithmic_bytes_per_request": LR_REQUEST_BYTES, "k_lr_finish_avg_launch_us": lr_us,
+            "k_lr_finish_achieved_gbs": LR_REQUEST_BYTES * t1_req / max(1, t1_launches) / (lr_us * 1e-6) / 1e9 if lr_us > 0 else None,
+            "k_lr_heavy_avg_launch_us": per_launch_us["k_lr_heavy"],
+            "note": "while a player's cached longest path is exact, a new road only searches the paths THROUGH the new edge "
+                    "(DESIGN.md 4.2); requests that exceed the tier-1 iteration budget go to tier 2"}
         if lockstep is not None:
             g = per_step_bytes * n / (lockstep["ms_per_step"] * 1e-3) / 1e9
             roofline["end_to_end"].update(lockstep_gbs=g, lockstep_frac=g / HBM_PEAK_GBS)

@@ -119,6 +119,11 @@ int catan_policy_counters(catan_env_t* env, uint32_t* out, catan_stream_t stream
 int catan_set_policy_counters(catan_env_t* env, const uint32_t* in, catan_stream_t stream);
 /* tier-1 longest-road search budget (iterations) before a request is handed to tier 2: lock-step / deferred mode */
 int catan_set_lr_budgets(catan_env_t* env, int32_t lockstep, int32_t deferred);
+/* cumulative slow-path counters since creation (synchronises the stream): out3 = { longest-road requests handled by tier 1
+ * (k_lr_finish), requests handed on to tier 2 (k_lr_heavy), k_lr_finish launches } - bench.py derives the bytes a launch moves */
+int catan_slow_path_counts(catan_env_t* env, catan_stream_t stream, uint64_t* out3);
+/* tier-2 longest-road search: iterations per bulk-synchronous round (work is re-shared between rounds): lock-step / deferred */
+int catan_set_lr_rounds(catan_env_t* env, int32_t lockstep, int32_t deferred);
 
 /* the rollout loops with a hipEvent around every kernel launch (recorded on `stream`); window <= 0: the lock-step
  * loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST

@@ -39,6 +39,7 @@ struct catan_env {
     u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
+    int lr_round[2];      // tier-2 iterations per bulk-synchronous round: [0] lock-step, [1] deferred
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
     hipEvent_t ev_fork, ev_join;
     hipStream_t fstream[2];  // deferred rollouts: tier-1 longest road + completion of iteration t run on fstream[t & 1] during t+1
@@ -51,7 +52,7 @@ struct catan_env {
     u8* s_done;
 };
 
-constexpr int LR_BUDGET_DEFERRED = 24;
+constexpr int LR_BUDGET_DEFERRED = 12;   // (swept together with the window length: tools/deferred_sweep.py)
 // cross-stream ordering inside one device: no timing, no system-scope release (which would flush L2 at every record)
 constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
 static thread_local std::string g_err;
@@ -249,7 +250,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.type, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.who, (size_t)e->N);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.len, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.arrive, (size_t)e->N * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.spec, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
@@ -265,6 +266,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
+    e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
@@ -373,7 +375,7 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
     hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
-                       sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr);
+                       sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -403,7 +405,7 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
     hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len,
-                       lockstep ? LR_ROUND_LOCKSTEP : LR_ROUND, e->mpk, reward, done, sc, e->pend);   // search + completion
+                       e->lr_round[lockstep ? 0 : 1], e->mpk, reward, done, sc, e->pend);   // search + completion
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     if (ev) HIPCHK(hipEventRecord(ev[7], st));
     if (e->cfg.auto_reset) {
@@ -605,6 +607,19 @@ int catan_set_policy_counters(catan_env_t* e, const uint32_t* in, catan_stream_t
 int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
     if (!e || lockstep < 1 || deferred < 1) return fail(CATAN_EINVAL, "catan_set_lr_budgets: bad arguments");
     e->lr_budget[0] = lockstep; e->lr_budget[1] = deferred;
+    return CATAN_OK;
+}
+
+int catan_slow_path_counts(catan_env_t* e, catan_stream_t stream, uint64_t* out3) {
+    if (!e || !out3) return fail(CATAN_EINVAL, "catan_slow_path_counts: null argument");
+    HIPCHK(hipMemcpyAsync(out3, e->err + 4, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return CATAN_OK;
+}
+
+int catan_set_lr_rounds(catan_env_t* e, int32_t lockstep, int32_t deferred) {
+    if (!e || lockstep < 1 || deferred < 1) return fail(CATAN_EINVAL, "catan_set_lr_rounds: bad arguments");
+    e->lr_round[0] = lockstep; e->lr_round[1] = deferred;
     return CATAN_OK;
 }
 

@@ -466,65 +466,194 @@ DEVI void update_players_go(const S& s, int order, bool left) {
 // DFS state per lane: the vertex path is a 1-byte-per-level stack in LDS (children are re-derived from the
 // adjacency bitmasks and the `seen` bitmask on backtrack; bit 6 = "remaining siblings were given away").
 constexpr int LR_QN = 256;          // tier-1 (wave) queue entries
-constexpr int LR_BUDGET = 48;       // tier-1 double-iterations per lane before the game is handed to tier 2
+constexpr int LR_BUDGET = 16;       // tier-1 double-iterations per lane before the game is handed to tier 2 (lock-step; swept)
 constexpr int LR_HEAVY_THREADS = 1024;
 constexpr int LR_POOL = 3072;       // tier-2 workgroup pool entries
-constexpr int LR_ROUND = 48;        // tier-2 iterations per bulk-synchronous round: deferred windows (throughput)
-constexpr int LR_ROUND_LOCKSTEP = 8;    // ... inside a lock-step step (latency: the step waits for the deepest search; swept)
+constexpr int LR_ROUND = 16;        // tier-2 iterations per bulk-synchronous round: deferred windows (throughput)
+constexpr int LR_ROUND_LOCKSTEP = 4;    // ... inside a lock-step step (latency: the step waits for the deepest search; swept)
 
-struct Dfs { bool active; int cur, d, base, best; u64 seen, cand; };
+// Two kinds of search share the DFS below.
+//   FULL     Game.get_longest_path: every lane v < 54 starts at its own corner (phase 1 from the start).
+//   THROUGH  the longest valid path that CONTAINS a given edge (u, v) - what a newly built road can add.  While the player's
+//            cached longest path is exact (LrCache), max(cached, THROUGH(new edge)) is the new longest path, and THROUGH is an
+//            order of magnitude cheaper than FULL (measured with the oracle over 30 000 road builds: mean 21 vs 153 DFS
+//            expansions, 0.05 % vs 0.4 % above 4 096).  One seed: phase 0 walks an arm away from u (v is marked seen from
+//            the start); at EVERY arm tip the extra move SW crosses the new edge to v, phase 1 then walks the second arm.
+//            SW is candidate bit 63, i.e. always the last sibling.  A path is valid unless BOTH its end corners hold an
+//            opponent building (either end may be the directed path's last vertex, game.py:850-858): `ablk` remembers
+//            whether the phase-0 end is blocked.
+// Every lane tracks the vertex set of its best path (`bseen`): len << 54 | vertex mask is the search result.
+constexpr u64 LR_SW = 1ull << 63;
+constexpr u64 LR_VMASK = (1ull << 54) - 1;
+constexpr u64 LRQ_PH1 = 1ull << 62, LRQ_ABLK = 1ull << 61;      // flags of a queued task, in the spare bits of its `seen`
+struct Dfs { bool active; int cur, d, base, best; u64 seen, cand, bseen; int ph; bool ablk; };
 struct DfsQueue { u64* seen; unsigned short* cd; int* n; int cap; };
-typedef unsigned short lrstk_t;   // stack entry: vertex | sibling << 6 | mode << 12 (0 none left, 1 one sibling, 2 re-derive)
+struct LrGraph { const u64* adj; u64 blk; int sw_v; };            // adj[v] = 0 for a blocked corner; blk = blocked corners
+typedef unsigned short lrstk_t;   // stack entry: vertex | sibling << 6 | mode << 12 (0 none left, 1 one sibling, 2 re-derive) | phase-0 level << 14
 
-// One DFS step of one lane: (at most) one backtrack followed by one descend attempt.  adj[v]: bitmask of road
-// neighbours of v (0 if v is blocked).  path: this lane's column (entry for level d at path[d * stride]).
-DEVI void dfs_iter(Dfs& t, const u64* adj, lrstk_t* path, int stride, bool donate, const DfsQueue& q) {
+DEVI bool lrq_push(const DfsQueue& q, u64 seen, int vertex, int depth) {
+    const int qi = atomicAdd(q.n, 1);
+    if (qi < q.cap) { q.seen[qi] = seen; q.cd[qi] = (unsigned short)(vertex | (depth << 8)); return true; }
+    atomicSub(q.n, 1);                                  // pool full: the owner keeps the sibling (an already pushed one is re-explored; harmless)
+    return false;
+}
+// One DFS step of one lane: (at most) one backtrack followed by one descend attempt.  path: this lane's column (entry for
+// level d at path[d * stride]).
+DEVI void dfs_iter(Dfs& t, const LrGraph& G, lrstk_t* path, int stride, bool donate, const DfsQueue& q) {
     if (!t.active) return;
     if (t.cand == 0) {
         if (t.d == t.base) { t.active = false; return; }
-        t.seen &= ~(1ull << t.cur);
         const int child = t.cur;
         t.d--;
         const int pk = path[t.d * stride];
+        const bool lvl0 = (pk >> 14) & 1;
+        if (t.ph == 1 && lvl0) t.ph = 0;                // back over the new edge: v stays marked
+        else t.seen &= ~(1ull << child);
         t.cur = pk & 63;
-        const int mode = pk >> 12;
-        t.cand = mode == 0 ? 0ull : (mode == 1 ? (1ull << ((pk >> 6) & 63)) : (adj[t.cur] & ~t.seen & ~((2ull << child) - 1)));
+        const int mode = (pk >> 12) & 3;
+        t.cand = mode == 0 ? 0ull : (mode == 1 ? (1ull << ((pk >> 6) & 63))
+                                               : ((G.adj[t.cur] & ~t.seen & ~((2ull << child) - 1)) | (lvl0 ? LR_SW : 0ull)));
         if (t.cand == 0) return;
     }
-    const int v = __ffsll((long long)t.cand) - 1;
-    t.cand &= t.cand - 1;
-    t.best = max(t.best, t.d + 1);
-    const u64 a = adj[v] & ~t.seen & ~(1ull << v);
+    const bool sw = (t.cand & LR_VMASK) == 0;            // only the crossing move is left
+    int v;
+    if (sw) { v = G.sw_v; t.cand = 0; }
+    else { v = __ffsll((long long)t.cand) - 1; t.cand &= t.cand - 1; }
+    const int nph = sw ? 1 : t.ph;
+    const bool ablk = sw ? (((G.blk >> t.cur) & 1) != 0) : t.ablk;
+    const u64 nseen = t.seen | (1ull << v);
+    if (nph == 1 && t.d + 1 > t.best && !(ablk && ((G.blk >> v) & 1))) { t.best = t.d + 1; t.bseen = nseen; }
+    const u64 a = (G.adj[v] & ~nseen) | (nph == 0 ? LR_SW : 0ull);
     if (a) {
-        if (t.cand && donate) {                       // give the untaken siblings (<= 2) away
+        if (t.cand && donate) {                         // give the untaken siblings (<= 2 corners, and / or the crossing) away
             bool all = true;
             u64 cc = t.cand;
             while (cc) {
-                const int sb = __ffsll((long long)cc) - 1;
-                cc &= cc - 1;
-                t.best = max(t.best, t.d + 1);
-                if (adj[sb] & ~t.seen & ~(1ull << sb)) {
-                    const int qi = atomicAdd(q.n, 1);
-                    if (qi < q.cap) { q.seen[qi] = t.seen | (1ull << sb); q.cd[qi] = (unsigned short)(sb | ((t.d + 1) << 8)); }
-                    else { atomicSub(q.n, 1); all = false; }   // pool full: keep (an already pushed sibling is re-explored; harmless)
+                if ((cc & LR_VMASK) == 0) {             // the crossing from this tip
+                    cc = 0;
+                    const bool ab = ((G.blk >> t.cur) & 1) != 0;
+                    const u64 sseen = t.seen;            // (v is in it already)
+                    if (t.d + 1 > t.best && !(ab && ((G.blk >> G.sw_v) & 1))) { t.best = t.d + 1; t.bseen = sseen; }
+                    if (G.adj[G.sw_v] & ~sseen) all &= lrq_push(q, sseen | LRQ_PH1 | (ab ? LRQ_ABLK : 0ull), G.sw_v, t.d + 1);
+                } else {
+                    const int sb = __ffsll((long long)cc) - 1;
+                    cc &= cc - 1;
+                    const u64 sseen = t.seen | (1ull << sb);
+                    if (t.ph == 1) {
+                        if (t.d + 1 > t.best && !(t.ablk && ((G.blk >> sb) & 1))) { t.best = t.d + 1; t.bseen = sseen; }
+                        if (G.adj[sb] & ~sseen) all &= lrq_push(q, sseen | LRQ_PH1 | (t.ablk ? LRQ_ABLK : 0ull), sb, t.d + 1);
+                    } else all &= lrq_push(q, sseen, sb, t.d + 1);      // an arm tip can always cross
                 }
             }
             if (all) t.cand = 0;
         }
-        int entry = t.cur;
+        int entry = t.cur | (t.ph == 0 ? (1 << 14) : 0);
         if (t.cand) {
             const u64 rest = t.cand & (t.cand - 1);
             entry |= rest ? (2 << 12) : ((1 << 12) | ((__ffsll((long long)t.cand) - 1) << 6));
         }
         path[t.d * stride] = (lrstk_t)entry;
-        t.cur = v; t.seen |= 1ull << v; t.d++; t.cand = a;
+        t.cur = v; t.seen = nseen; t.d++; t.cand = a; t.ph = nph; t.ablk = ablk;
     }
 }
-DEVI void dfs_take(Dfs& t, const u64* adj, u64 seen, int cd) {
-    t.seen = seen; t.cur = cd & 255; t.d = cd >> 8; t.base = t.d;
-    t.cand = adj[t.cur] & ~seen;
+DEVI void dfs_take(Dfs& t, const LrGraph& G, u64 seen, int cd) {
+    t.seen = seen & LR_VMASK; t.ph = (seen & LRQ_PH1) ? 1 : 0; t.ablk = (seen & LRQ_ABLK) != 0;
+    t.cur = cd & 255; t.d = cd >> 8; t.base = t.d;
+    t.cand = (G.adj[t.cur] & ~t.seen) | (t.ph == 0 ? LR_SW : 0ull);
     t.active = true;
 }
+// Static split of a search over many lanes without any communication: lane `code` walks the prefix whose level-l move is
+// the (code >> 2l & 3)-th candidate of that level (corners ascending, the crossing last: at most 4 moves per level), then owns
+// the subtree below (base = its depth).  Every prefix node's own path length is counted by all lanes that pass it (a
+// maximum: harmless); a code that names a move which does not exist leaves its lane idle (it will take shared work).
+DEVI void dfs_walk_prefix(Dfs& t, const LrGraph& G, int code, int levels) {
+    for (int l = 0; l < levels && t.active; l++) {
+        u64 cc = t.cand;
+        for (int i = (code >> (2 * l)) & 3; i > 0 && cc; i--) cc &= cc - 1;
+        if (cc == 0) { t.active = false; break; }
+        const bool sw = (cc & LR_VMASK) == 0;
+        const int v = sw ? G.sw_v : __ffsll((long long)cc) - 1;
+        const int nph = sw ? 1 : t.ph;
+        const bool ablk = sw ? (((G.blk >> t.cur) & 1) != 0) : t.ablk;
+        const u64 nseen = t.seen | (1ull << v);
+        if (nph == 1 && t.d + 1 > t.best && !(ablk && ((G.blk >> v) & 1))) { t.best = t.d + 1; t.bseen = nseen; }
+        t.cur = v; t.seen = nseen; t.d++; t.ph = nph; t.ablk = ablk;
+        t.cand = (G.adj[v] & ~nseen) | (nph == 0 ? LR_SW : 0ull);
+        if (t.cand == 0) t.active = false;
+    }
+    t.base = t.d;
+}
+DEVI void dfs_seed_full(Dfs& t, int v, u64 adjv) {
+    t.active = adjv != 0; t.cur = v; t.d = 0; t.base = 0; t.best = 0; t.bseen = 0; t.ph = 1; t.ablk = false;
+    t.seen = 1ull << (v & 63); t.cand = adjv;
+}
+DEVI void dfs_seed_through(Dfs& t, bool mine, int u, int v, u64 adju) {
+    t.active = mine; t.cur = u; t.d = 0; t.base = 0; t.best = 0; t.bseen = 0; t.ph = 0; t.ablk = false;
+    t.seen = (1ull << u) | (1ull << v); t.cand = (adju & ~t.seen) | LR_SW;
+}
+// search result: len << 54 | vertex mask of one longest path; the length of a cached result
+DEVI u64 lr_pack(int best, u64 bseen) { return ((u64)best << 54) | (bseen & LR_VMASK); }
+DEVI int lr_len(u64 packed_or_cache) { const u64 m = packed_or_cache & LR_VMASK; return m ? __popcll(m) - 1 : 0; }
+constexpr u64 LR_OVERFLOW = ~0ull;
+
+// The exact longest path of every player, cached in the seven spare words behind the card lists of the game's record
+// (words NROWS .. REC-1; zero in a fresh record): per player the vertex mask of ONE longest valid path (54 bits; the length
+// is popcount - 1) and an INVALID flag.  Exact means: what Game.get_longest_path would return now.  It stays exact while
+//   - the player builds roads: max(cached, THROUGH(new edge)) (a new road only adds paths that contain it);
+//   - opponents build settlements that are not on the cached path (blocking removes paths, the cached one survives);
+// an opponent settlement ON the cached path, or an imported state, sets INVALID: the next need is a FULL search.
+// Packing: player p < 3 in words 2p (mask bits 0..31), 2p+1 (bits 0..21: mask bits 32..53, bit 31: INVALID, bits 22..30:
+// spare); player 3: word 6 (mask bits 0..31), its upper 22 mask bits and INVALID in the 27 spare bits.
+constexpr int W_LRC = NROWS;
+static_assert(W_LRC + 7 == REC, "the longest-path cache fills the record's tail");
+constexpr u64 LRC_INVALID = 1ull << 63;
+struct LrCache {
+    u32 w[7];
+    DEVI void load(const u32* P) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = P[W_LRC + i];
+    }
+    DEVI void store(u32* P) const {
+#pragma unroll
+        for (int i = 0; i < 7; i++) P[W_LRC + i] = w[i];
+    }
+    DEVI u64 get(int p) const {                           // mask | INVALID
+        u64 r = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (p == q) r = (u64)w[2 * q] | ((u64)(w[2 * q + 1] & 0x3FFFFFu) << 32) | ((u64)(w[2 * q + 1] >> 31) << 63);
+        if (p == 3) {
+            const u32 s0 = (w[1] >> 22) & 0x1FFu, s1 = (w[3] >> 22) & 0x1FFu, s2 = (w[5] >> 22) & 0x1FFu;
+            r = (u64)w[6] | ((u64)(s0 | (s1 << 9) | ((s2 & 0xFu) << 18)) << 32) | ((u64)((s2 >> 4) & 1u) << 63);
+        }
+        return r;
+    }
+    DEVI void set(int p, u64 v) {
+        const u32 lo = (u32)v, hi = (u32)(v >> 32) & 0x3FFFFFu, inv = (u32)(v >> 63);
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (p == q) { w[2 * q] = lo; w[2 * q + 1] = (w[2 * q + 1] & (0x1FFu << 22)) | hi | (inv << 31); }
+        if (p == 3) {
+            w[6] = lo;
+            w[1] = (w[1] & ~(0x1FFu << 22)) | ((hi & 0x1FFu) << 22);
+            w[3] = (w[3] & ~(0x1FFu << 22)) | (((hi >> 9) & 0x1FFu) << 22);
+            w[5] = (w[5] & ~(0x1FFu << 22)) | ((((hi >> 18) & 0xFu) | (inv << 4)) << 22);
+        }
+    }
+    DEVI bool valid(int p) const { return (get(p) & LRC_INVALID) == 0; }
+    // an opponent of `builder` whose cached path runs over corner cn loses it
+    DEVI bool settle_invalidate(int builder, int cn) {
+        bool ch = false;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const u64 v = get(o);
+            if (o != builder && !(v & LRC_INVALID) && ((v >> cn) & 1)) { set(o, v | LRC_INVALID); ch = true; }
+        }
+        return ch;
+    }
+    DEVI void invalidate_all() {
+#pragma unroll
+        for (int o = 0; o < 4; o++) set(o, get(o) | LRC_INVALID);
+    }
+};
 // static neighbour tables of corner v packed in two registers (loaded once per kernel): 3 x 8 bit each
 DEVI void lr_load_nbr(int v, u32& nc, u32& ne) {
     nc = 0xFFFFFFu; ne = 0xFFFFFFu;
@@ -557,10 +686,52 @@ struct LrWave {
     lrstk_t path[54][64];
 };
 
-// tier 1.  Returns the path length for lanes with want=true, or -1 if the search ran out of budget (budget <= 0:
-// unlimited).  Must be called by all 64 lanes of the wave.
+// One search by the whole wave (all 64 lanes call it with the same arguments): the road set (R, RH) - the new edge
+// included -, the blocked corners BL; through: THROUGH(u, v), else FULL.  Returns len << 54 | vertex mask, or LR_OVERFLOW
+// when the iteration budget ran out (budget <= 0: unlimited).
+DEVI u64 lr_wave_search(u64 R, u32 RH, u64 BL, bool through, int u, int v, LrWave& L, int budget, u32 nbr_c, u32 nbr_e,
+                        unsigned long long* stat = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const DfsQueue q{ L.q_seen, L.q_cd, &L.qn, LR_QN };
+    const u64 myadj = lr_adj_of(lane, nbr_c, nbr_e, R, RH, BL);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 54) L.adj[lane] = myadj;
+    if (lane == 0) L.qn = 0;
+    __builtin_amdgcn_wave_barrier();
+    const LrGraph G{ L.adj, BL, v };
+    Dfs t;
+    if (through) { dfs_seed_through(t, true, u, v, L.adj[u]); dfs_walk_prefix(t, G, lane, 3); }     // 4^3 prefixes = the 64 lanes
+    else dfs_seed_full(t, lane, myadj);
+    u64 idle = __ballot(!t.active);
+    int it = 0;
+    bool overflow = false;
+    while (true) {
+        dfs_iter(t, G, &L.path[0][lane], 64, idle != 0, q);
+        dfs_iter(t, G, &L.path[0][lane], 64, idle != 0, q);
+        idle = __ballot(!t.active);
+        const int qn = L.qn;
+        if (idle == ~0ull && qn <= 0) break;
+        if (budget > 0 && ++it > budget) { overflow = true; break; }
+        if (!t.active && qn > 0) {
+            const int qi = atomicSub(&L.qn, 1) - 1;
+            if (qi >= 0) dfs_take(t, G, L.q_seen[qi], L.q_cd[qi]);
+            else atomicAdd(&L.qn, 1);
+        }
+    }
+    if (stat != nullptr && lane == 0) { atomicAdd(&stat[0], 1ull); atomicAdd(&stat[1], (unsigned long long)it); if (overflow) atomicAdd(&stat[2], 1ull); }
+    u64 best = lr_pack(t.best, t.bseen);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(best >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)best, off);
+        best = o > best ? o : best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return overflow ? LR_OVERFLOW : best;
+}
+// FULL searches for the lanes with want = true (one after the other, each by the whole wave): the packed result of lane
+// i's game / player in lane i (LR_OVERFLOW if the budget ran out).  Must be called by all 64 lanes of the wave.
 template <class S>
-DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget, u32 nbr_c, u32 nbr_e, unsigned long long* stat = nullptr) {
+DEVI u64 coop_longest_path_packed(bool want, const S& s, int pid, LrWave& L, int budget, u32 nbr_c, u32 nbr_e, unsigned long long* stat = nullptr) {
     u64 bal = __ballot(want);
     if (bal == 0) return 0;
     u64 rlo = 0, blocked = 0;
@@ -570,45 +741,22 @@ DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget
         for (int o = 0; o < 4; o++) if (o != pid) blocked |= s.settle(o) | s.city(o);
     }
     const int lane = threadIdx.x & 63;
-    int result = 0;
-    const DfsQueue q{ L.q_seen, L.q_cd, &L.qn, LR_QN };
+    u64 result = 0;
     while (bal) {
         const int src = __ffsll((long long)bal) - 1;
         bal &= bal - 1;
         const u64 R = ((u64)(u32)__shfl((int)(u32)(rlo >> 32), src) << 32) | (u32)__shfl((int)(u32)rlo, src);
         const u32 RH = (u32)__shfl((int)rhi, src);
         const u64 BL = ((u64)(u32)__shfl((int)(u32)(blocked >> 32), src) << 32) | (u32)__shfl((int)(u32)blocked, src);
-        const u64 myadj = lr_adj_of(lane, nbr_c, nbr_e, R, RH, BL);
-        if (lane < 54) L.adj[lane] = myadj;
-        if (lane == 0) L.qn = 0;
-        __builtin_amdgcn_wave_barrier();
-        Dfs t;
-        t.active = myadj != 0; t.cur = lane; t.d = 0; t.base = 0; t.best = 0;
-        t.seen = 1ull << (lane & 63); t.cand = myadj;
-        u64 idle = __ballot(!t.active);
-        int it = 0;
-        bool overflow = false;
-        while (true) {
-            dfs_iter(t, L.adj, &L.path[0][lane], 64, idle != 0, q);
-            dfs_iter(t, L.adj, &L.path[0][lane], 64, idle != 0, q);
-            idle = __ballot(!t.active);
-            const int qn = L.qn;
-            if (idle == ~0ull && qn <= 0) break;
-            if (budget > 0 && ++it > budget) { overflow = true; break; }
-            if (!t.active && qn > 0) {
-                const int qi = atomicSub(&L.qn, 1) - 1;
-                if (qi >= 0) dfs_take(t, L.adj, L.q_seen[qi], L.q_cd[qi]);
-                else atomicAdd(&L.qn, 1);
-            }
-        }
-        if (stat != nullptr && lane == 0) { atomicAdd(&stat[0], 1ull); atomicAdd(&stat[1], (unsigned long long)it); if (overflow) atomicAdd(&stat[2], 1ull); }
-        int best = t.best;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
-        if (lane == src) result = overflow ? -1 : best;
-        __builtin_amdgcn_wave_barrier();
+        const u64 r = lr_wave_search(R, RH, BL, false, 0, 0, L, budget, nbr_c, nbr_e, stat);
+        if (lane == src) result = r;
     }
     return result;
+}
+template <class S>
+DEVI int coop_longest_path(bool want, const S& s, int pid, LrWave& L, int budget, u32 nbr_c, u32 nbr_e, unsigned long long* stat = nullptr) {
+    const u64 r = coop_longest_path_packed(want, s, pid, L, budget, nbr_c, nbr_e, stat);
+    return r == LR_OVERFLOW ? -1 : (int)(r >> 54);
 }
 
 // scratch of the one-wave-per-game re-deal (wave_reset_game): the game's Philox stream is generated in bulk by all 64 lanes
@@ -1231,7 +1379,7 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
-struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; i32* len; u32* arrive; i32* resets[2][3]; u8* busy;
+struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; u64* len; u32* arrive; i32* resets[2][3]; u8* busy;
                  u64* spec;                 // lock-step steps: the longest-road requests of games that this step may end (ctr[6])
                  i32* lists;                // the sort: game ids per action-type bin, [NBINS][N] (bin b, rank r at b * N + r)
                  int bsel;                  // which of the two bin-count sets (ctr[16 + NBINS * bsel ..]) this pass uses
@@ -1256,14 +1404,17 @@ struct StepScratch { LrWave lr; };
 // Everything of a step that needs the longest-road length: the holder logic of game/game.py:864-919, done/rewards
 // (env/wrapper.py:85-112), auto-reset (RL/ppo/game_manager.py:112-113) and the next legal-action masks.
 // Must be called by all 64 lanes; `doit` selects the lanes it applies to.
-// LR = false: no lane has a longest-road update (k_step: those games take the slow path); scratch may be null then.
-template <bool LR, class S>
+// LR = 0: no lane has a longest-road update; LR = 1: lanes may have one whose length `len` came from the cache (k_step,
+// lane per game; "the holder's road was cut" cannot happen then: an exact cached length equals the holder's count);
+// LR = 2: the slow-path kernels (one game per wave, `lc` = the game's cache in the doit lane): the rare cut case takes the
+// other players' lengths from the cache, or searches (whole wave) and caches them.
+template <int LR, class S>
 DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const StepCfg& cfg, int lane, bool doit, int type,
                       int lr_who, int len, float* __restrict__ reward, u8* __restrict__ done, u32* __restrict__ mpk,
                       long long& tprof, u32 nbr_c, u32 nbr_e, const Pending& pend, int rlist, bool clear_busy,
-                      u32* m_out = nullptr, bool* m_valid = nullptr) {
+                      u32* m_out = nullptr, bool* m_valid = nullptr, LrCache* lc = nullptr) {
     const long e = s.e;
-    if constexpr (LR) {
+    if constexpr (LR != 0) {
         bool cut = false;
         int holder = 0, hcount = 0;
         if (doit && lr_who >= 0) {
@@ -1279,12 +1430,17 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
                 s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len);
             }
         }
+        if constexpr (LR == 2) {
         if (__ballot(cut)) {                                               // game.py:880-912 (rare)
             int max_len = len, player = lr_who;
             bool tied = false;
             for (int o = 0; o < 4; o++) {                                  // White, Blue, Orange, Red (game.py:886)
-                int pl = coop_longest_path(cut && o != lr_who, s, o, scratch->lr, 0, nbr_c, nbr_e);
-                if (cut && o != lr_who) {
+                const bool mine = cut && o != lr_who;
+                const bool need = mine && !lc->valid(o);
+                const u64 found = coop_longest_path_packed(need, s, o, scratch->lr, 0, nbr_c, nbr_e);
+                if (need) lc->set(o, found & LR_VMASK);
+                if (mine) {
+                    const int pl = lr_len(lc->get(o));
                     if (pl == max_len) tied = true;
                     else if (pl > max_len) { max_len = pl; tied = false; player = o; }
                 }
@@ -1301,6 +1457,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
                     }
                 } else { s.sb(B_LR_PLAYER, 0); s.sb(B_LR_COUNT, 0); s.spb(lr_who, P_VP, s.pb(lr_who, P_VP) - 2); }
             }
+        }
         }
     }
     // ---- done / rewards (wrapper.py:85-112)
@@ -1440,7 +1597,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int order = s.b(B_ORDER), seatof = s.b(B_SEATOF);
     const int pid = s.b(B_GO);
     int flags = s.flags();
-    int lr_who = -1;
+    int lr_who = -1, lr_edge = 127, lr_len_now = 0;         // longest-road update: for whom, the new edge (127: none), cached length
+    bool lr_inline = false;                                 // ... whose length the cache already knows
     const long long t_sw0 = cfg.prof_wave ? clock_fenced() : 0;
 
     switch (type) {
@@ -1457,6 +1615,9 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         }
         s.spb(pid, P_SLEFT, s.pb(pid, P_SLEFT) - 1);
         s.spb(pid, P_VP, s.pb(pid, P_VP) + 1);
+        LrCache lc;                                                        // an opponent's cached longest path over this corner is gone
+        lc.load(s.P);
+        if (lc.settle_invalidate(pid, cn)) lc.store(s.P);
         if (flags & F_INITIAL) {
             int k = s.pb(pid, P_ISET) + 1;
             s.spb(pid, P_ISET, k);
@@ -1480,7 +1641,12 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
             D5 d; d.v[R_BRICK] = -1; d.v[R_WOOD] = -1; d.v[R_ORE] = 0; d.v[R_SHEEP] = -1; d.v[R_WHEAT] = -1;
             update_estimates(s, seatof, d, 0b11011, pid, -1);
             int lrp = s.b(B_LR_PLAYER);
-            if (lrp) lr_who = lrp - 1;
+            if (lrp) {                                                     // game.py:552-553: the holder's path is looked at again
+                lr_who = lrp - 1;
+                // still exact in the cache (the usual case: the new settlement is not on it): nothing to search, and the
+                // length equals the holder's count, so the step completes right here
+                if (lc.valid(lr_who) && lr_len(lc.get(lr_who)) >= s.b(B_LR_COUNT)) { lr_inline = true; lr_len_now = lr_len(lc.get(lr_who)); }
+            }
         }
         break;
     }
@@ -1502,6 +1668,12 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
             }
         }
         lr_who = pid;
+        if (ed != 72) lr_edge = ed;
+        else {                                                             // the dummy edge of road building: nothing new to search
+            LrCache lc;
+            lc.load(s.P);
+            if (lc.valid(pid)) { lr_inline = true; lr_len_now = lr_len(lc.get(pid)); }
+        }
         if (flags & F_RB_ACTIVE) {
             int k = s.b(B_RB_COUNT) + 1;
             if (k >= 2) { flags &= ~(F_RB_ACTIVE | F_MUST_USE_DEV); k = 0; }
@@ -1733,11 +1905,11 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     prof_mark(cfg, 1, tprof);
     // ---- update_longest_road (game.py:864-919): the path search runs in k_lr_finish / k_lr_heavy, which also complete
     // the step of these games (sorted waves would otherwise serialise up to 64 searches in the road-placement waves)
-    const int len = 0;
-    const bool pending = lr_who >= 0;
+    const int len = lr_len_now;
+    const bool pending = lr_who >= 0 && !lr_inline;
     if (pending) {
         const u32 slot = atomicAdd(&pend.ctr[4 + pend.fa], 1u);
-        pend.req[pend.fa][slot] = (u64)e | ((u64)lr_who << 56);
+        pend.req[pend.fa][slot] = (u64)e | ((u64)lr_edge << 40) | ((u64)lr_who << 56);
         if (pend.stag < 2) {                               // lock-step: a game whose completion can end it (longest road: +2 points for
             bool may_end = false;                          // one player) gets a speculative successor (k_reset_list)
 #pragma unroll
@@ -1751,8 +1923,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     prof_mark(cfg, 2, tprof);
     u32 m_new[MASK_WORDS];
     bool have_masks = false;
-    finish_step<false>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, -1, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend, 0, false,
-                       m_new, &have_masks);
+    finish_step<1>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, lr_inline ? lr_who : -1, len, reward, done, mpk, tprof, nbr_c, nbr_e,
+                   pend, 0, false, m_new, &have_masks);
     // ---- write the tile back, then the new mask rows through the tile
     __builtin_amdgcn_wave_barrier();
     if (w_board) stage_out<28, 0>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
@@ -1763,57 +1935,89 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     prof_mark(cfg, 7, tprof);
 }
 
+constexpr u64 LR_GAME_MASK = (1ull << 40) - 1;             // request: game | new edge (127: none) << 40 | pid0 << 56
+// What a longest-road request needs: THROUGH(new edge) when the player's cached path is exact, else FULL.  (A request of
+// a settlement is always FULL: k_step completes those whose holder's cache is intact itself.)
+struct LrPlan { bool through; int u, v; };
+DEVI LrPlan lr_plan(const LrCache& lc, int who, int edge) {
+    LrPlan pl;
+    pl.through = edge < 72 && lc.valid(who);
+    const int ed = edge < 72 ? edge : 0;
+    pl.u = EDGE_CORNER[ed][0]; pl.v = EDGE_CORNER[ed][1];
+    return pl;
+}
+// the player's new longest path from a search result: length and the cache entry (valid)
+DEVI int lr_apply(LrCache& lc, int who, bool through, u64 found) {
+    const u64 old = lc.get(who);
+    const int flen = (int)(found >> 54);
+    if (through && lr_len(old) >= flen) return lr_len(old);
+    lc.set(who, found & LR_VMASK);
+    return flen;
+}
 // Tier 1 of the longest road and the completion of the step, one request per wave: all 64 lanes cooperate on the path
 // search (budgeted; overflow hands the game to the tier-2 list), then the game's hot record is staged linearly in LDS and
 // lane 0 completes the step (holder logic, done/reward, next masks).  `fl` selects the request list.
 __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
-                                                  StepCfg cfg, Pending pend, int fl, int budget, unsigned long long* stat) {
+                                                  StepCfg cfg, Pending pend, int fl, int budget, unsigned long long* stat,
+                                                  unsigned long long* slow_ctr) {
     __shared__ StepScratch scratch;
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     const int lane = threadIdx.x;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
     const u32 count = pend.ctr[4 + fl];
+    if (blockIdx.x == 0 && lane == 0 && slow_ctr != nullptr) { atomicAdd(&slow_ctr[0], (unsigned long long)count); atomicAdd(&slow_ctr[2], 1ull); }
     StepCfg cfg2 = cfg;
     cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
         const u64 rq = pend.req[fl][r];
-        const long e = (long)(rq & 0x00FFFFFFFFFFFFFFull);
-        const int who = (int)(rq >> 56);
+        const long e = (long)(rq & LR_GAME_MASK);
+        const int who = (int)(rq >> 56), edge = (int)((rq >> 40) & 127);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
         __builtin_amdgcn_wave_barrier();
         StL1 s(rec, c.R, c.N, e);
-        int len = coop_longest_path(lane == 0, s, who, scratch.lr, budget, nbr_c, nbr_e, stat);
-        len = __shfl(len, 0);
-        if (len < 0) {                                   // tier 2 takes over; the record is untouched
+        LrCache lc;
+        lc.load(s.P);                                     // (every lane: the same seven words)
+        const LrPlan pl = lr_plan(lc, who, edge);
+        u64 BL = 0;
+        for (int o = 0; o < 4; o++) if (o != who) BL |= s.settle(o) | s.city(o);
+        const u64 found = lr_wave_search(s.road_lo(who), s.road_hi(who), BL, pl.through, pl.u, pl.v, scratch.lr, budget, nbr_c, nbr_e, stat);
+        if (found == LR_OVERFLOW) {                      // tier 2 takes over; the record is untouched
             if (lane == 0) {
                 const u32 slot = atomicAdd(&pend.ctr[8 + 4 * pend.sa], 1u);
                 pend.heavy[pend.sa][slot] = rq; pend.len[e] = 0; pend.arrive[e] = 0; pend.busy[e] = (u8)pend.stag;
+                if (slow_ctr != nullptr) atomicAdd(&slow_ctr[1], 1ull);
             }
             continue;
         }
+        const int len = lr_apply(lc, who, pl.through, found);
         long long tprof = 0;
-        finish_step<true>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
-                    pend.stag < 2 ? 2 : 0, pend.ftag < 2);
+        finish_step<2>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
+                       pend.stag < 2 ? 2 : 0, pend.ftag < 2, nullptr, nullptr, &lc);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+        if (lane == 0) lc.store(s.P);
     }
 }
 
-// tier 2: `split` workgroups per request (static partition of the start corners, combined with atomicMax); few requests
+// tier 2: `split` workgroups per request (FULL: static partition of the start corners; THROUGH: the single seed starts
+// in part 0, the other parts only arrive; results combined with a 64-bit atomicMax of len << 54 | vertex mask); few requests
 // (lock-step) get 8 workgroups each for latency, many (a deferred window) share the grid for throughput.
-// req[i] = game | pid0 << 56; out_len[game] (zeroed when the request was pushed) collects the path length.  The workgroup
-// that arrives LAST at a request (pend.arrive[game]) completes the step of that game - holder logic, done / rewards, next
-// masks - on its first wave, as k_lr_finish does for tier 1 (a separate completion kernel cost 28 us of every lock-step step).
+// req[i] = game | new edge << 40 | pid0 << 56; out64[game] (zeroed when the request was pushed) collects the result.  The
+// workgroup that arrives LAST at a request (pend.arrive[game]) completes the step of that game - cache, holder logic,
+// done / rewards, next masks - on its first wave, as k_lr_finish does for tier 1 (a separate completion kernel cost 28 us of
+// every lock-step step).
 __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32* __restrict__ req_count,
-                                                              const u64* __restrict__ req, i32* __restrict__ out_len, int round_iters,
+                                                              const u64* __restrict__ req, u64* __restrict__ out64, int round_iters,
                                                               u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
                                                               StepCfg cfg, Pending pend) {
     __shared__ u64 adj[54];
     __shared__ u64 pool_seen[LR_POOL];
     __shared__ unsigned short pool_cd[LR_POOL];
-    __shared__ int pool_n, best_all, is_last;
+    __shared__ unsigned long long best_all;
+    __shared__ u64 blk_all;
+    __shared__ int pool_n, is_last;
     __shared__ __attribute__((aligned(16))) lrstk_t path[54][LR_HEAVY_THREADS];
     static_assert(sizeof(StepScratch) + ROWS_HOT * 4 + 64 <= sizeof(lrstk_t) * 54 * LR_HEAVY_THREADS, "the completion reuses the DFS stacks");
     const int tid = threadIdx.x;
@@ -1827,38 +2031,51 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
         const u64 rq = req[r / LR_SPLIT];
         const int part = (int)(r % LR_SPLIT);
-        const long game = (long)(rq & 0x00FFFFFFFFFFFFFFull);
-        const int pid = (int)(rq >> 56);
+        const long game = (long)(rq & LR_GAME_MASK);
+        const int pid = (int)(rq >> 56), edge = (int)((rq >> 40) & 127);
         St s(c.R, c.N, game);
+        LrCache lc;
+        lc.load(s.P);                              // (no part writes the cache before every part has arrived)
+        const LrPlan pl = lr_plan(lc, pid, edge);
         __syncthreads();
         if (tid < 54) {
             u64 BL = 0;
             for (int o = 0; o < 4; o++) if (o != pid) BL |= s.settle(o) | s.city(o);
             adj[tid] = lr_adj_of(tid, nbr_c, nbr_e, s.road_lo(pid), s.road_hi(pid), BL);
+            if (tid == 0) blk_all = BL;
         }
-        if (tid == 0) { pool_n = 0; best_all = 0; }
+        if (tid == 0) { pool_n = 0; best_all = 0ull; }
         __syncthreads();
+        const LrGraph G{ adj, blk_all, pl.v };
         Dfs t;
-        t.active = tid < 54 && ((u32)tid % LR_SPLIT) == (u32)part && adj[tid < 54 ? tid : 0] != 0;
-        t.cur = tid; t.d = 0; t.base = 0; t.best = 0; t.seen = 1ull << (tid & 63); t.cand = tid < 54 ? adj[tid] : 0ull;
+        if (pl.through) {                                  // 4^5 prefixes = the 1 024 threads of part 0; with >= 4 parts: 4^6 over parts 0..3
+            const bool wide = LR_SPLIT >= 4;
+            dfs_seed_through(t, wide ? part < 4 : part == 0, pl.u, pl.v, adj[pl.u]);
+            dfs_walk_prefix(t, G, wide ? part * LR_HEAVY_THREADS + tid : tid, wide ? 6 : 5);
+        } else {                                           // start corner tid % 54 (this part's share), 16 two-level prefixes each
+            const int st = tid % 54, code = tid / 54;
+            dfs_seed_full(t, st, adj[st]);
+            t.active = t.active && code < 16 && ((u32)st % LR_SPLIT) == (u32)part;
+            dfs_walk_prefix(t, G, code, 2);
+        }
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
         while (true) {
-            for (int it = 0; it < round_iters; it++) dfs_iter(t, adj, &path[0][tid], LR_HEAVY_THREADS, hint, q);
+            for (int it = 0; it < round_iters; it++) dfs_iter(t, G, &path[0][tid], LR_HEAVY_THREADS, hint, q);
             __syncthreads();                       // all pushes of this round are complete
             if (!t.active) {
                 const int qi = atomicSub(&pool_n, 1) - 1;
-                if (qi >= 0) dfs_take(t, adj, pool_seen[qi], pool_cd[qi]);
+                if (qi >= 0) dfs_take(t, G, pool_seen[qi], pool_cd[qi]);
                 else atomicAdd(&pool_n, 1);
             }
             const int busy = __syncthreads_count(t.active);   // all pops complete
             if (busy == 0) break;                  // nobody active -> the pool is empty too (idle threads drained it)
             hint = busy < LR_HEAVY_THREADS;
         }
-        atomicMax(&best_all, t.best);
+        if (t.best > 0) atomicMax(&best_all, (unsigned long long)lr_pack(t.best, t.bseen));
         __syncthreads();
         if (tid == 0) {
-            if (best_all > 0) atomicMax(&out_len[game], best_all);
+            if (best_all > 0) atomicMax(reinterpret_cast<unsigned long long*>(&out64[game]), best_all);
             __threadfence();                                           // this part's result before its arrival
             is_last = atomicAdd(&pend.arrive[game], 1u) == LR_SPLIT - 1 ? 1 : 0;
         }
@@ -1867,17 +2084,19 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
             StepScratch* scratch = reinterpret_cast<StepScratch*>(&path[0][0]);
             u32* rec = reinterpret_cast<u32*>(reinterpret_cast<char*>(&path[0][0]) + ((sizeof(StepScratch) + 63) & ~size_t(63)));
             const int lane = tid;
-            const int len = atomicMax(&out_len[game], 0);              // (device-scope read of the combined length)
+            const u64 found = atomicMax(reinterpret_cast<unsigned long long*>(&out64[game]), 0ull);   // (device-scope read of the combined result)
             if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + game * REC)[lane];
             __builtin_amdgcn_wave_barrier();
             StL1 sl(rec, c.R, c.N, game);
             u32 nc, ne;
             lr_load_nbr(lane, nc, ne);
+            const int len = lr_apply(lc, pid, pl.through, found);
             long long tprof = 0;
-            finish_step<true>(c, sl, scratch, cfg2, lane, lane == 0, (int)pend.type[game] - 1, pid, len, reward, done, mpk, tprof, nc, ne, pend,
-                              1, pend.stag < 2);
+            finish_step<2>(c, sl, scratch, cfg2, lane, lane == 0, (int)pend.type[game] - 1, pid, len, reward, done, mpk, tprof, nc, ne, pend,
+                           1, pend.stag < 2, nullptr, nullptr, &lc);
             __builtin_amdgcn_wave_barrier();
             if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + game * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
+            if (lane == 0) lc.store(sl.P);
         }
     }
 }
@@ -2468,6 +2687,10 @@ __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict_
     for (int p = 0; p < 4; p++) s.sb(B_CURVP + p, in.get());
     s.sb(B_WINNER, in.get());
     s.sw(W_RNG, (u32)in.get());
+    LrCache lc;                    // nothing is known about the longest paths of an imported position
+    lc.load(s.P);
+    lc.invalidate_all();
+    lc.store(s.P);
 }
 
 // test/diagnostic entry: longest path of player players[i] (PlayerId 1..4) in game i, unbudgeted tier-1 search

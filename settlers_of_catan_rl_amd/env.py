@@ -145,6 +145,15 @@ class VecCatanEnv(object):
     def set_lr_budgets(self, lockstep, deferred):
         _lib.check(self.L.catan_set_lr_budgets(self.h, int(lockstep), int(deferred)))
 
+    def slow_path_counts(self):
+        """-> cumulative (tier-1 longest-road requests, requests handed to tier 2, k_lr_finish launches)"""
+        out = (C.c_uint64 * 3)()
+        _lib.check(self.L.catan_slow_path_counts(self.h, _stream(), out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def set_lr_rounds(self, lockstep, deferred):
+        _lib.check(self.L.catan_set_lr_rounds(self.h, int(lockstep), int(deferred)))
+
     def random_rollout_timed(self, step_idx0, steps, window=0):
         """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream); window > 0: the deferred loop."""
         ms = (C.c_float * 7)()
