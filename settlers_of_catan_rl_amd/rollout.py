@@ -78,7 +78,11 @@ class RolloutCollector(object):
         self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
         self.recurrent = bool(getattr(policy, "include_lstm", False))
         self.lstm_size = int(policy.lstm_size) if self.recurrent else 0
-        self.storage = RolloutStorage(num_steps, self.N, self.device, lstm_size=self.lstm_size)
+        # Under autocast the net casts its inputs to the autocast dtype before the first GEMM anyway, and every observation
+        # value is a small multiple of 1/8 (exact in bf16): the rollout tensors are kept in that dtype - half the HBM
+        # (config 3: 58 instead of 116 GB) and no cast pass per minibatch.
+        obs_dtype = autocast_dtype if (autocast_dtype in (torch.bfloat16, torch.float16) and torch.device(self.device).type == "cuda") else torch.float32
+        self.storage = RolloutStorage(num_steps, self.N, self.device, obs_dtype=obs_dtype, lstm_size=self.lstm_size)
         # game_manager.py:94-95 sums the env's rewards (Python floats) over the other seats' moves and process_batch.py:63
         # rounds the sum to fp32: the env leaves its unrounded rewards in a float64 buffer for that
         self.reward64 = env.enable_reward64() if hasattr(env, "enable_reward64") else None

@@ -93,13 +93,14 @@ class PPOTrainer(object):
         rec = getattr(self.policy, "include_lstm", False)
         if rec:
             hid = st.hidden[:, :T1].reshape(2, T1 * N, -1); nt = st.masks[:T1].reshape(T1 * N)
+        cast = (lambda x: x) if (self.autocast_dtype is not None and f.dtype == self.autocast_dtype) else (lambda x: x.float())
         for s in range(0, T1 * N, ch):
             with self._autocast():
                 if rec:
-                    v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long(),
+                    v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(),
                                               (hid[0, s:s + ch], hid[1, s:s + ch]), nt[s:s + ch])
                 else:
-                    v = self.policy.get_value(f[s:s + ch].float(), lists[s:s + ch], lens[s:s + ch].long())
+                    v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long())
             out[s:s + ch] = v[:, 0]
         return self.policy.denormalise(out).reshape(T1, N)
 
@@ -116,6 +117,7 @@ class PPOTrainer(object):
         rewards = st.rewards[:T].contiguous(); masks = st.masks[:T + 1].contiguous()
         rec = getattr(pol, "include_lstm", False)
         nt_all = masks[:T].reshape(total)                 # masks_batch of generator_lstm (process_batch.py:249)
+        cast = (lambda x: x) if (self.autocast_dtype is not None and f_all.dtype == self.autocast_dtype) else (lambda x: x.float())
         sums = torch.zeros(3, device=dev)                 # action loss, value loss, entropy (accumulated on device)
         t_val = t_gae = t_opt = 0.0
         for _ in range(cfg.ppo_epoch):
@@ -135,11 +137,11 @@ class PPOTrainer(object):
             for idx, hidden in batches:
                 with self._autocast():
                     if rec:
-                        v, lp, ent, _ = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
+                        v, lp, ent, _ = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
                                                              st.unpack_action_masks(amask_all[idx]), acts_all[idx],
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
                     else:
-                        v, lp, ent = pol.evaluate_actions(f_all[idx].float(), lists_all[idx], lens_all[idx].long(),
+                        v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx])
                 loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
                                                    cfg.clip_param, cfg.value_loss_coef,

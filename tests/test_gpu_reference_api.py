@@ -106,7 +106,8 @@ def test_config3_shape_65536_games_sampled_parity(oracle, hip_lib):
         for a in rec.trace[j] + [None]:
             if o.deciding_player() == active[gidx] and t_obs <= T:
                 f, lists, lens, _ = o.obs()
-                assert np.array_equal(st.obs_f[t_obs, gidx].cpu().numpy(), f), (gidx, t_obs)
+                assert st.obs_f.dtype == torch.bfloat16                 # stored in the autocast dtype: exact (multiples of 1/8)
+                assert np.array_equal(st.obs_f[t_obs, gidx].float().cpu().numpy(), f), (gidx, t_obs)
                 assert np.array_equal(st.lens[t_obs, gidx].cpu().numpy(), lens)
                 if t_obs < T:
                     assert np.array_equal(st.unpack_action_masks(st.action_masks[t_obs, gidx]).cpu().numpy(), o.masks()), (gidx, t_obs)

@@ -208,3 +208,31 @@ def test_reference_state_dict_loads_strictly_into_the_reference_net(tmp_path):
         build_agent_model().load_state_dict(e, strict=True)
     # and the other way round
     loop.load_reference_tuple(str(tmp_path / "ref.pt"))
+
+
+def test_compact_head_evaluation_equals_the_dense_one(oracle):
+    """evaluate_actions runs every action head only on the rows whose action type uses it (`_evaluate_compact`): same joint
+    log-probs, entropy and gradients as the dense evaluation of all heads on all rows."""
+    torch.manual_seed(4)
+    net = CatanPolicy()
+    _perturb(net, seed=6)
+    x = policy_util.oracle_batch_inputs(oracle, n=160, seed=21, steps=(0, 9, 60, 200, 500, 900, 1300, 1700))
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        _, acts, _ = net.act(x["obs_f"], x["lists"], x["lens"], x["masks"], generator=g)
+    types = set(acts[:, 0].tolist())
+    assert len(types) >= 11, types                       # nearly every action type occurs (incl. trades, cards, robber, discard)
+    assert ((acts[:, 0] == 4) & (acts[:, 4] == 2)).any() or ((acts[:, 0] == 4) & (acts[:, 4] == 4)).any() or (acts[:, 0] == 5).any()
+    res = {}
+    for compact in (False, True):
+        net.action_head_module.compact_evaluate = compact
+        net.zero_grad()
+        v, lp, ent = net.evaluate_actions(x["obs_f"], x["lists"], x["lens"], x["masks"], acts)
+        ((lp[:, 0] * torch.linspace(0.5, 1.5, lp.shape[0])).sum() + 3.0 * ent + v.sum()).backward()
+        res[compact] = (lp.detach().clone(), float(ent), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    net.action_head_module.compact_evaluate = True
+    assert torch.allclose(res[True][0], res[False][0], atol=1e-5)
+    assert abs(res[True][1] - res[False][1]) < 1e-6
+    assert set(res[True][2]) == set(res[False][2])
+    for k, gd in res[False][2].items():
+        assert torch.allclose(res[True][2][k], gd, atol=2e-5, rtol=1e-4), (k, float((res[True][2][k] - gd).abs().max()))
