@@ -227,6 +227,26 @@ int catan_categorical_fwd(const float* logits, const float* mask, int64_t mask_l
 int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* action, const float* lse, const float* entropy,
                           const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream);
 
+/* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
+ * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card
+ * CLASS (a list has <= 6 distinct ids; see csrc/catan_nn.hip).  ids: [rows][pitch] integers of id_bytes (1, 4 or 8) bytes, the
+ * first min(lens[r], 25) entries of a row are valid; params: float[catan_card_summary_params()] = S[4][6][6] (scaled q.k of the
+ * six ids per head), V[6][16], out-projection W[16][16], its bias[16], LayerNorm weight[16], bias[16]; out / dout: float
+ * [rows][16]; dparams: gradients of `params`, ACCUMULATED into (zero first).
+ * keys (int32 [rows], may be NULL): the forward also writes each list's PATTERN number - its six counts, bounded by the deck
+ * (2 x 15 x 6 x 3 x 3 x 3 = catan_card_summary_patterns() patterns; pattern k has counts c0 = k % 2, c1 = k / 2 % 15, c2 = k / 30 % 6,
+ * c3 = k / 180 % 3, c4 = k / 540 % 3, c5 = k / 1620) - or -1 for counts outside the deck.  The gradient is linear in dout, so a
+ * caller may sum dout per pattern and differentiate catan_card_summary_patterns() synthetic lists instead of all rows;
+ * only_unkeyed (int32 [rows], may be NULL) makes the backward skip the rows whose entry is >= 0 (those went through the patterns). */
+int32_t catan_card_summary_params(void);
+int32_t catan_card_summary_patterns(void);
+int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, float* out,
+                           int32_t* keys, int64_t rows, catan_stream_t stream);
+int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
+                           float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream);
+/* dpat[keys[r]][0..15] += dout[r][0..15] for the rows with keys[r] >= 0 (dpat: float [catan_card_summary_patterns()][16]) */
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int64_t rows, catan_stream_t stream);
+
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
 int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);

@@ -837,6 +837,36 @@ int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_l
     return CATAN_OK;
 }
 
+int32_t catan_card_summary_params(void) { return CS_NPAR; }
+
+static int card_summary_check(const void* ids, int esz, int64_t pitch, const int32_t* lens, const float* params, int64_t rows) {
+    if (!ids || !lens || !params || rows <= 0 || pitch < 1 || (esz != 1 && esz != 4 && esz != 8)) return fail(CATAN_EINVAL, "catan_card_summary: bad arguments");
+    return CATAN_OK;
+}
+int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, float* out,
+                           int32_t* keys, int64_t rows, catan_stream_t stream) {
+    if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !out) return fail(CATAN_EINVAL, "catan_card_summary_fwd: bad arguments");
+    hipLaunchKernelGGL(k_card_summary_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, out, (long)rows, keys);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
+                           float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream) {
+    if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !dout || !dparams) return fail(CATAN_EINVAL, "catan_card_summary_bwd: bad arguments");
+    const int rpl = rows >= 65536 ? 4 : 1;                 // lists per lane: few rows (the pattern table) want all the lanes they can get
+    const dim3 grid((unsigned)((rows + 256 * rpl - 1) / (256 * rpl)), 7);
+    hipLaunchKernelGGL(k_card_summary_bwd, grid, dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, dout, dparams, (long)rows, only_unkeyed, rpl);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int32_t catan_card_summary_patterns(void) { return CS_PATTERNS; }
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int64_t rows, catan_stream_t stream) {
+    if (!keys || !dout || !dpat || rows <= 0) return fail(CATAN_EINVAL, "catan_card_pattern_sum: bad arguments");
+    hipLaunchKernelGGL(k_card_pattern_sum, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), keys, dout, dpat, (long)rows);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int64_t catan_missed_speculation_count(catan_env_t* e, catan_stream_t stream) {
     if (!e) return -1;
     u32 v = 0;

@@ -940,4 +940,265 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ card-list summary
+// The dev-card list modules of RL/models/player_modules.py:55-69 (embedding -> 4-head attention with key mask -> out
+// projection -> LayerNorm -> zero the padding -> sum over the list), one lane per list.  A list holds at most 6 distinct
+// card ids, and everything computed per token depends only on the token's id and on how many valid tokens of each id the
+// list has: the softmax over the keys j of s(id_i, id_j) equals the softmax over the ids b of s(id_i, b) + log(count_b).
+// So the kernel reads the 25 ids, counts them, and evaluates <= 6 query classes against <= 6 key classes from tiny tables:
+//   S[h][a][b] = q_h(a) . k_h(b) / sqrt(hd)   (4 x 6 x 6)      V[b][16]      out-projection W[16][16], bias     LayerNorm w, b
+// (the tables are functions of the embedding and the Q/K/V weights - 6 x 16 numbers through 16 x 48 - and are built by
+// torch on the host side of the call, so their gradients flow on from dS / dV by autograd).  Traffic: 26 B in, 64 B out per
+// list instead of a dozen [B, 25, 16..48] tensors.  ids: element size `esz` (1, 4 or 8 bytes), row pitch `pitch` elements.
+constexpr int CS_V = 6, CS_H = 4, CS_HD = 4, CS_D = 16, CS_L = 25;
+struct CardTables { float S[CS_H][CS_V][CS_V]; float Vt[CS_V][CS_D]; float W[CS_D][CS_D]; float bo[CS_D]; float lw[CS_D]; float lb[CS_D]; };
+constexpr int CS_NPAR = CS_H * CS_V * CS_V + CS_V * CS_D + CS_D * CS_D + 3 * CS_D;     // 544 floats, in this order
+static_assert(sizeof(CardTables) == CS_NPAR * sizeof(float), "CardTables is the flat parameter block");
+
+DEVI void cs_counts(const void* __restrict__ ids, int esz, long pitch, long r, int len, float (&cnt)[CS_V]) {
+#pragma unroll
+    for (int a = 0; a < CS_V; a++) cnt[a] = 0.f;
+    for (int i = 0; i < CS_L && i < len; i++) {
+        long id;
+        if (esz == 1) id = reinterpret_cast<const signed char*>(ids)[r * pitch + i];
+        else if (esz == 4) id = reinterpret_cast<const int*>(ids)[r * pitch + i];
+        else id = reinterpret_cast<const long long*>(ids)[r * pitch + i];
+#pragma unroll
+        for (int a = 0; a < CS_V; a++) cnt[a] += (id == a) ? 1.f : 0.f;
+    }
+}
+// one query class: attention output, projection, LayerNorm.  p[h][b] (softmax), attn[16], xhat[16], rstd are kept for the backward
+DEVI void cs_class_fwd(const CardTables& T, const float (&logc)[CS_V], int a, float eps, float (&p)[CS_H][CS_V], float (&attn)[CS_D],
+                       float (&xhat)[CS_D], float& rstd, float (&rep)[CS_D]) {
+#pragma unroll
+    for (int h = 0; h < CS_H; h++) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < CS_V; b++) { p[h][b] = T.S[h][a][b] + logc[b]; mx = fmaxf(mx, p[h][b]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < CS_V; b++) { p[h][b] = __expf(p[h][b] - mx); sum += p[h][b]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int b = 0; b < CS_V; b++) p[h][b] *= inv;
+#pragma unroll
+        for (int d = 0; d < CS_HD; d++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int b = 0; b < CS_V; b++) acc += p[h][b] * T.Vt[b][h * CS_HD + d];
+            attn[h * CS_HD + d] = acc;
+        }
+    }
+    float o[CS_D], mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) {
+        float acc = T.bo[i];
+#pragma unroll
+        for (int j = 0; j < CS_D; j++) acc += T.W[i][j] * attn[j];
+        o[i] = acc; mean += acc;
+    }
+    mean *= 1.f / CS_D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) { const float c = o[i] - mean; var += c * c; }
+    rstd = rsqrtf(var * (1.f / CS_D) + eps);
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) { xhat[i] = (o[i] - mean) * rstd; rep[i] = xhat[i] * T.lw[i] + T.lb[i]; }
+}
+// The count vector of a real list is bounded by the deck (game/game.py:77: 14 knights, 5 victory points, 2 year of plenty, 2
+// road building, 2 monopoly; id 0 = the reference's placeholder of an empty list): 2 x 15 x 6 x 3 x 3 x 3 = 4 860 possible
+// PATTERNS.  The forward kernel can emit each list's pattern number (-1: counts outside the deck, e.g. synthetic test data);
+// the backward then sums `dout` per pattern (one index_add) and differentiates 4 860 lists instead of 10^5..10^6.
+constexpr int CS_PATTERNS = 2 * 15 * 6 * 3 * 3 * 3;
+DEVI int cs_pattern(const float (&cnt)[CS_V]) {
+    const int c0 = (int)cnt[0], c1 = (int)cnt[1], c2 = (int)cnt[2], c3 = (int)cnt[3], c4 = (int)cnt[4], c5 = (int)cnt[5];
+    if (c0 > 1 || c1 > 14 || c2 > 5 || c3 > 2 || c4 > 2 || c5 > 2) return -1;
+    return c0 + 2 * (c1 + 15 * (c2 + 6 * (c3 + 3 * (c4 + 3 * c5))));
+}
+__global__ __launch_bounds__(256) void k_card_summary_fwd(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
+                                                          const float* __restrict__ params, float eps, float* __restrict__ out, long rows,
+                                                          int* __restrict__ keys) {
+    __shared__ CardTables T;
+    for (int i = threadIdx.x; i < CS_NPAR; i += 256) reinterpret_cast<float*>(&T)[i] = params[i];
+    __syncthreads();
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float cnt[CS_V], logc[CS_V];
+    cs_counts(ids, esz, pitch, r, lens[r], cnt);
+    if (keys != nullptr) keys[r] = cs_pattern(cnt);
+#pragma unroll
+    for (int a = 0; a < CS_V; a++) logc[a] = cnt[a] > 0.f ? __logf(cnt[a]) : -INFINITY;
+    float acc[CS_D];
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) acc[i] = 0.f;
+    for (int a = 0; a < CS_V; a++) {
+        if (cnt[a] == 0.f) continue;
+        float p[CS_H][CS_V], attn[CS_D], xhat[CS_D], rep[CS_D], rstd;
+        cs_class_fwd(T, logc, a, eps, p, attn, xhat, rstd, rep);
+#pragma unroll
+        for (int i = 0; i < CS_D; i++) acc[i] += cnt[a] * rep[i];
+    }
+    float4* o4 = reinterpret_cast<float4*>(out + r * CS_D);
+#pragma unroll
+    for (int i = 0; i < 4; i++) o4[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+}
+// dparams (CS_NPAR floats, ACCUMULATED into: zero first): gradients of S, V, W, bias, LayerNorm weight / bias.  A parameter
+// gradient is a sum over all lists.  Every lane keeps a SLICE of the parameter block in registers over CS_RPL lists, then the
+// wave adds its lanes up with shuffles once, one LDS add per wave and one global atomic per block and parameter.  Slices
+// (GROUP): 0..3 = four rows of W each (64 accumulators), 4 = V (96), 5 = bias + LayerNorm weight / bias (48), 6 = S (24 per
+// query class: the class loop is the outer one there).  Each slice recomputes the (cheap) forward: summing every contribution
+// across the wave as it arises cost 2 ms per call, and wider slices spill.
+DEVI float cs_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int GROUP>
+DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
+                       const float* __restrict__ params, float eps, const float* __restrict__ dout,
+                       float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl) {
+    constexpr int NACC = GROUP <= 3 ? 64 : GROUP == 4 ? 96 : GROUP == 5 ? 48 : 24;
+    constexpr int OFF_S = 0, OFF_V = CS_H * CS_V * CS_V, OFF_W = OFF_V + CS_V * CS_D, OFF_B = OFF_W + CS_D * CS_D;
+    __shared__ CardTables T;
+    __shared__ float G[144];
+    for (int i = threadIdx.x; i < CS_NPAR; i += 256) reinterpret_cast<float*>(&T)[i] = params[i];
+    if (threadIdx.x < 144) G[threadIdx.x] = 0.f;
+    __syncthreads();
+    const bool lead = (threadIdx.x & 63) == 0;
+    const long stride = (long)gridDim.x * 256;
+    constexpr int A_OUTER = GROUP == 6 ? CS_V : 1;
+#pragma unroll 1
+    for (int ao = 0; ao < A_OUTER; ao++) {
+        float acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < rpl; it++) {
+            const long r = (long)blockIdx.x * 256 + threadIdx.x + it * stride;
+            if (r >= rows) break;
+            if (only_unkeyed != nullptr && only_unkeyed[r] >= 0) continue;      // this list went through its pattern
+            float cnt[CS_V], logc[CS_V], dy[CS_D];
+            const float4* d4 = reinterpret_cast<const float4*>(dout + r * CS_D);
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 v = d4[i]; dy[4 * i] = v.x; dy[4 * i + 1] = v.y; dy[4 * i + 2] = v.z; dy[4 * i + 3] = v.w;
+                any |= v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+            }
+            if (!any) continue;                                                 // (a pattern no list of the batch has)
+            cs_counts(ids, esz, pitch, r, lens[r], cnt);
+#pragma unroll
+            for (int a = 0; a < CS_V; a++) logc[a] = cnt[a] > 0.f ? __logf(cnt[a]) : -INFINITY;
+#pragma unroll 1
+            for (int a = (GROUP == 6 ? ao : 0); a < (GROUP == 6 ? ao + 1 : CS_V); a++) {
+                float ca = 0.f;
+#pragma unroll
+                for (int q = 0; q < CS_V; q++) ca = (q == a) ? cnt[q] : ca;
+                if (ca == 0.f) continue;
+                float p[CS_H][CS_V], attn[CS_D], xhat[CS_D], rep[CS_D], rstd;
+                cs_class_fwd(T, logc, a, eps, p, attn, xhat, rstd, rep);
+                // LayerNorm backward (drep = count * dy)
+                float dxh[CS_D], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < CS_D; i++) {
+                    const float dr = ca * dy[i];
+                    if constexpr (GROUP == 5) { acc[16 + i] += dr * xhat[i]; acc[32 + i] += dr; }
+                    dxh[i] = dr * T.lw[i]; m1 += dxh[i]; m2 += dxh[i] * xhat[i];
+                }
+                m1 *= 1.f / CS_D; m2 *= 1.f / CS_D;
+                float dattn[CS_D];
+#pragma unroll
+                for (int j = 0; j < CS_D; j++) dattn[j] = 0.f;
+#pragma unroll
+                for (int i = 0; i < CS_D; i++) {
+                    const float d_o = rstd * (dxh[i] - m1 - xhat[i] * m2);           // d(out-projection output i)
+                    if constexpr (GROUP == 5) acc[i] += d_o;
+#pragma unroll
+                    for (int j = 0; j < CS_D; j++) {
+                        if constexpr (GROUP <= 3) { if (i / 4 == GROUP) acc[(i % 4) * 16 + j] += d_o * attn[j]; }
+                        if constexpr (GROUP >= 4) dattn[j] += d_o * T.W[i][j];
+                    }
+                }
+                if constexpr (GROUP == 4 || GROUP == 6) {
+#pragma unroll
+                    for (int h = 0; h < CS_H; h++) {
+                        float dp[CS_V], dot = 0.f;
+#pragma unroll
+                        for (int b = 0; b < CS_V; b++) {
+                            float s1 = 0.f;
+#pragma unroll
+                            for (int d = 0; d < CS_HD; d++) {
+                                s1 += dattn[h * CS_HD + d] * T.Vt[b][h * CS_HD + d];
+                                if constexpr (GROUP == 4) acc[b * CS_D + h * CS_HD + d] += p[h][b] * dattn[h * CS_HD + d];
+                            }
+                            dp[b] = s1; dot += p[h][b] * s1;
+                        }
+                        if constexpr (GROUP == 6) {
+#pragma unroll
+                            for (int b = 0; b < CS_V; b++) acc[h * CS_V + b] += p[h][b] * (dp[b] - dot);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; i++) {
+            const float v = cs_wave_sum(acc[i]);
+            // slot of accumulator i inside the block's G (group 6: S[h][ao][b] at (h * 6 + ao) * 6 + b)
+            const int slot = GROUP == 6 ? ((i / CS_V) * CS_V + ao) * CS_V + (i % CS_V) : i;
+            if (lead && v != 0.f) atomicAdd(&G[slot], v);
+        }
+    }
+    __syncthreads();
+    constexpr int NOUT = GROUP == 6 ? 144 : NACC;
+    constexpr int BASE = GROUP <= 3 ? OFF_W + 64 * GROUP : GROUP == 4 ? OFF_V : GROUP == 5 ? OFF_B : OFF_S;
+    if (threadIdx.x < NOUT && G[threadIdx.x] != 0.f) atomicAdd(&dparams[BASE + threadIdx.x], G[threadIdx.x]);
+}
+// blockIdx.y = the parameter slice: the seven slices of one backward run side by side in ONE launch
+__global__ __launch_bounds__(256) void k_card_summary_bwd(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
+                                                          const float* __restrict__ params, float eps, const float* __restrict__ dout,
+                                                          float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl) {
+    switch (blockIdx.y) {
+    case 0: cs_bwd_group<0>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 1: cs_bwd_group<1>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 2: cs_bwd_group<2>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 3: cs_bwd_group<3>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 4: cs_bwd_group<4>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 5: cs_bwd_group<5>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    default: cs_bwd_group<6>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    }
+}
+
+// dpat[key[r]] += dout[r] for the rows with key >= 0.  Many rows share a pattern (most lists are empty for most of a game), so
+// plain atomics would pile up on a few addresses: the lanes of a wave that hold the same pattern are added up with shuffles
+// first (one pass per distinct pattern in the wave) and only the first of them issues the 16 atomics.
+__global__ __launch_bounds__(256) void k_card_pattern_sum(const int* __restrict__ keys, const float* __restrict__ dout, float* __restrict__ dpat, long rows) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int key = r < rows ? keys[r] : -1;
+    float v[CS_D];
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) v[i] = 0.f;
+    if (key >= 0) {
+        const float4* d4 = reinterpret_cast<const float4*>(dout + r * CS_D);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 q = d4[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+    }
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, first);
+        const bool mine = key == k0;
+        todo &= ~__ballot(mine);
+#pragma unroll
+        for (int i = 0; i < CS_D; i++) {
+            float x = mine ? v[i] : 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == first) atomicAdd(&dpat[(long)k0 * CS_D + i], x);
+        }
+    }
+}
+
 }  // namespace catan

@@ -221,6 +221,70 @@ def lstm_cell(gx, gh, c_prev, mask=None):
     return _LSTMCell.apply(gx, gh, c_prev, None if mask is None else mask.float().reshape(-1))
 
 
+_PATTERN_LISTS = {}
+
+
+def _pattern_lists(device):
+    """the synthetic list of every count pattern (include/catan_hip.h): ids int8 [P, 25] and lens int32 [P]"""
+    if device not in _PATTERN_LISTS:
+        P = _lib.lib().catan_card_summary_patterns()
+        k = torch.arange(P)
+        counts = torch.stack((k % 2, k // 2 % 15, k // 30 % 6, k // 180 % 3, k // 540 % 3, k // 1620), 1)      # [P, 6]
+        lens = counts.sum(1).clamp(max=25)                       # (patterns with more than 25 cards cannot occur; their dout is zero)
+        ids = torch.repeat_interleave(torch.arange(6).repeat(P), counts.reshape(-1)).split(counts.sum(1).tolist())
+        rows = torch.zeros((P, 25), dtype=torch.int8)
+        for i, r in enumerate(ids):
+            rows[i, :min(25, r.numel())] = r[:25].to(torch.int8)
+        _PATTERN_LISTS[device] = (rows.to(device), lens.to(device=device, dtype=torch.int32))
+    return _PATTERN_LISTS[device]
+
+
+class _CardSummary(torch.autograd.Function):
+    """k_card_summary_fwd / _bwd (csrc/catan_nn.hip): the dev-card list module evaluated per card class from small tables.
+    Backward: the gradient of the tables is linear in dout and a list's Jacobian depends only on its count PATTERN (4 860
+    possible ones), so dout is summed per pattern and the 4 860 synthetic lists are differentiated; lists whose counts fall
+    outside the deck (key -1) go through the kernel directly."""
+
+    @staticmethod
+    def forward(ctx, ids, lens, params, eps):
+        rows = ids.shape[0]
+        out = torch.empty((rows, 16), dtype=torch.float32, device=ids.device)
+        keys = torch.empty((rows,), dtype=torch.int32, device=ids.device)
+        p = params.detach().contiguous()
+        _lib.check(_lib.lib().catan_card_summary_fwd(_ptr(ids), ids.element_size(), ids.stride(0), _ptr(lens), _ptr(p), float(eps), _ptr(out), _ptr(keys),
+                                                     rows, _stream()))
+        ctx.save_for_backward(ids, lens, p, keys)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, lens, p, keys = ctx.saved_tensors
+        L = _lib.lib()
+        dparams = torch.zeros_like(p)
+        d = dout.contiguous().float()
+        pid, plen = _pattern_lists(ids.device)
+        dpat = torch.zeros((pid.shape[0], 16), dtype=torch.float32, device=ids.device)
+        _lib.check(L.catan_card_pattern_sum(_ptr(keys), _ptr(d), _ptr(dpat), ids.shape[0], _stream()))
+        _lib.check(L.catan_card_summary_bwd(_ptr(pid), 1, pid.stride(0), _ptr(plen), _ptr(p), ctx.eps, _ptr(dpat), _ptr(dparams), None, pid.shape[0], _stream()))
+        _lib.check(L.catan_card_summary_bwd(_ptr(ids), ids.element_size(), ids.stride(0), _ptr(lens), _ptr(p), ctx.eps, _ptr(d), _ptr(dparams), _ptr(keys),
+                                            ids.shape[0], _stream()))
+        return None, None, dparams, None
+
+
+def card_summary_supported(ids, vocab, heads, hd, width):
+    return ids.is_cuda and ids.dim() == 2 and ids.shape[1] <= 25 and (vocab, heads, hd, width) == (6, 4, 4, 16) \
+        and ids.dtype in (torch.int8, torch.int32, torch.int64)
+
+
+def card_summary(ids, lens, params, eps):
+    """ids [rows, L<=25] integer (any row pitch), lens [rows], params float32 [544] (S, V, W, bias, LayerNorm weight / bias:
+    include/catan_hip.h) -> float32 [rows, 16]; gradient w.r.t. params."""
+    if ids.stride(1) != 1:
+        ids = ids.contiguous()
+    return _CardSummary.apply(ids, lens.to(torch.int32).contiguous(), params, eps)
+
+
 class _MaskedCategorical(torch.autograd.Function):
     """csrc/catan_nn.hip k_categorical_fwd / _bwd: one launch for log_softmax(logits + log(mask)), the action (given /
     arg-max / inverse-CDF sample), its log-prob and the entropy."""

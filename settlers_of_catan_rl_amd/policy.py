@@ -131,13 +131,31 @@ class _TileEncoder(nn.Module):
 
 
 def _card_summary(ids, lens, embedding, mha, norm):
-    """masked attention over a padded card-id list, zero the padding, sum (player_modules.py:55-69)."""
-    L = ids.shape[1]
-    valid = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
-    # 6-row embedding as a one-hot matmul: its backward is a GEMM instead of a 6-way atomic scatter
-    emb = _lin(F.one_hot(ids, embedding.num_embeddings).to(embedding.weight.dtype), embedding.weight.t())
-    rep = _ln(norm, mha(emb, lens))
-    return (rep * valid[..., None].to(rep.dtype)).sum(1)
+    """Masked attention over a padded card-id list, zero the padding, sum (player_modules.py:55-69) - computed per card
+    CLASS instead of per token.  A list holds at most 6 distinct ids, and everything the reference computes per token
+    (embedding, Q/K/V, attention output, out-projection, LayerNorm) depends only on the token's id and on how many valid
+    tokens of each id the list has: softmax over keys j of s(id_i, id_j) equals softmax over classes b of
+    s(id_i, b) + log(count_b), so the whole module is a function of the six counts.  Same value as the per-token form
+    (it merges identical terms of the same sums).  On the GPU it is one fused kernel per list (nn_kernels.card_summary) fed
+    with the 4 x 6 x 6 score table and the six value vectors; elsewhere the same algebra in torch ops."""
+    B, L = ids.shape
+    V, H, hd = embedding.num_embeddings, mha.heads, mha.hd
+    with torch.autocast(device_type=ids.device.type, enabled=False):          # a few hundred flops per row: keep them fp32
+        w = torch.cat([n.weight for n in mha.qkv_nets], 0).float()
+        b = torch.cat([n.bias for n in mha.qkv_nets], 0).float()
+        qkv = F.linear(embedding.weight.float(), w, b).view(V, 3, H, hd)      # Q / K / V of each of the six ids
+        s_ab = torch.einsum("ahd,bhd->hab", qkv[:, 0], qkv[:, 1]) * (1.0 / math.sqrt(hd))
+        if nn_kernels.card_summary_supported(ids, V, H, hd, H * hd):           # GPU: one fused kernel, 26 B in / 64 B out per list
+            params = torch.cat((s_ab.reshape(-1), qkv[:, 2].reshape(-1), mha.out_proj_net.weight.float().reshape(-1),
+                                mha.out_proj_net.bias.float(), norm.weight.float(), norm.bias.float()))
+            return nn_kernels.card_summary(ids, lens, params, norm.eps)
+        valid = (torch.arange(L, device=ids.device)[None, :] < lens[:, None]).float()
+        cnt = torch.zeros((B, V), dtype=torch.float32, device=ids.device).scatter_add_(1, ids.long(), valid)     # valid tokens per id
+        p = torch.softmax(s_ab[None] + torch.log(cnt)[:, None, None, :], -1)  # [B, H, 6, 6]; absent classes: log 0 = -inf
+        attn = torch.einsum("rhab,bhd->rahd", p, qkv[:, 2]).reshape(B, V, H * hd)
+        rep = F.layer_norm(F.linear(attn, mha.out_proj_net.weight.float(), mha.out_proj_net.bias.float()), norm.normalized_shape,
+                           norm.weight.float(), norm.bias.float(), norm.eps)
+        return (rep * cnt[..., None]).sum(1)
 
 
 class _CurrentPlayer(nn.Module):
@@ -194,7 +212,6 @@ class _ObservationModule(nn.Module):
         B = obs_f.shape[0]
         tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
         cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
-        lists = lists.long()
         parts = [self.tile_encoder(tiles),
                  self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
                                             self.hidden_card_mha, self.played_card_mha)]

@@ -405,3 +405,50 @@ def test_inference_copy_acts_like_the_master_under_autocast(hip_lib):
                 for p in net.parameters():
                     p.add_(0.01 * torch.randn_like(p))
             inf.load_from(net)
+
+
+def test_card_summary_kernel_vs_torch_formulation(hip_lib):
+    """k_card_summary_fwd / _bwd (the dev-card list module per card class, one lane per list) against the same algebra in torch
+    ops, which the CPU tests pin to the reference net: outputs and the gradients of every parameter it touches."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels
+    from settlers_of_catan_rl_amd.policy import CatanPolicy, _card_summary
+    torch.manual_seed(0)
+    net = CatanPolicy().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    om = net.observation_module
+    B = 5000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    lens = torch.randint(1, 26, (B,), device="cuda", generator=g)
+    lens[:700] = 1
+    ids_full = torch.randint(1, 6, (B, 5, 25), device="cuda", generator=g).to(torch.int8)
+    ids_full[:700, :, 0] = 0                                         # empty lists: the reference's [0]
+    ids_full = ids_full * (torch.arange(25, device="cuda")[None, None, :] < lens[:, None, None]).to(torch.int8)
+    w = torch.randn(B, 16, device="cuda", generator=g)
+    params = [om.dev_card_embedding.weight] + list(om.played_card_mha.parameters()) + list(om.current_player_module.norm.parameters())
+    res = {}
+    for use_kernel in (True, False):
+        saved = nn_kernels.card_summary_supported
+        if not use_kernel:
+            nn_kernels.card_summary_supported = lambda *a: False
+        try:
+            deck = torch.tensor([1] * 14 + [2] * 5 + [3] * 2 + [4] * 2 + [5] * 2, device="cuda")
+            real = deck[torch.rand(B, 25, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).argsort(1)]
+            real = (real * (torch.arange(25, device="cuda")[None] < lens[:, None])).to(torch.int8)
+            real[:700] = 0                                                                       # (empty lists: id 0, length 1)
+            # strided int8, int64, int32 with arbitrary counts (beyond the deck: the direct backward), and deck-bounded lists
+            # (the per-pattern backward)
+            for ids in (ids_full[:, 2], ids_full[:, 1].long().contiguous(), ids_full[:, 3].to(torch.int32), real):
+                for p in params:
+                    p.grad = None
+                out = _card_summary(ids, lens, om.dev_card_embedding, om.played_card_mha, om.current_player_module.norm)
+                (out * w).sum().backward()
+                res.setdefault(use_kernel, []).append((out.detach().clone(), [p.grad.clone() for p in params]))
+        finally:
+            nn_kernels.card_summary_supported = saved
+    for (o1, g1), (o2, g2) in zip(res[True], res[False]):
+        assert o1.shape == (B, 16) and torch.allclose(o1, o2, atol=2e-5, rtol=1e-5), float((o1 - o2).abs().max())
+        for a, b in zip(g1, g2):
+            assert float((a - b).abs().max()) <= 3e-4 * max(1.0, float(b.abs().max())), float((a - b).abs().max())   # fp32 sums in another order
