@@ -156,10 +156,13 @@ int catan_adv_normalise(float* adv, int64_t total, const double* stats3, catan_s
 
 /* PPO.update loss: RL/ppo/ppo.py:46-48 (value normaliser, when use_norm) and :54-66.  All arrays float32 [B] on device.
  * losses2 = (action_loss, value_loss); d_logp, d_values = gradient of value_coef*value_loss + action_loss w.r.t.
- * action_log_probs and values (the entropy term stays in the network's autograd graph). */
+ * action_log_probs and values (the entropy term stays in the network's autograd graph).  workspace: device double
+ * [catan_ppo_loss_workspace_doubles()], ZERO before the first call and left zero by every call (per-workgroup partial sums
+ * and an arrival counter: the kernel runs on up to 256 workgroups and adds the partial sums up in a fixed order). */
+int64_t catan_ppo_loss_workspace_doubles(void);
 int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, const float* values, const float* old_values,
                    const float* returns, int64_t B, float clip, float value_coef, int use_norm, float norm_mean, float norm_std,
-                   float* losses2, float* d_logp, float* d_values, catan_stream_t stream);
+                   float* losses2, float* d_logp, float* d_values, double* workspace, catan_stream_t stream);
 
 /* Fused small-sequence multi-head attention of the policy net (RL/models/multi_headed_attention.py:25-54 as used by
  * tile_encoder.py:41-60 with L=19, 4 heads x 16 and by player_modules.py:55-69 with L<=25, 4 heads x 4).

@@ -70,7 +70,8 @@ _SIGS = {
     "catan_gae_workspace_doubles": (C.c_int64, [C.c_int64]),
     "catan_gae": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "catan_adv_normalise": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
-    "catan_ppo_loss": (C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "catan_ppo_loss_workspace_doubles": (C.c_int64, []),
+    "catan_ppo_loss": (C.c_int, [_vp] * 6 + [C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "catan_attention_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "catan_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "catan_layer_norm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int, _vp]),

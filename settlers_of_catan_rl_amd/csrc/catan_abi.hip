@@ -705,13 +705,18 @@ int catan_adv_normalise(float* adv, int64_t total, const double* stats3, catan_s
     return CATAN_OK;
 }
 
+int64_t catan_ppo_loss_workspace_doubles(void) { return 2 * PPO_BLOCKS + 1; }
+
 int catan_ppo_loss(const float* logp, const float* old_logp, const float* adv, const float* values, const float* old_values,
                    const float* returns, int64_t B, float clip, float value_coef, int use_norm, float norm_mean, float norm_std,
-                   float* losses2, float* d_logp, float* d_values, catan_stream_t stream) {
-    if (!logp || !old_logp || !adv || !values || !old_values || !returns || !losses2 || !d_logp || !d_values || B <= 0)
+                   float* losses2, float* d_logp, float* d_values, double* workspace, catan_stream_t stream) {
+    if (!logp || !old_logp || !adv || !values || !old_values || !returns || !losses2 || !d_logp || !d_values || !workspace || B <= 0)
         return fail(CATAN_EINVAL, "catan_ppo_loss: bad arguments");
     PpoArgs a{ clip, value_coef, norm_mean, norm_std, use_norm };
-    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, S(stream), logp, old_logp, adv, values, old_values, returns, (long)B, a, losses2, d_logp, d_values);
+    long nb = (B + PPO_THREADS * 4 - 1) / (PPO_THREADS * 4);
+    if (nb > PPO_BLOCKS) nb = PPO_BLOCKS;
+    hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)nb), dim3(PPO_THREADS), 0, S(stream), logp, old_logp, adv, values, old_values, returns, (long)B, a, losses2, d_logp,
+                       d_values, workspace);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -70,18 +70,23 @@ __global__ __launch_bounds__(GAE_BLOCK) void k_adv_normalise(float* __restrict__
 }
 
 struct PpoArgs { float clip, value_coef, norm_mean, norm_std; int use_norm; };
-// One workgroup, grid-stride over B (B = T*N/num_mini_batch, 2 000 .. ~2*10^5): losses[0] = action loss,
-// losses[1] = value loss (means); d_logp / d_values = gradient of value_coef * L_v + L_pi (upstream gradient 1).
-__global__ __launch_bounds__(1024) void k_ppo_loss(const float* __restrict__ logp, const float* __restrict__ old_logp,
-                                                   const float* __restrict__ adv, const float* __restrict__ values,
-                                                   const float* __restrict__ old_values, const float* __restrict__ returns,
-                                                   long B, PpoArgs a, float* __restrict__ losses,
-                                                   float* __restrict__ d_logp, float* __restrict__ d_values) {
-    __shared__ double sh[2][1024];
+// losses[0] = action loss, losses[1] = value loss (means over B = T*N/num_mini_batch rows, 2 000 .. ~2*10^5);
+// d_logp / d_values = gradient of value_coef * L_v + L_pi (upstream gradient 1).  PPO_BLOCKS workgroups stream their share of
+// the rows (24 B read + 8 B written per row); the per-workgroup fp64 partial sums go to `ws` and the workgroup that arrives
+// last adds them up in index order, so the result does not depend on the schedule (ws: 2 * PPO_BLOCKS + 1 doubles, the last
+// one the arrival counter - zero before the first call, left zero by every call).
+constexpr int PPO_BLOCKS = 256, PPO_THREADS = 256;
+__global__ __launch_bounds__(PPO_THREADS) void k_ppo_loss(const float* __restrict__ logp, const float* __restrict__ old_logp,
+                                                          const float* __restrict__ adv, const float* __restrict__ values,
+                                                          const float* __restrict__ old_values, const float* __restrict__ returns,
+                                                          long B, PpoArgs a, float* __restrict__ losses,
+                                                          float* __restrict__ d_logp, float* __restrict__ d_values, double* __restrict__ ws) {
+    __shared__ double sh[2][PPO_THREADS];
+    __shared__ bool last;
     double la = 0.0, lv = 0.0;
     const float invB = 1.0f / (float)B;
     const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
-    for (long i = threadIdx.x; i < B; i += 1024) {
+    for (long i = (long)blockIdx.x * PPO_THREADS + threadIdx.x; i < B; i += (long)gridDim.x * PPO_THREADS) {
         float vp = old_values[i], ret = returns[i];
         if (a.use_norm) { vp = (vp - a.norm_mean) / (a.norm_std + 1e-4f); ret = (ret - a.norm_mean) / (a.norm_std + 1e-4f); }   // ppo.py:46-48
         const float ratio = expf(logp[i] - old_logp[i]);                    // ppo.py:54
@@ -103,11 +108,27 @@ __global__ __launch_bounds__(1024) void k_ppo_loss(const float* __restrict__ log
     }
     sh[0][threadIdx.x] = la; sh[1][threadIdx.x] = lv;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = PPO_THREADS / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { losses[0] = (float)(sh[0][0] / (double)B); losses[1] = (float)(sh[1][0] / (double)B); }
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x] = sh[0][0]; ws[PPO_BLOCKS + blockIdx.x] = sh[1][0];
+        __threadfence();
+        unsigned long long* counter = reinterpret_cast<unsigned long long*>(ws + 2 * PPO_BLOCKS);
+        last = atomicAdd(counter, 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double sa = 0.0, sv = 0.0;
+        for (unsigned k = 0; k < gridDim.x; k++) {             // (device-scope loads: the other workgroups' partial sums)
+            sa += __hip_atomic_load(&ws[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sv += __hip_atomic_load(&ws[PPO_BLOCKS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        losses[0] = (float)(sa / (double)B); losses[1] = (float)(sv / (double)B);
+        *reinterpret_cast<unsigned long long*>(ws + 2 * PPO_BLOCKS) = 0ull;
+    }
 }
 
 }  // namespace catan

@@ -306,80 +306,77 @@ class _ActionHeads(nn.Module):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
         typ, card = actions[:, 0], actions[:, 4]
         pre_of = lambda i, x: F.linear(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
-        _, logp, e0 = _categorical(H[0].logits(pre_of(0, main)), m[:, MO[0]:MO[0] + 13], typ, False, None)
-        out = actions.clone()
-        ent_sum = e0.sum()
+        _, logp0, e0 = _categorical(H[0].logits(pre_of(0, main)), m[:, MO[0]:MO[0] + 13], typ, False, None)
         # one sort by (type, card of a played development card) and one host read give every head's rows
         key = typ * 8 + torch.where(typ == T_PLAYDEV, card.clamp(0, 7), torch.zeros_like(card))
         perm = torch.argsort(key, stable=True)
         ends = torch.cumsum(torch.bincount(key, minlength=13 * 8), 0).tolist()
         rng = lambda k: perm[(ends[k - 1] if k else 0):ends[k]]
         of_type = lambda t: perm[(ends[8 * t - 1] if t else 0):ends[8 * t + 7]]
-
-        def add(rows, lp, ent):
-            nonlocal logp, ent_sum
-            logp = logp.index_add(0, rows, lp)
-            ent_sum = ent_sum + ent.sum()
-
-        def simple(i, rows, lo, width, col, extra=None, custom=None):
-            if rows.numel() == 0:
-                return
-            _, lp, ent = _categorical(H[i].logits(pre_of(i, main[rows]), extra, custom), m[rows, lo:lo + width], actions[rows, col], False, None)
-            add(rows, lp, ent)
-
-        # head 1: corner (settlement / city), its mask row picked by the type (build_agent_model.py:113-115)
-        rs, rc = of_type(T_SETTLE), of_type(T_CITY)
-        rows = torch.cat((rs, rc))
-        if rows.numel():
-            x = torch.zeros(rows.numel(), 2, device=dev); x[:rs.numel(), 0] = 1.0; x[rs.numel():, 1] = 1.0
-            mrow = torch.cat((m[rs, MO[1]:MO[1] + 54], m[rc, MO[1] + 54:MO[1] + 108]))
-            _, lp, ent = _categorical(H[1].logits(pre_of(1, main[rows]), x), mrow, actions[rows, 1], False, None)
-            add(rows, lp, ent)
-        simple(2, of_type(T_ROAD), MO[2], 73, 2)
-        simple(3, of_type(T_ROBBER), MO[3], 19, 3)
-        rows = of_type(T_PLAYDEV)
-        simple(4, rows, MO[4], 5, 4)
-        rows = of_type(T_RESPOND)
-        simple(5, rows, MO[5], 2, 5, custom=trade[rows].to(main.dtype))
-        # head 6: relative player (propose: mask row 0, steal: row 1)
-        rp, rst = of_type(T_PROPOSE), of_type(T_STEAL)
-        rows = torch.cat((rp, rst))
-        if rows.numel():
-            x = torch.zeros(rows.numel(), 2, device=dev); x[:rp.numel(), 0] = 1.0; x[rp.numel():, 1] = 1.0
-            mrow = torch.cat((m[rp, MO[6]:MO[6] + 3], m[rst, MO[6] + 3:MO[6] + 6]))
-            _, lp, ent = _categorical(H[6].logits(pre_of(6, main[rows]), x), mrow, actions[rows, 6], False, None)
-            add(rows, lp, ent)
-        # heads 7 / 8: the recurrent give / receive lists of a proposed trade
-        if rp.numel():
-            mp, cr = main[rp], cur_res[rp]
-            give_out, _, lp7, e7 = self._recurrent(H[7], pre_of(7, mp), None, cr, True, actions[rp, 7:11], False, None)
-            add(rp, lp7, e7)
-            filt7 = (lp7 == 0).float()                                           # action_heads_module.py:175
-            _, _, lp8, e8 = self._recurrent(H[8], pre_of(8, mp), give_out * (1 - filt7)[:, None], cr, False, actions[rp, 11:15], False, None)
-            add(rp, lp8, e8)
-        # heads 9 / 10: resources of an exchange / a Year of Plenty or Monopoly card
+        rs, rc, rp, rst = of_type(T_SETTLE), of_type(T_CITY), of_type(T_PROPOSE), of_type(T_STEAL)
         rex, ryop, rmono = of_type(T_EXCHANGE), rng(8 * T_PLAYDEV + C_YOP), rng(8 * T_PLAYDEV + C_MONO)
-        for i, rows_c in ((9, (rex, ryop, rmono)), (10, (rex, ryop))):
-            rows = torch.cat(rows_c)
-            if rows.numel() == 0:
+        sets = {1: torch.cat((rs, rc)), 2: of_type(T_ROAD), 3: of_type(T_ROBBER), 4: of_type(T_PLAYDEV), 5: of_type(T_RESPOND),
+                6: torch.cat((rp, rst)), 7: rp, 9: torch.cat((rex, ryop, rmono)), 10: torch.cat((rex, ryop)), 11: of_type(T_DISCARD)}
+        # ONE gather of the trunk rows (and of the mask / action rows) for all heads: its backward is one scatter-add
+        order = [i for i in sets if sets[i].numel()]
+        if not order:
+            return actions.clone(), logp0, e0.sum() / B
+        all_rows = torch.cat([sets[i] for i in order])
+        mg, mm_g, ag = main[all_rows], m[all_rows], actions[all_rows]
+        at, off = {}, 0
+        for i in order:
+            at[i] = slice(off, off + sets[i].numel()); off += sets[i].numel()
+        lps, ents = [], []                                   # (slice, log-probs) per head; entropies
+
+        def run(i, sl, mask, col, extra=None, custom=None):
+            _, lp, ent = _categorical(H[i].logits(pre_of(i, mg[sl]), extra, custom), mask, ag[sl, col], False, None)
+            lps.append((sl, lp)); ents.append(ent.sum())
+
+        def two_hot(n_first, n):
+            x = torch.zeros(n, 2, device=dev); x[:n_first, 0] = 1.0; x[n_first:, 1] = 1.0
+            return x
+
+        if 1 in at:        # corner (settlement / city), its mask row picked by the type (build_agent_model.py:113-115)
+            sl, n1 = at[1], rs.numel()
+            mk = mm_g[sl, MO[1]:MO[1] + 108]
+            run(1, sl, torch.cat((mk[:n1, :54], mk[n1:, 54:])), 1, two_hot(n1, mk.shape[0]))
+        for i, (lo, w, col) in {2: (MO[2], 73, 2), 3: (MO[3], 19, 3), 4: (MO[4], 5, 4), 11: (MO[11], 5, 17)}.items():
+            if i in at:
+                run(i, at[i], mm_g[at[i], lo:lo + w], col)
+        if 5 in at:
+            run(5, at[5], mm_g[at[5], MO[5]:MO[5] + 2], 5, custom=trade[sets[5]].to(main.dtype))
+        if 6 in at:        # relative player (propose: mask row 0, steal: row 1)
+            sl, n1 = at[6], rp.numel()
+            mk = mm_g[sl, MO[6]:MO[6] + 6]
+            run(6, sl, torch.cat((mk[:n1, :3], mk[n1:, 3:])), 6, two_hot(n1, mk.shape[0]))
+        if 7 in at:        # the recurrent give / receive lists of a proposed trade
+            sl, cr = at[7], cur_res[rp]
+            give_out, _, lp7, e7 = self._recurrent(H[7], pre_of(7, mg[sl]), None, cr, True, ag[sl, 7:11], False, None)
+            filt7 = (lp7 == 0).float()                                           # action_heads_module.py:175
+            _, _, lp8, e8 = self._recurrent(H[8], pre_of(8, mg[sl]), give_out * (1 - filt7)[:, None], cr, False, ag[sl, 11:15], False, None)
+            lps.append((sl, lp7 + lp8)); ents.append(e7.sum() + e8.sum())
+        n_ex, n_yop = rex.numel(), ryop.numel()
+        for i in (9, 10):  # resources of an exchange / a Year of Plenty or Monopoly card
+            if i not in at:
                 continue
-            n_ex, n_yop = rex.numel(), ryop.numel()
-            x = torch.zeros(rows.numel(), 4, device=dev)
+            sl = at[i]
+            n = sets[i].numel()
+            x = torch.zeros(n, 4, device=dev)
             x[:n_ex, 1] = 1.0; x[n_ex:, 0] = 1.0                                  # (play dev, exchange)
             x[n_ex:n_ex + n_yop, 2] = 1.0                                         # (card is YoP, card is Monopoly)
             if i == 9:
                 x[n_ex + n_yop:, 3] = 1.0
-                m9 = m[rows, MO[9]:MO[9] + 20].reshape(-1, 4, 5)
+                m9 = mm_g[sl, MO[9]:MO[9] + 20].reshape(-1, 4, 5)
                 # exchange: row 0; a card: row 1 (all ones in the env's masks) x the card's row (Monopoly 2, YoP 3)
-                mrow = torch.cat((m9[:n_ex, 0], m9[n_ex:n_ex + n_yop, 1] * m9[n_ex:n_ex + n_yop, 3], m9[n_ex + n_yop:, 1] * m9[n_ex + n_yop:, 2]))
-                col = 15
+                mask = torch.cat((m9[:n_ex, 0], m9[n_ex:n_ex + n_yop, 1] * m9[n_ex:n_ex + n_yop, 3], m9[n_ex + n_yop:, 1] * m9[n_ex + n_yop:, 2]))
+                run(9, sl, mask, 15, x)
             else:
-                x = torch.cat((x, F.one_hot(actions[rows, 15], 5).float()), -1)
-                mrow, col = m[rows, MO[10]:MO[10] + 5], 16
-            _, lp, ent = _categorical(H[i].logits(pre_of(i, main[rows]), x), mrow, actions[rows, col], False, None)
-            add(rows, lp, ent)
-        simple(11, of_type(T_DISCARD), MO[11], 5, 17)
-        return out, logp, ent_sum / B
+                run(10, sl, mm_g[sl, MO[10]:MO[10] + 5], 16, torch.cat((x, F.one_hot(ag[sl, 15], 5).float()), -1))
+        lp_all = torch.zeros(all_rows.numel(), device=dev)
+        for sl, lp in lps:
+            lp_all[sl] = lp
+        logp = logp0.index_add(0, all_rows, lp_all)
+        return actions.clone(), logp, (e0.sum() + torch.stack(ents).sum()) / B
 
     def _recurrent(self, head, pre, fixed, cur_res, from_hand, acts, deterministic, generator):
         """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask.
@@ -597,8 +594,11 @@ class CatanPolicy(nn.Module):
         import copy
         c = copy.deepcopy(self).eval().requires_grad_(False)
         c._inference_dtype = dtype
-        for mod in c.modules():
-            if isinstance(mod, (nn.Linear, nn.Embedding)):
+        # (the dev-card list modules - the 6-row embedding and the two 16-wide attentions - are evaluated in fp32 from
+        # small tables whatever the autocast dtype, _card_summary: their parameters stay fp32)
+        fp32_prefixes = ("observation_module.dev_card_embedding", "observation_module.hidden_card_mha", "observation_module.played_card_mha")
+        for name, mod in c.named_modules():
+            if isinstance(mod, (nn.Linear, nn.Embedding)) and not name.startswith(fp32_prefixes):
                 mod.to(dtype)
             elif isinstance(mod, nn.LSTM):         # its two bias vectors are added in fp32 before the cast (_forward_lstm)
                 for name, prm in mod.named_parameters():

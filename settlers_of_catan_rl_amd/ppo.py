@@ -56,6 +56,17 @@ def compute_gae(rewards, values, masks, gamma=0.999, gae_lambda=0.95, process_gr
     return returns, adv
 
 
+_LOSS_WS = {}
+
+
+def _loss_workspace(device):
+    """zeroed once; every k_ppo_loss call leaves it zero (include/catan_hip.h)"""
+    key = (device.type, device.index)
+    if key not in _LOSS_WS:
+        _LOSS_WS[key] = torch.zeros((_lib.lib().catan_ppo_loss_workspace_doubles(),), dtype=torch.float64, device=device)
+    return _LOSS_WS[key]
+
+
 class _PpoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, values, old_logp, adv, old_values, returns, clip, value_coef, norm):
@@ -67,7 +78,7 @@ class _PpoLoss(torch.autograd.Function):
         d_values = torch.empty((B,), dtype=torch.float32, device=logp.device)
         use_norm, mean, std = (0, 0.0, 1.0) if norm is None else (1, float(norm[0]), float(norm[1]))
         _lib.check(L.catan_ppo_loss(*[_ptr(x) for x in args], B, float(clip), float(value_coef), use_norm, mean, std,
-                                    _ptr(losses), _ptr(d_logp), _ptr(d_values), _stream()))
+                                    _ptr(losses), _ptr(d_logp), _ptr(d_values), _ptr(_loss_workspace(logp.device)), _stream()))
         ctx.save_for_backward(d_logp, d_values)
         ctx.shapes = (logp.shape, values.shape)
         total = losses[1] * value_coef + losses[0]
