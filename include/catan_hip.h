@@ -125,11 +125,10 @@ int catan_slow_path_counts(catan_env_t* env, catan_stream_t stream, uint64_t* ou
 /* tier-2 longest-road search: iterations per bulk-synchronous round (work is re-shared between rounds): lock-step / deferred */
 int catan_set_lr_rounds(catan_env_t* env, int32_t lockstep, int32_t deferred);
 
-/* the rollout loops with a hipEvent around every kernel launch (recorded on `stream`); window <= 0: the lock-step
- * loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST
- * float[7] receiving the summed milliseconds of k_sample_random (which also sorts the games by action type), 0 (slot of
- * k_classify, the sort for caller-supplied actions: not launched by the rollout loops), k_step, k_lr_finish, k_lr_heavy,
- * 0 (slot of the former completion kernel; tier 2 completes its own games), k_reset_list / k_install_list (bench.py roofline). */
+/* the rollout loops with a hipEvent around every kernel launch (recorded on the stream the kernel runs on); window <= 0: the
+ * lock-step loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST
+ * float[5] receiving the summed milliseconds of k_sample_random (which also sorts the games by action type), k_step,
+ * k_lr_finish, k_lr_heavy, k_reset_list / k_install_list (bench.py roofline). */
 int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms);
 
 /* EnvWrapper._get_obs(): env/wrapper.py:52-83 (+ _get_tile_features :491-524, _get_player_inputs :526-709), batched.
@@ -247,8 +246,10 @@ int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const i
                            int32_t* keys, int64_t rows, catan_stream_t stream);
 int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
                            float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream);
-/* dpat[keys[r]][0..15] += dout[r][0..15] for the rows with keys[r] >= 0 (dpat: float [catan_card_summary_patterns()][16]) */
-int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int64_t rows, catan_stream_t stream);
+/* dpat[c][keys[r]][0..15] += dout[r][0..15] for the rows with keys[r] >= 0; dpat: float [replicas][catan_card_summary_patterns()][16],
+ * zero before the call: copy c takes the rows of the workgroups b with b % replicas == c (the caller sums the copies) - a
+ * handful of patterns covers most lists, and one copy would serialise the atomics of the whole grid on a few cache lines */
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int64_t rows, catan_stream_t stream);
 
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */

@@ -29,13 +29,17 @@ def _sources():
 def build_library(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (it travels with the repo snapshot)."""
     srcs = _sources()
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
-        return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        if verbose:
+            print(f"libcatan_hip.so is newer than its {len(srcs)} sources: not recompiled (command: {' '.join(cmd)})")
+        return LIB_PATH
     if verbose:
-        print(" ".join(cmd))
+        print("compiling: " + " ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    if verbose:
+        print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH)} bytes)")
     return LIB_PATH
 
 
@@ -95,7 +99,7 @@ _SIGS = {
     "catan_calib_copy": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_params": (C.c_int32, []),
     "catan_card_summary_patterns": (C.c_int32, []),
-    "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
     "catan_card_summary_fwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_bwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_randomise_uncertainty": (C.c_int, [_vp, _vp, _vp]),

@@ -624,10 +624,10 @@ int catan_set_lr_rounds(catan_env_t* e, int32_t lockstep, int32_t deferred) {
 }
 
 // The rollout loops with a hipEvent around every kernel launch (recorded on the stream the kernel runs on).
-// window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host, float[7])
+// window <= 0: the lock-step loop of catan_random_rollout; window > 0: the deferred loop.  kernel_ms (host, float[5])
 // receives the summed elapsed milliseconds of:
-// [0] k_sample_random (incl. the sort by action type)  [1] 0 (k_classify only runs for caller-supplied actions)  [2] k_step
-// [3] k_lr_finish  [4] k_lr_heavy (incl. the completion of its games)  [5] 0 (slot of the former k_step_finish)  [6] re-deals / installs.
+// [0] k_sample_random (incl. the sort by action type)  [1] k_step  [2] k_lr_finish  [3] k_lr_heavy (incl. the completion of
+// its games)  [4] re-deals / installs (k_reset_list, k_install_list).
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
     hipStream_t st = S(stream);
@@ -651,17 +651,16 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipStreamSynchronize(e->fstream[0]));
     HIPCHK(hipStreamSynchronize(e->sstream));
-    for (int k = 0; k < 7; k++) kernel_ms[k] = 0.0f;
+    for (int k = 0; k < 5; k++) kernel_ms[k] = 0.0f;
     for (int64_t s = 0; s < steps; s++) {
         hipEvent_t* v = &ev[(size_t)s * K];
         float ms = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (sampling + sort lists)
-        HIPCHK(hipEventElapsedTime(&ms, v[0], v[2])); kernel_ms[2] += ms;      // k_step
-        HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[3] += ms;      // k_lr_finish
+        HIPCHK(hipEventElapsedTime(&ms, v[0], v[2])); kernel_ms[1] += ms;      // k_step
+        HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[2] += ms;      // k_lr_finish
         if (!slow[s]) continue;
-        HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[4] += ms;      // k_lr_heavy
-        HIPCHK(hipEventElapsedTime(&ms, v[3], v[7])); kernel_ms[5] += ms;      // (nothing is launched here any more)
-        HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[6] += ms;      // k_reset_list (wait for the side stream + second pass)
+        HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[3] += ms;      // k_lr_heavy
+        HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[4] += ms;      // k_reset_list / k_install_list (wait for the side stream + second pass)
     }
     for (auto& x : ev) hipEventDestroy(x);
     return CATAN_OK;
@@ -865,9 +864,9 @@ int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const i
     return CATAN_OK;
 }
 int32_t catan_card_summary_patterns(void) { return CS_PATTERNS; }
-int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int64_t rows, catan_stream_t stream) {
-    if (!keys || !dout || !dpat || rows <= 0) return fail(CATAN_EINVAL, "catan_card_pattern_sum: bad arguments");
-    hipLaunchKernelGGL(k_card_pattern_sum, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), keys, dout, dpat, (long)rows);
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int64_t rows, catan_stream_t stream) {
+    if (!keys || !dout || !dpat || rows <= 0 || replicas < 1) return fail(CATAN_EINVAL, "catan_card_pattern_sum: bad arguments");
+    hipLaunchKernelGGL(k_card_pattern_sum, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), keys, dout, dpat, (long)rows, replicas);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1173,7 +1173,11 @@ __global__ __launch_bounds__(256) void k_card_summary_bwd(const void* __restrict
 // dpat[key[r]] += dout[r] for the rows with key >= 0.  Many rows share a pattern (most lists are empty for most of a game), so
 // plain atomics would pile up on a few addresses: the lanes of a wave that hold the same pattern are added up with shuffles
 // first (one pass per distinct pattern in the wave) and only the first of them issues the 16 atomics.
-__global__ __launch_bounds__(256) void k_card_pattern_sum(const int* __restrict__ keys, const float* __restrict__ dout, float* __restrict__ dpat, long rows) {
+// dpat holds `replicas` copies of the table ([replicas][CS_PATTERNS][16], summed by the caller): workgroup b adds to copy
+// b % replicas - the few patterns nearly every list has would otherwise serialise thousands of atomics on one cache line.
+__global__ __launch_bounds__(256) void k_card_pattern_sum(const int* __restrict__ keys, const float* __restrict__ dout, float* __restrict__ dpat, long rows,
+                                                          int replicas) {
+    dpat += (long)(blockIdx.x % replicas) * CS_PATTERNS * CS_D;
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int key = r < rows ? keys[r] : -1;

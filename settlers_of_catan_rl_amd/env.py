@@ -156,9 +156,9 @@ class VecCatanEnv(object):
 
     def random_rollout_timed(self, step_idx0, steps, window=0):
         """-> dict of summed per-kernel milliseconds (hipEvents on the launch stream); window > 0: the deferred loop."""
-        ms = (C.c_float * 7)()
+        ms = (C.c_float * 5)()
         _lib.check(self.L.catan_random_rollout_timed(self.h, int(step_idx0), int(steps), int(window), _stream(), ms))
-        return dict(zip(("k_sample_random", "k_classify", "k_step", "k_lr_finish", "k_lr_heavy", "k_step_finish", "k_reset_list"), [float(x) for x in ms]))
+        return dict(zip(("k_sample_random", "k_step", "k_lr_finish", "k_lr_heavy", "k_reset_list"), [float(x) for x in ms]))
 
     def export_state(self, env_idx=None):
         """-> int32 [cnt][736] canonical blobs (host-friendly orientation)."""

@@ -196,3 +196,24 @@ def test_estimate_bytes_above_127_take_the_fieldwise_path(oracle, hip_lib):
         done_steps += chunk
         _assert_blobs_equal(env.export_state().cpu().numpy(), o, f"state {done_steps - 600} steps after the edit")
     assert env.invalid_action_count() == 0
+
+
+def test_full_size_lockstep_sampled_parity(oracle, hip_lib):
+    """The lock-step schedule (catan_step / the learner's schedule) at BASELINE.json's full size: 65 536 games x 600 steps
+    with auto-reset, then blocks of games from the start, the middle and the end of the range replayed by the CPU oracle
+    (global game ids: the oracle batch starts at the block's first id): state blobs and masks bit-identical; no missed
+    speculation, no rejected action."""
+    n, steps, seed = 65536, 600, 41
+    env = _env(n, seed)
+    env.random_rollout(0, steps)
+    assert env.invalid_action_count() == 0 and env.missed_speculation_count() == 0
+    state, masks = env.export_state().cpu().numpy(), env.get_action_masks().cpu().numpy()
+    for first in (0, 31000, n - 96):
+        ob = oracle.OracleBatch(96, seed, env_id0=first)
+        want = ob.run_random(steps)
+        got = state[first:first + 96]
+        bad = np.flatnonzero((got != want).any(axis=1))
+        assert len(bad) == 0, f"block at {first}: game {first + bad[0]}:\n" + spec.describe_state_diff(want[bad[0]], got[bad[0]])
+        assert np.array_equal(masks[first:first + 96], ob.masks())
+    t1, t2, launches = env.slow_path_counts()
+    assert launches == steps and 0 < t2 < t1 < n * steps

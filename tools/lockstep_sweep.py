@@ -14,4 +14,4 @@ for rnd in (2, 4, 8):
         env.random_rollout(step, 256); step += 256
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 256
         k = env.random_rollout_timed(step, 64, 0); step += 64
-        print(f"round {rnd} budget {budget:3d}: {dt * 1e6:6.1f} us per step; sample {k['k_sample_random'] / 64 * 1e3:.0f} step {k['k_step'] / 64 * 1e3:.0f} lr_finish {k['k_lr_finish'] / 64 * 1e3:.0f} heavy {k['k_lr_heavy'] / 64 * 1e3:.0f} install {k['k_step_finish'] / 64 * 1e3:.0f} reset {k['k_reset_list'] / 64 * 1e3:.0f}", flush=True)
+        print(f"round {rnd} budget {budget:3d}: {dt * 1e6:6.1f} us per step; sample {k['k_sample_random'] / 64 * 1e3:.0f} step {k['k_step'] / 64 * 1e3:.0f} lr_finish {k['k_lr_finish'] / 64 * 1e3:.0f} heavy {k['k_lr_heavy'] / 64 * 1e3:.0f} reset {k['k_reset_list'] / 64 * 1e3:.0f}", flush=True)

@@ -22,4 +22,4 @@ for budget in (12, 24, 48, 96, 192, 384, 768, 1536):
     kms = env.random_rollout_timed(0, 256, window)
     nslow = -(-256 // window)
     print(f"budget {budget:5d}: requests/iter {out[2*NP]/64:8.1f}  iterations/request {out[2*NP+1]/max(1,out[2*NP]):6.2f}  overflows/iter {out[2*NP+2]/64:7.2f}"
-          f" | k_lr_finish {kms['k_lr_finish']*1e3/256:7.1f} us  k_lr_heavy {kms['k_lr_heavy']*1e3/nslow:7.1f} us  finish {kms['k_step_finish']*1e3/nslow:6.1f}  reset {kms['k_reset_list']*1e3/nslow:6.1f}")
+          f" | k_lr_finish {kms['k_lr_finish']*1e3/256:7.1f} us  k_lr_heavy {kms['k_lr_heavy']*1e3/nslow:7.1f} us  reset {kms['k_reset_list']*1e3/nslow:6.1f}")
