@@ -14,9 +14,11 @@ Here R root games are searched at once.  Every piece keeps the reference's arith
                          `elif done` reward rule.
   * `gae_estimate`     - worker.gae, vectorised over simulations (the unused final value, the `len(values) <= 1` shortcut).
   * `UCBStats`         - _select_action / _update_stats / MovingAvgCalculator, vectorised over roots (host, float64).
-  * `ForwardSearch`    - the act() loop with a fixed simulation budget instead of a wall-clock one (the reference's own
-                         "deterministic testing" variant, policy.py:112): rounds of K simulations per root; inside a round
-                         simulations are allocated one after the other exactly as the reference hands them to free workers.
+  * `ForwardSearch`    - the act() loop in rounds of K simulations per root (inside a round simulations are allocated one
+                         after the other exactly as the reference hands them to free workers), with a fixed simulation
+                         budget (the reference's own "deterministic testing" variant, policy.py:112) or the reference's
+                         wall-clock budget per root (`max_thinking_time`, policy.py:91,111); LSTM policies carry every
+                         seat's (h, c) through proposals and simulations (policy.py:72-106, worker.py:61-95).
 State broadcast = catan_state_export / catan_state_import; every simulation gets its own Philox substream.
 """
 import math
@@ -90,8 +92,9 @@ class UCBStats(object):
         return np.argmax(score, axis=1)
 
     def start(self, action_id, sel=None):
-        rows = np.arange(self.R) if sel is None else sel
-        self.started_each[rows, action_id] += 1
+        """action_id: one id per root (all R); sel: the roots that really start the simulation"""
+        rows = np.arange(self.R) if sel is None else np.asarray(sel)
+        self.started_each[rows, np.asarray(action_id)[rows] if sel is not None else action_id] += 1
 
     def update(self, val, action_id, sel=None):
         """_update_stats + MovingAvgCalculator.update for one finished simulation per selected root."""
@@ -178,9 +181,12 @@ class GraphedAct(object):
 # ---------------------------------------------------------------------------------------------------- simulations
 @torch.no_grad()
 def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, deterministic=False, generator=None, autocast_dtype=None,
-             graphed=None):
+             graphed=None, hidden=None, init_hidden=None):
     """run_simulation_forward (worker.py:61-114) for all env.n simulations in lock-step.  env: dense-reward, no auto-reset,
     already holding the (randomised) start states; ctrl int [n] PlayerId of the searching player; init_actions [n,18].
+    LSTM policies (`include_lstm`): hidden [2, n, 4, L] = every seat's (h, c) at the start state (`curr_hidden_states`),
+    init_hidden [2, n, L] = the searching seat's state after it took the initial action (`init_player_hs`, worker.py:73); each
+    decision runs from the deciding seat's state and stores the new one (:84-95; the terminal mask is 1 throughout).
     -> float64 numpy [n] value estimates."""
     n, dev = env.n, env.device
     ar = torch.arange(n, device=dev)
@@ -201,6 +207,13 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
     agent_actions = torch.ones(n, dtype=torch.long, device=dev)
     active = ~first_done                                                                    # `if done: return actual_rewards[0]`
     finished = torch.zeros(n, dtype=torch.bool, device=dev)
+    rec = bool(getattr(policy, "include_lstm", False))
+    if rec:
+        L = int(policy.lstm_size)
+        hid = torch.zeros((2, n, 4, L), dtype=torch.float32, device=dev) if hidden is None else hidden.to(dev).float().clone()
+        if init_hidden is not None:
+            hid[:, ar, ctrl - 1] = init_hidden.to(dev).float()                              # worker.py:73
+        graphed = None
     while True:
         live = active & (agent_actions < D)                                                 # worker.py:81
         if not bool(live.any()):
@@ -212,13 +225,21 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
         idx = live.nonzero(as_tuple=True)[0]
         sub = idx.numel() < n
         args = (f[idx], lists[idx], lens[idx].long(), masks[idx]) if sub else (f, lists, lens.long(), masks)
+        kw = {}
+        if rec:
+            seat = players_go[idx] - 1
+            kw = {"hidden": (hid[0, idx, seat], hid[1, idx, seat]), "nonterminal": torch.ones(idx.numel(), device=dev)}
         if graphed is not None and sub:
             value_s, action_s = graphed(*args)                                             # small batch: hipGraph replay
         elif autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=autocast_dtype):
-                value_s, action_s, _ = policy.act(*args, deterministic=deterministic, generator=generator)
+                res = policy.act(*args, deterministic=deterministic, generator=generator, **kw)
+            value_s, action_s = res[0], res[1]
         else:
-            value_s, action_s, _ = policy.act(*args, deterministic=deterministic, generator=generator)
+            res = policy.act(*args, deterministic=deterministic, generator=generator, **kw)
+            value_s, action_s = res[0], res[1]
+        if rec:
+            hid[0, idx, seat], hid[1, idx, seat] = res[3][0].float(), res[3][1].float()     # :95
         if sub:
             value = torch.zeros((n, 1), dtype=value_s.dtype, device=dev); value[idx] = value_s
             action = torch.zeros((n, spec.ACTION_WORDS), dtype=action_s.dtype, device=dev); action[idx] = action_s
@@ -268,10 +289,14 @@ def _update_action_masks(action, m):
 
 @torch.no_grad()
 def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settlement_phase=None,
-                    consider_all_initial_settlements=False, rngs=None, deterministic=False, generator=None, autocast_dtype=None):
+                    consider_all_initial_settlements=False, rngs=None, deterministic=False, generator=None, autocast_dtype=None,
+                    hidden=None, return_hidden=False):
     """default_sample_actions (sample_actions_fn.py:55-328, with dont_propose_devcards = dont_propose_trades = False) for R
     roots.  f/lists/lens/masks: the roots' observations and masks (device tensors); rngs: one `random.Random` per root for
-    the procedure's random.choice calls.  -> (actions int64 numpy [R, A, 18], counts [R]) in proposal order."""
+    the procedure's random.choice calls.  hidden (LSTM policies): (h, c) [R, L] each, the deciding seat's state; every proposal
+    is sampled from it, and the state after the decision - the same for all proposals of a root, the LSTM step precedes the
+    action heads - is returned with return_hidden (`player_next_hidden_states`, sample_actions_fn.py).
+    -> (actions int64 numpy [R, A, 18], counts [R]) in proposal order [, (h, c) [R, L]]."""
     R, dev = f.shape[0], f.device
     m = masks.detach().cpu().numpy().astype(np.float32).copy()            # working copies, updated as targets are used up
     type_masks = m[:, MO[0]:MO[0] + 13].copy()
@@ -283,17 +308,26 @@ def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settl
     exchanges = [[] for _ in range(R)]
     trades = np.zeros(R, dtype=np.int64)
 
+    rec = bool(getattr(policy, "include_lstm", False))
+    if rec:
+        Lh = int(policy.lstm_size)
+        h_in = (torch.zeros(R, Lh, device=dev), torch.zeros(R, Lh, device=dev)) if hidden is None else (hidden[0].to(dev).float(), hidden[1].to(dev).float())
+        h_next = (h_in[0].clone(), h_in[1].clone())
+
     def act(rows, types):
         idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
         forced = torch.as_tensor(types, device=dev, dtype=torch.long)
         mk = torch.from_numpy(m[rows]).to(dev)
         args = (f[idx], lists[idx], lens[idx].long(), mk)
+        kw = {"hidden": (h_in[0][idx], h_in[1][idx]), "nonterminal": torch.ones(idx.numel(), device=dev)} if rec else {}
         if autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=autocast_dtype):
-                _, a, _ = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced)
+                res = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced, **kw)
         else:
-            _, a, _ = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced)
-        return a.cpu().numpy()
+            res = policy.act(*args, deterministic=deterministic, generator=generator, condition_on_action_type=forced, **kw)
+        if rec:
+            h_next[0][idx], h_next[1][idx] = res[3][0].float(), res[3][1].float()
+        return res[1].cpu().numpy()
 
     count_of = {0: lambda r: m[r, MO[1]:MO[1] + 54].sum() - 1, 1: lambda r: m[r, MO[2]:MO[2] + 73].sum() - 1,
                 2: lambda r: m[r, MO[1] + 54:MO[1] + 108].sum() - 1, 4: lambda r: m[r, MO[4]:MO[4] + 5].sum() - 1,
@@ -374,6 +408,8 @@ def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settl
         counts[r] = len(proposed[r])
         for j, a in enumerate(proposed[r]):
             out[r, j] = a
+    if return_hidden:
+        return out, counts, (h_next if rec else None)
     return out, counts
 
 
@@ -385,10 +421,6 @@ class ForwardSearch(object):
     def __init__(self, policy, make_sim_env, n_roots, max_init_actions=10, max_depth=20, gamma=0.999, sims_per_root=64,
                  sims_per_round=16, consider_all_moves_for_opening_placement=False, seed=0, autocast_dtype=None, use_graphs=False):
         assert sims_per_root % sims_per_round == 0
-        if getattr(policy, "include_lstm", False):
-            # the reference threads (h, c) of every seat through proposals and simulations (forward_search_policy/policy.py:72-106,
-            # zero_opponent_hidden_states); that is not restated here - refuse instead of searching with stale states
-            raise NotImplementedError("ForwardSearch does not carry LSTM states; use a feed-forward CatanPolicy")
         if autocast_dtype is not None and hasattr(policy, "inference_copy") and getattr(policy, "_inference_dtype", None) is None:
             policy = policy.inference_copy(autocast_dtype)      # weights in the autocast dtype: no per-call casts
         self.policy, self.R = policy, n_roots
@@ -408,15 +440,37 @@ class ForwardSearch(object):
         self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]
 
     @torch.no_grad()
-    def act(self, root_env, initial_settlement=None, deterministic=False):
-        """-> (actions int64 numpy [R,18], info dict).  Roots with a single proposal skip the search (policy.py:88-89)."""
+    def act(self, root_env, initial_settlement=None, deterministic=False, hidden=None, zero_opponent_hidden_states=False,
+            max_thinking_time=None):
+        """-> (actions int64 numpy [R,18], info dict).  Roots with a single proposal skip the search (policy.py:88-89).
+        LSTM policies: hidden [2, R, 4, L] = the (h, c) of every seat of every root (`curr_hidden_states`, policy.py:72; zeros if
+        omitted); proposals and simulations run from them as the reference's do (:73-86, worker.py:61-95), and
+        info["next_hidden"] [2, R, L] is the searching seat's state after its decision (`player_next_hidden_states`).
+        max_thinking_time (seconds; None = the fixed budget of `sims_per_root`): the reference's wall-clock budget
+        (policy.py:91,112-138): root r thinks for max_thinking_time * n_proposed[r] / max_init_actions; rounds of K simulations
+        per root are run until the longest of those budgets is spent, and a root stops taking results once its own is."""
         R, K = self.R, self.K
         assert root_env.n == R
         ctrl = root_env.deciding_player().long()
         f, lists, lens = root_env.get_obs()
         masks = root_env.get_action_masks()
-        props, counts = propose_actions(self.policy, f, lists, lens, masks, self.max_init_actions, initial_settlement, self.consider_all,
-                                        self.rngs, deterministic, self.gen, self.autocast_dtype)
+        rec = bool(getattr(self.policy, "include_lstm", False))
+        hid_sim = init_sim = next_hidden = None
+        if rec:
+            Lh = int(self.policy.lstm_size)
+            hidden = torch.zeros((2, R, 4, Lh), device=root_env.device) if hidden is None else hidden.to(root_env.device).float()
+            ar_r = torch.arange(R, device=root_env.device)
+            own = (hidden[0, ar_r, ctrl - 1], hidden[1, ar_r, ctrl - 1])
+        props, counts, nh = propose_actions(self.policy, f, lists, lens, masks, self.max_init_actions, initial_settlement, self.consider_all,
+                                            self.rngs, deterministic, self.gen, self.autocast_dtype, hidden=own if rec else None, return_hidden=True)
+        if rec:
+            next_hidden = torch.stack(nh)                                           # [2, R, L]
+            if zero_opponent_hidden_states:                                         # policy.py:81-86
+                keep = torch.zeros((R, 4), dtype=torch.bool, device=root_env.device)
+                keep[ar_r, ctrl - 1] = True
+                hidden = hidden * keep[None, :, :, None]
+            hid_sim = hidden.repeat_interleave(K, dim=1)
+            init_sim = next_hidden.repeat_interleave(K, dim=1)
         self.stats.new_decision(counts)
         blobs = root_env.export_state()                                             # [R, 736] int32 (state broadcast)
         blobs = blobs.repeat_interleave(K, dim=0).clone()
@@ -424,11 +478,24 @@ class ForwardSearch(object):
         base_draws = blobs[:, self._rng_word].long() & 0xFFFFFFFF
         props_t = torch.from_numpy(props).to(root_env.device)
         ar_sim = torch.arange(R * K, device=root_env.device)
-        for rnd in range(self.S // K):
+        import time as _time
+        t_start = _time.perf_counter()
+        think = None if max_thinking_time is None else max_thinking_time * (counts / float(self.max_init_actions))      # policy.py:91
+        rnd = -1
+        while True:
+            rnd += 1
+            if think is None:
+                if rnd >= self.S // K:
+                    break
+                thinking = np.ones(R, dtype=bool)
+            else:
+                thinking = (_time.perf_counter() - t_start) < think                 # `while elapsed_time < thinking_time`
+                if not thinking.any():
+                    break
             ids = np.zeros((R, K), dtype=np.int64)
             for k in range(K):                                                      # one simulation after the other (:118-125)
                 a = self.stats.select(explore=True)
-                self.stats.start(a)
+                self.stats.start(a, np.flatnonzero(thinking))
                 ids[:, k] = a
             # every simulation its own philox substream: offset the game stream's draw counter by a large stride
             sub = (base_draws + (1 + rnd * K + (ar_sim % K)) * (1 << 22)) & 0xFFFFFFFF
@@ -437,12 +504,13 @@ class ForwardSearch(object):
             self.sim_env.randomise_uncertainty(ctrl_sim)                            # :46
             init = props_t[torch.arange(R, device=props_t.device).repeat_interleave(K), torch.from_numpy(ids.reshape(-1)).to(props_t.device)]
             vals = simulate(self.sim_env, self.policy, ctrl_sim, init, self.max_depth, self.gamma, deterministic, self.gen,
-                            self.autocast_dtype, None if deterministic else self.graphed).reshape(R, K)
+                            self.autocast_dtype, None if deterministic else self.graphed, hidden=hid_sim, init_hidden=init_sim).reshape(R, K)
+            rows = np.flatnonzero(thinking)
             for k in range(K):
-                self.stats.update(vals[:, k], ids[:, k])
-            self.sims_run += R * K
+                self.stats.update(vals[rows, k], ids[rows, k], rows)
+            self.sims_run += int(rows.size) * K
         best = self.stats.select(explore=False)
         best = np.where(counts == 1, 0, best)
         chosen = props[np.arange(R), best]
         return chosen, {"n_proposed": counts, "best": best, "finished_each": self.stats.finished_each.copy(),
-                        "mean_value": self.stats.exploit / np.maximum(self.stats.finished_each, 1)}
+                        "mean_value": self.stats.exploit / np.maximum(self.stats.finished_each, 1), "next_hidden": next_hidden}

@@ -119,6 +119,8 @@ class PPOTrainer(object):
         nt_all = masks[:T].reshape(total)                 # masks_batch of generator_lstm (process_batch.py:249)
         cast = (lambda x: x) if (self.autocast_dtype is not None and f_all.dtype == self.autocast_dtype) else (lambda x: x.float())
         sums = torch.zeros(3, device=dev)                 # action loss, value loss, entropy (accumulated on device)
+        timed_allreduce = dev.type == "cuda" and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        ar_events = []
         t_val = t_gae = t_opt = 0.0
         for _ in range(cfg.ppo_epoch):
             t0 = time.perf_counter()
@@ -148,7 +150,14 @@ class PPOTrainer(object):
                                                    value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
                 self.bucket.zero()
                 (loss - ent * cfg.entropy_coef).backward()                                 # ppo.py:66
-                self.bucket.allreduce()                                                    # one RCCL all-reduce per step
+                if timed_allreduce:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self.bucket.allreduce()                                                # one RCCL all-reduce per step
+                    e1.record()
+                    ar_events.append((e0, e1))
+                else:
+                    self.bucket.allreduce()
                 torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
                 self.optimiser.step()
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))
@@ -156,5 +165,8 @@ class PPOTrainer(object):
             t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2
         n = cfg.ppo_epoch * len(batches)
         self.timings = {"values_s": t_val, "gae_s": t_gae, "minibatches_s": t_opt}
+        if timed_allreduce:                               # device time inside the gradient all-reduces (part of minibatches_s)
+            self._sync()
+            self.timings["allreduce_s"] = sum(a.elapsed_time(b) for a, b in ar_events) * 1e-3
         al, vl, en = (sums / n).tolist()
         return vl * cfg.value_loss_coef, al, en * cfg.entropy_coef

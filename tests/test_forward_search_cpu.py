@@ -92,26 +92,34 @@ def test_ucb_stats_match_reference_policy_object():
             assert abs(o.value_moving_average.get_std() - st.last_std[r]) < 1e-9
 
 
-def _perturbed_reference_net(seed=9):
-    from RL.models.build_agent_model import build_agent_model
-    net = build_agent_model(device="cpu")
+def _perturbed_reference_net(seed=9, lstm=False):
+    import RL.models.build_agent_model as bam
+    old_flag = bam.include_lstm
+    bam.include_lstm = lstm
+    try:
+        net = bam.build_agent_model(device="cpu")
+    finally:
+        bam.include_lstm = old_flag
     g = torch.Generator().manual_seed(seed)
     sd = {k: (v + 0.05 * torch.randn(v.shape, generator=g) if v.numel() and v.dtype == torch.float32 else v) for k, v in net.state_dict().items()}
     net.load_state_dict(sd)
     net.eval()
     orig = net.act
     net.act = lambda *a, **kw: orig(*a, **{**kw, "deterministic": True})      # arg-max decisions on both sides
-    mine = CatanPolicy(); mine.load_reference_state_dict(sd); mine.eval()
+    mine = CatanPolicy(include_lstm=lstm); mine.load_reference_state_dict(sd); mine.eval()
     return net, mine
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="upstream reference not mounted")
-def test_simulate_matches_run_simulation_forward():
+@pytest.mark.parametrize("lstm", [False, True])
+def test_simulate_matches_run_simulation_forward(lstm):
     """The batched simulator against the reference's run_simulation_forward: same start state, same (arg-max) policy for
-    every seat, same philox game stream; the value estimate must agree (fp32 net on both sides)."""
+    every seat, same philox game stream; the value estimate must agree (fp32 net on both sides).  lstm: the LSTM policy with
+    a different (h, c) per seat at the start and the searching seat's post-decision state (worker.py:61-95)."""
     import ref_harness as rh
     from RL.forward_search_policy.worker import run_simulation_forward
-    ref_net, net = _perturbed_reference_net()
+    ref_net, net = _perturbed_reference_net(lstm=lstm)
+    gh = torch.Generator().manual_seed(77)
     checked = 0
     for (seed, warm, depth) in [(5, 40, 6), (5, 400, 8), (8, 900, 5), (11, 1500, 20)]:
         rng = np.random.default_rng(seed)
@@ -135,12 +143,15 @@ def test_simulate_matches_run_simulation_forward():
         blob = env.b.export()
         env_dense = OracleVecEnv(1, seed, dense_reward=True, auto_reset=False)
         env_dense.import_state(blob)
+        hid = 0.3 * torch.randn(2, 1, 4, 256, generator=gh) if lstm else None      # every seat's (h, c) at the start state
+        init_h = 0.3 * torch.randn(2, 1, 256, generator=gh) if lstm else None       # the searching seat's state after its decision
         with rh.patched_rng(ref.stream):
             want = run_simulation_forward(ref.env, ref_net, player_id=rh.PIDS[ctrl - 1], init_action=rh.action_to_heads(init),
-                                          init_player_hs=None, curr_hidden_states={p: None for p in rh.PIDS},
+                                          init_player_hs=(init_h[0], init_h[1]) if lstm else None,
+                                          curr_hidden_states={p: ((hid[0, :, int(p) - 1], hid[1, :, int(p) - 1]) if lstm else None) for p in rh.PIDS},
                                           curr_obs=ref_net.obs_to_torch(copy.deepcopy(obs)), max_depth=depth, gamma=0.999)
         got = fs.simulate(env_dense, net, torch.tensor([ctrl]), torch.tensor(np.asarray(init)[None]), max_depth=depth, gamma=0.999,
-                          deterministic=True)
+                          deterministic=True, hidden=hid, init_hidden=init_h)
         assert abs(float(got[0]) - float(want)) < 2e-3 * max(1.0, abs(float(want))), (seed, warm, got, want)
         checked += 1
     assert checked == 4
@@ -206,3 +217,29 @@ def test_forward_search_end_to_end_on_oracle_env():
         a = np.ascontiguousarray(chosen[r], dtype=np.int32)
         assert root.L.orc_action_is_legal(root.b.env_ptr(r), a.ctypes.data_as(C.POINTER(C.c_int32)))
         assert 1 <= info["n_proposed"][r] <= 10
+
+
+def test_forward_search_lstm_states_and_time_budget():
+    """LSTM policy: per-seat states go through proposals and simulations, `next_hidden` is the searching seat's state after
+    one LSTM step on its root observation; and the wall-clock budget (policy.py:91,111) instead of a simulation count."""
+    torch.manual_seed(1)
+    R, K = 2, 2
+    root = OracleVecEnv(R, seed=17)
+    root.advance_random(300)
+    net = CatanPolicy(include_lstm=True).eval()
+    hidden = 0.2 * torch.randn(2, R, 4, net.lstm_size)
+    search = fs.ForwardSearch(net, lambda n: OracleVecEnv(n, seed=5, dense_reward=True, auto_reset=False), R, max_depth=2,
+                              sims_per_root=2, sims_per_round=K)
+    chosen, info = search.act(root, deterministic=True, hidden=hidden, zero_opponent_hidden_states=True)
+    ctrl = root.deciding_player().long()
+    f, lists, lens = root.get_obs()
+    ar = torch.arange(R)
+    with torch.no_grad():
+        _, _, _, (h1, c1) = net.act(f, lists, lens.long(), root.get_action_masks(), deterministic=True,
+                                    hidden=(hidden[0, ar, ctrl - 1], hidden[1, ar, ctrl - 1]), nonterminal=torch.ones(R))
+    assert torch.allclose(info["next_hidden"][0], h1, atol=1e-6) and torch.allclose(info["next_hidden"][1], c1, atol=1e-6)
+    assert search.sims_run == R * 2
+    # wall-clock budget: at least one round for every root that has more than one proposal, then it stops
+    search.sims_run = 0
+    chosen, info = search.act(root, deterministic=True, hidden=hidden, max_thinking_time=0.05)
+    assert search.sims_run >= K * int((info["n_proposed"] > 0).sum()) and (info["finished_each"].sum(1) >= K).all()

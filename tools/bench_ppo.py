@@ -3,7 +3,9 @@
 its split (rollout collection / value recompute / GAE / minibatch SGD).
 
     python tools/bench_ppo.py --envs 65536 --num-steps 200            # reference T (arguments.py:54-56); ~100 GB of HBM
-    python -m torch.distributed.run --nproc-per-node 8 ... tools/bench_ppo.py --envs 65536   # 524 288 games, RCCL grads
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        tools/bench_ppo.py --envs 65536                                  # config 4: 524 288 games, RCCL gradient all-reduce;
+                                                                         # `split.allreduce_s` = device time inside the all-reduces
 
 Self-play here = every seat plays the central policy (the reference's league opponents are a `next` row).
 Prints one JSON line on rank 0.  Not the driver's bench (that is bench.py = config 2)."""
@@ -45,6 +47,7 @@ def main():
     env.random_rollout(0, args.warm_games)
     make_net = lambda: CatanPolicy(include_lstm=args.lstm).cuda()
     net = make_net()
+    cdist.broadcast_parameters(net)                         # every rank starts from rank 0's weights
     ac = None if args.fp32 else torch.bfloat16
     col = RolloutCollector(env, net, args.num_steps, seed=rank, autocast_dtype=ac)
     tr = PPOTrainer(net, PPOConfig(ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch), autocast_dtype=ac, seed=rank)
