@@ -301,6 +301,7 @@ class _ActionHeads(nn.Module):
     # multiplied by 0 everywhere else), so every head but the type head runs on just those rows - a few per cent of the
     # batch each.  Same value, same gradient (the skipped rows' terms are exact zeros); 27 -> 8 ms at 204 800 rows.
     compact_evaluate = True
+    compact_min_rows = 49152       # below this a minibatch step is launch-bound and the extra gathers (and the host read) cost more than they save
 
     def _evaluate_compact(self, main, m, cur_res, trade, actions):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
@@ -410,7 +411,7 @@ class _ActionHeads(nn.Module):
         forced_type int64 [B] or None: rows with a value >= 0 take that action type instead of sampling the type head
         (`condition_on_action_type`, action_heads_module.py:37-48: the type head is skipped, its output is the one-hot).
         -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
-        if actions is not None and forced_type is None and self.compact_evaluate:
+        if actions is not None and forced_type is None and self.compact_evaluate and main.shape[0] >= self.compact_min_rows:
             return self._evaluate_compact(main, masks, cur_res, trade, actions)
         B, dev = main.shape[0], main.device
         H = self.action_heads

@@ -452,3 +452,30 @@ def test_card_summary_kernel_vs_torch_formulation(hip_lib):
         assert o1.shape == (B, 16) and torch.allclose(o1, o2, atol=2e-5, rtol=1e-5), float((o1 - o2).abs().max())
         for a, b in zip(g1, g2):
             assert float((a - b).abs().max()) <= 3e-4 * max(1.0, float(b.abs().max())), float((a - b).abs().max())   # fp32 sums in another order
+
+
+def test_compact_head_evaluation_on_device(hip_lib):
+    """evaluate_actions at a minibatch width where the heads run only on the rows that use them (>= compact_min_rows):
+    joint log-probs, entropy and the trunk gradient equal the dense evaluation (fp32, HIP kernels on both sides)."""
+    import torch
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(0)
+    n = 65536
+    env = VecCatanEnv(n, seed=4); env.random_rollout(0, 700)
+    f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+    net = CatanPolicy().cuda()
+    with torch.no_grad():
+        _, acts, _ = net.act(f, lists, lens, masks)
+    assert n >= net.action_head_module.compact_min_rows
+    out = {}
+    for compact in (True, False):
+        net.action_head_module.compact_evaluate = compact
+        net.zero_grad()
+        v, lp, ent = net.evaluate_actions(f, lists, lens, masks, acts)
+        (lp.mean() + ent + v.mean()).backward()
+        out[compact] = (lp.detach().clone(), float(ent), net.observation_module.final_layer.weight.grad.clone())
+    net.action_head_module.compact_evaluate = True
+    assert torch.allclose(out[True][0], out[False][0], atol=2e-4), float((out[True][0] - out[False][0]).abs().max())
+    assert abs(out[True][1] - out[False][1]) < 1e-5
+    assert torch.allclose(out[True][2], out[False][2], atol=1e-5, rtol=1e-3)
