@@ -1,5 +1,6 @@
-"""Aggregates rocprofv3 counter-collection CSVs (one directory per --pmc pass) into profiles/r01_pmc_summary.json:
-mean counter value per launch for every catan kernel, calibrated with k_calib_copy (known bytes)."""
+"""Aggregates rocprofv3 counter-collection CSVs (one directory per --pmc pass) into profiles/rNN_pmc_summary.json:
+mean counter value per launch over the LAST `TAIL` launches of every catan kernel (the measured section of
+tools/pmc_workload.py: 96 deferred passes after the pre-roll), calibrated with k_calib_copy (known bytes)."""
 import csv
 import glob
 import json
@@ -8,9 +9,10 @@ import sys
 from collections import defaultdict
 
 CALIB_BYTES = 256 << 20
+TAIL = 96
 out_path = sys.argv[1]
 dirs = sys.argv[2:]
-acc = defaultdict(lambda: [0.0, 0])          # (kernel, counter) -> [sum, launches]
+vals = defaultdict(list)                     # (kernel, counter) -> [(dispatch id, value)]
 for d in dirs:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
@@ -19,11 +21,12 @@ for d in dirs:
                 if "catan::" not in name:
                     continue
                 short = name.split("catan::")[1].split("(")[0].split("<")[0]
-                a = acc[(short, row["Counter_Name"])]
-                a[0] += float(row["Counter_Value"]); a[1] += 1
+                vals[(short, row["Counter_Name"])].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
 kern = defaultdict(dict)
-for (k, c), (s, n) in acc.items():
-    kern[k][c] = {"mean_per_launch": s / n, "launches": n}
+for (k, c), lst in vals.items():
+    lst.sort()
+    tail = [v for _, v in lst[-TAIL:]]
+    kern[k][c] = {"mean_per_launch": sum(tail) / len(tail), "launches_averaged": len(tail), "launches_profiled": len(lst)}
 calib = kern.get("k_calib_copy", {})
 res = {"calibration": {"kernel": "k_calib_copy", "bytes_read": CALIB_BYTES, "bytes_written": CALIB_BYTES}, "kernels": {}}
 fr = fw = None
