@@ -76,6 +76,7 @@ struct PpoArgs { float clip, value_coef, norm_mean, norm_std; int use_norm; };
 // last adds them up in index order, so the result does not depend on the schedule (ws: 2 * PPO_BLOCKS + 1 doubles, the last
 // one the arrival counter - zero before the first call, left zero by every call).
 constexpr int PPO_BLOCKS = 256, PPO_THREADS = 256;
+static_assert(PPO_BLOCKS <= PPO_THREADS, "the last workgroup reduces one partial sum per lane");
 __global__ __launch_bounds__(PPO_THREADS) void k_ppo_loss(const float* __restrict__ logp, const float* __restrict__ old_logp,
                                                           const float* __restrict__ adv, const float* __restrict__ values,
                                                           const float* __restrict__ old_values, const float* __restrict__ returns,
@@ -119,15 +120,20 @@ __global__ __launch_bounds__(PPO_THREADS) void k_ppo_loss(const float* __restric
         last = atomicAdd(counter, 1ull) == (unsigned long long)gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
+    if (last) {                                             // the whole last workgroup: partial k at lane k, then the same tree as above
         __threadfence();
-        double sa = 0.0, sv = 0.0;
-        for (unsigned k = 0; k < gridDim.x; k++) {             // (device-scope loads: the other workgroups' partial sums)
-            sa += __hip_atomic_load(&ws[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sv += __hip_atomic_load(&ws[PPO_BLOCKS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool have = threadIdx.x < gridDim.x;
+        sh[0][threadIdx.x] = have ? __hip_atomic_load(&ws[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        sh[1][threadIdx.x] = have ? __hip_atomic_load(&ws[PPO_BLOCKS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        for (int s2 = PPO_THREADS / 2; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s2]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s2]; }
+            __syncthreads();
         }
-        losses[0] = (float)(sa / (double)B); losses[1] = (float)(sv / (double)B);
-        *reinterpret_cast<unsigned long long*>(ws + 2 * PPO_BLOCKS) = 0ull;
+        if (threadIdx.x == 0) {
+            losses[0] = (float)(sh[0][0] / (double)B); losses[1] = (float)(sh[1][0] / (double)B);
+            *reinterpret_cast<unsigned long long*>(ws + 2 * PPO_BLOCKS) = 0ull;
+        }
     }
 }
 
