@@ -131,7 +131,7 @@ class GraphedAct(object):
     padding and ignored.  Sampling uses torch's default CUDA generator, which graphs advance correctly.  Falls back to the
     eager call if capture is unavailable."""
 
-    def __init__(self, policy, buckets=(512, 4096), autocast_dtype=None, deterministic=False):
+    def __init__(self, policy, buckets=(512, 4096, 16384), autocast_dtype=None, deterministic=False):
         self.policy, self.buckets, self.autocast_dtype, self.deterministic = policy, tuple(sorted(buckets)), autocast_dtype, deterministic
         self.graphs = {}
         self.failed = False
@@ -302,10 +302,7 @@ def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settl
     type_masks = m[:, MO[0]:MO[0] + 13].copy()
     rngs = rngs or [_py_random.Random(i) for i in range(R)]
     init_phase = np.zeros(R, dtype=bool) if initial_settlement_phase is None else np.asarray(initial_settlement_phase, dtype=bool)
-    proposed = [[] for _ in range(R)]
-    avail = [dict() for _ in range(R)]
     effective = np.zeros(R)
-    exchanges = [[] for _ in range(R)]
     trades = np.zeros(R, dtype=np.int64)
 
     rec = bool(getattr(policy, "include_lstm", False))
@@ -329,85 +326,113 @@ def propose_actions(policy, f, lists, lens, masks, max_actions=10, initial_settl
             h_next[0][idx], h_next[1][idx] = res[3][0].float(), res[3][1].float()
         return res[1].cpu().numpy()
 
-    count_of = {0: lambda r: m[r, MO[1]:MO[1] + 54].sum() - 1, 1: lambda r: m[r, MO[2]:MO[2] + 73].sum() - 1,
-                2: lambda r: m[r, MO[1] + 54:MO[1] + 108].sum() - 1, 4: lambda r: m[r, MO[4]:MO[4] + 5].sum() - 1,
-                5: lambda r: m[r, MO[10]:MO[10] + 5].sum() * m[r, MO[9]:MO[9] + 5].sum() - 1,
-                6: lambda r: MAX_PROP_TRADE_ACTIONS - 1, 8: lambda r: m[r, MO[3]:MO[3] + 19].sum() - 1,
-                11: lambda r: m[r, MO[6] + 3:MO[6] + 6].sum() - 1, 12: lambda r: m[r, MO[11]:MO[11] + 5].sum() - 1}
+    # Bookkeeping as arrays over the roots (round 1 walked Python dicts / lists per root: 1.5 s at 4 096 roots):
+    #   avail [R, 13]   refinement draws left per type (sample_actions_fn.py `available_actions`; only refinable types > 0)
+    #   props [R, cap, 18], n_prop [R]   the proposals in order;   ex [R, cap, 2], n_ex [R]   exchange pairs proposed so far
+    REFINABLE = (0, 1, 2, 4, 5, 6, 8, 11, 12)
+    cap = max(int(max_actions), 13) + (54 if consider_all_initial_settlements else 0) + 1
+    avail = np.zeros((R, 13))
+    props = np.zeros((R, cap, spec.ACTION_WORDS), dtype=np.int64); n_prop = np.zeros(R, dtype=np.int64)
+    ex = np.zeros((R, cap, 2), dtype=np.int64); n_ex = np.zeros(R, dtype=np.int64)
+
+    def counts_for(t, rows):
+        """`count - 1` further targets of type t (sample_actions_fn.py:117-196), for all `rows` at once"""
+        mr = m[rows]
+        if t == 0: return mr[:, MO[1]:MO[1] + 54].sum(1) - 1
+        if t == 1: return mr[:, MO[2]:MO[2] + 73].sum(1) - 1
+        if t == 2: return mr[:, MO[1] + 54:MO[1] + 108].sum(1) - 1
+        if t == 4: return mr[:, MO[4]:MO[4] + 5].sum(1) - 1
+        if t == 5: return mr[:, MO[10]:MO[10] + 5].sum(1) * mr[:, MO[9]:MO[9] + 5].sum(1) - 1
+        if t == 6: return np.full(len(rows), MAX_PROP_TRADE_ACTIONS - 1.0)
+        if t == 8: return mr[:, MO[3]:MO[3] + 19].sum(1) - 1
+        if t == 11: return mr[:, MO[6] + 3:MO[6] + 6].sum(1) - 1
+        return mr[:, MO[11]:MO[11] + 5].sum(1) - 1                        # 12
+
+    # _update_action_masks (sample_actions_fn.py:31-53) for many roots at once: (first mask column, width, action word, minimum sum)
+    TARGET = {0: (MO[1], 54, 1, 1), 1: (MO[2], 73, 2, 1), 2: (MO[1] + 54, 54, 1, 1), 4: (MO[4], 5, 4, 1), 8: (MO[3], 19, 3, 0),
+              11: (MO[6] + 3, 3, 6, 0), 12: (MO[11], 5, 17, 1)}
+
+    def use_up(t, rows, acts):
+        if t not in TARGET or len(rows) == 0:
+            return
+        lo, w, word, least = TARGET[t]
+        rows = np.asarray(rows)
+        ok = m[rows, lo:lo + w].sum(1) > least
+        m[rows[ok], lo + acts[ok, word]] = 0
+
+    def append(rows, acts):
+        rows = np.asarray(rows)
+        props[rows, n_prop[rows]] = acts
+        n_prop[rows] += 1
+
     name_of = {v: k for k, v in TYPE_TO_IND.items()}
     for t in range(13):                                                   # first pass: one proposal per available type
         rows = np.flatnonzero(type_masks[:, t] == 1)
         if rows.size == 0:
             continue
-        for r in rows:
-            if t in count_of:
-                c = float(count_of[t](r))
-                avail[r][name_of[t]] = c
-                effective[r] += c
-            elif t == 7:
-                effective[r] += m[r, MO[5]:MO[5] + 2].sum() - 1            # respond: counted but not refinable (:198)
+        if t in REFINABLE:
+            c = counts_for(t, rows).astype(np.float64)
+            avail[rows, t] = c
+            effective[rows] += c
+        elif t == 7:
+            effective[rows] += m[rows, MO[5]:MO[5] + 2].sum(1) - 1         # respond: counted but not refinable (:198)
         a = act(rows, np.full(rows.size, t))
-        for j, r in enumerate(rows):
-            assert a[j, 0] == t
-            proposed[r].append(a[j])
-            if t == 5:
-                exchanges[r].append((int(a[j, 15]), int(a[j, 16])))
-            if t == 6:
-                trades[r] += 1
-            if t in (0, 1, 2, 4, 8, 11, 12):
-                _update_action_masks(a[j], m[r])
+        assert (a[:, 0] == t).all()
+        append(rows, a)
+        if t == 5:
+            ex[rows, n_ex[rows]] = a[:, 15:17]; n_ex[rows] += 1
+        if t == 6:
+            trades[rows] += 1
+        use_up(t, rows, a)
     # refinement draws (:286-328)
-    n_more = np.zeros(R, dtype=np.int64)
-    for r in range(R):
-        if init_phase[r] and consider_all_initial_settlements:
-            n_more[r] = int(avail[r]["settlement"])
-        else:
-            n_more[r] = int(min(max_actions - len(proposed[r]), effective[r]))
+    if consider_all_initial_settlements:
+        n_more = np.where(init_phase, avail[:, 0].astype(np.int64), np.minimum(max_actions - n_prop, effective).astype(np.int64))
+    else:
+        n_more = np.minimum(max_actions - n_prop, effective).astype(np.int64)
     alive = n_more > 0
+    prio = [[TYPE_TO_IND[x] for x in pr] for pr in PRIORITIES]
     for i in range(int(n_more.max()) if R else 0):
         rows, types = [], []
-        for r in range(R):
-            if not alive[r] or i >= n_more[r]:
-                continue
-            ac_type = None
-            for pr in PRIORITIES:
-                av = [x for x in pr if avail[r].get(x, 0) > 0]
-                if trades[r] >= MAX_PROP_TRADE_ACTIONS and "prop_trade" in av:
-                    av.remove("prop_trade")
+        for r in np.flatnonzero(alive & (i < n_more)):
+            ac_type = -1
+            av_r = avail[r]
+            for pr in prio:
+                av = [x for x in pr if av_r[x] > 0]
+                if trades[r] >= MAX_PROP_TRADE_ACTIONS and 6 in av:
+                    av.remove(6)
                 if av:
-                    ac_type = rngs[r].choice(av)
-                    avail[r][ac_type] -= 1
+                    ac_type = TYPE_TO_IND[rngs[r].choice([name_of[x] for x in av])]
+                    av_r[ac_type] -= 1
                     break
-            if ac_type is None:
+            if ac_type < 0:
                 alive[r] = False                                          # "something gone wrong - just return what we have"
                 continue
-            rows.append(r); types.append(TYPE_TO_IND[ac_type])
+            rows.append(r); types.append(ac_type)
         if not rows:
             break
-        a = act(np.asarray(rows), np.asarray(types))
-        for j, r in enumerate(rows):
-            act_j = a[j]
-            if types[j] == 6:
-                proposed[r].append(act_j); trades[r] += 1
-            elif types[j] == 5:
-                # the reference re-draws the pair `while prop_exchange not in exchanges_proposed` (:316-320): a NEW pair is
-                # replaced by random legal picks until it coincides with one proposed before
+        rows, types = np.asarray(rows), np.asarray(types)
+        a = act(rows, types)
+        is_ex = types == 5
+        for j in np.flatnonzero(is_ex):
+            # the reference re-draws the pair `while prop_exchange not in exchanges_proposed` (:316-320): a NEW pair is
+            # replaced by random legal picks until it coincides with one proposed before
+            r, act_j = rows[j], a[j]
+            seen = {(int(x), int(y)) for x, y in ex[r, :n_ex[r]]}
+            pair = (int(act_j[15]), int(act_j[16]))
+            give_ok = np.flatnonzero(m[r, MO[9]:MO[9] + 5]); recv_ok = np.flatnonzero(m[r, MO[10]:MO[10] + 5])
+            while pair not in seen:
+                act_j[15] = rngs[r].choice(list(give_ok)); act_j[16] = rngs[r].choice(list(recv_ok))
                 pair = (int(act_j[15]), int(act_j[16]))
-                give_ok = np.flatnonzero(m[r, MO[9]:MO[9] + 5]); recv_ok = np.flatnonzero(m[r, MO[10]:MO[10] + 5])
-                while pair not in exchanges[r]:
-                    act_j[15] = rngs[r].choice(list(give_ok)); act_j[16] = rngs[r].choice(list(recv_ok))
-                    pair = (int(act_j[15]), int(act_j[16]))
-                proposed[r].append(act_j); exchanges[r].append(pair)
-            else:
-                proposed[r].append(act_j)
-                _update_action_masks(act_j, m[r])
-    A = max(len(p) for p in proposed) if R else 0
-    out = np.zeros((R, A, spec.ACTION_WORDS), dtype=np.int64)
-    counts = np.zeros(R, dtype=np.int64)
-    for r in range(R):
-        counts[r] = len(proposed[r])
-        for j, a in enumerate(proposed[r]):
-            out[r, j] = a
+            ex[r, n_ex[r]] = pair; n_ex[r] += 1
+        append(rows, a)
+        trades[rows[types == 6]] += 1
+        for t in TARGET:
+            sel = types == t
+            if sel.any():
+                use_up(t, rows[sel], a[sel])
+    A = int(n_prop.max()) if R else 0
+    out = props[:, :A].copy()
+    counts = n_prop.copy()
     if return_hidden:
         return out, counts, (h_next if rec else None)
     return out, counts
