@@ -229,6 +229,20 @@ int catan_categorical_fwd(const float* logits, const float* mask, int64_t mask_l
 int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* action, const float* lse, const float* entropy,
                           const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream);
 
+/* The tile encoder of the policy net (RL/models/tile_encoder.py:41-91: Linear(60, 64) + LayerNorm + ReLU, two pre-norm
+ * transformer layers with 4 heads x 16 and a x2 feed-forward net, Linear(64, 25) + LayerNorm + ReLU per tile) as ONE forward
+ * kernel for inference: a workgroup takes 8 boards through the whole encoder in LDS (csrc/catan_tile_encoder.hip).
+ * tiles: bfloat16 [boards][19][60] contiguous, 8-byte aligned; out: bfloat16 [boards][475]; weights: bfloat16
+ * [catan_tile_encoder_weight_elems()] = the matrices row-major [out][in] with `in` zero-padded to a multiple of 32 and `out`
+ * to a multiple of 16, in the order first_layer [64][64], per layer qkv [192][64] (q, k, v nets stacked), out_proj [64][64],
+ * linear1 [128][64], linear2 [64][128], then out_proj [32][64]; vecs: float [catan_tile_encoder_vec_elems()] = first-layer
+ * bias, norm_2 weight, bias [64 each]; per layer: sublayer-0 norm weight, bias [64], qkv bias [192], out_proj bias [64],
+ * sublayer-1 norm weight, bias [64], linear1 bias [128], linear2 bias [64]; then out_proj bias, norm weight, norm bias [32
+ * each, 25 used].  (settlers_of_catan_rl_amd/nn_kernels.py packs them from the module.) */
+int32_t catan_tile_encoder_weight_elems(void);
+int32_t catan_tile_encoder_vec_elems(void);
+int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream);
+
 /* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
  * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card
  * CLASS (a list has <= 6 distinct ids; see csrc/catan_nn.hip).  ids: [rows][pitch] integers of id_bytes (1, 4 or 8) bytes, the

@@ -97,6 +97,9 @@ _SIGS = {
     "catan_lstm_cell_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "catan_lstm_cell_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "catan_calib_copy": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "catan_tile_encoder_weight_elems": (C.c_int32, []),
+    "catan_tile_encoder_vec_elems": (C.c_int32, []),
+    "catan_tile_encoder_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_params": (C.c_int32, []),
     "catan_card_summary_patterns": (C.c_int32, []),
     "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),

@@ -12,6 +12,7 @@
 #include "catan_obs.hip"
 #include "catan_ppo.hip"
 #include "catan_nn.hip"
+#include "catan_tile_encoder.hip"
 
 using namespace catan;
 
@@ -837,6 +838,17 @@ int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_l
         return fail(CATAN_EINVAL, "catan_categorical_bwd: bad arguments");
     hipLaunchKernelGGL(k_categorical_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), logits, mask, (long)mask_ld,
                        (const long long*)action, lse, entropy, dlogp, dent, dlogits, (long)rows, K);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int32_t catan_tile_encoder_weight_elems(void) { return TE_WTOTAL; }
+int32_t catan_tile_encoder_vec_elems(void) { return TE_VTOTAL; }
+int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream) {
+    if (!tiles || !weights || !vecs || !out || boards <= 0) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd: bad arguments");
+    long nb = (boards + TE_G - 1) / TE_G;
+    hipLaunchKernelGGL(k_tile_encoder_fwd, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+                       (unsigned short*)out, (long)boards);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

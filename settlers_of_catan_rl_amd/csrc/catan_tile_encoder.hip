@@ -1,0 +1,275 @@
+// catan_tile_encoder.hip - the tile encoder of the policy net (RL/models/tile_encoder.py:41-91: Linear(60, 64) + LayerNorm +
+// ReLU, two pre-norm transformer layers (4 heads x 16, FFN x 2), Linear(64, 25) + LayerNorm + ReLU per tile) as ONE forward
+// kernel for inference (acting in rollouts and evaluation, the value passes of a PPO update, forward search).
+//
+// Unfused, every op of the encoder streams a [boards x 19, 64..192] activation tensor through HBM: ~14 GB per layer at
+// 204 800 boards, 7.7 ms for the forward.  Here a workgroup (8 waves) takes 8 boards = 152 tokens through the whole encoder
+// in LDS: HBM sees the 2 280 B of tile features per board once and 950 B of output; the 142 KB of weights come from L2
+// (18 KB per board), the 6.8 KB of bias / LayerNorm vectors are copied to LDS once per workgroup.  All per-token linear layers
+// run on v_mfma_f32_16x16x32_bf16: the 152 tokens are 10 row tiles of 16 (8 padding rows); a wave owns every fourth
+// 16-column tile of a layer's output for one half of the rows, holds that tile's weight fragments in registers - fetched one
+// phase ahead of the product that uses them - and walks its 5 row tiles (fragments = 16-byte LDS reads).  The product is
+// formed transposed (weights as the A operand) so a lane ends up with 4 consecutive columns of one token: 8-byte epilogue
+// accesses.  LayerNorm is two lanes per token, the 19 x 19 attention one (board, head) per wave pass on
+// v_mfma_f32_32x32x16_bf16 (S^T = K Q^T, in-lane softmax, O^T = V^T P^T).
+// Measured (MI355X, 204 800 boards): 2.7 ms; SQ counters put the VALU floor of this instruction stream at ~1.35 ms, the rest
+// is exposed L2 latency (tile staging, weight fragments) with one workgroup per CU (114 KB of LDS).
+// Numerics: bf16 storage between the ops (as the unfused bf16-autocast path stores them), fp32 accumulation, fp32 softmax
+// and LayerNorm statistics.
+#pragma once
+
+namespace catan {
+
+constexpr int TE_G = 8, TE_L = 19, TE_TOK = TE_G * TE_L, TE_MT = (TE_TOK + 15) / 16, TE_ROWS = TE_MT * 16;    // 152 tokens, 10 tiles, 160 rows
+constexpr int TE_THREADS = 512, TE_W = TE_THREADS / 64, TE_MP = TE_W / 4;    // waves per workgroup; row partitions of a product
+constexpr int TE_LT = TE_THREADS >= 4 * TE_TOK ? 4 : 2;                       // lanes per token in a LayerNorm
+constexpr int TE_IN = 60, TE_D = 64, TE_F = 128, TE_OUT = 25, TE_H = 4, TE_HD = 16;
+constexpr int TE_PX = TE_D + 8, TE_PQ = 3 * TE_D + 8, TE_PH = TE_F + 8;      // LDS row pitches (bf16 elements; 16 B aligned rows)
+// packed weights (bf16), row-major [N][K], K padded to a multiple of 32, N to a multiple of 16
+constexpr int TE_W0 = 0;                                        // [64][64]  (first layer, K 60 -> 64)
+constexpr int TE_WL = TE_W0 + 64 * 64;                          // per layer: Wqkv [192][64], Wo [64][64], W1 [128][64], W2 [64][128]
+constexpr int TE_WL_SIZE = 192 * 64 + 64 * 64 + 128 * 64 + 64 * 128;
+constexpr int TE_WP = TE_WL + 2 * TE_WL_SIZE;                   // [32][64]  (output projection, N 25 -> 32)
+constexpr int TE_WTOTAL = TE_WP + 32 * 64;
+// packed fp32 vectors: b0[64] ln0w[64] ln0b[64]; per layer: ln1w ln1b [64] bqkv[192] bo[64] ln2w ln2b [64] b1[128] b2[64]; bp[32] lnpw[32] lnpb[32]
+constexpr int TE_V0 = 0, TE_VL = 192, TE_VL_SIZE = 64 * 2 + 192 + 64 + 64 * 2 + 128 + 64, TE_VP = TE_VL + 2 * TE_VL_SIZE, TE_VTOTAL = TE_VP + 96;
+
+DEVI float te_bf(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+DEVI unsigned short te_to_bf(float v) { const __hip_bfloat16 h = __float2bfloat16(v); return *reinterpret_cast<const unsigned short*>(&h); }
+// 8 consecutive bf16 of an LDS row (16-byte aligned) as floats
+DEVI void te_load8(const unsigned short* p, float* o) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+DEVI void te_store8(unsigned short* p, const float* v) {
+    uint4 u;
+    u.x = (unsigned)te_to_bf(v[0]) | ((unsigned)te_to_bf(v[1]) << 16); u.y = (unsigned)te_to_bf(v[2]) | ((unsigned)te_to_bf(v[3]) << 16);
+    u.z = (unsigned)te_to_bf(v[4]) | ((unsigned)te_to_bf(v[5]) << 16); u.w = (unsigned)te_to_bf(v[6]) | ((unsigned)te_to_bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+
+// the weight fragments (and bias values) of this wave's column tiles nt = wave, wave + 4, ... of one layer: fetched from L2 one
+// phase AHEAD of the product that uses them (the ~1 us of a dependent global load would otherwise be paid 16 times per group)
+template <int K, int N> struct TeW { bf16x8_t f[(N / 16 + 3) / 4][K / 32]; };
+template <int K, int N>
+DEVI void te_fetch(TeW<K, N>& w, const unsigned short* __restrict__ W, int lane, int wave) {
+    const int lr = lane & 15, lk = (lane >> 4) * 8, ntb = wave / TE_MP;
+#pragma unroll
+    for (int i = 0; i < (N / 16 + 3) / 4; i++) {
+        const int nt = ntb + 4 * i;
+        if (nt < N / 16) {
+#pragma unroll
+            for (int ks = 0; ks < K / 32; ks++) {
+                const uint4 u = *reinterpret_cast<const uint4*>(W + (long)(nt * 16 + lr) * K + ks * 32 + lk);
+                w.f[i][ks] = *reinterpret_cast<const bf16x8_t*>(&u);
+            }
+        }
+    }
+}
+// out[m][n] (+)= sum_k A[m][k] * W[n][k] + bias[n] for the TE_ROWS rows in LDS; this wave's column tiles nt = wave, wave + 4, ...
+// MODE 0: store; 1: ReLU then store; 2: add to what `out` holds (residual stream)
+template <int K, int N, int MODE>
+DEVI void te_gemm(const unsigned short* A, int pa, const TeW<K, N>& w, const float* bias, unsigned short* out, int po, int lane, int wave) {
+    constexpr int KS = K / 32, NT = N / 16;
+    const int lr = lane & 15, lk = (lane >> 4) * 8, ntb = wave / TE_MP, part = wave % TE_MP;
+    static_assert(TE_MT % TE_MP == 0, "equal row partitions");
+    const int m0 = part * (TE_MT / TE_MP);
+#pragma unroll
+    for (int i = 0; i < (NT + 3) / 4; i++) {
+        const int nt = ntb + 4 * i;
+        if (nt >= NT) break;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nt * 16 + 4 * (lane >> 4));   // (LDS)
+#pragma unroll
+        for (int mj = 0; mj < TE_MT / TE_MP; mj++) {
+            const int mt = m0 + mj;
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const uint4 u = *reinterpret_cast<const uint4*>(A + (mt * 16 + lr) * pa + ks * 32 + lk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[i][ks], *reinterpret_cast<const bf16x8_t*>(&u), acc, 0, 0, 0);
+            }
+            // the product is formed TRANSPOSED (weights as the A operand): the lane holds token mt * 16 + (lane & 15) and the four
+            // consecutive output columns nt * 16 + 4 * (lane >> 4) + r - one 8-byte LDS access per tile instead of four 2-byte ones
+            unsigned short* o = out + (mt * 16 + lr) * po + nt * 16 + 4 * (lane >> 4);
+            float v[4] = { acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w };
+            if (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (MODE == 2) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xFFFF0000u);
+                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xFFFF0000u);
+            }
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)te_to_bf(v[0]) | ((unsigned)te_to_bf(v[1]) << 16),
+                                                      (unsigned)te_to_bf(v[2]) | ((unsigned)te_to_bf(v[3]) << 16));
+        }
+    }
+}
+// LayerNorm over the first D columns of every token row (TE_LT adjacent lanes per token), optional ReLU; src / dst may alias
+template <int D, bool RELU>
+DEVI void te_layer_norm(const unsigned short* src, int ps, unsigned short* dst, int pd, const float* w, const float* b, int tid) {
+    constexpr int DP = (D + 7) & ~7, E = DP / TE_LT;                  // rows are read / written in 16-byte pieces (the pad columns exist)
+    static_assert(E % 8 == 0 && TE_TOK * TE_LT <= TE_THREADS, "one pass");
+    const int t = tid / TE_LT, e0 = (tid % TE_LT) * E;
+    if (t >= TE_TOK) return;
+    float x[E], mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; i += 8) te_load8(src + t * ps + e0 + i, x + i);
+#pragma unroll
+    for (int i = 0; i < E; i++) if (e0 + i < D || D == DP) mean += x[i];
+#pragma unroll
+    for (int m = 1; m < TE_LT; m <<= 1) mean += __shfl_xor(mean, m);
+    mean *= 1.f / D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; i++) { const float c = x[i] - mean; if (e0 + i < D || D == DP) var += c * c; }
+#pragma unroll
+    for (int m = 1; m < TE_LT; m <<= 1) var += __shfl_xor(var, m);
+    const float rstd = rsqrtf(var * (1.f / D) + 1e-5f);
+    const float4* w4 = reinterpret_cast<const float4*>(w + e0);       // (the packed vectors are padded to whole 16-byte pieces)
+    const float4* b4 = reinterpret_cast<const float4*>(b + e0);
+#pragma unroll
+    for (int i = 0; i < E; i += 4) {
+        const float4 wv = w4[i >> 2], bv = b4[i >> 2];
+        const float ww[4] = { wv.x, wv.y, wv.z, wv.w }, bb[4] = { bv.x, bv.y, bv.z, bv.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float y = (e0 + i + k < D || D == DP) ? (x[i + k] - mean) * rstd * ww[k] + bb[k] : 0.f;
+            if (RELU) y = fmaxf(y, 0.f);
+            x[i + k] = y;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E; i += 8) te_store8(dst + t * pd + e0 + i, x + i);
+}
+// 4-head attention inside every board: qkv rows [token][3][head][16] -> out rows [token][head * 16 + d].  One (board, head) per
+// wave pass, on v_mfma_f32_32x32x16_bf16 exactly as k_attn_mfma_fwd (catan_nn.hip) does it: S^T = K Q^T lands with lane = query
+// column and the keys down the registers, so the softmax is in-lane plus one xor-32 exchange, and the probabilities are already
+// the B operand of O^T = V^T P^T; the V^T fragments are gathered from the token-major V rows (2-byte LDS reads).
+DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane, int wave) {
+    const int hf = lane >> 5, c31 = lane & 31;
+    const bool rowok = c31 < TE_L;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int bh = wave; bh < TE_G * TE_H; bh += TE_W) {
+        const int g = bh >> 2, h = bh & 3;
+        const unsigned short* base = qkv + g * TE_L * TE_PQ + h * TE_HD;
+        const bf16x8_t ka = ld_frag<TE_HD>(base + c31 * TE_PQ + TE_D, hf, rowok);
+        const bf16x8_t qb = ld_frag<TE_HD>(base + c31 * TE_PQ, hf, rowok);
+        // V^T: row d = c31 & 15; the keys of k-step s for this lane half are 16 s + 4 hf + {0..3} and 16 s + 8 + 4 hf + {0..3}
+        union { bf16x8_t f; unsigned short u[8]; } va[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                int key = 16 * s + 8 * (e >> 2) + 4 * hf + (e & 3);
+                key = key < TE_L ? key : TE_L - 1;                                   // weight 0 there; the row only has to be finite
+                va[s].u[e] = base[key * TE_PQ + 2 * TE_D + (c31 & 15)];
+            }
+        const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);     // S^T[j][i]
+        float p[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            p[r] = j < TE_L ? st[r] * 0.25f : -INFINITY;                             // 1 / sqrt(16)
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; r++) p[r] *= inv;
+        f32x16_t ot = zero16;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < TE_HD ? va[s].f : zero_bf8(), pack_bf8(p + 8 * s), ot, 0, 0, 0);   // O^T[d][i]
+        if (rowok) st_head<TE_HD>(out + (g * TE_L + c31) * TE_PX + h * TE_HD, ot, hf);
+    }
+}
+
+// tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
+__global__ __launch_bounds__(TE_THREADS) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
+                                                          const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards) {
+    __shared__ __attribute__((aligned(16))) unsigned short X[TE_ROWS * TE_PX];     // residual stream
+    __shared__ __attribute__((aligned(16))) unsigned short Nb[TE_ROWS * TE_PX];    // LayerNorm output / attention output / staged input
+    __shared__ __attribute__((aligned(16))) unsigned short Q[TE_ROWS * TE_PQ];     // Q | K | V; the FFN hidden layer; the output projection
+    __shared__ __attribute__((aligned(16))) float V[TE_VTOTAL];                    // every bias / LayerNorm vector (read in every phase)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* const gvecs = vecs;
+    for (int c = tid; c < TE_VTOTAL / 4; c += TE_THREADS) reinterpret_cast<float4*>(V)[c] = reinterpret_cast<const float4*>(gvecs)[c];
+    {                                                                          // one group of TE_G boards per workgroup
+        const long g0 = (long)blockIdx.x * TE_G;
+        const int nb = (int)(boards - g0 < TE_G ? boards - g0 : TE_G);
+        TeW<64, 64> w0; te_fetch<64, 64>(w0, wts + TE_W0, lane, wave);
+        __syncthreads();
+        // ---- stage the tile features: token rows of 60 bf16 (15 x 8 B), columns 60..63 and the rows beyond the last token zero
+        {
+            constexpr int IT = TE_ROWS * 16 / TE_THREADS;                         // 16 chunks of 4 elements per row; all loads in flight together
+            static_assert(TE_ROWS * 16 % TE_THREADS == 0, "whole passes");
+            uint2 v[IT];
+#pragma unroll
+            for (int i = 0; i < IT; i++) {
+                const int c = tid + i * TE_THREADS, row = c >> 4, ch = c & 15;
+                v[i] = make_uint2(0u, 0u);
+                if (ch < 15 && row < nb * TE_L) v[i] = *reinterpret_cast<const uint2*>(tiles + (g0 * TE_L + row) * TE_IN + ch * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < IT; i++) {
+                const int c = tid + i * TE_THREADS, row = c >> 4, ch = c & 15;
+                *reinterpret_cast<uint2*>(Nb + row * TE_PX + ch * 4) = v[i];
+            }
+        }
+        __syncthreads();
+        // ---- x = relu(LayerNorm(first_layer(tiles)))
+        te_gemm<64, 64, 0>(Nb, TE_PX, w0, V + TE_V0, X, TE_PX, lane, wave);
+        __syncthreads();
+        te_layer_norm<TE_D, true>(X, TE_PX, X, TE_PX, V + TE_V0 + 64, V + TE_V0 + 128, tid);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 0; l < 2; l++) {
+            const unsigned short* wl = wts + TE_WL + l * TE_WL_SIZE;
+            const float* vl = V + TE_VL + l * TE_VL_SIZE;
+            // x = x + out_proj(attention(qkv(LayerNorm(x))))
+            TeW<64, 192> wq; te_fetch<64, 192>(wq, wl, lane, wave);
+            te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl, vl + 64, tid);
+            __syncthreads();
+            te_gemm<64, 192, 0>(Nb, TE_PX, wq, vl + 128, Q, TE_PQ, lane, wave);
+            TeW<64, 64> wo; te_fetch<64, 64>(wo, wl + 192 * 64, lane, wave);
+            __syncthreads();
+            te_attention(Q, Nb, lane, wave);
+            __syncthreads();
+            te_gemm<64, 64, 2>(Nb, TE_PX, wo, vl + 320, X, TE_PX, lane, wave);
+            TeW<64, 128> w1; te_fetch<64, 128>(w1, wl + 192 * 64 + 64 * 64, lane, wave);
+            TeW<128, 64> w2; te_fetch<128, 64>(w2, wl + 192 * 64 + 64 * 64 + 128 * 64, lane, wave);
+            __syncthreads();
+            // x = x + linear2(relu(linear1(LayerNorm(x))))
+            te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl + 384, vl + 448, tid);
+            __syncthreads();
+            te_gemm<64, 128, 1>(Nb, TE_PX, w1, vl + 512, Q, TE_PH, lane, wave);
+            __syncthreads();
+            te_gemm<128, 64, 2>(Q, TE_PH, w2, vl + 640, X, TE_PX, lane, wave);
+            __syncthreads();
+        }
+        // ---- out = relu(LayerNorm25(out_proj(x)))
+        {
+            TeW<64, 32> wp; te_fetch<64, 32>(wp, wts + TE_WP, lane, wave);
+            te_gemm<64, 32, 0>(X, TE_PX, wp, V + TE_VP, Q, TE_PX, lane, wave);
+        }
+        __syncthreads();
+        te_layer_norm<TE_OUT, true>(Q, TE_PX, Q, TE_PX, V + TE_VP + 32, V + TE_VP + 64, tid);
+        __syncthreads();
+        for (int c = tid; c < nb * TE_L * TE_OUT; c += TE_THREADS) {
+            const int t = c / TE_OUT, i = c - t * TE_OUT;
+            out[(g0 * TE_L + t) * TE_OUT + i] = Q[t * TE_PX + i];
+        }
+    }
+}
+
+}  // namespace catan

@@ -221,6 +221,67 @@ def lstm_cell(gx, gh, c_prev, mask=None):
     return _LSTMCell.apply(gx, gh, c_prev, None if mask is None else mask.float().reshape(-1))
 
 
+def _pad2(w, rows, cols):
+    out = torch.zeros((rows, cols), dtype=torch.bfloat16, device=w.device)
+    out[:w.shape[0], :w.shape[1]] = w.to(torch.bfloat16)
+    return out.reshape(-1)
+
+
+def _pad1(v, n):
+    out = torch.zeros((n,), dtype=torch.float32, device=v.device)
+    out[:v.shape[0]] = v.float()
+    return out
+
+
+def tile_encoder_pack(te):
+    """The tile encoder's parameters in the layout of catan_tile_encoder_fwd (include/catan_hip.h), cached on the module and
+    re-packed when a parameter changed (optimiser step, inference-copy refresh)."""
+    params = list(te.parameters())
+    stamp = (sum(p._version for p in params), params[0].device, params[0].data_ptr())
+    cache = getattr(te, "_fused_pack", None)
+    if cache is not None and cache[0] == stamp:
+        return cache[1], cache[2]
+    def lb(bias, n):                                           # a Linear bias as bf16 autocast hands it to the GEMM (rounded once)
+        return _pad1(bias.to(torch.bfloat16), n)
+    with torch.no_grad():
+        w = [_pad2(te.first_layer.weight, 64, 64)]
+        v = [lb(te.first_layer.bias, 64), _pad1(te.norm_2.weight, 64), _pad1(te.norm_2.bias, 64)]
+        for layer in te.encoder_layers:
+            mha, ffn = layer.multi_headed_attention, layer.pointwise_net
+            w += [_pad2(torch.cat([n.weight for n in mha.qkv_nets], 0), 192, 64), _pad2(mha.out_proj_net.weight, 64, 64),
+                  _pad2(ffn.linear1.weight, 128, 64), _pad2(ffn.linear2.weight, 64, 128)]
+            v += [_pad1(layer.sublayers[0].norm.weight, 64), _pad1(layer.sublayers[0].norm.bias, 64),
+                  lb(torch.cat([n.bias for n in mha.qkv_nets], 0), 192), lb(mha.out_proj_net.bias, 64),
+                  _pad1(layer.sublayers[1].norm.weight, 64), _pad1(layer.sublayers[1].norm.bias, 64),
+                  lb(ffn.linear1.bias, 128), lb(ffn.linear2.bias, 64)]
+        w.append(_pad2(te.out_proj.weight, 32, 64))
+        v += [lb(te.out_proj.bias, 32), _pad1(te.norm.weight, 32), _pad1(te.norm.bias, 32)]
+        wts, vecs = torch.cat(w).contiguous(), torch.cat(v).contiguous()
+    L = _lib.lib()
+    assert wts.numel() == L.catan_tile_encoder_weight_elems() and vecs.numel() == L.catan_tile_encoder_vec_elems()
+    te._fused_pack = (stamp, wts, vecs)
+    return wts, vecs
+
+
+def tile_encoder_supported(te, tiles):
+    """inference (no autograd), GPU, bf16 compute, the reference's sizes (19 tiles x 60 features, 64 wide, 4 heads, 2 layers, 25 out)"""
+    if torch.is_grad_enabled() or not tiles.is_cuda or tiles.dim() != 3 or tuple(tiles.shape[1:]) != (19, 60):
+        return False
+    if not (tiles.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return False
+    return (te.first_layer.weight.shape == (64, 60) and len(te.encoder_layers) == 2 and te.out_proj.weight.shape == (25, 64)
+            and te.encoder_layers[0].multi_headed_attention.heads == 4 and te.encoder_layers[0].pointwise_net.linear1.weight.shape == (128, 64))
+
+
+def tile_encoder_forward(te, tiles):
+    """tiles [B, 19, 60] -> bf16 [B, 475]: the whole tile encoder in one kernel (k_tile_encoder_fwd)"""
+    wts, vecs = tile_encoder_pack(te)
+    x = _aligned(tiles.to(torch.bfloat16))
+    out = torch.empty((x.shape[0], 19 * 25), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().catan_tile_encoder_fwd(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), x.shape[0], _stream()))
+    return out
+
+
 _PATTERN_LISTS = {}
 
 

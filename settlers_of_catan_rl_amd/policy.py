@@ -124,6 +124,8 @@ class _TileEncoder(nn.Module):
         self.out_proj = _ortho_linear(dim, out_dim)
 
     def forward(self, tiles):
+        if nn_kernels.tile_encoder_supported(self, tiles):           # inference on the GPU: the whole encoder in one kernel
+            return nn_kernels.tile_encoder_forward(self, tiles)
         x = _ln(self.norm_2, _lin(tiles, self.first_layer.weight, self.first_layer.bias), relu=True)
         for layer in self.encoder_layers:
             x = layer(x)

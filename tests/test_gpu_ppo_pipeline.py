@@ -479,3 +479,49 @@ def test_compact_head_evaluation_on_device(hip_lib):
     assert torch.allclose(out[True][0], out[False][0], atol=2e-4), float((out[True][0] - out[False][0]).abs().max())
     assert abs(out[True][1] - out[False][1]) < 1e-5
     assert torch.allclose(out[True][2], out[False][2], atol=1e-5, rtol=1e-3)
+
+
+def test_fused_tile_encoder_forward_vs_unfused(hip_lib):
+    """k_tile_encoder_fwd (the whole tile encoder in one kernel, inference) against the unfused path: both compute in bf16
+    with fp32 accumulation, so each is compared with the fp32 evaluation of the same module; the fused kernel must be as
+    close to it as the unfused bf16 path is.  Ragged board counts exercise partial groups of 8."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(0)
+    net = CatanPolicy().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    te = net.observation_module.tile_encoder
+    env = VecCatanEnv(1037, seed=3); env.random_rollout(0, 600)
+    f, _, _ = env.get_obs()
+    for B in (1, 7, 8, 9, 1037):
+        tiles = f[:B, 18:18 + 1140].reshape(B, 19, 60)
+        with torch.no_grad():
+            ref32 = te(tiles.float())                                            # fp32, torch ops / fp32 kernels
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert nn_kernels.tile_encoder_supported(te, tiles)
+                fused = te(tiles)
+                saved = nn_kernels.tile_encoder_supported
+                nn_kernels.tile_encoder_supported = lambda *a: False
+                try:
+                    unfused = te(tiles)
+                finally:
+                    nn_kernels.tile_encoder_supported = saved
+        assert fused.shape == (B, 475) and fused.dtype == torch.bfloat16
+        e_f = float((fused.float() - ref32).abs().max()); e_u = float((unfused.float() - ref32).abs().max())
+        assert e_f <= max(2.0 * e_u, 0.06), (B, e_f, e_u)
+        assert float((fused.float() - ref32).abs().mean()) <= max(2.0 * float((unfused.float() - ref32).abs().mean()), 5e-3)
+    # boards are independent of their neighbours in a workgroup and of the grid size: 40 003 boards = the 1 037 repeated, bit-exact
+    big = tiles.repeat(39, 1, 1)[:40003].contiguous()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        fb = te(big)
+    assert torch.equal(fb, fused.repeat(39, 1)[:40003])
+    # a changed parameter re-packs the weights
+    with torch.no_grad():
+        te.norm.bias.add_(1.0)                                                     # (after the ReLU-free LayerNorm: shifts every output)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            again = te(tiles)
+    assert float((again.float() - fused.float()).abs().max()) > 0.5
