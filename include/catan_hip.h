@@ -205,6 +205,12 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
 int catan_linear_rows_supported(int64_t rows, int in_features, int out_features);
 int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
                       catan_stream_t stream);
+/* The same product with an elementwise epilogue fused into its row stores (out a multiple of 8; aux [rows][out] bfloat16,
+ * 16-byte aligned), applied to the bf16-rounded product exactly as the separate op of the unfused net would:
+ *   mode 0: none;  1: ReLU (the FFN's hidden layer, RL/models/ pointwise net);  2: + aux (the residual stream of an encoder
+ *   sub-layer: x + sublayer(norm(x)));  3: zero where aux <= 0 (the backward of a ReLU whose OUTPUT is aux). */
+int catan_linear_rows_fused(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
+                            const void* aux, int mode, catan_stream_t stream);
 
 /* One step of the optional LSTM policy (`include_lstm`, RL/models/policy.py:36-45,113-166: torch.nn.LSTM(512, 256), gate
  * order i, f, g, o): the arithmetic between the step's two GEMMs.  gx = x W_ih^T + b_ih + b_hh and gh = (h_prev*mask) W_hh^T,

@@ -92,6 +92,7 @@ _SIGS = {
     "catan_profile_read_waves": (C.c_int, [_vp, _vp]),
     "catan_linear_rows_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "catan_linear_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "catan_linear_rows_fused": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "catan_categorical_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp]),
     "catan_categorical_bwd": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp]),
     "catan_lstm_cell_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),

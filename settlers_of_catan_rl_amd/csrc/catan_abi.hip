@@ -159,11 +159,11 @@ static int wgrad_dispatch_it(int it, const void* x, const void* dy, float* dw, f
 }
 
 template <int KS>
-static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void* b, void* y, long R, int K, int N, hipStream_t st) {
+static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void* b, void* y, long R, int K, int N, const void* aux, int mode, hipStream_t st) {
     long nb = ((R + 15) / 16 + 3) / 4;
     if (nb > 2048) nb = 2048;
 #define CATAN_LINROWS(NT) hipLaunchKernelGGL((k_linear_rows<KS, NT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, \
-                                             (const unsigned short*)w, (const unsigned short*)b, (unsigned short*)y, R, K, N)
+                                             (const unsigned short*)w, (const unsigned short*)b, (unsigned short*)y, R, K, N, (const unsigned short*)aux, mode)
     if (nt <= 1) CATAN_LINROWS(1);
     else if (nt <= 2) CATAN_LINROWS(2);
     else if (nt <= 4) CATAN_LINROWS(4);
@@ -787,19 +787,26 @@ int catan_linear_rows_supported(int64_t rows, int in_features, int out_features)
     return ks_i * nt_i <= 32;                                // W fragments (4 VGPRs each) must fit the register file
 }
 
-int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
-                      catan_stream_t stream) {
+int catan_linear_rows_fused(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
+                            const void* aux, int mode, catan_stream_t stream) {
     if (!x || !w || !y || !catan_linear_rows_supported(rows, in_features, out_features))
         return fail(CATAN_EINVAL, "catan_linear_rows: bad arguments / unsupported widths (in multiple of 8 and <= 192, out <= 192, ceil(in/32)*ceil(out/16) <= 24)");
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return fail(CATAN_EINVAL, "catan_linear_rows: x, w, y must be 16-byte aligned");
+    if (mode < 0 || mode > 3 || (mode >= 2 && !aux) || (mode != 0 && (out_features & 7)))
+        return fail(CATAN_EINVAL, "catan_linear_rows_fused: mode 0..3; modes 2, 3 need aux; a fused epilogue needs out_features % 8 == 0");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)aux) & 15) return fail(CATAN_EINVAL, "catan_linear_rows: x, w, y, aux must be 16-byte aligned");
     const int ks = (in_features + 31) / 32, nt = (out_features + 15) / 16;
     switch (ks) {
-    case 1: return linrows_dispatch_nt<1>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
-    case 2: return linrows_dispatch_nt<2>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
-    case 3: return linrows_dispatch_nt<3>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
-    case 4: return linrows_dispatch_nt<4>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
-    default: return linrows_dispatch_nt<6>(nt, x, w, bias, y, rows, in_features, out_features, S(stream));
+    case 1: return linrows_dispatch_nt<1>(nt, x, w, bias, y, rows, in_features, out_features, aux, mode, S(stream));
+    case 2: return linrows_dispatch_nt<2>(nt, x, w, bias, y, rows, in_features, out_features, aux, mode, S(stream));
+    case 3: return linrows_dispatch_nt<3>(nt, x, w, bias, y, rows, in_features, out_features, aux, mode, S(stream));
+    case 4: return linrows_dispatch_nt<4>(nt, x, w, bias, y, rows, in_features, out_features, aux, mode, S(stream));
+    default: return linrows_dispatch_nt<6>(nt, x, w, bias, y, rows, in_features, out_features, aux, mode, S(stream));
     }
+}
+
+int catan_linear_rows(const void* x, const void* w, const void* bias, void* y, int64_t rows, int in_features, int out_features,
+                      catan_stream_t stream) {
+    return catan_linear_rows_fused(x, w, bias, y, rows, in_features, out_features, nullptr, 0, stream);
 }
 
 int catan_lstm_cell_fwd(const void* gx, const void* gh, const float* c_prev, const float* mask, float* h_out, float* c_out, int64_t rows,

@@ -516,10 +516,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict_
 // row) are 16 B global loads straight from x, the whole W sits in B-fragment registers for the kernel's lifetime
 // (v_mfma_f32_16x16x32_bf16), and the 16 x N result goes through a small LDS tile so that it leaves as 16 B row stores.
 // HBM-bound by construction: R x (K + N) x 2 B moved once.  bf16 in / out, fp32 accumulate; bias optional.
+// Optional fused epilogue (mode; N a multiple of 8): 1 = ReLU, 2 = + aux (residual stream), 3 = zero where aux <= 0 (the backward of
+// a ReLU whose output is aux) - each applied to the bf16-rounded product exactly as the separate elementwise op would.
+__device__ __forceinline__ unsigned short f2bf_nn(float x) { const __hip_bfloat16 h = __float2bfloat16(x); return *reinterpret_cast<const unsigned short*>(&h); }
 template <int KS, int NT>
 __global__ __launch_bounds__(256) void k_linear_rows(const unsigned short* __restrict__ x, const unsigned short* __restrict__ W,
                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ y,
-                                                     long R, int K, int N) {
+                                                     long R, int K, int N, const unsigned short* __restrict__ aux, int mode) {
     constexpr int NP = NT * 16 + 8;                              // LDS row pitch (elements): 16 B aligned, conflict-light
     __shared__ __attribute__((aligned(16))) unsigned short ot[4][16 * NP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -571,7 +574,23 @@ __global__ __launch_bounds__(256) void k_linear_rows(const unsigned short* __res
             const int cpr = N / 8;                               // chunks per row
             for (int c = lane; c < 16 * cpr; c += 64) {
                 const int row = c / cpr, ch = c - row * cpr;
-                if (r0 + row < R) *reinterpret_cast<uint4*>(y + (r0 + row) * (long)N + ch * 8) = *reinterpret_cast<const uint4*>(o + row * NP + ch * 8);
+                if (r0 + row >= R) continue;
+                uint4 v = *reinterpret_cast<const uint4*>(o + row * NP + ch * 8);
+                if (mode != 0) {                                 // fused epilogue on the (already bf16-rounded) result, as the separate op would see it
+                    uint4 a = make_uint4(0, 0, 0, 0);
+                    if (mode >= 2) a = *reinterpret_cast<const uint4*>(aux + (r0 + row) * (long)N + ch * 8);
+                    unsigned* vw = reinterpret_cast<unsigned*>(&v); const unsigned* aw = reinterpret_cast<const unsigned*>(&a);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float lo = __uint_as_float(vw[i] << 16), hi = __uint_as_float(vw[i] & 0xFFFF0000u);
+                        const float alo = __uint_as_float(aw[i] << 16), ahi = __uint_as_float(aw[i] & 0xFFFF0000u);
+                        if (mode == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }                       // ReLU
+                        else if (mode == 2) { lo += alo; hi += ahi; }                                        // + residual
+                        else { lo = alo > 0.f ? lo : 0.f; hi = ahi > 0.f ? hi : 0.f; }                      // ReLU backward: aux = the ReLU's output
+                        vw[i] = (unsigned)f2bf_nn(lo) | ((unsigned)f2bf_nn(hi) << 16);
+                    }
+                }
+                *reinterpret_cast<uint4*>(y + (r0 + row) * (long)N + ch * 8) = v;
             }
         } else {
             for (int c = lane; c < 16 * N; c += 64) {

@@ -133,16 +133,103 @@ class _LinearTallSkinny(torch.autograd.Function):
 ROWS_KERNEL_MIN_ROWS = 262144      # below this the library GEMM is as fast (measured: 65 536 x 128 x 128: 20 us vs 25 us)
 
 
-def _linear_rows(x, w, b):
-    """x [..., K] @ w[N, K].T (+ b) through k_linear_rows when the shape is in its range, else None."""
+MODE_NONE, MODE_RELU, MODE_ADD, MODE_RELU_MASK = 0, 1, 2, 3
+
+
+def _linear_rows(x, w, b, aux=None, mode=MODE_NONE):
+    """x [..., K] @ w[N, K].T (+ b) through k_linear_rows when the shape is in its range, else None.  mode / aux: the fused
+    epilogue of catan_linear_rows_fused (ReLU, + residual, ReLU-backward mask)."""
     N, K = w.shape
     rows = x.numel() // K
-    if rows < ROWS_KERNEL_MIN_ROWS or not _lib.lib().catan_linear_rows_supported(rows, K, N):
+    if rows < ROWS_KERNEL_MIN_ROWS or not _lib.lib().catan_linear_rows_supported(rows, K, N) or (mode != MODE_NONE and N % 8):
         return None
     x2, w2 = _aligned(x.reshape(rows, K)), _aligned(w)
+    a2 = None if aux is None else _aligned(aux.reshape(rows, N))
     y = torch.empty((rows, N), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().catan_linear_rows(_ptr(x2), _ptr(w2), _ptr(b.contiguous() if b is not None else None), _ptr(y), rows, K, N, _stream()))
+    _lib.check(_lib.lib().catan_linear_rows_fused(_ptr(x2), _ptr(w2), _ptr(b.contiguous() if b is not None else None), _ptr(y), rows, K, N,
+                                                  _ptr(a2), mode, _stream()))
     return y.reshape(x.shape[:-1] + (N,))
+
+
+def _wgrad(x2, dy2, has_bias):
+    O, I = dy2.shape[1], x2.shape[1]
+    acc = torch.zeros((O * I + O,), dtype=torch.float32, device=dy2.device)             # one fill for dw and db
+    dw, db = acc[:O * I].view(O, I), (acc[O * I:] if has_bias else None)
+    _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))
+    return dw, db
+
+
+class _LinearResidual(torch.autograd.Function):
+    """res + (x @ w.T + b): the out-projection of an encoder sub-layer with the residual add fused into the product's row
+    stores (same values as the two separate ops: the product is rounded to bf16 before the add)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res):
+        xb, wb, bb, rb = x.to(torch.bfloat16), w.to(torch.bfloat16), b.to(torch.bfloat16), res.to(torch.bfloat16)
+        y = _linear_rows(xb, wb, bb, rb, MODE_ADD)
+        ctx.save_for_backward(xb, wb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        O, I = wb.shape
+        dy2 = _aligned(dy.reshape(-1, O).to(torch.bfloat16))
+        dx = _linear_rows(dy2, wb.t().contiguous(), None).reshape(xb.shape) if ctx.needs_input_grad[0] else None
+        dw, db = _wgrad(_aligned(xb.reshape(-1, I)), dy2, True)
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
+
+
+class _FFNResidual(torch.autograd.Function):
+    """res + linear2(relu(linear1(x))) (the pointwise net of an encoder layer, reference pointwise_feedforward) as two
+    row-kernel launches: ReLU fused into the first product, the residual add into the second; the backward masks the hidden
+    gradient inside the dX product (aux = the ReLU output) - no elementwise pass touches the [rows, 2 dim] hidden tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        bf = torch.bfloat16
+        xb, w1b, w2b = x.to(bf), w1.to(bf), w2.to(bf)
+        h = _linear_rows(xb, w1b, b1.to(bf), None, MODE_RELU)
+        y = _linear_rows(h, w2b, b2.to(bf), res.to(bf), MODE_ADD)
+        ctx.save_for_backward(xb, h, w1b, w2b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, h, w1b, w2b = ctx.saved_tensors
+        D, F2 = w2b.shape                                          # w2 [dim][hidden]
+        dy2 = _aligned(dy.reshape(-1, D).to(torch.bfloat16))
+        h2 = h.reshape(-1, F2)
+        dh = _linear_rows(dy2, w2b.t().contiguous(), None, h2, MODE_RELU_MASK)           # (dy @ w2) where h > 0
+        dw2, db2 = _wgrad(_aligned(h2), dy2, True)
+        dw1, db1 = _wgrad(_aligned(xb.reshape(-1, D)), dh, True)
+        dx = _linear_rows(dh, w1b.t().contiguous(), None).reshape(xb.shape) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.needs_input_grad[5] else None)
+
+
+def fused_sublayer_supported(x, dim, hidden=None):
+    """training / inference on the GPU in bf16 with enough rows for the row kernels, widths they are built for"""
+    if not x.is_cuda or x.shape[-1] != dim or dim % 8 or x.numel() // dim < ROWS_KERNEL_MIN_ROWS:
+        return False
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+        return False
+    L = _lib.lib()
+    rows = x.numel() // dim
+    ok = L.catan_linear_rows_supported(rows, dim, dim) and L.catan_linear_wgrad_supported(rows, dim, dim)
+    if hidden is not None:
+        ok = ok and hidden % 8 == 0 and L.catan_linear_rows_supported(rows, dim, hidden) and L.catan_linear_rows_supported(rows, hidden, dim) \
+            and L.catan_linear_wgrad_supported(rows, dim, hidden) and L.catan_linear_wgrad_supported(rows, hidden, dim)
+    return bool(ok)
+
+
+def linear_residual(x, w, b, res):
+    with torch.autocast("cuda", enabled=False):
+        return _LinearResidual.apply(x, w, b, res)
+
+
+def ffn_residual(x, w1, b1, w2, b2, res):
+    with torch.autocast("cuda", enabled=False):
+        return _FFNResidual.apply(x, w1, b1, w2, b2, res)
 
 
 def linear_inference(x, w, b=None):

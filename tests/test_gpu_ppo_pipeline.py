@@ -525,3 +525,44 @@ def test_fused_tile_encoder_forward_vs_unfused(hip_lib):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             again = te(tiles)
     assert float((again.float() - fused.float()).abs().max()) > 0.5
+
+
+def test_fused_encoder_sublayers_vs_unfused(hip_lib):
+    """An encoder layer with the residual adds / the FFN's ReLU fused into the row-kernel products (catan_linear_rows_fused,
+    modes 1-3) against the same layer with the separate elementwise ops: the fused epilogues act on the bf16-rounded
+    product exactly as the separate ops do, so outputs and every gradient are identical."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels
+    from settlers_of_catan_rl_amd.policy import _EncoderLayer
+    torch.manual_seed(0)
+    layer = _EncoderLayer(64, 4).cuda()
+    B = 16000                                                                      # x 19 tokens = 304 000 rows (>= the row kernels' minimum)
+    x = torch.randn(B, 19, 64, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(B, 19, 64, device="cuda").to(torch.bfloat16)
+
+    def run():
+        for p in layer.parameters():
+            p.grad = None
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = layer(x)
+        y.backward(g)
+        return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()]
+
+    assert nn_kernels.fused_sublayer_supported(x, 64, 128)
+    y1, dx1, gp1 = run()
+    saved = nn_kernels.fused_sublayer_supported
+    nn_kernels.fused_sublayer_supported = lambda *a, **k: False
+    try:
+        y0, dx0, gp0 = run()
+    finally:
+        nn_kernels.fused_sublayer_supported = saved
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))      # (fp32 atomics: order of the row chunks)
+    # and the kernel's argument checks
+    import ctypes as C
+    L = hip_lib
+    t = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    assert L.catan_linear_rows_fused(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None, C.c_void_p(t.data_ptr()), 64, 64, 64, None, 2, None) != 0
+    assert L.catan_linear_rows_fused(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None, C.c_void_p(t.data_ptr()), 64, 64, 64, None, 4, None) != 0

@@ -1,0 +1,25 @@
+import os, sys
+sys.path.insert(0, '/root/repo')
+import torch
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd.policy import CatanPolicy
+from settlers_of_catan_rl_amd import nn_kernels, spec
+MB = 204800; B = 65536
+env = VecCatanEnv(B, seed=0); env.random_rollout(0, 500)
+f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+net = CatanPolicy().cuda(); nn_kernels.use_tuned_gemms()
+rep = 4
+fm, lm, nm, mm = (t.repeat((rep,) + (1,) * (t.dim() - 1))[:MB] for t in (f, lists, lens, masks))
+fm = fm.to(torch.bfloat16)
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+    _, acts, _ = net.act(fm, lm, nm, mm)
+torch.cuda.synchronize()
+import ctypes
+from settlers_of_catan_rl_amd import _lib
+for it in range(5):
+    if it == 1:
+        torch.cuda.synchronize(); print("MARK", flush=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v, lp, ent = net.evaluate_actions(fm, lm, nm, mm, acts)
+    (v.float().sum() + lp.float().sum() + ent).backward()
+torch.cuda.synchronize()
