@@ -146,7 +146,10 @@ static int wgrad_launch(const void* x, const void* dy, float* dw, float* db, lon
     long nb = stages / 8 < 1 ? 1 : (stages / 8 < 1024 ? stages / 8 : 1024);
     long per = (stages + nb - 1) / nb * WG_KT;
     nb = (R + per - 1) / per;
-    hipLaunchKernelGGL((k_wgrad<OTW, IT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, I, O, per);
+    if ((I & 7) == 0 && (O & 7) == 0)      // 16 B vectors never straddle a row: row-major LDS image + transposing LDS reads
+        hipLaunchKernelGGL((k_wgrad_tr<OTW, IT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, I, O, per);
+    else
+        hipLaunchKernelGGL((k_wgrad<OTW, IT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, I, O, per);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

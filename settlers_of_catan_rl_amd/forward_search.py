@@ -131,16 +131,20 @@ class GraphedAct(object):
     padding and ignored.  Sampling uses torch's default CUDA generator, which graphs advance correctly.  Falls back to the
     eager call if capture is unavailable."""
 
-    def __init__(self, policy, buckets=(512, 4096, 16384), autocast_dtype=None, deterministic=False):
+    def __init__(self, policy, buckets=(512, 4096, 16384), autocast_dtype=None, deterministic=False, generator=None):
+        """generator: the CUDA torch.Generator the sampling draws from (registered with every captured graph, so replays
+        advance it as eager calls would); None = torch's default CUDA generator."""
         self.policy, self.buckets, self.autocast_dtype, self.deterministic = policy, tuple(sorted(buckets)), autocast_dtype, deterministic
+        self.generator = generator
         self.graphs = {}
         self.failed = False
 
     def _run(self, f, lists, lens, masks):
+        kw = {} if self.generator is None else {"generator": self.generator}
         if self.autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
-                return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic)
-        return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic)
+                return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic, **kw)
+        return self.policy.act(f, lists, lens, masks, deterministic=self.deterministic, **kw)
 
     def _capture(self, B, f, lists, lens, masks):
         st = {"f": f[:1].expand(B, -1).clone(), "lists": lists[:1].expand(B, -1, -1).clone(),
@@ -152,29 +156,37 @@ class GraphedAct(object):
                 self._run(st["f"], st["lists"], st["lens"], st["masks"])
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
+        if self.generator is not None:
+            g.register_generator_state(self.generator)
         with torch.cuda.graph(g):
-            v, a, _ = self._run(st["f"], st["lists"], st["lens"], st["masks"])
-        st["g"], st["v"], st["a"] = g, v, a
+            v, a, lp = self._run(st["f"], st["lists"], st["lens"], st["masks"])[:3]
+        st["g"], st["v"], st["a"], st["lp"] = g, v, a, lp
         return st
 
-    def __call__(self, f, lists, lens, masks):
-        """-> (value [n,1], actions [n,18]) for n rows; eager when n exceeds the largest bucket."""
+    def __call__(self, f, lists, lens, masks, with_logp=False):
+        """-> (value [n,1], actions [n,18]) (+ log-prob [n,1] with `with_logp`) for n rows; eager when n exceeds the largest
+        bucket."""
         n = f.shape[0]
         B = next((b for b in self.buckets if n <= b), None)
         if B is None or self.failed or not f.is_cuda:
-            v, a, _ = self._run(f, lists, lens, masks)
-            return v, a
+            v, a, lp = self._run(f, lists, lens, masks)[:3]
+            return (v, a, lp) if with_logp else (v, a)
         if B not in self.graphs:
             try:
                 self.graphs[B] = self._capture(B, f, lists, lens, masks)
             except Exception:                                   # capture not available: stay eager
                 self.failed = True
                 torch.cuda.synchronize()
-                v, a, _ = self._run(f, lists, lens, masks)
-                return v, a
+                v, a, lp = self._run(f, lists, lens, masks)[:3]
+                return (v, a, lp) if with_logp else (v, a)
         st = self.graphs[B]
+        refresh = getattr(self.policy, "refresh_kernel_packs", None)
+        if refresh is not None:
+            refresh()                                           # host-side parameter packs a replay would not rebuild
         st["f"][:n] = f; st["lists"][:n] = lists; st["lens"][:n] = lens; st["masks"][:n] = masks
         st["g"].replay()
+        if with_logp:
+            return st["v"][:n].clone(), st["a"][:n].clone(), st["lp"][:n].clone()
         return st["v"][:n].clone(), st["a"][:n].clone()
 
 

@@ -346,6 +346,10 @@ def tile_encoder_pack(te):
         wts, vecs = torch.cat(w).contiguous(), torch.cat(v).contiguous()
     L = _lib.lib()
     assert wts.numel() == L.catan_tile_encoder_weight_elems() and vecs.numel() == L.catan_tile_encoder_vec_elems()
+    if cache is not None and cache[1].device == wts.device:
+        # re-pack IN PLACE: a captured hipGraph of the forward (GraphedAct) holds these buffers' addresses
+        cache[1].copy_(wts); cache[2].copy_(vecs)
+        wts, vecs = cache[1], cache[2]
     te._fused_pack = (stamp, wts, vecs)
     return wts, vecs
 

@@ -623,6 +623,13 @@ class CatanPolicy(nn.Module):
                         prm.data = prm.data.to(dtype)
         return c
 
+    def refresh_kernel_packs(self):
+        """Brings the parameter packs the fused kernels read (the tile encoder's, nn_kernels.tile_encoder_pack) up to date, in
+        place - what a forward would do on its way; a captured hipGraph replay (GraphedAct) does not run that host code."""
+        te = self.observation_module.tile_encoder
+        if next(te.parameters()).is_cuda and getattr(te, "_fused_pack", None) is not None:
+            nn_kernels.tile_encoder_pack(te)
+
     @torch.no_grad()
     def load_from(self, master):
         """Copies (and casts) the parameters of `master` into this copy."""

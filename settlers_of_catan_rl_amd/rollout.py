@@ -53,7 +53,9 @@ def pack_action_masks(m):
 
 
 class RolloutCollector(object):
-    def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None):
+    GRAPH_ACT_MIN_GAMES = 8192
+
+    def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None, graph_act=None):
         """policy: central net (policy 0); opponents: list of up to 3 nets for policy slots 1..3 of every game (None =
         every seat plays the central policy).  A league (league.League.assign) installs per-game opponents instead."""
         self.env, self.policy, self.T = env, policy, num_steps
@@ -77,6 +79,13 @@ class RolloutCollector(object):
         self.active_pid = (perm[:, 0] + 1).to(self.device)                                  # PlayerId 1..4
         self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
         self.recurrent = bool(getattr(policy, "include_lstm", False))
+        # Self-play with one feed-forward net: the policy pass of an env iteration is ~500 small launches and host-bound
+        # (7.0 ms of host time for 5.3 ms of kernels at 65 536 rows) - replayed as one captured hipGraph instead
+        # (forward_search.GraphedAct; sampling draws from the same registered generator).  graph_act: None = automatic.
+        if graph_act is None:
+            graph_act = (torch.device(self.device).type == "cuda" and not self.recurrent and hasattr(policy, "refresh_kernel_packs")
+                         and self.N >= self.GRAPH_ACT_MIN_GAMES)
+        self.graph_act, self._graphed = bool(graph_act), None
         self.lstm_size = int(policy.lstm_size) if self.recurrent else 0
         # Under autocast the net casts its inputs to the autocast dtype before the first GEMM anyway, and every observation
         # value is a small multiple of 1/8 (exact in bf16): the rollout tensors are kept in that dtype - half the HBM
@@ -217,7 +226,12 @@ class RolloutCollector(object):
             if self.recurrent:
                 sel = slice(None) if idx is None else idx
                 kw.update(hidden=(h_in[sel], c_in[sel]), nonterminal=term[sel])
-            if self.autocast_dtype is not None:
+            if idx is None and self.graph_act and not self.recurrent:
+                if self._graphed is None or self._graphed.policy is not net:
+                    from .forward_search import GraphedAct
+                    self._graphed = GraphedAct(net, buckets=(N,), autocast_dtype=self.autocast_dtype, generator=self.sample_gen)
+                res = self._graphed(f, lists, lens, masks, with_logp=True)
+            elif self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                     res = net.act(*args, **kw)
             else:

