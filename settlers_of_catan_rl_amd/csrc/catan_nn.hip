@@ -980,12 +980,19 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     const float scale = HD == 16 ? 0.25f : 0.5f;
     float* stat = &Stat[wv][0][0];
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+    // every head's row fragments are requested up front: with one or two waves per SIMD (the LDS tiles cap the occupancy) a
+    // load issued inside the head loop is ~2 us of exposed latency per head
+    bf16x8_t qr_[H], kr_[H], vr_[H], gr_[H];
+#pragma unroll
     for (int h = 0; h < H; h++) {
-        const bf16x8_t qr = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);            // row c31 of Q, K, V, dO
-        const bf16x8_t kr = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
-        const bf16x8_t vr = ld_frag<HD>(base + (c31 * 3 + 2) * D + h * HD, hf, rowok);
-        const bf16x8_t gr = ld_frag<HD>(dob + c31 * D + h * HD, hf, rowok);
+        qr_[h] = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);                         // row c31 of Q, K, V, dO
+        kr_[h] = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
+        vr_[h] = ld_frag<HD>(base + (c31 * 3 + 2) * D + h * HD, hf, rowok);
+        gr_[h] = ld_frag<HD>(dob + c31 * D + h * HD, hf, rowok);
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        const bf16x8_t qr = qr_[h], kr = kr_[h], vr = vr_[h], gr = gr_[h];
         const int trow = (h * HD + (c31 % HD)) * AT_LP;                                            // this lane's transposed row (dim d)
         // ---- lane = query i, registers = keys j
         {

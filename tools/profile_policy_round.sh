@@ -1,9 +1,9 @@
 #!/bin/bash
 # Learner-side profiles on the MI355X box: kernel-trace statistics of the policy training step, then the MFMA-busy counter in
-# its own pass (no trace domains with --pmc).  Outputs: gpurun_out/prof_policy_r01.
+# its own pass (no trace domains with --pmc).  Outputs: gpurun_out/prof_policy_r02.
 set -u
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_policy_r01
+OUT=$REPO/gpurun_out/prof_policy_r02
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
