@@ -269,7 +269,7 @@ class _Head(nn.Module):
             parts.append(_ln(self.custom_norm, _lin(custom, self.custom_mlp.weight, self.custom_mlp.bias), relu=True))
         if parts:
             e = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
-            pre = pre + F.linear(e.to(pre.dtype), self.mlp_1.weight[:, self.mlp_1.in_features - e.shape[-1]:])
+            pre = pre + _lin(e.to(pre.dtype), self.mlp_1.weight[:, self.mlp_1.in_features - e.shape[-1]:])     # (tall-skinny weight gradient: 2..12 columns x 10^4..10^5 rows)
         # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
         h = _lin(_ln(self.norm, pre, relu=True), self.mlp_2.weight, self.mlp_2.bias)
         return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
