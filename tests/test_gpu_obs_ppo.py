@@ -217,6 +217,19 @@ def test_ppo_loss_vs_reference(oracle, hip_lib):
         assert abs(float(losses[1]) - float(g[f"ppo{ci}_value_loss"])) < 1e-5
         assert np.allclose(logp.grad.cpu().numpy(), g[f"ppo{ci}_dlogp"], atol=1e-6)
         assert np.allclose(v.grad.cpu().numpy(), g[f"ppo{ci}_dv"], atol=1e-6)
+    # the reference's OWN PPO.update (ppo.py:26-79, driven by tools/gen_golden.py with stub storage / actor-critic): losses as it
+    # returns them and the gradients its backward hands to the values / log-probs, value normaliser (lines 46-48) on and off
+    for ci in range(3):
+        t = {k: torch.from_numpy(g[f"ppoU{ci}_{k}"]).cuda() for k in ("logp", "old", "adv", "v", "v_old", "ret")}
+        logp = t["logp"].clone().requires_grad_(True); v = t["v"].clone().requires_grad_(True)
+        coef = float(g["ppoU_value_loss_coef"])
+        total, losses = ppo.ppo_loss(logp, v, t["old"], t["adv"], t["v_old"], t["ret"], float(g["ppoU_clip"]), coef,
+                                     value_normaliser=(150.0, 150.0) if int(g[f"ppoU{ci}_use_norm"]) else None)
+        total.backward()
+        assert abs(float(losses[0]) - float(g[f"ppoU{ci}_action_loss"])) < 1e-5
+        assert abs(float(losses[1]) * coef - float(g[f"ppoU{ci}_value_loss_x_coef"])) < 1e-5
+        assert np.allclose(logp.grad.cpu().numpy(), g[f"ppoU{ci}_dlogp"], atol=1e-7, rtol=1e-4)
+        assert np.allclose(v.grad.cpu().numpy(), g[f"ppoU{ci}_dv"], atol=1e-7, rtol=1e-3)
     # value normaliser path (ppo.py:46-48) against plain torch fp32 at the cfg-3 minibatch size
     B = 204800
     gen = torch.Generator(device="cuda").manual_seed(2)

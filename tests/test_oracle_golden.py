@@ -134,6 +134,19 @@ def test_gae_and_ppo_loss(oracle):
         assert np.allclose(dl, g[f"ppo{ci}_dlogp"], atol=1e-6)
         assert np.allclose(dv, g[f"ppo{ci}_dv"], atol=1e-6)
 
+    # the reference's own PPO.update (ppo.py:26-79) on one minibatch: gradients seen by hooks on the values / log-probs, the
+    # returned losses (value x coef, action); the value normaliser of lines 46-48 is applied here as the reference's class does
+    for ci in range(3):
+        norm = (lambda x: (x - 150.0) / (150.0 + 1e-4)) if int(g[f"ppoU{ci}_use_norm"]) else (lambda x: x)
+        coef = float(g["ppoU_value_loss_coef"])
+        la, lv, dl, dv = oracle.ppo_loss(g[f"ppoU{ci}_logp"], g[f"ppoU{ci}_old"], g[f"ppoU{ci}_adv"], g[f"ppoU{ci}_v"],
+                                         norm(g[f"ppoU{ci}_v_old"].astype(np.float64)).astype(np.float32),
+                                         norm(g[f"ppoU{ci}_ret"].astype(np.float64)).astype(np.float32), float(g["ppoU_clip"]), coef)
+        assert abs(la - float(g[f"ppoU{ci}_action_loss"])) < 1e-5
+        assert abs(lv * coef - float(g[f"ppoU{ci}_value_loss_x_coef"])) < 1e-5
+        assert np.allclose(dl, g[f"ppoU{ci}_dlogp"], atol=1e-7, rtol=1e-4)
+        assert np.allclose(dv, g[f"ppoU{ci}_dv"], atol=1e-7, rtol=1e-3)
+
 
 def test_state_layout_constants(oracle):
     assert spec.STATE_WORDS == oracle.STATE_WORDS == 736

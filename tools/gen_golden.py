@@ -232,6 +232,56 @@ def gen_gae_ppo():
             out[f"ppo{ci}_{k}"] = t.detach().numpy()[:, 0]
         out[f"ppo{ci}_action_loss"] = action_loss.item(); out[f"ppo{ci}_value_loss"] = value_loss.item()
         out[f"ppo{ci}_dlogp"] = logp.grad.numpy()[:, 0]; out[f"ppo{ci}_dv"] = v.grad.numpy()[:, 0]
+    # the reference's OWN PPO.update (RL/ppo/ppo.py:26-79) on one minibatch: stub storage + stub actor-critic whose values /
+    # log-probs are parameters, so the hooks see d(loss)/d(values), d(loss)/d(log-probs) of lines 46-66 incl. the value
+    # normaliser lines 46-48 (the reference's ValueFunctionNormaliser) and the returned (value, action, entropy) losses
+    from RL.ppo.ppo import PPO
+    from RL.models.utils import ValueFunctionNormaliser
+    for ci, (B, use_norm) in enumerate([(96, True), (3000, True), (500, False)]):
+        g = torch.Generator().manual_seed(100 + ci)
+        lp0 = torch.randn(B, 1, generator=g) * 0.5 - 3
+        v0 = torch.randn(B, 1, generator=g)
+        old = lp0 + torch.randn(B, 1, generator=g) * 0.3
+        adv = torch.randn(B, 1, generator=g)
+        scale = (lambda x: 150 + 150 * x) if use_norm else (lambda x: x)
+        v_old = scale(v0 + torch.randn(B, 1, generator=g) * 0.3)
+        ret = scale(torch.randn(B, 1, generator=g))
+        grads = {}
+
+        class AC(torch.nn.Module):
+            include_lstm = False
+
+            def __init__(self):
+                super().__init__()
+                self.use_value_normalisation = use_norm
+                self.value_normaliser = ValueFunctionNormaliser(mean=150.0, std=150.0)
+                self.v = torch.nn.Parameter(v0.clone()); self.lp = torch.nn.Parameter(lp0.clone())
+                self.ent = torch.nn.Parameter(torch.tensor(0.7))
+                self.v.register_hook(lambda gr: grads.__setitem__("dv", gr.clone()))
+                self.lp.register_hook(lambda gr: grads.__setitem__("dlogp", gr.clone()))
+
+            def evaluate_actions(self, obs, rec, masks, actions, action_masks):
+                return self.v * 1.0, self.lp * 1.0, self.ent * 1.0, None
+
+        class Storage:
+            num_parallel = 1; num_steps = B
+
+            def compute_advantages_alt(self, ac, n):
+                pass
+
+            def generator_standard(self, num_mini_batch):
+                yield ({}, None, None, None, v_old, ret, None, old, adv)
+
+        a = types.SimpleNamespace(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, value_loss_coef=0.5, entropy_coef_start=0.01,
+                                  max_grad_norm=0.5, recompute_returns=True, gamma=0.999, gae_lambda=0.95, lr=1e-4, eps=1e-5, truncated_seq_len=10)
+        agent = PPO(AC(), a)
+        vl, al, el = agent.update(Storage())
+        for k, t in dict(logp=lp0, old=old, adv=adv, v=v0, v_old=v_old, ret=ret).items():
+            out[f"ppoU{ci}_{k}"] = t.numpy()[:, 0]
+        out[f"ppoU{ci}_value_loss_x_coef"] = vl; out[f"ppoU{ci}_action_loss"] = al; out[f"ppoU{ci}_entropy_x_coef"] = el
+        out[f"ppoU{ci}_dlogp"] = grads["dlogp"].numpy()[:, 0]; out[f"ppoU{ci}_dv"] = grads["dv"].numpy()[:, 0]
+        out[f"ppoU{ci}_use_norm"] = np.int32(use_norm)
+    out["ppoU_value_loss_coef"] = 0.5; out["ppoU_clip"] = 0.2
     np.savez_compressed(os.path.join(OUT, "gae_ppo.npz"), **out)
 
 
@@ -426,6 +476,8 @@ if __name__ == "__main__":
         print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
         print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gae_ppo":
+        gen_gae_ppo(); print("gae/ppo"); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
         gen_league(); print("league"); sys.exit(0)
     gen_topology(); print("topology")
