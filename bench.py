@@ -74,6 +74,47 @@ def cpu_baseline(sample_envs=16384, sample_steps=2048):
     }
 
 
+def live_pmc_traffic(kernel, timeout_s=150):
+    """HBM bytes per launch of `kernel`, MEASURED NOW: the two counter passes MI355X_MICROARCH.md prescribes (rocprofv3 --pmc
+    FETCH_SIZE, then --pmc WRITE_SIZE; never combined with a trace domain) over tools/pmc_workload.py - the same 65 536 games
+    after the same kind of pre-roll, plus k_calib_copy launches of exactly known traffic that calibrate the counter units -
+    summarised by tools/pmc_summarise.py (mean over the last 96 launches).  Returns (bytes, note) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = tempfile.mkdtemp(prefix="catan_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, sub), "-o", "pmc", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py")],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with {r.returncode}"
+        summ = os.path.join(out, "pmc_summary.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summarise.py"), summ, os.path.join(out, "fetch"),
+                            os.path.join(out, "write")], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+        if r.returncode != 0 or not os.path.exists(summ):
+            return None, "pmc_summarise failed"
+        with open(summ) as f:
+            pm = json.load(f)
+        v = pm.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        if v is None:
+            return None, f"no counters for {kernel}"
+        cal = pm.get("calibration", {})
+        return v, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py "
+                   f"(65 536 games, same pre-roll, last 96 launches of {kernel}), units calibrated on k_calib_copy "
+                   f"({cal.get('bytes_per_FETCH_SIZE_unit', 0):.0f} B per FETCH_SIZE unit, {cal.get('bytes_per_WRITE_SIZE_unit', 0):.0f} B per WRITE_SIZE unit)")
+    except Exception as e:                                   # (timeouts included) - the bench line must still be printed
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 PREROLL_PASSES = 8192        # untimed deferred passes before --warmup: several game lengths, so that the games' ages are mixed
 MIN_TIMED_S = 0.30           # the timed region is `reps` x --steps passes, reps chosen so that it lasts at least this long
 
@@ -125,6 +166,7 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="games per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1)")
     ap.add_argument("--no-validate", action="store_true", help="skip the mask-bit legality check in k_step")
     ap.add_argument("--window", type=int, default=32,
                     help="W > 0: deferred loop, tier-2 longest road + re-deals once per W passes; 0: lock-step loop")
@@ -218,12 +260,17 @@ def main():
         achieved = ALGO_BYTES[dom] * n * active / (per_launch_us[dom] * 1e-6) / 1e9
         fast_us = sum(per_launch_us[k] for k in FAST_PATH)
         traffic, traffic_src = None, None
-        if os.path.exists(PMC_SUMMARY):
+        if world == 1 and n == 65536 and not args.no_live_pmc:     # (the counter workload runs the BASELINE size)
+            traffic, traffic_src = live_pmc_traffic(dom)
+            if traffic is None:
+                traffic_src = f"live counter passes unavailable ({traffic_src}); "
+        if traffic is None and os.path.exists(PMC_SUMMARY):
+            live_note = traffic_src or ""
             with open(PMC_SUMMARY) as f:
                 pm = json.load(f)
             k = pm.get("kernels", {}).get(dom, {})
             traffic = k.get("hbm_bytes_per_launch")
-            traffic_src = (f"steady-state PMC of the same kernel, NOT collected in this run (counters need rocprofv3): "
+            traffic_src = live_note + (f"steady-state PMC of the same kernel, NOT collected in this run: "
                            f"{os.path.relpath(PMC_SUMMARY, ROOT)}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated, "
                            f"65 536 games after the same pre-roll")
         per_step_bytes = sum(ALGO_BYTES[k] for k in FAST_PATH)

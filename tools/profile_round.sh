@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 python $REPO/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --no-cpu-baseline --ppo-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --no-cpu-baseline --no-live-pmc --ppo-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $REPO/tools/pmc_workload.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $REPO/tools/pmc_workload.py > $OUT/pmc_write.log 2>&1
