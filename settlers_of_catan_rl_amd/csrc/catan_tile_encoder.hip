@@ -154,7 +154,6 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
     const int hf = lane >> 5, c31 = lane & 31;
     const bool rowok = c31 < TE_L;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
     for (int bh = wave; bh < TE_G * TE_H; bh += TE_W) {
         const int g = bh >> 2, h = bh & 3;
         const unsigned short* base = qkv + g * TE_L * TE_PQ + h * TE_HD;
