@@ -3,25 +3,25 @@
 // kernel for inference (acting in rollouts and evaluation, the value passes of a PPO update, forward search).
 //
 // Unfused, every op of the encoder streams a [boards x 19, 64..192] activation tensor through HBM: ~14 GB per layer at
-// 204 800 boards, 7.7 ms for the forward.  Here a workgroup (8 waves) takes 8 boards = 152 tokens through the whole encoder
-// in LDS: HBM sees the 2 280 B of tile features per board once and 950 B of output; the 142 KB of weights come from L2
-// (18 KB per board), the 6.8 KB of bias / LayerNorm vectors are copied to LDS once per workgroup.  All per-token linear layers
-// run on v_mfma_f32_16x16x32_bf16: the 152 tokens are 10 row tiles of 16 (8 padding rows); a wave owns every fourth
-// 16-column tile of a layer's output for one half of the rows, holds that tile's weight fragments in registers - fetched one
-// phase ahead of the product that uses them - and walks its 5 row tiles (fragments = 16-byte LDS reads).  The product is
-// formed transposed (weights as the A operand) so a lane ends up with 4 consecutive columns of one token: 8-byte epilogue
-// accesses.  LayerNorm is two lanes per token, the 19 x 19 attention one (board, head) per wave pass on
-// v_mfma_f32_32x32x16_bf16 (S^T = K Q^T, in-lane softmax, O^T = V^T P^T).
-// Measured (MI355X, 204 800 boards): 2.7 ms; SQ counters put the VALU floor of this instruction stream at ~1.35 ms, the rest
-// is exposed L2 latency (tile staging, weight fragments) with one workgroup per CU (114 KB of LDS).
+// 204 800 boards, 7.7 ms for the forward.  Here a workgroup (4 waves) takes 5 boards = 95 tokens through the whole encoder
+// in LDS (73 KB: two workgroups per CU, so that one computes while the other waits for L2): HBM sees the 2 280 B of tile
+// features per board once and 950 B of output; the 142 KB of weights come from L2 (29 KB per board), the 6.8 KB of bias /
+// LayerNorm vectors are copied to LDS once per workgroup.  All per-token linear layers run on v_mfma_f32_16x16x32_bf16: the 95
+// tokens are 6 row tiles of 16 (one padding row); a wave owns every fourth 16-column tile of a layer's output, holds that
+// tile's weight fragments in registers - fetched one phase ahead of the product that uses them - and walks the row tiles
+// (fragments = 16-byte LDS reads).  The product is formed transposed (weights as the A operand) so a lane ends up with 4
+// consecutive columns of one token: 8-byte epilogue accesses.  LayerNorm is two lanes per token, the 19 x 19 attention one
+// (board, head) per wave pass on v_mfma_f32_32x32x16_bf16 (S^T = K Q^T, in-lane softmax, O^T = V^T P^T).
+// Measured (MI355X, 204 800 boards): 2.4 ms (8 boards per 512-thread workgroup, one workgroup per CU: 2.7 ms; SQ counters put
+// the VALU floor of that instruction stream at ~1.35 ms, 60 % of its wave-cycles were waits on L2: tile staging, weights).
 // Numerics: bf16 storage between the ops (as the unfused bf16-autocast path stores them), fp32 accumulation, fp32 softmax
 // and LayerNorm statistics.
 #pragma once
 
 namespace catan {
 
-constexpr int TE_G = 8, TE_L = 19, TE_TOK = TE_G * TE_L, TE_MT = (TE_TOK + 15) / 16, TE_ROWS = TE_MT * 16;    // 152 tokens, 10 tiles, 160 rows
-constexpr int TE_THREADS = 512, TE_W = TE_THREADS / 64, TE_MP = TE_W / 4;    // waves per workgroup; row partitions of a product
+constexpr int TE_G = 5, TE_L = 19, TE_TOK = TE_G * TE_L, TE_MT = (TE_TOK + 15) / 16, TE_ROWS = TE_MT * 16;    // 95 tokens, 6 tiles, 96 rows
+constexpr int TE_THREADS = 256, TE_W = TE_THREADS / 64, TE_MP = TE_W / 4;    // waves per workgroup; row partitions of a product
 constexpr int TE_LT = TE_THREADS >= 4 * TE_TOK ? 4 : 2;                       // lanes per token in a LayerNorm
 constexpr int TE_IN = 60, TE_D = 64, TE_F = 128, TE_OUT = 25, TE_H = 4, TE_HD = 16;
 constexpr int TE_PX = TE_D + 8, TE_PQ = 3 * TE_D + 8, TE_PH = TE_F + 8;      // LDS row pitches (bf16 elements; 16 B aligned rows)
@@ -194,7 +194,7 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
 }
 
 // tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
-__global__ __launch_bounds__(TE_THREADS) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
+__global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
                                                           const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards) {
     __shared__ __attribute__((aligned(16))) unsigned short X[TE_ROWS * TE_PX];     // residual stream
     __shared__ __attribute__((aligned(16))) unsigned short Nb[TE_ROWS * TE_PX];    // LayerNorm output / attention output / staged input

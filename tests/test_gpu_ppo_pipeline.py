@@ -485,7 +485,7 @@ def test_compact_head_evaluation_on_device(hip_lib):
 def test_fused_tile_encoder_forward_vs_unfused(hip_lib):
     """k_tile_encoder_fwd (the whole tile encoder in one kernel, inference) against the unfused path: both compute in bf16
     with fp32 accumulation, so each is compared with the fp32 evaluation of the same module; the fused kernel must be as
-    close to it as the unfused bf16 path is.  Ragged board counts exercise partial groups of 8."""
+    close to it as the unfused bf16 path is.  Ragged board counts exercise partial groups of boards."""
     import torch
     from settlers_of_catan_rl_amd import nn_kernels
     from settlers_of_catan_rl_amd.env import VecCatanEnv
