@@ -660,7 +660,7 @@ class PPO(object):
         self.max_grad_norm, self.recompute_returns = args.max_grad_norm, getattr(args, "recompute_returns", True)
         self.gamma, self.gae_lambda = args.gamma, args.gae_lambda
         self.optimiser = torch.optim.Adam(actor_critic.parameters(), lr=args.lr, eps=args.eps)
-        self.bucket = cdist.GradBucket(actor_critic.parameters())     # persistent flat gradient buffer (one all-reduce per step)
+        self.bucket = cdist.GradBucket(actor_critic.parameters(), assign_when_single_rank=True)     # persistent flat gradient buffer (one all-reduce per step)
         self.timings = {}
 
     def update(self, rollout_storage):

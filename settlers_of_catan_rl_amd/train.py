@@ -71,7 +71,7 @@ class PPOTrainer(object):
         self.optimiser = torch.optim.Adam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)   # ppo.py:23
         # gradients live in one persistent flat buffer with a fixed layout (dist.GradBucket): the all-reduce of a step is one
         # collective on that buffer, and zeroing the gradients is one memset
-        self.bucket = cdist.GradBucket(policy.parameters())
+        self.bucket = cdist.GradBucket(policy.parameters(), assign_when_single_rank=True)
         dev = next(policy.parameters()).device
         self._sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
         self.gen = torch.Generator(device=dev).manual_seed(seed + 17 * (1 + (torch.distributed.get_rank()

@@ -1,0 +1,43 @@
+"""Diagnostics (GPU box): torch-profiler view of real PPOTrainer minibatch steps at config 3 (65 536 games x T = 200):
+wall time per step, device time per step and the ops outside the net's forward / backward (gathers, mask unpacking,
+loss, gradient clipping, Adam)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd.policy import CatanPolicy
+from settlers_of_catan_rl_amd.rollout import RolloutCollector
+from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+N, T = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+env = VecCatanEnv(N, seed=0); env.random_rollout(0, 500)
+net = CatanPolicy().cuda()
+col = RolloutCollector(env, net, T, seed=1, autocast_dtype=torch.bfloat16)
+st = col.gather_rollouts()
+tr = PPOTrainer(net, PPOConfig(ppo_epoch=1, num_mini_batch=64), autocast_dtype=torch.bfloat16, seed=3)
+class Stop(Exception): pass
+calls = [0]
+orig = tr.optimiser.step
+prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+NS = 4
+def step(*a, **k):
+    r = orig(*a, **k)
+    calls[0] += 1
+    if calls[0] == 4:
+        torch.cuda.synchronize(); prof.__enter__(); step.t0 = time.perf_counter()
+    if calls[0] == 4 + NS:
+        torch.cuda.synchronize(); step.t1 = time.perf_counter(); prof.__exit__(None, None, None); raise Stop()
+    return r
+tr.optimiser.step = step
+try:
+    tr.update(st)
+except Stop:
+    pass
+print("ms per minibatch step under the profiler: %.2f" % ((step.t1 - step.t0) / NS * 1e3))
+ev = prof.key_averages()
+kern = [e for e in ev if e.device_type is not None and str(e.device_type).endswith("CUDA")]
+print("kernel time per step: %.2f ms in %.0f launches" % (sum(e.self_device_time_total for e in kern) / NS / 1e3, sum(e.count for e in kern) / NS))
+ops = [e for e in ev if not (e.device_type is not None and str(e.device_type).endswith("CUDA"))]
+ops.sort(key=lambda e: -e.self_device_time_total)
+for e in ops[:40]:
+    print("%-40s dev %8.1f us/step  cpu %8.1f us/step  x%.0f" % (e.key[:40], e.self_device_time_total / NS, e.self_cpu_time_total / NS, e.count / NS))
