@@ -303,6 +303,50 @@ def _choose(logp, given, deterministic, generator):
     return torch.multinomial(logp.exp(), 1, generator=generator).squeeze(-1)
 
 
+class _SegmentedTrunk(torch.autograd.Function):
+    """out_k = x[a_k:b_k] @ w_k.T + bias_k for a list of row segments of ONE gathered trunk tensor x (the heads of
+    `_evaluate_compact`: every head sees its own rows).  As separate slices + F.linear the backward of every slice
+    materialises a zero tensor of the whole of x, copies its rows in and adds it to the gradient of x (ten times 170 000 x 512
+    per minibatch); here the backward writes every segment of dx once.  The segments must cover x; they may repeat (two heads
+    on the same rows).  Same arithmetic as F.linear under the caller's autocast dtype."""
+
+    @staticmethod
+    def forward(ctx, x, segs, *wb):
+        n = len(segs)
+        ws, bs = wb[:n], wb[n:]
+        outs = []
+        for (a, b), w, bias in zip(segs, ws, bs):
+            outs.append(F.linear(x[a:b], w.to(x.dtype), bias.to(x.dtype)))
+        ctx.segs = segs
+        ctx.save_for_backward(x, *ws)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dx = torch.empty_like(x)
+        seen = set()
+        dws, dbs = [], []
+        for (a, b), w, g in zip(ctx.segs, ws, douts):
+            if g is None:
+                dws.append(None); dbs.append(None)
+                continue
+            g = g.to(x.dtype)
+            contrib = g @ w.to(x.dtype)
+            if (a, b) in seen:
+                dx[a:b] += contrib
+            else:
+                dx[a:b] = contrib
+                seen.add((a, b))
+            dws.append((g.t() @ x[a:b]).to(w.dtype))
+            dbs.append(g.float().sum(0))
+        for (a, b) in ctx.segs:
+            if (a, b) not in seen:
+                dx[a:b] = 0
+                seen.add((a, b))
+        return (dx, None) + tuple(dws) + tuple(dbs)
+
+
 class _ActionHeads(nn.Module):
     def __init__(self, D=512):
         super().__init__()
@@ -367,9 +411,14 @@ class _ActionHeads(nn.Module):
         for i in order:
             at[i] = slice(off, off + sets[i].numel()); off += sets[i].numel()
         lps, ents = [], []                                   # (slice, log-probs) per head; entropies
+        # every head's trunk projection on its own rows, as ONE autograd node over the gathered rows (head 8 shares head 7's rows)
+        jobs = [(j, at[i]) for i in order for j in ((7, 8) if i == 7 else (i,))]
+        pres = _SegmentedTrunk.apply(mg, tuple((sl.start, sl.stop) for _, sl in jobs), *[H[j].mlp_1.weight[:, :D] for j, _ in jobs],
+                                     *[H[j].mlp_1.bias for j, _ in jobs])
+        pre = {j: p for (j, _), p in zip(jobs, pres)}
 
         def run(i, sl, mask, col, extra=None, custom=None):
-            _, lp, ent = _categorical(H[i].logits(pre_of(i, mg[sl]), extra, custom), mask, ag[sl, col], False, None)
+            _, lp, ent = _categorical(H[i].logits(pre[i], extra, custom), mask, ag[sl, col], False, None)
             lps.append((sl, lp)); ents.append(ent.sum())
 
         def two_hot(n_first, n):
@@ -391,9 +440,9 @@ class _ActionHeads(nn.Module):
             run(6, sl, torch.cat((mk[:n1, :3], mk[n1:, 3:])), 6, two_hot(n1, mk.shape[0]))
         if 7 in at:        # the recurrent give / receive lists of a proposed trade
             sl, cr = at[7], cur_res[rp]
-            give_out, _, lp7, e7 = self._recurrent(H[7], pre_of(7, mg[sl]), None, cr, True, ag[sl, 7:11], False, None)
+            give_out, _, lp7, e7 = self._recurrent(H[7], pre[7], None, cr, True, ag[sl, 7:11], False, None)
             filt7 = (lp7 == 0).float()                                           # action_heads_module.py:175
-            _, _, lp8, e8 = self._recurrent(H[8], pre_of(8, mg[sl]), give_out * (1 - filt7)[:, None], cr, False, ag[sl, 11:15], False, None)
+            _, _, lp8, e8 = self._recurrent(H[8], pre[8], give_out * (1 - filt7)[:, None], cr, False, ag[sl, 11:15], False, None)
             lps.append((sl, lp7 + lp8)); ents.append(e7.sum() + e8.sum())
         n_ex, n_yop = rex.numel(), ryop.numel()
         for i in (9, 10):  # resources of an exchange / a Year of Plenty or Monopoly card
