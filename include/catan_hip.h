@@ -176,6 +176,12 @@ int catan_attention_bwd(const void* qkv, const int32_t* lens, const void* dout, 
 int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y, int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream);
 int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
                          float eps, int relu, int is_bf16, catan_stream_t stream);
+/* The same backward with the gradient of a SECOND use of x added in: dx = LayerNorm'(dy) + dres - the pre-norm sub-layers of
+ * RL/models/tile_encoder.py compute x + sublayer(norm(x)), so x's gradient is the sum of the LayerNorm's and the residual
+ * stream's; autograd would form it with a separate add over the whole tensor.  Widths 64, 128, 256, 512; x, dy, dres, dx
+ * 16-byte aligned.  bf16: the LayerNorm term is rounded to bf16 before the add, exactly as the separate add sees it. */
+int catan_layer_norm_bwd_res(const void* x, const float* w, const float* b, const void* dy, const void* dres, void* dx, float* dw, float* db,
+                             int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream);
 
 /* Game.randomise_uncertainty(controlling_player_id): game/game.py:1207-1282 (forward search, worker.py:46): re-deals
  * the dev-card pile + the other players' hidden cards and the other players' resource hands, consistently with what the

@@ -80,6 +80,7 @@ _SIGS = {
     "catan_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "catan_layer_norm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int, _vp]),
     "catan_layer_norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int, _vp]),
+    "catan_layer_norm_bwd_res": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int, _vp]),
     "catan_profile_enable": (C.c_int, [_vp, C.c_int]),
     "catan_profile_read": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "catan_random_rollout_timed": (C.c_int, [_vp, C.c_uint32, C.c_int64, C.c_int32, _vp, C.POINTER(C.c_float)]),

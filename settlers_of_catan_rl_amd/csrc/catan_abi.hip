@@ -177,6 +177,24 @@ static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void*
     return CATAN_OK;
 }
 
+// the wide-row backward with the gradient of a second use of x added in (dx = LayerNorm'(dy) + dres): D = 64 (16-byte aligned rows), 128, 256, 512
+template <class T>
+static int lnw_res_dispatch(const void* x, const float* w, const float* b, const void* dy, const void* dres, void* dx, float* dw, float* db,
+                            long rows, int D, float eps, int relu, hipStream_t st) {
+#define CATAN_LNW_RES(EPL, GL) do { constexpr int RPB = 256 / GL; long nb = (rows + RPB - 1) / RPB; if (nb > 1024) nb = 1024; \
+        hipLaunchKernelGGL((k_lnw_bwd<T, EPL, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (const T*)dy, (T*)dx, dw, db, rows, eps, relu, (const T*)dres); } while (0)
+    switch (D) {
+    case 64: CATAN_LNW_RES(8, 8); break;
+    case 128: CATAN_LNW_RES(2, 64); break;
+    case 256: CATAN_LNW_RES(4, 64); break;
+    case 512: CATAN_LNW_RES(8, 64); break;
+    default: return fail(CATAN_EINVAL, "catan_layer_norm_bwd_res: built for the widths 64, 128, 256, 512");
+    }
+#undef CATAN_LNW_RES
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 extern "C" {
 
 const char* catan_last_error(void) { return g_err.c_str(); }
@@ -739,6 +757,13 @@ int catan_layer_norm_fwd(const void* x, const float* w, const float* b, void* y,
     if (!x || !w || !b || !y || rows <= 0) return fail(CATAN_EINVAL, "catan_layer_norm_fwd: bad arguments");
     return is_bf16 ? ln_dispatch<__hip_bfloat16>(false, x, w, b, nullptr, y, nullptr, nullptr, rows, D, eps, relu, S(stream))
                    : ln_dispatch<float>(false, x, w, b, nullptr, y, nullptr, nullptr, rows, D, eps, relu, S(stream));
+}
+int catan_layer_norm_bwd_res(const void* x, const float* w, const float* b, const void* dy, const void* dres, void* dx, float* dw, float* db,
+                             int64_t rows, int D, float eps, int relu, int is_bf16, catan_stream_t stream) {
+    if (!x || !w || !b || !dy || !dres || !dx || !dw || !db || rows <= 0) return fail(CATAN_EINVAL, "catan_layer_norm_bwd_res: bad arguments");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx) & 15) return fail(CATAN_EINVAL, "catan_layer_norm_bwd_res: buffers must be 16-byte aligned");
+    return is_bf16 ? lnw_res_dispatch<__hip_bfloat16>(x, w, b, dy, dres, dx, dw, db, rows, D, eps, relu, S(stream))
+                   : lnw_res_dispatch<float>(x, w, b, dy, dres, dx, dw, db, rows, D, eps, relu, S(stream));
 }
 int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const void* dy, void* dx, float* dw, float* db, int64_t rows, int D,
                          float eps, int relu, int is_bf16, catan_stream_t stream) {

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const T* __restrict__ x, const f
 // works on the same columns, so dw / db accumulate in registers and leave through one LDS reduction + atomics per block.
 template <class T, int EPL> struct RowVec;
 template <int EPL> struct RowVec<float, EPL> {
+    static __device__ __forceinline__ float rounded(float a) { return a; }
     static __device__ __forceinline__ void load(const float* p, float (&v)[EPL]) {
 #pragma unroll
         for (int e = 0; e < EPL; e += 4) { const float4 u = *reinterpret_cast<const float4*>(p + e); v[e] = u.x; v[e + 1] = u.y; v[e + 2] = u.z; v[e + 3] = u.w; }
@@ -298,10 +299,12 @@ template <int EPL> struct RowVec<float, EPL> {
     }
 };
 template <> struct RowVec<float, 2> {
+    static __device__ __forceinline__ float rounded(float a) { return a; }
     static __device__ __forceinline__ void load(const float* p, float (&v)[2]) { const float2 u = *reinterpret_cast<const float2*>(p); v[0] = u.x; v[1] = u.y; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
 };
 template <int EPL> struct RowVec<__hip_bfloat16, EPL> {
+    static __device__ __forceinline__ float rounded(float a) { return __bfloat162float(__float2bfloat16(a)); }
     static __device__ __forceinline__ unsigned pack(float a, float b) {
         const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
         return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void k_lnw_fwd(const T* __restrict__ x, const 
 template <class T, int EPL, int GL>
 __global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
                                                  const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dw,
-                                                 float* __restrict__ db, long rows, float eps, int relu) {
+                                                 float* __restrict__ db, long rows, float eps, int relu, const T* __restrict__ dres = nullptr) {
     constexpr int D = GL * EPL, RPB = 256 / GL;
     const int j = threadIdx.x % GL, wv = threadIdx.x / GL;
     float wj[EPL], bj[EPL], aw[EPL], ab[EPL];
@@ -379,6 +382,12 @@ __global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const 
         const float m1 = group_sum<GL>(s1) * (1.0f / D), m2 = group_sum<GL>(s2) * (1.0f / D);
 #pragma unroll
         for (int e = 0; e < EPL; e++) v[e] = rstd * (g[e] - m1 - v[e] * m2);
+        if (dres != nullptr) {                                     // the gradient of a second use of x (the residual stream of a pre-norm
+            float r[EPL];                                          // sub-layer), added as autograd would add the two tensors
+            RowVec<T, EPL>::load(dres + row * D + j * EPL, r);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) v[e] = RowVec<T, EPL>::rounded(v[e]) + r[e];
+        }
         RowVec<T, EPL>::store(dx + row * D + j * EPL, v);
     }
     __shared__ float sw[RPB][D + 1], sb[RPB][D + 1];

@@ -88,6 +88,55 @@ class _SmallLayerNorm(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _PreNorm(torch.autograd.Function):
+    """(LayerNorm(x), x) for a pre-norm sub-layer `x + f(norm(x))`: x leaves through the function a second time, so the
+    function is x's ONLY consumer and its backward forms x's whole gradient - the LayerNorm's plus the residual stream's - in
+    the LayerNorm backward kernel (catan_layer_norm_bwd_res) instead of autograd adding two [rows, D] tensors afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        D = x.shape[-1]
+        x = _aligned(x)
+        y = torch.empty_like(x)
+        rows = x.numel() // D
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        _lib.check(_lib.lib().catan_layer_norm_fwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(y), rows, D, float(eps), 0,
+                                                   int(x.dtype == torch.bfloat16), _stream()))
+        ctx.save_for_backward(x, wf, bf)
+        ctx.eps = eps
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, wf, bf = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        dwb = torch.zeros((2, D), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        if dy is None:
+            return dres, None, None, None
+        dy = _aligned(dy.to(x.dtype))
+        if dres is None:
+            _lib.check(L.catan_layer_norm_bwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]), rows, D,
+                                              float(ctx.eps), 0, int(x.dtype == torch.bfloat16), _stream()))
+        else:
+            dres = _aligned(dres.to(x.dtype))
+            _lib.check(L.catan_layer_norm_bwd_res(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]),
+                                                  rows, D, float(ctx.eps), 0, int(x.dtype == torch.bfloat16), _stream()))
+        return dx, dwb[0], dwb[1], None
+
+
+def pre_norm_supported(x, ln):
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and len(ln.normalized_shape) == 1
+            and ln.normalized_shape[0] in (64, 128, 256, 512) and torch.is_grad_enabled() and x.requires_grad)
+
+
+def pre_norm(x, ln):
+    """-> (ln(x), x'): use x' as the residual stream (see _PreNorm)"""
+    return _PreNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
 def small_layer_norm(x, ln, relu=False):
     """nn.LayerNorm `ln` (normalised dim in LN_WIDTHS) applied to CUDA tensor x (float32 / bfloat16), optional fused ReLU."""
     return _SmallLayerNorm.apply(x, ln.weight, ln.bias, ln.eps, relu)

@@ -120,6 +120,11 @@ class _EncoderLayer(nn.Module):
         self.pointwise_net = _FFN(dim, 2)
 
     def forward(self, x):
+        if nn_kernels.pre_norm_supported(x, self.sublayers[0].norm):     # training on the GPU: x's gradient formed in the LayerNorm backward
+            n, x = nn_kernels.pre_norm(x, self.sublayers[0].norm)
+            x = self.multi_headed_attention(n, residual=x)
+            n, x = nn_kernels.pre_norm(x, self.sublayers[1].norm)
+            return self.pointwise_net(n, residual=x)
         x = self.multi_headed_attention(_ln(self.sublayers[0].norm, x), residual=x)
         return self.pointwise_net(_ln(self.sublayers[1].norm, x), residual=x)
 

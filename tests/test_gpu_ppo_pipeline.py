@@ -530,7 +530,8 @@ def test_fused_tile_encoder_forward_vs_unfused(hip_lib):
 
 def test_fused_encoder_sublayers_vs_unfused(hip_lib):
     """An encoder layer with the residual adds / the FFN's ReLU fused into the row-kernel products (catan_linear_rows_fused,
-    modes 1-3) against the same layer with the separate elementwise ops: the fused epilogues act on the bf16-rounded
+    modes 1-3) and the residual stream's gradient added inside the LayerNorm backward (catan_layer_norm_bwd_res) against the
+    same layer with the separate elementwise ops and autograd's own gradient accumulation: the fused epilogues act on the bf16-rounded
     product exactly as the separate ops do, so outputs and every gradient are identical."""
     import torch
     from settlers_of_catan_rl_amd import nn_kernels
@@ -552,12 +553,14 @@ def test_fused_encoder_sublayers_vs_unfused(hip_lib):
 
     assert nn_kernels.fused_sublayer_supported(x, 64, 128)
     y1, dx1, gp1 = run()
-    saved = nn_kernels.fused_sublayer_supported
+    assert nn_kernels.pre_norm_supported(x, layer.sublayers[0].norm)               # x's gradient formed in the LayerNorm backward
+    saved = nn_kernels.fused_sublayer_supported, nn_kernels.pre_norm_supported
     nn_kernels.fused_sublayer_supported = lambda *a, **k: False
+    nn_kernels.pre_norm_supported = lambda *a, **k: False
     try:
         y0, dx0, gp0 = run()
     finally:
-        nn_kernels.fused_sublayer_supported = saved
+        nn_kernels.fused_sublayer_supported, nn_kernels.pre_norm_supported = saved
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
     for a, b in zip(gp1, gp0):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))      # (fp32 atomics: order of the row chunks)
