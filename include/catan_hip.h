@@ -75,6 +75,9 @@ int catan_step(catan_env_t* env, const int32_t* actions, float* reward, uint8_t*
 int catan_masks(catan_env_t* env, float* out_masks, catan_stream_t stream);
 /* the same masks as 325-bit strings: uint32 [n][pitch], pitch = 16 words (bit i of the flat mask = word i>>5, bit i&31) */
 int catan_masks_packed(catan_env_t* env, const uint32_t** out_ptr, int64_t* out_pitch);
+/* packed 325-bit mask rows (uint32 [rows][pitch_words], pitch_words >= 11; the rollout storage keeps 11 words per decision)
+ * -> float32 [rows][325], the layout `action_masks` has in RL/ppo/process_batch.py:96-104 */
+int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out_masks, catan_stream_t stream);
 
 /* deciding player (discarder > trade target > players_go): env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.
  * out: int32 [n], PlayerId 1..4 */

@@ -489,6 +489,13 @@ int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
     return CATAN_OK;
 }
 
+int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out, catan_stream_t stream) {
+    if (!packed || !out || rows <= 0 || pitch_words < (MASK_BITS + 31) / 32) return fail(CATAN_EINVAL, "catan_expand_masks: bad arguments");
+    hipLaunchKernelGGL(k_expand_masks, dim3(blocks(rows * MASK_BITS, BLOCK)), dim3(BLOCK), 0, S(stream), packed, (long)rows, (long)rows, out, (int)pitch_words);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int catan_masks_packed(catan_env_t* e, const uint32_t** out_ptr, int64_t* out_pitch) {
     if (!e || !out_ptr || !out_pitch) return fail(CATAN_EINVAL, "catan_masks_packed: null argument");
     *out_ptr = e->mpk; *out_pitch = MPK_STRIDE;

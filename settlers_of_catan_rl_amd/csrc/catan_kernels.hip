@@ -1131,12 +1131,12 @@ __global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, i
 }
 
 // packed [N][16] -> float32 [n][325] row-major (what EnvWrapper.get_action_masks returns, batched)
-__global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ mpk, long N, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ mpk, long N, long n, float* __restrict__ out, int pitch = MPK_STRIDE) {
     long i = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n * MASK_BITS) return;
     long e = i / MASK_BITS;
     int j = (int)(i - e * MASK_BITS);
-    out[i] = (float)((mpk[e * MPK_STRIDE + (j >> 5)] >> (j & 31)) & 1u);
+    out[i] = (float)((mpk[e * pitch + (j >> 5)] >> (j & 31)) & 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ step

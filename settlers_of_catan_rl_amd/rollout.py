@@ -39,6 +39,15 @@ class RolloutStorage(object):
 
     def unpack_action_masks(self, packed):
         """int32 [..., 11] -> float32 [..., 325]"""
+        if packed.is_cuda and packed.dtype == torch.int32:            # one kernel (catan_expand_masks) instead of shift / and / slice / cast passes
+            import ctypes as C
+            from . import _lib
+            p = packed.contiguous()
+            rows = p.numel() // p.shape[-1]
+            out = torch.empty(packed.shape[:-1] + (spec.MASK_WORDS,), dtype=torch.float32, device=p.device)
+            _lib.check(_lib.lib().catan_expand_masks(C.c_void_p(p.data_ptr()), rows, int(p.shape[-1]), C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return out
         bits = (packed[..., None] >> torch.arange(32, device=packed.device, dtype=torch.int32)) & 1
         return bits.reshape(packed.shape[:-1] + (352,))[..., :spec.MASK_WORDS].float()
 

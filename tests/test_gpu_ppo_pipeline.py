@@ -605,3 +605,20 @@ def test_collector_graphed_act_uses_current_weights(hip_lib):
     # the eager collector on the same states emits from the same distribution (spot check: same mean log-prob within noise)
     col2 = RolloutCollector(VecCatanEnv(N, seed=9), net, T, seed=1, autocast_dtype=torch.bfloat16, graph_act=False)
     assert not col2.graph_act
+
+
+def test_unpack_action_masks_kernel_vs_torch(hip_lib):
+    """RolloutStorage.unpack_action_masks on the GPU (catan_expand_masks: packed int32 [.., 11] -> float32 [.., 325]) against the
+    torch bit arithmetic it replaces, on real masks and on random bit patterns (incl. bit 31 of every word)."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.rollout import RolloutStorage, pack_action_masks
+    env = VecCatanEnv(1000, seed=4); env.random_rollout(0, 700)
+    m = env.get_action_masks()
+    st = RolloutStorage(2, 8, "cuda")
+    packed = pack_action_masks(m)
+    assert torch.equal(st.unpack_action_masks(packed), m)
+    rnd = torch.randint(-2 ** 31, 2 ** 31 - 1, (3, 77, 11), dtype=torch.int64, device="cuda").int()
+    bits = (rnd[..., None] >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1
+    ref = bits.reshape(3, 77, 352)[..., :spec.MASK_WORDS].float()
+    assert torch.equal(st.unpack_action_masks(rnd), ref)
+    assert torch.equal(st.unpack_action_masks(rnd.cpu()), ref.cpu())              # (the torch path, CPU tensors)
