@@ -493,8 +493,12 @@ class _ActionHeads(nn.Module):
             mask[:, 0] = 1.0
             if i > 0:
                 keep = (chosen[-1] > 0).float()
-                step_lp, ent = step_lp * keep, ent * keep
-            logp_sum, ent_sum = logp_sum + step_lp, ent_sum + ent
+                step_lp = step_lp * keep
+                if acts is not None:
+                    ent = ent * keep
+            logp_sum = logp_sum + step_lp
+            if acts is not None:                        # (sampling discards the entropy)
+                ent_sum = ent_sum + ent
             chosen.append(a)
             out = torch.cat((torch.zeros_like(out[:, :1]), out[:, 1:]), 1)     # column 0 ("stop") never feeds back; no host constant
         return out, torch.stack(chosen, 1), logp_sum, ent_sum
@@ -510,7 +514,7 @@ class _ActionHeads(nn.Module):
         H = self.action_heads
         given = (lambda i: None) if actions is None else (lambda i: actions[:, i])
         m = masks
-        out = torch.zeros(B, 18, dtype=torch.int64, device=dev)
+        cols = {}                                        # action columns, assembled once at the end (not 18 strided column writes)
         one = torch.ones(B, device=dev)
 
         # mlp_1 of all twelve heads over the trunk: one [B, D] x [D, 12*128] GEMM (each head's weight columns 0..D-1)
@@ -518,9 +522,11 @@ class _ActionHeads(nn.Module):
         pre_all = F.linear(main, torch.cat([h.mlp_1.weight[:, :D] for h in H], 0), torch.cat([h.mlp_1.bias for h in H], 0))
         pre = lambda i: pre_all[:, 128 * i:128 * (i + 1)]
 
+        want_ent = actions is not None                  # sampling (`act`) discards the entropy: ~60 tiny launches of a launch-bound pass
+
         def run(i, extra, mask, idx, count, custom=None):
             a, lpa, ent = _categorical(H[i].logits(pre(i), extra, custom), mask, given(idx), deterministic, generator)
-            return a, lpa * count, (count * ent).mean()
+            return a, lpa * count, ((count * ent).mean() if want_ent else 0.0)
 
         # head 0: action type
         typ, logp, entropy = run(0, None, m[:, MO[0]:MO[0] + 13], 0, one)
@@ -528,31 +534,31 @@ class _ActionHeads(nn.Module):
             forced = forced_type >= 0
             typ = torch.where(forced, forced_type, typ)
             logp = torch.where(forced, torch.zeros_like(logp), logp)
-        out[:, 0] = typ
+        cols[0] = typ
         is_ = lambda t: (typ == t).float()
         # head 1: corner, conditioned on (settlement, city); mask row by type (build_agent_model.py:113-115)
         row = torch.where(typ == T_SETTLE, 0, torch.where(typ == T_CITY, 1, 2))
         cm = m[:, MO[1]:MO[1] + 162].reshape(B, 3, 54).gather(1, row[:, None, None].expand(B, 1, 54)).squeeze(1)
         x = torch.stack((is_(T_SETTLE), is_(T_CITY)), -1)
-        a, lp, e = run(1, x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); out[:, 1] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(2, None, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); out[:, 2] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(3, None, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); out[:, 3] = a; logp = logp + lp; entropy = entropy + e
-        card, lp, e = run(4, None, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); out[:, 4] = card; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(5, None, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); out[:, 5] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(1, x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); cols[1] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(2, None, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); cols[2] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(3, None, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); cols[3] = a; logp = logp + lp; entropy = entropy + e
+        card, lp, e = run(4, None, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); cols[4] = card; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(5, None, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); cols[5] = a; logp = logp + lp; entropy = entropy + e
         # head 6: relative player, conditioned on (propose, steal)
         row = torch.where(typ == T_PROPOSE, 0, torch.where(typ == T_STEAL, 1, 2))
         pm = m[:, MO[6]:MO[6] + 9].reshape(B, 3, 3).gather(1, row[:, None, None].expand(B, 1, 3)).squeeze(1)
         x = torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1)
-        a, lp, e = run(6, x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); out[:, 6] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(6, x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); cols[6] = a; logp = logp + lp; entropy = entropy + e
         # heads 7 / 8: recurrent give / receive resource lists
         prop = is_(T_PROPOSE)
         give_out, give_a, lp7, e7 = self._recurrent(H[7], pre(7), None, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
         lp7 = lp7 * prop
-        out[:, 7:11] = give_a; logp = logp + lp7; entropy = entropy + (e7 * prop).mean()
+        cols[7] = give_a; logp = logp + lp7; entropy = entropy + ((e7 * prop).mean() if want_ent else 0.0)
         filt7 = (lp7 == 0).float()                                               # action_heads_module.py:175
         _, recv_a, lp8, e8 = self._recurrent(H[8], pre(8), give_out * (1 - filt7)[:, None], cur_res, False,
                                              None if actions is None else actions[:, 11:15], deterministic, generator)
-        out[:, 11:15] = recv_a; logp = logp + lp8 * prop; entropy = entropy + (e8 * prop).mean()
+        cols[11] = recv_a; logp = logp + lp8 * prop; entropy = entropy + ((e8 * prop).mean() if want_ent else 0.0)
         # heads 9 / 10: resource A / B, conditioned on (play dev, exchange) and on the card (YoP, Monopoly)
         playdev = typ == T_PLAYDEV
         tcond = torch.stack((is_(T_PLAYDEV), is_(T_EXCHANGE)), -1)
@@ -565,11 +571,12 @@ class _ActionHeads(nn.Module):
         mask9 = mask_t * torch.where(playdev[:, None], mask_c, torch.ones_like(mask_c))
         cnt9 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, ((card == C_YOP) | (card == C_MONO)).float(), one)
         x = torch.cat((tcond, ccond), -1)
-        ra, lp, e = run(9, x, mask9, 15, cnt9); out[:, 15] = ra; logp = logp + lp; entropy = entropy + e
+        ra, lp, e = run(9, x, mask9, 15, cnt9); cols[15] = ra; logp = logp + lp; entropy = entropy + e
         cnt10 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, (card == C_YOP).float(), one)
         x = torch.cat((x, F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]), -1)
-        a, lp, e = run(10, x, m[:, MO[10]:MO[10] + 5], 16, cnt10); out[:, 16] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(11, None, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); out[:, 17] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(10, x, m[:, MO[10]:MO[10] + 5], 16, cnt10); cols[16] = a; logp = logp + lp; entropy = entropy + e
+        a, lp, e = run(11, None, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); cols[17] = a; logp = logp + lp; entropy = entropy + e
+        out = torch.cat((torch.stack([cols[i] for i in range(7)], 1), cols[7], cols[11], torch.stack([cols[15], cols[16], cols[17]], 1)), 1)
         return out, logp, entropy
 
 
