@@ -233,16 +233,19 @@ class _ObservationModule(nn.Module):
         B = obs_f.shape[0]
         tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
         cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
-        parts = [self.tile_encoder(tiles),
-                 self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
-                                            self.hidden_card_mha, self.played_card_mha)]
+        br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
+        with br.on(1):
+            te = br.keep(self.tile_encoder(tiles))
+        with br.on(2):
+            cp = br.keep(self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
+                                                    self.hidden_card_mha, self.played_card_mha))
         # the three opponents share one module: run them as one batch of 3B rows
         k0 = o["next_player_main"]
         others = obs_f[:, k0:k0 + 3 * 159].reshape(B * 3, 159)
         op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
                                        self.dev_card_embedding, self.played_card_mha)
-        parts.append(op.reshape(B, 3 * 128))
-        return _ln(self.norm, self.final_layer(torch.cat(parts, -1)), relu=True)
+        br.join()
+        return _ln(self.norm, self.final_layer(torch.cat([te, cp, op.reshape(B, 3 * 128)], -1)), relu=True)
 
 
 class _Dist(nn.Module):
@@ -306,6 +309,58 @@ def _choose(logp, given, deterministic, generator):
     if deterministic:
         return logp.argmax(-1)
     return torch.multinomial(logp.exp(), 1, generator=generator).squeeze(-1)
+
+
+class _Branches(object):
+    """Independent branches of an INFERENCE pass on side streams.  A policy pass at rollout width is a few hundred kernels of
+    5-15 us whose cost is their launch-to-launch latency, not their work; enqueued on forked streams (and captured that way
+    into the hipGraph of `GraphedAct`) independent chains - the tile encoder beside the player modules, the action heads that
+    depend on the sampled type only - overlap.  Program order (and with it the order of the random draws) is unchanged; only
+    the stream a branch is enqueued on differs.  Off under autograd and on the CPU."""
+    N_SIDE = 3
+    enabled = True
+
+    def __init__(self):
+        self.side = None
+        self.active = False
+
+    def fork(self, ref):
+        self.active = bool(self.enabled and ref.is_cuda and not torch.is_grad_enabled())
+        if not self.active:
+            return self
+        if self.side is None or self.side[0].device != ref.device:
+            self.side = [torch.cuda.Stream(device=ref.device) for _ in range(self.N_SIDE)]
+        self.main = torch.cuda.current_stream(ref.device)
+        for st in self.side:
+            st.wait_stream(self.main)
+        self.made = []
+        return self
+
+    def on(self, k):
+        """context: branch k (0 = stay on the main stream)"""
+        import contextlib
+        if not self.active or k % (self.N_SIDE + 1) == 0:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.side[k % (self.N_SIDE + 1) - 1])
+
+    def keep(self, *tensors):
+        """tensors made on a side stream that the main stream reads after join()"""
+        if self.active:
+            self.made.extend(t for t in tensors if torch.is_tensor(t))
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def join(self):
+        if not self.active:
+            return
+        for st in self.side:
+            self.main.wait_stream(st)
+        for t in self.made:
+            t.record_stream(self.main)
+        self.made = []
+        self.active = False
+
+
+_HEAD_BRANCHES, _OBS_BRANCHES = _Branches(), _Branches()
 
 
 class _SegmentedTrunk(torch.autograd.Function):
@@ -536,46 +591,56 @@ class _ActionHeads(nn.Module):
             logp = torch.where(forced, torch.zeros_like(logp), logp)
         cols[0] = typ
         is_ = lambda t: (typ == t).float()
-        # head 1: corner, conditioned on (settlement, city); mask row by type (build_agent_model.py:113-115)
-        row = torch.where(typ == T_SETTLE, 0, torch.where(typ == T_CITY, 1, 2))
-        cm = m[:, MO[1]:MO[1] + 162].reshape(B, 3, 54).gather(1, row[:, None, None].expand(B, 1, 54)).squeeze(1)
-        x = torch.stack((is_(T_SETTLE), is_(T_CITY)), -1)
-        a, lp, e = run(1, x, cm, 1, is_(T_SETTLE) + is_(T_CITY)); cols[1] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(2, None, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)); cols[2] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(3, None, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)); cols[3] = a; logp = logp + lp; entropy = entropy + e
-        card, lp, e = run(4, None, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV)); cols[4] = card; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(5, None, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)); cols[5] = a; logp = logp + lp; entropy = entropy + e
-        # head 6: relative player, conditioned on (propose, steal)
-        row = torch.where(typ == T_PROPOSE, 0, torch.where(typ == T_STEAL, 1, 2))
-        pm = m[:, MO[6]:MO[6] + 9].reshape(B, 3, 3).gather(1, row[:, None, None].expand(B, 1, 3)).squeeze(1)
-        x = torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1)
-        a, lp, e = run(6, x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)); cols[6] = a; logp = logp + lp; entropy = entropy + e
-        # heads 7 / 8: recurrent give / receive resource lists
-        prop = is_(T_PROPOSE)
-        give_out, give_a, lp7, e7 = self._recurrent(H[7], pre(7), None, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
-        lp7 = lp7 * prop
+        # Everything below depends on the sampled type only (heads 9 / 10 also on the card of head 4, head 8 on head 7): four
+        # independent chains, forked onto side streams in inference (see _Branches); the results are combined after the join.
+        br = _HEAD_BRANCHES.fork(main)
+        res = {}
+        with br.on(1):       # heads 1, 2, 3: corner (conditioned on (settlement, city); mask row by type, build_agent_model.py:113-115), edge, tile
+            row = torch.where(typ == T_SETTLE, 0, torch.where(typ == T_CITY, 1, 2))
+            cm = m[:, MO[1]:MO[1] + 162].reshape(B, 3, 54).gather(1, row[:, None, None].expand(B, 1, 54)).squeeze(1)
+            x = torch.stack((is_(T_SETTLE), is_(T_CITY)), -1)
+            res[1] = br.keep(*run(1, x, cm, 1, is_(T_SETTLE) + is_(T_CITY)))
+            res[2] = br.keep(*run(2, None, m[:, MO[2]:MO[2] + 73], 2, is_(T_ROAD)))
+            res[3] = br.keep(*run(3, None, m[:, MO[3]:MO[3] + 19], 3, is_(T_ROBBER)))
+        with br.on(2):       # heads 5, 6, 11: trade response, relative player (conditioned on (propose, steal)), discard
+            res[5] = br.keep(*run(5, None, m[:, MO[5]:MO[5] + 2], 5, is_(T_RESPOND), custom=trade.to(main.dtype)))
+            row = torch.where(typ == T_PROPOSE, 0, torch.where(typ == T_STEAL, 1, 2))
+            pm = m[:, MO[6]:MO[6] + 9].reshape(B, 3, 3).gather(1, row[:, None, None].expand(B, 1, 3)).squeeze(1)
+            x = torch.stack((is_(T_PROPOSE), is_(T_STEAL)), -1)
+            res[6] = br.keep(*run(6, x, pm, 6, is_(T_PROPOSE) + is_(T_STEAL)))
+            res[11] = br.keep(*run(11, None, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)))
+        with br.on(3):       # heads 4 -> 9 -> 10: development card, then resource A / B conditioned on (play dev, exchange) and on the card (YoP, Monopoly)
+            card, lp4, e4 = run(4, None, m[:, MO[4]:MO[4] + 5], 4, is_(T_PLAYDEV))
+            res[4] = br.keep(card, lp4, e4)
+            playdev = typ == T_PLAYDEV
+            tcond = torch.stack((is_(T_PLAYDEV), is_(T_EXCHANGE)), -1)
+            ccond = torch.stack(((card == C_YOP).float(), (card == C_MONO).float()), -1) * playdev.float()[:, None]   # filtered when head 4 is masked out
+            m9 = m[:, MO[9]:MO[9] + 20].reshape(B, 4, 5)
+            row_t = torch.where(typ == T_EXCHANGE, 0, 1)
+            row_c = torch.where(card == C_MONO, 2, torch.where(card == C_YOP, 3, 1))
+            mask_t = m9.gather(1, row_t[:, None, None].expand(B, 1, 5)).squeeze(1)
+            mask_c = m9.gather(1, row_c[:, None, None].expand(B, 1, 5)).squeeze(1)
+            mask9 = mask_t * torch.where(playdev[:, None], mask_c, torch.ones_like(mask_c))
+            cnt9 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, ((card == C_YOP) | (card == C_MONO)).float(), one)
+            x = torch.cat((tcond, ccond), -1)
+            ra, lp9, e9 = run(9, x, mask9, 15, cnt9)
+            res[9] = br.keep(ra, lp9, e9)
+            cnt10 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, (card == C_YOP).float(), one)
+            x = torch.cat((x, F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]), -1)
+            res[10] = br.keep(*run(10, x, m[:, MO[10]:MO[10] + 5], 16, cnt10))
+        with br.on(0):       # heads 7 -> 8: the recurrent give / receive resource lists (the longest chain: eight sequential draws)
+            prop = is_(T_PROPOSE)
+            give_out, give_a, lp7, e7 = self._recurrent(H[7], pre(7), None, cur_res, True, None if actions is None else actions[:, 7:11], deterministic, generator)
+            lp7 = lp7 * prop
+            filt7 = (lp7 == 0).float()                                           # action_heads_module.py:175
+            _, recv_a, lp8, e8 = self._recurrent(H[8], pre(8), give_out * (1 - filt7)[:, None], cur_res, False,
+                                                 None if actions is None else actions[:, 11:15], deterministic, generator)
+        br.join()
+        for i, col in ((1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (9, 15), (10, 16), (11, 17)):
+            a, lp, e = res[i]
+            cols[col] = a; logp = logp + lp; entropy = entropy + e
         cols[7] = give_a; logp = logp + lp7; entropy = entropy + ((e7 * prop).mean() if want_ent else 0.0)
-        filt7 = (lp7 == 0).float()                                               # action_heads_module.py:175
-        _, recv_a, lp8, e8 = self._recurrent(H[8], pre(8), give_out * (1 - filt7)[:, None], cur_res, False,
-                                             None if actions is None else actions[:, 11:15], deterministic, generator)
         cols[11] = recv_a; logp = logp + lp8 * prop; entropy = entropy + ((e8 * prop).mean() if want_ent else 0.0)
-        # heads 9 / 10: resource A / B, conditioned on (play dev, exchange) and on the card (YoP, Monopoly)
-        playdev = typ == T_PLAYDEV
-        tcond = torch.stack((is_(T_PLAYDEV), is_(T_EXCHANGE)), -1)
-        ccond = torch.stack(((card == C_YOP).float(), (card == C_MONO).float()), -1) * playdev.float()[:, None]   # filtered when head 4 is masked out
-        m9 = m[:, MO[9]:MO[9] + 20].reshape(B, 4, 5)
-        row_t = torch.where(typ == T_EXCHANGE, 0, 1)
-        row_c = torch.where(card == C_MONO, 2, torch.where(card == C_YOP, 3, 1))
-        mask_t = m9.gather(1, row_t[:, None, None].expand(B, 1, 5)).squeeze(1)
-        mask_c = m9.gather(1, row_c[:, None, None].expand(B, 1, 5)).squeeze(1)
-        mask9 = mask_t * torch.where(playdev[:, None], mask_c, torch.ones_like(mask_c))
-        cnt9 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, ((card == C_YOP) | (card == C_MONO)).float(), one)
-        x = torch.cat((tcond, ccond), -1)
-        ra, lp, e = run(9, x, mask9, 15, cnt9); cols[15] = ra; logp = logp + lp; entropy = entropy + e
-        cnt10 = (is_(T_PLAYDEV) + is_(T_EXCHANGE)) * torch.where(playdev, (card == C_YOP).float(), one)
-        x = torch.cat((x, F.one_hot(ra, 5).float() * (cnt9 != 0).float()[:, None]), -1)
-        a, lp, e = run(10, x, m[:, MO[10]:MO[10] + 5], 16, cnt10); cols[16] = a; logp = logp + lp; entropy = entropy + e
-        a, lp, e = run(11, None, m[:, MO[11]:MO[11] + 5], 17, is_(T_DISCARD)); cols[17] = a; logp = logp + lp; entropy = entropy + e
         out = torch.cat((torch.stack([cols[i] for i in range(7)], 1), cols[7], cols[11], torch.stack([cols[15], cols[16], cols[17]], 1)), 1)
         return out, logp, entropy
 
