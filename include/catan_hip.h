@@ -75,6 +75,14 @@ int catan_step(catan_env_t* env, const int32_t* actions, float* reward, uint8_t*
 int catan_masks(catan_env_t* env, float* out_masks, catan_stream_t stream);
 /* the same masks as 325-bit strings: uint32 [n][pitch], pitch = 16 words (bit i of the flat mask = word i>>5, bit i&31) */
 int catan_masks_packed(catan_env_t* env, const uint32_t** out_ptr, int64_t* out_pitch);
+/* the masks of catan_masks as packed rows of 11 words, uint32 [n][11] (what the rollout storage keeps per decision) */
+int catan_masks_packed_copy(catan_env_t* env, uint32_t* out, catan_stream_t stream);
+/* dst[t[r]][r][:] = src[r][:] for the rows r with sel[r] != 0: "append this game's observation / action / mask to its own
+ * list" of RL/ppo/game_manager.py:102-133 for all games at once, the selected rows found on the device (no host read of how
+ * many there are).  dst: [steps][rows][row_bytes] with `step_stride_bytes` between steps; t: int64 [rows] step index per row
+ * (in range for the selected rows); sel: uint8 [rows]. */
+int catan_masked_row_store(void* dst, const void* src, const int64_t* t, const uint8_t* sel, int64_t rows, int64_t row_bytes,
+                           int64_t step_stride_bytes, catan_stream_t stream);
 /* packed 325-bit mask rows (uint32 [rows][pitch_words], pitch_words >= 11; the rollout storage keeps 11 words per decision)
  * -> float32 [rows][325], the layout `action_masks` has in RL/ppo/process_batch.py:96-104 */
 int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out_masks, catan_stream_t stream);

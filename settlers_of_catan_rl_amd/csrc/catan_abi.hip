@@ -489,6 +489,23 @@ int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
     return CATAN_OK;
 }
 
+int catan_masks_packed_copy(catan_env_t* e, uint32_t* out, catan_stream_t stream) {
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_masks_packed_copy: null argument");
+    hipLaunchKernelGGL(k_copy_masks11, dim3(blocks(e->n * 11, BLOCK)), dim3(BLOCK), 0, S(stream), (const u32*)e->mpk, (long)e->n, out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_masked_row_store(void* dst, const void* src, const int64_t* t, const uint8_t* sel, int64_t rows, int64_t row_bytes,
+                           int64_t step_stride_bytes, catan_stream_t stream) {
+    if (!dst || !src || !t || !sel || rows <= 0 || row_bytes <= 0 || step_stride_bytes < rows * row_bytes)
+        return fail(CATAN_EINVAL, "catan_masked_row_store: bad arguments");
+    hipLaunchKernelGGL(k_masked_row_store, dim3((unsigned)rows), dim3(256), 0, S(stream), (unsigned char*)dst, (const unsigned char*)src,
+                       (const long long*)t, sel, (long)row_bytes, (long)step_stride_bytes);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out, catan_stream_t stream) {
     if (!packed || !out || rows <= 0 || pitch_words < (MASK_BITS + 31) / 32) return fail(CATAN_EINVAL, "catan_expand_masks: bad arguments");
     hipLaunchKernelGGL(k_expand_masks, dim3(blocks(rows * MASK_BITS, BLOCK)), dim3(BLOCK), 0, S(stream), packed, (long)rows, (long)rows, out, (int)pitch_words);

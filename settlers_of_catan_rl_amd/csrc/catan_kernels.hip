@@ -1139,6 +1139,31 @@ __global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ 
     out[i] = (float)((mpk[e * pitch + (j >> 5)] >> (j & 31)) & 1u);
 }
 
+// the first 11 words (325 bits) of every game's packed mask row, contiguous: what the rollout storage keeps per decision
+__global__ __launch_bounds__(BLOCK) void k_copy_masks11(const u32* __restrict__ mpk, long n, u32* __restrict__ out) {
+    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n * 11) return;
+    const long e = i / 11;
+    out[i] = mpk[e * MPK_STRIDE + (int)(i - e * 11)];
+}
+// dst[t[r]][r][:] = src[r][:] for the rows with sel[r] != 0 (one workgroup per row): the rollout collector's "append this
+// game's observation / action to its own list" (RL/ppo/game_manager.py:102-133) without compacting the selected rows on the host
+__global__ __launch_bounds__(256) void k_masked_row_store(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src,
+                                                          const long long* __restrict__ t, const unsigned char* __restrict__ sel,
+                                                          long row_bytes, long step_stride_bytes) {
+    const long r = blockIdx.x;
+    if (!sel[r]) return;
+    unsigned char* d = dst + t[r] * step_stride_bytes + r * row_bytes;
+    const unsigned char* s = src + r * row_bytes;
+    if ((((unsigned long long)d | (unsigned long long)s | (unsigned long long)row_bytes) & 3) == 0) {
+        for (long i = threadIdx.x; i < row_bytes / 4; i += 256) reinterpret_cast<u32*>(d)[i] = reinterpret_cast<const u32*>(s)[i];
+    } else if ((((unsigned long long)d | (unsigned long long)s | (unsigned long long)row_bytes) & 1) == 0) {
+        for (long i = threadIdx.x; i < row_bytes / 2; i += 256) reinterpret_cast<unsigned short*>(d)[i] = reinterpret_cast<const unsigned short*>(s)[i];
+    } else {
+        for (long i = threadIdx.x; i < row_bytes; i += 256) d[i] = s[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ step
 // "mask bit set" legality (validate mode): every head relevant to the chosen type must be unmasked, plus the
 // ownership check of game/game.py:455-466 for ProposeTrade.

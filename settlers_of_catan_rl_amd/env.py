@@ -89,6 +89,12 @@ class VecCatanEnv(object):
         _lib.check(self.L.catan_masks(self.h, _ptr(out), _stream()))
         return out
 
+    def get_action_masks_packed(self):
+        """int32 [n][11]: the same masks as 325-bit rows (bit i of the flat mask = word i >> 5, bit i & 31)"""
+        out = torch.empty((self.n, 11), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.catan_masks_packed_copy(self.h, _ptr(out), _stream()))
+        return out
+
     def get_action_masks_by_head(self):
         flat = self.get_action_masks()
         return [flat[:, o:o + s].reshape((self.n,) + shp)

@@ -127,87 +127,117 @@ class RolloutCollector(object):
         if self.recurrent:            # game_manager.py:54-59: every seat of every game starts from the zero state
             self.hid = torch.zeros((2, N, 4, self.lstm_size), dtype=torch.float32, device=dev)
 
-    def _store_obs(self, sel, f, lists, lens):
-        st = self.storage
-        idx = sel.nonzero(as_tuple=True)[0]
-        if idx.numel() == 0:
+    # ---- "append to this game's list" for all games at once.  The selected games are never compacted on the host (a
+    # `nonzero` is a device-to-host read of how many there are: five of them per env iteration kept the host from running
+    # ahead, and the GPU idle while the host launched the next policy pass): big rows go through catan_masked_row_store,
+    # per-game scalars through a read-modify-write of the whole column.
+    def _row_store(self, dst, src, t, sel):
+        """dst[t[n], n] = src[n] where sel[n]; dst [steps, N, ...], src [N, ...] (same trailing shape and dtype)"""
+        if dst.is_cuda and hasattr(self.env, "L"):
+            import ctypes as C
+            from . import _lib
+            src = src.contiguous()
+            row_bytes = src[0].numel() * src.element_size()
+            _lib.check(_lib.lib().catan_masked_row_store(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(t.data_ptr()),
+                                                         C.c_void_p(sel.data_ptr()), self.N, row_bytes, dst.stride(0) * dst.element_size(),
+                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             return
-        t = self.n_obs[idx]
-        st.obs_f[t, idx] = f[idx].to(st.obs_f.dtype)
-        st.lists[t, idx] = lists[idx].to(torch.int8)
-        st.lens[t, idx] = lens[idx].to(torch.int8)
+        idx = sel.nonzero(as_tuple=True)[0]
+        if idx.numel():
+            dst[t[idx], idx] = src[idx]
+
+    def _col_store(self, dst, value, t, sel):
+        """dst[t[n], n] = value[n] (or a scalar) where sel[n]; t in range for every n"""
+        ar = self._ar
+        cur = dst[t, ar]
+        v = value if torch.is_tensor(value) else torch.full_like(cur, value)
+        m = sel if cur.dim() == 1 else sel.reshape((-1,) + (1,) * (cur.dim() - 1))
+        dst[t, ar] = torch.where(m, v.to(cur.dtype), cur)
+
+    def _store_obs(self, sel, f, lists, lens):
+        st, T = self.storage, self.T
+        t = self.n_obs.clamp(max=T)
+        sel8 = sel.to(torch.uint8)
+        self._row_store(st.obs_f, f.to(st.obs_f.dtype), t, sel8)
+        self._row_store(st.lists, lists.to(torch.int8), t, sel8)
+        self._col_store(st.lens, lens.to(torch.int8), t, sel)
         if self.recurrent:            # game_manager.py:55,133: the state the active seat will enter this decision with
-            st.hidden[:, t, idx] = self.hid[:, idx, self.active_pid[idx] - 1]
-        self.n_obs[idx] += 1
+            hid = self.hid[:, self._ar, self.active_pid - 1]                                  # [2, N, L]
+            for k in range(2):
+                self._row_store(st.hidden[k], hid[k], t, sel8)
+        self.n_obs += sel.long()
+
+    CHECK_EVERY = 8      # env iterations between two host reads of "every game has its T + 1 observations" (iterations past that point are no-ops)
 
     @torch.no_grad()
     def gather_rollouts(self, max_iters=None):
         """game_manager.py:69-140.  Returns the storage (first T(+1) entries per game are the rollout)."""
         env, st, T, N, dev = self.env, self.storage, self.T, self.N, self.device
-        ar = torch.arange(N, device=dev)
+        ar = self._ar = torch.arange(N, device=dev)
         if self._shadow is not None:
             self._shadow.load_from(self.policy)  # the central policy as of this rollout (game_manager.py:161-162 `_update_policy`)
         self.racc.zero_()                        # `rewards = {...: 0}` at the start of every gather call (:76)
         self.done_since.zero_()                  # `done_since_prev_turn = [False ...]` (:77)
         term = st.masks[0].clone()               # `terminal_mask = terminal_masks[env_num][0]` (:74-75)
         iters = 0
+        n_live_iters = torch.zeros((), dtype=torch.int64, device=dev)       # iterations in which some game still stepped
+        n_complete = torch.zeros((), dtype=torch.int64, device=dev)
+        packed_from_env = hasattr(env, "get_action_masks_packed")
         while True:
             f, lists, lens = env.get_obs()
             # an observation produced by the previous step for the active seat (:126-133) - or the carried one
             self._store_obs(self.pending_obs & (self.n_obs < T + 1), f, lists, lens)
             self.pending_obs = torch.zeros(N, dtype=torch.bool, device=dev)
             frozen = self.n_obs >= T + 1                                                    # while len(observations) < T+1 (:78)
-            if bool(frozen.all()) or (max_iters is not None and iters >= max_iters):
+            if max_iters is not None and iters >= max_iters:
+                break
+            if iters % self.CHECK_EVERY == 0 and bool(frozen.all()):
                 break
             iters += 1
+            live = ~frozen
+            n_live_iters += live.any()
             deciding = env.deciding_player().long()                                         # :79
             masks = env.get_action_masks()                                                  # :83
             pol = self.policy_of_pid[ar, deciding - 1]
-            actions, logp = self._act(f, lists, lens, masks, pol, deciding, term, ~frozen)  # :85-89
+            actions, logp = self._act(f, lists, lens, masks, pol, deciding, term, live)     # :85-89
             a_env = actions.to(torch.int32)
             a_env[:, 0] = torch.where(frozen, torch.full_like(a_env[:, 0], -1), a_env[:, 0])   # frozen games: no-op
+            pmasks = env.get_action_masks_packed() if packed_from_env else pack_action_masks(masks)   # (before the step replaces them)
             reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
-            live = ~frozen
             done = done.bool() & live
             term = torch.where(live, 1.0 - done.float(), term)                              # :97
             self.racc += (reward.double() if self.reward64 is None else self.reward64) * live[:, None]   # :94-95
-            was_active = (deciding == self.active_pid) & live
-            idx = was_active.nonzero(as_tuple=True)[0]                                      # :102-105
-            if idx.numel():
-                t = self.n_act[idx]
-                st.actions[t, idx] = actions[idx]
-                st.action_log_probs[t, idx] = logp[idx]
-                st.action_masks[t, idx] = pack_action_masks(masks[idx])
-                self.n_act[idx] += 1
+            was_active = (deciding == self.active_pid) & live                               # :102-105
+            t = self.n_act.clamp(max=T - 1)
+            self._col_store(st.actions, actions, t, was_active)
+            self._col_store(st.action_log_probs, logp, t, was_active)
+            self._col_store(st.action_masks, pmasks, t, was_active)
+            self.n_act += was_active.long()
             n_deciding = env.deciding_player().long()                                       # after the step (and the reset)
             next_active = (n_deciding == self.active_pid) & live
             r_active = self.racc[ar, self.active_pid - 1]
             # :106-110 (not done: uses the post-step deciding player) and :112-118 (done: exactly one reward is appended)
             app = torch.where(done, torch.ones_like(done), next_active & (self.n_act > 0) & ~self.done_since) & live
-            idx = app.nonzero(as_tuple=True)[0]
-            if idx.numel():
-                st.rewards[self.n_rew[idx].clamp(max=T + 1), idx] = r_active[idx].float()              # process_batch.py:63
-                self.n_rew[idx] += 1
-                self.racc[idx, self.active_pid[idx] - 1] = 0.0
-            idx = done.nonzero(as_tuple=True)[0]                                            # :112-124
-            if idx.numel():
-                st.masks[self.n_msk[idx].clamp(max=T + 1), idx] = 0.0
-                self.n_msk[idx] += 1
-                self.done_since[idx] = False
-                self.racc[idx] = 0.0
-                if self.recurrent:
-                    self.hid[:, idx] = 0.0                                                  # :121-124
-                st.games_complete += int(idx.numel())
+            self._col_store(st.rewards, r_active.float(), self.n_rew.clamp(max=T + 1), app)        # process_batch.py:63
+            self.n_rew += app.long()
+            self.racc[ar, self.active_pid - 1] = torch.where(app, torch.zeros_like(r_active), r_active)
+            # :112-124
+            self._col_store(st.masks, 0.0, self.n_msk.clamp(max=T + 1), done)
+            self.n_msk += done.long()
+            self.done_since = self.done_since & ~done
+            self.racc = torch.where(done[:, None], torch.zeros_like(self.racc), self.racc)
+            if self.recurrent:
+                self.hid = torch.where(done[None, :, None, None], torch.zeros_like(self.hid), self.hid)   # :121-124
+            n_complete += done.sum()
             # :128-136
             add_mask = next_active & ~done & ~self.done_since
-            idx = add_mask.nonzero(as_tuple=True)[0]
-            if idx.numel():
-                st.masks[self.n_msk[idx].clamp(max=T + 1), idx] = 1.0
-                self.n_msk[idx] += 1
+            self._col_store(st.masks, 1.0, self.n_msk.clamp(max=T + 1), add_mask)
+            self.n_msk += add_mask.long()
             self.done_since = torch.where(next_active, torch.zeros_like(self.done_since),
                                           torch.where(done & live, torch.ones_like(self.done_since), self.done_since))
             self.pending_obs = next_active
-        self.iters = iters
+        st.games_complete += int(n_complete)
+        self.iters = int(n_live_iters) if max_iters is None else iters
         return st
 
     def _act(self, f, lists, lens, masks, pol, deciding=None, term=None, live=None):
