@@ -241,8 +241,8 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
         if rec:
             seat = players_go[idx] - 1
             kw = {"hidden": (hid[0, idx, seat], hid[1, idx, seat]), "nonterminal": torch.ones(idx.numel(), device=dev)}
-        if graphed is not None and sub:
-            value_s, action_s = graphed(*args)                                             # small batch: hipGraph replay
+        if graphed is not None and idx.numel() <= graphed.buckets[-1]:
+            value_s, action_s = graphed(*args)                                             # hipGraph replay of the pass at the next bucket size (a pass is launch-bound at every width up to 65 536 rows)
         elif autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=autocast_dtype):
                 res = policy.act(*args, deterministic=deterministic, generator=generator, **kw)
@@ -472,7 +472,7 @@ class ForwardSearch(object):
         if torch.cuda.is_available() and next(policy.parameters()).is_cuda:
             from . import nn_kernels
             nn_kernels.use_tuned_gemms()
-        self.graphed = GraphedAct(policy, autocast_dtype=autocast_dtype) if use_graphs else None
+        self.graphed = GraphedAct(policy, buckets=(512, 4096, 16384, 32768, 65536), autocast_dtype=autocast_dtype) if use_graphs else None
         self.sims_run = 0
         self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]
 
