@@ -622,3 +622,67 @@ def test_unpack_action_masks_kernel_vs_torch(hip_lib):
     ref = bits.reshape(3, 77, 352)[..., :spec.MASK_WORDS].float()
     assert torch.equal(st.unpack_action_masks(rnd), ref)
     assert torch.equal(st.unpack_action_masks(rnd.cpu()), ref.cpu())              # (the torch path, CPU tensors)
+
+
+def test_masked_row_store_and_packed_masks(hip_lib):
+    """catan_masked_row_store (dst[t[r], r] = src[r] where sel[r]) against the torch indexing it replaces, for 4- / 2- / 1-byte
+    aligned rows; catan_masks_packed_copy against packing the float masks."""
+    import ctypes as C
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.rollout import pack_action_masks
+    L = hip_lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, S = 3001, 7
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for shape, dt in (((1787,), torch.bfloat16), ((5, 25), torch.int8), ((16,), torch.float32), ((3,), torch.int8)):
+        dst = torch.zeros((S, N) + shape, device="cuda").to(dt)
+        dst.copy_(torch.randint(0, 100, dst.shape, device="cuda", generator=g))
+        ref = dst.clone()
+        src = torch.randint(0, 100, (N,) + shape, device="cuda", generator=g).to(dt)
+        t = torch.randint(0, S, (N,), device="cuda", generator=g)
+        sel = torch.rand(N, device="cuda", generator=g) < 0.3
+        idx = sel.nonzero(as_tuple=True)[0]
+        ref[t[idx], idx] = src[idx]
+        sel8 = sel.to(torch.uint8)
+        rb = src[0].numel() * src.element_size()
+        assert L.catan_masked_row_store(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(sel8.data_ptr()),
+                                        N, rb, dst.stride(0) * dst.element_size(), st) == 0
+        assert torch.equal(dst, ref), (shape, dt)
+    assert L.catan_masked_row_store(None, None, None, None, 1, 1, 1, st) != 0
+    env = VecCatanEnv(2000, seed=8); env.random_rollout(0, 900)
+    assert torch.equal(env.get_action_masks_packed(), pack_action_masks(env.get_action_masks()))
+
+
+def test_forked_inference_streams_change_nothing(hip_lib):
+    """policy._Branches: the independent chains of an inference pass on side streams - same actions, values and log-probs as
+    the single-stream pass (same generator state), eagerly and inside a captured hipGraph."""
+    from settlers_of_catan_rl_amd import policy as P
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.forward_search import GraphedAct
+    torch.manual_seed(0)
+    env = VecCatanEnv(4096, seed=12); env.random_rollout(0, 800)
+    f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+    net = P.CatanPolicy().cuda().inference_copy(torch.bfloat16)
+
+    def act(seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return net.act(f, lists, lens, masks, generator=g)
+
+    a1 = act(3)
+    saved = P._Branches.enabled
+    P._Branches.enabled = False
+    try:
+        a0 = act(3)
+    finally:
+        P._Branches.enabled = saved
+    assert torch.equal(a1[1], a0[1]) and torch.equal(a1[0], a0[0]) and torch.equal(a1[2], a0[2])
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    ga = GraphedAct(net, buckets=(4096,), autocast_dtype=torch.bfloat16, generator=gen)
+    v, a, lp = ga(f, lists, lens, masks, with_logp=True)
+    assert not ga.failed and 4096 in ga.graphs
+    # the replayed actions are legal and their log-probs are the net's own evaluation of them
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, lp_e, _ = net.evaluate_actions(f, lists, lens, masks, a)
+    assert float((lp_e.float().reshape(-1) - lp.float().reshape(-1)).abs().max()) < 0.05
+    assert (masks[:, :13].gather(1, a[:, :1]) == 1).all()
