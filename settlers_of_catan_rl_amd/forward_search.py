@@ -207,11 +207,10 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
     rewards = torch.zeros((n, D + 2), dtype=torch.float64, device=dev); n_rew = torch.zeros(n, dtype=torch.long, device=dev)
     values = torch.zeros((n, D + 1), dtype=torch.float64, device=dev); n_val = torch.zeros(n, dtype=torch.long, device=dev)
 
-    def push(buf, cnt, sel, x):
-        idx = sel.nonzero(as_tuple=True)[0]
-        if idx.numel():
-            buf[idx, cnt[idx]] = x[idx].double()
-            cnt[idx] += 1
+    def push(buf, cnt, sel, x):                         # append x[i] to row i's list where sel[i] (masked write: no host read)
+        c = cnt.clamp(max=buf.shape[1] - 1)
+        buf[ar, c] = torch.where(sel, x.double(), buf[ar, c])
+        cnt += sel.long()
 
     reward, done = env.step(torch.as_tensor(init_actions, device=dev).to(torch.int32))      # worker.py:71
     reward = reward.clone(); first_done = done.bool().clone()
