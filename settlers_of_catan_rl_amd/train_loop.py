@@ -79,8 +79,17 @@ class TrainingLoop(object):
         trainer.cfg.entropy_coef = self.entropy_coef
         if league is not None:
             if len(league.earlier) == 0:
-                league.add(policy)                                                          # :62-64
-            league.assign(collector, make_net)
+                # a fresh start (robust_train.py:60-64): the deque gets the initial policy, and the FIRST rollout is played against
+                # independently random-initialised opponents - the nets every reference worker builds for its policy slots 1..3
+                # (game_manager.py:14); snapshots are drawn for the first time after update 0 (:140-141).  One such set serves all
+                # games here (the reference has one per worker process).
+                league.add(policy)
+                nets = [make_net() for _ in range(3)]
+                for nt in nets:
+                    nt.eval()
+                collector.set_opponents(nets, torch.arange(3).expand(collector.N, 3))
+            else:
+                league.assign(collector, make_net)                                          # resumed: :55-56
 
     def run_update(self):
         a, u = self.args, self.update_num
