@@ -1937,8 +1937,16 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         pend.req[pend.fa][slot] = (u64)e | ((u64)lr_edge << 40) | ((u64)lr_who << 56);
         if (pend.stag < 2) {                               // lock-step: a game whose completion can end it (longest road: +2 points for
             bool may_end = false;                          // one player) gets a speculative successor (k_reset_list)
+            if (type == T_ROAD) {
+                // a new road can only hand the longest road to its builder (+2 for him, -2 for the previous holder): the game can
+                // end only if he has 8 points and does not hold it already.  (A superset filter is all that is needed -
+                // k_install_list re-deals a finished game without a shadow - but every speculative re-deal lengthens
+                // k_reset_list, whose duration is its slowest re-deal.)
+                may_end = s.pb(lr_who, P_VP) >= 8 && s.b(B_LR_PLAYER) != lr_who + 1;
+            } else {
 #pragma unroll
-            for (int p = 0; p < 4; p++) may_end |= s.pb(p, P_VP) >= 8;
+                for (int p = 0; p < 4; p++) may_end |= s.pb(p, P_VP) >= 8;
+            }
             if (may_end) pend.spec[atomicAdd(&pend.ctr[6], 1u)] = (u64)e;
         }
         pend.type[e] = (u8)(type + 1);
