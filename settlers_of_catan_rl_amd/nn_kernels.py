@@ -521,13 +521,28 @@ def categorical_supported(logits):
     return logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
 
 
+class UniformPool(object):
+    """The uniforms of all the categorical draws of one policy pass from ONE `torch.rand` (a pass makes 18 draws; at rollout
+    width every launch counts): pass it where a generator is expected; rows are handed out in call order."""
+
+    def __init__(self, generator, rows, draws, device):
+        self.u = torch.rand((draws, rows), device=device, generator=generator)
+        self.generator, self.k = generator, 0
+
+    def take(self, rows):
+        if self.k < self.u.shape[0] and rows == self.u.shape[1]:
+            self.k += 1
+            return self.u[self.k - 1]
+        return torch.rand(rows, device=self.u.device, generator=self.generator)
+
+
 def masked_categorical(logits, mask, given=None, deterministic=False, generator=None):
     """logits fp32 [B,K]; mask [B,K] (a column window of the mask matrix is fine); given int64 [B] or None.
     -> (action int64 [B], log-prob of the action [B], entropy [B])."""
     B = logits.shape[0]
     u = None
     if given is None and not deterministic:
-        u = torch.rand(B, device=logits.device, generator=generator)
+        u = generator.take(B) if isinstance(generator, UniformPool) else torch.rand(B, device=logits.device, generator=generator)
     if given is not None:
         given = given.contiguous()
     return _MaskedCategorical.apply(logits, mask, given, u)

@@ -578,6 +578,8 @@ class _ActionHeads(nn.Module):
         pre = lambda i: pre_all[:, 128 * i:128 * (i + 1)]
 
         want_ent = actions is not None                  # sampling (`act`) discards the entropy: ~60 tiny launches of a launch-bound pass
+        if actions is None and not deterministic and main.is_cuda:
+            generator = nn_kernels.UniformPool(generator, B, 18, dev)    # the 18 draws of a pass from one torch.rand
 
         def run(i, extra, mask, idx, count, custom=None):
             a, lpa, ent = _categorical(H[i].logits(pre(i), extra, custom), mask, given(idx), deterministic, generator)
@@ -590,7 +592,12 @@ class _ActionHeads(nn.Module):
             typ = torch.where(forced, forced_type, typ)
             logp = torch.where(forced, torch.zeros_like(logp), logp)
         cols[0] = typ
-        is_ = lambda t: (typ == t).float()
+        _is = {}
+
+        def is_(t):                                      # (typ == t) as float, computed once per type
+            if t not in _is:
+                _is[t] = (typ == t).float()
+            return _is[t]
         # Everything below depends on the sampled type only (heads 9 / 10 also on the card of head 4, head 8 on head 7): four
         # independent chains, forked onto side streams in inference (see _Branches); the results are combined after the join.
         br = _HEAD_BRANCHES.fork(main)
@@ -636,11 +643,13 @@ class _ActionHeads(nn.Module):
             _, recv_a, lp8, e8 = self._recurrent(H[8], pre(8), give_out * (1 - filt7)[:, None], cur_res, False,
                                                  None if actions is None else actions[:, 11:15], deterministic, generator)
         br.join()
+        lps = [logp, lp7, lp8 * prop]
         for i, col in ((1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (9, 15), (10, 16), (11, 17)):
             a, lp, e = res[i]
-            cols[col] = a; logp = logp + lp; entropy = entropy + e
-        cols[7] = give_a; logp = logp + lp7; entropy = entropy + ((e7 * prop).mean() if want_ent else 0.0)
-        cols[11] = recv_a; logp = logp + lp8 * prop; entropy = entropy + ((e8 * prop).mean() if want_ent else 0.0)
+            cols[col] = a; lps.append(lp); entropy = entropy + e
+        logp = torch.stack(lps).sum(0)                   # (one reduction instead of eleven adds)
+        cols[7] = give_a; entropy = entropy + ((e7 * prop).mean() if want_ent else 0.0)
+        cols[11] = recv_a; entropy = entropy + ((e8 * prop).mean() if want_ent else 0.0)
         out = torch.cat((torch.stack([cols[i] for i in range(7)], 1), cols[7], cols[11], torch.stack([cols[15], cols[16], cols[17]], 1)), 1)
         return out, logp, entropy
 
