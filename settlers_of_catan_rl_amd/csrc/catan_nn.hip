@@ -919,7 +919,7 @@ __device__ __forceinline__ void st_head(unsigned short* head, const f32x16_t& c,
 template <int L, int H, int HD>
 __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
                                                        unsigned short* __restrict__ out, long B) {
-    constexpr int D = H * HD;
+    constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;
     static_assert(L <= 32 && D % 8 == 0 && (HD == 16 || HD == 4), "one 32x32 tile per product");
     __shared__ __attribute__((aligned(16))) unsigned short Vt[4][D * AT_LP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
@@ -940,9 +940,10 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __r
         const bf16x8_t ka = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
         const bf16x8_t qb = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);
         const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);   // S^T[j][i]
-        float p[16], mx = -INFINITY;
+        // registers 12..15 hold keys 24..31: beyond every key when L <= 24 (the 19-token tile sequences) - not computed
+        float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < NR; r++) {
             const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
             p[r] = j < len ? st[r] * scale : -INFINITY;
             mx = fmaxf(mx, p[r]);
@@ -950,11 +951,11 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __r
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+        for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
 #pragma unroll
-        for (int r = 0; r < 16; r++) p[r] *= inv;
+        for (int r = 0; r < NR; r++) p[r] *= inv;
         f32x16_t ot = zero16;
         const unsigned short* vrow = vt + (h * HD + (c31 % HD)) * AT_LP;
 #pragma unroll
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __r
 template <int L, int H, int HD>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
                                                        const unsigned short* __restrict__ dout, unsigned short* __restrict__ dqkv, long B) {
-    constexpr int D = H * HD;
+    constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;      // registers 12..15 = keys / queries 24..31: beyond the sequence when L <= 24
     __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][D * AT_LP];          // K^T, Q^T, dO^T: [dim][key / query]
     __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: row max, 1 / row sum, delta
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
@@ -1007,9 +1008,9 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
         {
             const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qr, zero16, 0, 0, 0);    // S^T[j][i]
             const f32x16_t dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr, gr, zero16, 0, 0, 0);   // dP^T[j][i] = sum_d V[j][d] dO[i][d]
-            float p[16], mx = -INFINITY;
+            float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < NR; r++) {
                 const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
                 p[r] = j < len ? st[r] * scale : -INFINITY;
                 mx = fmaxf(mx, p[r]);
@@ -1017,16 +1018,16 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+            for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
             float delta = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { p[r] *= inv; delta += p[r] * dpt[r]; }
+            for (int r = 0; r < NR; r++) { p[r] *= inv; delta += p[r] * dpt[r]; }
             delta += __shfl_xor(delta, 32);
             if (hf == 0) { stat[c31] = mx; stat[32 + c31] = inv; stat[64 + c31] = delta; }
 #pragma unroll
-            for (int r = 0; r < 16; r++) p[r] = p[r] * (dpt[r] - delta) * scale;                     // dS^T[j][i]
+            for (int r = 0; r < NR; r++) p[r] = p[r] * (dpt[r] - delta) * scale;                     // dS^T[j][i]
             f32x16_t dq = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++)
@@ -1039,9 +1040,9 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             const f32x16_t s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kr, zero16, 0, 0, 0);     // S[i][j]
             const f32x16_t dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr, vr, zero16, 0, 0, 0);     // dP[i][j] = sum_d dO[i][d] V[j][d]
             const bool keyok = c31 < len;                       // a masked key has probability 0 for every query
-            float p[16], ds[16];
+            float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ds[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {                    // registers 4 q4 .. 4 q4 + 3 <-> queries 8 q4 + 4 hf .. + 3
+            for (int q4 = 0; q4 < NR / 4; q4++) {                    // registers 4 q4 .. 4 q4 + 3 <-> queries 8 q4 + 4 hf .. + 3
                 const float4 m4 = *reinterpret_cast<const float4*>(stat + 8 * q4 + 4 * hf);
                 const float4 i4 = *reinterpret_cast<const float4*>(stat + 32 + 8 * q4 + 4 * hf);
                 const float4 d4 = *reinterpret_cast<const float4*>(stat + 64 + 8 * q4 + 4 * hf);

@@ -170,9 +170,10 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
                 va[s].u[e] = base[key * TE_PQ + 2 * TE_D + (c31 & 15)];
             }
         const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);     // S^T[j][i]
-        float p[16], mx = -INFINITY;
+        constexpr int NR = TE_L <= 24 ? 12 : 16;                                   // registers 12..15 = keys 24..31: never valid
+        float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < NR; r++) {
             const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
             p[r] = j < TE_L ? st[r] * 0.25f : -INFINITY;                             // 1 / sqrt(16)
             mx = fmaxf(mx, p[r]);
@@ -180,11 +181,11 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+        for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
 #pragma unroll
-        for (int r = 0; r < 16; r++) p[r] *= inv;
+        for (int r = 0; r < NR; r++) p[r] *= inv;
         f32x16_t ot = zero16;
 #pragma unroll
         for (int s = 0; s < 2; s++)
