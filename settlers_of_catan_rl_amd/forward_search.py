@@ -161,7 +161,13 @@ class GraphedAct(object):
         with torch.cuda.graph(g):
             v, a, lp = self._run(st["f"], st["lists"], st["lens"], st["masks"])[:3]
         st["g"], st["v"], st["a"], st["lp"] = g, v, a, lp
+        st["sig"] = self._signature()
         return st
+
+    def _signature(self):
+        """where the policy's parameters live: a captured graph reads exactly these addresses"""
+        ps = list(self.policy.parameters())
+        return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), ps[0].dtype) if ps else ()
 
     def __call__(self, f, lists, lens, masks, with_logp=False):
         """-> (value [n,1], actions [n,18]) (+ log-prob [n,1] with `with_logp`) for n rows; eager when n exceeds the largest
@@ -180,6 +186,9 @@ class GraphedAct(object):
                 v, a, lp = self._run(f, lists, lens, masks)[:3]
                 return (v, a, lp) if with_logp else (v, a)
         st = self.graphs[B]
+        if st["sig"] != self._signature():                  # the parameters moved (a .to() / a rebuilt module): the graph is stale
+            self.graphs.clear()
+            return self.__call__(f, lists, lens, masks, with_logp)
         refresh = getattr(self.policy, "refresh_kernel_packs", None)
         if refresh is not None:
             refresh()                                           # host-side parameter packs a replay would not rebuild

@@ -53,3 +53,29 @@ def test_simulate_on_device_matches_oracle_env(hip_lib, oracle):
     got = fs.simulate(dev_env, net.cuda(), ctrl, init, max_depth=6, deterministic=True)
     assert np.allclose(got, want, rtol=2e-3, atol=2e-2), np.abs(got - want).max()
     assert np.array_equal(dev_env.export_state().cpu().numpy(), cpu_env.b.export())
+
+
+def test_graphed_act_recaptures_when_parameters_move(hip_lib):
+    """A captured hipGraph reads the parameters at fixed addresses: when they move (here: the net is rebuilt in place through
+    `.to()` round trips that reallocate), GraphedAct drops its graphs and captures again instead of replaying stale weights."""
+    import torch
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.forward_search import GraphedAct
+    torch.manual_seed(0)
+    env = VecCatanEnv(512, seed=3); env.random_rollout(0, 600)
+    f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+    net = CatanPolicy().cuda().inference_copy(torch.bfloat16)
+    ga = GraphedAct(net, buckets=(512,), autocast_dtype=torch.bfloat16, deterministic=True)
+    v0, a0 = ga(f, lists, lens, masks)
+    sig0 = ga.graphs[512]["sig"]
+    with torch.no_grad():
+        for p in net.parameters():                       # new storage for every parameter, different values
+            p.data = (p.data.float() + 0.05 * torch.randn_like(p.data.float())).to(p.dtype)
+    v1, a1 = ga(f, lists, lens, masks)
+    assert ga.graphs[512]["sig"] != sig0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ve, ae, _ = net.act(f, lists, lens, masks, deterministic=True)
+    # (a replay and an eager pass may pick different library GEMM kernels: bf16-rounding differences, a few arg-max flips)
+    assert float((v1.float() - ve.float()).abs().max()) < 0.1 and float((a1[:, 0] == ae[:, 0]).float().mean()) > 0.9
+    assert float((v1.float() - v0.float()).abs().max()) > 0.2                      # and it is not the old net that answered
