@@ -210,7 +210,8 @@ int64_t catan_missed_speculation_count(catan_env_t* env, catan_stream_t stream);
 /* Weight / bias gradient of a Linear layer with a huge row count and small widths (the tile / card / player modules of
  * RL/models: rows = 19 B .. 75 B, widths 6..256): dw[out][in] += sum_r dy[r][out] * x[r][in], db[out] += sum_r dy[r][out].
  * x [rows][in], dy [rows][out] bfloat16 row-major, 16-byte aligned; dw, db float32, ACCUMULATED into (zero them first);
- * db may be NULL.  MFMA (v_mfma_f32_16x16x32_bf16) with the rows split over the grid; in + 1 <= 160, out <= 256. */
+ * db may be NULL.  MFMA (v_mfma_f32_16x16x32_bf16) with the rows split over the grid; in + 1 <= 160, out <= 256 - or a wider input
+ * (in a multiple of 8 up to 1024, out a multiple of 8: the 512-wide trunk into the heads / the value head), done in column slices of 128. */
 int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features);
 int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
                        catan_stream_t stream);

@@ -138,6 +138,18 @@ static int lstm_cell_launch(bool bwd, const void* gx, const void* gh, const floa
     return CATAN_OK;
 }
 
+// the column slice [col0, col0 + W) of a layer whose input is `ld` wide (W, col0, ld multiples of 8; W + 1 <= 160): X rows are strided
+template <int OTW>
+static int wgrad_launch_slice(const void* x, const void* dy, float* dw, float* db, long R, int ld, int col0, int W, int O, hipStream_t st) {
+    long stages = (R + WG_KT - 1) / WG_KT;
+    long nb = stages / 8 < 1 ? 1 : (stages / 8 < 1024 ? stages / 8 : 1024);
+    long per = (stages + nb - 1) / nb * WG_KT;
+    nb = (R + per - 1) / per;
+    hipLaunchKernelGGL((k_wgrad_tr<OTW, 10>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, W, O, per,
+                       (long)ld, col0);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 template <int OTW, int IT>
 static int wgrad_launch(const void* x, const void* dy, float* dw, float* db, long R, int I, int O, hipStream_t st) {
     long stages = (R + WG_KT - 1) / WG_KT;
@@ -798,15 +810,35 @@ int catan_layer_norm_bwd(const void* x, const float* w, const float* b, const vo
 
 // k_step phase profile (100 MHz wall_clock64 ticks): enable/zero, then read [8] sums over waves + [8] maxima.
 // phases: stage-in, validate+apply, tier-1 longest road, holder logic (+cut), done/reward, reset, masks, write-back.
+static bool wgrad_sliced(int in_features, int out_features) {      // wide inputs: column slices of <= 128 (k_wgrad_tr on strided rows)
+    return in_features + 1 > 160 && in_features <= 1024 && (in_features & 7) == 0 && (out_features & 7) == 0 && out_features <= 256;
+}
 int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features) {
+    if (rows >= 1 && wgrad_sliced(in_features, out_features)) return 1;
     return rows >= 1 && in_features >= 1 && out_features >= 1 && in_features + 1 <= 160 && out_features <= 256;
 }
 
 int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
                        catan_stream_t stream) {
     if (!x || !dy || !dw || !catan_linear_wgrad_supported(rows, in_features, out_features))
-        return fail(CATAN_EINVAL, "catan_linear_wgrad: bad arguments / unsupported widths (in + 1 <= 160, out <= 256)");
+        return fail(CATAN_EINVAL, "catan_linear_wgrad: bad arguments / unsupported widths (in + 1 <= 160 or in a multiple of 8 up to 1024; out <= 256)");
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return fail(CATAN_EINVAL, "catan_linear_wgrad: x and dy must be 16-byte aligned");
+    if (wgrad_sliced(in_features, out_features)) {
+        const int otw = ((out_features + 15) / 16 + 3) / 4;
+        for (int c0 = 0; c0 < in_features; c0 += 128) {
+            const int W = in_features - c0 < 128 ? in_features - c0 : 128;
+            float* b = c0 == 0 ? db : nullptr;                // the bias gradient comes with the first slice
+            int r;
+            switch (otw) {
+            case 1: r = wgrad_launch_slice<1>(x, dy, dw, b, rows, in_features, c0, W, out_features, S(stream)); break;
+            case 2: r = wgrad_launch_slice<2>(x, dy, dw, b, rows, in_features, c0, W, out_features, S(stream)); break;
+            case 3: r = wgrad_launch_slice<3>(x, dy, dw, b, rows, in_features, c0, W, out_features, S(stream)); break;
+            default: r = wgrad_launch_slice<4>(x, dy, dw, b, rows, in_features, c0, W, out_features, S(stream)); break;
+            }
+            if (r != CATAN_OK) return r;
+        }
+        return CATAN_OK;
+    }
     const int it = (in_features + 1 + 15) / 16, otw = ((out_features + 15) / 16 + 3) / 4;
     switch (otw) {
     case 1: return wgrad_dispatch_it<1>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));

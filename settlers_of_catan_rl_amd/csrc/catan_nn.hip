@@ -549,12 +549,30 @@ __device__ __forceinline__ bf16x8_t wg_frag_tr(const unsigned short* T, int tile
     return r.f;
 }
 
+// the 64 x W block of rows r0 .. r0 + 63, columns col0 .. col0 + W - 1 of a row-major matrix with leading dimension ld
+// (W, col0, ld multiples of 8: every 16 B vector lies inside one row); rows >= R read as zero
+template <int NV>
+__device__ __forceinline__ void wg_load_cols(const unsigned short* __restrict__ src, long r0, long R, long ld, int col0, int W, uint4 (&v)[NV], int tid) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const unsigned f0 = (unsigned)(tid + 256 * j) * 8u;
+        v[j] = make_uint4(0, 0, 0, 0);
+        if (f0 < (unsigned)(WG_KT * W)) {
+            const unsigned row = f0 / (unsigned)W, col = f0 - row * (unsigned)W;
+            if (r0 + row < R) v[j] = *reinterpret_cast<const uint4*>(src + (r0 + row) * ld + col0 + col);
+        }
+    }
+}
 template <int OTW, int IT>
 __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
-                                                  float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block) {
+                                                  float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
+                                                  long ldx = 0, int col0 = 0) {
+    // ldx != 0: X is a column slice - columns col0 .. col0 + I - 1 of a matrix with leading dimension ldx, and dW the same
+    // columns of a weight gradient with that leading dimension (the layers wider than one launch covers are done in slices)
     constexpr int XC = IT * 16, YC = OTW * 4 * 16;           // padded column counts
     constexpr int NX = (WG_KT * XC / 8 + 255) / 256, NY = (WG_KT * YC / 8 + 255) / 256;
     constexpr int XE = IT * (WG_KT / 32) * WG_SUB, YE = OTW * 4 * (WG_KT / 32) * WG_SUB;
+    const long ldw = ldx ? ldx : I;
     __shared__ __attribute__((aligned(16))) unsigned short Xs[XE];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[YE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restri
 #pragma unroll
         for (int b = 0; b < IT; b++) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     uint4 vx[NX], vy[NY];
-    wg_load<NX>(X, r_begin * I, R * (long)I, I, vx, tid);
+    if (ldx) wg_load_cols<NX>(X, r_begin, R, ldx, col0, I, vx, tid); else wg_load<NX>(X, r_begin * I, R * (long)I, I, vx, tid);
     wg_load<NY>(dY, r_begin * O, R * (long)O, O, vy, tid);
     __syncthreads();                                         // zero fill complete
     for (long r0 = r_begin; r0 < r_end; r0 += WG_KT) {
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restri
         if (tid < WG_KT) Xs[wg_sub_off(I >> 4, tid >> 5) + (tid & 31) * 16 + (I & 15)] = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;   // bf16 1.0: the bias column
         __syncthreads();
         if (r0 + WG_KT < r_end) {                            // next stage's loads fly during the MFMAs
-            wg_load<NX>(X, (r0 + WG_KT) * I, R * (long)I, I, vx, tid);
+            if (ldx) wg_load_cols<NX>(X, r0 + WG_KT, R, ldx, col0, I, vx, tid); else wg_load<NX>(X, (r0 + WG_KT) * I, R * (long)I, I, vx, tid);
             wg_load<NY>(dY, (r0 + WG_KT) * O, R * (long)O, O, vy, tid);
         }
 #pragma unroll
@@ -604,7 +622,7 @@ __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restri
                 const int o = (wave * OTW + a) * 16 + 4 * (lane >> 4) + r, i = b * 16 + (lane & 15);
                 const float v = acc[a][b][r];
                 if (o < O && v != 0.0f) {
-                    if (i < I) atomicAdd(&dW[(long)o * I + i], v);
+                    if (i < I) atomicAdd(&dW[(long)o * ldw + col0 + i], v);
                     else if (i == I && db != nullptr) atomicAdd(&db[o], v);
                 }
             }

@@ -208,6 +208,15 @@ def _wgrad(x2, dy2, has_bias):
     return dw, db
 
 
+def wgrad_supported(rows, in_features, out_features):
+    return bool(_lib.lib().catan_linear_wgrad_supported(rows, in_features, out_features))
+
+
+def wgrad(x2, dy2):
+    """dW [O, I] (fp32) and db [O] of y = x @ W.T + b from bf16 x2 [rows, I], dy2 [rows, O] (catan_linear_wgrad)"""
+    return _wgrad(_aligned(x2), _aligned(dy2.to(torch.bfloat16)), True)
+
+
 class _LinearResidual(torch.autograd.Function):
     """res + (x @ w.T + b): the out-projection of an encoder sub-layer with the residual add fused into the product's row
     stores (same values as the two separate ops: the product is rounded to bf16 before the add)."""

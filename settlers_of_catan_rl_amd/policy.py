@@ -398,8 +398,12 @@ class _SegmentedTrunk(torch.autograd.Function):
             else:
                 dx[a:b] = contrib
                 seen.add((a, b))
-            dws.append((g.t() @ x[a:b]).to(w.dtype))
-            dbs.append(g.float().sum(0))
+            if x.is_cuda and x.dtype == torch.bfloat16 and b - a >= 4096 and nn_kernels.wgrad_supported(b - a, x.shape[1], g.shape[1]):
+                dw, db = nn_kernels.wgrad(x[a:b], g)        # MFMA weight-gradient kernel (column slices of the 512-wide trunk)
+                dws.append(dw.to(w.dtype)); dbs.append(db)
+            else:
+                dws.append((g.t() @ x[a:b]).to(w.dtype))
+                dbs.append(g.float().sum(0))
         for (a, b) in ctx.segs:
             if (a, b) not in seen:
                 dx[a:b] = 0

@@ -170,10 +170,11 @@ def test_small_layer_norm_kernel_vs_torch(hip_lib, D, dtype, relu):
 
 
 @pytest.mark.parametrize("R,I,O", [(100003, 60, 64), (5000, 6, 16), (70001, 64, 192), (33333, 152, 256), (4097, 16, 25),
-                                   (20000, 128, 64), (64, 16, 48), (130, 159, 256), (3001, 8, 8), (100001, 64, 128), (50001, 128, 256), (777, 152, 8)])
+                                   (20000, 128, 64), (64, 16, 48), (130, 159, 256), (3001, 8, 8), (100001, 64, 128), (50001, 128, 256), (777, 152, 8),
+                                   (20001, 512, 128), (30001, 256, 256), (5000, 1024, 64), (777, 168, 8)])
 def test_linear_wgrad_kernel_vs_torch(hip_lib, R, I, O):
     """k_wgrad / k_wgrad_tr (MFMA, rows split over the grid; widths that are multiples of 8 take the variant with the row-major
-    LDS image and transposing LDS reads): dw = dy^T x, db = column sums of dy, against fp32 torch on the same bf16 inputs.
+    LDS image and transposing LDS reads; inputs wider than 159 in column slices of 128): dw = dy^T x, db = column sums of dy, against fp32 torch on the same bf16 inputs.
     Asymmetric random data (a transposed or row/column-swapped result cannot pass)."""
     import ctypes as C
     from settlers_of_catan_rl_amd import _lib
