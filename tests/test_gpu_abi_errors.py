@@ -26,7 +26,8 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "bad device" in err(L.catan_create(C.byref(h), 99, 8, 0, 0, None))
     x = torch.zeros((128, 16), device="cuda", dtype=torch.bfloat16)
     dw = torch.zeros((300, 16), device="cuda")
-    assert not L.catan_linear_wgrad_supported(128, 16, 300) and not L.catan_linear_wgrad_supported(128, 200, 16)
+    assert not L.catan_linear_wgrad_supported(128, 16, 300) and not L.catan_linear_wgrad_supported(128, 203, 16) and not L.catan_linear_wgrad_supported(128, 2048, 16)
+    assert L.catan_linear_wgrad_supported(128, 200, 16)                      # (a wide input that is a multiple of 8: column slices)
     assert "unsupported" in err(L.catan_linear_wgrad(C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(dw.data_ptr()), None, 128, 16, 300, st))
     q = torch.zeros((4, 7, 3, 2, 8), device="cuda")
     assert "unsupported" in err(L.catan_attention_fwd(C.c_void_p(q.data_ptr()), None, C.c_void_p(q.data_ptr()), 4, 7, 2, 8, 0, st))
