@@ -252,7 +252,10 @@ void orc_set_config(OrcEnv* e, int max_trades_per_turn, double win_reward, int d
 }
 void orc_config_default(OrcEnv* e) {
     e->max_trades_per_turn = 4; e->win_reward = 500.0; e->dense_reward = 0; e->reward_annealing_factor = 1.0;
+    e->max_actions_per_turn = -1;
 }
+/* EnvWrapper(max_actions_per_turn) (env/wrapper.py:12-17): negative = None = np.inf */
+void orc_set_max_actions_per_turn(OrcEnv* e, int max_actions_per_turn) { e->max_actions_per_turn = max_actions_per_turn; }
 
 /* ====================================================================== reset */
 /* ref: board.py:50-65 */
@@ -602,7 +605,8 @@ void orc_masks(const OrcEnv* e, float* m) {
         }
         return;
     }
-    m[M0 + T_ENDTURN] = 1.0f;                                               /* :232 (max_actions_per_turn = inf) */
+    m[M0 + T_ENDTURN] = 1.0f;                                               /* :232 */
+    if (e->max_actions_per_turn >= 0 && e->actions_this_turn > e->max_actions_per_turn) return;   /* :233-234 */
     const int* res = pl->res;
     if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_WOOD] > 0 && res[R_BRICK] > 0) {      /* :238-243 */
         float v[54]; int any = 0;

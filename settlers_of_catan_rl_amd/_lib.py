@@ -17,7 +17,8 @@ class CatanHipError(RuntimeError):
 
 class CatanCfg(C.Structure):
     _fields_ = [("max_proposed_trades_per_turn", C.c_int32), ("dense_reward", C.c_int32), ("validate_actions", C.c_int32),
-                ("auto_reset", C.c_int32), ("win_reward", C.c_double), ("reward_annealing_factor", C.c_double)]
+                ("auto_reset", C.c_int32), ("win_reward", C.c_double), ("reward_annealing_factor", C.c_double),
+                ("max_actions_per_turn", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def _sources():
@@ -26,18 +27,51 @@ def _sources():
     return out
 
 
+_HASH_MARK = b"CATAN_BUILD_HASH="
+
+
+def source_hash():
+    """sha256 over the names and contents of csrc/* and include/catan_hip.h: what the library is built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in _sources():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:32]
+
+
+def binary_hash(path=None):
+    """The source hash baked into a built library (`catan_build_hash()`), read from the file without loading it."""
+    path = LIB_PATH if path is None else path
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        blob = f.read()
+    i = blob.find(_HASH_MARK)
+    if i < 0:
+        return None
+    return blob[i + len(_HASH_MARK):i + len(_HASH_MARK) + 32].decode("ascii", "replace")
+
+
 def build_library(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (it travels with the repo snapshot)."""
-    srcs = _sources()
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (it travels with the repo snapshot).  Rebuilt
+    whenever the hash of the sources differs from the one baked into the binary - file times mean nothing on a fresh checkout
+    or on a snapshot copied to the GPU box."""
+    want = source_hash()
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+           f'-DCATAN_BUILD_HASH_STR="{want}"', "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
+    have = binary_hash()
+    if not force and have == want:
         if verbose:
-            print(f"libcatan_hip.so is newer than its {len(srcs)} sources: not recompiled (command: {' '.join(cmd)})")
+            print(f"libcatan_hip.so carries the hash of its {len(_sources())} sources ({want}): not recompiled (command: {' '.join(cmd)})")
         return LIB_PATH
     if verbose:
-        print("compiling: " + " ".join(cmd))
+        print(f"compiling (binary hash {have}, source hash {want}): " + " ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    if binary_hash() != want:
+        raise CatanHipError("the freshly built libcatan_hip.so does not carry the source hash")
     if verbose:
         print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH)} bytes)")
     return LIB_PATH
@@ -47,6 +81,7 @@ _lib = None
 _vp = C.c_void_p
 
 _SIGS = {
+    "catan_build_hash": (C.c_char_p, []),
     "catan_cfg_default": (None, [C.POINTER(CatanCfg)]),
     "catan_state_words": (C.c_int32, []),
     "catan_mask_words": (C.c_int32, []),
@@ -137,6 +172,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        have, want = L.catan_build_hash().decode(), source_hash()
+        if have != want and not os.environ.get("CATAN_ALLOW_STALE_LIB"):
+            raise CatanHipError(f"{LIB_PATH} was built from other sources (binary {have}, sources {want}): rebuild with "
+                                "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = L
     return _lib
 

@@ -211,10 +211,19 @@ extern "C" {
 
 const char* catan_last_error(void) { return g_err.c_str(); }
 
+#ifndef CATAN_BUILD_HASH_STR
+#define CATAN_BUILD_HASH_STR "unhashed-build-0000000000000000"
+#endif
+// "CATAN_BUILD_HASH=" + the sha256 prefix of csrc/* and include/catan_hip.h the build script computed (_lib.source_hash):
+// the marker makes it readable from the file without loading the library
+static const char g_build_hash[] = "CATAN_BUILD_HASH=" CATAN_BUILD_HASH_STR;
+const char* catan_build_hash(void) { return g_build_hash + 17; }
+
 void catan_cfg_default(catan_cfg_t* c) {
     c->max_proposed_trades_per_turn = 4; c->win_reward = 500.0; c->dense_reward = 0;
-    c->reward_annealing_factor = 1.0; c->validate_actions = 1; c->auto_reset = 1;
+    c->reward_annealing_factor = 1.0; c->validate_actions = 1; c->auto_reset = 1; c->max_actions_per_turn = -1;
 }
+static inline Limits limits_of(const catan_env_t* e) { return Limits{ e->cfg.max_proposed_trades_per_turn, e->cfg.max_actions_per_turn }; }
 int32_t catan_state_words(void) { return STATE_WORDS; }
 int32_t catan_mask_words(void) { return MASK_BITS; }
 int32_t catan_action_words(void) { return ACTION_WORDS; }
@@ -226,7 +235,7 @@ static inline hipStream_t S(catan_stream_t s) { return (hipStream_t)s; }
 static inline unsigned blocks(long n, int b) { return (unsigned)((n + b - 1) / b); }
 
 static int launch_masks(catan_env_t* e, hipStream_t st) {
-    hipLaunchKernelGGL(k_masks, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn);
+    hipLaunchKernelGGL(k_masks, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, limits_of(e));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -367,7 +376,7 @@ int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream
 static StepCfg step_cfg(const catan_env_t* e) {
     StepCfg sc;
     sc.validate = e->cfg.validate_actions; sc.dense_reward = e->cfg.dense_reward; sc.win_reward = e->cfg.win_reward;
-    sc.annealing = e->cfg.reward_annealing_factor; sc.max_trades = e->cfg.max_proposed_trades_per_turn; sc.auto_reset = e->cfg.auto_reset;
+    sc.annealing = e->cfg.reward_annealing_factor; sc.lim = limits_of(e); sc.auto_reset = e->cfg.auto_reset;
     sc.reward64 = e->reward64;
     sc.prof = e->prof_on ? e->prof : nullptr;
     sc.prof_wave = e->prof_on == 2 ? e->prof_wave : nullptr;
@@ -424,7 +433,7 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
 // ev (optional): [9] before k_lr_heavy, [3] / [7] after it, [4] at the end
 static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int heavy_grid) {
     StepCfg sc = step_cfg(e);
-    const int sa = e->pend.sa, max_trades = e->cfg.max_proposed_trades_per_turn;
+    const int sa = e->pend.sa; const Limits max_trades = limits_of(e);
     const bool lockstep = heavy_grid == LR_HEAVY_GRID;
     u32* sctr = e->pend.ctr + 8 + 4 * sa;
     u8* busy = e->pend.stag < 2 ? e->pend.busy : nullptr;       // tagged games are released by the sampler, not here
@@ -478,7 +487,7 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
         HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         // ... and every game on the longest-road path that this step may end (k_step's list pend.spec) gets a speculative successor
         e->spec_epoch++;
-        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, e->cfg.max_proposed_trades_per_turn,
+        hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, limits_of(e),
                            (const u32*)(e->pend.ctr + 8 + 1), (const i32*)e->pend.resets[0][0], e->pend.busy, step_cfg(e).prof,
                            (const u32*)(e->pend.ctr + 6), (const u64*)e->pend.spec, e->spec_state, e->spec_mpk, e->spec_epoch);
         HIPCHK(hipEventRecord(e->ev_join, e->side));
@@ -851,7 +860,7 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
     hipLaunchKernelGGL(k_randomise_uncertainty, dim3(blocks(e->n, 64)), dim3(64), 0, S(stream), e->ctx, controlling_player, e->mpk, e->err,
-                       100000, e->cfg.max_proposed_trades_per_turn);
+                       100000, limits_of(e));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

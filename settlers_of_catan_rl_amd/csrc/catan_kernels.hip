@@ -993,8 +993,10 @@ DEVI int dev_card_mask(const S& s, int pid, u32& bank_bits) {
     return m;
 }
 // ref: env/wrapper.py:168-290
+// EnvWrapper(max_proposed_trades_per_turn, max_actions_per_turn) (wrapper.py:12-18); negative = None (no limit)
+struct Limits { int max_trades; int max_actions; };
 template <class S>
-DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
+DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], Limits lim) {
     // defaults: head 0 zeros, every other head all ones (wrapper.py:172-185)
     m[0] = 0xFFFFE000u;
 #pragma unroll
@@ -1073,7 +1075,11 @@ DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
         setr<M0, 13>(m, types);
         return;
     }
-    types = 1u << T_ENDTURN;                                               // wrapper.py:232 (max_actions_per_turn = inf)
+    types = 1u << T_ENDTURN;                                               // wrapper.py:232
+    if (lim.max_actions >= 0 && (int)s.w(W_ACTIONS) > lim.max_actions) {   // wrapper.py:233-234: only EndTurn is left
+        setr<M0, 13>(m, types);
+        return;
+    }
     load_boards(s, pid, b);
     int res[5];
 #pragma unroll
@@ -1116,16 +1122,16 @@ DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], int max_trades) {
     }
     {                                                                                      // :283-289
         int tot = res[0] + res[1] + res[2] + res[3] + res[4];
-        if (tot > 0 && (max_trades < 0 || s.b(B_TRADES) < max_trades)) types |= 1u << T_PROPOSE;
+        if (tot > 0 && (lim.max_trades < 0 || s.b(B_TRADES) < lim.max_trades)) types |= 1u << T_PROPOSE;
     }
     setr<M0, 13>(m, types);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, int max_trades) {
+__global__ __launch_bounds__(BLOCK) void k_masks(Ctx c, u32* __restrict__ mpk, Limits lim) {
     St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
     if (s.e >= c.N) return;
     u32 m[MASK_WORDS];
-    compute_masks(s, m, max_trades);
+    compute_masks(s, m, lim);
 #pragma unroll
     for (int i = 0; i < MASK_WORDS; i++) mpk[s.e * MPK_STRIDE + i] = m[i];
 }
@@ -1364,7 +1370,7 @@ DEVI void update_largest_army(const S& s) {
     }
 }
 
-struct StepCfg { int validate; int dense_reward; double win_reward; double annealing; int max_trades; int auto_reset;
+struct StepCfg { int validate; int dense_reward; double win_reward; double annealing; Limits lim; int auto_reset;
                  double* reward64;              // optional unrounded rewards [n][4] (catan_set_reward_f64_buffer)
                  unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
                  u32* prof_wave; };             // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
@@ -1533,7 +1539,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
     if (doit && !want_reset) {
         u32 m[MASK_WORDS];
-        compute_masks(s, m, cfg.max_trades);
+        compute_masks(s, m, cfg.lim);
         if (m_out != nullptr) {                       // the caller stores the rows (k_step: row-wise through LDS)
 #pragma unroll
             for (int i = 0; i < MASK_WORDS; i++) m_out[i] = m[i];
@@ -2145,7 +2151,7 @@ __global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ 
 // the masks of the fresh game.
 // dstR != nullptr: a SPECULATIVE re-deal - the fresh record (and its masks, through `mpk`) go to the shadow arrays, the game
 // itself is only read (its stream position).  k_install_list copies the shadow over the game if the game did end.
-DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, int max_trades, u8* busy,
+DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, Limits lim, u8* busy,
                            unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr) {
     u32* const outR = dstR ? dstR : c.R;
     __builtin_amdgcn_wave_barrier();
@@ -2180,7 +2186,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
         }
         if (mpk != nullptr) {
             u32 m[MASK_WORDS];
-            compute_masks(s, m, max_trades);
+            compute_masks(s, m, lim);
 #pragma unroll
             for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
         }
@@ -2194,7 +2200,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
 // every game on the tier-2 list - if such a game turns out to end, k_install_list copies the shadow over it
 // instead of a second, fully exposed re-deal pass at the end of the step (a re-deal depends only on the game's stream
 // position, which the rest of the step does not move).
-__global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
+__global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, Limits lim, const u32* __restrict__ count_p,
                                                    const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof,
                                                    const u32* __restrict__ spec_count_p, const u64* __restrict__ spec_list,
                                                    u32* __restrict__ specR, u32* __restrict__ spec_mpk, u32 epoch) {
@@ -2202,17 +2208,17 @@ __global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk,
     __shared__ ResetScratch sc;
     const u32 count = *count_p, scount = spec_list ? *spec_count_p : 0u;
     for (u32 r = blockIdx.x; r < count + scount; r += gridDim.x) {
-        if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, max_trades, busy, prof);
+        if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, lim, busy, prof);
         else {
             const long e = (long)(spec_list[r - count] & 0x00FFFFFFFFFFFFFFull);
-            wave_reset_game(c, e, rec, sc, threadIdx.x, spec_mpk, max_trades, nullptr, nullptr, specR);
+            wave_reset_game(c, e, rec, sc, threadIdx.x, spec_mpk, lim, nullptr, nullptr, specR);
             if (threadIdx.x == 0) spec_mpk[e * MPK_STRIDE + MPK_STRIDE - 1] = epoch;      // "this shadow belongs to step `epoch`"
         }
     }
 }
 // the games of `list` take their speculatively dealt successors: record (hot and cold part) and masks.  A game without a
 // shadow of this step (the may-end filter of k_step is meant to be a superset; this is the safety net) is re-dealt here.
-__global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mpk, int max_trades, const u32* __restrict__ count_p,
+__global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mpk, Limits lim, const u32* __restrict__ count_p,
                                                      const i32* __restrict__ list, u8* __restrict__ busy, const u32* __restrict__ specR,
                                                      const u32* __restrict__ spec_mpk, u32 epoch, u32* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
@@ -2223,7 +2229,7 @@ __global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mp
         const long e = list[r];
         if (spec_mpk[e * MPK_STRIDE + MPK_STRIDE - 1] != epoch) {
             if (lane == 0) atomicAdd(err + 2, 1u);                                       // counted: catan_missed_speculation_count
-            wave_reset_game(c, e, rec, sc, lane, mpk, max_trades, busy, nullptr);
+            wave_reset_game(c, e, rec, sc, lane, mpk, lim, busy, nullptr);
             continue;
         }
         if (lane < REC / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(specR + e * REC)[lane];
@@ -2241,7 +2247,7 @@ __global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel)
     __shared__ ResetScratch sc;
     for (long e = blockIdx.x; e < c.N; e += gridDim.x) {
         if (sel != nullptr && (e >= c.n || sel[e] == 0)) continue;
-        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, 0, nullptr);
+        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, Limits{ -1, -1 }, nullptr);
     }
 }
 
@@ -2417,7 +2423,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
 // [index][lane].  ctrl[e] = controlling PlayerId 1..4 (0: leave game e alone).  The reference loops forever on states
 // whose estimates admit no consistent deal; here the loop is capped (max_attempts) and such games are counted in err[1].
 __global__ __launch_bounds__(64) void k_randomise_uncertainty(Ctx c, const i32* __restrict__ ctrl, u32* __restrict__ mpk, u32* __restrict__ err,
-                                                              int max_attempts, int max_trades) {
+                                                              int max_attempts, Limits lim) {
     __shared__ u8 pool[32][64];
     __shared__ u8 lst[96][64];
     __shared__ u8 prop[20][64], hand[20][64], emx[20][64];
@@ -2527,7 +2533,7 @@ __global__ __launch_bounds__(64) void k_randomise_uncertainty(Ctx c, const i32* 
         for (int r = 0; r < 5; r++) s.spb(p, P_RES + r, prop[p * 5 + r][lane]);
     s.sw(W_RNG, rng.draws);
     u32 m[MASK_WORDS];
-    compute_masks(s, m, max_trades);
+    compute_masks(s, m, lim);
 #pragma unroll
     for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
 }

@@ -121,8 +121,9 @@ class GradBucket(object):
 
 
 def allreduce_flat_grads(params, world=None):
-    """Stateless variant for callers without a GradBucket: fixed layout over ALL the given parameters (missing gradients
-    are sent as zeros and left missing).  Averages in place."""
+    """Stateless variant for callers without a GradBucket: fixed layout over ALL the given parameters.  A parameter without a
+    gradient on this rank sends zeros and RECEIVES the average like everybody else (left missing, the ranks that do have a
+    gradient would apply the averaged update and this one would skip it: the replicas would drift apart).  Averages in place."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
     params = [p for p in params]
@@ -136,6 +137,8 @@ def allreduce_flat_grads(params, world=None):
         n = p.numel()
         if p.grad is not None:
             p.grad.copy_(flat[off:off + n].view_as(p))
+        else:
+            p.grad = flat[off:off + n].view_as(p).clone()
         off += n
 
 

@@ -25,7 +25,7 @@ def _stream():
 
 class VecCatanEnv(object):
     def __init__(self, num_envs, seed=0, env_id0=0, device=None, max_proposed_trades_per_turn=4, win_reward=500.0,
-                 dense_reward=False, validate_actions=True, auto_reset=True):
+                 dense_reward=False, validate_actions=True, auto_reset=True, max_actions_per_turn=None):
         if not torch.cuda.is_available():
             raise _lib.CatanHipError("VecCatanEnv needs a HIP device (no CPU fallback)")
         self.L = _lib.lib()
@@ -38,6 +38,11 @@ class VecCatanEnv(object):
         cfg.dense_reward = int(bool(dense_reward))
         cfg.validate_actions = int(bool(validate_actions))
         cfg.auto_reset = int(bool(auto_reset))
+        if max_actions_per_turn is not None and (max_actions_per_turn != max_actions_per_turn or max_actions_per_turn < 0):
+            raise ValueError("max_actions_per_turn must be None (no limit) or a non-negative number")
+        # env/wrapper.py:14-17,233: None -> np.inf; the test is `actions_this_turn > max_actions_per_turn` on an integer counter
+        cfg.max_actions_per_turn = -1 if (max_actions_per_turn is None or max_actions_per_turn == float("inf")) \
+            else int(min(max_actions_per_turn // 1, 2 ** 31 - 1))
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -269,11 +274,20 @@ class _GameView(object):
 class EnvWrapper(object):
     """Single-game view with the reference EnvWrapper signatures (env/wrapper.py:11-50)."""
 
-    def __init__(self, max_proposed_trades_per_turn=4, validate_actions=True, win_reward=500, dense_reward=False,
-                 seed=0, env_id=0, **_ignored):
+    def __init__(self, interactive=False, max_actions_per_turn=None, max_proposed_trades_per_turn=4, validate_actions=True,
+                 debug_mode=False, win_reward=500, dense_reward=False, policies=None, seed=0, env_id=0):
+        """The reference's keyword arguments in the reference's order (env/wrapper.py:12-13) plus the game's Philox stream
+        (seed, env_id).  Anything else is a TypeError, as with the reference; `interactive` / `debug_mode` / `policies` drive
+        the reference's pygame display and its text log (game/game.py:30-37), which are out of scope: only their defaults."""
+        if interactive or debug_mode or policies is not None:
+            raise NotImplementedError("EnvWrapper(interactive / debug_mode / policies): the reference's display and text log "
+                                      "are not part of the batched HIP path")
         self.vec = VecCatanEnv(1, seed=seed, env_id0=env_id, max_proposed_trades_per_turn=max_proposed_trades_per_turn,
                                win_reward=win_reward, dense_reward=dense_reward, validate_actions=validate_actions,
-                               auto_reset=False)
+                               auto_reset=False, max_actions_per_turn=max_actions_per_turn)
+        self.max_actions_per_turn = float("inf") if max_actions_per_turn is None else max_actions_per_turn
+        self.max_proposed_trades_per_turn = max_proposed_trades_per_turn
+        self.win_reward, self.dense_reward = win_reward, dense_reward
         self.vec.enable_reward64()       # step() hands back the reference's Python floats (unrounded doubles)
         self.validate_actions = validate_actions
         self.game = _GameView(self)

@@ -167,7 +167,7 @@ class GraphedAct(object):
     def _signature(self):
         """where the policy's parameters live: a captured graph reads exactly these addresses"""
         ps = list(self.policy.parameters())
-        return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), ps[0].dtype) if ps else ()
+        return (len(ps), hash(tuple(p.data_ptr() for p in ps)), ps[0].dtype) if ps else ()   # EVERY parameter: one replaced in the middle is stale too
 
     def __call__(self, f, lists, lens, masks, with_logp=False):
         """-> (value [n,1], actions [n,18]) (+ log-prob [n,1] with `with_logp`) for n rows; eager when n exceeds the largest

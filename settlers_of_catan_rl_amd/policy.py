@@ -602,6 +602,11 @@ class _ActionHeads(nn.Module):
             if t not in _is:
                 _is[t] = (typ == t).float()
             return _is[t]
+        # Every (typ == t) the branches share is produced HERE, on the current stream, before the fork: a value first computed
+        # (and cached) inside one branch and read by another would cross streams without an event edge between them - in the
+        # captured hipGraph the reader would have no dependency on its producer.
+        for t in (T_SETTLE, T_CITY, T_ROAD, T_ROBBER, T_RESPOND, T_PROPOSE, T_STEAL, T_DISCARD, T_PLAYDEV, T_EXCHANGE):
+            is_(t)
         # Everything below depends on the sampled type only (heads 9 / 10 also on the card of head 4, head 8 on head 7): four
         # independent chains, forked onto side streams in inference (see _Branches); the results are combined after the join.
         br = _HEAD_BRANCHES.fork(main)

@@ -60,8 +60,10 @@ _LOSS_WS = {}
 
 
 def _loss_workspace(device):
-    """zeroed once; every k_ppo_loss call leaves it zero (include/catan_hip.h)"""
-    key = (device.type, device.index)
+    """zeroed once; every k_ppo_loss call leaves it zero (include/catan_hip.h).  One per (device, STREAM): launches in flight on
+    two streams (the trainer beside the reference_api.PPO adapter, a side-stream caller) must not share partial sums and the
+    arrival counter."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     if key not in _LOSS_WS:
         _LOSS_WS[key] = torch.zeros((_lib.lib().catan_ppo_loss_workspace_doubles(),), dtype=torch.float64, device=device)
     return _LOSS_WS[key]

@@ -45,6 +45,8 @@ class RolloutStorage(object):
             p = packed.contiguous()
             rows = p.numel() // p.shape[-1]
             out = torch.empty(packed.shape[:-1] + (spec.MASK_WORDS,), dtype=torch.float32, device=p.device)
+            if rows == 0:                                             # an empty selection (empty minibatch / group): nothing to expand
+                return out
             _lib.check(_lib.lib().catan_expand_masks(C.c_void_p(p.data_ptr()), rows, int(p.shape[-1]), C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             return out

@@ -36,12 +36,15 @@ def decode_obs(traj):
 
 # the last two were generated with EnvWrapper's NON-default keyword arguments (env/wrapper.py:12-13): dense rewards x
 # env.reward_annealing_factor 0.37 with 1 proposed trade per turn; dense rewards with unlimited trades
-TRAJS = ["traj_s3_e0.npz", "traj_s3_e1.npz", "traj_s17_e4.npz", "traj_dense037_t1_s5_e2.npz", "traj_dense_tnone_s5_e3.npz"]
+# ; a finite max_actions_per_turn = 2 (wrapper.py:233-234: only EndTurn stays legal once actions_this_turn exceeds it)
+TRAJS = ["traj_s3_e0.npz", "traj_s3_e1.npz", "traj_s17_e4.npz", "traj_dense037_t1_s5_e2.npz", "traj_dense_tnone_s5_e3.npz",
+         "traj_maxact2_s7_e1.npz"]
 
 
 def traj_kwargs(t):
-    """-> (dense_reward, reward_annealing_factor, max_proposed_trades_per_turn) a trajectory was generated with"""
+    """-> (dense_reward, reward_annealing_factor, max_proposed_trades_per_turn, max_actions_per_turn) a trajectory was generated with"""
+    ma = None if ("max_actions" not in t.files or int(t["max_actions"]) < 0) else int(t["max_actions"])
     if "dense" not in t.files:
-        return False, 1.0, 4
+        return False, 1.0, 4, ma
     tr = int(t["trades"])
-    return bool(int(t["dense"])), float(t["anneal"]), (None if tr < 0 else tr)
+    return bool(int(t["dense"])), float(t["anneal"]), (None if tr < 0 else tr), ma

@@ -35,6 +35,7 @@ def lib():
         L.orc_rng_draws.argtypes = [vp]; L.orc_rng_draws.restype = C.c_uint32
         L.orc_config_default.argtypes = [vp]
         L.orc_set_config.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double]
+        L.orc_set_max_actions_per_turn.argtypes = [vp, C.c_int]
         L.orc_last_reward64.argtypes = [vp, C.POINTER(C.c_double)]
         L.orc_board_reset.argtypes = [vp]
         L.orc_game_reset.argtypes = [vp]
@@ -92,10 +93,12 @@ class OracleEnv(object):
         else:
             L.orc_seed_philox(self.p, seed, env_id)
 
-    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0):
-        """EnvWrapper keyword arguments (env/wrapper.py:12-13); max_trades_per_turn None = unlimited"""
+    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0,
+                   max_actions_per_turn=None):
+        """EnvWrapper keyword arguments (env/wrapper.py:12-13); max_trades_per_turn / max_actions_per_turn None = unlimited"""
         mt = -1 if max_trades_per_turn is None else int(max_trades_per_turn)
         self.L.orc_set_config(self.p, mt, float(win_reward), int(dense_reward), float(reward_annealing_factor))
+        self.L.orc_set_max_actions_per_turn(self.p, -1 if max_actions_per_turn is None else int(max_actions_per_turn))
 
     def last_reward64(self):
         r = np.zeros((4,), dtype=np.float64)
@@ -201,10 +204,13 @@ class OracleBatch(object):
         for i in range(self.n):
             self.L.orc_import(self.env_ptr(i), _p(blobs[i], C.c_int32))
 
-    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0):
+    def set_config(self, max_trades_per_turn=4, win_reward=500.0, dense_reward=False, reward_annealing_factor=1.0,
+                   max_actions_per_turn=None):
         mt = -1 if max_trades_per_turn is None else int(max_trades_per_turn)
+        ma = -1 if max_actions_per_turn is None else int(max_actions_per_turn)
         for i in range(self.n):
             self.L.orc_set_config(self.env_ptr(i), mt, float(win_reward), int(dense_reward), float(reward_annealing_factor))
+            self.L.orc_set_max_actions_per_turn(self.env_ptr(i), ma)
 
     def masks(self):
         m = np.zeros((self.n, MASK_WORDS), dtype=np.float32)

@@ -27,8 +27,9 @@ def test_reset_states_vs_reference(hip_lib):
 def test_trajectory_vs_reference(hip_lib, name):
     import torch
     t = gu.load(name)
-    dense, anneal, trades = gu.traj_kwargs(t)
-    env = _env(1, int(t["seed"]), env_id0=int(t["env_id"]), auto_reset=True, dense_reward=dense, max_proposed_trades_per_turn=trades)
+    dense, anneal, trades, max_actions = gu.traj_kwargs(t)
+    env = _env(1, int(t["seed"]), env_id0=int(t["env_id"]), auto_reset=True, dense_reward=dense, max_proposed_trades_per_turn=trades,
+               max_actions_per_turn=max_actions)
     env.set_reward_annealing_factor(anneal)
     r64 = env.enable_reward64()
     sample = {int(i): k for k, i in enumerate(t["sample_idx"])}
@@ -56,13 +57,13 @@ def test_reference_states_masks(hip_lib):
     groups = {}
     for name in gu.TRAJS:
         t = gu.load(name)
-        _, _, trades = gu.traj_kwargs(t)
-        blobs, masks = groups.setdefault(trades, ([], []))
+        _, _, trades, max_actions = gu.traj_kwargs(t)
+        blobs, masks = groups.setdefault((trades, max_actions), ([], []))
         for k, i in enumerate(t["sample_idx"]):
             blobs.append(t["sample_blob"][k].astype(np.int32)); masks.append(gu.unpack_masks(t["masks"][int(i)]))
-    assert len(groups) >= 3
-    for trades, (blobs, masks) in groups.items():
-        env = _env(len(blobs), 0, max_proposed_trades_per_turn=trades)
+    assert len(groups) >= 4
+    for (trades, max_actions), (blobs, masks) in groups.items():
+        env = _env(len(blobs), 0, max_proposed_trades_per_turn=trades, max_actions_per_turn=max_actions)
         env.import_state(np.array(blobs))
         assert np.array_equal(env.export_state().cpu().numpy(), np.array(blobs))
         assert np.array_equal(env.get_action_masks().cpu().numpy(), np.array(masks)), trades

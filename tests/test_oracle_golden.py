@@ -64,8 +64,8 @@ def test_reset_states(oracle):
 def test_trajectory(oracle, name):
     t = gu.load(name)
     e = oracle.OracleEnv(int(t["seed"]), int(t["env_id"]))
-    dense, anneal, trades = gu.traj_kwargs(t)
-    e.set_config(max_trades_per_turn=trades, dense_reward=dense, reward_annealing_factor=anneal)
+    dense, anneal, trades, max_actions = gu.traj_kwargs(t)
+    e.set_config(max_trades_per_turn=trades, dense_reward=dense, reward_annealing_factor=anneal, max_actions_per_turn=max_actions)
     e.reset()
     sample = {int(i): k for k, i in enumerate(t["sample_idx"])}
     obs_gold = gu.decode_obs(t)

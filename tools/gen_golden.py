@@ -67,11 +67,12 @@ def gen_resets(n=192, seed=11):
     np.savez_compressed(os.path.join(OUT, "reset_states.npz"), seed=seed, blobs=np.array(blobs, dtype=np.int32))
 
 
-def gen_traj(seed, env_id, steps, sample_every=97, name=None, dense=False, anneal=1.0, trades=4):
-    """name/dense/anneal/trades: EnvWrapper's non-default keyword arguments (env/wrapper.py:12-13: dense shaping :95-106 x
-    env.reward_annealing_factor, trade limit :284-289); `rewards64` holds the reference's Python-float rewards."""
+def gen_traj(seed, env_id, steps, sample_every=97, name=None, dense=False, anneal=1.0, trades=4, max_actions=None):
+    """name/dense/anneal/trades/max_actions: EnvWrapper's non-default keyword arguments (env/wrapper.py:12-13: dense shaping
+    :95-106 x env.reward_annealing_factor, trade limit :284-289, max_actions_per_turn :14-17,233-234); `rewards64` holds the
+    reference's Python-float rewards."""
     rng = np.random.default_rng(seed * 7919 + env_id)
-    e = rh.RefEnv(seed, env_id, dense_reward=dense, max_proposed_trades_per_turn=trades)
+    e = rh.RefEnv(seed, env_id, dense_reward=dense, max_proposed_trades_per_turn=trades, max_actions_per_turn=max_actions)
     e.env.reward_annealing_factor = anneal
     obs = e.reset()
     actions, rewards, dones, deciding, masks, crcs, rewards64 = [], [], [], [], [], [], []
@@ -90,7 +91,8 @@ def gen_traj(seed, env_id, steps, sample_every=97, name=None, dense=False, annea
             obs = e.reset()
     np.savez_compressed(
         os.path.join(OUT, name or f"traj_s{seed}_e{env_id}.npz"), seed=seed, env_id=env_id,
-        dense=int(dense), anneal=float(anneal), trades=-1 if trades is None else int(trades), rewards64=np.array(rewards64, dtype=np.float64),
+        dense=int(dense), anneal=float(anneal), trades=-1 if trades is None else int(trades),
+        max_actions=-1 if max_actions is None else int(max_actions), rewards64=np.array(rewards64, dtype=np.float64),
         actions=np.array(actions, dtype=np.int8), rewards=np.array(rewards, dtype=np.float32), dones=np.array(dones, dtype=np.uint8),
         deciding=np.array(deciding, dtype=np.int8), masks=np.array(masks, dtype=np.uint8), state_crc=np.array(crcs, dtype=np.uint32),
         sample_idx=np.array(s_idx, dtype=np.int32), sample_blob=np.array(s_blob, dtype=np.int16),
@@ -476,6 +478,9 @@ if __name__ == "__main__":
         print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
         print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "maxact":
+        print("max_actions_per_turn = 2: games", gen_traj(7, 1, 5200, name="traj_maxact2_s7_e1.npz", max_actions=2))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gae_ppo":
         gen_gae_ppo(); print("gae/ppo"); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
@@ -491,6 +496,7 @@ if __name__ == "__main__":
     print("randomise", gen_randomise())
     print("dense x 0.37, 1 trade/turn: games", gen_traj(5, 2, 2400, name="traj_dense037_t1_s5_e2.npz", dense=True, anneal=0.37, trades=1))
     print("dense, unlimited trades: games", gen_traj(5, 3, 2400, name="traj_dense_tnone_s5_e3.npz", dense=True, anneal=1.0, trades=None))
+    print("max_actions_per_turn = 2: games", gen_traj(7, 1, 5200, name="traj_maxact2_s7_e1.npz", max_actions=2))
     print("rollout_small", gen_rollout_small())
     print("eval_small", gen_eval_small())
     os.system(f"ls -la {OUT}; du -sh {OUT}")
