@@ -127,9 +127,9 @@ def _reps_for(per_pass_s, steps):
 def ppo_update_record(env, n, rank, world, T, cdist):
     """The metric's second half (BASELINE.json: "PPO wall-clock/update, 1->8 GPU"; workload RL/ppo/arguments.py:48-56) on the
     same games: one rollout of T active-seat decisions per game + one PPO update with the reference's 10 epochs x 64
-    minibatches, bf16 autocast, fp32 master weights, flat-bucket gradient all-reduce over RCCL when world > 1.  T is REDUCED
-    from the reference's 200 so that the default bench run stays within minutes (the minibatch count is the reference's;
-    a minibatch has T * n / 64 rows); tools/bench_ppo.py runs the full T = 200."""
+    minibatches, bf16 autocast, fp32 master weights, flat-bucket gradient all-reduce over RCCL when world > 1.  T defaults to
+    the reference's 200 (a minibatch has T * n / 64 = 204 800 rows at 65 536 games; ~63 GB of rollout tensors in HBM); two
+    updates are run and the SECOND is reported (the first one also captures the policy pass's hipGraph and warms the allocator)."""
     import torch
     from settlers_of_catan_rl_amd.policy import CatanPolicy
     from settlers_of_catan_rl_amd.rollout import RolloutCollector
@@ -161,8 +161,11 @@ def ppo_update_record(env, n, rank, world, T, cdist):
             "decisions_per_s": dec / (rollout_s + update_s), "dtype": "bf16 autocast, fp32 master weights",
             "losses": {"value": vl, "action": al, "entropy": el},
             "first_update": first,
-            "note": "T reduced from the reference's 200 (stated); every seat plays the central policy; value = the second update (steady "
-                    "state), the first one (one-time hipGraph capture of the policy pass included) is in first_update; full T: tools/bench_ppo.py"}
+            "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "note": ("the reference's workload (RL/ppo/arguments.py:48-56: T = 200, 10 epochs x 64 minibatches)" if T == 200 else
+                     f"T = {T} instead of the reference's 200 (stated)") +
+                    "; every seat plays the central policy; value = the second update (steady state), the first one (one-time "
+                    "hipGraph capture of the policy pass included) is in first_update"}
 
 
 def main():
@@ -179,8 +182,9 @@ def main():
                     help="W > 0: deferred loop, tier-2 longest road + re-deals once per W passes; 0: lock-step loop")
     ap.add_argument("--no-lockstep", action="store_true", help="skip the lock-step measurement of a deferred run")
     ap.add_argument("--preroll", type=int, default=PREROLL_PASSES, help="untimed passes before --warmup (mixes the games' ages)")
-    ap.add_argument("--ppo-steps", type=int, default=16,
-                    help="T of the `ppo_update` sub-record (one rollout + one PPO update on the same games); 0: skip")
+    ap.add_argument("--ppo-steps", type=int, default=200,
+                    help="T of the `ppo_update` sub-record (two rollouts + PPO updates on the same games, the second one reported; "
+                         "200 = the reference's num_steps, RL/ppo/arguments.py:54-56); 0: skip")
     args = ap.parse_args()
 
     import torch

@@ -136,11 +136,11 @@ def test_validate_rejects_illegal_action(hip_lib):
     assert np.array_equal(env.export_state().cpu().numpy(), before)
 
 
-def test_full_size_invariants_and_sampled_parity(oracle, hip_lib):
-    """BASELINE.json's full size (65 536 games, the bench's deferred schedule): size-independent properties of every game
-    - cards are conserved (bank + hands = 19 per resource; pile + hidden + played = 25 development cards), buildings
-    and roads are owned consistently, no busy game is left behind - and bit-exact state parity with the oracle for a sample
-    of the games (each after exactly its own number of decisions)."""
+def test_full_size_deferred_all_games_parity_and_invariants(oracle, hip_lib):
+    """BASELINE.json's full size on the bench's schedule (65 536 games, deferred, W = 32): EVERY game's state and masks
+    bit-identical to the CPU oracle after exactly that game's own number of decisions (OpenMP over the host cores), plus the
+    size-independent properties - cards are conserved (bank + hands = 19 per resource; pile + hidden + played = 25
+    development cards), buildings and roads are owned consistently, no finished game is left standing."""
     n, seed, iters = 65536, 4, 2200
     env = _env(n, seed)
     env.random_rollout_deferred(iters, 32)
@@ -161,12 +161,11 @@ def test_full_size_invariants_and_sampled_parity(oracle, hip_lib):
     bld, own = f("corner_bld"), f("corner_owner")
     assert ((bld > 0) == (own > 0)).all() and (own <= 4).all() and (f("edge_owner") <= 4).all()
     assert (f("winner")[:, 0] == 0).all()                      # auto-reset: no finished game is left standing
-    # sampled parity: every 257th game against the oracle after exactly its own number of decisions
-    idx = np.arange(0, n, 257)
-    for i in idx[:: max(1, len(idx) // 64)]:
-        ob = oracle.OracleBatch(1, seed, env_id0=int(i))
-        want = ob.run_random_counts(np.array([cnt[i]]))
-        assert np.array_equal(blobs[i], want[0]), f"game {i} after {cnt[i]} decisions:\n" + spec.describe_state_diff(want[0], blobs[i])
+    ob = oracle.OracleBatch(n, seed)
+    want = ob.run_random_counts(cnt)
+    _assert_blobs_equal(blobs, want, f"all {n} games after their own number of decisions (deferred, W = 32)")
+    assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+    assert ob.games.value > 1000
 
 
 def test_estimate_bytes_above_127_take_the_fieldwise_path(oracle, hip_lib):
@@ -198,22 +197,81 @@ def test_estimate_bytes_above_127_take_the_fieldwise_path(oracle, hip_lib):
     assert env.invalid_action_count() == 0
 
 
-def test_full_size_lockstep_sampled_parity(oracle, hip_lib):
+@pytest.mark.parametrize("dense", [False, True])
+def test_full_size_lockstep_all_games_parity(oracle, hip_lib, dense):
     """The lock-step schedule (catan_step / the learner's schedule) at BASELINE.json's full size: 65 536 games x 600 steps
-    with auto-reset, then blocks of games from the start, the middle and the end of the range replayed by the CPU oracle
-    (global game ids: the oracle batch starts at the block's first id): state blobs and masks bit-identical; no missed
-    speculation, no rejected action."""
-    n, steps, seed = 65536, 600, 41
-    env = _env(n, seed)
+    with auto-reset, ALL games replayed by the CPU oracle (OpenMP over the host cores): state blobs and masks
+    bit-identical; no missed speculation, no rejected action.  Once with the reference's defaults, once with
+    EnvWrapper(dense_reward=True, max_proposed_trades_per_turn=None) x reward_annealing_factor 0.37 and
+    max_actions_per_turn = 6 (the shaping itself is compared reward by reward in the trajectory fixtures; here the different
+    trade / action limits change every game's trajectory)."""
+    n, steps, seed = 65536, 600, 41 + int(dense)
+    kw = dict(dense_reward=True, max_proposed_trades_per_turn=None, max_actions_per_turn=6) if dense else {}
+    env = _env(n, seed, **kw)
+    ob = oracle.OracleBatch(n, seed)
+    if dense:
+        env.set_reward_annealing_factor(0.37)
+        ob.set_config(max_trades_per_turn=None, dense_reward=True, reward_annealing_factor=0.37, max_actions_per_turn=6)
     env.random_rollout(0, steps)
     assert env.invalid_action_count() == 0 and env.missed_speculation_count() == 0
-    state, masks = env.export_state().cpu().numpy(), env.get_action_masks().cpu().numpy()
-    for first in (0, 31000, n - 96):
-        ob = oracle.OracleBatch(96, seed, env_id0=first)
-        want = ob.run_random(steps)
-        got = state[first:first + 96]
-        bad = np.flatnonzero((got != want).any(axis=1))
-        assert len(bad) == 0, f"block at {first}: game {first + bad[0]}:\n" + spec.describe_state_diff(want[bad[0]], got[bad[0]])
-        assert np.array_equal(masks[first:first + 96], ob.masks())
+    want = ob.run_random(steps)
+    _assert_blobs_equal(env.export_state().cpu().numpy(), want, f"all {n} games after {steps} lock-step steps (dense={dense})")
+    assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
     t1, t2, launches = env.slow_path_counts()
     assert launches == steps and 0 <= t2 < t1 < n * steps
+    assert ob.games.value > 100
+
+
+def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
+    """SURVEY a4 (Game.validate_action, game/game.py:264-525, env/wrapper.py:38-41): random LEGAL and ILLEGAL 18-word actions
+    on 4 096 games of mixed ages -> the HIP path accepts exactly the actions `orc_action_is_legal` accepts; a rejected
+    action leaves the game untouched (state, masks), pays no reward, is counted; the accepted ones advance the games exactly as
+    the oracle does.  Corruptions: another action type, and / or random values (in and out of range) in the sub-heads."""
+    import ctypes as C
+    import torch
+    n, seed = 4096, 23
+    env = _env(n, seed)
+    ob = oracle.OracleBatch(n, seed)
+    env.random_rollout(0, 300)
+    ob.run_random(300, want_blobs=False)
+    rng = np.random.default_rng(99)
+    hi = np.array([13, 54, 73, 19, 5, 2, 3, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5])          # exclusive upper bound of every action word
+    rejected_total, accepted_total, legal_after_corruption = 0, 0, 0
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    for rnd in range(24):
+        a = env.sample_random_actions(300 + rnd).cpu().numpy().astype(np.int32)
+        mode = rng.integers(0, 4, size=n)                    # 0: keep legal; 1: other type; 2: random sub-heads; 3: both, with out-of-range values
+        for i in np.flatnonzero(mode == 1):
+            a[i, 0] = rng.integers(0, 13)
+        for i in np.flatnonzero(mode == 2):
+            a[i, 1:] = rng.integers(0, hi[1:])
+        for i in np.flatnonzero(mode == 3):
+            a[i, 0] = rng.integers(0, 13)
+            a[i, 1:] = rng.integers(-1, hi[1:] + 2)
+        want_ok = np.zeros(n, dtype=bool)
+        before = ob.export()
+        orew = np.zeros((n, 4), dtype=np.float32); odone = np.zeros(n, dtype=bool)
+        for i in range(n):
+            e, ai = ob.env_ptr(i), np.ascontiguousarray(a[i])
+            want_ok[i] = bool(ob.L.orc_action_is_legal(e, ai.ctypes.data_as(i32p)))
+            if want_ok[i]:
+                d = C.c_int(0)
+                ob.L.orc_step(e, ai.ctypes.data_as(i32p), orew[i].ctypes.data_as(f32p), C.byref(d))
+                odone[i] = bool(d.value)
+                if d.value:
+                    ob.L.orc_game_reset(e)
+        legal_after_corruption += int(want_ok[mode > 0].sum())
+        bad0 = env.invalid_action_count()
+        rew, done = env.step(torch.from_numpy(a))
+        rew, done = rew.cpu().numpy(), done.cpu().numpy().astype(bool)
+        n_rej = env.invalid_action_count() - bad0
+        got = env.export_state().cpu().numpy()
+        want = ob.export()
+        changed = (got != before).any(axis=1)
+        assert not changed[~want_ok].any(), f"round {rnd}: a rejected action changed game {np.flatnonzero(changed & ~want_ok)[0]}"
+        _assert_blobs_equal(got, want, f"round {rnd}: state after mixed legal / illegal actions")
+        assert n_rej == int((~want_ok).sum()), (rnd, n_rej, int((~want_ok).sum()))
+        assert np.array_equal(rew, orew) and np.array_equal(done, odone), rnd
+        assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks()), rnd
+        rejected_total += n_rej; accepted_total += int(want_ok.sum())
+    assert rejected_total > 20000 and accepted_total > 20000 and legal_after_corruption > 500, (rejected_total, accepted_total, legal_after_corruption)

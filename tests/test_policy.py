@@ -237,3 +237,14 @@ def test_compact_head_evaluation_equals_the_dense_one(oracle):
     assert set(res[True][2]) == set(res[False][2])
     for k, gd in res[False][2].items():
         assert torch.allclose(res[True][2][k], gd, atol=2e-5, rtol=1e-4), (k, float((res[True][2][k] - gd).abs().max()))
+
+
+@pytest.mark.parametrize("which", ["ff", "lstm"])
+def test_policy_fixture_from_the_reference_net(which):
+    """tests/golden/policy_small.npz (tools/gen_golden.py gen_policy_small: the reference's own net on real observations):
+    identical arg-max actions; value / joint log-prob / entropy / LSTM state within 1e-5; every parameter's gradient (norm and
+    a hashed projection) within 1e-4 of its size.  The same fixture is checked with the HIP kernels on under -m gpu."""
+    import golden_util as gu
+    import policy_fixture as pf
+    dev = pf.check_policy_fixture(gu.load("policy_small.npz"), which, "cpu", tol=1e-5, grad_tol=1e-4)
+    assert dev["act_argmax_agreement"] == 1.0

@@ -467,6 +467,137 @@ def gen_eval_small(n_games=3, seed=41):
     return [out[f"g{g}_result"].tolist() for g in range(n_games)]
 
 
+def _ref_policy_inputs(x):
+    """flat fixture inputs -> the reference net's (obs dict, 12-list masks) (RL/models/policy.py:168-191 layouts)"""
+    import torch
+    B = x["obs_f"].shape[0]
+    o = spec.OBS_FLOAT_OFFSETS
+    obs = {k: x["obs_f"][:, o[k]:o[k] + int(np.prod(shp))].reshape((B,) + shp).clone() for k, shp in spec.OBS_FLOAT_KEYS.items()}
+    for i, k in enumerate(spec.OBS_LIST_KEYS):
+        obs[k] = x["lists"][:, i].long()
+    masks = []
+    for hi, (off, sz, shp) in enumerate(zip(spec.MASK_OFFSETS, spec.MASK_SIZES, spec.MASK_SHAPES)):
+        mk = x["masks"][:, off:off + sz].reshape((B,) + shp).clone()
+        masks.append(mk.transpose(0, 1).contiguous() if hi in (1, 6, 9) else mk)
+    return obs, masks
+
+
+def _flat_actions(a_r, B):
+    import torch
+    return torch.cat([torch.stack([t.view(-1) for t in h], 1) if isinstance(h, list) else h.view(B, -1) for h in a_r], 1)
+
+
+def gen_policy_small(n_games=40, lstm_T=5, lstm_B=8):
+    """VERDICT r2 item 2 / SURVEY a21: the reference's OWN net (`build_agent_model()`, RL/models/policy.py:71-111,
+    action_heads_module.py:25-312, distributions.py:25-40) with the deterministic weights of tests/policy_fixture.py on real
+    observations / masks -> what `act(deterministic)` and `evaluate_actions` return (value, arg-max actions, joint log-prob,
+    entropy, incl. the recurrent trade heads) and, for one backward of a weighted sum of them, the norm and a hashed projection
+    of every parameter's gradient.  Twice: the default feed-forward net and `include_lstm=True` (one step per row, and the
+    T x B truncated-BPTT form with zeros inside the terminal masks)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib, policy_util, policy_fixture as pf
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    import RL.models.build_agent_model as bam
+    out = {}
+
+    def store_inputs(prefix, x):
+        f = x["obs_f"].numpy()
+        assert np.array_equal(f.astype(np.float16).astype(np.float32), f)
+        out[prefix + "obs_f"] = f.astype(np.float16); out[prefix + "lists"] = x["lists"].numpy().astype(np.int8)
+        out[prefix + "lens"] = x["lens"].numpy().astype(np.int8)
+        out[prefix + "masks"] = np.packbits(x["masks"].numpy().astype(np.uint8), axis=1, bitorder="little")
+
+    def load_fixture_weights(ref, salt):
+        sd = ref.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in sd.items() if v.numel() > 0 and not k.startswith("value_normaliser.")}
+        new = pf.fixture_state_dict(shapes, salt)
+        full = dict(sd); full.update(new)
+        ref.load_state_dict(full, strict=True)
+        names = sorted(shapes)
+        return names, np.array([pf.tensor_crc(new[k]) for k in names], dtype=np.uint32)
+
+    def grads_of(ref, names, loss):
+        ref.zero_grad()
+        loss.backward()
+        prm = dict(ref.named_parameters())
+        gn = np.array([float(prm[k].grad.double().norm()) if prm[k].grad is not None else 0.0 for k in names])
+        gp = np.array([pf.projection(k, prm[k].grad) if prm[k].grad is not None else 0.0 for k in names])
+        return gn, gp
+
+    # ---------------- feed-forward net (the reference's default)
+    torch.manual_seed(0)
+    ref = bam.build_agent_model()
+    names, crcs = load_fixture_weights(ref, "ff:")
+    ref.eval()
+    x = policy_util.oracle_batch_inputs(oracle_lib, n=n_games, seed=8, steps=(0, 7, 60, 300, 700, 1100, 1500, 1900))
+    B = x["obs_f"].shape[0]
+    store_inputs("ff_", x)
+    out["ff_param_names"] = np.array(names); out["ff_param_crc"] = crcs
+    obs, masks = _ref_policy_inputs(x)
+    cp = lambda d: {k: v.clone() for k, v in d.items()}
+    with torch.no_grad():
+        v, a, lp, _ = ref.act(cp(obs), None, None, [m.clone() for m in masks], deterministic=True)
+        out["ff_act_value"] = v.numpy(); out["ff_act_actions"] = _flat_actions(a, B).numpy().astype(np.int8); out["ff_act_logp"] = lp.numpy()
+        # sampled (non-greedy) actions to evaluate: drawn by this package's net on the CPU with the same weights
+        mine = CatanPolicy(); mine.load_reference_state_dict(ref.state_dict()); mine.eval()
+        # ... with the action TYPE drawn uniformly among each row's legal types, so that the rarely chosen heads (city, robber,
+        # steal, development cards, exchange) are evaluated too
+        rs = np.random.default_rng(77)
+        legal = x["masks"][:, :13].numpy() > 0
+        forced = torch.tensor([int(rs.choice(np.flatnonzero(r))) for r in legal])
+        _, a_s, _ = mine.act(x["obs_f"], x["lists"], x["lens"], x["masks"], generator=torch.Generator().manual_seed(11),
+                             condition_on_action_type=forced)
+    out["ff_eval_actions"] = a_s.numpy().astype(np.int8)
+    acts_ref = [a_s[:, off:off + ln].clone() for off, ln in spec.ACTION_HEAD_SLICES]
+    v, lp, ent, _ = ref.evaluate_actions(cp(obs), None, None, acts_ref, [m.clone() for m in masks])
+    out["ff_eval_value"] = v.detach().numpy(); out["ff_eval_logp"] = lp.detach().numpy(); out["ff_eval_entropy"] = float(ent)
+    wv, wl = torch.linspace(0.5, 1.5, B)[:, None], torch.linspace(1.5, 0.5, B)[:, None]
+    out["ff_grad_norm"], out["ff_grad_proj"] = grads_of(ref, names, (v * wv).sum() + (lp * wl).sum() + 3.0 * ent)
+    types = sorted(set(a_s[:, 0].tolist()))
+
+    # ---------------- include_lstm = True (build_agent_model.py:26 switched on)
+    old = bam.include_lstm
+    bam.include_lstm = True
+    try:
+        torch.manual_seed(3)
+        ref = bam.build_agent_model()
+    finally:
+        bam.include_lstm = old
+    names, crcs = load_fixture_weights(ref, "lstm:")
+    ref.eval()
+    T, Bs = lstm_T, lstm_B
+    x = {k: v[:T * Bs] for k, v in policy_util.oracle_batch_inputs(oracle_lib, n=T * Bs, seed=9, steps=(200,)).items()}
+    B = T * Bs
+    store_inputs("lstm_", x)
+    out["lstm_param_names"] = np.array(names); out["lstm_param_crc"] = crcs; out["lstm_T"] = T; out["lstm_B"] = Bs
+    obs, masks = _ref_policy_inputs(x)
+    g = torch.Generator().manual_seed(21)
+    h0 = torch.randn(B, 256, generator=g) * 0.5; c0 = torch.randn(B, 256, generator=g) * 0.5
+    nt = (torch.rand(B, 1, generator=g) > 0.3).float()
+    hs = torch.randn(Bs, 256, generator=g) * 0.5; cs = torch.randn(Bs, 256, generator=g) * 0.5
+    nts = torch.ones(T, Bs); nts[0, 1] = 0; nts[2, 3] = 0; nts[2, 5] = 0; nts[4, 0] = 0
+    nts = nts.reshape(T * Bs, 1)
+    for k, t in dict(h0=h0, c0=c0, nt=nt, hs=hs, cs=cs, nts=nts).items():
+        out["lstm_" + k] = t.numpy()
+    with torch.no_grad():
+        v, a, lp, (h1, c1) = ref.act(cp(obs), (h0.clone(), c0.clone()), nt.clone(), [m.clone() for m in masks], deterministic=True)
+        out["lstm_act_value"] = v.numpy(); out["lstm_act_actions"] = _flat_actions(a, B).numpy().astype(np.int8)
+        out["lstm_act_logp"] = lp.numpy(); out["lstm_act_h"] = h1.numpy(); out["lstm_act_c"] = c1.numpy()
+        mine = CatanPolicy(include_lstm=True); mine.load_reference_state_dict(ref.state_dict()); mine.eval()
+        _, a_s, _, _ = mine.act(x["obs_f"], x["lists"], x["lens"], x["masks"], generator=torch.Generator().manual_seed(12), hidden=(h0, c0), nonterminal=nt)
+    out["lstm_eval_actions"] = a_s.numpy().astype(np.int8)
+    acts_ref = [a_s[:, off:off + ln].clone() for off, ln in spec.ACTION_HEAD_SLICES]
+    v, lp, ent, (h2, c2) = ref.evaluate_actions(cp(obs), (hs.clone(), cs.clone()), nts.clone(), acts_ref, [m.clone() for m in masks])
+    out["lstm_eval_value"] = v.detach().numpy(); out["lstm_eval_logp"] = lp.detach().numpy(); out["lstm_eval_entropy"] = float(ent)
+    out["lstm_eval_h"] = h2.detach().numpy(); out["lstm_eval_c"] = c2.detach().numpy()
+    wv, wl = torch.linspace(0.5, 1.5, B)[:, None], torch.linspace(1.5, 0.5, B)[:, None]
+    out["lstm_grad_norm"], out["lstm_grad_proj"] = grads_of(ref, names, (v * wv).sum() + (lp * wl).sum() + 3.0 * ent)
+    np.savez_compressed(os.path.join(OUT, "policy_small.npz"), **out)
+    return {"ff_rows": int(out["ff_lens"].shape[0]), "ff_action_types_evaluated": types, "lstm_rows": B,
+            "bytes": os.path.getsize(os.path.join(OUT, "policy_small.npz"))}
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rollout":
         print("rollout_small (games complete, pre-advance, first-game lengths):", gen_rollout_small()); sys.exit(0)
@@ -481,6 +612,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "maxact":
         print("max_actions_per_turn = 2: games", gen_traj(7, 1, 5200, name="traj_maxact2_s7_e1.npz", max_actions=2))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "policy":
+        print("policy_small", gen_policy_small()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gae_ppo":
         gen_gae_ppo(); print("gae/ppo"); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
@@ -499,4 +632,5 @@ if __name__ == "__main__":
     print("max_actions_per_turn = 2: games", gen_traj(7, 1, 5200, name="traj_maxact2_s7_e1.npz", max_actions=2))
     print("rollout_small", gen_rollout_small())
     print("eval_small", gen_eval_small())
+    print("policy_small", gen_policy_small())
     os.system(f"ls -la {OUT}; du -sh {OUT}")
