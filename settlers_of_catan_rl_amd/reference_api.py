@@ -623,6 +623,41 @@ class BatchProcessor(object):
             yield (obs_dict_batch, None, actions_batch, action_masks_batch, vp[idx], ret[idx], mk[idx], lp[idx], adv[idx])
 
 
+    # ---- generator_lstm (process_batch.py:203-293)
+    def _permutation(self, n, device):
+        """`np.random.permutation(len(time_inds))` (process_batch.py:216) - drawn on the device from this storage's generator"""
+        if self._gen is None:
+            self._gen = torch.Generator(device=device)
+            self._gen.manual_seed(int(torch.initial_seed() % (2 ** 31)) + 17 * (1 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)))
+        return torch.randperm(n, generator=self._gen, device=device)
+
+    def generator_lstm(self, num_mini_batch, total_batch_size, truncated_seq_len):
+        """Truncated-BPTT minibatches with the reference's 9-tuples: every game's T stored decisions are cut into T / L
+        consecutive pieces (numbered game-major, :210-215), a minibatch is `total_batch_size // num_mini_batch // L` randomly
+        drawn pieces laid out TIME-major (`_flatten_helper`: row l * n + j is step l of piece j); `recurrent_hidden_batch` =
+        [h, c], each (n, lstm) = the state stored at each piece's first decision (:238-239,257-258); the masks of heads 1, 6, 9
+        come as (types, L * n, d) (:281-284)."""
+        from .train import lstm_minibatches
+        st = self.storage
+        T, N = st.T, st.N
+        dev = st.obs_f.device
+        if total_batch_size != T * N:
+            raise ValueError(f"total_batch_size {total_batch_size} != num_steps * num_parallel = {T * N}")
+        perm = self._permutation(N * (T // truncated_seq_len), dev)
+        hid = self.hidden_states
+        f_all = st.obs_f[:T].reshape(T * N, -1); lists_all = st.lists[:T].reshape(T * N, 5, -1)
+        acts_all = st.actions.reshape(T * N, -1); am_all = st.action_masks.reshape(T * N, -1)
+        vp = self._values[:T].reshape(T * N, 1); ret = self._returns.reshape(T * N, 1)
+        mk = st.masks[:T].reshape(T * N, 1); lp = st.action_log_probs.reshape(T * N, 1); adv = self._adv.reshape(T * N, 1)
+        for t, game in lstm_minibatches(T, N, truncated_seq_len, num_mini_batch, perm):
+            idx = (t * N + game[None, :]).reshape(-1)                                   # time-major rows of the flat (T*N) tensors
+            obs_dict_batch = obs_flat_to_dict(f_all[idx], lists_all[idx], self._list_pad)
+            recurrent_hidden_batch = [hid[0][t[0], game].to(dev), hid[1][t[0], game].to(dev)]
+            actions_batch = actions_flat_to_list(acts_all[idx])
+            action_masks_batch = masks_flat_to_list(st.unpack_action_masks(am_all[idx]))
+            yield (obs_dict_batch, recurrent_hidden_batch, actions_batch, action_masks_batch, vp[idx], ret[idx], mk[idx], lp[idx], adv[idx])
+
+
 def storage_from_reference_lists(rollouts, num_steps, device, lstm_dim=0):
     """The reference's nested rollouts (list over processes of 7-tuples, game_manager.py:137-140) -> RolloutStorage
     (process_batch.py:37-104 restated for the flat layout).  Interop path; the device collector never goes through it."""
@@ -665,8 +700,6 @@ class PPO(object):
 
     def update(self, rollout_storage):
         ac = self.actor_critic
-        if getattr(ac, "include_lstm", False):
-            raise NotImplementedError("truncated-BPTT minibatches: use train.PPOTrainer (generator_lstm lives there)")
         sums = None
         t_adv = t_opt = 0.0
         n_steps = 0
@@ -675,7 +708,13 @@ class PPO(object):
             with torch.no_grad():
                 rollout_storage.compute_advantages_alt(ac, 10)                               # ppo.py:31-32
             t1 = time.perf_counter()
-            for sample in rollout_storage.generator_standard(self.num_mini_batch):
+            if getattr(ac, "include_lstm", False):                                           # ppo.py:34-38
+                data_generator = rollout_storage.generator_lstm(num_mini_batch=self.num_mini_batch,
+                                                                total_batch_size=rollout_storage.num_parallel * rollout_storage.num_steps,
+                                                                truncated_seq_len=self.args.truncated_seq_len)
+            else:
+                data_generator = rollout_storage.generator_standard(self.num_mini_batch)
+            for sample in data_generator:
                 obs_dict_batch, recurrent_batch, actions_batch, action_masks_batch, value_preds_batch, returns_batch, \
                     masks_batch, old_action_log_probs_batch, adv_target = sample
                 values, action_log_probs, entropy, _ = ac.evaluate_actions(obs_dict_batch, recurrent_batch, masks_batch,

@@ -103,9 +103,20 @@ def check_policy_fixture(g, which, device, autocast_dtype=None, tol=1e-5, grad_t
     want_a = t("act_actions").long()
     same = (a == want_a).all(1)
     dev["act_argmax_agreement"] = float(same.float().mean())
+    # the columns that MATTER for the chosen type (the env ignores the others: _translate_action, env/wrapper.py:114-166)
+    typ, card = want_a[:, 0], want_a[:, 4]
+    rel_cols = torch.zeros_like(want_a, dtype=torch.bool)
+    rel_cols[:, 0] = True
+    for ty, cols in {0: [1], 1: [2], 2: [1], 4: [4], 5: [15, 16], 6: [6] + list(range(7, 15)), 7: [5], 8: [3], 11: [6], 12: [17]}.items():
+        for cc in cols:
+            rel_cols[:, cc] |= typ == ty
+    rel_cols[:, 15] |= (typ == 4) & ((card == 2) | (card == 4))
+    rel_cols[:, 16] |= (typ == 4) & (card == 2)
+    dev["act_type_agreement"] = float((a[:, 0] == typ).float().mean())
+    dev["act_relevant_agreement"] = float((((a == want_a) | ~rel_cols).all(1)).float().mean())
     if argmax_equal:
         assert bool(same.all()), f"{int((~same).sum())} of {B} rows choose other arg-max actions than the reference net"
-    assert dev["act_argmax_agreement"] >= min_argmax_agreement, dev
+    assert dev["act_relevant_agreement"] >= min_argmax_agreement, dev
     dev["act_value"] = rel(v[same], t("act_value")[same]); dev["act_logp"] = rel(lp[same], t("act_logp")[same])
     acts = t("eval_actions").long()
     net.zero_grad()

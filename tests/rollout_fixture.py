@@ -109,7 +109,42 @@ def check_rollout_fixture(make_env):
         assert [gu.crc(b) for b in blobs] == [int(c) for c in g[f"r{r}_state_crc"]], r
         ends += int((g[f"r{r}_masks"] == 0).sum())
     assert ends >= 3                                       # the fixture covers game ends and the carry-over behind them
+    check_generator_lstm(g, bp, T, n)
     return mgr, bp, ro
+
+
+def check_generator_lstm(g, bp, T, n):
+    """`BatchProcessor.generator_lstm` (process_batch.py:203-293) on the last rollout: the reference's generator ran on the same
+    tensors with tagged values / returns / advantages / LSTM states and the stored permutation; every tensor of every
+    minibatch tuple must be the reference's (shapes included: time-major rows, (n, lstm) states, (types, rows, d) masks)."""
+    st = bp.storage
+    dev = st.obs_f.device
+    L, nmb = int(g["lstm_gen_L"]), int(g["lstm_gen_nmb"])
+    tag = (torch.arange(T + 1)[:, None] * 100.0 + torch.arange(n)[None, :]).float().to(dev)
+    lanes = (torch.arange(256).float() / 1024.0).to(dev)
+    bp._values = tag + 0.5; bp._returns = tag[:T] + 0.25; bp._adv = tag[:T] - 0.75
+    st.hidden = torch.stack((tag[:, :, None] + lanes, -tag[:, :, None] - lanes))
+    bp._cache.pop("hidden", None)
+    bp._permutation = lambda count, device: torch.from_numpy(g["lstm_gen_perm"].astype(np.int64)).to(device)
+    names9 = ["obs", "hidden", "actions", "action_masks", "value_preds", "returns", "masks", "old_log_probs", "adv"]
+    batches = list(bp.generator_lstm(nmb, T * n, L))
+    assert len(batches) == nmb
+    for b, tup in enumerate(batches):
+        assert len(tup) == 9
+        for name, item in zip(names9, tup):
+            if isinstance(item, dict):
+                pairs = [(f"lstm_gen_b{b}_{name}_{k}", v) for k, v in item.items()]
+            elif isinstance(item, (list, tuple)):
+                pairs = [(f"lstm_gen_b{b}_{name}_{i}", v) for i, v in enumerate(item)]
+            else:
+                pairs = [(f"lstm_gen_b{b}_{name}", item)]
+            for key, v in pairs:
+                want = g[key]
+                got = v.float().cpu().numpy()
+                assert got.shape == want.shape, (key, got.shape, want.shape)
+                assert np.array_equal(got, want), key
+    st.hidden = None
+    bp._cache.pop("hidden", None)
 
 
 def check_eval_fixture(make_env):

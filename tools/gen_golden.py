@@ -422,6 +422,31 @@ def gen_rollout_small(n_envs=4, T=12, n_rollouts=6, seed=31):
         out[f"r{r}_games_complete"] = bp.games_complete
         out[f"r{r}_state_crc"] = np.array([crc(rh.state_blob(env, streams[i].draws)) for i, env in enumerate(mgr.envs)], dtype=np.uint32)
     assert bp.games_complete >= 3, bp.games_complete
+    # the reference's OWN truncated-BPTT generator (process_batch.py:203-293) on the LAST rollout's tensors, with tagged values /
+    # returns / advantages / LSTM states standing in for what compute_advantages_alt and an LSTM net would have left there:
+    # the permutation it drew (np.random.permutation, :216) and every tensor of every minibatch tuple, verbatim
+    import torch
+    L, nmb = 4, 2
+    tag = (torch.arange(T + 1)[:, None] * 100.0 + torch.arange(n_envs)[None, :]).float()
+    lanes = torch.arange(mgr.policies[0].lstm_size).float() / 1024.0
+    bp.values = tag[:, :, None] + 0.5; bp.returns = tag[:T, :, None] + 0.25; bp.advantages = tag[:T, :, None] - 0.75
+    bp.hidden_states = (tag[:, :, None] + lanes, -tag[:, :, None] - lanes)
+    np.random.seed(5)
+    out["lstm_gen_perm"] = np.random.permutation(n_envs * (T // L))
+    np.random.seed(5)
+    batches = list(bp.generator_lstm(nmb, T * n_envs, L))
+    out["lstm_gen_L"], out["lstm_gen_nmb"] = L, nmb
+    names9 = ["obs", "hidden", "actions", "action_masks", "value_preds", "returns", "masks", "old_log_probs", "adv"]
+    for b, tup in enumerate(batches):
+        for name, item in zip(names9, tup):
+            if isinstance(item, dict):
+                for k, v in item.items():
+                    out[f"lstm_gen_b{b}_{name}_{k}"] = v.numpy().astype(np.float32)
+            elif isinstance(item, (list, tuple)):
+                for i, v in enumerate(item):
+                    out[f"lstm_gen_b{b}_{name}_{i}"] = v.numpy().astype(np.float32)
+            else:
+                out[f"lstm_gen_b{b}_{name}"] = item.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "rollout_small.npz"), **out)
     return bp.games_complete, pre, lengths
 
