@@ -123,23 +123,24 @@ DEVI void stage_in(u32* tile, const u32* __restrict__ R, int e, int lane) {
 // chunks [FIRST, FIRST + NCH) of the 28 16-byte chunks of the hot record, GP = 64 / NCH games per pass: k_step writes back
 // only what its wave's action type can have changed (the type is wave-uniform: sorted, padded bins) - the bitboards
 // (chunks 0..6) change with settle / road / city only, the estimates (7..15) with the resource-moving types.
-template <int NCH = 28, int FIRST = 0>
+template <int NCH = 28, int FIRST = 0, int G = 64>
 DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
-    constexpr int GP = 64 / NCH, NP = (64 + GP - 1) / GP;
+    constexpr int TSG = G + 1;
+    constexpr int GP = 64 / NCH, NP = (G + GP - 1) / GP;
     const int gi = lane / NCH, q = FIRST + lane - NCH * gi;
     const bool act = lane < GP * NCH;
     uint4 v[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         const int g = p * GP + gi;
-        const u32* t = tile + (4 * (act ? q : FIRST)) * TS + (g & 63);
-        v[p].x = t[0]; v[p].y = t[TS]; v[p].z = t[2 * TS]; v[p].w = t[3 * TS];
+        const u32* t = tile + (4 * (act ? q : FIRST)) * TSG + (g < G ? g : 0);
+        v[p].x = t[0]; v[p].y = t[TSG]; v[p].z = t[2 * TSG]; v[p].w = t[3 * TSG];
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         const int g = p * GP + gi;
         const int eg = __shfl(e, g & 63);
-        if (act && g < 64 && eg >= 0) reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v[p];
+        if (act && g < G && eg >= 0) reinterpret_cast<uint4*>(R + (long)eg * REC)[q] = v[p];
     }
 }
 
@@ -150,74 +151,82 @@ DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
 // owning lane's registers before the state is written into it; all global loads are issued up front.
 // EST = false: the nine estimate chunks (7..15) are left out - the wave's action type neither reads nor writes them
 // (propose, end_turn, robber, knight / victory point / road building cards: 40 % of the waves) - 19 chunks, 3 games per pass.
-template <bool EST>
+template <bool EST, int G = 64>
 DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, const u32* __restrict__ mpk, int e, int lane,
                        int (&a)[ACTION_WORDS], u32 (&m)[MASK_WORDS]) {
-    constexpr int NCH = EST ? 28 : 19, GP = 64 / NCH, NP = (64 + GP - 1) / GP;
+    constexpr int TSG = G + 1;
+    constexpr int NCH = EST ? 28 : 19, GP = 64 / NCH, NP = (G + GP - 1) / GP;
+    constexpr int NPA = (G + 6) / 7, NPM = (G + 20) / 21;
     const int gi = lane / NCH, q0 = lane - NCH * gi, q = (EST || q0 < 7) ? q0 : q0 + 9;
     const bool act = lane < GP * NCH;
     const int ag = lane / 9, aq = lane - 9 * ag, mg = lane / 3, mq = lane - 3 * mg;
-    uint4 v[NP], mv[4];
-    uint2 av[10];
+    uint4 v[NP], mv[NPM];
+    uint2 av[NPA];
 #pragma unroll
-    for (int p = 0; p < 10; p++) {
+    for (int p = 0; p < NPA; p++) {
         const int g = p * 7 + ag, eg = __shfl(e, g & 63);
         av[p] = make_uint2(0, 0);
-        if (lane < 63 && g < 64 && eg >= 0) av[p] = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
+        if (lane < 63 && g < G && eg >= 0) av[p] = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
     }
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int p = 0; p < NPM; p++) {
         const int g = p * 21 + mg, eg = __shfl(e, g & 63);
         mv[p] = make_uint4(0, 0, 0, 0);
-        if (lane < 63 && g < 64 && eg >= 0) mv[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq);
+        if (lane < 63 && g < G && eg >= 0) mv[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq);
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         const int g = p * GP + gi, eg = __shfl(e, g & 63);
         v[p] = make_uint4(0, 0, 0, 0);
-        if (act && g < 64 && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
+        if (act && g < G && eg >= 0) v[p] = reinterpret_cast<const uint4*>(R + (long)eg * REC)[q];
     }
 #pragma unroll
-    for (int p = 0; p < 10; p++) {
+    for (int p = 0; p < NPA; p++) {
         const int g = p * 7 + ag;
-        if (lane < 63 && g < 64) { tile[(2 * aq) * TS + g] = av[p].x; tile[(2 * aq + 1) * TS + g] = av[p].y; }
+        if (lane < 63 && g < G) { tile[(2 * aq) * TSG + g] = av[p].x; tile[(2 * aq + 1) * TSG + g] = av[p].y; }
     }
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int p = 0; p < NPM; p++) {
         const int g = p * 21 + mg;
-        if (lane < 63 && g < 64) {
-            u32* t = tile + (ACTION_WORDS + 4 * mq) * TS + g;
-            t[0] = mv[p].x; t[TS] = mv[p].y; t[2 * TS] = mv[p].z; t[3 * TS] = mv[p].w;
+        if (lane < 63 && g < G) {
+            u32* t = tile + (ACTION_WORDS + 4 * mq) * TSG + g;
+            t[0] = mv[p].x; t[TSG] = mv[p].y; t[2 * TSG] = mv[p].z; t[3 * TSG] = mv[p].w;
         }
     }
     __builtin_amdgcn_wave_barrier();
+    const int sl = lane < G ? lane : G - 1;               // (lanes >= G carry no game: they read slot G-1 and are never used)
 #pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = (int)tile[i * TS + lane];
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = (int)tile[i * TSG + sl];
 #pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) m[i] = tile[(ACTION_WORDS + i) * TS + lane];
+    for (int i = 0; i < MASK_WORDS; i++) m[i] = tile[(ACTION_WORDS + i) * TSG + sl];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         const int g = p * GP + gi;
-        if (act && g < 64) {
-            u32* t = tile + (4 * q) * TS + g;
-            t[0] = v[p].x; t[TS] = v[p].y; t[2 * TS] = v[p].z; t[3 * TS] = v[p].w;
+        if (act && g < G) {
+            u32* t = tile + (4 * q) * TSG + g;
+            t[0] = v[p].x; t[TSG] = v[p].y; t[2 * TSG] = v[p].z; t[3 * TSG] = v[p].w;
         }
     }
 }
 // the reverse for the new masks: rows of the games with e >= 0, through the (free again) tile
+template <int G = 64>
 DEVI void stage_out_masks(u32* tile, u32* __restrict__ mpk, int e, int lane, const u32 (&m)[MASK_WORDS]) {
+    constexpr int TSG = G + 1;
+    constexpr int NPM = (G + 20) / 21;
     const int mg = lane / 3, mq = lane - 3 * mg;
+    if (lane < G) {
 #pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) tile[i * TS + lane] = m[i];
-    tile[MASK_WORDS * TS + lane] = 0;
+        for (int i = 0; i < MASK_WORDS; i++) tile[i * TSG + lane] = m[i];
+        tile[MASK_WORDS * TSG + lane] = 0;
+    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int p = 0; p < NPM; p++) {
         const int g = p * 21 + mg, eg = __shfl(e, g & 63);
-        if (lane < 63 && g < 64 && eg >= 0) {
-            const u32* t = tile + (4 * mq) * TS + g;
-            uint4 val; val.x = t[0]; val.y = t[TS]; val.z = t[2 * TS]; val.w = t[3 * TS];
+        if (lane < 63 && g < G && eg >= 0) {
+            const u32* t = tile + (4 * mq) * TSG + g;
+            uint4 val; val.x = t[0]; val.y = t[TSG]; val.z = t[2 * TSG]; val.w = t[3 * TSG];
             *reinterpret_cast<uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq) = val;
         }
     }
@@ -1559,10 +1568,16 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // time is the dependent-latency chain of a single wave: LDS (~64 cycles) instead of HBM/L2 (~200-900 cycles) per hop.
 // actions: int32 [n][18]; reward: float [n][4] (index PlayerId-1); done: u8 [n]; err: [1] invalid-action
 // counter; mpk: packed masks [N][16], read for validation, rewritten with the masks of the new state.
+// G = games per wave (64, 32 or 16; lanes >= G carry no game and only help with the row-wise transfers): with G < 64 there
+// are 64 / G waves per SIMD at 65 536 games, each with a tile of ROWS_HOT x (G + 1) words, so that one wave's transfers
+// overlap the others' dependent-instruction chains (with one wave per SIMD the HBM is idle while the step computes).
+template <int G>
 __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
-    __shared__ u32 tile[ROWS_HOT * TS];
+    constexpr int TSG = G + 1;
+    typedef StLT<TSG> StG;
+    __shared__ u32 tile[ROWS_HOT * TSG];
     __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * (pend.bsel ^ 1) + lane] = 0;     // the next pass's bin counts
@@ -1571,18 +1586,18 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     // and offset from the 18 counts.
     int bin = -1, cnt = 0, first = 0;
     {
-        const int pos = (int)blockIdx.x * 64;
+        const int pos = (int)blockIdx.x * G;
         int start = 0;
 #pragma unroll
         for (int k = 0; k < NBINS; k++) {
-            const int ck = (int)bins[k], len = (ck + 63) & ~63;
+            const int ck = (int)bins[k], len = (ck + G - 1) & ~(G - 1);
             if (bin < 0 && pos < start + len) { bin = k; cnt = ck; first = pos - start; }
             start += len;
         }
     }
     if (bin < 0) return;                                   // behind the last bin
     const int rnk = first + lane;
-    const long e = rnk < cnt ? (long)pend.lists[(long)bin * c.N + rnk] : 0x7fffffffL;
+    const long e = (lane < G && rnk < cnt) ? (long)pend.lists[(long)bin * c.N + rnk] : 0x7fffffffL;
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     const bool live = e < c.n;
     // the last bin = explicit no-op (negative type: frozen game) or a busy game (the sampler gives those the no-op): none
@@ -1605,10 +1620,10 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const bool t_est = t_board || type == T_BUYDEV || bin == 12 + C_YOP || bin == 12 + C_MONO || type == T_EXCHANGE || type == T_RESPOND ||
                        type == T_ROLL || type == T_STEAL || type == T_DISCARD;
     const bool w_board = __ballot(type >= 0 && t_board) != 0, w_est = __ballot(type >= 0 && t_est) != 0;
-    if (w_est) stage_in_all<true>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
-    else stage_in_all<false>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
+    if (w_est) stage_in_all<true, G>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
+    else stage_in_all<false, G>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
     __builtin_amdgcn_wave_barrier();
-    StL s(tile + lane, c.R, c.N, e);
+    StG s(tile + (lane < G ? lane : G - 1), c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
     bool rejected = false;
     if (cfg.validate && type >= 0 && !action_legal(s, m_in, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
@@ -1966,11 +1981,11 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
                    pend, 0, false, m_new, &have_masks);
     // ---- write the tile back, then the new mask rows through the tile
     __builtin_amdgcn_wave_barrier();
-    if (w_board) stage_out<28, 0>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
-    else if (w_est) stage_out<21, 7>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
-    else stage_out<12, 16>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    if (w_board) stage_out<28, 0, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    else if (w_est) stage_out<21, 7, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
+    else stage_out<12, 16, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     __builtin_amdgcn_wave_barrier();
-    stage_out_masks(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
+    stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
 }
 

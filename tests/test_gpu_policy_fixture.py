@@ -44,14 +44,15 @@ def test_policy_fixture_fp32_with_hip_kernels(hip_lib, monkeypatch, which):
 
 @pytest.mark.parametrize("which", ["ff", "lstm"])
 def test_policy_fixture_bf16_autocast(hip_lib, monkeypatch, which):
-    """bf16 autocast (config 3's dtype; fp32 master weights): bound STATED - value within 0.05 (normalised units, i.e. 7.5
-    reward points of the 150-point scale), joint log-prob within 0.05 relative to max(1, |logp|), entropy within 0.05, at least
-    93 % of the rows with the reference's arg-max action in every column that matters for the chosen type (the others are
-    near-ties flipped by bf16 rounding; the fixture's weights make the heads decisive, not one-hot), every parameter's gradient
-    within 6 % of its own size."""
+    """bf16 autocast (config 3's dtype; fp32 master weights): bound STATED - value within 0.03 (normalised units, i.e. 4.5
+    reward points of the 150-point scale), joint log-prob within 0.03 relative to max(1, |logp|), entropy within 0.03, LSTM
+    state within 0.03; the reference's arg-max action TYPE in every row and its arg-max in every column that matters for that
+    type in at least 95 % of the rows (the others are near-ties flipped by bf16 rounding); every parameter's gradient within
+    8 % of its own size.  (Measured on MI355X, round 3: 0.018 / 0.010 / 0.001 / 0.015; 98.75 % and 97.5 %; 3.2 % and 5.8 %.)"""
     calls = _count_kernel_calls(monkeypatch)
     g = gu.load("policy_small.npz")
-    dev = pf.check_policy_fixture(g, which, "cuda", autocast_dtype=torch.bfloat16, tol=0.05, grad_tol=0.06, argmax_equal=False,
-                                  min_argmax_agreement=0.93)
+    dev = pf.check_policy_fixture(g, which, "cuda", autocast_dtype=torch.bfloat16, tol=0.03, grad_tol=0.08, argmax_equal=False,
+                                  min_argmax_agreement=0.95)
+    assert dev["act_type_agreement"] == 1.0, dev
     print(which, "bf16 deviations from the reference net:", dev, "kernel calls:", calls)
     assert calls.get("small_layer_norm", 0) >= 10 and calls.get("masked_categorical", 0) >= 18, calls
