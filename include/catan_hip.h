@@ -135,6 +135,10 @@ int catan_random_rollout_deferred(catan_env_t* env, int64_t iters, int32_t windo
 /* per-game decision counters of the deferred rollout: read into / set from a DEVICE uint32[n] (in == NULL: zero them) */
 int catan_policy_counters(catan_env_t* env, uint32_t* out, catan_stream_t stream);
 int catan_set_policy_counters(catan_env_t* env, const uint32_t* in, catan_stream_t stream);
+/* Scheduling knob of k_step (results do not depend on it): games per wave, 64 / 32 / 16.  With fewer games per wave there are
+ * 2 / 4 waves per SIMD at 65 536 games, so that one wave's record transfers overlap the other waves' dependent-instruction
+ * chains.  Default DEFAULT_STEP_WAVE_GAMES (csrc/catan_abi.hip), or the environment variable CATAN_STEP_WAVE_GAMES at creation. */
+int catan_set_step_wave_games(catan_env_t* env, int32_t games);
 /* tier-1 longest-road search budget (iterations) before a request is handed to tier 2: lock-step / deferred mode */
 int catan_set_lr_budgets(catan_env_t* env, int32_t lockstep, int32_t deferred);
 /* cumulative slow-path counters since creation (synchronises the stream): out3 = { longest-road requests handled by tier 1

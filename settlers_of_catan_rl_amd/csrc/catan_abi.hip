@@ -41,6 +41,7 @@ struct catan_env {
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
     int lr_round[2];      // tier-2 iterations per bulk-synchronous round: [0] lock-step, [1] deferred
+    int step_games;       // games per k_step wave: 64, 32 or 16 (catan_set_step_wave_games; CATAN_STEP_WAVE_GAMES at creation)
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
     hipEvent_t ev_fork, ev_join;
     hipStream_t fstream[2];  // deferred rollouts: tier-1 longest road + completion of iteration t run on fstream[t & 1] during t+1
@@ -53,6 +54,7 @@ struct catan_env {
     u8* s_done;
 };
 
+constexpr int DEFAULT_STEP_WAVE_GAMES = 64;   // games per k_step wave (catan_set_step_wave_games)
 constexpr int LR_BUDGET_DEFERRED = 12;   // (swept together with the window length: tools/deferred_sweep.py)
 // cross-stream ordering inside one device: no timing, no system-scope release (which would flush L2 at every record)
 constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
@@ -298,7 +300,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.spec, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 16 + SORT_PAD_WAVES) * 8 * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
@@ -310,6 +312,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
+    e->step_games = DEFAULT_STEP_WAVE_GAMES;
+    if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
@@ -408,7 +412,11 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
         hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists, e->pend.ctr + 4, 12);
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
     }
-    hipLaunchKernelGGL(k_step, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+    switch (e->step_games) {
+    case 16: hipLaunchKernelGGL(k_step<16>, dim3(blocks(e->N, 16) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
+    case 32: hipLaunchKernelGGL(k_step<32>, dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
+    default: hipLaunchKernelGGL(k_step<64>, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
+    }
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -668,6 +676,12 @@ int catan_set_policy_counters(catan_env_t* e, const uint32_t* in, catan_stream_t
     if (!e) return fail(CATAN_EINVAL, "catan_set_policy_counters: null handle");
     if (in) HIPCHK(hipMemcpyAsync(e->pctr, in, (size_t)e->n * sizeof(u32), hipMemcpyDeviceToDevice, S(stream)));
     else HIPCHK(hipMemsetAsync(e->pctr, 0, (size_t)e->N * sizeof(u32), S(stream)));
+    return CATAN_OK;
+}
+
+int catan_set_step_wave_games(catan_env_t* e, int32_t games) {
+    if (!e || (games != 64 && games != 32 && games != 16)) return fail(CATAN_EINVAL, "catan_set_step_wave_games: 64, 32 or 16");
+    e->step_games = games;
     return CATAN_OK;
 }
 
@@ -1002,14 +1016,14 @@ int catan_profile_enable(catan_env_t* e, int on) {
     if (!e) return fail(CATAN_EINVAL, "catan_profile_enable: null handle");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(e->prof, 0, PROF_WORDS * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(e->prof_wave, 0, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32)));
+    HIPCHK(hipMemset(e->prof_wave, 0, (size_t)(e->N / 16 + SORT_PAD_WAVES) * 8 * sizeof(u32)));
     e->prof_on = on;
     return CATAN_OK;
 }
 int catan_profile_read_waves(catan_env_t* e, uint32_t* out) {
     if (!e || !out) return fail(CATAN_EINVAL, "catan_profile_read_waves: bad arguments");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 64 + SORT_PAD_WAVES) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 16 + SORT_PAD_WAVES) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 int catan_profile_read(catan_env_t* e, uint64_t* out16) {

@@ -52,6 +52,10 @@ class VecCatanEnv(object):
         self.done = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
         self.reward64 = None
 
+    def set_step_wave_games(self, games):
+        """scheduling knob of k_step: 64 / 32 / 16 games per wave (results do not depend on it)"""
+        _lib.check(self.L.catan_set_step_wave_games(self.h, int(games)))
+
     def enable_reward64(self):
         """Every later step also leaves its rewards UNROUNDED (the reference's Python floats, env/wrapper.py:85-112) in
         `self.reward64` (float64 [n][4]); rollout collection sums those over a turn before rounding, as

@@ -243,3 +243,13 @@ def test_forward_search_lstm_states_and_time_budget():
     search.sims_run = 0
     chosen, info = search.act(root, deterministic=True, hidden=hidden, max_thinking_time=0.05)
     assert search.sims_run >= K * int((info["n_proposed"] > 0).sum()) and (info["finished_each"].sum(1) >= K).all()
+
+
+def test_forward_search_fixture_from_the_reference(oracle):
+    """tests/golden/forward_search.npz: the reference's proposals, UCB selections and simulator values as data (the same
+    fixture runs on the HIP env + device net under -m gpu)."""
+    import forward_search_fixture as ff
+    net = ff.fixture_net("cpu")
+    assert ff.check_proposals(net, "cpu") == 10
+    ff.check_ucb()
+    ff.check_simulations(net, lambda n, seed: OracleVecEnv(n, seed, dense_reward=True, auto_reset=False), "cpu")

@@ -79,3 +79,16 @@ def test_graphed_act_recaptures_when_parameters_move(hip_lib):
     # (a replay and an eager pass may pick different library GEMM kernels: bf16-rounding differences, a few arg-max flips)
     assert float((v1.float() - ve.float()).abs().max()) < 0.1 and float((a1[:, 0] == ae[:, 0]).float().mean()) > 0.9
     assert float((v1.float() - v0.float()).abs().max()) > 0.2                      # and it is not the old net that answered
+
+
+def test_forward_search_fixture_on_device(hip_lib):
+    """tests/golden/forward_search.npz - the reference's `default_sample_actions` proposal lists, UCB selections and
+    `run_simulation_forward` value estimates (tools/gen_golden.py gen_forward_search) - with the net on the device (fp32, HIP
+    kernels on) and the simulations on the HIP env: equal proposals, equal selections, values within 2e-3."""
+    import forward_search_fixture as ff
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    net = ff.fixture_net("cuda")
+    assert ff.check_proposals(net, "cuda") == 10
+    ff.check_ucb()
+    worst = ff.check_simulations(net, lambda n, seed: VecCatanEnv(n, seed=seed, dense_reward=True, auto_reset=False), "cuda")
+    print("forward-search fixture on the device: largest relative deviation of a simulation value", worst)

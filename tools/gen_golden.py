@@ -623,6 +623,116 @@ def gen_policy_small(n_games=40, lstm_T=5, lstm_B=8):
             "bytes": os.path.getsize(os.path.join(OUT, "policy_small.npz"))}
 
 
+def gen_forward_search(n_ucb_roots=3):
+    """the reference's forward-search HOST logic and simulator, as data.
+      prop_*   `default_sample_actions` (sample_actions_fn.py:55-329) root by root with the reference net (fixture weights,
+               arg-max heads, `random.seed` given): inputs and the proposal lists it returns;
+      ucb_*    `_select_action / _update_stats / MovingAvgCalculator` (policy.py:151-177, utils.py) driven with a recorded stream of
+               simulation results: every selection it makes, the final choice and the running std;
+      sim_*    `run_simulation_forward` + `gae` (worker.py:61-143) from four mid-game states with the same net (arg-max for every
+               seat, the game's Philox stream): start blob, searching player, initial action, depth -> value estimate."""
+    import copy
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import policy_fixture as pf
+    import RL.models.build_agent_model as bam
+    from RL.forward_search_policy.sample_actions_fn import default_sample_actions
+    from RL.forward_search_policy.policy import ForwardSearchPolicy
+    from RL.forward_search_policy.utils import MovingAvgCalculator
+    from RL.forward_search_policy.worker import run_simulation_forward
+    torch.manual_seed(0)
+    ref_net = bam.build_agent_model(device="cpu")
+    sd = ref_net.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if v.numel() > 0 and not k.startswith("value_normaliser.")}
+    full = dict(sd); full.update(pf.fixture_state_dict(shapes, "ff:"))
+    ref_net.load_state_dict(full, strict=True)
+    ref_net.eval()
+    orig = ref_net.act
+    ref_net.act = lambda *a, **kw: orig(*a, **{**kw, "deterministic": True})
+    out = {}
+    # ---- proposals
+    F, L, Ln, M, init_flags, seeds, wants = [], [], [], [], [], [], []
+    for (seed, warm) in [(3, 0), (3, 5), (3, 60), (3, 300), (6, 700), (6, 1100), (9, 1500), (9, 2100), (12, 2500), (12, 40)]:
+        rng = np.random.default_rng(seed + warm)
+        ref = rh.RefEnv(seed, 0)
+        obs = ref.reset()
+        for _ in range(warm):
+            obs, _, done = ref.step(rh.random_legal_action(ref.masks(), ref.env, rng))
+            if done:
+                obs = ref.reset()
+        random.seed(1234 + warm)
+        masks_t = ref_net.act_masks_to_torch(ref.env.get_action_masks())
+        initial = bool(ref.env.game.initial_placement_phase)
+        want, _ = default_sample_actions(ref_net.obs_to_torch(copy.deepcopy(obs)), None, masks_t, ref_net, 10, initial_settlement_phase=initial)
+        want = np.array([np.concatenate([np.asarray(h).reshape(-1) for h in a]) for a in want], dtype=np.int8)
+        f, lists, lens, _ = rh.obs_flat(obs)
+        F.append(f); L.append(lists); Ln.append(lens); M.append(rh.masks_flat(ref.masks())); init_flags.append(initial); seeds.append(1234 + warm)
+        wants.append(want)
+    out["prop_obs_f"] = np.stack(F).astype(np.float16); out["prop_lists"] = np.stack(L).astype(np.int8); out["prop_lens"] = np.stack(Ln).astype(np.int8)
+    assert np.array_equal(out["prop_obs_f"].astype(np.float32), np.stack(F))
+    out["prop_masks"] = np.packbits(np.stack(M).astype(np.uint8), axis=1, bitorder="little")
+    out["prop_initial"] = np.array(init_flags, dtype=np.uint8); out["prop_seed"] = np.array(seeds, dtype=np.int64)
+    out["prop_count"] = np.array([len(w) for w in wants], dtype=np.int32)
+    out["prop_actions"] = np.concatenate(wants).astype(np.int8)
+    # ---- UCB bookkeeping
+    rng = np.random.default_rng(1)
+    R, A, K = n_ucb_roots, 10, 4
+    refs = []
+    for r in range(R):
+        o = ForwardSearchPolicy.__new__(ForwardSearchPolicy)
+        o.value_moving_average = MovingAvgCalculator(window_size=500)
+        refs.append(o)
+    n_acts, sel, vals_all, best_all, std_all = [], [], [], [], []
+    for decision in range(3):
+        n_act = rng.integers(2, A + 1, size=R)
+        n_acts.append(n_act)
+        for r, o in enumerate(refs):
+            o.proposed_actions = list(range(n_act[r]))
+            o.num_simulations_finished = 0; o.num_simulations_in_progress = 0
+            o.num_simulations_finished_each_action = np.zeros(n_act[r]); o.num_simulations_started_each_action = np.zeros(n_act[r])
+            o.exploit_scores = np.zeros(n_act[r])
+        for rnd in range(40):
+            ids = np.zeros((R, K), dtype=np.int64)
+            for k in range(K):
+                for r, o in enumerate(refs):
+                    ar = o._select_action()
+                    ids[r, k] = ar
+                    o.num_simulations_in_progress += 1; o.num_simulations_started_each_action[ar] += 1
+            vals = rng.normal(120, 60, size=(R, K)) + 10 * ids
+            for k in range(K):
+                for r, o in enumerate(refs):
+                    o._update_stats(vals[r, k], ids[r, k])
+            sel.append(ids); vals_all.append(vals)
+        best_all.append([o._select_action(explore=False) for o in refs])
+        std_all.append([o.value_moving_average.get_std() for o in refs])
+    out["ucb_n_act"] = np.array(n_acts); out["ucb_sel"] = np.array(sel); out["ucb_vals"] = np.array(vals_all)
+    out["ucb_best"] = np.array(best_all); out["ucb_std"] = np.array(std_all, dtype=np.float64)
+    # ---- simulations
+    blobs, ctrls, inits, depths, values, sim_seeds = [], [], [], [], [], []
+    for (seed, warm, depth) in [(5, 40, 6), (5, 400, 8), (8, 900, 5), (11, 1500, 20)]:
+        rng = np.random.default_rng(seed)
+        ref = rh.RefEnv(seed, 0, dense_reward=True)
+        obs = ref.reset()
+        for _ in range(warm):
+            obs, _, done = ref.step(rh.random_legal_action(ref.masks(), ref.env, rng))
+            if done:
+                obs = ref.reset()
+        blobs.append(ref.state_blob())
+        ctrl = ref.deciding_player()
+        init = rh.random_legal_action(ref.masks(), ref.env, rng)
+        with rh.patched_rng(ref.stream):
+            want = run_simulation_forward(ref.env, ref_net, player_id=rh.PIDS[ctrl - 1], init_action=rh.action_to_heads(init), init_player_hs=None,
+                                          curr_hidden_states={p: None for p in rh.PIDS}, curr_obs=ref_net.obs_to_torch(copy.deepcopy(obs)),
+                                          max_depth=depth, gamma=0.999)
+        ctrls.append(ctrl); inits.append(np.asarray(init)); depths.append(depth); values.append(float(want)); sim_seeds.append(seed)
+    out["sim_blob"] = np.array(blobs, dtype=np.int32); out["sim_ctrl"] = np.array(ctrls, dtype=np.int32)
+    out["sim_init"] = np.array(inits, dtype=np.int8); out["sim_depth"] = np.array(depths, dtype=np.int32)
+    out["sim_value"] = np.array(values, dtype=np.float64); out["sim_seed"] = np.array(sim_seeds, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "forward_search.npz"), **out)
+    return {"proposal_counts": out["prop_count"].tolist(), "types": sorted(set(out["prop_actions"][:, 0].tolist())), "sim_values": values,
+            "bytes": os.path.getsize(os.path.join(OUT, "forward_search.npz"))}
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rollout":
         print("rollout_small (games complete, pre-advance, first-game lengths):", gen_rollout_small()); sys.exit(0)
@@ -637,6 +747,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "maxact":
         print("max_actions_per_turn = 2: games", gen_traj(7, 1, 5200, name="traj_maxact2_s7_e1.npz", max_actions=2))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "forward_search":
+        print("forward_search", gen_forward_search()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "policy":
         print("policy_small", gen_policy_small()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gae_ppo":
@@ -658,4 +770,5 @@ if __name__ == "__main__":
     print("rollout_small", gen_rollout_small())
     print("eval_small", gen_eval_small())
     print("policy_small", gen_policy_small())
+    print("forward_search", gen_forward_search())
     os.system(f"ls -la {OUT}; du -sh {OUT}")
