@@ -9,6 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libcatan_oracle.so")
+if os.environ.get("CATAN_ORACLE_ASAN"):      # tools/fuzz_oracle_asan.sh: the -fsanitize=address,undefined build (`make -C oracle asan`)
+    LIB_PATH = os.path.join(ORACLE_DIR, "libcatan_oracle_asan.so")
 
 STATE_WORDS, MASK_WORDS, OBS_FLOATS, OBS_LISTS, OBS_LIST_PAD, ACTION_WORDS = 736, 325, 1787, 5, 25, 18
 
@@ -18,7 +20,8 @@ _lib = None
 def build(force=False):
     src = [os.path.join(ORACLE_DIR, f) for f in ("catan_oracle.c", "catan_oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["asan"] if LIB_PATH.endswith("_asan.so") else []),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return LIB_PATH
 
 
