@@ -61,8 +61,13 @@ def _worker(rank, world, port, q):
     cdist.finalize()
 
 
-def test_two_rank_sharding_and_reductions():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_sharding_and_reductions(world):
+    """world_size 2 and 8 (one rank per GPU of an 8-GPU node, BASELINE config 4): shard invariance by global game id, the
+    3-double advantage statistics, the flat gradient average, max / sum over ranks"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -79,5 +84,5 @@ def test_two_rank_sharding_and_reductions():
     assert np.array_equal(out["blobs"], single), "sharded games differ from the single-process run"
     assert abs(out["mean"] - out["ref_mean"]) < 1e-9 and abs(out["std"] - out["ref_std"]) < 1e-9
     for i, g in enumerate(out["grads"]):
-        assert np.allclose(g, (1 + i + 2 + i) / 2.0)
-    assert out["tmax"] == 2.0 and out["tsum"] == 3.0
+        assert np.allclose(g, np.mean([r + 1 + i for r in range(world)]))
+    assert out["tmax"] == float(world) and out["tsum"] == world * (world + 1) / 2.0
