@@ -159,6 +159,14 @@ int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t ste
  * (current played, current hidden, next x3 played; ids = card+1, zero padded); out_lens: int32 [n][5] (1 when empty,
  * like the reference's [0]).  The deciding player of each game is catan_deciding_seat(). */
 int catan_obs(catan_env_t* env, float* out_f, int32_t* out_lists, int32_t* out_lens, catan_stream_t stream);
+/* The same observations in ONE pass for the rollout collector (RL/ppo/game_manager.py:69-140 keeps, per game, the list of the
+ * ACTIVE seat's observations while every seat's policy needs the current one): `dense_*` = the [n][1787] matrix (float32, or
+ * bfloat16 when bf16 != 0 - every value is a multiple of 1/8 below 32: exact) + int32 lists / lengths for the policy pass;
+ * `rows_*` = the rollout storage, obs_f [steps][n][1787] of the same element type and int8 [steps][n][5][25] / [steps][n][5]:
+ * game g with sel[g] != 0 appends its observation at step t_idx[g] (int64 [n], in range for the selected games).  Either
+ * group may be NULL.  Replaces catan_obs + a cast + catan_masked_row_store of round 2. */
+int catan_obs_rows(catan_env_t* env, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                   int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, catan_stream_t stream);
 
 /* Game.get_longest_path(player): game/game.py:843-862 for players[i] (PlayerId) in game i -> out[i].  Diagnostic/test
  * entry; inside catan_step the same search runs as part of update_longest_road. */

@@ -108,6 +108,7 @@ _SIGS = {
     "catan_invalid_action_count": (C.c_int64, [_vp, _vp]),
     "catan_random_rollout": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp]),
     "catan_obs": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "catan_obs_rows": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catan_longest_path": (C.c_int, [_vp, _vp, _vp, _vp]),
     "catan_gae_workspace_doubles": (C.c_int64, [C.c_int64]),
     "catan_gae": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),

@@ -749,7 +749,28 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
 
 int catan_obs(catan_env_t* e, float* out_f, int32_t* out_lists, int32_t* out_lens, catan_stream_t stream) {
     if (!e || !out_f || !out_lists || !out_lens) return fail(CATAN_EINVAL, "catan_obs: null argument");
-    hipLaunchKernelGGL(k_obs, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens);
+    static const bool v1 = getenv("CATAN_OBS_V1") != nullptr;          // (the round-1 kernel, kept for A/B timing)
+    if (v1) hipLaunchKernelGGL(k_obs, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens);
+    else hipLaunchKernelGGL((k_obs_rows<ObsF32, OBS_OG>), dim3(blocks(e->n, OBS_OG)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens,
+                            (float*)nullptr, (signed char*)nullptr, (signed char*)nullptr, (const long long*)nullptr, (const u8*)nullptr);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int catan_obs_rows(catan_env_t* e, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                   int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, catan_stream_t stream) {
+    if (!e || (!dense_f && !rows_f)) return fail(CATAN_EINVAL, "catan_obs_rows: no output");
+    if ((dense_lists == nullptr) != (dense_lens == nullptr) || (rows_lists == nullptr) != (rows_lens == nullptr))
+        return fail(CATAN_EINVAL, "catan_obs_rows: lists and lens come together");
+    if (rows_f && (!t_idx || !sel)) return fail(CATAN_EINVAL, "catan_obs_rows: row stores need t_idx and sel");
+    if ((rows_lists && !rows_f) || (dense_lists && !dense_f)) return fail(CATAN_EINVAL, "catan_obs_rows: lists without their observation rows");
+    static const int og = getenv("CATAN_OBS_OG") ? atoi(getenv("CATAN_OBS_OG")) : OBS_OG;      // (A/B: games per wave 16 / 8 / 4)
+    const dim3 grid(blocks(e->n, og == 16 ? 16 : og == 4 ? 4 : 8));
+#define CATAN_OBS_LAUNCH(OT, CT, G) hipLaunchKernelGGL((k_obs_rows<OT, G>), grid, dim3(64), 0, S(stream), e->ctx, (CT*)dense_f, dense_lists, dense_lens, \
+                                                       (CT*)rows_f, (signed char*)rows_lists, (signed char*)rows_lens, (const long long*)t_idx, sel)
+    if (bf16) { if (og == 16) CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 16); else if (og == 4) CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 4); else CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 8); }
+    else { if (og == 16) CATAN_OBS_LAUNCH(ObsF32, float, 16); else if (og == 4) CATAN_OBS_LAUNCH(ObsF32, float, 4); else CATAN_OBS_LAUNCH(ObsF32, float, 8); }
+#undef CATAN_OBS_LAUNCH
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

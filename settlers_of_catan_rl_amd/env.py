@@ -203,6 +203,10 @@ class VecCatanEnv(object):
         from . import obs as _obs
         return _obs.get_obs(self, out)
 
+    def get_obs_rows(self, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True):
+        from . import obs as _obs
+        return _obs.get_obs_rows(self, dtype, out, rows, t, sel, dense)
+
     def longest_path(self, players):
         """Game.get_longest_path for PlayerId players[i] of game i (diagnostic/test entry)."""
         p = torch.as_tensor(players, dtype=torch.int32, device=self.device).contiguous()

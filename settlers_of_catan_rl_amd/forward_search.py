@@ -169,9 +169,16 @@ class GraphedAct(object):
         ps = list(self.policy.parameters())
         return (len(ps), hash(tuple(p.data_ptr() for p in ps)), ps[0].dtype) if ps else ()   # EVERY parameter: one replaced in the middle is stale too
 
-    def __call__(self, f, lists, lens, masks, with_logp=False):
+    def static_inputs(self, B):
+        """The captured graph's own input buffers (f, lists, lens, masks) for bucket B, or None before the capture: a producer that
+        writes straight into them (the collector's k_obs_rows / mask expansion) saves the copy of every replay."""
+        st = self.graphs.get(B)
+        return None if st is None else (st["f"], st["lists"], st["lens"], st["masks"])
+
+    def __call__(self, f, lists, lens, masks, with_logp=False, clone=True):
         """-> (value [n,1], actions [n,18]) (+ log-prob [n,1] with `with_logp`) for n rows; eager when n exceeds the largest
-        bucket."""
+        bucket.  Inputs that ARE the graph's static buffers (static_inputs) are not copied; clone=False hands out the graph's
+        output buffers themselves (valid until the next replay)."""
         n = f.shape[0]
         B = next((b for b in self.buckets if n <= b), None)
         if B is None or self.failed or not f.is_cuda:
@@ -192,11 +199,12 @@ class GraphedAct(object):
         refresh = getattr(self.policy, "refresh_kernel_packs", None)
         if refresh is not None:
             refresh()                                           # host-side parameter packs a replay would not rebuild
-        st["f"][:n] = f; st["lists"][:n] = lists; st["lens"][:n] = lens; st["masks"][:n] = masks
+        for k, x in (("f", f), ("lists", lists), ("lens", lens), ("masks", masks)):
+            if x.data_ptr() != st[k].data_ptr():
+                st[k][:n] = x
         st["g"].replay()
-        if with_logp:
-            return st["v"][:n].clone(), st["a"][:n].clone(), st["lp"][:n].clone()
-        return st["v"][:n].clone(), st["a"][:n].clone()
+        out = (st["v"][:n], st["a"][:n], st["lp"][:n]) if with_logp else (st["v"][:n], st["a"][:n])
+        return tuple(o.clone() for o in out) if clone else out
 
 
 # ---------------------------------------------------------------------------------------------------- simulations

@@ -28,6 +28,36 @@ def get_obs(vec, out=None):
     return f, lists, lens
 
 
+def get_obs_rows(vec, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True):
+    """catan_obs_rows: the observations of all games in ONE pass, as the dense matrix for the policy (`out` = (f [n][1787] of
+    `dtype` float32 / bfloat16, int32 lists, int32 lens) or None to allocate; dense=False: no dense output) and - for the games
+    with sel[g] - appended to the rollout storage `rows` = (obs_f [steps][n][1787] of `dtype`, int8 lists [steps][n][5][25],
+    int8 lens [steps][n][5]) at step t[g] (int64).  -> (f, lists, lens) or None."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("observations are written as float32 or bfloat16")
+    f = lists = lens = None
+    if dense:
+        if out is None:
+            f = torch.empty((vec.n, spec.OBS_FLOATS), dtype=dtype, device=vec.device)
+            lists = torch.empty((vec.n, 5, spec.OBS_LIST_PAD), dtype=torch.int32, device=vec.device)
+            lens = torch.empty((vec.n, 5), dtype=torch.int32, device=vec.device)
+        else:
+            f, lists, lens = out
+            if f.dtype != dtype or lists.dtype != torch.int32 or lens.dtype != torch.int32 or not (f.is_contiguous() and lists.is_contiguous() and lens.is_contiguous()):
+                raise ValueError("out = (f of the requested dtype, int32 lists, int32 lens), contiguous")
+    rf = rl = rn = None
+    if rows is not None:
+        rf, rl, rn = rows
+        if rf.dtype != dtype or rl.dtype != torch.int8 or rn.dtype != torch.int8 or rf.shape[1] != vec.n or not (rf.is_contiguous() and rl.is_contiguous() and rn.is_contiguous()):
+            raise ValueError("rows = (obs_f [steps][n][1787] of the requested dtype, int8 lists, int8 lens), contiguous")
+        t = t.to(torch.int64).contiguous()
+        sel = (sel.view(torch.uint8) if sel.dtype == torch.bool else sel.to(torch.uint8)).contiguous()    # (bool is one byte, 0 / 1: no copy)
+    p = lambda x: None if x is None else _ptr(x)
+    _lib.check(vec.L.catan_obs_rows(vec.h, int(dtype == torch.bfloat16), p(f), p(lists), p(lens), p(rf), p(rl), p(rn), p(t) if rows is not None else None,
+                                    p(sel) if rows is not None else None, _stream()))
+    return (f, lists, lens) if dense else None
+
+
 def obs_dict(vec, f, lists, lens):
     """Split the flat encoder output into the reference's observation keys (RL/ppo/process_batch.py:10-13), batched:
     'normal' keys -> float32 [n, ...], 'list' keys -> int64 [n, 25] zero padded (the net masks by length)."""

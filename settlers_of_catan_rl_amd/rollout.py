@@ -156,13 +156,16 @@ class RolloutCollector(object):
         m = sel if cur.dim() == 1 else sel.reshape((-1,) + (1,) * (cur.dim() - 1))
         dst[t, ar] = torch.where(m, v.to(cur.dtype), cur)
 
-    def _store_obs(self, sel, f, lists, lens):
+    def _store_obs(self, sel, f, lists, lens, t=None):
+        """f is None: the observation rows were already appended by the env (catan_obs_rows); only the bookkeeping is left"""
         st, T = self.storage, self.T
-        t = self.n_obs.clamp(max=T)
+        if t is None:
+            t = self.n_obs.clamp(max=T)
         sel8 = sel.to(torch.uint8)
-        self._row_store(st.obs_f, f.to(st.obs_f.dtype), t, sel8)
-        self._row_store(st.lists, lists.to(torch.int8), t, sel8)
-        self._col_store(st.lens, lens.to(torch.int8), t, sel)
+        if f is not None:
+            self._row_store(st.obs_f, f.to(st.obs_f.dtype), t, sel8)
+            self._row_store(st.lists, lists.to(torch.int8), t, sel8)
+            self._col_store(st.lens, lens.to(torch.int8), t, sel)
         if self.recurrent:            # game_manager.py:55,133: the state the active seat will enter this decision with
             hid = self.hid[:, self._ar, self.active_pid - 1]                                  # [2, N, L]
             for k in range(2):
@@ -185,10 +188,20 @@ class RolloutCollector(object):
         n_live_iters = torch.zeros((), dtype=torch.int64, device=dev)       # iterations in which some game still stepped
         n_complete = torch.zeros((), dtype=torch.int64, device=dev)
         packed_from_env = hasattr(env, "get_action_masks_packed")
+        # one kernel writes the dense observations the policy pass reads (in the storage's dtype: every value is exact in bf16)
+        # AND appends the active seats' rows to the storage (k_obs_rows; round 2: k_obs, a cast pass and a masked row store)
+        fused_obs = hasattr(env, "get_obs_rows") and st.obs_f.is_cuda and st.obs_f.dtype in (torch.float32, torch.bfloat16)
+        obs_out = mask_out = None
         while True:
-            f, lists, lens = env.get_obs()
-            # an observation produced by the previous step for the active seat (:126-133) - or the carried one
-            self._store_obs(self.pending_obs & (self.n_obs < T + 1), f, lists, lens)
+            if fused_obs:
+                sel = self.pending_obs & (self.n_obs < T + 1)
+                t_obs = self.n_obs.clamp(max=T)
+                f, lists, lens = env.get_obs_rows(st.obs_f.dtype, out=obs_out, rows=(st.obs_f, st.lists, st.lens), t=t_obs, sel=sel)
+                self._store_obs(sel, None, None, None, t=t_obs)
+            else:
+                f, lists, lens = env.get_obs()
+                # an observation produced by the previous step for the active seat (:126-133) - or the carried one
+                self._store_obs(self.pending_obs & (self.n_obs < T + 1), f, lists, lens)
             self.pending_obs = torch.zeros(N, dtype=torch.bool, device=dev)
             frozen = self.n_obs >= T + 1                                                    # while len(observations) < T+1 (:78)
             if max_iters is not None and iters >= max_iters:
@@ -199,9 +212,14 @@ class RolloutCollector(object):
             live = ~frozen
             n_live_iters += live.any()
             deciding = env.deciding_player().long()                                         # :79
-            masks = env.get_action_masks()                                                  # :83
+            masks = env.get_action_masks(mask_out) if mask_out is not None else env.get_action_masks()   # :83
             pol = self.policy_of_pid[ar, deciding - 1]
             actions, logp = self._act(f, lists, lens, masks, pol, deciding, term, live)     # :85-89
+            if fused_obs and obs_out is None and self._graphed is not None and not self.opponent_nets:
+                # from now on the env writes straight into the captured graph's input buffers (no copy per replay)
+                bufs = self._graphed.static_inputs(N)
+                if bufs is not None and bufs[0].dtype == st.obs_f.dtype and bufs[1].dtype == torch.int32 and bufs[2].dtype == torch.int32:
+                    obs_out, mask_out = bufs[:3], bufs[3]
             a_env = actions.to(torch.int32)
             a_env[:, 0] = torch.where(frozen, torch.full_like(a_env[:, 0], -1), a_env[:, 0])   # frozen games: no-op
             pmasks = env.get_action_masks_packed() if packed_from_env else pack_action_masks(masks)   # (before the step replaces them)
@@ -271,7 +289,7 @@ class RolloutCollector(object):
                 if self._graphed is None or self._graphed.policy is not net:
                     from .forward_search import GraphedAct
                     self._graphed = GraphedAct(net, buckets=(N,), autocast_dtype=self.autocast_dtype, generator=self.sample_gen)
-                res = self._graphed(f, lists, lens, masks, with_logp=True)
+                res = self._graphed(f, lists, lens, masks, with_logp=True, clone=False)
             elif self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                     res = net.act(*args, **kw)

@@ -59,6 +59,44 @@ def test_obs_vs_reference_states(hip_lib):
     assert np.array_equal(gl.cpu().numpy(), np.array(lists)) and np.array_equal(gn.cpu().numpy(), np.array(lens))
 
 
+def test_obs_rows_bf16_and_storage_rows(oracle, hip_lib):
+    """catan_obs_rows: (1) the bf16 dense matrix equals the fp32 one exactly (every observation value is a multiple of 1/8 below
+    32), at game counts that are not multiples of the 16 games a wave takes; (2) the rows appended to a rollout storage -
+    obs_f[t[g]][g], int8 lists / lengths - are the dense rows of the selected games, at every alignment a row can start at, and
+    nothing else in the storage is touched; (3) the oracle's observations once more through this entry point."""
+    import torch
+    for n, seed, steps in ((333, 6, 700), (1024, 2, 1500), (5, 1, 40)):
+        env = _env(n, seed)
+        ob = oracle.OracleBatch(n, seed)
+        env.random_rollout(0, steps); ob.run_random(steps, want_blobs=False)
+        of, olists, olens, _ = _oracle_obs(ob, n)
+        f32, l32, n32 = env.get_obs_rows(torch.float32)
+        assert np.array_equal(f32.cpu().numpy(), of) and np.array_equal(l32.cpu().numpy(), olists) and np.array_equal(n32.cpu().numpy(), olens)
+        fb, lb, nb = env.get_obs_rows(torch.bfloat16)
+        assert torch.equal(fb.float(), f32) and torch.equal(lb, l32) and torch.equal(nb, n32)
+        assert float(f32.max()) < 32.0 and torch.equal((f32 * 8).round(), f32 * 8)
+        for dtype, dense in ((torch.bfloat16, fb), (torch.float32, f32)):
+            S = 7
+            g = torch.Generator().manual_seed(n)
+            t = torch.randint(0, S, (n,), generator=g).cuda()
+            sel = (torch.rand(n, generator=g) < 0.4).cuda()
+            rows_f = torch.full((S, n, spec.OBS_FLOATS), -3.0, dtype=dtype, device="cuda")
+            rows_l = torch.full((S, n, 5, 25), -7, dtype=torch.int8, device="cuda")
+            rows_n = torch.full((S, n, 5), -7, dtype=torch.int8, device="cuda")
+            out = env.get_obs_rows(dtype, rows=(rows_f, rows_l, rows_n), t=t, sel=sel)
+            assert torch.equal(out[0], dense)
+            ar = torch.arange(n, device="cuda")
+            touched = torch.zeros((S, n), dtype=torch.bool, device="cuda")
+            touched[t[sel], ar[sel]] = True
+            assert torch.equal(rows_f[t[sel], ar[sel]], dense[sel]), "appended observation rows differ from the dense rows"
+            assert torch.equal(rows_l[t[sel], ar[sel]].int(), l32[sel]) and torch.equal(rows_n[t[sel], ar[sel]].int(), n32[sel])
+            assert bool((rows_f[~touched] == -3.0).all()) and bool((rows_l[~touched] == -7).all()) and bool((rows_n[~touched] == -7).all())
+            # rows only (no dense output)
+            rows_f2 = torch.full_like(rows_f, -3.0); rows_l2 = torch.full_like(rows_l, -7); rows_n2 = torch.full_like(rows_n, -7)
+            assert env.get_obs_rows(dtype, rows=(rows_f2, rows_l2, rows_n2), t=t, sel=sel, dense=False) is None
+            assert torch.equal(rows_f2, rows_f) and torch.equal(rows_l2, rows_l) and torch.equal(rows_n2, rows_n)
+
+
 def test_env_wrapper_shim_signatures(oracle, hip_lib):
     """Single-game view with the reference's EnvWrapper signatures (env/wrapper.py:30-50,168-185,711-721)."""
     from settlers_of_catan_rl_amd.env import EnvWrapper
