@@ -286,6 +286,19 @@ int32_t catan_tile_encoder_weight_elems(void);
 int32_t catan_tile_encoder_vec_elems(void);
 int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream);
 
+/* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
+ * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.
+ * pre: bfloat16 [B][..], the head's 128 columns of the trunk product all heads share (row pitch pre_ld elements); cond: float
+ * [B][ncond] conditioning columns that follow the trunk in mlp_1's input (ncond <= 32; NULL when 0); wts: bfloat16
+ * [catan_head_weight_elems()] = W2 [128][128] | W3 [80][128] (rows >= K zero) | W1e^T [32][128] (column j of the conditioning
+ * block of mlp_1.weight as row j); vec: float [catan_head_vec_elems()] = LayerNorm weight, bias, b2 (128 each), b3 [80];
+ * mask: float [B][K] with row pitch mask_ld; u: uniform per row for the inverse-CDF sample, NULL = arg-max.
+ * -> action int64 [B], logp float [B] (log-probability of the action under the masked distribution). */
+int32_t catan_head_weight_elems(void);
+int32_t catan_head_vec_elems(void);
+int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,
+                   int32_t K, const float* mask, int64_t mask_ld, const float* u, int64_t* action, float* logp, int64_t B, catan_stream_t stream);
+
 /* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
  * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card
  * CLASS (a list has <= 6 distinct ids; see csrc/catan_nn.hip).  ids: [rows][pitch] integers of id_bytes (1, 4 or 8) bytes, the
@@ -301,6 +314,11 @@ int32_t catan_card_summary_params(void);
 int32_t catan_card_summary_patterns(void);
 int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, float* out,
                            int32_t* keys, int64_t rows, catan_stream_t stream);
+/* Inference: out[r] = table[pattern of list r] with table = float [catan_card_summary_patterns()][16], the outputs of
+ * catan_card_summary_fwd on the synthetic list of every pattern (rebuilt by the caller when the weights change); lists whose
+ * counts fall outside the deck are evaluated directly from `params`. */
+int catan_card_summary_lookup(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* table, const float* params, float eps,
+                              float* out, int64_t rows, catan_stream_t stream);
 int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
                            float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream);
 /* dpat[c][keys[r]][0..15] += dout[r][0..15] for the rows with keys[r] >= 0; dpat: float [replicas][catan_card_summary_patterns()][16],

@@ -142,10 +142,14 @@ _SIGS = {
     "catan_tile_encoder_weight_elems": (C.c_int32, []),
     "catan_tile_encoder_vec_elems": (C.c_int32, []),
     "catan_tile_encoder_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_head_weight_elems": (C.c_int32, []),
+    "catan_head_vec_elems": (C.c_int32, []),
+    "catan_head_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_params": (C.c_int32, []),
     "catan_card_summary_patterns": (C.c_int32, []),
     "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
     "catan_card_summary_fwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, C.c_int64, _vp]),
+    "catan_card_summary_lookup": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_float, _vp, C.c_int64, _vp]),
     "catan_card_summary_bwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_randomise_uncertainty": (C.c_int, [_vp, _vp, _vp]),
     "catan_players_turn_sim": (C.c_int, [_vp, _vp, _vp]),

@@ -13,6 +13,7 @@
 #include "catan_ppo.hip"
 #include "catan_nn.hip"
 #include "catan_tile_encoder.hip"
+#include "catan_heads.hip"
 
 using namespace catan;
 
@@ -892,6 +893,29 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
     }
 }
 
+int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
+int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
+int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,
+                   int32_t K, const float* mask, int64_t mask_ld, const float* u, int64_t* action, float* logp, int64_t B, catan_stream_t stream) {
+    if (!pre || !wts || !vec || !mask || !action || !logp || B <= 0 || K < 1 || K > HD_KP || ncond < 0 || ncond > HD_NCP || (ncond > 0 && !cond) ||
+        pre_ld % 8 != 0 || ((uintptr_t)pre & 15) != 0)
+        return fail(CATAN_EINVAL, "catan_head_fwd: bad arguments (K <= 80, ncond <= 32, pre 16-byte aligned with a row pitch that is a multiple of 8)");
+    HeadArgs a;
+    a.pre = (const unsigned short*)pre; a.pre_ld = pre_ld; a.cond = cond; a.cond_ld = cond_ld; a.ncond = ncond;
+    a.wts = (const unsigned short*)wts; a.vec = vec; a.eps = eps; a.K = K; a.mask = mask; a.mask_ld = mask_ld; a.u = u;
+    a.action = (long long*)action; a.logp = logp; a.B = B;
+    const dim3 grid(blocks(B, HD_ROWS));
+    switch ((K + 15) / 16) {
+    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(256), 0, S(stream), a); break;
+    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(256), 0, S(stream), a); break;
+    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(256), 0, S(stream), a); break;
+    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(256), 0, S(stream), a); break;
+    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(256), 0, S(stream), a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
     hipLaunchKernelGGL(k_randomise_uncertainty, dim3(blocks(e->n, 64)), dim3(64), 0, S(stream), e->ctx, controlling_player, e->mpk, e->err,
@@ -998,6 +1022,13 @@ int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const i
                            int32_t* keys, int64_t rows, catan_stream_t stream) {
     if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !out) return fail(CATAN_EINVAL, "catan_card_summary_fwd: bad arguments");
     hipLaunchKernelGGL(k_card_summary_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, out, (long)rows, keys);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_card_summary_lookup(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* table, const float* params, float eps,
+                              float* out, int64_t rows, catan_stream_t stream) {
+    if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !out || !table) return fail(CATAN_EINVAL, "catan_card_summary_lookup: bad arguments");
+    hipLaunchKernelGGL(k_card_summary_lookup, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, table, params, eps, out, (long)rows);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

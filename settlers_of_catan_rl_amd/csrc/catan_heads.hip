@@ -1,0 +1,239 @@
+// catan_heads.hip - one action head of the policy net as ONE inference kernel (acting in rollouts, evaluation, forward search).
+//
+// A head is  mlp_1 -> LayerNorm -> ReLU -> mlp_2 -> distribution.linear -> masked categorical  (reference
+// RL/models/action_heads_module.py:202-228, RL/distributions.py:10-40).  Its mlp_1 over the trunk comes out of the one GEMM all
+// twelve heads share (policy._ActionHeads: `pre_all`); what is left per head evaluation was ~8 launches of 5-15 us each - the
+// conditioning columns' product and add, LayerNorm + ReLU, two small GEMMs, a cast, the categorical - and a policy pass makes
+// twenty such evaluations one after the other (the heads are autoregressive): 4.3 of the 6 ms of a 65 536-row pass.
+// Here, per head evaluation: a 256-thread workgroup copies the head's weights to LDS (W2 128x128, W3 Kx128, the conditioning
+// columns of W1: 64 KB, from L2) and takes 256 rows through the whole chain, 16 rows per wave pass:
+//   x = pre (+ cond . W1e^T)            16-byte loads in the MFMA operand layout: lane = (row l % 16, eight k at 8 (l / 16) + 32 s)
+//   y = relu(LayerNorm(x))              in registers; a row's 128 values sit in 4 lanes x 32: two xor-shuffles per statistic
+//   h^T = W2 . y^T + b2                 v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand: the result leaves a lane with
+//                                       h[row l % 16][16 j + 4 (l / 16) + i] - which IS the A-operand layout of the next product
+//                                       once its contraction index is permuted (both operands of a product may permute k alike)
+//   logits = h . W3^T + b3              B fragments = two 8-byte LDS reads in the same permuted order; K <= 80 (5 column tiles)
+//   masked categorical                  logits through a small LDS tile; 4 lanes per row: max / sum / inverse-CDF pick with
+//                                       quad shuffles; the first index whose cumulative probability exceeds u, as k_categorical_fwd
+// Rounding follows the unfused bf16-autocast path: bf16 after the conditioning add, after LayerNorm + ReLU, after each Linear
+// (bias added in fp32 first); softmax statistics in fp32.
+#pragma once
+
+namespace catan {
+
+constexpr int HD_PITCH = 136;            // LDS row pitch of the weight matrices (bf16 elements): 272 B, 16-byte aligned, conflict-free fragments
+constexpr int HD_LG = 84;                // floats per logits row in LDS (row groups 16 banks apart)
+constexpr int HD_RT = 4, HD_WAVES = 4;   // row tiles per wave, waves per workgroup
+constexpr int HD_ROWS = HD_WAVES * HD_RT * 16;
+constexpr int HD_NCP = 32;               // conditioning columns, padded
+constexpr int HD_KP = 80;                // output columns, padded (73 road edges)
+constexpr int HD_WELEMS = 128 * 128 + HD_KP * 128 + HD_NCP * 128;      // packed bf16: W2 [128][128], W3 [80][128], W1e^T [32][128]
+constexpr int HD_VELEMS = 128 * 3 + HD_KP;                             // packed fp32: ln_w, ln_b, b2 [128] each, b3 [80]
+
+struct HeadArgs {
+    const unsigned short* pre; long pre_ld;      // bf16 [B][.. 128 ..]: this head's columns of the shared trunk product (bias included)
+    const float* cond; long cond_ld; int ncond;  // float [B][ncond] conditioning columns that follow the trunk in mlp_1's input, or null
+    const unsigned short* wts; const float* vec; // the head's packs (HD_WELEMS / HD_VELEMS)
+    float eps; int K;
+    const float* mask; long mask_ld;             // float [B][K] (a column window of the mask matrix is fine)
+    const float* u;                              // uniform per row (inverse-CDF sample) or null (arg-max)
+    long long* action; float* logp; long B;
+};
+
+DEVI float hd_bf(float v) { return te_bf(te_to_bf(v)); }
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * HD_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short sW3[KT * 16 * HD_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
+    __shared__ float sV[HD_VELEMS];
+    __shared__ float sLg[HD_WAVES][16 * HD_LG];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+    for (int i = tid; i < 128 * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        *reinterpret_cast<uint4*>(sW2 + n * HD_PITCH + c * 8) = *reinterpret_cast<const uint4*>(a.wts + n * 128 + c * 8);
+    }
+    for (int i = tid; i < KT * 16 * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        *reinterpret_cast<uint4*>(sW3 + n * HD_PITCH + c * 8) = *reinterpret_cast<const uint4*>(a.wts + 128 * 128 + n * 128 + c * 8);
+    }
+    if (a.ncond > 0)
+        for (int i = tid; i < HD_NCP * 16; i += 256)
+            *reinterpret_cast<uint4*>(sW1 + i * 8) = *reinterpret_cast<const uint4*>(a.wts + 128 * 128 + HD_KP * 128 + i * 8);
+    for (int i = tid; i < HD_VELEMS; i += 256) sV[i] = a.vec[i];
+    const float* lnw = sV; const float* lnb = sV + 128; const float* b2 = sV + 256; const float* b3 = sV + 384;
+    float* lg = sLg[wave];
+    // the trunk products of all of this wave's row tiles, requested before the weights have even landed (a tile's chain is
+    // otherwise one exposed HBM round trip after the other: there is one wave per SIMD)
+    uint4 xr[HD_RT][4];
+#pragma unroll
+    for (int tt = 0; tt < HD_RT; tt++) {
+        const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) xr[tt][s] = *reinterpret_cast<const uint4*>(a.pre + row * a.pre_ld + s * 32 + g * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < HD_RT; tt++) {
+        const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+        if (row0 >= a.B) break;                                       // (wave-uniform)
+        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;        // rows past the end repeat the last one; nothing is stored for them
+        // the mask entries of the categorical at the end of the tile: four lanes per row, 20 columns each
+        const int rr = lane >> 2, part = lane & 3, c0 = part * 20;
+        const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
+        const float* mrow = a.mask + grow * a.mask_ld;
+        float mk[20];
+#pragma unroll
+        for (int q = 0; q < 20; q++) mk[q] = c0 + q < a.K ? mrow[c0 + q] : 0.0f;
+        const float thr = a.u ? a.u[grow] : 0.0f;
+        // ---- x = pre (+ cond . W1e^T), in the operand layout
+        float x[4][8];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint4 u4 = xr[tt][s];
+            x[s][0] = __uint_as_float(u4.x << 16); x[s][1] = __uint_as_float(u4.x & 0xFFFF0000u);
+            x[s][2] = __uint_as_float(u4.y << 16); x[s][3] = __uint_as_float(u4.y & 0xFFFF0000u);
+            x[s][4] = __uint_as_float(u4.z << 16); x[s][5] = __uint_as_float(u4.z & 0xFFFF0000u);
+            x[s][6] = __uint_as_float(u4.w << 16); x[s][7] = __uint_as_float(u4.w & 0xFFFF0000u);
+        }
+        if (a.ncond > 0) {
+            float acc[4][8];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[s][e] = 0.0f;
+            for (int j = 0; j < a.ncond; j++) {
+                const float cj = hd_bf(a.cond[row * a.cond_ld + j]);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    float wv[8];
+                    te_load8(sW1 + j * 128 + s * 32 + g * 8, wv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) acc[s][e] += cj * wv[e];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) x[s][e] = hd_bf(x[s][e] + hd_bf(acc[s][e]));
+        }
+        // ---- LayerNorm(128) + ReLU: the row's values sit in the lanes lr, lr + 16, lr + 32, lr + 48
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) sum += x[s][e];
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 128.0f);
+        float sq = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = x[s][e] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / 128.0f) + a.eps);
+        bf16x8_t xa[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            unsigned short hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int col = s * 32 + g * 8 + e;
+                hv[e] = te_to_bf(fmaxf((x[s][e] - mean) * rstd * lnw[col] + lnb[col], 0.0f));
+            }
+            uint4 u4;
+            u4.x = (unsigned)hv[0] | ((unsigned)hv[1] << 16); u4.y = (unsigned)hv[2] | ((unsigned)hv[3] << 16);
+            u4.z = (unsigned)hv[4] | ((unsigned)hv[5] << 16); u4.w = (unsigned)hv[6] | ((unsigned)hv[7] << 16);
+            xa[s] = *reinterpret_cast<const bf16x8_t*>(&u4);
+        }
+        // ---- h^T = W2 . y^T + b2: column tile j of h lands as h[row lr][16 j + 4 g + i] in c[i]
+        unsigned hp[4][4];                                            // A operand of the next product: k-step s = tiles 2 s, 2 s + 1
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f32x4_t c = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(sW2 + (j * 16 + lr) * HD_PITCH + s * 32 + g * 8);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xa[s], c, 0, 0, 0);
+            }
+            const int n0 = 16 * j + 4 * g;
+            const unsigned h0 = te_to_bf(c[0] + b2[n0]), h1 = te_to_bf(c[1] + b2[n0 + 1]), h2 = te_to_bf(c[2] + b2[n0 + 2]), h3 = te_to_bf(c[3] + b2[n0 + 3]);
+            hp[j >> 1][(j & 1) * 2] = h0 | (h1 << 16);
+            hp[j >> 1][(j & 1) * 2 + 1] = h2 | (h3 << 16);
+        }
+        // ---- logits = h . W3^T + b3, the contraction index in the order the lanes hold h: k = 32 s + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3}
+#pragma unroll
+        for (int t = 0; t < KT; t++) {
+            f32x4_t c = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const unsigned short* wr = sW3 + (t * 16 + lr) * HD_PITCH + 32 * s + 4 * g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(wr), hi = *reinterpret_cast<const uint2*>(wr + 16);
+                uint4 bu; bu.x = lo.x; bu.y = lo.y; bu.z = hi.x; bu.w = hi.y;
+                uint4 au; au.x = hp[s][0]; au.y = hp[s][1]; au.z = hp[s][2]; au.w = hp[s][3];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&au), *reinterpret_cast<const bf16x8_t*>(&bu), c, 0, 0, 0);
+            }
+            const float bb = b3[16 * t + lr];
+#pragma unroll
+            for (int i = 0; i < 4; i++) lg[(4 * g + i) * HD_LG + 16 * t + lr] = hd_bf(c[i] + bb);       // logits[row 4 g + i][16 t + lr]
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- masked categorical: four lanes per row, 20 columns each
+        {
+            float z[20];
+            u32 valid = 0;
+            float mx = -INFINITY;
+            int amax = 0x7fff;
+#pragma unroll
+            for (int q = 0; q < 20; q++) {
+                const int col = c0 + q;
+                z[q] = lg[rr * HD_LG + (col < KT * 16 ? col : 0)];
+                const bool ok = mk[q] > 0.0f;
+                if (ok) { valid |= 1u << q; if (z[q] > mx) { mx = z[q]; amax = col; } }
+            }
+#pragma unroll
+            for (int d = 1; d <= 2; d <<= 1) {
+                const float om = __shfl_xor(mx, d); const int oa = __shfl_xor(amax, d);
+                if (om > mx || (om == mx && oa < amax)) { mx = om; amax = oa; }
+            }
+            if (amax == 0x7fff) amax = 0;
+            float sum2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 20; q++) if ((valid >> q) & 1u) sum2 += __expf(z[q] - mx);
+            float tot = sum2;
+            tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2);
+            const float lse = mx + __logf(tot);
+            // cumulative probabilities in column order: exclusive prefix over the four parts, then in-lane
+            float mine = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 20; q++) if ((valid >> q) & 1u) mine += __expf(z[q] - lse);
+            float incl = mine;
+            { const float v1 = __shfl_up(incl, 1); if (part >= 1) incl += v1; }
+            { const float v2 = __shfl_up(incl, 2); if (part >= 2) incl += v2; }
+            float cdf = incl - mine;
+            int pick = 0x7fff, last = -1;
+#pragma unroll
+            for (int q = 0; q < 20; q++) if ((valid >> q) & 1u) {
+                cdf += __expf(z[q] - lse);
+                last = c0 + q;
+                if (pick == 0x7fff && cdf > thr) pick = c0 + q;
+            }
+#pragma unroll
+            for (int d = 1; d <= 2; d <<= 1) {
+                pick = min(pick, __shfl_xor(pick, d));
+                last = max(last, __shfl_xor(last, d));
+            }
+            int act = a.u ? (pick != 0x7fff ? pick : (last >= 0 ? last : amax)) : amax;
+            act = min(max(act, 0), a.K - 1);
+            if (part == 0 && row0 + rr < a.B) {
+                a.action[grow] = act;
+                a.logp[grow] = (mrow[act] > 0.0f ? lg[rr * HD_LG + act] : -INFINITY) - lse;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace catan

@@ -1190,6 +1190,41 @@ __global__ __launch_bounds__(256) void k_card_summary_fwd(const void* __restrict
 #pragma unroll
     for (int i = 0; i < 4; i++) o4[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
 }
+// Inference: the module's output is a function of the list's count PATTERN alone, so a table of the 4 860 patterns' outputs
+// (built with k_card_summary_fwd on the synthetic pattern lists whenever the weights change: once per rollout) turns the forward
+// into count -> pattern -> one 64-byte row copy (k_card_summary_fwd: ~260 us per 65 536..196 608 lists, a fifth of a policy pass
+// at rollout width).  Lists whose counts fall outside the deck (never in a real game) are evaluated directly.
+__global__ __launch_bounds__(256) void k_card_summary_lookup(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
+                                                             const float* __restrict__ table, const float* __restrict__ params, float eps,
+                                                             float* __restrict__ out, long rows) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float cnt[CS_V];
+    cs_counts(ids, esz, pitch, r, lens[r], cnt);
+    const int key = cs_pattern(cnt);
+    float4* o4 = reinterpret_cast<float4*>(out + r * CS_D);
+    if (key >= 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(table + (long)key * CS_D);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o4[i] = t4[i];
+        return;
+    }
+    const CardTables& T = *reinterpret_cast<const CardTables*>(params);          // (rare: straight from global memory)
+    float logc[CS_V], acc[CS_D];
+#pragma unroll
+    for (int a = 0; a < CS_V; a++) logc[a] = cnt[a] > 0.f ? __logf(cnt[a]) : -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CS_D; i++) acc[i] = 0.f;
+    for (int a = 0; a < CS_V; a++) {
+        if (cnt[a] == 0.f) continue;
+        float p[CS_H][CS_V], attn[CS_D], xhat[CS_D], rep[CS_D], rstd;
+        cs_class_fwd(T, logc, a, eps, p, attn, xhat, rstd, rep);
+#pragma unroll
+        for (int i = 0; i < CS_D; i++) acc[i] += cnt[a] * rep[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o4[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+}
 // dparams (CS_NPAR floats, ACCUMULATED into: zero first): gradients of S, V, W, bias, LayerNorm weight / bias.  A parameter
 // gradient is a sum over all lists.  Every lane keeps a SLICE of the parameter block in registers over CS_RPL lists, then the
 // wave adds its lanes up with shuffles once, one LDS add per wave and one global atomic per block and parameter.  Slices

@@ -431,6 +431,71 @@ def tile_encoder_forward(te, tiles):
     return out
 
 
+def head_pack(head, trunk_dim):
+    """An action head's parameters in the layout of catan_head_fwd (include/catan_hip.h), cached on the module and re-packed - IN
+    PLACE, a captured hipGraph holds the buffers' addresses - when a parameter changed.  trunk_dim: the columns of mlp_1's input
+    that the shared trunk product covers; the rest (conditioning columns, head 5's trade features) is W1e."""
+    params = [head.mlp_1.weight, head.mlp_2.weight, head.mlp_2.bias, head.norm.weight, head.norm.bias,
+              head.distribution.linear.weight, head.distribution.linear.bias]
+    stamp = (sum(p._version for p in params), params[0].device, params[0].data_ptr(), trunk_dim)
+    cache = getattr(head, "_fused_pack", None)
+    if cache is not None and cache[0] == stamp:
+        return cache[1], cache[2]
+    L = _lib.lib()
+    K = head.distribution.linear.weight.shape[0]
+    e = head.mlp_1.weight.shape[1] - trunk_dim
+    assert head.mlp_2.weight.shape == (128, 128) and K <= 80 and 0 <= e <= 32
+    with torch.no_grad():
+        w1e = torch.zeros((32, 128), dtype=torch.bfloat16, device=params[0].device)
+        if e:
+            w1e[:e] = head.mlp_1.weight[:, trunk_dim:].t().to(torch.bfloat16)
+        wts = torch.cat([_pad2(head.mlp_2.weight, 128, 128), _pad2(head.distribution.linear.weight, 80, 128), w1e.reshape(-1)]).contiguous()
+        rb = lambda b, n: _pad1(b.to(torch.bfloat16), n)             # a Linear bias as bf16 autocast hands it to the GEMM
+        vec = torch.cat([_pad1(head.norm.weight, 128), _pad1(head.norm.bias, 128), rb(head.mlp_2.bias, 128),
+                         rb(head.distribution.linear.bias, 80)]).contiguous()
+    assert wts.numel() == L.catan_head_weight_elems() and vec.numel() == L.catan_head_vec_elems()
+    if cache is not None and cache[1].device == wts.device:
+        cache[1].copy_(wts); cache[2].copy_(vec)
+        wts, vec = cache[1], cache[2]
+    head._fused_pack = (stamp, wts, vec)
+    return wts, vec
+
+
+def head_fused_supported(pre_all):
+    """inference (no autograd) on the GPU with the trunk product in bf16"""
+    return (not torch.is_grad_enabled()) and pre_all.is_cuda and pre_all.dtype == torch.bfloat16 and pre_all.stride(-1) == 1 \
+        and pre_all.stride(0) % 8 == 0 and fused_heads_enabled
+
+
+fused_heads_enabled = True
+
+
+def head_sample(head, trunk_dim, pre, cond, mask, deterministic=False, generator=None):
+    """One head evaluation as one kernel (catan_head_fwd).  pre: bf16 [B, 128] view of the shared trunk product (row pitch =
+    stride(0)); cond: [B, e] conditioning columns or None; mask float [B, K] (a column window is fine).
+    -> (action int64 [B], log-prob [B])."""
+    wts, vec = head_pack(head, trunk_dim)
+    B = pre.shape[0]
+    K = head.distribution.linear.weight.shape[0]
+    if mask.stride(-1) != 1 or mask.dtype != torch.float32:
+        mask = mask.float().contiguous()
+    u = None
+    if not deterministic:
+        u = generator.take(B) if isinstance(generator, UniformPool) else torch.rand(B, device=pre.device, generator=generator)
+    ncond = 0
+    if cond is not None:
+        cond = cond.float()
+        if cond.stride(-1) != 1:
+            cond = cond.contiguous()
+        ncond = cond.shape[1]
+    assert ncond == head.mlp_1.weight.shape[1] - trunk_dim and mask.shape[1] == K
+    action = torch.empty(B, dtype=torch.int64, device=pre.device)
+    logp = torch.empty(B, dtype=torch.float32, device=pre.device)
+    _lib.check(_lib.lib().catan_head_fwd(_ptr(pre), pre.stride(0), _ptr(cond), cond.stride(0) if cond is not None else 0, ncond, _ptr(wts), _ptr(vec),
+                                         float(head.norm.eps), K, _ptr(mask), mask.stride(0), _ptr(u), _ptr(action), _ptr(logp), B, _stream()))
+    return action, logp
+
+
 _PATTERN_LISTS = {}
 
 
@@ -495,6 +560,63 @@ def card_summary(ids, lens, params, eps):
     if ids.stride(1) != 1:
         ids = ids.contiguous()
     return _CardSummary.apply(ids, lens.to(torch.int32).contiguous(), params, eps)
+
+
+import weakref
+_CARD_TABLES = weakref.WeakKeyDictionary()
+
+
+def card_summary_params(embedding, mha, norm):
+    """the 544 floats catan_card_summary_* read (include/catan_hip.h), from the module's weights"""
+    import math
+    V, H, hd = embedding.num_embeddings, mha.heads, mha.hd
+    w = torch.cat([n.weight for n in mha.qkv_nets], 0).float()
+    b = torch.cat([n.bias for n in mha.qkv_nets], 0).float()
+    qkv = torch.nn.functional.linear(embedding.weight.float(), w, b).view(V, 3, H, hd)      # Q / K / V of each of the six ids
+    s_ab = torch.einsum("ahd,bhd->hab", qkv[:, 0], qkv[:, 1]) * (1.0 / math.sqrt(hd))
+    return torch.cat((s_ab.reshape(-1), qkv[:, 2].reshape(-1), mha.out_proj_net.weight.float().reshape(-1),
+                      mha.out_proj_net.bias.float(), norm.weight.float(), norm.bias.float()))
+
+
+def card_summary_table(embedding, mha, norm):
+    """(params [544], table [patterns, 16]) for inference, cached on the attention module per LayerNorm and rebuilt - IN PLACE: a
+    captured hipGraph holds the addresses - when a weight changed (the inference copy is refreshed once per rollout)."""
+    prm = [embedding.weight, norm.weight, norm.bias] + list(mha.parameters())
+    stamp = (sum(p._version for p in prm), prm[0].device, prm[0].data_ptr())
+    caches = _CARD_TABLES.setdefault(mha, {})              # (not on the module: a deepcopy - inference_copy - must not carry them along)
+    cache = caches.get(id(norm))
+    if cache is not None and cache[0] == stamp:
+        return cache[1], cache[2]
+    with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+        params = card_summary_params(embedding, mha, norm).contiguous()
+        pid, plen = _pattern_lists(params.device)
+        table = torch.empty((pid.shape[0], 16), dtype=torch.float32, device=params.device)
+        _lib.check(_lib.lib().catan_card_summary_fwd(_ptr(pid), 1, pid.stride(0), _ptr(plen), _ptr(params), float(norm.eps), _ptr(table), None,
+                                                     pid.shape[0], _stream()))
+    if cache is not None and cache[1].device == params.device:
+        cache[1].copy_(params); cache[2].copy_(table)
+        params, table = cache[1], cache[2]
+    caches[id(norm)] = (stamp, params, table, embedding, norm)
+    return params, table
+
+
+def card_summary_lookup(ids, lens, embedding, mha, norm):
+    """inference form of card_summary: pattern table look-up (k_card_summary_lookup)"""
+    params, table = card_summary_table(embedding, mha, norm)
+    if ids.stride(1) != 1:
+        ids = ids.contiguous()
+    lens = lens.to(torch.int32).contiguous()
+    out = torch.empty((ids.shape[0], 16), dtype=torch.float32, device=ids.device)
+    _lib.check(_lib.lib().catan_card_summary_lookup(_ptr(ids), ids.element_size(), ids.stride(0), _ptr(lens), _ptr(table), _ptr(params), float(norm.eps),
+                                                    _ptr(out), ids.shape[0], _stream()))
+    return out
+
+
+def refresh_card_tables(module):
+    """brings every cached pattern table under `module` up to date in place (for captured graphs: policy.refresh_kernel_packs)"""
+    for m in module.modules():
+        for cache in list(_CARD_TABLES.get(m, {}).values()):
+            card_summary_table(cache[3], m, cache[4])
 
 
 class _MaskedCategorical(torch.autograd.Function):

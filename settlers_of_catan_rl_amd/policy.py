@@ -161,6 +161,8 @@ def _card_summary(ids, lens, embedding, mha, norm):
     with the 4 x 6 x 6 score table and the six value vectors; elsewhere the same algebra in torch ops."""
     B, L = ids.shape
     V, H, hd = embedding.num_embeddings, mha.heads, mha.hd
+    if not torch.is_grad_enabled() and nn_kernels.card_summary_supported(ids, V, H, hd, H * hd):
+        return nn_kernels.card_summary_lookup(ids, lens, embedding, mha, norm)       # inference: a table of the 4 860 count patterns
     with torch.autocast(device_type=ids.device.type, enabled=False):          # a few hundred flops per row: keep them fp32
         w = torch.cat([n.weight for n in mha.qkv_nets], 0).float()
         b = torch.cat([n.bias for n in mha.qkv_nets], 0).float()
@@ -542,9 +544,15 @@ class _ActionHeads(nn.Module):
         logp_sum = torch.zeros(B, device=x.device)
         ent_sum = torch.zeros(B, device=x.device)
         chosen = []
+        fused = acts is None and getattr(self, "_fused_now", False) and nn_kernels.head_fused_supported(pre)
         for i in range(4):
-            a, step_lp, ent = _categorical(head.logits(pre, out if fixed is None else torch.cat((fixed, out), -1)), mask,
-                                           None if acts is None else acts[:, i], deterministic, generator)
+            cond = out if fixed is None else torch.cat((fixed, out), -1)
+            if fused:
+                a, step_lp = nn_kernels.head_sample(head, self.D, pre, cond, mask, deterministic, generator)
+                ent = None
+            else:
+                a, step_lp, ent = _categorical(head.logits(pre, cond), mask,
+                                               None if acts is None else acts[:, i], deterministic, generator)
             onehot = F.one_hot(a, 6).float()
             out = out + onehot
             res = torch.clamp(res - onehot, min=0)
@@ -585,7 +593,18 @@ class _ActionHeads(nn.Module):
         if actions is None and not deterministic and main.is_cuda:
             generator = nn_kernels.UniformPool(generator, B, 18, dev)    # the 18 draws of a pass from one torch.rand
 
+        # inference on the GPU: a head evaluation is ONE kernel (csrc/catan_heads.hip) instead of ~8 small launches
+        fused = actions is None and nn_kernels.head_fused_supported(pre_all)
+        self._fused_now = fused
+
         def run(i, extra, mask, idx, count, custom=None):
+            if fused:
+                cond = extra
+                if custom is not None:
+                    cf = _ln(H[i].custom_norm, _lin(custom, H[i].custom_mlp.weight, H[i].custom_mlp.bias), relu=True)
+                    cond = cf if extra is None else torch.cat((extra, cf.float()), -1)
+                a, lpa = nn_kernels.head_sample(H[i], D, pre(i), cond, mask, deterministic, generator)
+                return a, lpa * count, 0.0
             a, lpa, ent = _categorical(H[i].logits(pre(i), extra, custom), mask, given(idx), deterministic, generator)
             return a, lpa * count, ((count * ent).mean() if want_ent else 0.0)
 
@@ -798,6 +817,11 @@ class CatanPolicy(nn.Module):
         te = self.observation_module.tile_encoder
         if next(te.parameters()).is_cuda and getattr(te, "_fused_pack", None) is not None:
             nn_kernels.tile_encoder_pack(te)
+        nn_kernels.refresh_card_tables(self.observation_module)
+        for h in self.action_head_module.action_heads:          # the fused head kernels' packs (nn_kernels.head_pack)
+            cache = getattr(h, "_fused_pack", None)
+            if cache is not None and h.mlp_2.weight.is_cuda:
+                nn_kernels.head_pack(h, cache[0][3])
 
     @torch.no_grad()
     def load_from(self, master):

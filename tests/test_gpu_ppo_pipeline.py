@@ -687,3 +687,113 @@ def test_forked_inference_streams_change_nothing(hip_lib):
         _, lp_e, _ = net.evaluate_actions(f, lists, lens, masks, a)
     assert float((lp_e.float().reshape(-1) - lp.float().reshape(-1)).abs().max()) < 0.05
     assert (masks[:, :13].gather(1, a[:, :1]) == 1).all()
+
+
+def test_fused_head_kernel_vs_unfused_heads(hip_lib):
+    """csrc/catan_heads.hip (one kernel per head evaluation: conditioning add, LayerNorm + ReLU, 128 x 128, 128 x K, masked
+    categorical) against the unfused bf16 chain of the same heads: (1) every head alone, arg-max - the same action and a
+    log-prob within 0.02 on all but a handful of near-tie rows; (2) the whole autoregressive pass, arg-max and sampled with the
+    same uniforms; (3) the sampled actions' log-probs equal the net's own evaluation of them; every sampled action is legal."""
+    from settlers_of_catan_rl_amd import policy as P, nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    torch.manual_seed(0)
+    B = 4096 + 37                                   # not a multiple of the 256 rows a workgroup takes
+    env = VecCatanEnv(B, seed=21); env.random_rollout(0, 900)
+    f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+    net = P.CatanPolicy().cuda()
+    with torch.no_grad():
+        for p in net.parameters():                  # decisive heads (the default init has near-uniform output layers)
+            p.add_(0.05 * torch.randn_like(p))
+    net = net.inference_copy(torch.bfloat16)
+    ahm = net.action_head_module
+    # (1) head by head on random bf16 trunk products and random conditioning columns
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pre_all = (torch.randn(B, 12 * 128, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    for i, head in enumerate(ahm.action_heads):
+        K = head.distribution.linear.weight.shape[0]
+        e = head.mlp_1.weight.shape[1] - ahm.D
+        cond = None if e == 0 else torch.randint(0, 3, (B, e), device="cuda", generator=g).float()
+        mask = (torch.rand(B, K, device="cuda", generator=g) < 0.6).float()
+        mask[:, 0] = 1.0
+        pre = pre_all[:, 128 * i:128 * (i + 1)]
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            a1, lp1 = nn_kernels.head_sample(head, ahm.D, pre, cond, mask, deterministic=True)
+            logits = head.logits(pre, cond, None) if i != 5 else head.logits(pre, cond, None)
+            a0, lp0, _ = P._categorical(logits, mask, None, True, None)
+        same = a1 == a0
+        assert float(same.float().mean()) > 0.995, (i, float(same.float().mean()))
+        assert float((lp1[same] - lp0[same]).abs().max()) < 0.03, (i, float((lp1[same] - lp0[same]).abs().max()))
+        assert bool((mask.gather(1, a1[:, None]) == 1).all()), i
+        u = torch.rand(B, device="cuda", generator=g)
+
+        class _U(object):                            # hands the same uniforms to both paths
+            def take(self, rows): return u
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            wts, vec = nn_kernels.head_pack(head, ahm.D)
+        act = torch.empty(B, dtype=torch.int64, device="cuda"); lp = torch.empty(B, device="cuda")
+        import ctypes as C
+        from settlers_of_catan_rl_amd import _lib
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().catan_head_fwd(p(pre), pre.stride(0), p(cond), cond.stride(0) if cond is not None else 0, e, p(wts), p(vec), float(head.norm.eps), K,
+                                             p(mask), mask.stride(0), p(u), p(act), p(lp), B, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        from settlers_of_catan_rl_amd.nn_kernels import _MaskedCategorical
+        a0s, lp0s, _ = _MaskedCategorical.apply(logits, mask, None, u)
+        same = act == a0s
+        assert float(same.float().mean()) > 0.99, (i, float(same.float().mean()))
+        assert bool((mask.gather(1, act[:, None]) == 1).all()), i
+    # (2) the whole pass
+    def act_pass(fused, deterministic, seed=3):
+        nn_kernels.fused_heads_enabled = fused
+        try:
+            gg = torch.Generator(device="cuda").manual_seed(seed)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return net.act(f, lists, lens, masks, deterministic=deterministic, generator=gg)
+        finally:
+            nn_kernels.fused_heads_enabled = True
+    v1, a1, lp1 = act_pass(True, True)
+    v0, a0, lp0 = act_pass(False, True)
+    assert torch.equal(v1, v0)
+    assert float((a1[:, 0] == a0[:, 0]).float().mean()) > 0.995
+    same = (a1 == a0).all(1)
+    assert float(same.float().mean()) > 0.95, float(same.float().mean())
+    assert float((lp1[same] - lp0[same]).abs().max()) < 0.05
+    v1, a1, lp1 = act_pass(True, False)
+    v0, a0, lp0 = act_pass(False, False)
+    assert float((a1[:, 0] == a0[:, 0]).float().mean()) > 0.99          # same uniforms: the same type nearly everywhere
+    # (3) legal, and the log-probs are the net's own evaluation of the sampled actions
+    assert (masks[:, :13].gather(1, a1[:, :1]) == 1).all()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, lp_e, _ = net.evaluate_actions(f, lists, lens, masks, a1)
+    assert float((lp_e.float().reshape(-1) - lp1.float().reshape(-1)).abs().max()) < 0.06
+    r, d = env.step(a1.to(torch.int32))
+    assert env.invalid_action_count() == 0
+
+
+def test_card_summary_pattern_table_lookup(hip_lib):
+    """Inference form of the dev-card list module (k_card_summary_lookup: count pattern -> a row of the 4 860-pattern table) against
+    the direct kernel on real lists, after a weight change too (the table is rebuilt in place), and on lists whose counts fall
+    outside the deck (evaluated directly)."""
+    from settlers_of_catan_rl_amd import policy as P, nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    torch.manual_seed(0)
+    env = VecCatanEnv(4096, seed=7); env.random_rollout(0, 1500)
+    f, lists, lens = env.get_obs(); lens = lens.long()
+    net = P.CatanPolicy().cuda()
+    om = net.observation_module
+    for rnd in range(2):
+        for li, (mha, norm) in enumerate(((om.played_card_mha, om.current_player_module.norm), (om.hidden_card_mha, om.current_player_module.norm),
+                                          (om.played_card_mha, om.other_players_module.norm))):
+            ids, ln = lists[:, li], lens[:, li]
+            direct = P._card_summary(ids, ln, om.dev_card_embedding, mha, norm)                  # grad enabled: k_card_summary_fwd
+            with torch.no_grad():
+                looked = P._card_summary(ids, ln, om.dev_card_embedding, mha, norm)
+            assert torch.allclose(looked, direct.detach(), rtol=1e-6, atol=1e-6), float((looked - direct).abs().max())
+        with torch.no_grad():
+            for p in om.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+    odd = torch.randint(0, 6, (512, 25), device="cuda", dtype=torch.int32)                       # 25 random ids: counts outside the deck
+    ln = torch.full((512,), 25, device="cuda")
+    direct = P._card_summary(odd, ln, om.dev_card_embedding, om.played_card_mha, om.current_player_module.norm)
+    with torch.no_grad():
+        looked = P._card_summary(odd, ln, om.dev_card_embedding, om.played_card_mha, om.current_player_module.norm)
+    assert torch.allclose(looked, direct.detach(), rtol=1e-5, atol=1e-5)

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd import spec
