@@ -104,14 +104,23 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) acc[s][e] = 0.0f;
-            for (int j = 0; j < a.ncond; j++) {
-                const float cj = hd_bf(a.cond[row * a.cond_ld + j]);
+            // four conditioning columns per round, their loads issued together (a load per column inside the loop is an exposed
+            // HBM round trip each: 12 columns x 4 tiles of them made this kernel three times longer)
+            const float* crow = a.cond + row * a.cond_ld;
+            for (int j0 = 0; j0 < a.ncond; j0 += 4) {
+                float cj[4];
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    float wv[8];
-                    te_load8(sW1 + j * 128 + s * 32 + g * 8, wv);
+                for (int jj = 0; jj < 4; jj++) cj[jj] = j0 + jj < a.ncond ? crow[j0 + jj] : 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) acc[s][e] += cj * wv[e];
+                for (int jj = 0; jj < 4; jj++) {
+                    const float cv = hd_bf(cj[jj]);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        float wv[8];
+                        te_load8(sW1 + (j0 + jj) * 128 + s * 32 + g * 8, wv);       // (rows >= ncond of the pack are zero)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) acc[s][e] += cv * wv[e];
+                    }
                 }
             }
 #pragma unroll
