@@ -154,7 +154,16 @@ def ppo_update_record(env, n, rank, world, T, cdist):
         if u == 0:
             first = {"rollout_s": rollout_s, "update_s": update_s}
     dec = world * n * T
-    return {"value": rollout_s + update_s, "unit": "s/update", "higher_is_better": False, "num_steps": T,
+    learner = None
+    if rank == 0:                       # per-kernel rooflines of the learner side, measured in this run (tools/learner_rooflines.py)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from learner_rooflines import learner_rooflines
+            del st
+            learner = learner_rooflines(env, net, T=200, rows_mb=204800)
+        except Exception as e:          # (the bench line must still be printed)
+            learner = {"error": f"{type(e).__name__}: {e}"}
+    return {"value": rollout_s + update_s, "unit": "s/update", "higher_is_better": False, "num_steps": T, "roofline_learner": learner,
             "reference_num_steps": 200, "games_per_gpu": n, "ppo_epoch": tr.cfg.ppo_epoch, "num_mini_batch": tr.cfg.num_mini_batch,
             "minibatch_rows": n * T // tr.cfg.num_mini_batch, "active_seat_decisions_per_update": dec,
             "rollout_s": rollout_s, "update_s": update_s, "env_passes_in_rollout": col.iters, **tr.timings,
@@ -262,6 +271,8 @@ def main():
     ppo = None
     if args.ppo_steps > 0:
         ppo = ppo_update_record(env, n, rank, world, args.ppo_steps, cdist)
+    if ppo is not None and rank != 0:
+        ppo.pop("roofline_learner", None)
     if rank == 0:
         slow_launches = prof_steps if args.window <= 0 else -(-prof_steps // args.window)
         launches = {k: (slow_launches if k in ("k_lr_heavy", "k_reset_list") else prof_steps) for k in kms}
@@ -337,6 +348,7 @@ def main():
         if lockstep is not None:
             out["lockstep"] = lockstep
         if ppo is not None:
+            out["roofline_learner"] = ppo.pop("roofline_learner", None)
             out["ppo_update"] = ppo
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,115 @@
+"""`roofline_learner` of bench.py: the learner-side kernels of a PPO update (BASELINE config 3), each timed ALONE with HIP
+events on the stream it is launched on, at the shapes of the real update (65 536 games, T = 200, 204 800-row minibatches), against
+the HBM roofline on its ALGORITHMIC bytes (the tensors it must read and write once, stated per kernel below) and - where it runs
+on the matrix cores - its MFMA FLOP/s against the dense bf16 peak.
+
+Kernels: the two fused learner kernels north_star names (k_gae, k_ppo_loss), the observation encoder of a rollout pass
+(k_obs_rows), the fused tile encoder of every inference pass (k_tile_encoder_fwd), one fused action-head evaluation
+(k_head_fwd), and the longest hand-written kernels of a minibatch step by the kernel trace (profiles/r03_train_step_kernel_stats.csv):
+the tile encoder's attention backward, its FFN row product, its LayerNorm backward and a weight gradient.  The library GEMMs of the
+step are not listed: they are rocBLAS / hipBLASLt code."""
+import torch
+
+HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
+
+
+def _time_us(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def _entry(kernel, what, us, nbytes, flops=None, note=None):
+    gbs = nbytes / (us * 1e-6) / 1e9
+    e = {"kernel": kernel, "shape": what, "avg_us": us, "algorithmic_bytes": nbytes, "achieved_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "bound": "hbm"}
+    if flops is not None:
+        tf = flops / (us * 1e-6) / 1e12
+        e.update(mfma_flops=flops, achieved_tflops=tf, mfma_frac=tf / MFMA_PEAK_TFLOPS)
+    if note:
+        e["note"] = note
+    return e
+
+
+def learner_rooflines(env, net, T=200, rows_mb=204800):
+    """env: VecCatanEnv with n games (mid-game states); net: CatanPolicy on the device (fp32 master).  -> list of dicts."""
+    from settlers_of_catan_rl_amd import nn_kernels, ppo as K, spec
+    out = []
+    dev, n = env.device, env.n
+    g = torch.Generator(device=dev).manual_seed(0)
+    # ---- k_gae + k_adv_stats + k_adv_normalise: 3 reads + 2 writes of (T, n) fp32 = 20 B per (t, game); normalise: read + write = 8 B
+    r = torch.randn(T, n, device=dev, generator=g); v = torch.randn(T + 1, n, device=dev, generator=g); m = (torch.rand(T + 1, n, device=dev, generator=g) > 0.02).float()
+    out.append(_entry("k_gae + k_adv_stats + k_adv_normalise", f"T = {T} x {n} games", _time_us(lambda: K.compute_gae(r, v, m, 0.999, 0.95, process_group=False)),
+                      28 * T * n, note="rewards, values, masks in; returns, advantages out (20 B per (t, game)); the normalisation reads and writes the advantages once more (8 B)"))
+    del r, v, m
+    # ---- k_ppo_loss: 6 fp32 streams in, 2 gradient streams out = 32 B per row
+    x = [torch.randn(rows_mb, device=dev, generator=g) for _ in range(6)]
+    out.append(_entry("k_ppo_loss (forward + analytic gradients)", f"{rows_mb} rows", _time_us(lambda: K.ppo_loss(x[0] - 3, x[1], x[2] - 3, x[3], x[4], x[5], 0.2, 1.0, value_normaliser=(150.0, 150.0))),
+                      32 * rows_mb, note="launch-sized problem (6.5 MB): the time is the launch + the 256-workgroup reduction, not bandwidth"))
+    del x
+    # ---- k_obs_rows: record in (704 B), bf16 observation row (3 574 B) + int32 card lists / lengths (520 B) out per game;
+    #      + the rollout-storage rows of the games whose active seat decides (one in four: 3 574 + 130 B each)
+    dense = env.get_obs_rows(torch.bfloat16)
+    st_f = torch.zeros((4, n, spec.OBS_FLOATS), dtype=torch.bfloat16, device=dev); st_l = torch.zeros((4, n, 5, 25), dtype=torch.int8, device=dev)
+    st_n = torch.zeros((4, n, 5), dtype=torch.int8, device=dev)
+    t = torch.randint(0, 4, (n,), device=dev, generator=g); sel = torch.rand(n, device=dev, generator=g) < 0.25
+    out.append(_entry("k_obs_rows (bf16 dense)", f"{n} games", _time_us(lambda: env.get_obs_rows(torch.bfloat16, out=dense), reps=30), (704 + 3574 + 520) * n))
+    frac = float(sel.float().mean())
+    out.append(_entry("k_obs_rows (bf16 dense + rollout-storage rows of 1 game in 4)", f"{n} games",
+                      _time_us(lambda: env.get_obs_rows(torch.bfloat16, out=dense, rows=(st_f, st_l, st_n), t=t, sel=sel), reps=30),
+                      int((704 + 3574 + 520 + 9 + frac * (3574 + 130)) * n)))
+    del st_f, st_l, st_n
+    # ---- k_tile_encoder_fwd: 19 x 60 bf16 in (2 280 B), 19 x 25 bf16 out (950 B) per board; MFMA work per board: 19 tokens x
+    #      (64x64 + 2 x (64x192 + 64x64 + 64x128 + 128x64) + 64x32) MACs + 2 layers x 4 heads x 2 products of 32x32x16 (padded)
+    te = net.observation_module.tile_encoder
+    boards = rows_mb
+    tiles = (torch.rand(boards, 19, 60, device=dev, generator=g) < 0.1).to(torch.bfloat16)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        us = _time_us(lambda: nn_kernels.tile_encoder_forward(te, tiles), reps=5)
+    macs = 19 * (64 * 64 + 2 * (64 * 192 + 64 * 64 + 64 * 128 + 128 * 64) + 64 * 32) + 2 * 4 * 2 * 32 * 32 * 16
+    out.append(_entry("k_tile_encoder_fwd (whole tile encoder, inference)", f"{boards} boards", us, (2280 + 950) * boards, flops=2 * macs * boards,
+                      note="VALU / L2-latency bound (LayerNorm, softmax, epilogues), not HBM- or MFMA-bound: DESIGN.md 4.5 (iv)"))
+    del tiles
+    # ---- k_head_fwd: one action-head evaluation at rollout width: 128 bf16 in (256 B) + mask row (4 K B) + u in, action + logp out (12 B)
+    ahm = net.action_head_module
+    head = ahm.action_heads[2]                       # the road head: K = 73, no conditioning columns
+    pre_all = torch.randn(n, 1536, device=dev, generator=g).to(torch.bfloat16)
+    mask = torch.ones(n, 73, device=dev)
+    with torch.no_grad():
+        us = _time_us(lambda: nn_kernels.head_sample(head, ahm.D, pre_all[:, 256:384], None, mask, deterministic=True), reps=30)
+    out.append(_entry("k_head_fwd (LayerNorm + 128x128 + 128x73 + masked categorical)", f"{n} rows, K = 73", us, (256 + 4 * 73 + 12) * n,
+                      flops=2 * (128 * 128 + 128 * 80) * n, note="includes the Python wrapper's launch (two allocations): launch-bound at this size"))
+    del pre_all, mask
+    # ---- the hand-written kernels that lead the kernel trace of a minibatch step (tile encoder, 204 800 boards x 19 tokens)
+    tok = rows_mb * 19
+    qkv = torch.randn(rows_mb, 19, 3, 4, 16, device=dev, generator=g).to(torch.bfloat16).requires_grad_(True)
+    o = nn_kernels.small_attention(qkv)
+    go = torch.randn_like(o)
+    out.append(_entry("k_attn_mfma_fwd (19 x 19 attention, 4 heads x 16)", f"{rows_mb} sequences", _time_us(lambda: nn_kernels.small_attention(qkv.detach()), reps=5),
+                      (19 * 192 + 19 * 64) * 2 * rows_mb, flops=2 * 2 * 4 * 19 * 19 * 16 * rows_mb))
+    out.append(_entry("k_attn_mfma_bwd", f"{rows_mb} sequences", _time_us(lambda: torch.autograd.grad(o, qkv, go, retain_graph=True), reps=5),
+                      (19 * 192 * 2 + 19 * 64) * 2 * rows_mb, flops=2 * 5 * 4 * 19 * 19 * 16 * rows_mb, note="qkv and dout in, dqkv out; the probabilities are recomputed"))
+    del qkv, o, go
+    x64 = torch.randn(tok, 64, device=dev, generator=g).to(torch.bfloat16)
+    w = torch.randn(128, 64, device=dev, generator=g).to(torch.bfloat16); b = torch.zeros(128, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        us = _time_us(lambda: nn_kernels.linear_inference(x64, w, b), reps=5)
+    out.append(_entry("k_linear_rows (64 -> 128, the FFN's first product)", f"{tok} rows", us, (64 + 128) * 2 * tok, flops=2 * 64 * 128 * tok))
+    dy = torch.randn(tok, 128, device=dev, generator=g).to(torch.bfloat16)
+    out.append(_entry("k_wgrad_tr (dW = dY^T X, 128 x 64)", f"{tok} rows", _time_us(lambda: nn_kernels.wgrad(x64, dy), reps=5), (64 + 128) * 2 * tok, flops=2 * 64 * 128 * tok))
+    del dy, w, b
+    ln = torch.nn.LayerNorm(64).to(dev)
+    xg = x64.clone().requires_grad_(True)
+    y = nn_kernels.small_layer_norm(xg, ln, False)
+    gy = torch.randn_like(y)
+    out.append(_entry("k_lnw_fwd (LayerNorm 64)", f"{tok} rows", _time_us(lambda: nn_kernels.small_layer_norm(x64, ln, False), reps=5), 2 * 64 * 2 * tok))
+    out.append(_entry("k_lnw_bwd (LayerNorm 64)", f"{tok} rows", _time_us(lambda: torch.autograd.grad(y, xg, gy, retain_graph=True), reps=5), 3 * 64 * 2 * tok,
+                      note="x and dy in, dx out; weight / bias gradients are reduced per block"))
+    return out
