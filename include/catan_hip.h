@@ -64,7 +64,7 @@ int32_t catan_state_bytes_per_game(void); /* packed HBM bytes per game */
 int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, uint64_t env_id0, const catan_cfg_t* cfg);
 void catan_destroy(catan_env_t* env);
 const char* catan_last_error(void);
-/* The hash of the sources (csrc/*, include/catan_hip.h) this binary was built from, baked in by the build
+/* The hash of the sources (every file under csrc/, include/catan_hip.h) this binary was built from, baked in by the build
  * (settlers_of_catan_rl_amd/_lib.py: build_library / source_hash); the loader refuses a binary whose hash differs from
  * the sources beside it - the .so is kept out of git but shipped in-tree, and file times mean nothing after a checkout. */
 const char* catan_build_hash(void);

@@ -1,0 +1,184 @@
+/* catan_cpu_abi.c - libcatan_cpu.so: the env entry points of include/catan_hip.h implemented over the CPU
+ * oracle, with HOST pointers and the stream argument ignored.  TEST INFRASTRUCTURE and CPU baseline, like the rest of oracle/:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; nothing under settlers_of_catan_rl_amd/
+ * does.  It exists so that the same caller code (same struct, same call sequence, same buffers) can be run against the CPU
+ * restatement of the reference and against libcatan_hip.so, and the two compared buffer by buffer (tests/test_cpu_abi.py,
+ * tests/test_gpu_abi_errors.py).
+ * Semantics follow the device library: catan_step validates against the current masks when cfg.validate_actions (an illegal
+ * action leaves the game untouched, pays nothing and is counted), a negative action type is an explicit no-op, a finished game
+ * is reset inside the step when cfg.auto_reset.  Layouts: actions int32 [n][18], reward float [n][4], done uint8 [n], masks
+ * float [n][325], state blobs int32 [736][cnt] (word-major, as catan_state_export writes them). */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/catan_hip.h"
+#include "catan_oracle.h"
+
+struct catan_env {
+    int64_t n;
+    uint64_t seed, env_id0;
+    catan_cfg_t cfg;
+    OrcEnv* envs;
+    int64_t invalid;
+    double* reward64;
+};
+
+static _Thread_local const char* g_err = "";
+static int fail(int code, const char* msg) { g_err = msg; return code; }
+
+const char* catan_last_error(void) { return g_err; }
+const char* catan_build_hash(void) { return "cpu-oracle"; }
+void catan_cfg_default(catan_cfg_t* c) {
+    memset(c, 0, sizeof *c);
+    c->max_proposed_trades_per_turn = 4; c->win_reward = 500.0; c->dense_reward = 0; c->reward_annealing_factor = 1.0;
+    c->validate_actions = 1; c->auto_reset = 1; c->max_actions_per_turn = -1;
+}
+int32_t catan_state_words(void) { return ORC_STATE_WORDS; }
+int32_t catan_mask_words(void) { return ORC_MASK_WORDS; }
+int32_t catan_action_words(void) { return 18; }
+int32_t catan_obs_floats(void) { return 1787; }
+int32_t catan_state_bytes_per_game(void) { return (int32_t)sizeof(OrcEnv); }
+int64_t catan_num_envs(const catan_env_t* e) { return e ? e->n : 0; }
+
+static void apply_cfg(catan_env_t* e) {
+    for (int64_t i = 0; i < e->n; i++) {
+        orc_set_config(&e->envs[i], e->cfg.max_proposed_trades_per_turn, e->cfg.win_reward, e->cfg.dense_reward, e->cfg.reward_annealing_factor);
+        orc_set_max_actions_per_turn(&e->envs[i], e->cfg.max_actions_per_turn);
+    }
+}
+
+int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, uint64_t env_id0, const catan_cfg_t* cfg) {
+    (void)device;
+    if (!out || n_envs <= 0) return fail(CATAN_EINVAL, "catan_create: bad arguments");
+    catan_env_t* e = (catan_env_t*)calloc(1, sizeof *e);
+    if (!e) return fail(CATAN_ENOMEM, "catan_create: out of memory");
+    e->envs = (OrcEnv*)calloc((size_t)n_envs, sizeof(OrcEnv));
+    if (!e->envs) { free(e); return fail(CATAN_ENOMEM, "catan_create: out of memory"); }
+    e->n = n_envs; e->seed = seed; e->env_id0 = env_id0;
+    if (cfg) e->cfg = *cfg; else catan_cfg_default(&e->cfg);
+    orc_batch_create(e->envs, n_envs, seed, env_id0);      /* EnvWrapper() x n + reset() */
+    apply_cfg(e);
+    *out = e;
+    return CATAN_OK;
+}
+void catan_destroy(catan_env_t* e) { if (e) { free(e->envs); free(e); } }
+
+int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
+    (void)stream;
+    if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < e->n; i++) if (!reset_mask || reset_mask[i]) orc_game_reset(&e->envs[i]);
+    return CATAN_OK;
+}
+
+int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !actions || !reward || !done) return fail(CATAN_EINVAL, "catan_step: null argument");
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t i = 0; i < e->n; i++) {
+        const int32_t* a = actions + i * 18;
+        float* r = reward + i * 4;
+        r[0] = r[1] = r[2] = r[3] = 0.0f; done[i] = 0;
+        if (e->reward64) memset(e->reward64 + i * 4, 0, 4 * sizeof(double));
+        if (a[0] < 0) continue;                                           /* explicit no-op */
+        if (e->cfg.validate_actions && !orc_action_is_legal(&e->envs[i], a)) { bad++; continue; }
+        int d = 0;
+        orc_step(&e->envs[i], a, r, &d);
+        if (e->reward64) orc_last_reward64(&e->envs[i], e->reward64 + i * 4);
+        done[i] = (uint8_t)(d != 0);
+        if (d && e->cfg.auto_reset) orc_game_reset(&e->envs[i]);
+    }
+    e->invalid += bad;
+    return CATAN_OK;
+}
+
+int catan_masks(catan_env_t* e, float* out_masks, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !out_masks) return fail(CATAN_EINVAL, "catan_masks: null argument");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < e->n; i++) orc_masks(&e->envs[i], out_masks + i * ORC_MASK_WORDS);
+    return CATAN_OK;
+}
+
+int catan_deciding_seat(catan_env_t* e, int32_t* out, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_deciding_seat: null argument");
+    for (int64_t i = 0; i < e->n; i++) out[i] = orc_deciding_player(&e->envs[i]);
+    return CATAN_OK;
+}
+int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !out) return fail(CATAN_EINVAL, "catan_players_turn_sim: null argument");
+    for (int64_t i = 0; i < e->n; i++) out[i] = orc_players_turn_sim(&e->envs[i]);
+    return CATAN_OK;
+}
+
+int catan_obs(catan_env_t* e, float* out_f, int32_t* out_lists, int32_t* out_lens, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !out_f || !out_lists || !out_lens) return fail(CATAN_EINVAL, "catan_obs: null argument");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < e->n; i++) {
+        int32_t pid;
+        orc_obs(&e->envs[i], out_f + i * 1787, out_lists + i * 125, out_lens + i * 5, &pid);
+    }
+    return CATAN_OK;
+}
+
+int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !blob || cnt <= 0) return fail(CATAN_EINVAL, "catan_state_export: bad arguments");
+    int32_t tmp[ORC_STATE_WORDS];
+    for (int64_t k = 0; k < cnt; k++) {
+        const int64_t i = env_idx ? env_idx[k] : k;
+        if (i < 0 || i >= e->n) return fail(CATAN_EINVAL, "catan_state_export: game index out of range");
+        orc_export(&e->envs[i], tmp);
+        for (int w = 0; w < ORC_STATE_WORDS; w++) blob[(int64_t)w * cnt + k] = tmp[w];
+    }
+    return CATAN_OK;
+}
+int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !blob || cnt <= 0) return fail(CATAN_EINVAL, "catan_state_import: bad arguments");
+    int32_t tmp[ORC_STATE_WORDS];
+    for (int64_t k = 0; k < cnt; k++) {
+        const int64_t i = env_idx ? env_idx[k] : k;
+        if (i < 0 || i >= e->n) return fail(CATAN_EINVAL, "catan_state_import: game index out of range");
+        for (int w = 0; w < ORC_STATE_WORDS; w++) tmp[w] = blob[(int64_t)w * cnt + k];
+        orc_import(&e->envs[i], tmp);
+    }
+    return CATAN_OK;
+}
+
+int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
+    for (int64_t i = 0; i < e->n; i++)
+        if (controlling_player[i] >= 1 && controlling_player[i] <= 4) orc_randomise_uncertainty(&e->envs[i], controlling_player[i]);
+    return CATAN_OK;
+}
+
+int catan_set_reward_annealing(catan_env_t* e, double factor) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_reward_annealing: null handle");
+    e->cfg.reward_annealing_factor = factor;
+    apply_cfg(e);
+    return CATAN_OK;
+}
+int catan_set_reward_f64_buffer(catan_env_t* e, double* reward64) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_reward_f64_buffer: null handle");
+    e->reward64 = reward64;
+    return CATAN_OK;
+}
+int64_t catan_invalid_action_count(catan_env_t* e, catan_stream_t stream) { (void)stream; return e ? e->invalid : -1; }
+
+int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < e->n; i++) {
+        float m[ORC_MASK_WORDS];
+        orc_masks(&e->envs[i], m);
+        orc_sample_action(&e->envs[i], e->seed, e->env_id0 + (uint64_t)i, step_idx, m, actions + i * 18);
+    }
+    return CATAN_OK;
+}

@@ -36,3 +36,39 @@ def test_no_device_fails_loudly():
     h = C.c_void_p()
     rc = L.catan_create(C.byref(h), 0, 4, 0, 0, None)
     assert rc != 0 and b"no HIP device" in L.catan_last_error()
+
+
+def test_libcatan_cpu_exports_the_env_abi_and_equals_the_oracle_batch(oracle):
+    """oracle/libcatan_cpu.so (the same C ABI over host pointers, implemented on the CPU oracle): every env entry
+    point is exported with the header's name, and a caller that only uses the ABI - sampled actions, a no-op, illegal actions -
+    ends in the states `OracleBatch` reaches when it is fed the same accepted actions."""
+    import cpu_abi_driver as drv
+    import numpy as np
+    L = drv.cpu_lib()
+    hdr = open(os.path.join(ROOT, "include", "catan_hip.h")).read()
+    for name in drv.ENTRY_POINTS:
+        assert hasattr(L, name) and re.search(r"\b" + name + r"\s*\(", hdr), name
+    n, seed, steps = 96, 5, 400
+    out = drv.drive(L, n, seed, steps, lambda s, d: drv.HostBuf(s, d), lambda b: b.a)
+    assert out["invalid"] > 0 and out["done"].sum() >= 0
+    # replay on the oracle batch API: same sampler, same corruption rule
+    import ctypes as C
+    b = oracle.OracleBatch(n, seed, env_id0=1000)
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    for t in range(steps):
+        m = b.masks()
+        for i in range(n):
+            a = np.zeros(18, dtype=np.int32)
+            b.L.orc_sample_action(b.env_ptr(i), seed, 1000 + i, t, m[i].ctypes.data_as(f32p), a.ctypes.data_as(i32p))
+            if t % 7 == 6:
+                if i < max(1, n // 4): a[0] = 9 if t % 2 else 10
+                if i == 1: a[0] = -1
+            if a[0] < 0 or not b.L.orc_action_is_legal(b.env_ptr(i), a.ctypes.data_as(i32p)):
+                continue
+            r = np.zeros(4, dtype=np.float32); d = C.c_int(0)
+            b.L.orc_step(b.env_ptr(i), a.ctypes.data_as(i32p), r.ctypes.data_as(f32p), C.byref(d))
+            assert np.array_equal(r, out["rew"][t][i]) and bool(d.value) == bool(out["done"][t][i])
+            if d.value:
+                b.L.orc_game_reset(b.env_ptr(i))
+    assert np.array_equal(b.export(), out["blob"].T)
+    assert np.array_equal(b.masks(), out["masks_after_import"])

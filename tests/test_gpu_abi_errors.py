@@ -38,3 +38,25 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     # the handle is still usable after the failed calls
     env.random_rollout_deferred(40, 8)
     assert env.invalid_action_count() == 0
+
+
+def test_same_caller_on_libcatan_hip_and_libcatan_cpu(hip_lib):
+    """One caller (tests/cpu_abi_driver.py) drives the env entry points of include/catan_hip.h through ctypes - create, sampled
+    actions with illegal ones and a no-op mixed in, step, deciding seat, masks, observations, state export / import - once on
+    libcatan_hip.so with device buffers and once on oracle/libcatan_cpu.so (the same ABI over the CPU oracle) with host buffers:
+    every buffer the calls fill is identical, step by step (rewards, done flags, deciding seats, masks) and at the end
+    (observations, card lists, exported states, the rejected-action count, the masks after importing the states)."""
+    import numpy as np
+    import cpu_abi_driver as drv
+    from settlers_of_catan_rl_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    tdt = {np.int32: torch.int32, np.float32: torch.float32, np.uint8: torch.uint8}
+    for dense in (False, True):
+        n, seed, steps = 256, 9, 900
+        dev = drv.drive(_lib.lib(), n, seed, steps, lambda s, d: torch.zeros(s, dtype=tdt[d], device="cuda"),
+                        lambda b: (torch.cuda.synchronize(), b.cpu().numpy())[1], stream=st, dense=dense)
+        cpu = drv.drive(drv.cpu_lib(), n, seed, steps, lambda s, d: drv.HostBuf(s, d), lambda b: b.a, dense=dense)
+        assert dev["invalid"] == cpu["invalid"] > 0
+        for k in ("rew", "done", "seat", "masks_crc", "obs", "lists", "lens", "blob", "masks_after_import"):
+            assert np.array_equal(dev[k], cpu[k]), (dense, k)
+        assert dev["done"].sum() > 0
