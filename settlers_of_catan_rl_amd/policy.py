@@ -50,6 +50,28 @@ def _lin(x, w, b=None):
     return F.linear(x, w, b)
 
 
+def _lin_parts(parts, w, b):
+    """Linear over the concatenation of `parts` along the last dim WITHOUT the concatenation: y = sum_k parts[k] @ W[:, cols_k].T
+    + b (the reference concatenates - player_modules.py:66-69,109-111, observation_module.py:58-60 - and multiplies once: the
+    same sums in another order).  Training on the GPU only: the concatenated widths (281, 306, 987) are not multiples of 8, so
+    their weight gradients - tall-skinny products over 2 x 10^5..6 x 10^5 rows - went to the library at 0.6-0.8 ms each; the
+    parts (256 / 128 / 384 / 25 wide) take the hand-written k_wgrad, and the concatenation's copy and its backward split go away."""
+    ok, c = False, 0
+    if torch.is_grad_enabled() and parts[0].is_cuda:
+        for x in parts:
+            ok = ok or nn_kernels.linear_supported(x, w[:, c:c + x.shape[-1]])
+            c += x.shape[-1]
+    if not ok:
+        return F.linear(torch.cat(parts, -1), w, b)
+    y, c = None, 0
+    for k, x in enumerate(parts):
+        n = x.shape[-1]
+        t = _lin(x, w[:, c:c + n], b if k == 0 else None)
+        y = t if y is None else y + t
+        c += n
+    return y
+
+
 def _ln(ln, x, relu=False):
     """LayerNorm (+ optional ReLU): the fused HIP kernel for the small widths on the GPU, torch otherwise."""
     if nn_kernels.ln_supported(x, ln):
@@ -198,7 +220,7 @@ class _CurrentPlayer(nn.Module):
         h = _ln(self.norm_2, _lin(_card_summary(hid, hid_len, emb, hid_mha, self.norm), self.proj_hidden_dev_card.weight, self.proj_hidden_dev_card.bias), relu=True)
         p = _ln(self.norm_3, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
         m = _ln(self.norm_1, _lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias), relu=True)
-        return _ln(self.norm_4, self.final_linear_layer(torch.cat((m, p, h), -1)), relu=True)
+        return _ln(self.norm_4, _lin_parts((m, p, h), self.final_linear_layer.weight, self.final_linear_layer.bias), relu=True)
 
 
 class _OtherPlayers(nn.Module):
@@ -215,7 +237,7 @@ class _OtherPlayers(nn.Module):
     def forward(self, main, played, played_len, emb, played_mha):
         p = _ln(self.norm_2, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
         m = _ln(self.norm_1, _lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias), relu=True)
-        return _ln(self.norm_3, self.final_linear_layer(torch.cat((m, p), -1)), relu=True)
+        return _ln(self.norm_3, _lin_parts((m, p), self.final_linear_layer.weight, self.final_linear_layer.bias), relu=True)
 
 
 class _ObservationModule(nn.Module):
@@ -247,7 +269,7 @@ class _ObservationModule(nn.Module):
         op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
                                        self.dev_card_embedding, self.played_card_mha)
         br.join()
-        return _ln(self.norm, self.final_layer(torch.cat([te, cp, op.reshape(B, 3 * 128)], -1)), relu=True)
+        return _ln(self.norm, _lin_parts((te, cp, op.reshape(B, 3 * 128)), self.final_layer.weight, self.final_layer.bias), relu=True)
 
 
 class _Dist(nn.Module):
@@ -454,7 +476,7 @@ class _ActionHeads(nn.Module):
     def _evaluate_compact(self, main, m, cur_res, trade, actions, grouping=None):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
         typ, card = actions[:, 0], actions[:, 4]
-        pre_of = lambda i, x: F.linear(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
+        pre_of = lambda i, x: _lin(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
         _, logp0, e0 = _categorical(H[0].logits(pre_of(0, main)), m[:, MO[0]:MO[0] + 13], typ, False, None)
         # one sort by (type, card of a played development card) and one host read give every head's rows
         perm, ends, ev = grouping if grouping is not None else self.start_grouping(actions)
@@ -762,7 +784,7 @@ class CatanPolicy(nn.Module):
                 nonterminal = torch.ones(main.shape[0], device=main.device)
             out, hidden = self._forward_lstm(main, hidden, nonterminal)
             main = torch.cat((main, out), -1)
-        v = _lin(_ln(self.v_norm_2, self.value_network_fc_2(_ln(self.v_norm_1, self.value_network_fc_1(main), relu=True)), relu=True),
+        v = _lin(_ln(self.v_norm_2, _lin(_ln(self.v_norm_1, _lin(main, self.value_network_fc_1.weight, self.value_network_fc_1.bias), relu=True), self.value_network_fc_2.weight, self.value_network_fc_2.bias), relu=True),
                  self.value_out.weight, self.value_out.bias)
         return v.float(), main, hidden
 

@@ -223,8 +223,9 @@ def test_policy_grads_with_wgrad_kernel_match_library_path(hip_lib, monkeypatch)
     g1 = grads(True)
     g0 = grads(False)
     assert g0.keys() == g1.keys()
-    for k in g0:
-        den = float(g0[k].norm()) + 1e-6
+    floor = 1e-3 * max(float(g.norm()) for g in g0.values())     # (the key bias of an attention has a ZERO true gradient - the softmax
+    for k in g0:                                                 #  ignores a constant added to every score: pure bf16 noise on both sides)
+        den = float(g0[k].norm()) + floor
         assert float((g1[k] - g0[k]).norm()) / den < 5e-2, k     # bf16 activations; the kernel path keeps dw in fp32
 
 
