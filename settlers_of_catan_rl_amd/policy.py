@@ -252,14 +252,16 @@ class _ObservationModule(nn.Module):
         self.final_layer = _ortho_linear(19 * 25 + 4 * 128, 512)
         self.norm = nn.LayerNorm(512)
 
-    def forward(self, obs_f, lists, lens):
+    def forward(self, obs_f, lists, lens, tile_features=None):
+        """tile_features [B, 475]: the tile encoder's output for these rows, computed by the caller (the value re-evaluation of a
+        PPO update encodes every DISTINCT board once: nine in ten consecutive observations of a game show the same board)"""
         o = spec.OBS_FLOAT_OFFSETS
         B = obs_f.shape[0]
         tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
         cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
         br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
         with br.on(1):
-            te = br.keep(self.tile_encoder(tiles))
+            te = br.keep(self.tile_encoder(tiles) if tile_features is None else tile_features)
         with br.on(2):
             cp = br.keep(self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
                                                     self.hidden_card_mha, self.played_card_mha))
@@ -774,9 +776,9 @@ class CatanPolicy(nn.Module):
         out = outs[0] if T == 1 else torch.stack(outs, 0).reshape(R, L)
         return out.to(x.dtype), (h, c)
 
-    def base(self, obs_f, lists, lens, hidden=None, nonterminal=None):
+    def base(self, obs_f, lists, lens, hidden=None, nonterminal=None, tile_features=None):
         """-> (value [B,1] fp32, main [B,512(+lstm_size)], hidden or None)   (policy.py:59-66)"""
-        main = self.observation_module(obs_f, lists, lens)
+        main = self.observation_module(obs_f, lists, lens, tile_features)
         if self.include_lstm:
             if hidden is None:
                 raise ValueError("include_lstm: hidden=(h, c) and nonterminal are required")
@@ -810,8 +812,8 @@ class CatanPolicy(nn.Module):
         _, logp, entropy = ahm(main, masks.float(), cur_res, trade, actions, grouping=grouping)
         return (value, logp[:, None], entropy, hidden) if self.include_lstm else (value, logp[:, None], entropy)
 
-    def get_value(self, obs_f, lists, lens, hidden=None, nonterminal=None):
-        return self.base(obs_f, lists, lens, hidden, nonterminal)[0]
+    def get_value(self, obs_f, lists, lens, hidden=None, nonterminal=None, tile_features=None):
+        return self.base(obs_f, lists, lens, hidden, nonterminal, tile_features)[0]
 
     def inference_copy(self, dtype=torch.bfloat16):
         """A no-grad copy for acting under `torch.autocast(dtype)`: the Linear / LSTM / embedding parameters are stored in

@@ -36,6 +36,7 @@ class RolloutStorage(object):
         self.action_log_probs = torch.zeros((T, N), dtype=torch.float32, device=device)
         self.action_masks = torch.zeros((T, N, 11), dtype=torch.int32, device=device)   # packed 325-bit masks
         self.games_complete = 0
+        self.generation = 0           # bumped by every gather_rollouts (consumers cache per-rollout derived data on it)
 
     def unpack_action_masks(self, packed):
         """int32 [..., 11] -> float32 [..., 325]"""
@@ -257,6 +258,7 @@ class RolloutCollector(object):
                                           torch.where(done & live, torch.ones_like(self.done_since), self.done_since))
             self.pending_obs = next_active
         st.games_complete += int(n_complete)
+        st.generation += 1
         self.iters = int(n_live_iters) if max_iters is None else iters
         return st
 

@@ -83,6 +83,30 @@ class PPOTrainer(object):
             return torch.autocast(device_type="cuda", enabled=False)
         return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
 
+    dedupe_boards = True          # value re-evaluation: run the tile encoder once per DISTINCT board of a game's stored observations
+
+    @torch.no_grad()
+    def board_runs(self, st):
+        """For the stored observations [T+1, N]: which rows show a board (tile features: robber, buildings, relative owners) that
+        differs from the game's previous stored observation - the only rows the tile encoder has to see - and, for every row, the
+        position of its board in that list.  Under self-play with one active seat per game nine in ten consecutive observations
+        repeat the board (trades, dice, development cards, end of turn do not touch it).  Computed once per update (the storage
+        does not change between the epochs).  -> (first_rows int64 [U], board_of_row int64 [(T+1) N])"""
+        from . import spec
+        T1, N = st.obs_f.shape[0], st.obs_f.shape[1]
+        o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+        tiles = st.obs_f[:, :, o:o + 1140]
+        new = torch.ones((T1, N), dtype=torch.bool, device=tiles.device)
+        for t0 in range(1, T1, 16):                            # (chunked: the comparison materialises a [t, N, 1140] mask)
+            t1 = min(T1, t0 + 16)
+            new[t0:t1] = (tiles[t0:t1] != tiles[t0 - 1:t1 - 1]).any(-1)
+        flat = new.reshape(-1)
+        first_rows = flat.nonzero(as_tuple=True)[0]
+        uid = torch.cumsum(flat.long(), 0) - 1                              # position in first_rows, valid where `new`
+        uid = torch.where(flat, uid, torch.full_like(uid, -1)).reshape(T1, N)
+        board_of_row = torch.cummax(uid, 0).values.reshape(-1)              # the last new board at or before t, per game
+        return first_rows, board_of_row
+
     @torch.no_grad()
     def compute_values(self, st):
         """process_batch.py:108-132: V(obs) for all (T+1)*N observations, denormalised (RL/models/utils.py:20-21)."""
@@ -91,6 +115,23 @@ class PPOTrainer(object):
         out = torch.empty((T1 * N,), dtype=torch.float32, device=f.device)
         ch = self.cfg.value_chunk
         rec = getattr(self.policy, "include_lstm", False)
+        cast = (lambda x: x) if (self.autocast_dtype is not None and f.dtype == self.autocast_dtype) else (lambda x: x.float())
+        te_u = board_of_row = None
+        if self.dedupe_boards and not rec and f.is_cuda and hasattr(self.policy, "observation_module"):
+            from . import spec
+            key = (st.obs_f.data_ptr(), getattr(st, "generation", None), T1, N)
+            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None:
+                self._runs = self.board_runs(st)                # once per rollout: the storage does not change between the epochs
+                self._runs_key = key
+            first_rows, board_of_row = self._runs
+            o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+            tiles_all = f[:, o:o + 1140]
+            for s in range(0, first_rows.numel(), ch):          # the tile encoder on the distinct boards only
+                with self._autocast():
+                    part = self.policy.observation_module.tile_encoder(cast(tiles_all[first_rows[s:s + ch]]).reshape(-1, 19, 60))
+                if te_u is None:
+                    te_u = torch.empty((first_rows.numel(), part.shape[1]), dtype=part.dtype, device=part.device)
+                te_u[s:s + ch] = part
         if rec:
             hid = st.hidden[:, :T1].reshape(2, T1 * N, -1); nt = st.masks[:T1].reshape(T1 * N)
         cast = (lambda x: x) if (self.autocast_dtype is not None and f.dtype == self.autocast_dtype) else (lambda x: x.float())
@@ -99,6 +140,8 @@ class PPOTrainer(object):
                 if rec:
                     v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(),
                                               (hid[0, s:s + ch], hid[1, s:s + ch]), nt[s:s + ch])
+                elif te_u is not None:
+                    v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(), tile_features=te_u[board_of_row[s:s + ch]])
                 else:
                     v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long())
             out[s:s + ch] = v[:, 0]

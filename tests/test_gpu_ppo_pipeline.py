@@ -798,3 +798,34 @@ def test_card_summary_pattern_table_lookup(hip_lib):
     with torch.no_grad():
         looked = P._card_summary(odd, ln, om.dev_card_embedding, om.played_card_mha, om.current_player_module.norm)
     assert torch.allclose(looked, direct.detach(), rtol=1e-5, atol=1e-5)
+
+
+def test_value_reevaluation_encodes_distinct_boards_only(hip_lib):
+    """PPOTrainer.compute_values runs the tile encoder once per DISTINCT board of a game's stored observations (consecutive
+    observations of the active seat mostly show the same board): the same values, bit for bit, as encoding every row; and the
+    run bookkeeping: the first row of every run really starts a new board, every other row repeats its predecessor's."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    torch.manual_seed(0)
+    N, T = 2048, 24
+    env = VecCatanEnv(N, seed=15); env.random_rollout(0, 900)
+    net = CatanPolicy().cuda()
+    col = RolloutCollector(env, net, T, seed=2, autocast_dtype=torch.bfloat16)
+    tr = PPOTrainer(net, PPOConfig(value_chunk=8192), autocast_dtype=torch.bfloat16, seed=0)
+    for rnd in range(2):
+        st = col.gather_rollouts()
+        first_rows, board_of_row = tr.board_runs(st)
+        o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+        tiles = st.obs_f.reshape((T + 1) * N, -1)[:, o:o + 1140]
+        assert torch.equal(tiles[first_rows[board_of_row]], tiles)                 # every row's board is the one it points to
+        frac = first_rows.numel() / tiles.shape[0]
+        assert 0.02 < frac < 0.6, frac                                             # most rows repeat a board
+        tr.dedupe_boards = True
+        v1 = tr.compute_values(st)
+        tr.dedupe_boards = False
+        v0 = tr.compute_values(st)
+        tr.dedupe_boards = True
+        assert torch.equal(v1, v0)
+        col.after_rollouts()
