@@ -18,7 +18,7 @@ tr = PPOTrainer(net, PPOConfig(ppo_epoch=1, num_mini_batch=64), autocast_dtype=t
 class Stop(Exception): pass
 calls = [0]
 orig = tr.optimiser.step
-prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True)
 NS = 4
 def step(*a, **k):
     r = orig(*a, **k)
@@ -41,3 +41,9 @@ ops = [e for e in ev if not (e.device_type is not None and str(e.device_type).en
 ops.sort(key=lambda e: -e.self_device_time_total)
 for e in ops[:40]:
     print("%-40s dev %8.1f us/step  cpu %8.1f us/step  x%.0f" % (e.key[:40], e.self_device_time_total / NS, e.self_cpu_time_total / NS, e.count / NS))
+
+print("---- copies / fills / gathers by shape (device us per step)")
+by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::fill_", "aten::index", "aten::cat", "aten::add_", "aten::add")]
+by.sort(key=lambda e: -e.self_device_time_total)
+for e in by[:40]:
+    print("%-14s %8.1f us/step x%.0f  %s" % (e.key, e.self_device_time_total / NS, e.count / NS, str(e.input_shapes)[:150]))
