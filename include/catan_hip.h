@@ -298,6 +298,19 @@ int32_t catan_head_weight_elems(void);
 int32_t catan_head_vec_elems(void);
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,
                    int32_t K, const float* mask, int64_t mask_ld, const float* u, int64_t* action, float* logp, int64_t B, catan_stream_t stream);
+/* The same kernel with the autoregressive glue of the twelve heads inside ("chained"): which mask row of the env's [B][325] mask
+ * matrix applies (type-conditional rows of heads 1, 6, 9: build_agent_model.py:113-124), the conditioning columns (action type,
+ * played card, first resource, the trade heads' running lists; head 5: custom_mlp + LayerNorm + ReLU of proposed_trade), whether
+ * the head enters the joint log-prob (log_prob_masks, build_agent_model.py:132-147), the recurrent give / receive lists with
+ * their hand bookkeeping (action_heads_module.py:258-329).  A policy pass is twenty calls in the order head 0; 1, 2, 3; 5, 6, 11;
+ * 4, 9, 10; 7 (steps 0..3); 8 (steps 0..3), handing `state` (float [B][catan_head_state_floats()], zeroed by the caller) on;
+ * every call fills its columns of `actions` (int64 [B][18]); the last one writes the joint log-prob to logp_out.
+ * custom (head 5): float [480] = custom_mlp W [32][12], b [32], custom_norm weight [32], bias [32]; forced (head 0): int64 [B],
+ * entries >= 0 replace the sampled type (condition_on_action_type) or NULL; u: this evaluation's uniforms or NULL (arg-max). */
+int32_t catan_head_state_floats(void);
+int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const float* vec, float eps, int32_t head_id, int32_t step, float* state,
+                     const float* maskmat, const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* u,
+                     int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream);
 
 /* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
  * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card

@@ -893,6 +893,18 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
     }
 }
 
+static int head_launch(const HeadArgs& a, hipStream_t st) {
+    const dim3 grid(blocks(a.B, HD_ROWS));
+    switch ((a.K + 15) / 16) {
+    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(256), 0, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,
@@ -904,17 +916,29 @@ int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t c
     a.pre = (const unsigned short*)pre; a.pre_ld = pre_ld; a.cond = cond; a.cond_ld = cond_ld; a.ncond = ncond;
     a.wts = (const unsigned short*)wts; a.vec = vec; a.eps = eps; a.K = K; a.mask = mask; a.mask_ld = mask_ld; a.u = u;
     a.action = (long long*)action; a.logp = logp; a.B = B;
-    const dim3 grid(blocks(B, HD_ROWS));
-    switch ((K + 15) / 16) {
-    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(256), 0, S(stream), a); break;
-    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(256), 0, S(stream), a); break;
-    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(256), 0, S(stream), a); break;
-    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(256), 0, S(stream), a); break;
-    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(256), 0, S(stream), a); break;
-    }
-    HIPCHK(hipGetLastError());
-    return CATAN_OK;
+    a.state = nullptr; a.head_id = 0; a.step = 0; a.maskmat = nullptr; a.cur_res = nullptr; a.trade = nullptr; a.custom = nullptr;
+    a.forced = nullptr; a.actions = nullptr; a.logp_out = nullptr;
+    return head_launch(a, S(stream));
 }
+
+int32_t catan_head_state_floats(void) { return HD_STATE; }
+int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const float* vec, float eps, int32_t head_id, int32_t step, float* state,
+                     const float* maskmat, const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* u,
+                     int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream) {
+    static const int KS[12] = { 13, 54, 73, 19, 5, 2, 3, 6, 6, 5, 5, 5 }, NC[12] = { 0, 2, 0, 0, 0, 32, 2, 6, 12, 4, 9, 0 };
+    if (!pre || !wts || !vec || !state || !maskmat || !cur_res || !actions || !logp_out || B <= 0 || head_id < 0 || head_id > 11 || step < 0 || step > 3 ||
+        ((head_id != 7 && head_id != 8) && step != 0) || (head_id == 5 && (!trade || !custom)) || pre_ld % 8 != 0 || ((uintptr_t)pre & 15) != 0 ||
+        ((uintptr_t)state & 15) != 0)
+        return fail(CATAN_EINVAL, "catan_head_chain: bad arguments");
+    HeadArgs a;
+    a.pre = (const unsigned short*)pre; a.pre_ld = pre_ld; a.cond = nullptr; a.cond_ld = 0; a.ncond = NC[head_id];
+    a.wts = (const unsigned short*)wts; a.vec = vec; a.eps = eps; a.K = KS[head_id]; a.mask = nullptr; a.mask_ld = 0; a.u = u;
+    a.action = nullptr; a.logp = nullptr; a.B = B;
+    a.state = state; a.head_id = head_id; a.step = step; a.maskmat = maskmat; a.cur_res = cur_res; a.trade = trade; a.custom = custom;
+    a.forced = (const long long*)forced; a.actions = (long long*)actions; a.logp_out = logp_out;
+    return head_launch(a, S(stream));
+}
+
 
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");

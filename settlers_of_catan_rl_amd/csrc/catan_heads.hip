@@ -30,6 +30,8 @@ constexpr int HD_KP = 80;                // output columns, padded (73 road edge
 constexpr int HD_WELEMS = 128 * 128 + HD_KP * 128 + HD_NCP * 128;      // packed bf16: W2 [128][128], W3 [80][128], W1e^T [32][128]
 constexpr int HD_VELEMS = 128 * 3 + HD_KP;                             // packed fp32: ln_w, ln_b, b2 [128] each, b3 [80]
 
+DEVI float hd_bf(float v) { return te_bf(te_to_bf(v)); }
+
 struct HeadArgs {
     const unsigned short* pre; long pre_ld;      // bf16 [B][.. 128 ..]: this head's columns of the shared trunk product (bias included)
     const float* cond; long cond_ld; int ncond;  // float [B][ncond] conditioning columns that follow the trunk in mlp_1's input, or null
@@ -38,9 +40,143 @@ struct HeadArgs {
     const float* mask; long mask_ld;             // float [B][K] (a column window of the mask matrix is fine)
     const float* u;                              // uniform per row (inverse-CDF sample) or null (arg-max)
     long long* action; float* logp; long B;
+    // ---- chained mode (state != null): the autoregressive glue of the twelve heads (which mask row, which conditioning
+    // columns, whether the head counts towards the joint log-prob, the trade heads' running hand) happens in the kernel, from a
+    // small per-row state that the twenty evaluations of a policy pass hand on to each other; cond / mask / action / logp above
+    // are unused then.  Restates RL/models/build_agent_model.py:113-147 + action_heads_module.py:66-179,258-329 per row.
+    float* state;                                // [B][HD_STATE]
+    int head_id, step;                           // head 0..11; step 0..3 of the recurrent trade heads 7 / 8
+    const float* maskmat;                        // float [B][325]: the env's masks
+    const float* cur_res;                        // float [B][6]: current_resources (index 0 unused)
+    const float* trade;                          // float [B][12]: proposed_trade (head 5)
+    const float* custom;                         // head 5: custom_mlp W [32][12], b [32], custom_norm w [32], b [32] (bf16-rounded W, b)
+    const long long* forced;                     // head 0: rows with a value >= 0 take that type (condition_on_action_type) or null
+    long long* actions;                          // int64 [B][18]
+    float* logp_out;                             // [B]: the joint log-prob, written by the last evaluation (head 8, step 3)
 };
+constexpr int HD_STATE = 32;                     // floats per row
+// state slots
+constexpr int HS_TYP = 0, HS_CARD = 1, HS_RA = 2, HS_CNT9 = 3, HS_TOTAL = 4, HS_LPSUM = 5, HS_PREV = 6, HS_FILT7 = 7, HS_OUT = 8, HS_RES = 14, HS_GIVE = 20;
 
-DEVI float hd_bf(float v) { return te_bf(te_to_bf(v)); }
+// what a row's evaluation of head `h` needs: its mask (K floats -> mk), its conditioning columns (-> cd) and the factor its
+// log-prob enters the joint log-prob with (log_prob_masks, build_agent_model.py:132-147).  One lane per row.
+DEVI float hd_glue(const HeadArgs& a, long row, float* st, float* mk, float* cd) {
+    const float* mm = a.maskmat + row * 325;
+    const int h = a.head_id;
+    const int typ = (int)st[HS_TYP], card = (int)st[HS_CARD];
+    auto is = [&](int t) { return typ == t ? 1.0f : 0.0f; };
+    switch (h) {
+    case 0: for (int k = 0; k < 13; k++) mk[k] = mm[M0 + k]; return 1.0f;
+    case 1: {                                                              // corner: settlement row, city row or the dummy row
+        const int r = typ == T_SETTLE ? 0 : (typ == T_CITY ? 1 : 2);
+        for (int k = 0; k < 54; k++) mk[k] = mm[M1 + 54 * r + k];
+        cd[0] = is(T_SETTLE); cd[1] = is(T_CITY);
+        return is(T_SETTLE) + is(T_CITY);
+    }
+    case 2: for (int k = 0; k < 73; k++) mk[k] = mm[M2 + k]; return is(T_ROAD);
+    case 3: for (int k = 0; k < 19; k++) mk[k] = mm[M3 + k]; return is(T_ROBBER);
+    case 4: for (int k = 0; k < 5; k++) mk[k] = mm[M4 + k]; return is(T_PLAYDEV);
+    case 5: {                                                              // accept / reject: conditioned on the offer (custom_mlp + LayerNorm + ReLU)
+        for (int k = 0; k < 2; k++) mk[k] = mm[M5 + k];
+        const float* tr = a.trade + row * 12;
+        float t[32], mean = 0.0f, var = 0.0f;
+        for (int o = 0; o < 32; o++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 12; k++) acc += a.custom[o * 12 + k] * hd_bf(tr[k]);
+            t[o] = hd_bf(acc + a.custom[384 + o]);
+            mean += t[o];
+        }
+        mean *= 1.0f / 32.0f;
+        for (int o = 0; o < 32; o++) var += (t[o] - mean) * (t[o] - mean);
+        const float rstd = rsqrtf(var * (1.0f / 32.0f) + a.eps);
+        for (int o = 0; o < 32; o++) cd[o] = hd_bf(fmaxf((t[o] - mean) * rstd * a.custom[416 + o] + a.custom[448 + o], 0.0f));
+        return is(T_RESPOND);
+    }
+    case 6: {                                                              // relative player: propose row, steal row or the dummy row
+        const int r = typ == T_PROPOSE ? 0 : (typ == T_STEAL ? 1 : 2);
+        for (int k = 0; k < 3; k++) mk[k] = mm[M6 + 3 * r + k];
+        cd[0] = is(T_PROPOSE); cd[1] = is(T_STEAL);
+        return is(T_PROPOSE) + is(T_STEAL);
+    }
+    case 9: case 10: {                                                     // resource A / B of an exchange, Year of Plenty or Monopoly
+        const bool playdev = typ == T_PLAYDEV;
+        cd[0] = is(T_PLAYDEV); cd[1] = is(T_EXCHANGE);
+        cd[2] = (playdev && card == C_YOP) ? 1.0f : 0.0f; cd[3] = (playdev && card == C_MONO) ? 1.0f : 0.0f;
+        const float base = is(T_PLAYDEV) + is(T_EXCHANGE);
+        if (h == 9) {
+            const int rt = typ == T_EXCHANGE ? 0 : 1, rc = card == C_MONO ? 2 : (card == C_YOP ? 3 : 1);
+            for (int k = 0; k < 5; k++) mk[k] = mm[M9 + 5 * rt + k] * (playdev ? mm[M9 + 5 * rc + k] : 1.0f);
+            return base * (playdev ? ((card == C_YOP || card == C_MONO) ? 1.0f : 0.0f) : 1.0f);
+        }
+        for (int k = 0; k < 5; k++) mk[k] = mm[M10 + k];
+        const int ra = (int)st[HS_RA];
+        for (int k = 0; k < 5; k++) cd[4 + k] = (k == ra && st[HS_CNT9] != 0.0f) ? 1.0f : 0.0f;
+        return base * (playdev ? (card == C_YOP ? 1.0f : 0.0f) : 1.0f);
+    }
+    case 11: for (int k = 0; k < 5; k++) mk[k] = mm[M11 + k]; return is(T_DISCARD);
+    default: {                                                             // 7: give list (from the hand), 8: receive list; four steps each
+        const bool from_hand = h == 7;
+        if (a.step == 0) {
+            float tot = 0.0f;
+            for (int k = 0; k < 6; k++) { st[HS_OUT + k] = 0.0f; st[HS_RES + k] = a.cur_res[row * 6 + k]; tot += st[HS_RES + k]; }
+            st[HS_LPSUM] = 0.0f; st[HS_PREV] = 1.0f;
+            for (int k = 0; k < 6; k++) mk[k] = from_hand ? (st[HS_RES + k] > 0.0f ? 1.0f : 0.0f) : 1.0f;
+            mk[0] = tot == 0.0f ? 1.0f : 0.0f;
+        } else {
+            for (int k = 0; k < 6; k++) mk[k] = from_hand ? (st[HS_RES + k] > 0.0f ? 1.0f : 0.0f) : 1.0f;
+            mk[0] = 1.0f;
+        }
+        if (from_hand) { for (int k = 0; k < 6; k++) cd[k] = st[HS_OUT + k]; }
+        else { for (int k = 0; k < 6; k++) { cd[k] = st[HS_GIVE + k] * (1.0f - st[HS_FILT7]); cd[6 + k] = st[HS_OUT + k]; } }
+        return 1.0f;
+    }
+    }
+}
+// after the row's action `act` with log-prob `lp` is known: the action column(s), the joint log-prob, the state for the next heads
+DEVI void hd_commit(const HeadArgs& a, long row, float* st, int act, float lp, float count) {
+    long long* out = a.actions + row * 18;
+    const int h = a.head_id;
+    auto add = [&](float v) { st[HS_TOTAL] += count != 0.0f ? v * count : 0.0f; };
+    switch (h) {
+    case 0: {
+        int typ = act; float l = lp;
+        if (a.forced != nullptr && a.forced[row] >= 0) { typ = (int)a.forced[row]; l = 0.0f; }
+        st[HS_TYP] = (float)typ; st[HS_TOTAL] = l; out[0] = typ;
+        return;
+    }
+    case 1: out[1] = act; add(lp); return;
+    case 2: out[2] = act; add(lp); return;
+    case 3: out[3] = act; add(lp); return;
+    case 4: out[4] = act; st[HS_CARD] = (float)act; add(lp); return;
+    case 5: out[5] = act; add(lp); return;
+    case 6: out[6] = act; add(lp); return;
+    case 9: out[15] = act; st[HS_RA] = (float)act; st[HS_CNT9] = count; add(lp); return;
+    case 10: out[16] = act; add(lp); return;
+    case 11: out[17] = act; add(lp); return;
+    default: {
+        out[(h == 7 ? 7 : 11) + a.step] = act;
+        st[HS_OUT + act] += 1.0f;
+        st[HS_RES + act] = fmaxf(st[HS_RES + act] - 1.0f, 0.0f);
+        const float keep = a.step == 0 ? 1.0f : (st[HS_PREV] > 0.0f ? 1.0f : 0.0f);       // a list ends at its first 0 ("stop")
+        st[HS_LPSUM] += keep != 0.0f ? lp : 0.0f;
+        st[HS_PREV] = (float)act;
+        st[HS_OUT] = 0.0f;                                                              // column 0 never feeds back
+        if (a.step == 3) {
+            const float prop = (int)st[HS_TYP] == T_PROPOSE ? 1.0f : 0.0f;
+            const float l = prop != 0.0f ? st[HS_LPSUM] : 0.0f;
+            st[HS_TOTAL] += l;
+            if (h == 7) {
+                st[HS_FILT7] = l == 0.0f ? 1.0f : 0.0f;                                 // action_heads_module.py:175
+                for (int k = 0; k < 6; k++) st[HS_GIVE + k] = st[HS_OUT + k];
+            } else {
+                a.logp_out[row] = st[HS_TOTAL];
+            }
+        }
+        return;
+    }
+    }
+}
+
 
 template <int KT>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
@@ -49,6 +185,11 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
     __shared__ float sV[HD_VELEMS];
     __shared__ float sLg[HD_WAVES][16 * HD_LG];
+    __shared__ float sCond[HD_WAVES][16][HD_NCP];            // chained mode: the rows' conditioning columns, masks and log-prob factors
+    __shared__ float sMask[HD_WAVES][16][HD_KP];
+    __shared__ float sCnt[HD_WAVES][16];
+    __shared__ __attribute__((aligned(16))) float sState[HD_WAVES][16][HD_STATE];   // the tile's rows of the chained state (LDS: ordered within the wave)
+    const bool chained = a.state != nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
     for (int i = tid; i < 128 * 16; i += 256) {
         const int n = i >> 4, c = i & 15;
@@ -83,7 +224,21 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
         // the mask entries of the categorical at the end of the tile: four lanes per row, 20 columns each
         const int rr = lane >> 2, part = lane & 3, c0 = part * 20;
         const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
-        const float* mrow = a.mask + grow * a.mask_ld;
+        const float* mrow = chained ? sMask[wave][rr] : a.mask + grow * a.mask_ld;
+        if (chained) {
+            {   // the 16 rows' state: lane = (row lane / 4, eight floats)
+                const long r = row0 + rr < a.B ? row0 + rr : a.B - 1;
+                const float4* src = reinterpret_cast<const float4*>(a.state + r * HD_STATE + part * 8);
+                float4* dst = reinterpret_cast<float4*>(&sState[wave][rr][part * 8]);
+                dst[0] = src[0]; dst[1] = src[1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) {                                           // one lane per row: mask, conditioning columns, log-prob factor
+                const long r = row0 + lane < a.B ? row0 + lane : a.B - 1;
+                sCnt[wave][lane] = hd_glue(a, r, sState[wave][lane], sMask[wave][lane], sCond[wave][lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         float mk[20];
 #pragma unroll
         for (int q = 0; q < 20; q++) mk[q] = c0 + q < a.K ? mrow[c0 + q] : 0.0f;
@@ -106,7 +261,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
                 for (int e = 0; e < 8; e++) acc[s][e] = 0.0f;
             // four conditioning columns per round, their loads issued together (a load per column inside the loop is an exposed
             // HBM round trip each: 12 columns x 4 tiles of them made this kernel three times longer)
-            const float* crow = a.cond + row * a.cond_ld;
+            const float* crow = chained ? sCond[wave][lr] : a.cond + row * a.cond_ld;
             for (int j0 = 0; j0 < a.ncond; j0 += 4) {
                 float cj[4];
 #pragma unroll
@@ -237,9 +392,16 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             int act = a.u ? (pick != 0x7fff ? pick : (last >= 0 ? last : amax)) : amax;
             act = min(max(act, 0), a.K - 1);
             if (part == 0 && row0 + rr < a.B) {
-                a.action[grow] = act;
-                a.logp[grow] = (mrow[act] > 0.0f ? lg[rr * HD_LG + act] : -INFINITY) - lse;
+                const float lpa = (mrow[act] > 0.0f ? lg[rr * HD_LG + act] : -INFINITY) - lse;
+                if (chained) hd_commit(a, grow, sState[wave][rr], act, lpa, sCnt[wave][rr]);
+                else { a.action[grow] = act; a.logp[grow] = lpa; }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (chained && row0 + rr < a.B) {                              // the rows' state goes back for the next evaluation
+            float4* dst = reinterpret_cast<float4*>(a.state + (row0 + rr) * HD_STATE + part * 8);
+            const float4* src = reinterpret_cast<const float4*>(&sState[wave][rr][part * 8]);
+            dst[0] = src[0]; dst[1] = src[1];
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -468,6 +468,7 @@ def head_fused_supported(pre_all):
 
 
 fused_heads_enabled = True
+chained_heads_enabled = True       # the heads' glue inside the fused kernels (heads_chain); off: one kernel per head + torch glue
 
 
 def head_sample(head, trunk_dim, pre, cond, mask, deterministic=False, generator=None):
@@ -494,6 +495,59 @@ def head_sample(head, trunk_dim, pre, cond, mask, deterministic=False, generator
     _lib.check(_lib.lib().catan_head_fwd(_ptr(pre), pre.stride(0), _ptr(cond), cond.stride(0) if cond is not None else 0, ncond, _ptr(wts), _ptr(vec),
                                          float(head.norm.eps), K, _ptr(mask), mask.stride(0), _ptr(u), _ptr(action), _ptr(logp), B, _stream()))
     return action, logp
+
+
+HEAD_CHAIN_ORDER = ((0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (6, 0), (11, 0), (4, 0), (9, 0), (10, 0),
+                    (7, 0), (7, 1), (7, 2), (7, 3), (8, 0), (8, 1), (8, 2), (8, 3))       # (head, step): the order of the pass's 18 draws
+
+
+def head5_custom_pack(head):
+    """head 5's custom_mlp + custom_norm as catan_head_chain reads them (fp32 [480]; W and b rounded to bf16 as autocast hands
+    them to the GEMM), cached and refreshed in place like head_pack"""
+    params = [head.custom_mlp.weight, head.custom_mlp.bias, head.custom_norm.weight, head.custom_norm.bias]
+    stamp = (sum(p._version for p in params), params[0].device, params[0].data_ptr())
+    cache = getattr(head, "_custom_pack", None)
+    if cache is not None and cache[0] == stamp:
+        return cache[1]
+    with torch.no_grad():
+        r = lambda t: t.to(torch.bfloat16).float().reshape(-1)
+        pack = torch.cat([r(head.custom_mlp.weight), r(head.custom_mlp.bias), head.custom_norm.weight.float(), head.custom_norm.bias.float()]).contiguous()
+    assert pack.numel() == 480 and float(head.custom_norm.eps) == float(head.norm.eps)
+    if cache is not None and cache[1].device == pack.device:
+        cache[1].copy_(pack)
+        pack = cache[1]
+    head._custom_pack = (stamp, pack)
+    return pack
+
+
+def heads_chain(heads, trunk_dim, pre_all, masks, cur_res, trade, deterministic=False, generator=None, forced_type=None):
+    """All twelve heads of an inference pass - eighteen head evaluations - as eighteen launches of the fused head kernel in its
+    chained mode (catan_head_chain): the glue between them (type-conditional mask rows, conditioning columns, log-prob masks,
+    the trade heads' lists) runs inside the kernels on a per-row state.  -> (actions int64 [B, 18], joint log-prob [B])"""
+    L = _lib.lib()
+    B, dev = pre_all.shape[0], pre_all.device
+    masks = masks if (masks.dtype == torch.float32 and masks.is_contiguous()) else masks.float().contiguous()
+    cur_res = cur_res.float().contiguous(); trade = trade.float().contiguous()
+    state = torch.zeros((B, L.catan_head_state_floats()), dtype=torch.float32, device=dev)
+    actions = torch.empty((B, 18), dtype=torch.int64, device=dev)
+    logp = torch.empty((B,), dtype=torch.float32, device=dev)
+    forced = None if forced_type is None else forced_type.to(torch.int64).contiguous()
+    us = None
+    if not deterministic:
+        if isinstance(generator, UniformPool):
+            us = [generator.take(B) for _ in HEAD_CHAIN_ORDER]
+        else:
+            u_all = torch.rand((len(HEAD_CHAIN_ORDER), B), device=dev, generator=generator)
+            us = [u_all[k] for k in range(len(HEAD_CHAIN_ORDER))]
+    custom = head5_custom_pack(heads[5])
+    st = _stream()
+    for k, (h, step) in enumerate(HEAD_CHAIN_ORDER):
+        wts, vec = head_pack(heads[h], trunk_dim)
+        pre = pre_all[:, 128 * h:128 * (h + 1)]
+        _lib.check(L.catan_head_chain(_ptr(pre), pre_all.stride(0), _ptr(wts), _ptr(vec), float(heads[h].norm.eps), h, step, _ptr(state), _ptr(masks),
+                                      _ptr(cur_res), _ptr(trade), _ptr(custom) if h == 5 else None, _ptr(forced) if h == 0 else None,
+                                      None if us is None else _ptr(us[k]), _ptr(actions), _ptr(logp), B, st))
+    return actions, logp
 
 
 _PATTERN_LISTS = {}

@@ -617,9 +617,14 @@ class _ActionHeads(nn.Module):
         if actions is None and not deterministic and main.is_cuda:
             generator = nn_kernels.UniformPool(generator, B, 18, dev)    # the 18 draws of a pass from one torch.rand
 
-        # inference on the GPU: a head evaluation is ONE kernel (csrc/catan_heads.hip) instead of ~8 small launches
+        # inference on the GPU: a head evaluation is ONE kernel (csrc/catan_heads.hip) instead of ~8 small launches ...
         fused = actions is None and nn_kernels.head_fused_supported(pre_all)
         self._fused_now = fused
+        if fused and nn_kernels.chained_heads_enabled:
+            # ... and the glue between the evaluations (type-conditional mask rows, conditioning columns, log-prob masks, the
+            # trade heads' lists: ~200 small torch launches) runs inside those kernels on a per-row state: eighteen launches
+            acts, lp = nn_kernels.heads_chain(H, D, pre_all, m, cur_res, trade, deterministic, generator, forced_type)
+            return acts, lp, 0.0
 
         def run(i, extra, mask, idx, count, custom=None):
             if fused:
