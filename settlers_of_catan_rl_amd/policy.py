@@ -851,6 +851,8 @@ class CatanPolicy(nn.Module):
             cache = getattr(h, "_fused_pack", None)
             if cache is not None and h.mlp_2.weight.is_cuda:
                 nn_kernels.head_pack(h, cache[0][3])
+            if getattr(h, "_custom_pack", None) is not None and h.mlp_2.weight.is_cuda:
+                nn_kernels.head5_custom_pack(h)
 
     @torch.no_grad()
     def load_from(self, master):
