@@ -252,16 +252,23 @@ class _ObservationModule(nn.Module):
         self.final_layer = _ortho_linear(19 * 25 + 4 * 128, 512)
         self.norm = nn.LayerNorm(512)
 
-    def forward(self, obs_f, lists, lens, tile_features=None):
+    def forward(self, obs_f, lists, lens, tile_features=None, tile_dedupe=None):
         """tile_features [B, 475]: the tile encoder's output for these rows, computed by the caller (the value re-evaluation of a
-        PPO update encodes every DISTINCT board once: nine in ten consecutive observations of a game show the same board)"""
+        PPO update encodes every DISTINCT board once: nine in ten consecutive observations of a game show the same board).
+        tile_dedupe = (tiles_u [U, 19 * 60], inv int64 [B]): the DISTINCT boards of this batch and, per row, which of them it
+        shows - the encoder runs on the U boards, its output is spread to the rows by `inv` and the rows' gradients are summed
+        per board on the way back (the same function of the same inputs: identical boards give identical encodings)."""
         o = spec.OBS_FLOAT_OFFSETS
         B = obs_f.shape[0]
         tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
         cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
         br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
         with br.on(1):
-            te = br.keep(self.tile_encoder(tiles) if tile_features is None else tile_features)
+            if tile_dedupe is not None:
+                te = self.tile_encoder(tile_dedupe[0].reshape(-1, 19, 60)).index_select(0, tile_dedupe[1])
+            else:
+                te = self.tile_encoder(tiles) if tile_features is None else tile_features
+            te = br.keep(te)
         with br.on(2):
             cp = br.keep(self.current_player_module(cur, lists[:, 1], lens[:, 1], lists[:, 0], lens[:, 0], self.dev_card_embedding,
                                                     self.hidden_card_mha, self.played_card_mha))
@@ -781,9 +788,9 @@ class CatanPolicy(nn.Module):
         out = outs[0] if T == 1 else torch.stack(outs, 0).reshape(R, L)
         return out.to(x.dtype), (h, c)
 
-    def base(self, obs_f, lists, lens, hidden=None, nonterminal=None, tile_features=None):
+    def base(self, obs_f, lists, lens, hidden=None, nonterminal=None, tile_features=None, tile_dedupe=None):
         """-> (value [B,1] fp32, main [B,512(+lstm_size)], hidden or None)   (policy.py:59-66)"""
-        main = self.observation_module(obs_f, lists, lens, tile_features)
+        main = self.observation_module(obs_f, lists, lens, tile_features, tile_dedupe)
         if self.include_lstm:
             if hidden is None:
                 raise ValueError("include_lstm: hidden=(h, c) and nonterminal are required")
@@ -809,10 +816,10 @@ class CatanPolicy(nn.Module):
                                                    forced_type=condition_on_action_type)
         return (value, actions, logp[:, None], hidden) if self.include_lstm else (value, actions, logp[:, None])
 
-    def evaluate_actions(self, obs_f, lists, lens, masks, actions, hidden=None, nonterminal=None):
+    def evaluate_actions(self, obs_f, lists, lens, masks, actions, hidden=None, nonterminal=None, tile_dedupe=None):
         ahm = self.action_head_module
         grouping = ahm.start_grouping(actions) if ahm.wants_grouping(obs_f.shape[0], actions) else None    # (before the long forward)
-        value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal)
+        value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal, tile_dedupe=tile_dedupe)
         cur_res, trade = self._custom(obs_f)
         _, logp, entropy = ahm(main, masks.float(), cur_res, trade, actions, grouping=grouping)
         return (value, logp[:, None], entropy, hidden) if self.include_lstm else (value, logp[:, None], entropy)

@@ -83,7 +83,8 @@ class PPOTrainer(object):
             return torch.autocast(device_type="cuda", enabled=False)
         return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
 
-    dedupe_boards = True          # value re-evaluation: run the tile encoder once per DISTINCT board of a game's stored observations
+    dedupe_boards = True          # run the tile encoder once per DISTINCT board: of a game's stored observations (value re-evaluation), of a minibatch
+    dedupe_min_rows = 16384       # minibatches below this are launch-bound: the extra gather / scatter-add is not worth it
 
     @torch.no_grad()
     def board_runs(self, st):
@@ -106,6 +107,24 @@ class PPOTrainer(object):
         uid = torch.where(flat, uid, torch.full_like(uid, -1)).reshape(T1, N)
         board_of_row = torch.cummax(uid, 0).values.reshape(-1)              # the last new board at or before t, per game
         return first_rows, board_of_row
+
+    @torch.no_grad()
+    def minibatch_boards(self, board_ids, perm, num_mini_batch, mbs):
+        """The distinct boards of every minibatch of an epoch, for all minibatches at once (one sort, ONE host read of the 64
+        counts - a `torch.unique` per step would drain the launch queue in the middle of every step).
+        board_ids int64 [T N] (board_runs); perm: the epoch's permutation.  -> list of (boards int64 [U_k], inv int64 [mbs]):
+        row j of minibatch k shows board boards[inv[j]]."""
+        ids = board_ids[perm[:num_mini_batch * mbs]].view(num_mini_batch, mbs)
+        srt, order = torch.sort(ids, dim=1)
+        first = torch.ones_like(srt, dtype=torch.bool)
+        first[:, 1:] = srt[:, 1:] != srt[:, :-1]
+        pos = torch.cumsum(first.long(), 1) - 1                      # rank of every sorted entry's board among the distinct ones
+        counts = (pos[:, -1] + 1).tolist()                           # the one host read
+        uq = torch.zeros_like(srt)
+        uq.scatter_(1, pos, srt)                                     # (duplicates write the same value)
+        inv = torch.empty_like(pos)
+        inv.scatter_(1, order, pos)
+        return [(uq[k, :counts[k]], inv[k]) for k in range(num_mini_batch)]
 
     @torch.no_grad()
     def compute_values(self, st):
@@ -162,6 +181,18 @@ class PPOTrainer(object):
         nt_all = masks[:T].reshape(total)                 # masks_batch of generator_lstm (process_batch.py:249)
         cast = (lambda x: x) if (self.autocast_dtype is not None and f_all.dtype == self.autocast_dtype) else (lambda x: x.float())
         sums = torch.zeros(3, device=dev)                 # action loss, value loss, entropy (accumulated on device)
+        # distinct boards (see board_runs): the encoder's share of a minibatch step shrinks with the boards a minibatch repeats
+        dedupe = bool(self.dedupe_boards and not rec and dev.type == "cuda" and hasattr(pol, "observation_module") and mbs >= self.dedupe_min_rows)
+        if dedupe:
+            from . import spec
+            key = (st.obs_f.data_ptr(), getattr(st, "generation", None), T + 1, N)
+            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None:
+                self._runs = self.board_runs(st)
+                self._runs_key = key
+            first_rows, board_of_row = self._runs
+            board_ids = board_of_row[:total]
+            o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+            tiles_all = st.obs_f.reshape((T + 1) * N, -1)[:, o:o + 1140]
         timed_allreduce = dev.type == "cuda" and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         ar_events = []
         t_val = t_gae = t_opt = 0.0
@@ -179,12 +210,19 @@ class PPOTrainer(object):
             else:
                 perm = torch.randperm(total, generator=self.gen, device=dev)               # SubsetRandomSampler
                 batches = [(perm[mb * mbs:(mb + 1) * mbs], None) for mb in range(cfg.num_mini_batch)]   # BatchSampler(drop_last=True)
-            for idx, hidden in batches:
+                if dedupe:                        # the tile encoder sees every distinct board of a minibatch once (forward and backward)
+                    boards = self.minibatch_boards(board_ids, perm, cfg.num_mini_batch, mbs)
+            for bi, (idx, hidden) in enumerate(batches):
                 with self._autocast():
                     if rec:
                         v, lp, ent, _ = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
                                                              st.unpack_action_masks(amask_all[idx]), acts_all[idx],
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
+                    elif dedupe:
+                        uqk, invk = boards[bi]
+                        v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
+                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                          tile_dedupe=(cast(tiles_all[first_rows[uqk]]), invk))
                     else:
                         v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx])

@@ -878,3 +878,43 @@ def test_chained_heads_equal_the_glued_heads(hip_lib):
     assert float((lp_e.float().reshape(-1) - lp.float().reshape(-1)).abs().max()) < 0.06
     env.step(a.to(torch.int32))
     assert env.invalid_action_count() == 0
+
+
+def test_minibatch_steps_encode_distinct_boards_only(hip_lib):
+    """PPOTrainer.update with the tile encoder run once per DISTINCT board of a minibatch (forward: spread by index; backward: the
+    rows' gradients summed per board) against the same update encoding every row: the bookkeeping is exact (every row's board is
+    the one it is mapped to) and the update is the same function - losses equal within bf16 noise, parameters after the update
+    close; fp32: equal within 1e-5."""
+    import copy
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    torch.manual_seed(0)
+    N, T = 2048, 24
+    env = VecCatanEnv(N, seed=19); env.random_rollout(0, 900)
+    net0 = CatanPolicy().cuda()
+    for ac, tol_loss, tol_par in ((None, 1e-5, 2e-5), (torch.bfloat16, 3e-3, 2e-3)):
+        col = RolloutCollector(env, net0, T, seed=2, autocast_dtype=ac)
+        st = col.gather_rollouts()
+        res = {}
+        for dedupe in (True, False):
+            net = copy.deepcopy(net0)
+            tr = PPOTrainer(net, PPOConfig(ppo_epoch=1, num_mini_batch=2), autocast_dtype=ac, seed=5)
+            tr.dedupe_boards = dedupe
+            if dedupe:
+                first_rows, board_of_row = tr.board_runs(st)
+                perm = torch.randperm(T * N, device="cuda")
+                o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+                tiles = st.obs_f.reshape((T + 1) * N, -1)[:, o:o + 1140]
+                mbs = T * N // 2
+                for k, (uq, inv) in enumerate(tr.minibatch_boards(board_of_row[:T * N], perm, 2, mbs)):
+                    idx = perm[k * mbs:(k + 1) * mbs]
+                    assert torch.equal(tiles[first_rows[uq]][inv], tiles[idx])          # every row gets exactly its own board
+                    assert uq.numel() < 0.97 * mbs and torch.equal(torch.unique(uq), uq)
+            losses = tr.update(st)
+            res[dedupe] = (losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+        for a, b in zip(res[True][0], res[False][0]):
+            assert abs(a - b) < tol_loss * max(1.0, abs(b)), (ac, res[True][0], res[False][0])
+        assert float((res[True][1] - res[False][1]).abs().max()) < tol_par, (ac, float((res[True][1] - res[False][1]).abs().max()))
+        col.after_rollouts()
