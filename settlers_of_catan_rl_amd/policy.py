@@ -265,7 +265,7 @@ class _ObservationModule(nn.Module):
         br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
         with br.on(1):
             if tile_dedupe is not None:
-                te = self.tile_encoder(tile_dedupe[0].reshape(-1, 19, 60)).index_select(0, tile_dedupe[1])
+                te = self.tile_encoder(tile_dedupe[0].reshape(-1, 19, 60))[tile_dedupe[1]]    # (indexing: its backward sums per board by sorting - index_select's uses bf16 atomics, twice as slow)
             else:
                 te = self.tile_encoder(tiles) if tile_features is None else tile_features
             te = br.keep(te)
