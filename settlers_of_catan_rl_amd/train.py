@@ -220,7 +220,11 @@ class PPOTrainer(object):
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
                     elif dedupe:
                         uqk, invk = boards[bi]
-                        v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
+                        # the rows' observations WITHOUT their tile features (64 % of a row: they come per distinct board below)
+                        fm = torch.empty((idx.numel(), f_all.shape[1]), dtype=f_all.dtype, device=dev)
+                        fm[:, :o] = f_all[:, :o][idx]
+                        fm[:, o + 1140:] = f_all[:, o + 1140:][idx]
+                        v, lp, ent = pol.evaluate_actions(cast(fm), lists_all[idx], lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx],
                                                           tile_dedupe=(cast(tiles_all[first_rows[uqk]]), invk))
                     else:
