@@ -94,6 +94,20 @@ int catan_masked_row_store(void* dst, const void* src, const int64_t* t, const u
  * -> float32 [rows][325], the layout `action_masks` has in RL/ppo/process_batch.py:96-104 */
 int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out_masks, catan_stream_t stream);
 
+/* The per-game bookkeeping of GamesAndPoliciesManager.gather_rollouts (RL/ppo/game_manager.py:69-140) for all games at once, two
+ * launches per env iteration (settlers_of_catan_rl_amd/rollout.py describes the four per-game counters that stand for the
+ * reference's Python lists).  pre: a_env int32 [n][18] = the actions for catan_step, with the no-op type for frozen games (n_obs =
+ * T + 1), and live uint8 [n].  post (after catan_step and catan_deciding_seat): :91-136 - terminal masks, the reward sums over a
+ * turn (doubles), the append of the active seat's action / log-prob / packed action mask, of rewards and terminal masks into the
+ * (T(+2), n, .) rollout tensors, finished games, and which games append their NEXT observation where (sel, t_obs: the inputs of
+ * catan_obs_rows).  counters4: int64 [4][n] = n_obs, n_msk, n_act, n_rew; flags4: uint8 [4][n] = done_since, pending_obs, live
+ * (from pre), sel (out); reward64 may be NULL (then `reward` is summed). */
+int catan_collector_pre(int64_t n, int32_t T, const int64_t* n_obs, const int64_t* actions, int32_t* a_env, uint8_t* live, catan_stream_t stream);
+int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc, uint8_t* flags4, float* term, int64_t* t_obs, const int64_t* active_pid,
+                         const int32_t* deciding, const int32_t* n_deciding, const int64_t* actions, const float* logp, const int32_t* pmasks,
+                         const float* reward, const double* reward64, const uint8_t* done, int64_t* st_actions, float* st_logp, int32_t* st_amasks,
+                         float* st_rewards, float* st_masks, int64_t* n_complete, catan_stream_t stream);
+
 /* deciding player (discarder > trade target > players_go): env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.
  * out: int32 [n], PlayerId 1..4 */
 int catan_deciding_seat(catan_env_t* env, int32_t* out, catan_stream_t stream);

@@ -99,6 +99,8 @@ _SIGS = {
     "catan_expand_masks": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "catan_masks_packed_copy": (C.c_int, [_vp, _vp, _vp]),
     "catan_masked_row_store": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
+    "catan_collector_pre": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "catan_collector_post": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 21),
     "catan_deciding_seat": (C.c_int, [_vp, _vp, _vp]),
     "catan_sample_random_actions": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "catan_state_export": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),

@@ -14,6 +14,7 @@
 #include "catan_nn.hip"
 #include "catan_tile_encoder.hip"
 #include "catan_heads.hip"
+#include "catan_collector.hip"
 
 using namespace catan;
 
@@ -902,6 +903,36 @@ static int head_launch(const HeadArgs& a, hipStream_t st) {
     case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(256), 0, st, a); break;
     }
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_collector_pre(int64_t n, int32_t T, const int64_t* n_obs, const int64_t* actions, int32_t* a_env, uint8_t* live, catan_stream_t stream) {
+    if (n <= 0 || T <= 0 || !n_obs || !actions || !a_env || !live) return fail(CATAN_EINVAL, "catan_collector_pre: bad arguments");
+    CollectorArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n; a.T = T; a.n_obs = (long long*)n_obs; a.actions = (const long long*)actions; a.a_env = a_env; a.live = live;
+    hipLaunchKernelGGL(k_collector_pre, dim3(blocks(n, 256)), dim3(256), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc, uint8_t* flags4, float* term, int64_t* t_obs, const int64_t* active_pid,
+                         const int32_t* deciding, const int32_t* n_deciding, const int64_t* actions, const float* logp, const int32_t* pmasks,
+                         const float* reward, const double* reward64, const uint8_t* done, int64_t* st_actions, float* st_logp, int32_t* st_amasks,
+                         float* st_rewards, float* st_masks, int64_t* n_complete, catan_stream_t stream) {
+    if (n <= 0 || T <= 0 || !counters4 || !racc || !flags4 || !term || !t_obs || !active_pid || !deciding || !n_deciding || !actions || !logp || !pmasks ||
+        !reward || !done || !st_actions || !st_logp || !st_amasks || !st_rewards || !st_masks || !n_complete)
+        return fail(CATAN_EINVAL, "catan_collector_post: null argument");
+    CollectorArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n; a.T = T;
+    a.n_obs = (long long*)counters4; a.n_msk = a.n_obs + n; a.n_act = a.n_obs + 2 * n; a.n_rew = a.n_obs + 3 * n;
+    a.racc = racc; a.done_since = flags4; a.pending_obs = flags4 + n; a.live = flags4 + 2 * n; a.sel = flags4 + 3 * n;
+    a.term = term; a.t_obs = (long long*)t_obs; a.active_pid = (const long long*)active_pid;
+    a.deciding = deciding; a.n_deciding = n_deciding; a.actions = (const long long*)actions; a.logp = logp; a.pmasks = pmasks;
+    a.reward = reward; a.reward64 = reward64; a.done = done;
+    a.st_actions = (long long*)st_actions; a.st_logp = st_logp; a.st_amasks = st_amasks; a.st_rewards = st_rewards; a.st_masks = st_masks;
+    a.n_complete = (long long*)n_complete;
+    hipLaunchKernelGGL(k_collector_post, dim3(blocks(n, 256)), dim3(256), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -88,7 +88,7 @@ class RolloutCollector(object):
         self.policy_of_pid = torch.empty((self.N, 4), dtype=torch.int64)
         self.policy_of_pid.scatter_(1, perm, torch.arange(4).expand(self.N, 4))
         self.policy_of_pid = self.policy_of_pid.to(self.device)
-        self.active_pid = (perm[:, 0] + 1).to(self.device)                                  # PlayerId 1..4
+        self.active_pid = (perm[:, 0] + 1).long().contiguous().to(self.device)                                  # PlayerId 1..4
         self.sample_gen = torch.Generator(device=self.device).manual_seed(seed + 1)
         self.recurrent = bool(getattr(policy, "include_lstm", False))
         # Self-play with one feed-forward net: the policy pass of an env iteration is ~500 small launches and host-bound
@@ -119,10 +119,11 @@ class RolloutCollector(object):
     # game_manager.py:35-59 (the env itself is already reset: EnvWrapper.reset() happened in catan_create / env.reset())
     def reset(self):
         N, dev, st = self.N, self.device, self.storage
-        self.n_obs = torch.zeros(N, dtype=torch.int64, device=dev)
-        self.n_msk = torch.ones(N, dtype=torch.int64, device=dev)                           # terminal_masks = [1.0]
-        self.n_act = torch.zeros(N, dtype=torch.int64, device=dev)
-        self.n_rew = torch.zeros(N, dtype=torch.int64, device=dev)
+        # the four counters are rows of one tensor (and only ever updated in place): catan_collector_post takes them as one block
+        self._cnt = torch.zeros((4, N), dtype=torch.int64, device=dev)
+        self.n_obs, self.n_msk, self.n_act, self.n_rew = self._cnt[0], self._cnt[1], self._cnt[2], self._cnt[3]
+        self.n_msk.fill_(1)                                                                 # terminal_masks = [1.0]
+        self._flags = torch.zeros((4, N), dtype=torch.uint8, device=dev)                    # done_since, pending_obs, live, sel of the fused bookkeeping
         st.masks[0] = 1.0
         self.pending_obs = self.env.deciding_player().long() == self.active_pid             # observations = [obs] iff the active seat moves first
         self.done_since = torch.zeros(N, dtype=torch.bool, device=dev)
@@ -173,6 +174,7 @@ class RolloutCollector(object):
                 self._row_store(st.hidden[k], hid[k], t, sel8)
         self.n_obs += sel.long()
 
+    fused_bookkeeping = True   # False: the tensor-operation form of the bookkeeping below (what the kernels are tested against)
     CHECK_EVERY = 8      # env iterations between two host reads of "every game has its T + 1 observations" (iterations past that point are no-ops)
 
     @torch.no_grad()
@@ -193,7 +195,54 @@ class RolloutCollector(object):
         # AND appends the active seats' rows to the storage (k_obs_rows; round 2: k_obs, a cast pass and a masked row store)
         fused_obs = hasattr(env, "get_obs_rows") and st.obs_f.is_cuda and st.obs_f.dtype in (torch.float32, torch.bfloat16)
         obs_out = mask_out = None
+        # ... and two kernels do the per-game bookkeeping of an iteration (catan_collector_pre / _post) instead of ~40 tensor operations
+        fused_book = fused_obs and packed_from_env and not self.recurrent and hasattr(env, "L") and self.fused_bookkeeping
+        if fused_book:
+            import ctypes as C
+            from . import _lib
+            L, P = _lib.lib(), (lambda x: C.c_void_p(x.data_ptr()))
+            fl = self._flags
+            fl[0].copy_(self.done_since)
+            fl[1].copy_(self.pending_obs)
+            t_next = torch.empty(N, dtype=torch.int64, device=dev)
+            a_env = torch.empty((N, spec.ACTION_WORDS), dtype=torch.int32, device=dev)
+            live8, sel_next = fl[2], fl[3]
+            first = True
         while True:
+            if fused_book:
+                if first:
+                    sel = self.pending_obs & (self.n_obs < T + 1)
+                    t_obs = self.n_obs.clamp(max=T)
+                else:
+                    sel, t_obs = sel_next, t_next       # written by catan_collector_post, which also counted the appends in n_obs
+                f, lists, lens = env.get_obs_rows(st.obs_f.dtype, out=obs_out, rows=(st.obs_f, st.lists, st.lens), t=t_obs, sel=sel)
+                if first:
+                    self.n_obs += sel.long()
+                    first = False
+                if max_iters is not None and iters >= max_iters:
+                    break
+                if iters % self.CHECK_EVERY == 0 and bool((self.n_obs >= T + 1).all()):
+                    break
+                iters += 1
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                deciding = env.deciding_player()                                                # :79
+                masks = env.get_action_masks(mask_out) if mask_out is not None else env.get_action_masks()   # :83
+                pol = self.policy_of_pid[ar, deciding.long() - 1] if self.opponent_nets else None
+                actions, logp = self._act(f, lists, lens, masks, pol)                           # :85-89
+                if obs_out is None and self._graphed is not None and not self.opponent_nets:
+                    bufs = self._graphed.static_inputs(N)
+                    if bufs is not None and bufs[0].dtype == st.obs_f.dtype and bufs[1].dtype == torch.int32 and bufs[2].dtype == torch.int32:
+                        obs_out, mask_out = bufs[:3], bufs[3]
+                actions, logp = actions.contiguous(), logp.contiguous()
+                _lib.check(L.catan_collector_pre(N, T, P(self.n_obs), P(actions), P(a_env), P(live8), stream))
+                n_live_iters += live8.any()
+                pmasks = env.get_action_masks_packed()                                          # (before the step replaces them)
+                reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
+                n_deciding = env.deciding_player()
+                _lib.check(L.catan_collector_post(N, T, P(self._cnt), P(self.racc), P(fl), P(term), P(t_next), P(self.active_pid), P(deciding), P(n_deciding),
+                                                  P(actions), P(logp), P(pmasks), P(reward), P(self.reward64) if self.reward64 is not None else None, P(done),
+                                                  P(st.actions), P(st.action_log_probs), P(st.action_masks), P(st.rewards), P(st.masks), P(n_complete), stream))
+                continue
             if fused_obs:
                 sel = self.pending_obs & (self.n_obs < T + 1)
                 t_obs = self.n_obs.clamp(max=T)
@@ -257,6 +306,10 @@ class RolloutCollector(object):
             self.done_since = torch.where(next_active, torch.zeros_like(self.done_since),
                                           torch.where(done & live, torch.ones_like(self.done_since), self.done_since))
             self.pending_obs = next_active
+        if fused_book:
+            # (the loop left after an observation append: sel / pending_obs of the flags are consumed)
+            self.done_since = fl[0].bool()
+            self.pending_obs = torch.zeros(N, dtype=torch.bool, device=dev)
         st.games_complete += int(n_complete)
         st.generation += 1
         self.iters = int(n_live_iters) if max_iters is None else iters
@@ -323,7 +376,7 @@ class RolloutCollector(object):
         if self.recurrent:
             st.hidden[:, 0] = st.hidden[:, last_t, ar]
         had_obs = self.n_obs > 0
-        self.n_obs = had_obs.long()
-        self.n_msk = torch.ones_like(self.n_msk)
+        self.n_obs.copy_(had_obs.long())
+        self.n_msk.fill_(1)
         self.n_act.zero_()
         self.n_rew.zero_()

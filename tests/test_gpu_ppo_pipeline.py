@@ -918,3 +918,37 @@ def test_minibatch_steps_encode_distinct_boards_only(hip_lib):
             assert abs(a - b) < tol_loss * max(1.0, abs(b)), (ac, res[True][0], res[False][0])
         assert float((res[True][1] - res[False][1]).abs().max()) < tol_par, (ac, float((res[True][1] - res[False][1]).abs().max()))
         col.after_rollouts()
+
+
+def test_fused_collector_bookkeeping_equals_the_tensor_form(hip_lib):
+    """catan_collector_pre / _post (one lane per game; game_manager.py:91-136) against the tensor-operation form of the same
+    bookkeeping (RolloutCollector.fused_bookkeeping = False): two collectors on identically seeded envs, same net, same sampling
+    generator - every rollout tensor, counter and flag identical, over two gather calls with after_rollouts between them, with
+    games finishing (dense terminal rewards) and games frozen at T + 1 observations while others still play."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    torch.manual_seed(0)
+    N, T = 1024, 6
+    net = CatanPolicy().cuda()
+    cols = []
+    for fused in (True, False):
+        env = VecCatanEnv(N, seed=5, dense_reward=True)
+        env.random_rollout(0, 1500)                      # late game: some games end inside the rollout
+        col = RolloutCollector(env, net, T, seed=3, graph_act=False)
+        col.fused_bookkeeping = fused
+        cols.append(col)
+    for rnd in range(2):
+        sts = [c.gather_rollouts() for c in cols]
+        a, b = cols
+        assert a.iters == b.iters and sts[0].games_complete == sts[1].games_complete, (a.iters, b.iters, sts[0].games_complete, sts[1].games_complete)
+        if rnd == 0:
+            assert sts[0].games_complete > 0
+        for name in ("obs_f", "lists", "lens", "actions", "action_log_probs", "action_masks", "rewards", "masks"):
+            x, y = getattr(sts[0], name), getattr(sts[1], name)
+            assert torch.equal(x, y), (rnd, name, int((x != y).sum()))
+        for name in ("n_obs", "n_msk", "n_act", "n_rew", "racc", "done_since", "pending_obs"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (rnd, name)
+        assert a.env.invalid_action_count() == 0
+        for c in cols:
+            c.after_rollouts()
