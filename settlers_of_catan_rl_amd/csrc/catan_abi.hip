@@ -897,11 +897,11 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
 static int head_launch(const HeadArgs& a, hipStream_t st) {
     const dim3 grid(blocks(a.B, HD_ROWS));
     switch ((a.K + 15) / 16) {
-    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(HD_THREADS), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(HD_THREADS), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(HD_THREADS), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(HD_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(HD_THREADS), 0, st, a); break;
     }
     HIPCHK(hipGetLastError());
     return CATAN_OK;

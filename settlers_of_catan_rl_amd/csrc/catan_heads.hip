@@ -23,7 +23,8 @@ namespace catan {
 
 constexpr int HD_PITCH = 136;            // LDS row pitch of the weight matrices (bf16 elements): 272 B, 16-byte aligned, conflict-free fragments
 constexpr int HD_LG = 84;                // floats per logits row in LDS (row groups 16 banks apart)
-constexpr int HD_RT = 4, HD_WAVES = 4;   // row tiles per wave, waves per workgroup
+constexpr int HD_RT = 2, HD_WAVES = 8;   // row tiles per wave, waves per workgroup (two per SIMD)
+constexpr int HD_THREADS = HD_WAVES * 64;
 constexpr int HD_ROWS = HD_WAVES * HD_RT * 16;
 constexpr int HD_NCP = 32;               // conditioning columns, padded
 constexpr int HD_KP = 80;                // output columns, padded (73 road edges)
@@ -58,26 +59,19 @@ constexpr int HD_STATE = 32;                     // floats per row
 // state slots
 constexpr int HS_TYP = 0, HS_CARD = 1, HS_RA = 2, HS_CNT9 = 3, HS_TOTAL = 4, HS_LPSUM = 5, HS_PREV = 6, HS_FILT7 = 7, HS_OUT = 8, HS_RES = 14, HS_GIVE = 20;
 
-// what a row's evaluation of head `h` needs: its mask (K floats -> mk), its conditioning columns (-> cd) and the factor its
-// log-prob enters the joint log-prob with (log_prob_masks, build_agent_model.py:132-147).  One lane per row.
-DEVI float hd_glue(const HeadArgs& a, long row, float* st, float* mk, float* cd) {
-    const float* mm = a.maskmat + row * 325;
+// what a row's evaluation of head `h` needs besides its mask: its conditioning columns (-> cd) and the factor its log-prob enters
+// the joint log-prob with (log_prob_masks, build_agent_model.py:132-147); the trade heads' running hand starts here.  One lane per row.
+DEVI float hd_glue(const HeadArgs& a, long row, float* st, float* cd) {
     const int h = a.head_id;
     const int typ = (int)st[HS_TYP], card = (int)st[HS_CARD];
     auto is = [&](int t) { return typ == t ? 1.0f : 0.0f; };
     switch (h) {
-    case 0: for (int k = 0; k < 13; k++) mk[k] = mm[M0 + k]; return 1.0f;
-    case 1: {                                                              // corner: settlement row, city row or the dummy row
-        const int r = typ == T_SETTLE ? 0 : (typ == T_CITY ? 1 : 2);
-        for (int k = 0; k < 54; k++) mk[k] = mm[M1 + 54 * r + k];
-        cd[0] = is(T_SETTLE); cd[1] = is(T_CITY);
-        return is(T_SETTLE) + is(T_CITY);
-    }
-    case 2: for (int k = 0; k < 73; k++) mk[k] = mm[M2 + k]; return is(T_ROAD);
-    case 3: for (int k = 0; k < 19; k++) mk[k] = mm[M3 + k]; return is(T_ROBBER);
-    case 4: for (int k = 0; k < 5; k++) mk[k] = mm[M4 + k]; return is(T_PLAYDEV);
+    case 0: return 1.0f;
+    case 1: cd[0] = is(T_SETTLE); cd[1] = is(T_CITY); return is(T_SETTLE) + is(T_CITY);
+    case 2: return is(T_ROAD);
+    case 3: return is(T_ROBBER);
+    case 4: return is(T_PLAYDEV);
     case 5: {                                                              // accept / reject: conditioned on the offer (custom_mlp + LayerNorm + ReLU)
-        for (int k = 0; k < 2; k++) mk[k] = mm[M5 + k];
         const float* tr = a.trade + row * 12;
         float t[32], mean = 0.0f, var = 0.0f;
         for (int o = 0; o < 32; o++) {
@@ -92,44 +86,66 @@ DEVI float hd_glue(const HeadArgs& a, long row, float* st, float* mk, float* cd)
         for (int o = 0; o < 32; o++) cd[o] = hd_bf(fmaxf((t[o] - mean) * rstd * a.custom[416 + o] + a.custom[448 + o], 0.0f));
         return is(T_RESPOND);
     }
-    case 6: {                                                              // relative player: propose row, steal row or the dummy row
-        const int r = typ == T_PROPOSE ? 0 : (typ == T_STEAL ? 1 : 2);
-        for (int k = 0; k < 3; k++) mk[k] = mm[M6 + 3 * r + k];
-        cd[0] = is(T_PROPOSE); cd[1] = is(T_STEAL);
-        return is(T_PROPOSE) + is(T_STEAL);
-    }
+    case 6: cd[0] = is(T_PROPOSE); cd[1] = is(T_STEAL); return is(T_PROPOSE) + is(T_STEAL);
     case 9: case 10: {                                                     // resource A / B of an exchange, Year of Plenty or Monopoly
         const bool playdev = typ == T_PLAYDEV;
         cd[0] = is(T_PLAYDEV); cd[1] = is(T_EXCHANGE);
         cd[2] = (playdev && card == C_YOP) ? 1.0f : 0.0f; cd[3] = (playdev && card == C_MONO) ? 1.0f : 0.0f;
         const float base = is(T_PLAYDEV) + is(T_EXCHANGE);
-        if (h == 9) {
-            const int rt = typ == T_EXCHANGE ? 0 : 1, rc = card == C_MONO ? 2 : (card == C_YOP ? 3 : 1);
-            for (int k = 0; k < 5; k++) mk[k] = mm[M9 + 5 * rt + k] * (playdev ? mm[M9 + 5 * rc + k] : 1.0f);
-            return base * (playdev ? ((card == C_YOP || card == C_MONO) ? 1.0f : 0.0f) : 1.0f);
-        }
-        for (int k = 0; k < 5; k++) mk[k] = mm[M10 + k];
+        if (h == 9) return base * (playdev ? ((card == C_YOP || card == C_MONO) ? 1.0f : 0.0f) : 1.0f);
         const int ra = (int)st[HS_RA];
         for (int k = 0; k < 5; k++) cd[4 + k] = (k == ra && st[HS_CNT9] != 0.0f) ? 1.0f : 0.0f;
         return base * (playdev ? (card == C_YOP ? 1.0f : 0.0f) : 1.0f);
     }
-    case 11: for (int k = 0; k < 5; k++) mk[k] = mm[M11 + k]; return is(T_DISCARD);
+    case 11: return is(T_DISCARD);
     default: {                                                             // 7: give list (from the hand), 8: receive list; four steps each
-        const bool from_hand = h == 7;
         if (a.step == 0) {
-            float tot = 0.0f;
-            for (int k = 0; k < 6; k++) { st[HS_OUT + k] = 0.0f; st[HS_RES + k] = a.cur_res[row * 6 + k]; tot += st[HS_RES + k]; }
+            for (int k = 0; k < 6; k++) { st[HS_OUT + k] = 0.0f; st[HS_RES + k] = a.cur_res[row * 6 + k]; }
             st[HS_LPSUM] = 0.0f; st[HS_PREV] = 1.0f;
-            for (int k = 0; k < 6; k++) mk[k] = from_hand ? (st[HS_RES + k] > 0.0f ? 1.0f : 0.0f) : 1.0f;
-            mk[0] = tot == 0.0f ? 1.0f : 0.0f;
-        } else {
-            for (int k = 0; k < 6; k++) mk[k] = from_hand ? (st[HS_RES + k] > 0.0f ? 1.0f : 0.0f) : 1.0f;
-            mk[0] = 1.0f;
         }
-        if (from_hand) { for (int k = 0; k < 6; k++) cd[k] = st[HS_OUT + k]; }
+        if (h == 7) { for (int k = 0; k < 6; k++) cd[k] = st[HS_OUT + k]; }
         else { for (int k = 0; k < 6; k++) { cd[k] = st[HS_GIVE + k] * (1.0f - st[HS_FILT7]); cd[6 + k] = st[HS_OUT + k]; } }
         return 1.0f;
     }
+    }
+}
+// the row's mask entries of columns c0 .. c0 + 19 (the categorical's split: four lanes per row), after hd_glue: which row of the
+// env's mask matrix depends on the type / card the earlier heads chose; the trade lists' masks are the running hand
+DEVI void hd_mask20(const HeadArgs& a, long row, const float* st, int c0, float* mk) {
+    const float* mm = a.maskmat + row * 325;
+    const int h = a.head_id;
+    const int typ = (int)st[HS_TYP], card = (int)st[HS_CARD];
+    const float* p1 = nullptr; const float* p2 = nullptr;
+    switch (h) {
+    case 0: p1 = mm + M0; break;
+    case 1: p1 = mm + M1 + 54 * (typ == T_SETTLE ? 0 : (typ == T_CITY ? 1 : 2)); break;   // settlement row, city row or the dummy row
+    case 2: p1 = mm + M2; break;
+    case 3: p1 = mm + M3; break;
+    case 4: p1 = mm + M4; break;
+    case 5: p1 = mm + M5; break;
+    case 6: p1 = mm + M6 + 3 * (typ == T_PROPOSE ? 0 : (typ == T_STEAL ? 1 : 2)); break;    // propose row, steal row or the dummy row
+    case 9:
+        p1 = mm + M9 + 5 * (typ == T_EXCHANGE ? 0 : 1);
+        if (typ == T_PLAYDEV) p2 = mm + M9 + 5 * (card == C_MONO ? 2 : (card == C_YOP ? 3 : 1));
+        break;
+    case 10: p1 = mm + M10; break;
+    case 11: p1 = mm + M11; break;
+    default: {
+        const bool from_hand = h == 7;
+        float tot = 0.0f;
+        for (int k = 0; k < 6; k++) tot += st[HS_RES + k];
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            const int col = c0 + q;
+            mk[q] = col >= 6 ? 0.0f : (col == 0 ? ((a.step == 0 && tot != 0.0f) ? 0.0f : 1.0f) : ((from_hand && !(st[HS_RES + (col < 6 ? col : 0)] > 0.0f)) ? 0.0f : 1.0f));
+        }
+        return;
+    }
+    }
+#pragma unroll
+    for (int q = 0; q < 20; q++) {
+        const int col = c0 + q;
+        mk[q] = col < a.K ? p1[col] * (p2 != nullptr ? p2[col] : 1.0f) : 0.0f;
     }
 }
 // after the row's action `act` with log-prob `lp` is known: the action column(s), the joint log-prob, the state for the next heads
@@ -179,70 +195,99 @@ DEVI void hd_commit(const HeadArgs& a, long row, float* st, int act, float lp, f
 
 
 template <int KT>
-__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
+__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * HD_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short sW3[KT * 16 * HD_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
     __shared__ float sV[HD_VELEMS];
-    __shared__ float sLg[HD_WAVES][16 * HD_LG];
-    __shared__ float sCond[HD_WAVES][16][HD_NCP];            // chained mode: the rows' conditioning columns, masks and log-prob factors
-    __shared__ float sMask[HD_WAVES][16][HD_KP];
-    __shared__ float sCnt[HD_WAVES][16];
-    __shared__ __attribute__((aligned(16))) float sState[HD_WAVES][16][HD_STATE];   // the tile's rows of the chained state (LDS: ordered within the wave)
+    __shared__ __attribute__((aligned(16))) unsigned short sLg[HD_WAVES][16 * HD_LG];   // a tile's logits (bf16, as the unfused path rounds them)
+    __shared__ float sCond[HD_WAVES][HD_RT][16][HD_NCP];     // chained mode: the rows' conditioning columns and log-prob factors
+    __shared__ float sCnt[HD_WAVES][HD_RT][16];
+    __shared__ __attribute__((aligned(16))) float sState[HD_WAVES][HD_RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
     const bool chained = a.state != nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
-    for (int i = tid; i < 128 * 16; i += 256) {
+    const int rr = lane >> 2, part = lane & 3, c0 = part * 20;   // the categorical's split: four lanes per row, 20 columns each
+    // Everything a wave's row tiles need from HBM is requested before the weights are staged: the trunk products, the rows' state,
+    // and - once the state is there - the mask entries (whose address depends on the type the earlier heads chose).  There are two
+    // waves per SIMD: what is left exposed is one round trip for the state and one for the masks per launch.
+    uint4 xr[HD_RT][4];
+    float4 sr[HD_RT][2];
+    float thr[HD_RT];
+#pragma unroll
+    for (int tt = 0; tt < HD_RT; tt++) {
+        const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;        // rows past the end repeat the last one; nothing is stored for them
+        const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) xr[tt][s] = *reinterpret_cast<const uint4*>(a.pre + row * a.pre_ld + s * 32 + g * 8);
+        if (chained) {
+            const float4* src = reinterpret_cast<const float4*>(a.state + grow * HD_STATE + part * 8);
+            sr[tt][0] = src[0]; sr[tt][1] = src[1];
+        }
+        thr[tt] = a.u ? a.u[grow] : 0.0f;
+    }
+    for (int i = tid; i < 128 * 16; i += HD_THREADS) {
         const int n = i >> 4, c = i & 15;
         *reinterpret_cast<uint4*>(sW2 + n * HD_PITCH + c * 8) = *reinterpret_cast<const uint4*>(a.wts + n * 128 + c * 8);
     }
-    for (int i = tid; i < KT * 16 * 16; i += 256) {
+    for (int i = tid; i < KT * 16 * 16; i += HD_THREADS) {
         const int n = i >> 4, c = i & 15;
         *reinterpret_cast<uint4*>(sW3 + n * HD_PITCH + c * 8) = *reinterpret_cast<const uint4*>(a.wts + 128 * 128 + n * 128 + c * 8);
     }
     if (a.ncond > 0)
-        for (int i = tid; i < HD_NCP * 16; i += 256)
+        for (int i = tid; i < HD_NCP * 16; i += HD_THREADS)
             *reinterpret_cast<uint4*>(sW1 + i * 8) = *reinterpret_cast<const uint4*>(a.wts + 128 * 128 + HD_KP * 128 + i * 8);
-    for (int i = tid; i < HD_VELEMS; i += 256) sV[i] = a.vec[i];
+    for (int i = tid; i < HD_VELEMS; i += HD_THREADS) sV[i] = a.vec[i];
     const float* lnw = sV; const float* lnb = sV + 128; const float* b2 = sV + 256; const float* b3 = sV + 384;
-    float* lg = sLg[wave];
-    // the trunk products of all of this wave's row tiles, requested before the weights have even landed (a tile's chain is
-    // otherwise one exposed HBM round trip after the other: there is one wave per SIMD)
-    uint4 xr[HD_RT][4];
+    unsigned short* lg = sLg[wave];
+    u32 mkb[HD_RT];                                                  // the rows' mask entries of this lane's 20 columns, as bits
+    if (chained) {
 #pragma unroll
-    for (int tt = 0; tt < HD_RT; tt++) {
-        const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
-        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;
+        for (int tt = 0; tt < HD_RT; tt++) {
+            float4* dst = reinterpret_cast<float4*>(&sState[wave][tt][rr][part * 8]);
+            dst[0] = sr[tt][0]; dst[1] = sr[tt][1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16 * HD_RT) {                                       // one lane per row: conditioning columns, log-prob factor
+            const int tt = lane >> 4, r16 = lane & 15;
+            const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+            const long r = row0 + r16 < a.B ? row0 + r16 : a.B - 1;
+            sCnt[wave][tt][r16] = hd_glue(a, r, sState[wave][tt][r16], sCond[wave][tt][r16]);
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; s++) xr[tt][s] = *reinterpret_cast<const uint4*>(a.pre + row * a.pre_ld + s * 32 + g * 8);
+        for (int tt = 0; tt < HD_RT; tt++) {
+            const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+            const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
+            float mk[20];
+            hd_mask20(a, grow, sState[wave][tt][rr], c0, mk);
+            u32 b = 0;
+#pragma unroll
+            for (int q = 0; q < 20; q++) b |= (mk[q] > 0.0f && c0 + q < KT * 16) ? 1u << q : 0u;
+            mkb[tt] = b;
+        }
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < HD_RT; tt++) {
+            const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
+            const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
+            const float* mrow = a.mask + grow * a.mask_ld;
+            float mk[20];
+#pragma unroll
+            for (int q = 0; q < 20; q++) mk[q] = c0 + q < a.K ? mrow[c0 + q] : 0.0f;
+            u32 b = 0;
+#pragma unroll
+            for (int q = 0; q < 20; q++) b |= (mk[q] > 0.0f && c0 + q < KT * 16) ? 1u << q : 0u;
+            mkb[tt] = b;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int tt = 0; tt < HD_RT; tt++) {
         const long row0 = (long)blockIdx.x * HD_ROWS + (wave * HD_RT + tt) * 16;
         if (row0 >= a.B) break;                                       // (wave-uniform)
-        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;        // rows past the end repeat the last one; nothing is stored for them
-        // the mask entries of the categorical at the end of the tile: four lanes per row, 20 columns each
-        const int rr = lane >> 2, part = lane & 3, c0 = part * 20;
+        const long row = row0 + lr < a.B ? row0 + lr : a.B - 1;
         const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
-        const float* mrow = chained ? sMask[wave][rr] : a.mask + grow * a.mask_ld;
-        if (chained) {
-            {   // the 16 rows' state: lane = (row lane / 4, eight floats)
-                const long r = row0 + rr < a.B ? row0 + rr : a.B - 1;
-                const float4* src = reinterpret_cast<const float4*>(a.state + r * HD_STATE + part * 8);
-                float4* dst = reinterpret_cast<float4*>(&sState[wave][rr][part * 8]);
-                dst[0] = src[0]; dst[1] = src[1];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 16) {                                           // one lane per row: mask, conditioning columns, log-prob factor
-                const long r = row0 + lane < a.B ? row0 + lane : a.B - 1;
-                sCnt[wave][lane] = hd_glue(a, r, sState[wave][lane], sMask[wave][lane], sCond[wave][lane]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        float mk[20];
-#pragma unroll
-        for (int q = 0; q < 20; q++) mk[q] = c0 + q < a.K ? mrow[c0 + q] : 0.0f;
-        const float thr = a.u ? a.u[grow] : 0.0f;
         // ---- x = pre (+ cond . W1e^T), in the operand layout
         float x[4][8];
 #pragma unroll
@@ -261,7 +306,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
                 for (int e = 0; e < 8; e++) acc[s][e] = 0.0f;
             // four conditioning columns per round, their loads issued together (a load per column inside the loop is an exposed
             // HBM round trip each: 12 columns x 4 tiles of them made this kernel three times longer)
-            const float* crow = chained ? sCond[wave][lr] : a.cond + row * a.cond_ld;
+            const float* crow = chained ? sCond[wave][tt][lr] : a.cond + row * a.cond_ld;
             for (int j0 = 0; j0 < a.ncond; j0 += 4) {
                 float cj[4];
 #pragma unroll
@@ -341,21 +386,24 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             }
             const float bb = b3[16 * t + lr];
 #pragma unroll
-            for (int i = 0; i < 4; i++) lg[(4 * g + i) * HD_LG + 16 * t + lr] = hd_bf(c[i] + bb);       // logits[row 4 g + i][16 t + lr]
+            for (int i = 0; i < 4; i++) lg[(4 * g + i) * HD_LG + 16 * t + lr] = te_to_bf(c[i] + bb);       // logits[row 4 g + i][16 t + lr]
         }
         __builtin_amdgcn_wave_barrier();
         // ---- masked categorical: four lanes per row, 20 columns each
         {
             float z[20];
-            u32 valid = 0;
+            const u32 valid = mkb[tt];
             float mx = -INFINITY;
             int amax = 0x7fff;
+            const unsigned* lrow = reinterpret_cast<const unsigned*>(lg + rr * HD_LG + c0);
+#pragma unroll
+            for (int q = 0; q < 20; q += 2) {
+                const unsigned pr = lrow[q >> 1];
+                z[q] = __uint_as_float(pr << 16); z[q + 1] = __uint_as_float(pr & 0xFFFF0000u);
+            }
 #pragma unroll
             for (int q = 0; q < 20; q++) {
-                const int col = c0 + q;
-                z[q] = lg[rr * HD_LG + (col < KT * 16 ? col : 0)];
-                const bool ok = mk[q] > 0.0f;
-                if (ok) { valid |= 1u << q; if (z[q] > mx) { mx = z[q]; amax = col; } }
+                if (((valid >> q) & 1u) && z[q] > mx) { mx = z[q]; amax = c0 + q; }
             }
 #pragma unroll
             for (int d = 1; d <= 2; d <<= 1) {
@@ -382,7 +430,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             for (int q = 0; q < 20; q++) if ((valid >> q) & 1u) {
                 cdf += __expf(z[q] - lse);
                 last = c0 + q;
-                if (pick == 0x7fff && cdf > thr) pick = c0 + q;
+                if (pick == 0x7fff && cdf > thr[tt]) pick = c0 + q;
             }
 #pragma unroll
             for (int d = 1; d <= 2; d <<= 1) {
@@ -391,19 +439,20 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a) {
             }
             int act = a.u ? (pick != 0x7fff ? pick : (last >= 0 ? last : amax)) : amax;
             act = min(max(act, 0), a.K - 1);
+            // is the chosen column legal?  its mask bit sits in the lane of this row that holds column `act`
+            const u32 vb = __shfl(valid, (lane & ~3) | (act / 20));
             if (part == 0 && row0 + rr < a.B) {
-                const float lpa = (mrow[act] > 0.0f ? lg[rr * HD_LG + act] : -INFINITY) - lse;
-                if (chained) hd_commit(a, grow, sState[wave][rr], act, lpa, sCnt[wave][rr]);
+                const float lpa = (((vb >> (act % 20)) & 1u) ? te_bf(lg[rr * HD_LG + act]) : -INFINITY) - lse;
+                if (chained) hd_commit(a, grow, sState[wave][tt][rr], act, lpa, sCnt[wave][tt][rr]);
                 else { a.action[grow] = act; a.logp[grow] = lpa; }
             }
         }
         __builtin_amdgcn_wave_barrier();
         if (chained && row0 + rr < a.B) {                              // the rows' state goes back for the next evaluation
             float4* dst = reinterpret_cast<float4*>(a.state + (row0 + rr) * HD_STATE + part * 8);
-            const float4* src = reinterpret_cast<const float4*>(&sState[wave][rr][part * 8]);
+            const float4* src = reinterpret_cast<const float4*>(&sState[wave][tt][rr][part * 8]);
             dst[0] = src[0]; dst[1] = src[1];
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
