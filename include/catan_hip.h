@@ -336,7 +336,8 @@ int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const flo
  * (2 x 15 x 6 x 3 x 3 x 3 = catan_card_summary_patterns() patterns; pattern k has counts c0 = k % 2, c1 = k / 2 % 15, c2 = k / 30 % 6,
  * c3 = k / 180 % 3, c4 = k / 540 % 3, c5 = k / 1620) - or -1 for counts outside the deck.  The gradient is linear in dout, so a
  * caller may sum dout per pattern and differentiate catan_card_summary_patterns() synthetic lists instead of all rows;
- * only_unkeyed (int32 [rows], may be NULL) makes the backward skip the rows whose entry is >= 0 (those went through the patterns). */
+ * only_unkeyed (int32 [rows], may be NULL) makes the backward skip the rows whose entry is >= 0 (those went through the patterns);
+ * n_unkeyed (int32 [1] on the device, may be NULL; needs only_unkeyed): the launch returns at once when it holds 0. */
 int32_t catan_card_summary_params(void);
 int32_t catan_card_summary_patterns(void);
 int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, float* out,
@@ -347,11 +348,12 @@ int catan_card_summary_fwd(const void* ids, int id_bytes, int64_t pitch, const i
 int catan_card_summary_lookup(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* table, const float* params, float eps,
                               float* out, int64_t rows, catan_stream_t stream);
 int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
-                           float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream);
+                           float* dparams, const int32_t* only_unkeyed, const int32_t* n_unkeyed, int64_t rows, catan_stream_t stream);
 /* dpat[c][keys[r]][0..15] += dout[r][0..15] for the rows with keys[r] >= 0; dpat: float [replicas][catan_card_summary_patterns()][16],
  * zero before the call: copy c takes the rows of the workgroups b with b % replicas == c (the caller sums the copies) - a
- * handful of patterns covers most lists, and one copy would serialise the atomics of the whole grid on a few cache lines */
-int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int64_t rows, catan_stream_t stream);
+ * handful of patterns covers most lists, and one copy would serialise the atomics of the whole grid on a few cache lines.
+ * n_unkeyed (int32 [1] on the device, may be NULL): += the number of rows with keys[r] < 0. */
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int32_t* n_unkeyed, int64_t rows, catan_stream_t stream);
 
 /* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
  * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */

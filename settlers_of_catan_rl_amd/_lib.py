@@ -151,10 +151,10 @@ _SIGS = {
     "catan_head_chain": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_params": (C.c_int32, []),
     "catan_card_summary_patterns": (C.c_int32, []),
-    "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
+    "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int64, _vp]),
     "catan_card_summary_fwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_lookup": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_float, _vp, C.c_int64, _vp]),
-    "catan_card_summary_bwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_card_summary_bwd": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_randomise_uncertainty": (C.c_int, [_vp, _vp, _vp]),
     "catan_players_turn_sim": (C.c_int, [_vp, _vp, _vp]),
     "catan_inconsistent_deal_count": (C.c_int64, [_vp, _vp]),

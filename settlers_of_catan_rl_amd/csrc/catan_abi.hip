@@ -1088,18 +1088,19 @@ int catan_card_summary_lookup(const void* ids, int id_bytes, int64_t pitch, cons
     return CATAN_OK;
 }
 int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const int32_t* lens, const float* params, float eps, const float* dout,
-                           float* dparams, const int32_t* only_unkeyed, int64_t rows, catan_stream_t stream) {
-    if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !dout || !dparams) return fail(CATAN_EINVAL, "catan_card_summary_bwd: bad arguments");
+                           float* dparams, const int32_t* only_unkeyed, const int32_t* n_unkeyed, int64_t rows, catan_stream_t stream) {
+    if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !dout || !dparams || (n_unkeyed && !only_unkeyed))
+        return fail(CATAN_EINVAL, "catan_card_summary_bwd: bad arguments");
     const int rpl = rows >= 65536 ? 4 : 1;                 // lists per lane: few rows (the pattern table) want all the lanes they can get
     const dim3 grid((unsigned)((rows + 256 * rpl - 1) / (256 * rpl)), 7);
-    hipLaunchKernelGGL(k_card_summary_bwd, grid, dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, dout, dparams, (long)rows, only_unkeyed, rpl);
+    hipLaunchKernelGGL(k_card_summary_bwd, grid, dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, dout, dparams, (long)rows, only_unkeyed, rpl, n_unkeyed);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
 int32_t catan_card_summary_patterns(void) { return CS_PATTERNS; }
-int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int64_t rows, catan_stream_t stream) {
+int catan_card_pattern_sum(const int32_t* keys, const float* dout, float* dpat, int replicas, int32_t* n_unkeyed, int64_t rows, catan_stream_t stream) {
     if (!keys || !dout || !dpat || rows <= 0 || replicas < 1) return fail(CATAN_EINVAL, "catan_card_pattern_sum: bad arguments");
-    hipLaunchKernelGGL(k_card_pattern_sum, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), keys, dout, dpat, (long)rows, replicas);
+    hipLaunchKernelGGL(k_card_pattern_sum, dim3((unsigned)((rows + CPS_ROWS - 1) / CPS_ROWS)), dim3(256), 0, S(stream), keys, dout, dpat, (long)rows, replicas, n_unkeyed);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1340,7 +1340,9 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
 // blockIdx.y = the parameter slice: the seven slices of one backward run side by side in ONE launch
 __global__ __launch_bounds__(256) void k_card_summary_bwd(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
                                                           const float* __restrict__ params, float eps, const float* __restrict__ dout,
-                                                          float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl) {
+                                                          float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl,
+                                                          const int* __restrict__ n_unkeyed) {
+    if (n_unkeyed != nullptr && *n_unkeyed == 0) return;      // (uniform) every list went through its pattern
     switch (blockIdx.y) {
     case 0: cs_bwd_group<0>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
     case 1: cs_bwd_group<1>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
@@ -1352,38 +1354,55 @@ __global__ __launch_bounds__(256) void k_card_summary_bwd(const void* __restrict
     }
 }
 
-// dpat[key[r]] += dout[r] for the rows with key >= 0.  Many rows share a pattern (most lists are empty for most of a game), so
-// plain atomics would pile up on a few addresses: the lanes of a wave that hold the same pattern are added up with shuffles
-// first (one pass per distinct pattern in the wave) and only the first of them issues the 16 atomics.
+// dpat[key[r]] += dout[r] for the rows with key >= 0.  Many rows share a pattern (a minibatch of 614 400 lists holds ~1 400
+// distinct ones, a handful of them cover most lists), so neither plain global atomics (they pile up on a few cache lines) nor
+// adding up the lanes of a wave per distinct pattern (one shuffle tree of 16 values per distinct key in the wave: 526 us) fit.
+// A workgroup sums its 1 024 rows in an LDS hash table first (512 slots of key + 16 floats, native ds_add_f32; a row whose 16
+// probes all hit other keys adds to global memory directly) and then adds each occupied slot to the table once.
 // dpat holds `replicas` copies of the table ([replicas][CS_PATTERNS][16], summed by the caller): workgroup b adds to copy
-// b % replicas - the few patterns nearly every list has would otherwise serialise thousands of atomics on one cache line.
+// b % replicas.  n_unkeyed (may be null) += the rows with key < 0: the caller's per-row backward for those returns at once
+// when there are none (the usual case: their counts are outside the deck).
+constexpr int CPS_SLOTS = 512, CPS_PITCH = 17, CPS_ROWS = 1024;
 __global__ __launch_bounds__(256) void k_card_pattern_sum(const int* __restrict__ keys, const float* __restrict__ dout, float* __restrict__ dpat, long rows,
-                                                          int replicas) {
+                                                          int replicas, int* __restrict__ n_unkeyed) {
+    __shared__ int skey[CPS_SLOTS];
+    __shared__ float sval[CPS_SLOTS * CPS_PITCH];
     dpat += (long)(blockIdx.x % replicas) * CS_PATTERNS * CS_D;
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int key = r < rows ? keys[r] : -1;
-    float v[CS_D];
-#pragma unroll
-    for (int i = 0; i < CS_D; i++) v[i] = 0.f;
-    if (key >= 0) {
+    for (int i = threadIdx.x; i < CPS_SLOTS; i += 256) skey[i] = -1;
+    for (int i = threadIdx.x; i < CPS_SLOTS * CPS_PITCH; i += 256) sval[i] = 0.f;
+    __syncthreads();
+    int unk = 0;
+#pragma unroll 1
+    for (int it = 0; it < CPS_ROWS / 256; it++) {
+        const long r = (long)blockIdx.x * CPS_ROWS + it * 256 + threadIdx.x;
+        if (r >= rows) break;
+        const int key = keys[r];
+        if (key < 0) { unk++; continue; }
+        float v[CS_D];
         const float4* d4 = reinterpret_cast<const float4*>(dout + r * CS_D);
 #pragma unroll
         for (int i = 0; i < 4; i++) { const float4 q = d4[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
-    }
-    unsigned long long todo = __ballot(key >= 0);
-    while (todo) {
-        const int first = __ffsll((long long)todo) - 1;
-        const int k0 = __shfl(key, first);
-        const bool mine = key == k0;
-        todo &= ~__ballot(mine);
-#pragma unroll
-        for (int i = 0; i < CS_D; i++) {
-            float x = mine ? v[i] : 0.f;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == first) atomicAdd(&dpat[(long)k0 * CS_D + i], x);
+        int s = (int)(((unsigned)key * 2654435761u) >> 23), slot = -1;
+#pragma unroll 1
+        for (int probe = 0; probe < 16; probe++, s = (s + 1) & (CPS_SLOTS - 1)) {
+            const int old = atomicCAS(&skey[s], -1, key);
+            if (old == -1 || old == key) { slot = s; break; }
         }
+        if (slot >= 0) {
+#pragma unroll
+            for (int i = 0; i < CS_D; i++) atomicAdd(&sval[slot * CPS_PITCH + i], v[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CS_D; i++) atomicAdd(&dpat[(long)key * CS_D + i], v[i]);
+        }
+    }
+    if (n_unkeyed != nullptr && unk) atomicAdd(n_unkeyed, unk);
+    __syncthreads();
+    for (int e = threadIdx.x; e < CPS_SLOTS * CS_D; e += 256) {
+        const int slot = e / CS_D, i = e % CS_D, key = skey[slot];
+        if (key < 0) continue;
+        const float x = sval[slot * CPS_PITCH + i];
+        if (x != 0.f) atomicAdd(&dpat[(long)key * CS_D + i], x);
     }
 }
 

@@ -593,13 +593,14 @@ class _CardSummary(torch.autograd.Function):
         dparams = torch.zeros_like(p)
         d = dout.contiguous().float()
         pid, plen = _pattern_lists(ids.device)
-        reps = 32 if ids.shape[0] >= 32768 else 1
+        reps = 8 if ids.shape[0] >= 32768 else 1
         dpat = torch.zeros((reps, pid.shape[0], 16), dtype=torch.float32, device=ids.device)
-        _lib.check(L.catan_card_pattern_sum(_ptr(keys), _ptr(d), _ptr(dpat), reps, ids.shape[0], _stream()))
+        n_unkeyed = torch.zeros((1,), dtype=torch.int32, device=ids.device)
+        _lib.check(L.catan_card_pattern_sum(_ptr(keys), _ptr(d), _ptr(dpat), reps, _ptr(n_unkeyed), ids.shape[0], _stream()))
         dpat = dpat.sum(0) if reps > 1 else dpat[0]
-        _lib.check(L.catan_card_summary_bwd(_ptr(pid), 1, pid.stride(0), _ptr(plen), _ptr(p), ctx.eps, _ptr(dpat), _ptr(dparams), None, pid.shape[0], _stream()))
+        _lib.check(L.catan_card_summary_bwd(_ptr(pid), 1, pid.stride(0), _ptr(plen), _ptr(p), ctx.eps, _ptr(dpat), _ptr(dparams), None, None, pid.shape[0], _stream()))
         _lib.check(L.catan_card_summary_bwd(_ptr(ids), ids.element_size(), ids.stride(0), _ptr(lens), _ptr(p), ctx.eps, _ptr(d), _ptr(dparams), _ptr(keys),
-                                            ids.shape[0], _stream()))
+                                            _ptr(n_unkeyed), ids.shape[0], _stream()))
         return None, None, dparams, None
 
 

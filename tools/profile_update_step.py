@@ -47,3 +47,9 @@ by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten
 by.sort(key=lambda e: -e.self_device_time_total)
 for e in by[:40]:
     print("%-14s %8.1f us/step x%.0f  %s" % (e.key, e.self_device_time_total / NS, e.count / NS, str(e.input_shapes)[:150]))
+
+print("---- the net's own autograd functions by shape (device us per step)")
+by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("_") and not e.key.startswith("_foreach")]
+by.sort(key=lambda e: -e.self_device_time_total)
+for e in by[:70]:
+    print("%-28s %8.1f us/step x%.1f  %s" % (e.key[:28], e.self_device_time_total / NS, e.count / NS, str(e.input_shapes)[:170]))
