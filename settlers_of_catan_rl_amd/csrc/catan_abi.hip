@@ -143,12 +143,23 @@ static int lstm_cell_launch(bool bwd, const void* gx, const void* gh, const floa
 }
 
 // the column slice [col0, col0 + W) of a layer whose input is `ld` wide (W, col0, ld multiples of 8; W + 1 <= 160): X rows are strided
+// How the rows of a weight gradient are split over the grid.  Every block ends with one atomic per element of its O x (I + 1)
+// accumulator tile, so the grid is a balance between streaming parallelism and atomics (measured on MI355X, tools/bench_wgrad_shapes.py:
+// 614 400 x (160 -> 256): 456 us with up to 1 024 blocks, 307 us with 256; 3.4 M x (64 -> 128): 340 / 288 / 395 us with 1 024 / 512 /
+// 256; 3.4 M x (64 -> 32): 158 / 184 / 290 us): the wider the tile, the fewer blocks; long inputs take 16 stages per block, short ones 8.
+static void wgrad_grid(long R, int I, int O, long& nb, long& per) {
+    const long stages = (R + WG_KT - 1) / WG_KT;
+    const long tile = (long)((O + 15) / 16 * 16) * ((I + 1 + 15) / 16 * 16);
+    const long cap = tile >= 24576 ? 256 : (tile >= 3072 ? 512 : 1024);
+    const long spb = R >= 131072 ? 16 : 8;
+    nb = stages / spb < 1 ? 1 : (stages / spb < cap ? stages / spb : cap);
+    per = (stages + nb - 1) / nb * WG_KT;
+    nb = (R + per - 1) / per;
+}
 template <int OTW>
 static int wgrad_launch_slice(const void* x, const void* dy, float* dw, float* db, long R, int ld, int col0, int W, int O, hipStream_t st) {
-    long stages = (R + WG_KT - 1) / WG_KT;
-    long nb = stages / 8 < 1 ? 1 : (stages / 8 < 1024 ? stages / 8 : 1024);
-    long per = (stages + nb - 1) / nb * WG_KT;
-    nb = (R + per - 1) / per;
+    long nb, per;
+    wgrad_grid(R, W, O, nb, per);
     hipLaunchKernelGGL((k_wgrad_tr<OTW, 10>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, W, O, per,
                        (long)ld, col0);
     HIPCHK(hipGetLastError());
@@ -156,12 +167,8 @@ static int wgrad_launch_slice(const void* x, const void* dy, float* dw, float* d
 }
 template <int OTW, int IT>
 static int wgrad_launch(const void* x, const void* dy, float* dw, float* db, long R, int I, int O, hipStream_t st) {
-    long stages = (R + WG_KT - 1) / WG_KT;
-    // every block ends with O x (I+1) atomics, so a block should stream several stages: with 65 536 rows, one block per
-    // stage spent 150 us in 17 M atomics; 8 stages per block bring the layer to ~35 us
-    long nb = stages / 8 < 1 ? 1 : (stages / 8 < 1024 ? stages / 8 : 1024);
-    long per = (stages + nb - 1) / nb * WG_KT;
-    nb = (R + per - 1) / per;
+    long nb, per;
+    wgrad_grid(R, I, O, nb, per);
     if ((I & 7) == 0 && (O & 7) == 0)      // 16 B vectors never straddle a row: row-major LDS image + transposing LDS reads
         hipLaunchKernelGGL((k_wgrad_tr<OTW, IT>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)dy, dw, db, R, I, O, per);
     else
