@@ -299,6 +299,25 @@ int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_l
 int32_t catan_tile_encoder_weight_elems(void);
 int32_t catan_tile_encoder_vec_elems(void);
 int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream);
+/* Training forward: the same kernel also stores, per tile token (boards x 19 rows, bf16, row-major [rows][width], 16-byte aligned
+ * buffers), every activation the backward kernels of the encoder's sub-layers read - what the reference's autograd keeps for
+ * tile_encoder.py:41-91: catan_layer_norm_bwd(_res), catan_attention_bwd, catan_linear_rows_fused (dX) and catan_linear_wgrad are
+ * then run over them by the caller (settlers_of_catan_rl_amd/nn_kernels.py: _TileEncoderTrain). */
+typedef struct catan_te_saves {
+    void* tiles64;      /* [64]  tile features zero-padded 60 -> 64 (first_layer's input) */
+    void* a0;           /* [64]  first_layer output, before LayerNorm + ReLU */
+    void* xin[2];       /* [64]  encoder layer input (residual stream) */
+    void* n1[2];        /* [64]  LayerNorm 1 output */
+    void* qkv[2];       /* [192] Q | K | V */
+    void* o[2];         /* [64]  attention output */
+    void* xmid[2];      /* [64]  residual stream after the attention sub-layer */
+    void* n2[2];        /* [64]  LayerNorm 2 output */
+    void* h[2];         /* [128] relu(linear1) */
+    void* xfin;         /* [64]  last layer's output */
+    void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */
+} catan_te_saves_t;
+int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, const catan_te_saves_t* saves, int64_t boards,
+                                 catan_stream_t stream);
 
 /* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
  * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.

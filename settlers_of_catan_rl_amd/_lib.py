@@ -144,6 +144,7 @@ _SIGS = {
     "catan_tile_encoder_weight_elems": (C.c_int32, []),
     "catan_tile_encoder_vec_elems": (C.c_int32, []),
     "catan_tile_encoder_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_tile_encoder_fwd_train": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_head_weight_elems": (C.c_int32, []),
     "catan_head_vec_elems": (C.c_int32, []),
     "catan_head_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),

@@ -1068,8 +1068,25 @@ int32_t catan_tile_encoder_vec_elems(void) { return TE_VTOTAL; }
 int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream) {
     if (!tiles || !weights || !vecs || !out || boards <= 0) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd: bad arguments");
     long nb = (boards + TE_G - 1) / TE_G;
-    hipLaunchKernelGGL(k_tile_encoder_fwd, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
-                       (unsigned short*)out, (long)boards);
+    TeSaves sv;
+    memset(&sv, 0, sizeof sv);
+    hipLaunchKernelGGL(k_tile_encoder_fwd<false>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+                       (unsigned short*)out, (long)boards, sv);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, const catan_te_saves_t* saves, int64_t boards,
+                                 catan_stream_t stream) {
+    if (!tiles || !weights || !vecs || !out || !saves || boards <= 0) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: bad arguments");
+    static_assert(sizeof(catan_te_saves_t) == sizeof(TeSaves), "the header's struct is the kernel's");
+    const void* const* ptrs = reinterpret_cast<const void* const*>(saves);
+    for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++)
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer must be set and 16-byte aligned");
+    TeSaves sv;
+    memcpy(&sv, saves, sizeof sv);
+    long nb = (boards + TE_G - 1) / TE_G;
+    hipLaunchKernelGGL(k_tile_encoder_fwd<true>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+                       (unsigned short*)out, (long)boards, sv);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -194,9 +194,35 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
     }
 }
 
+// Training (SAVE): the same forward also leaves, per token row, every activation the backward kernels of the sub-layers read
+// (csrc/catan_nn.hip: LayerNorm, attention, row products, weight gradients) - the tensors the unfused training forward keeps for
+// autograd, written once from LDS as 16-byte row pieces while the next phase computes: bf16 [boards * 19][width] each.
+struct TeSaves {
+    unsigned short* tiles64;          // [64]: the tile features, zero-padded 60 -> 64 (the first layer's input)
+    unsigned short* a0;               // [64]: first_layer output (before its LayerNorm + ReLU)
+    unsigned short* xin[2];           // [64]: the layer's input (residual stream)
+    unsigned short* n1[2];            // [64]: LayerNorm 1 output (the QKV product's input)
+    unsigned short* qkv[2];           // [192]
+    unsigned short* o[2];             // [64]: attention output (the out-projection's input)
+    unsigned short* xmid[2];          // [64]: residual stream after the attention sub-layer
+    unsigned short* n2[2];            // [64]: LayerNorm 2 output (the FFN's input)
+    unsigned short* h[2];             // [128]: relu(linear1)
+    unsigned short* xfin;             // [64]: the last layer's output (out_proj's input)
+    unsigned short* p;                // [25]: out_proj output (before the final LayerNorm + ReLU)
+};
+template <int W>
+DEVI void te_dump(const unsigned short* lds, int pitch, unsigned short* __restrict__ g, long row0, int rows, int tid) {
+    constexpr int CH = W / 8;
+    g += row0 * W;
+    for (int c = tid; c < rows * CH; c += TE_THREADS) {
+        const int row = c / CH, ch = c - row * CH;
+        *reinterpret_cast<uint4*>(g + (long)row * W + ch * 8) = *reinterpret_cast<const uint4*>(lds + row * pitch + ch * 8);
+    }
+}
 // tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
+template <bool SAVE>
 __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
-                                                          const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards) {
+                                                          const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards, TeSaves sv) {
     __shared__ __attribute__((aligned(16))) unsigned short X[TE_ROWS * TE_PX];     // residual stream
     __shared__ __attribute__((aligned(16))) unsigned short Nb[TE_ROWS * TE_PX];    // LayerNorm output / attention output / staged input
     __shared__ __attribute__((aligned(16))) unsigned short Q[TE_ROWS * TE_PQ];     // Q | K | V; the FFN hidden layer; the output projection
@@ -227,9 +253,13 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         __syncthreads();
+        const long t0 = g0 * TE_L;                                              // this group's first token row
+        const int nt = nb * TE_L;
         // ---- x = relu(LayerNorm(first_layer(tiles)))
+        if (SAVE) te_dump<64>(Nb, TE_PX, sv.tiles64, t0, nt, tid);
         te_gemm<64, 64, 0>(Nb, TE_PX, w0, V + TE_V0, X, TE_PX, lane, wave);
         __syncthreads();
+        if (SAVE) { te_dump<64>(X, TE_PX, sv.a0, t0, nt, tid); __syncthreads(); }   // (the LayerNorm below is in place)
         te_layer_norm<TE_D, true>(X, TE_PX, X, TE_PX, V + TE_V0 + 64, V + TE_V0 + 128, tid);
         __syncthreads();
 #pragma unroll 1
@@ -238,31 +268,46 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const float* vl = V + TE_VL + l * TE_VL_SIZE;
             // x = x + out_proj(attention(qkv(LayerNorm(x))))
             TeW<64, 192> wq; te_fetch<64, 192>(wq, wl, lane, wave);
+            if (SAVE) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl, vl + 64, tid);
             __syncthreads();
+            if (SAVE) te_dump<64>(Nb, TE_PX, sv.n1[l], t0, nt, tid);
             te_gemm<64, 192, 0>(Nb, TE_PX, wq, vl + 128, Q, TE_PQ, lane, wave);
             TeW<64, 64> wo; te_fetch<64, 64>(wo, wl + 192 * 64, lane, wave);
             __syncthreads();
+            if (SAVE) te_dump<192>(Q, TE_PQ, sv.qkv[l], t0, nt, tid);
             te_attention(Q, Nb, lane, wave);
             __syncthreads();
+            if (SAVE) te_dump<64>(Nb, TE_PX, sv.o[l], t0, nt, tid);
             te_gemm<64, 64, 2>(Nb, TE_PX, wo, vl + 320, X, TE_PX, lane, wave);
             TeW<64, 128> w1; te_fetch<64, 128>(w1, wl + 192 * 64 + 64 * 64, lane, wave);
             TeW<128, 64> w2; te_fetch<128, 64>(w2, wl + 192 * 64 + 64 * 64 + 128 * 64, lane, wave);
             __syncthreads();
             // x = x + linear2(relu(linear1(LayerNorm(x))))
+            if (SAVE) te_dump<64>(X, TE_PX, sv.xmid[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl + 384, vl + 448, tid);
             __syncthreads();
+            if (SAVE) te_dump<64>(Nb, TE_PX, sv.n2[l], t0, nt, tid);
             te_gemm<64, 128, 1>(Nb, TE_PX, w1, vl + 512, Q, TE_PH, lane, wave);
             __syncthreads();
+            if (SAVE) te_dump<128>(Q, TE_PH, sv.h[l], t0, nt, tid);
             te_gemm<128, 64, 2>(Q, TE_PH, w2, vl + 640, X, TE_PX, lane, wave);
             __syncthreads();
         }
         // ---- out = relu(LayerNorm25(out_proj(x)))
         {
             TeW<64, 32> wp; te_fetch<64, 32>(wp, wts + TE_WP, lane, wave);
+            if (SAVE) te_dump<64>(X, TE_PX, sv.xfin, t0, nt, tid);
             te_gemm<64, 32, 0>(X, TE_PX, wp, V + TE_VP, Q, TE_PX, lane, wave);
         }
         __syncthreads();
+        if (SAVE) {
+            for (int c = tid; c < nt * TE_OUT; c += TE_THREADS) {
+                const int t = c / TE_OUT, i = c - t * TE_OUT;
+                sv.p[(t0 + t) * TE_OUT + i] = Q[t * TE_PX + i];
+            }
+            __syncthreads();                                                     // (the LayerNorm below is in place)
+        }
         te_layer_norm<TE_OUT, true>(Q, TE_PX, Q, TE_PX, V + TE_VP + 32, V + TE_VP + 64, tid);
         __syncthreads();
         for (int c = tid; c < nb * TE_L * TE_OUT; c += TE_THREADS) {

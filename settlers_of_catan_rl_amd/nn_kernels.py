@@ -439,6 +439,131 @@ def tile_encoder_forward(te, tiles):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The tile encoder's TRAINING forward as the one fused kernel (k_tile_encoder_fwd<SAVE>): the minibatch steps of a PPO update
+# spent 5.5 of their 41 ms in the encoder's forward as ~20 kernels that each stream a [boards x 19, 64..192] activation tensor
+# through HBM; the fused kernel keeps a board on chip and only WRITES what the backward kernels read.  The backward is the
+# chain autograd ran through the unfused sub-layers (same kernels, same order), spelled out.
+_TE_SAVES = (("tiles64", 64), ("a0", 64), ("xin0", 64), ("xin1", 64), ("n1_0", 64), ("n1_1", 64), ("qkv0", 192), ("qkv1", 192), ("o0", 64), ("o1", 64),
+             ("xmid0", 64), ("xmid1", 64), ("n2_0", 64), ("n2_1", 64), ("h0", 128), ("h1", 128), ("xfin", 64), ("p", 25))     # catan_te_saves_t's order
+
+
+def _te_params(te):
+    ps = [te.first_layer.weight, te.first_layer.bias, te.norm_2.weight, te.norm_2.bias]
+    for layer in te.encoder_layers:
+        mha, ffn = layer.multi_headed_attention, layer.pointwise_net
+        ps += [layer.sublayers[0].norm.weight, layer.sublayers[0].norm.bias]
+        for n in mha.qkv_nets:
+            ps += [n.weight, n.bias]
+        ps += [mha.out_proj_net.weight, mha.out_proj_net.bias, layer.sublayers[1].norm.weight, layer.sublayers[1].norm.bias,
+               ffn.linear1.weight, ffn.linear1.bias, ffn.linear2.weight, ffn.linear2.bias]
+    return ps + [te.out_proj.weight, te.out_proj.bias, te.norm.weight, te.norm.bias]
+
+
+def _rows_product(x2, wt, aux=None, mode=MODE_NONE):
+    """x2 [rows, K] @ wt[N, K].T (bf16), optional ReLU-backward mask: the row kernel, or the library for shapes outside its range"""
+    y = _linear_rows(x2, wt, None, aux, mode)
+    if y is None:
+        y = torch.nn.functional.linear(x2, wt)
+        if mode == MODE_RELU_MASK:
+            y = y * (aux > 0).to(y.dtype)
+    return y
+
+
+def _ln_backward(x, w, b, dy, eps, relu, dres=None):
+    """-> (dx, dw, db) of LayerNorm (+ ReLU) over the last dim of bf16 x [rows, D]; dres: a second gradient of x added in"""
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    dwb = torch.zeros((2, D), dtype=torch.float32, device=x.device)
+    wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+    L = _lib.lib()
+    if dres is None:
+        _lib.check(L.catan_layer_norm_bwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]), rows, D, float(eps), int(relu), 1, _stream()))
+    else:
+        _lib.check(L.catan_layer_norm_bwd_res(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]), rows, D, float(eps),
+                                              int(relu), 1, _stream()))
+    return dx, dwb[0], dwb[1]
+
+
+class _TileEncoderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tiles, te, *params):
+        import ctypes as C
+        wts, vecs = tile_encoder_pack(te)
+        x = _aligned(tiles.detach().to(torch.bfloat16))
+        B = x.shape[0]
+        T = B * 19
+        buf = torch.empty((T * sum(w for _, w in _TE_SAVES),), dtype=torch.bfloat16, device=x.device)
+        saves, off = [], 0
+        for _, w in _TE_SAVES:
+            saves.append(buf[off:off + T * w].view(T, w))
+            off += T * w
+        ptrs = (C.c_void_p * len(saves))(*[t.data_ptr() for t in saves])
+        out = torch.empty((B, 19 * 25), dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.lib().catan_tile_encoder_fwd_train(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), C.cast(ptrs, C.c_void_p), B, _stream()))
+        ctx.save_for_backward(*saves, *params)
+        ctx.eps = float(te.norm.eps)
+        ctx.B = B
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ns = len(_TE_SAVES)
+        sv = dict(zip([n for n, _ in _TE_SAVES], ctx.saved_tensors[:ns]))
+        P = ctx.saved_tensors[ns:]
+        B, eps, bf = ctx.B, ctx.eps, torch.bfloat16
+        T = B * 19
+        g = [None] * len(P)
+        with torch.autocast("cuda", enabled=False):
+            d = _aligned(dout.reshape(T, 25).to(bf))
+            dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
+            dx = _rows_product(dp, P[36].to(bf).t().contiguous())                         # [T, 64]
+            g[36], g[37] = _wgrad(sv["xfin"], dp, True)
+            for l in (1, 0):
+                b = 4 + 16 * l
+                xin, n1, qkv, o, xmid, n2, h = (sv[k + str(l)] for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
+                w1, w2 = P[b + 12].to(bf), P[b + 14].to(bf)
+                dh = _rows_product(dx, w2.t().contiguous(), h, MODE_RELU_MASK)            # (dx @ w2) where h > 0
+                g[b + 14], g[b + 15] = _wgrad(h, dx, True)
+                g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
+                dn2 = _rows_product(dh, w1.t().contiguous())
+                dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
+                do = _rows_product(dxmid, P[b + 8].to(bf).t().contiguous())
+                g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
+                dqkv = torch.empty_like(qkv)
+                _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
+                wqkv = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf)
+                dn1 = _rows_product(dqkv, wqkv.t().contiguous())
+                dwq, dbq = _wgrad(n1, dqkv, True)
+                for k in range(3):
+                    g[b + 2 + 2 * k], g[b + 3 + 2 * k] = dwq[64 * k:64 * k + 64], dbq[64 * k:64 * k + 64]
+                dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)
+            da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
+            dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
+            g[0] = dw0[:, :60]
+        return (None, None) + tuple(g)
+
+
+def tile_encoder_train_supported(te, tiles):
+    """training on the GPU under bf16 autocast, the reference's sizes; CATAN_TE_TRAIN_UNFUSED=1 keeps the sub-layer kernels"""
+    import os
+    if not torch.is_grad_enabled() or not tiles.is_cuda or tiles.dim() != 3 or tuple(tiles.shape[1:]) != (19, 60) or tiles.requires_grad:
+        return False
+    if os.environ.get("CATAN_TE_TRAIN_UNFUSED") == "1":
+        return False
+    if not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return False
+    return (te.first_layer.weight.shape == (64, 60) and len(te.encoder_layers) == 2 and te.out_proj.weight.shape == (25, 64)
+            and te.encoder_layers[0].multi_headed_attention.heads == 4 and te.encoder_layers[0].pointwise_net.linear1.weight.shape == (128, 64)
+            and te.first_layer.weight.dtype == torch.float32
+            and all(abs(m.eps - 1e-5) < 1e-12 for m in [te.norm, te.norm_2] + [s.norm for l in te.encoder_layers for s in l.sublayers]))
+
+
+def tile_encoder_train(te, tiles):
+    """tiles [B, 19, 60] -> bf16 [B, 475] with gradients to the encoder's parameters (see _TileEncoderTrain)"""
+    return _TileEncoderTrain.apply(tiles, te, *_te_params(te))
+
+
 def head_pack(head, trunk_dim):
     """An action head's parameters in the layout of catan_head_fwd (include/catan_hip.h), cached on the module and re-packed - IN
     PLACE, a captured hipGraph holds the buffers' addresses - when a parameter changed.  trunk_dim: the columns of mlp_1's input

@@ -163,6 +163,8 @@ class _TileEncoder(nn.Module):
     def forward(self, tiles):
         if nn_kernels.tile_encoder_supported(self, tiles):           # inference on the GPU: the whole encoder in one kernel
             return nn_kernels.tile_encoder_forward(self, tiles)
+        if nn_kernels.tile_encoder_train_supported(self, tiles):     # training on the GPU: the same kernel, leaving what the backward reads
+            return nn_kernels.tile_encoder_train(self, tiles)
         w0 = self.first_layer.weight
         if tiles.is_cuda and tiles.shape[-1] % 8:                     # 60 features: zero-pad to 64 so the row kernels take the layer (as a
             pad = -tiles.shape[-1] % 8                                # strided 3-D F.linear it ran as a batched GEMM: 2.6 ms of a 55 ms step)

@@ -952,3 +952,54 @@ def test_fused_collector_bookkeeping_equals_the_tensor_form(hip_lib):
         assert a.env.invalid_action_count() == 0
         for c in cols:
             c.after_rollouts()
+
+
+def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
+    """The tile encoder's TRAINING forward as the one fused kernel that also leaves what the backward kernels read
+    (catan_tile_encoder_fwd_train + nn_kernels._TileEncoderTrain) against the unfused training path (one kernel per sub-layer,
+    autograd between them): same output within bf16 rounding, and every parameter's gradient as close to the fp32 gradient of
+    the same module as the unfused bf16 path's is.  1 037 boards take the library fall-backs of the row products, 14 518 boards
+    (275 842 token rows) the row kernels; ragged counts exercise partial groups of boards."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(0)
+    net = CatanPolicy().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    te = net.observation_module.tile_encoder
+    env = VecCatanEnv(1037, seed=3); env.random_rollout(0, 600)
+    f, _, _ = env.get_obs()
+    base = f[:, 18:18 + 1140].reshape(1037, 19, 60)
+    names = [n for n, _ in te.named_parameters()]
+
+    def run(tiles, mode):
+        for p in te.parameters():
+            p.grad = None
+        gout = torch.Generator(device="cuda").manual_seed(5)
+        if mode == "fp32":
+            out = te(tiles.float())
+        else:
+            monkeypatch.setenv("CATAN_TE_TRAIN_UNFUSED", "1" if mode == "unfused" else "0")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode == "fused")
+                out = te(tiles)
+        w = torch.randn(out.shape, device="cuda", generator=gout)
+        (out.float() * w).sum().backward()
+        return out.detach().float(), {n: p.grad.detach().float().clone() for n, p in te.named_parameters()}
+
+    for B in (9, 1037, 14518):
+        tiles = base.repeat((B + 1036) // 1037, 1, 1)[:B].contiguous()
+        o32, g32 = run(tiles, "fp32")
+        ou, gu = run(tiles, "unfused")
+        of, gf = run(tiles, "fused")
+        assert of.shape == (B, 475)
+        e_f, e_u = float((of - o32).abs().max()), float((ou - o32).abs().max())
+        assert e_f <= max(2.0 * e_u, 0.06), (B, e_f, e_u)
+        assert set(gf) == set(names)
+        for n in names:
+            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
+            d_f, d_u = float((gf[n] - g32[n]).norm()) / scale, float((gu[n] - g32[n]).norm()) / scale
+            assert d_f <= max(2.0 * d_u, 0.05), (B, n, d_f, d_u)
