@@ -94,6 +94,18 @@ int catan_masked_row_store(void* dst, const void* src, const int64_t* t, const u
  * -> float32 [rows][325], the layout `action_masks` has in RL/ppo/process_batch.py:96-104 */
 int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out_masks, catan_stream_t stream);
 
+/* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
+ * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
+ * catan_gather_rows: dst row j = src row idx[j]; rows of `row_bytes` (even) at any even address and pitch.
+ * catan_expand_rows: out row j = src row inv[j], rows of whole 16-byte pieces (a per-board result spread to the rows that show the board).
+ * catan_segment_sum_rows: its backward - out row u = the sum (fp32, rounded to bf16) of the bf16 rows dy[order[j]], start[u] <= j <
+ * start[u + 1]; start has segments + 1 entries; dy's rows lie dy_pitch_bytes apart (a column window of a wider gradient). */
+int catan_gather_rows(const void* src, int64_t src_pitch_bytes, const int64_t* idx, int64_t n, void* dst, int64_t dst_pitch_bytes, int64_t row_bytes,
+                      catan_stream_t stream);
+int catan_expand_rows(const void* src, const int64_t* inv, int64_t n, void* out, int64_t row_bytes, catan_stream_t stream);
+int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t* order, const int64_t* start, int64_t segments, void* out, int64_t row_bytes,
+                           catan_stream_t stream);
+
 /* The per-game bookkeeping of GamesAndPoliciesManager.gather_rollouts (RL/ppo/game_manager.py:69-140) for all games at once, two
  * launches per env iteration (settlers_of_catan_rl_amd/rollout.py describes the four per-game counters that stand for the
  * reference's Python lists).  pre: a_env int32 [n][18] = the actions for catan_step, with the no-op type for frozen games (n_obs =
@@ -316,8 +328,9 @@ typedef struct catan_te_saves {
     void* xfin;         /* [64]  last layer's output */
     void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */
 } catan_te_saves_t;
-int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, const catan_te_saves_t* saves, int64_t boards,
-                                 catan_stream_t stream);
+/* out_pitch: elements between two boards' rows of `out` (>= 475; the columns beyond 475 are not written) */
+int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, const catan_te_saves_t* saves,
+                                 int64_t boards, catan_stream_t stream);
 
 /* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
  * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.

@@ -99,6 +99,9 @@ _SIGS = {
     "catan_expand_masks": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "catan_masks_packed_copy": (C.c_int, [_vp, _vp, _vp]),
     "catan_masked_row_store": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
+    "catan_gather_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp]),
+    "catan_expand_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
+    "catan_segment_sum_rows": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_collector_pre": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "catan_collector_post": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 21),
     "catan_deciding_seat": (C.c_int, [_vp, _vp, _vp]),
@@ -144,7 +147,7 @@ _SIGS = {
     "catan_tile_encoder_weight_elems": (C.c_int32, []),
     "catan_tile_encoder_vec_elems": (C.c_int32, []),
     "catan_tile_encoder_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
-    "catan_tile_encoder_fwd_train": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_tile_encoder_fwd_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_head_weight_elems": (C.c_int32, []),
     "catan_head_vec_elems": (C.c_int32, []),
     "catan_head_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),

@@ -15,6 +15,7 @@
 #include "catan_tile_encoder.hip"
 #include "catan_heads.hip"
 #include "catan_collector.hip"
+#include "catan_rows.hip"
 
 using namespace catan;
 
@@ -943,6 +944,37 @@ int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc,
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_gather_rows(const void* src, int64_t src_pitch_bytes, const int64_t* idx, int64_t n, void* dst, int64_t dst_pitch_bytes, int64_t row_bytes,
+                      catan_stream_t stream) {
+    if (!src || !idx || !dst || n <= 0 || row_bytes <= 0 || (row_bytes & 1) || row_bytes > (1 << 30) || (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)src_pitch_bytes | (uintptr_t)dst_pitch_bytes) & 1))
+        return fail(CATAN_EINVAL, "catan_gather_rows: rows are an even number of bytes at even addresses");
+    const long nb = n < 16384 ? n : 16384;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned char*)src, (long)src_pitch_bytes, (const long long*)idx, (long)n,
+                       (unsigned char*)dst, (long)dst_pitch_bytes, (int)row_bytes);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_expand_rows(const void* src, const int64_t* inv, int64_t n, void* out, int64_t row_bytes, catan_stream_t stream) {
+    if (!src || !inv || !out || n <= 0 || row_bytes <= 0 || (row_bytes & 15) || (((uintptr_t)src | (uintptr_t)out) & 15))
+        return fail(CATAN_EINVAL, "catan_expand_rows: rows are whole 16-byte pieces at 16-byte aligned addresses");
+    const int chunks = (int)(row_bytes / 16);
+    const long total = n * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;
+    hipLaunchKernelGGL(k_expand_rows16, dim3((unsigned)nb), dim3(256), 0, S(stream), (const uint4*)src, (const long long*)inv, (long)n, (uint4*)out, chunks);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t* order, const int64_t* start, int64_t segments, void* out, int64_t row_bytes,
+                           catan_stream_t stream) {
+    if (!dy || !order || !start || !out || segments <= 0 || row_bytes <= 0 || (row_bytes & 15) || (((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dy_pitch_bytes) & 15) ||
+        dy_pitch_bytes < row_bytes)
+        return fail(CATAN_EINVAL, "catan_segment_sum_rows: rows are whole 16-byte pieces at 16-byte aligned addresses");
+    const int chunks = (int)(row_bytes / 16);
+    const long total = segments * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;
+    hipLaunchKernelGGL(k_segment_sum16, dim3((unsigned)nb), dim3(256), 0, S(stream), (const uint4*)dy, (const long long*)order, (const long long*)start, (long)segments,
+                       (uint4*)out, chunks, (long)(dy_pitch_bytes / 16));
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,
@@ -1071,13 +1103,13 @@ int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* 
     TeSaves sv;
     memset(&sv, 0, sizeof sv);
     hipLaunchKernelGGL(k_tile_encoder_fwd<false>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
-                       (unsigned short*)out, (long)boards, sv);
+                       (unsigned short*)out, (long)boards, sv, (long)(TE_L * TE_OUT));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, const catan_te_saves_t* saves, int64_t boards,
-                                 catan_stream_t stream) {
-    if (!tiles || !weights || !vecs || !out || !saves || boards <= 0) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: bad arguments");
+int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, const catan_te_saves_t* saves,
+                                 int64_t boards, catan_stream_t stream) {
+    if (!tiles || !weights || !vecs || !out || !saves || boards <= 0 || out_pitch < TE_L * TE_OUT) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: bad arguments");
     static_assert(sizeof(catan_te_saves_t) == sizeof(TeSaves), "the header's struct is the kernel's");
     const void* const* ptrs = reinterpret_cast<const void* const*>(saves);
     for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++)
@@ -1086,7 +1118,7 @@ int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const f
     memcpy(&sv, saves, sizeof sv);
     long nb = (boards + TE_G - 1) / TE_G;
     hipLaunchKernelGGL(k_tile_encoder_fwd<true>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
-                       (unsigned short*)out, (long)boards, sv);
+                       (unsigned short*)out, (long)boards, sv, (long)out_pitch);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1,0 +1,61 @@
+// catan_rows.hip - row gathers of the PPO learner (RL/ppo/ppo.py:44-50: `obs_batch = [obs[i] for i in indices]`; here the rollout
+// lives in HBM as (T + 1, N, 1 787) bf16 rows of 3 574 bytes - 2-byte aligned - and a minibatch is 204 800 of its rows):
+//   k_gather_rows     dst[j] = src[idx[j]] for byte rows of any even length and alignment (the generic indexing kernel moves such rows
+//                     element by element: 580 us for the 180 000 x 2 280 B tile features of a minibatch, 410 MB each way)
+//   k_expand_rows16   out[j] = src[inv[j]] for rows that are whole 16-byte pieces (a per-board result spread to the rows showing it)
+//   k_segment_sum16   its backward: out[u] = sum of dy[order[j]] over start[u] <= j < start[u + 1] (the rows of board u), fp32 sums
+#pragma once
+
+namespace catan {
+
+__global__ __launch_bounds__(256) void k_gather_rows(const unsigned char* __restrict__ src, long src_pitch, const long long* __restrict__ idx, long n,
+                                                     unsigned char* __restrict__ dst, long dst_pitch, int row_bytes) {
+    const int words = row_bytes >> 2;                                   // whole 4-byte words; an odd 2-byte tail follows
+    for (long r = blockIdx.x; r < n; r += gridDim.x) {
+        const unsigned char* s = src + idx[r] * src_pitch;
+        unsigned char* d = dst + r * dst_pitch;
+        const bool s4 = (((unsigned long long)s) & 3) == 0, d4 = (((unsigned long long)d) & 3) == 0;
+        for (int w = threadIdx.x; w < words; w += 256) {
+            unsigned v;
+            if (s4) v = *reinterpret_cast<const unsigned*>(s + 4 * w);
+            else v = (unsigned)*reinterpret_cast<const unsigned short*>(s + 4 * w) | ((unsigned)*reinterpret_cast<const unsigned short*>(s + 4 * w + 2) << 16);
+            if (d4) *reinterpret_cast<unsigned*>(d + 4 * w) = v;
+            else { *reinterpret_cast<unsigned short*>(d + 4 * w) = (unsigned short)v; *reinterpret_cast<unsigned short*>(d + 4 * w + 2) = (unsigned short)(v >> 16); }
+        }
+        if ((row_bytes & 2) && threadIdx.x == 0) *reinterpret_cast<unsigned short*>(d + 4 * words) = *reinterpret_cast<const unsigned short*>(s + 4 * words);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_expand_rows16(const uint4* __restrict__ src, const long long* __restrict__ inv, long n, uint4* __restrict__ out, int chunks) {
+    const long total = n * chunks;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / chunks; const int c = (int)(e - r * chunks);
+        out[e] = src[inv[r] * chunks + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_segment_sum16(const uint4* __restrict__ dy, const long long* __restrict__ order, const long long* __restrict__ start, long U,
+                                                       uint4* __restrict__ out, int chunks, long dy_pitch) {      // dy_pitch: 16-byte pieces between two rows of dy
+    const long total = U * chunks;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long u = e / chunks; const int c = (int)(e - u * chunks);
+        const long j0 = start[u], j1 = start[u + 1];
+        float acc[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        for (long j = j0; j < j1; j++) {
+            const uint4 v = dy[order[j] * dy_pitch + c];
+            acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xFFFF0000u);
+            acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xFFFF0000u);
+            acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xFFFF0000u);
+        }
+        uint4 o;
+        if (j1 - j0 == 1) o = dy[order[j0] * dy_pitch + c];                  // (one row: its bits, not a round trip through fp32 - the same value)
+        else {
+            o.x = (unsigned)te_to_bf(acc[0]) | ((unsigned)te_to_bf(acc[1]) << 16); o.y = (unsigned)te_to_bf(acc[2]) | ((unsigned)te_to_bf(acc[3]) << 16);
+            o.z = (unsigned)te_to_bf(acc[4]) | ((unsigned)te_to_bf(acc[5]) << 16); o.w = (unsigned)te_to_bf(acc[6]) | ((unsigned)te_to_bf(acc[7]) << 16);
+        }
+        out[e] = o;
+    }
+}
+
+}  // namespace catan

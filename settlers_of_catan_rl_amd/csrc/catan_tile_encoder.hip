@@ -222,7 +222,7 @@ DEVI void te_dump(const unsigned short* lds, int pitch, unsigned short* __restri
 // tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
 template <bool SAVE>
 __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
-                                                          const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards, TeSaves sv) {
+                                                          const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards, TeSaves sv, long out_pitch) {
     __shared__ __attribute__((aligned(16))) unsigned short X[TE_ROWS * TE_PX];     // residual stream
     __shared__ __attribute__((aligned(16))) unsigned short Nb[TE_ROWS * TE_PX];    // LayerNorm output / attention output / staged input
     __shared__ __attribute__((aligned(16))) unsigned short Q[TE_ROWS * TE_PQ];     // Q | K | V; the FFN hidden layer; the output projection
@@ -310,9 +310,10 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         te_layer_norm<TE_OUT, true>(Q, TE_PX, Q, TE_PX, V + TE_VP + 32, V + TE_VP + 64, tid);
         __syncthreads();
+        // (out_pitch elements per board, 19 x 25 of them written: the training path pads the board rows to whole 16-byte pieces)
         for (int c = tid; c < nb * TE_L * TE_OUT; c += TE_THREADS) {
-            const int t = c / TE_OUT, i = c - t * TE_OUT;
-            out[(g0 * TE_L + t) * TE_OUT + i] = Q[t * TE_PX + i];
+            const int t = c / TE_OUT, i = c - t * TE_OUT, g = t / TE_L;
+            out[(g0 + g) * out_pitch + (t - g * TE_L) * TE_OUT + i] = Q[t * TE_PX + i];
         }
     }
 }

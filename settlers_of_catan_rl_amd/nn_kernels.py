@@ -439,6 +439,61 @@ def tile_encoder_forward(te, tiles):
     return out
 
 
+def gather_rows(src, idx, out=None):
+    """src[idx] for a row-major tensor whose rows are contiguous (any row pitch: a column window of a wider matrix is fine) - into
+    `out` (same row shape, contiguous rows, any pitch) or a new contiguous tensor.  catan_gather_rows on the GPU for rows of an
+    even number of bytes (the bf16 rollout rows are only 2-byte aligned: the generic indexing kernel moves them per element)."""
+    row_shape = src.shape[1:]
+    cols = 1
+    for d in row_shape:
+        cols *= d
+    ok = (src.is_cuda and idx.dtype == torch.int64 and idx.dim() == 1 and idx.numel() > 0 and (cols * src.element_size()) % 2 == 0
+          and src[0].is_contiguous() and (out is None or (out[0].is_contiguous() and out.shape[1:] == row_shape and out.dtype == src.dtype)))
+    if not ok:
+        if out is None:
+            return src[idx]
+        out.copy_(src[idx])
+        return out
+    if out is None:
+        out = torch.empty((idx.numel(),) + tuple(row_shape), dtype=src.dtype, device=src.device)
+    es = src.element_size()
+    _lib.check(_lib.lib().catan_gather_rows(_ptr(src), src.stride(0) * es, _ptr(idx.contiguous()), idx.numel(), _ptr(out), out.stride(0) * es, cols * es, _stream()))
+    return out
+
+
+class _ExpandRows(torch.autograd.Function):
+    """out[j] = src[inv[j]] (a per-board result spread to the rows that show the board); backward: the rows' gradients summed per
+    board in fp32 over the board's rows (order / start: the rows sorted by board and where each board's run starts) - autograd's
+    indexing backward sorts the 204 800 indices again in every step and accumulates through index_put (0.87 ms)."""
+
+    @staticmethod
+    def forward(ctx, src, inv, order, start):
+        src = src.contiguous()
+        out = torch.empty((inv.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
+        _lib.check(_lib.lib().catan_expand_rows(_ptr(src), _ptr(inv), inv.numel(), _ptr(out), src.shape[1] * src.element_size(), _stream()))
+        ctx.save_for_backward(order, start)
+        ctx.U = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        order, start = ctx.saved_tensors
+        if dy.stride(1) != 1 or (dy.stride(0) * 2) % 16 or dy.data_ptr() % 16:          # (a column window of a wider gradient is taken in place)
+            dy = dy.contiguous()
+        dsrc = torch.empty((ctx.U, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+        _lib.check(_lib.lib().catan_segment_sum_rows(_ptr(dy), dy.stride(0) * 2, _ptr(order), _ptr(start), ctx.U, _ptr(dsrc), dy.shape[1] * 2, _stream()))
+        return dsrc, None, None, None
+
+
+def expand_rows(src, inv, order=None, start=None):
+    """src [U, W] -> [len(inv), W]; with (order, start) of the rows' boards and bf16 rows of whole 16-byte pieces on the GPU: the
+    kernels above, else plain indexing"""
+    if (order is not None and start is not None and src.is_cuda and src.dim() == 2 and src.dtype == torch.bfloat16 and (src.shape[1] * 2) % 16 == 0
+            and inv.dtype == torch.int64 and start.numel() == src.shape[0] + 1):
+        return _ExpandRows.apply(src, inv.contiguous(), order.contiguous(), start.contiguous())
+    return src[inv]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The tile encoder's TRAINING forward as the one fused kernel (k_tile_encoder_fwd<SAVE>): the minibatch steps of a PPO update
 # spent 5.5 of their 41 ms in the encoder's forward as ~20 kernels that each stream a [boards x 19, 64..192] activation tensor
@@ -487,7 +542,7 @@ def _ln_backward(x, w, b, dy, eps, relu, dres=None):
 
 class _TileEncoderTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tiles, te, *params):
+    def forward(ctx, tiles, te, out_cols, *params):
         import ctypes as C
         wts, vecs = tile_encoder_pack(te)
         x = _aligned(tiles.detach().to(torch.bfloat16))
@@ -499,8 +554,9 @@ class _TileEncoderTrain(torch.autograd.Function):
             saves.append(buf[off:off + T * w].view(T, w))
             off += T * w
         ptrs = (C.c_void_p * len(saves))(*[t.data_ptr() for t in saves])
-        out = torch.empty((B, 19 * 25), dtype=torch.bfloat16, device=x.device)
-        _lib.check(_lib.lib().catan_tile_encoder_fwd_train(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), C.cast(ptrs, C.c_void_p), B, _stream()))
+        # out_cols > 475: board rows padded with zero columns to whole 16-byte pieces (nn_kernels.expand_rows, aligned GEMM operands)
+        out = (torch.empty if out_cols == 475 else torch.zeros)((B, out_cols), dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.lib().catan_tile_encoder_fwd_train(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), out_cols, C.cast(ptrs, C.c_void_p), B, _stream()))
         ctx.save_for_backward(*saves, *params)
         ctx.eps = float(te.norm.eps)
         ctx.B = B
@@ -515,7 +571,7 @@ class _TileEncoderTrain(torch.autograd.Function):
         T = B * 19
         g = [None] * len(P)
         with torch.autocast("cuda", enabled=False):
-            d = _aligned(dout.reshape(T, 25).to(bf))
+            d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
             dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
             dx = _rows_product(dp, P[36].to(bf).t().contiguous())                         # [T, 64]
             g[36], g[37] = _wgrad(sv["xfin"], dp, True)
@@ -541,7 +597,7 @@ class _TileEncoderTrain(torch.autograd.Function):
             da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
             dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
             g[0] = dw0[:, :60]
-        return (None, None) + tuple(g)
+        return (None, None, None) + tuple(g)
 
 
 def tile_encoder_train_supported(te, tiles):
@@ -559,9 +615,9 @@ def tile_encoder_train_supported(te, tiles):
             and all(abs(m.eps - 1e-5) < 1e-12 for m in [te.norm, te.norm_2] + [s.norm for l in te.encoder_layers for s in l.sublayers]))
 
 
-def tile_encoder_train(te, tiles):
-    """tiles [B, 19, 60] -> bf16 [B, 475] with gradients to the encoder's parameters (see _TileEncoderTrain)"""
-    return _TileEncoderTrain.apply(tiles, te, *_te_params(te))
+def tile_encoder_train(te, tiles, out_cols=475):
+    """tiles [B, 19, 60] -> bf16 [B, out_cols >= 475] (zero beyond column 475) with gradients to the encoder's parameters (see _TileEncoderTrain)"""
+    return _TileEncoderTrain.apply(tiles, te, int(out_cols), *_te_params(te))
 
 
 def head_pack(head, trunk_dim):

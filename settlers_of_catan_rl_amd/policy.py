@@ -160,11 +160,13 @@ class _TileEncoder(nn.Module):
         self.norm_2 = nn.LayerNorm(dim)
         self.out_proj = _ortho_linear(dim, out_dim)
 
-    def forward(self, tiles):
+    def forward(self, tiles, out_cols=None):
+        """out_cols (training on the GPU only): the board rows zero-padded to that many columns (a multiple of 8: 16-byte rows)"""
         if nn_kernels.tile_encoder_supported(self, tiles):           # inference on the GPU: the whole encoder in one kernel
             return nn_kernels.tile_encoder_forward(self, tiles)
         if nn_kernels.tile_encoder_train_supported(self, tiles):     # training on the GPU: the same kernel, leaving what the backward reads
-            return nn_kernels.tile_encoder_train(self, tiles)
+            return nn_kernels.tile_encoder_train(self, tiles, 19 * self.out_proj.out_features if out_cols is None else out_cols)
+        assert out_cols is None
         w0 = self.first_layer.weight
         if tiles.is_cuda and tiles.shape[-1] % 8:                     # 60 features: zero-pad to 64 so the row kernels take the layer (as a
             pad = -tiles.shape[-1] % 8                                # strided 3-D F.linear it ran as a batched GEMM: 2.6 ms of a 55 ms step)
@@ -266,7 +268,14 @@ class _ObservationModule(nn.Module):
         cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
         br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
         with br.on(1):
-            if tile_dedupe is not None:
+            te_pad = 0
+            tiles_u = None if tile_dedupe is None else tile_dedupe[0].reshape(-1, 19, 60)
+            if tile_dedupe is not None and len(tile_dedupe) == 4 and nn_kernels.tile_encoder_train_supported(self.tile_encoder, tiles_u):
+                # per distinct board, its 475 columns padded to 480 (960-byte rows), spread to the rows showing the board by
+                # nn_kernels.expand_rows, whose backward sums the rows' gradients per board
+                te = nn_kernels.expand_rows(self.tile_encoder(tiles_u, out_cols=480), *tile_dedupe[1:])
+                te_pad = te.shape[1] - 475
+            elif tile_dedupe is not None:
                 te = self.tile_encoder(tile_dedupe[0].reshape(-1, 19, 60))[tile_dedupe[1]]    # (indexing: its backward sums per board by sorting - index_select's uses bf16 atomics, twice as slow)
             else:
                 te = self.tile_encoder(tiles) if tile_features is None else tile_features
@@ -280,6 +289,12 @@ class _ObservationModule(nn.Module):
         op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
                                        self.dev_card_embedding, self.played_card_mha)
         br.join()
+        if te_pad:
+            # (the concatenation is 992 wide - the reference's 987 columns and the 5 zero ones: one library product, as _lin_parts
+            # decides for these widths; the pad columns meet zero weights)
+            w = self.final_layer.weight
+            wp = torch.cat((w[:, :475], w.new_zeros((w.shape[0], te_pad)), w[:, 475:]), 1)
+            return _ln(self.norm, F.linear(torch.cat((te, cp, op.reshape(B, 3 * 128)), -1), wp, self.final_layer.bias), relu=True)
         return _ln(self.norm, _lin_parts((te, cp, op.reshape(B, 3 * 128)), self.final_layer.weight, self.final_layer.bias), relu=True)
 
 

@@ -19,6 +19,7 @@ import torch
 
 from . import dist as cdist
 from . import ppo as ppo_kernels
+from . import nn_kernels
 
 
 class PPOConfig(object):
@@ -124,7 +125,10 @@ class PPOTrainer(object):
         uq.scatter_(1, pos, srt)                                     # (duplicates write the same value)
         inv = torch.empty_like(pos)
         inv.scatter_(1, order, pos)
-        return [(uq[k, :counts[k]], inv[k]) for k in range(num_mini_batch)]
+        # where each board's run starts among the rows sorted by board (for the per-board sums of the backward: nn_kernels.expand_rows)
+        start = torch.full((num_mini_batch, mbs + 1), mbs, dtype=torch.int64, device=ids.device)
+        start[:, :mbs].scatter_reduce_(1, pos, torch.arange(mbs, device=ids.device).expand(num_mini_batch, mbs), "amin", include_self=True)
+        return [(uq[k, :counts[k]], inv[k], order[k], start[k, :counts[k] + 1]) for k in range(num_mini_batch)]
 
     @torch.no_grad()
     def compute_values(self, st):
@@ -219,14 +223,14 @@ class PPOTrainer(object):
                                                              st.unpack_action_masks(amask_all[idx]), acts_all[idx],
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
                     elif dedupe:
-                        uqk, invk = boards[bi]
+                        uqk, invk, orderk, startk = boards[bi]
                         # the rows' observations WITHOUT their tile features (64 % of a row: they come per distinct board below)
                         fm = torch.empty((idx.numel(), f_all.shape[1]), dtype=f_all.dtype, device=dev)
-                        fm[:, :o] = f_all[:, :o][idx]
-                        fm[:, o + 1140:] = f_all[:, o + 1140:][idx]
-                        v, lp, ent = pol.evaluate_actions(cast(fm), lists_all[idx], lens_all[idx].long(),
+                        nn_kernels.gather_rows(f_all[:, :o], idx, out=fm[:, :o])
+                        nn_kernels.gather_rows(f_all[:, o + 1140:], idx, out=fm[:, o + 1140:])
+                        v, lp, ent = pol.evaluate_actions(cast(fm), nn_kernels.gather_rows(lists_all, idx), lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx],
-                                                          tile_dedupe=(cast(tiles_all[first_rows[uqk]]), invk))
+                                                          tile_dedupe=(cast(nn_kernels.gather_rows(tiles_all, first_rows[uqk])), invk, orderk, startk))
                     else:
                         v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx])

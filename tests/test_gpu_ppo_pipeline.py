@@ -908,10 +908,15 @@ def test_minibatch_steps_encode_distinct_boards_only(hip_lib):
                 o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
                 tiles = st.obs_f.reshape((T + 1) * N, -1)[:, o:o + 1140]
                 mbs = T * N // 2
-                for k, (uq, inv) in enumerate(tr.minibatch_boards(board_of_row[:T * N], perm, 2, mbs)):
+                for k, (uq, inv, order, start) in enumerate(tr.minibatch_boards(board_of_row[:T * N], perm, 2, mbs)):
                     idx = perm[k * mbs:(k + 1) * mbs]
                     assert torch.equal(tiles[first_rows[uq]][inv], tiles[idx])          # every row gets exactly its own board
                     assert uq.numel() < 0.97 * mbs and torch.equal(torch.unique(uq), uq)
+                    # the rows sorted by board, and where each board's run starts: run u holds exactly the rows of board u
+                    assert start.numel() == uq.numel() + 1 and int(start[0]) == 0 and int(start[-1]) == mbs and bool((start[1:] > start[:-1]).all())
+                    assert torch.equal(torch.sort(order)[0], torch.arange(mbs, device="cuda"))
+                    run_of = torch.repeat_interleave(torch.arange(uq.numel(), device="cuda"), start[1:] - start[:-1])
+                    assert torch.equal(inv[order], run_of)
             losses = tr.update(st)
             res[dedupe] = (losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
         for a, b in zip(res[True][0], res[False][0]):
@@ -1003,3 +1008,40 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
             d_f, d_u = float((gf[n] - g32[n]).norm()) / scale, float((gu[n] - g32[n]).norm()) / scale
             assert d_f <= max(2.0 * d_u, 0.05), (B, n, d_f, d_u)
+
+
+def test_row_gather_expand_and_segment_sum_kernels(hip_lib):
+    """catan_gather_rows / catan_expand_rows / catan_segment_sum_rows against torch indexing: 2-byte aligned rows of odd word counts
+    taken out of a wider matrix (the rollout's 3 574-byte bf16 rows), into a column window of a wider destination; the per-board
+    sums of the backward against index_add in fp32."""
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator(device="cuda").manual_seed(0)
+    src = torch.randn(5000, 1787, device="cuda", generator=g).to(torch.bfloat16)
+    idx = torch.randint(0, 5000, (3001,), device="cuda", generator=g)
+    for c0, c1 in ((18, 1158), (0, 18), (1158, 1787), (1, 1786), (0, 1787)):
+        got = nn_kernels.gather_rows(src[:, c0:c1], idx)
+        assert got.is_contiguous() and torch.equal(got, src[:, c0:c1][idx]), (c0, c1)
+    out = torch.zeros(3001, 1787, dtype=torch.bfloat16, device="cuda")
+    nn_kernels.gather_rows(src[:, 1158:], idx, out=out[:, 1158:])
+    assert torch.equal(out[:, 1158:], src[:, 1158:][idx]) and not bool(out[:, :1158].any())
+    i8 = torch.randint(-3, 9, (5000, 5, 25), device="cuda", generator=g).to(torch.int8)[:, :, :24]      # rows of 5 x 24 bytes with pitch 125: not contiguous rows
+    assert torch.equal(nn_kernels.gather_rows(i8, idx), i8[idx])                                          # (falls back)
+    i8c = torch.randint(-3, 9, (5000, 5, 26), device="cuda", generator=g).to(torch.int8)
+    assert torch.equal(nn_kernels.gather_rows(i8c, idx), i8c[idx])
+    f32 = torch.randn(5000, 1787, device="cuda", generator=g)
+    assert torch.equal(nn_kernels.gather_rows(f32[:, 18:1158], idx), f32[:, 18:1158][idx])
+    # expand + per-board sums
+    U, B, W = 700, 4000, 512
+    inv = torch.randint(0, U, (B,), device="cuda", generator=g)
+    inv[:U] = torch.arange(U, device="cuda")                                # every board shown by at least one row
+    order = torch.argsort(inv, stable=True)
+    counts = torch.bincount(inv, minlength=U)
+    start = torch.cat((torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(counts, 0)))
+    srcu = torch.randn(U, W, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    y = nn_kernels.expand_rows(srcu, inv, order, start)
+    assert type(y.grad_fn).__name__ == "_ExpandRowsBackward" and torch.equal(y, srcu[inv])
+    dy = torch.randn(B, W, device="cuda", generator=g).to(torch.bfloat16)
+    (gsrc,) = torch.autograd.grad(y, srcu, dy)
+    ref = torch.zeros(U, W, device="cuda").index_add_(0, inv, dy.float())
+    assert gsrc.dtype == torch.bfloat16 and float((gsrc.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert torch.equal(gsrc[counts == 1], dy[order[start[:-1][counts == 1]]])  # single-row boards: the row's own bits

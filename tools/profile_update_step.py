@@ -43,9 +43,14 @@ for e in ops[:40]:
     print("%-40s dev %8.1f us/step  cpu %8.1f us/step  x%.0f" % (e.key[:40], e.self_device_time_total / NS, e.self_cpu_time_total / NS, e.count / NS))
 
 print("---- copies / fills / gathers by shape (device us per step)")
-by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::fill_", "aten::index", "aten::cat", "aten::add_", "aten::add")]
+by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::fill_", "aten::index", "aten::cat", "aten::add_", "aten::add", "aten::mm", "aten::addmm")]
 by.sort(key=lambda e: -e.self_device_time_total)
-for e in by[:40]:
+for k in ("aten::copy_", "aten::fill_", "aten::index", "aten::cat", "aten::add_", "aten::add", "aten::mm", "aten::addmm"):
+    es = [e for e in by if e.key == k]
+    small = [e for e in es if e.self_device_time_total / max(1, e.count) < 8.0]
+    print("%-12s total %8.1f us/step in %5.1f calls; of which launches under 8 us: %8.1f us/step in %5.1f calls" % (
+        k, sum(e.self_device_time_total for e in es) / NS, sum(e.count for e in es) / NS, sum(e.self_device_time_total for e in small) / NS, sum(e.count for e in small) / NS))
+for e in by[:60]:
     print("%-14s %8.1f us/step x%.0f  %s" % (e.key, e.self_device_time_total / NS, e.count / NS, str(e.input_shapes)[:150]))
 
 print("---- the net's own autograd functions by shape (device us per step)")
