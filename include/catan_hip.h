@@ -94,6 +94,15 @@ int catan_masked_row_store(void* dst, const void* src, const int64_t* t, const u
  * -> float32 [rows][325], the layout `action_masks` has in RL/ppo/process_batch.py:96-104 */
 int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words, float* out_masks, catan_stream_t stream);
 
+/* Backward of the tile encoder's pointwise sub-layer x_out = x + linear2(relu(linear1(LayerNorm(x)))) (width 64, hidden 128) for
+ * everything but the weight gradients, one pass over the token rows (csrc/catan_te_bwd.hip).  bf16 row-major: dx [rows][64] = the
+ * gradient of x_out; h [rows][128] = relu(linear1(.)); x [rows][64] = the LayerNorm's input; w2t [128][64] = linear2.weight^T;
+ * w1t [64][128] = linear1.weight^T; ln_w float [64].  Out: dh [rows][128] = the gradient of linear1's output (catan_linear_wgrad
+ * takes it for both weight gradients), dx_out [rows][64] = the gradient of x (LayerNorm backward + the residual dx); dln_w / dln_b
+ * float [64] are ACCUMULATED into (zero first). */
+int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dh, void* dx_out,
+                     float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
+
 /* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
  * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
  * catan_gather_rows: dst row j = src row idx[j]; rows of `row_bytes` (even) at any even address and pitch.

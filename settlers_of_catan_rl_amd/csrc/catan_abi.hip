@@ -16,6 +16,7 @@
 #include "catan_heads.hip"
 #include "catan_collector.hip"
 #include "catan_rows.hip"
+#include "catan_te_bwd.hip"
 
 using namespace catan;
 
@@ -972,6 +973,18 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
     const long total = segments * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;
     hipLaunchKernelGGL(k_segment_sum16, dim3((unsigned)nb), dim3(256), 0, S(stream), (const uint4*)dy, (const long long*)order, (const long long*)start, (long)segments,
                        (uint4*)out, chunks, (long)(dy_pitch_bytes / 16));
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dh, void* dx_out,
+                     float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
+    if (!dx || !h || !x || !w2t || !w1t || !ln_w || !dh || !dx_out || !dln_w || !dln_b || rows <= 0 ||
+        (((uintptr_t)dx | (uintptr_t)h | (uintptr_t)x | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dh | (uintptr_t)dx_out) & 15))
+        return fail(CATAN_EINVAL, "catan_ffn_bwd_dx: null or misaligned argument");
+    long nb = ((rows + 15) / 16 + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_ffn_bwd_dx, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dh, (unsigned short*)dx_out, dln_w, dln_b, (long)rows);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1,0 +1,178 @@
+// catan_te_bwd.hip - backward of the tile encoder's pointwise sub-layer  x_out = x + linear2(relu(linear1(LayerNorm(x))))
+// (reference RL/models/tile_encoder.py:41-91 via its transformer layers) for everything but the weight gradients, in ONE pass
+// over the token rows.  As separate kernels - (dX W2) masked by the ReLU, (dH W1), LayerNorm backward + residual - the chain
+// moved 1 152 bf16 elements per token through HBM (dH written and read twice, dN written and read); here a wave takes 16 tokens
+// through the whole chain: reads dX [64], the ReLU output H [128] and the LayerNorm input X [64], writes dH [128] (the two
+// weight-gradient kernels read it) and the gradient of X [64].
+//   dH^T = W2^T . dX^T      transposed product (weights as the A operand): a lane ends up with dH[token l % 16][16 j + 4 (l / 16) + i],
+//                           which - masked by H > 0 and rounded to bf16 - IS the A operand of the next product once its contraction
+//                           index is permuted (as k_head_fwd chains its two products)
+//   dN  = dH . W1           B fragments = two 8-byte loads of W1^T in the same permuted order
+//   dX' = LayerNorm'(dN) + dX   per-row statistics by xor-shuffles over the 16 lanes that hold a row; LayerNorm weight / bias gradients
+//                           accumulate in registers over the wave's tiles and leave as one atomic per column and workgroup
+// Rounding follows the unfused chain: dH, dN and the LayerNorm part of dX' are rounded to bf16 where the separate kernels stored them.
+#pragma once
+
+namespace catan {
+
+constexpr int FB_P = 72;          // LDS row pitch of the 16 x 64 tiles and of W2^T (bf16 elements): 144 B
+constexpr int FB_P1 = 136;        // ... of W1^T: 272 B
+
+__global__ __launch_bounds__(256) void k_ffn_bwd_dx(const unsigned short* __restrict__ dx, const unsigned short* __restrict__ h, const unsigned short* __restrict__ x,
+                                                    const unsigned short* __restrict__ w2t, const unsigned short* __restrict__ w1t, const float* __restrict__ lnw,
+                                                    float eps, unsigned short* __restrict__ dh, unsigned short* __restrict__ dxo, float* __restrict__ dlnw,
+                                                    float* __restrict__ dlnb, long rows) {
+    __shared__ __attribute__((aligned(16))) unsigned short sD[4][16 * FB_P];     // the tile's dX rows
+    __shared__ __attribute__((aligned(16))) unsigned short sX[4][16 * FB_P];     // the tile's X rows; then the outgoing dX' rows
+    __shared__ float sG[2][64];
+    __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * FB_P];
+    __shared__ __attribute__((aligned(16))) unsigned short sW1[64 * FB_P1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+    if (tid < 128) (&sG[0][0])[tid] = 0.f;
+    // weights in LDS (W2^T [128][64], W1^T [64][128]: 36 KB): as register fragments they cost 128 VGPRs and left one wave per SIMD,
+    // every global access of a tile fully exposed; from LDS a fragment is one 16-byte (two 8-byte) read per use
+    for (int c = tid; c < 128 * 8; c += 256) {
+        const int n = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(sW2 + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(w2t + n * 64 + ch * 8);
+    }
+    for (int c = tid; c < 64 * 16; c += 256) {
+        const int n = c >> 4, ch = c & 15;
+        *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8);
+    }
+    __syncthreads();
+    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    unsigned short* tD = sD[wave]; unsigned short* tX = sX[wave];
+    const long tiles = (rows + 15) / 16;
+    // the NEXT tile's rows are requested before the current tile is computed (register double buffer)
+    uint4 vd[2], vx[2];
+    uint2 hn[8];
+    auto request = [&](long tile) {
+        const long r0 = tile * 16;
+        const long row = r0 + lr < rows ? r0 + lr : rows - 1;                  // rows past the end repeat the last one; nothing is stored for them
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            const long gr = r0 + rr < rows ? r0 + rr : rows - 1;
+            vd[q] = *reinterpret_cast<const uint4*>(dx + gr * 64 + ch * 8);
+            vx[q] = *reinterpret_cast<const uint4*>(x + gr * 64 + ch * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) hn[j] = *reinterpret_cast<const uint2*>(h + row * 128 + 16 * j + 4 * g);     // the ReLU outputs at this lane's dH positions
+    };
+    const long step = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    if (tile < tiles) request(tile);
+    for (; tile < tiles; tile += step) {
+        const long r0 = tile * 16;
+        const long row = r0 + lr < rows ? r0 + lr : rows - 1;
+        uint2 hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) hv[j] = hn[j];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            *reinterpret_cast<uint4*>(tD + rr * FB_P + ch * 8) = vd[q];
+            *reinterpret_cast<uint4*>(tX + rr * FB_P + ch * 8) = vx[q];
+        }
+        if (tile + step < tiles) request(tile + step);
+        __builtin_amdgcn_wave_barrier();
+        // ---- dH^T = W2^T . dX^T, masked by H > 0
+        bf16x8_t db[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) db[s] = *reinterpret_cast<const bf16x8_t*>(tD + lr * FB_P + 32 * s + 8 * g);
+        unsigned hp[4][4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW2 + (16 * j + lr) * FB_P + 32 * s + 8 * g), db[s], c, 0, 0, 0);
+            const unsigned h01 = hv[j].x, h23 = hv[j].y;
+            // (H is a ReLU output: > 0 <=> its bf16 bits are neither +0 nor negative; the unfused kernel tests the value)
+            const unsigned d0 = __uint_as_float(h01 << 16) > 0.f ? te_to_bf(c[0]) : 0u, d1 = __uint_as_float(h01 & 0xFFFF0000u) > 0.f ? te_to_bf(c[1]) : 0u;
+            const unsigned d2 = __uint_as_float(h23 << 16) > 0.f ? te_to_bf(c[2]) : 0u, d3 = __uint_as_float(h23 & 0xFFFF0000u) > 0.f ? te_to_bf(c[3]) : 0u;
+            const unsigned p0 = d0 | (d1 << 16), p1 = d2 | (d3 << 16);
+            hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
+            if (r0 + lr < rows) *reinterpret_cast<uint2*>(dh + row * 128 + 16 * j + 4 * g) = make_uint2(p0, p1);
+        }
+        // ---- dN = dH . W1: lane holds rows 4 g + r, column 16 t + lr
+        float dn[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                uint4 au; au.x = hp[s][0]; au.y = hp[s][1]; au.z = hp[s][2]; au.w = hp[s][3];
+                const unsigned short* wr = sW1 + (16 * t + lr) * FB_P1 + 32 * s + 4 * g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(wr), hi = *reinterpret_cast<const uint2*>(wr + 16);
+                uint4 bu; bu.x = lo.x; bu.y = lo.y; bu.z = hi.x; bu.w = hi.y;
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&au), *reinterpret_cast<const bf16x8_t*>(&bu), c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) dn[t][r] = hd_bf(c[r]);
+        }
+        // ---- LayerNorm backward over the rows 4 g + r (their 64 columns sit in the 16 lanes of the quarter wave x 4 tiles) + the residual dX
+        float xv[4][4], res[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xv[t][r] = te_bf(tX[(4 * g + r) * FB_P + 16 * t + lr]);
+                res[t][r] = te_bf(tD[(4 * g + r) * FB_P + 16 * t + lr]);
+            }
+        __builtin_amdgcn_wave_barrier();                                       // (tX is overwritten with the result below)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float sum = xv[0][r] + xv[1][r] + xv[2][r] + xv[3][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { xv[t][r] -= mean; sq += xv[t][r] * xv[t][r]; }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+            const bool live = r0 + 4 * g + r < rows;
+            float gw[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                xv[t][r] *= rstd;                                              // x_hat
+                const float gy = live ? dn[t][r] : 0.f;
+                aw[t] += gy * xv[t][r]; ab[t] += gy;
+                gw[t] = gy * wl[t];
+                s1 += gw[t]; s2 += gw[t] * xv[t][r];
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                tX[(4 * g + r) * FB_P + 16 * t + lr] = te_to_bf(hd_bf(rstd * (gw[t] - m1 - xv[t][r] * m2)) + res[t][r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            if (r0 + rr < rows) *reinterpret_cast<uint4*>(dxo + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(tX + rr * FB_P + ch * 8);
+        }
+        __builtin_amdgcn_wave_barrier();                                       // (the next tile's staging overwrites tD / tX)
+    }
+    // ---- LayerNorm weight / bias gradients: over the four row groups of the wave, the waves of the workgroup, then one atomic per column
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        aw[t] += __shfl_xor(aw[t], 16); aw[t] += __shfl_xor(aw[t], 32);
+        ab[t] += __shfl_xor(ab[t], 16); ab[t] += __shfl_xor(ab[t], 32);
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { atomicAdd(&sG[0][16 * t + lr], aw[t]); atomicAdd(&sG[1][16 * t + lr], ab[t]); }
+    }
+    __syncthreads();
+    if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
+}
+
+}  // namespace catan

@@ -2,6 +2,7 @@
 (csrc/catan_nn.hip).  torch is plumbing: tensors, streams, autograd registration."""
 import ctypes as C
 
+import os
 import torch
 
 from . import _lib
@@ -579,11 +580,19 @@ class _TileEncoderTrain(torch.autograd.Function):
                 b = 4 + 16 * l
                 xin, n1, qkv, o, xmid, n2, h = (sv[k + str(l)] for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
                 w1, w2 = P[b + 12].to(bf), P[b + 14].to(bf)
-                dh = _rows_product(dx, w2.t().contiguous(), h, MODE_RELU_MASK)            # (dx @ w2) where h > 0
+                if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
+                    dh = _rows_product(dx, w2.t().contiguous(), h, MODE_RELU_MASK)        # (dx @ w2) where h > 0
+                    dn2 = _rows_product(dh, w1.t().contiguous())
+                    dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
+                else:                           # the same three steps in one pass over the rows (k_ffn_bwd_dx)
+                    dh, dxmid = torch.empty_like(h), torch.empty_like(xmid)
+                    dl = torch.zeros((2, 64), dtype=torch.float32, device=h.device)
+                    w2t, w1t, lw = w2.t().contiguous(), w1.t().contiguous(), P[b + 10].detach().float().contiguous()     # (named: alive until the launch is queued)
+                    _lib.check(_lib.lib().catan_ffn_bwd_dx(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dh), _ptr(dxmid),
+                                                           _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
+                    g[b + 10], g[b + 11] = dl[0], dl[1]
                 g[b + 14], g[b + 15] = _wgrad(h, dx, True)
                 g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
-                dn2 = _rows_product(dh, w1.t().contiguous())
-                dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
                 do = _rows_product(dxmid, P[b + 8].to(bf).t().contiguous())
                 g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
@@ -887,8 +896,9 @@ class _MaskedCategorical(torch.autograd.Function):
         logits, mask, action, lse, ent = ctx.saved_tensors
         B, K = logits.shape
         dlogits = torch.empty_like(logits)
+        dl, de = dlogp.float().contiguous(), dent.float().contiguous()        # (named: two temporaries would share one freed block)
         _lib.check(_lib.lib().catan_categorical_bwd(_ptr(logits), _ptr(mask), mask.stride(0), _ptr(action), _ptr(lse), _ptr(ent),
-                                                    _ptr(dlogp.float().contiguous()), _ptr(dent.float().contiguous()), _ptr(dlogits), B, K, _stream()))
+                                                    _ptr(dl), _ptr(de), _ptr(dlogits), B, K, _stream()))
         return dlogits, None, None, None
 
 

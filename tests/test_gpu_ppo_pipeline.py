@@ -988,8 +988,9 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             out = te(tiles.float())
         else:
             monkeypatch.setenv("CATAN_TE_TRAIN_UNFUSED", "1" if mode == "unfused" else "0")
+            monkeypatch.setenv("CATAN_TE_BWD_UNFUSED", "1" if mode == "fused, backward in separate steps" else "0")
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode == "fused")
+                assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
         w = torch.randn(out.shape, device="cuda", generator=gout)
         (out.float() * w).sum().backward()
@@ -1000,7 +1001,11 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         o32, g32 = run(tiles, "fp32")
         ou, gu = run(tiles, "unfused")
         of, gf = run(tiles, "fused")
-        assert of.shape == (B, 475)
+        oc, gc = run(tiles, "fused, backward in separate steps")      # the pointwise sub-layer's backward as three kernels instead of k_ffn_bwd_dx
+        assert of.shape == (B, 475) and torch.equal(oc, of)
+        for n in names:
+            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
+            assert float((gf[n] - gc[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - gc[n]).norm()) / scale)
         e_f, e_u = float((of - o32).abs().max()), float((ou - o32).abs().max())
         assert e_f <= max(2.0 * e_u, 0.06), (B, e_f, e_u)
         assert set(gf) == set(names)
