@@ -103,6 +103,12 @@ int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words
 int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dh, void* dx_out,
                      float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
 
+/* The attention sub-layer's input side x_mid = x + out_proj(attention(qkv(LayerNorm(x)))) (width 64): the gradient of x from dqkv
+ * [rows][192] (catan_attention_bwd's output) - (dqkv . Wqkv) through the LayerNorm backward, plus the residual gradient dres = d(x_mid)
+ * [rows][64] - in one pass.  wt = Wqkv^T bf16 [64][192]; x [rows][64] = the LayerNorm's input; dln_w / dln_b float [64] ACCUMULATED into. */
+int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const void* wt, const float* ln_w, float eps, void* dx_out, float* dln_w, float* dln_b,
+                     int64_t rows, catan_stream_t stream);
+
 /* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
  * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
  * catan_gather_rows: dst row j = src row idx[j]; rows of `row_bytes` (even) at any even address and pitch.

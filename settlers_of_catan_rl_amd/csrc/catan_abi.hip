@@ -988,6 +988,18 @@ int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const void* wt, const float* ln_w, float eps, void* dx_out, float* dln_w, float* dln_b,
+                     int64_t rows, catan_stream_t stream) {
+    if (!dqkv || !x || !dres || !wt || !ln_w || !dx_out || !dln_w || !dln_b || rows <= 0 ||
+        (((uintptr_t)dqkv | (uintptr_t)x | (uintptr_t)dres | (uintptr_t)wt | (uintptr_t)dx_out) & 15))
+        return fail(CATAN_EINVAL, "catan_qkv_bwd_dx: null or misaligned argument");
+    long nb = ((rows + 15) / 16 + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_qkv_bwd_dx, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
+                       (const unsigned short*)wt, ln_w, eps, (unsigned short*)dx_out, dln_w, dln_b, (long)rows);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,

@@ -175,4 +175,130 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_dx(const unsigned short* __rest
     if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
 }
 
+
+// The attention sub-layer's input side, x_mid = x + out_proj(attention(qkv(LayerNorm(x)))): the gradient of x from dQKV [rows][192]
+// (catan_attention_bwd's output) - dN = dQKV . Wqkv, then LayerNorm backward + the residual gradient d(x_mid) - in one pass.  The
+// separate kernels wrote dN and read it back (and the residual); here: dQKV, X and the residual in, dX out.  wt = Wqkv^T [64][192].
+constexpr int QB_K = 192, QB_PW = QB_K + 8;       // LDS row pitch of Wqkv^T (bf16 elements): 400 B
+__global__ __launch_bounds__(256) void k_qkv_bwd_dx(const unsigned short* __restrict__ dqkv, const unsigned short* __restrict__ x, const unsigned short* __restrict__ dres,
+                                                    const unsigned short* __restrict__ wt, const float* __restrict__ lnw, float eps,
+                                                    unsigned short* __restrict__ dxo, float* __restrict__ dlnw, float* __restrict__ dlnb, long rows) {
+    __shared__ __attribute__((aligned(16))) unsigned short sD[4][16 * FB_P];     // the tile's residual-gradient rows
+    __shared__ __attribute__((aligned(16))) unsigned short sX[4][16 * FB_P];     // the tile's X rows; then the outgoing dX rows
+    __shared__ __attribute__((aligned(16))) unsigned short sW[64 * QB_PW];
+    __shared__ float sG[2][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+    if (tid < 128) (&sG[0][0])[tid] = 0.f;
+    for (int c = tid; c < 64 * (QB_K / 8); c += 256) {
+        const int n = c / (QB_K / 8), ch = c - n * (QB_K / 8);
+        *reinterpret_cast<uint4*>(sW + n * QB_PW + ch * 8) = *reinterpret_cast<const uint4*>(wt + n * QB_K + ch * 8);
+    }
+    __syncthreads();
+    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    unsigned short* tD = sD[wave]; unsigned short* tX = sX[wave];
+    const long tiles = (rows + 15) / 16;
+    uint4 vd[2], vx[2], an[QB_K / 32];
+    auto request = [&](long tile) {
+        const long r0 = tile * 16;
+        const long row = r0 + lr < rows ? r0 + lr : rows - 1;                  // rows past the end repeat the last one; nothing is stored for them
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            const long gr = r0 + rr < rows ? r0 + rr : rows - 1;
+            vd[q] = *reinterpret_cast<const uint4*>(dres + gr * 64 + ch * 8);
+            vx[q] = *reinterpret_cast<const uint4*>(x + gr * 64 + ch * 8);
+        }
+#pragma unroll
+        for (int s = 0; s < QB_K / 32; s++) an[s] = *reinterpret_cast<const uint4*>(dqkv + row * QB_K + 32 * s + 8 * g);     // A fragments straight from the rows
+    };
+    const long step = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    if (tile < tiles) request(tile);
+    for (; tile < tiles; tile += step) {
+        const long r0 = tile * 16;
+        uint4 a[QB_K / 32];
+#pragma unroll
+        for (int s = 0; s < QB_K / 32; s++) a[s] = an[s];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            *reinterpret_cast<uint4*>(tD + rr * FB_P + ch * 8) = vd[q];
+            *reinterpret_cast<uint4*>(tX + rr * FB_P + ch * 8) = vx[q];
+        }
+        if (tile + step < tiles) request(tile + step);
+        __builtin_amdgcn_wave_barrier();
+        // ---- dN = dQKV . Wqkv: lane holds rows 4 g + r, column 16 t + lr
+        float dn[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < QB_K / 32; s++)
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a[s]),
+                                                            *reinterpret_cast<const bf16x8_t*>(sW + (16 * t + lr) * QB_PW + 32 * s + 8 * g), c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) dn[t][r] = hd_bf(c[r]);
+        }
+        float xv[4][4], res[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xv[t][r] = te_bf(tX[(4 * g + r) * FB_P + 16 * t + lr]);
+                res[t][r] = te_bf(tD[(4 * g + r) * FB_P + 16 * t + lr]);
+            }
+        __builtin_amdgcn_wave_barrier();                                       // (tX is overwritten with the result below)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float sum = xv[0][r] + xv[1][r] + xv[2][r] + xv[3][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { xv[t][r] -= mean; sq += xv[t][r] * xv[t][r]; }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+            const bool live = r0 + 4 * g + r < rows;
+            float gw[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                xv[t][r] *= rstd;                                              // x_hat
+                const float gy = live ? dn[t][r] : 0.f;
+                aw[t] += gy * xv[t][r]; ab[t] += gy;
+                gw[t] = gy * wl[t];
+                s1 += gw[t]; s2 += gw[t] * xv[t][r];
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                tX[(4 * g + r) * FB_P + 16 * t + lr] = te_to_bf(hd_bf(rstd * (gw[t] - m1 - xv[t][r] * m2)) + res[t][r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * q, rr = c >> 3, ch = c & 7;
+            if (r0 + rr < rows) *reinterpret_cast<uint4*>(dxo + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(tX + rr * FB_P + ch * 8);
+        }
+        __builtin_amdgcn_wave_barrier();                                       // (the next tile's staging overwrites tD / tX)
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        aw[t] += __shfl_xor(aw[t], 16); aw[t] += __shfl_xor(aw[t], 32);
+        ab[t] += __shfl_xor(ab[t], 16); ab[t] += __shfl_xor(ab[t], 32);
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { atomicAdd(&sG[0][16 * t + lr], aw[t]); atomicAdd(&sG[1][16 * t + lr], ab[t]); }
+    }
+    __syncthreads();
+    if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
+}
+
 }  // namespace catan

@@ -598,11 +598,19 @@ class _TileEncoderTrain(torch.autograd.Function):
                 dqkv = torch.empty_like(qkv)
                 _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
                 wqkv = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf)
-                dn1 = _rows_product(dqkv, wqkv.t().contiguous())
                 dwq, dbq = _wgrad(n1, dqkv, True)
                 for k in range(3):
                     g[b + 2 + 2 * k], g[b + 3 + 2 * k] = dwq[64 * k:64 * k + 64], dbq[64 * k:64 * k + 64]
-                dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)
+                wqt = wqkv.t().contiguous()
+                if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
+                    dn1 = _rows_product(dqkv, wqt)
+                    dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)
+                else:                           # the same two steps in one pass over the rows (k_qkv_bwd_dx)
+                    dx = torch.empty_like(xin)
+                    dl = torch.zeros((2, 64), dtype=torch.float32, device=xin.device)
+                    lw = P[b].detach().float().contiguous()
+                    _lib.check(_lib.lib().catan_qkv_bwd_dx(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
+                    g[b], g[b + 1] = dl[0], dl[1]
             da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
             dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
             g[0] = dw0[:, :60]
