@@ -4,9 +4,10 @@ the HBM roofline on its ALGORITHMIC bytes (the tensors it must read and write on
 on the matrix cores - its MFMA FLOP/s against the dense bf16 peak.
 
 Kernels: the two fused learner kernels north_star names (k_gae, k_ppo_loss), the observation encoder of a rollout pass
-(k_obs_rows), the fused tile encoder of every inference pass (k_tile_encoder_fwd), one fused action-head evaluation
-(k_head_fwd), and the longest hand-written kernels of a minibatch step by the kernel trace (profiles/r03_train_step_kernel_stats.csv):
-the tile encoder's attention backward, its FFN row product, its LayerNorm backward and a weight gradient.  The library GEMMs of the
+(k_obs_rows), the fused tile encoder of every inference pass and of the training forward (k_tile_encoder_fwd), the one-pass
+backward kernels of its sub-layers (k_ffn_bwd_dx, k_qkv_bwd_dx), the row gathers of a minibatch, one fused action-head evaluation
+(k_head_fwd), and the longest other hand-written kernels of a minibatch step by the kernel trace (profiles/r03_train_step_kernel_stats.csv):
+the tile encoder's attention backward, a row product, a LayerNorm backward and a weight gradient.  The library GEMMs of the
 step are not listed: they are rocBLAS / hipBLASLt code."""
 import torch
 
@@ -76,7 +77,47 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     macs = 19 * (64 * 64 + 2 * (64 * 192 + 64 * 64 + 64 * 128 + 128 * 64) + 64 * 32) + 2 * 4 * 2 * 32 * 32 * 16
     out.append(_entry("k_tile_encoder_fwd (whole tile encoder, inference)", f"{boards} boards", us, (2280 + 950) * boards, flops=2 * macs * boards,
                       note="VALU / L2-latency bound (LayerNorm, softmax, epilogues), not HBM- or MFMA-bound: DESIGN.md 4.5 (iv)"))
+    # ---- the same kernel as the TRAINING forward: it also stores what the backward kernels read (1 529 bf16 per token: 58 KB per board)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        us = _time_us(lambda: nn_kernels.tile_encoder_train(te, tiles), reps=5)
+    out.append(_entry("k_tile_encoder_fwd<SAVE> (training forward: + the activations the backward reads)", f"{boards} boards", us,
+                      (2280 + 950 + 19 * 1529 * 2) * boards, flops=2 * macs * boards, note="includes the per-step re-pack of the encoder's weights (~60 small launches)"))
     del tiles
+    # ---- the backward of the encoder's sub-layers up to the weight gradients, one pass each (csrc/catan_te_bwd.hip)
+    tokf = boards * 19
+    dxg = torch.randn(tokf, 64, device=dev, generator=g).to(torch.bfloat16); hh = torch.relu(torch.randn(tokf, 128, device=dev, generator=g)).to(torch.bfloat16)
+    xm = torch.randn(tokf, 64, device=dev, generator=g).to(torch.bfloat16)
+    w2t = torch.randn(128, 64, device=dev, generator=g).to(torch.bfloat16); w1t = torch.randn(64, 128, device=dev, generator=g).to(torch.bfloat16)
+    lw = torch.ones(64, device=dev); dh = torch.empty_like(hh); dxo = torch.empty_like(xm); dl = torch.zeros(2, 64, device=dev)
+    from settlers_of_catan_rl_amd import _lib
+    P, S = nn_kernels._ptr, nn_kernels._stream
+    us = _time_us(lambda: _lib.check(_lib.lib().catan_ffn_bwd_dx(P(dxg), P(hh), P(xm), P(w2t), P(w1t), P(lw), 1e-5, P(dh), P(dxo), P(dl[0]), P(dl[1]), tokf, S())), reps=5)
+    out.append(_entry("k_ffn_bwd_dx (masked dX W2, dH W1, LayerNorm backward + residual)", f"{tokf} rows", us, (64 + 128 + 64 + 128 + 64) * 2 * tokf,
+                      flops=2 * 2 * 64 * 128 * tokf, note="dX, H, X in; dH, dX' out"))
+    dq = torch.randn(tokf, 192, device=dev, generator=g).to(torch.bfloat16); wqt = torch.randn(64, 192, device=dev, generator=g).to(torch.bfloat16)
+    us = _time_us(lambda: _lib.check(_lib.lib().catan_qkv_bwd_dx(P(dq), P(xm), P(dxg), P(wqt), P(lw), 1e-5, P(dxo), P(dl[0]), P(dl[1]), tokf, S())), reps=5)
+    out.append(_entry("k_qkv_bwd_dx (dQKV Wqkv, LayerNorm backward + residual)", f"{tokf} rows", us, (192 + 64 + 64 + 64) * 2 * tokf, flops=2 * 192 * 64 * tokf))
+    del dxg, hh, xm, dh, dxo, dq
+    # ---- row movement of a minibatch: the distinct boards' tile features out of the rollout rows (2-byte aligned 3 574-byte rows),
+    #      a per-board result spread to the rows, the rows' gradients summed per board
+    rows_all = 16 * rows_mb
+    store = torch.randn(rows_all // 16, 16 * 1787, device=dev, generator=g).to(torch.bfloat16).view(rows_all, 1787)
+    idx = torch.randint(0, rows_all, (boards,), device=dev, generator=g)
+    out.append(_entry("k_gather_rows (tile features of the distinct boards)", f"{boards} rows of 2 280 B", _time_us(lambda: nn_kernels.gather_rows(store[:, 18:1158], idx), reps=5),
+                      2 * 2280 * boards))
+    del store
+    U = int(0.875 * rows_mb)
+    inv = torch.randint(0, U, (rows_mb,), device=dev, generator=g); inv[:U] = torch.arange(U, device=dev)
+    order = torch.argsort(inv, stable=True)
+    start = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(torch.bincount(inv, minlength=U), 0)))
+    srcu = torch.randn(U, 480, device=dev, generator=g).to(torch.bfloat16).requires_grad_(True)
+    y = nn_kernels.expand_rows(srcu, inv, order, start)
+    dy = torch.randn_like(y)
+    out.append(_entry("k_expand_rows16 (per-board rows of 960 B to the minibatch rows)", f"{U} -> {rows_mb} rows",
+                      _time_us(lambda: nn_kernels.expand_rows(srcu.detach(), inv, order, start), reps=5), 960 * (U + rows_mb) + 8 * rows_mb))
+    out.append(_entry("k_segment_sum16 (its backward: the rows' gradients summed per board)", f"{rows_mb} -> {U} rows",
+                      _time_us(lambda: torch.autograd.grad(y, srcu, dy, retain_graph=True), reps=5), 960 * (U + rows_mb) + 16 * rows_mb))
+    del srcu, y, dy
     # ---- k_head_fwd: one action-head evaluation at rollout width: 128 bf16 in (256 B) + mask row (4 K B) + u in, action + logp out (12 B)
     ahm = net.action_head_module
     head = ahm.action_heads[2]                       # the road head: K = 73, no conditioning columns
@@ -85,7 +126,7 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     with torch.no_grad():
         us = _time_us(lambda: nn_kernels.head_sample(head, ahm.D, pre_all[:, 256:384], None, mask, deterministic=True), reps=30)
     out.append(_entry("k_head_fwd (LayerNorm + 128x128 + 128x73 + masked categorical)", f"{n} rows, K = 73", us, (256 + 4 * 73 + 12) * n,
-                      flops=2 * (128 * 128 + 128 * 80) * n, note="includes the Python wrapper's launch (two allocations): launch-bound at this size"))
+                      flops=2 * (128 * 128 + 128 * 80) * n, note="includes the Python wrapper's launch (two allocations); two waves per SIMD, 256 workgroups"))
     del pre_all, mask
     # ---- the hand-written kernels that lead the kernel trace of a minibatch step (tile encoder, 204 800 boards x 19 tokens)
     tok = rows_mb * 19
