@@ -499,6 +499,21 @@ class _ActionHeads(nn.Module):
         ev.record()
         return perm, pin, ev
 
+    @torch.no_grad()
+    def precompute_groupings(self, actions_all, perm, num_mini_batch, mbs):
+        """start_grouping for every minibatch of an epoch at once: one batched sort, ONE host read of the 64 x 104 counts.  A read per
+        step - even behind an event - holds the host at the start of every step until the device has finished the previous one, and
+        the ~1 500 launches of a step then go out with the device waiting for each of them (the step is host-paced from there on).
+        actions_all [rows, 18]; perm: the epoch's permutation.  -> list of (perm_k, ends_k (host list), None)"""
+        a = actions_all[perm[:num_mini_batch * mbs]]
+        typ, card = a[:, 0].view(num_mini_batch, mbs), a[:, 4].view(num_mini_batch, mbs)
+        key = typ * 8 + torch.where(typ == T_PLAYDEV, card.clamp(0, 7), torch.zeros_like(card))
+        order = torch.argsort(key, dim=1, stable=True)
+        counts = torch.zeros((num_mini_batch, 13 * 8), dtype=torch.int64, device=a.device)
+        counts.scatter_add_(1, key, torch.ones_like(key))
+        ends = torch.cumsum(counts, 1).tolist()
+        return [(order[k], ends[k], None) for k in range(num_mini_batch)]
+
     def _evaluate_compact(self, main, m, cur_res, trade, actions, grouping=None):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
         typ, card = actions[:, 0], actions[:, 4]
@@ -508,7 +523,8 @@ class _ActionHeads(nn.Module):
         perm, ends, ev = grouping if grouping is not None else self.start_grouping(actions)
         if ev is not None:
             ev.synchronize()
-        ends = ends.tolist()
+        if torch.is_tensor(ends):
+            ends = ends.tolist()
         rng = lambda k: perm[(ends[k - 1] if k else 0):ends[k]]
         of_type = lambda t: perm[(ends[8 * t - 1] if t else 0):ends[8 * t + 7]]
         rs, rc, rp, rst = of_type(T_SETTLE), of_type(T_CITY), of_type(T_PROPOSE), of_type(T_STEAL)
@@ -833,9 +849,11 @@ class CatanPolicy(nn.Module):
                                                    forced_type=condition_on_action_type)
         return (value, actions, logp[:, None], hidden) if self.include_lstm else (value, actions, logp[:, None])
 
-    def evaluate_actions(self, obs_f, lists, lens, masks, actions, hidden=None, nonterminal=None, tile_dedupe=None):
+    def evaluate_actions(self, obs_f, lists, lens, masks, actions, hidden=None, nonterminal=None, tile_dedupe=None, grouping=None):
+        """grouping: this batch's entry of _ActionHeads.precompute_groupings (the learner computes them for a whole epoch at once)"""
         ahm = self.action_head_module
-        grouping = ahm.start_grouping(actions) if ahm.wants_grouping(obs_f.shape[0], actions) else None    # (before the long forward)
+        if grouping is None or not ahm.wants_grouping(obs_f.shape[0], actions):
+            grouping = ahm.start_grouping(actions) if ahm.wants_grouping(obs_f.shape[0], actions) else None    # (before the long forward)
         value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal, tile_dedupe=tile_dedupe)
         cur_res, trade = self._custom(obs_f)
         _, logp, entropy = ahm(main, masks.float(), cur_res, trade, actions, grouping=grouping)

@@ -216,6 +216,10 @@ class PPOTrainer(object):
                 batches = [(perm[mb * mbs:(mb + 1) * mbs], None) for mb in range(cfg.num_mini_batch)]   # BatchSampler(drop_last=True)
                 if dedupe:                        # the tile encoder sees every distinct board of a minibatch once (forward and backward)
                     boards = self.minibatch_boards(board_ids, perm, cfg.num_mini_batch, mbs)
+                ahm = getattr(pol, "action_head_module", None)
+                groupings = None                  # the heads' row sets of every minibatch: one sort and one host read per epoch
+                if ahm is not None and hasattr(ahm, "precompute_groupings") and dev.type == "cuda" and ahm.wants_grouping(mbs, acts_all):
+                    groupings = ahm.precompute_groupings(acts_all, perm, cfg.num_mini_batch, mbs)
             for bi, (idx, hidden) in enumerate(batches):
                 with self._autocast():
                     if rec:
@@ -230,10 +234,12 @@ class PPOTrainer(object):
                         nn_kernels.gather_rows(f_all[:, o + 1140:], idx, out=fm[:, o + 1140:])
                         v, lp, ent = pol.evaluate_actions(cast(fm), nn_kernels.gather_rows(lists_all, idx), lens_all[idx].long(),
                                                           st.unpack_action_masks(amask_all[idx]), acts_all[idx],
-                                                          tile_dedupe=(cast(nn_kernels.gather_rows(tiles_all, first_rows[uqk])), invk, orderk, startk))
+                                                          tile_dedupe=(cast(nn_kernels.gather_rows(tiles_all, first_rows[uqk])), invk, orderk, startk),
+                                                          **({} if groupings is None else {"grouping": groupings[bi]}))
                     else:
                         v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
-                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx])
+                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                          **({} if groupings is None else {"grouping": groupings[bi]}))
                 loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
                                                    cfg.clip_param, cfg.value_loss_coef,
                                                    value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
