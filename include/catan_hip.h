@@ -109,6 +109,17 @@ int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w
 int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const void* wt, const float* ln_w, float eps, void* dx_out, float* dln_w, float* dln_b,
                      int64_t rows, catan_stream_t stream);
 
+/* Every image of the net's fp32 parameters that a training step reads (bf16 copies, transposed bf16 copies, the fused tile
+ * encoder's packed blocks), refreshed by one launch after the optimiser step (the reference relies on autocast's per-use casts,
+ * RL/ppo/ppo.py has none: fp32 throughout).  table: n rows of catan_weight_image_t ON THE DEVICE; image i is the strided 2-D copy
+ * dst[r * d_r + c * d_c] = conv(src[r * s_r + c * s_c]), strides in elements; mode 0: fp32 -> bf16, 1: fp32 -> fp32, 2: fp32 ->
+ * bf16 -> fp32 (a bias as bf16 autocast hands it to a GEMM, kept in a float vector). */
+typedef struct catan_weight_image {
+    const float* src; void* dst; int32_t rows, cols; int64_t s_r, s_c, d_r, d_c; int32_t mode; int32_t reserved_;
+} catan_weight_image_t;
+int32_t catan_weight_image_bytes(void);
+int catan_weight_images(const void* table, int32_t n, catan_stream_t stream);
+
 /* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
  * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
  * catan_gather_rows: dst row j = src row idx[j]; rows of `row_bytes` (even) at any even address and pitch.

@@ -1000,6 +1000,14 @@ int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const vo
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int32_t catan_weight_image_bytes(void) { return (int32_t)sizeof(WeightImage); }
+int catan_weight_images(const void* table, int32_t n, catan_stream_t stream) {
+    if (!table || n <= 0) return fail(CATAN_EINVAL, "catan_weight_images: bad arguments");
+    static_assert(sizeof(WeightImage) == 64 && sizeof(catan_weight_image_t) == sizeof(WeightImage), "the header's struct is the kernel's");
+    hipLaunchKernelGGL(k_weight_images, dim3((unsigned)n, 8), dim3(256), 0, S(stream), (const WeightImage*)table, (int)n);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,

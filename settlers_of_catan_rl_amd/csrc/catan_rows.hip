@@ -59,3 +59,23 @@ __global__ __launch_bounds__(256) void k_segment_sum16(const uint4* __restrict__
 }
 
 }  // namespace catan
+
+namespace catan {
+// k_weight_images: every derived image of the net's fp32 parameters that a training step reads - bf16 copies, transposed bf16
+// copies, the fused tile encoder's packed weight / vector blocks - refreshed by ONE launch after the optimiser step.  As separate
+// casts / transposes / pads they were ~500 launches of 2-4 us per step (1.9 of its 34 ms on the device, and as much host time).
+// One table row per image: a strided 2-D copy with conversion, dst[r * d_r + c * d_c] = conv(src[r * s_r + c * s_c]).
+struct WeightImage { const float* src; void* dst; int rows, cols; long s_r, s_c, d_r, d_c; int mode; int pad_; };   // mode 0: -> bf16, 1: -> fp32, 2: -> bf16 -> fp32
+__global__ __launch_bounds__(256) void k_weight_images(const WeightImage* __restrict__ table, int n) {
+    const WeightImage w = table[blockIdx.x];
+    const long total = (long)w.rows * w.cols;
+    for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+        const long r = e / w.cols, c = e - r * w.cols;
+        const float v = w.src[r * w.s_r + c * w.s_c];
+        const long o = r * w.d_r + c * w.d_c;
+        if (w.mode == 0) reinterpret_cast<unsigned short*>(w.dst)[o] = te_to_bf(v);
+        else if (w.mode == 1) reinterpret_cast<float*>(w.dst)[o] = v;
+        else reinterpret_cast<float*>(w.dst)[o] = te_bf(te_to_bf(v));
+    }
+}
+}  // namespace catan

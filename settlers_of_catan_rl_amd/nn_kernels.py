@@ -147,6 +147,92 @@ def ln_supported(x, ln):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and len(ln.normalized_shape) == 1 and ln.normalized_shape[0] in LN_WIDTHS
 
 
+class _WeightImages(object):
+    """Every image of the fp32 master parameters that a training step under bf16 autocast reads - bf16 copies, transposed bf16
+    copies, the fused tile encoder's packed blocks - kept in persistent buffers and refreshed by ONE kernel launch after the
+    optimiser step (catan_weight_images).  An image is looked up by the parameter (view) it is made from; its source's version
+    counter tells whether it is current, so a caller that never refreshes still gets correct values (one small copy per stale
+    image, as before).  CATAN_WEIGHT_IMAGES=0 turns the registry off (every use casts, as autocast does)."""
+
+    class Entry(object):
+        __slots__ = ("src", "dst_view", "mode", "out", "version")
+
+    def __init__(self):
+        self.entries, self.by_key, self.dirty, self.table = [], {}, True, None
+        self.enabled = os.environ.get("CATAN_WEIGHT_IMAGES", "1") != "0"
+
+    def add(self, src2, dst_view, mode, out):
+        """src2: 2-D fp32 view of a parameter; dst_view: a view of the image buffer indexed like src2 (any strides)"""
+        e = _WeightImages.Entry()
+        e.src, e.dst_view, e.mode, e.out, e.version = src2.detach(), dst_view, mode, out, -1
+        self.entries.append(e)
+        self.dirty = True
+        return e
+
+    @staticmethod
+    def refresh_one(e):
+        with torch.no_grad():
+            e.dst_view.copy_(e.src.to(torch.bfloat16) if e.mode == 2 else e.src)
+        e.version = e.src._version
+
+    def image(self, w, transposed=False):
+        """bf16 image of parameter (view) w - [O, I] as it is, or its transpose [I, O], contiguous - or None (not a CUDA fp32 tensor)"""
+        if not self.enabled or not w.is_cuda or w.dtype != torch.float32 or w.dim() not in (1, 2) or (w.dim() == 1 and (transposed or not w.is_contiguous())):
+            return None
+        key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), transposed)
+        e = self.by_key.get(key)
+        if e is None:
+            src2 = w.detach() if w.dim() == 2 else w.detach().view(1, -1)
+            if transposed:
+                out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device)
+                dst_view = out.t()
+            else:
+                out = torch.empty(tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+                dst_view = out if w.dim() == 2 else out.view(1, -1)
+            e = self.by_key[key] = self.add(src2, dst_view, 0, out)
+        if e.version != w._version:
+            self.refresh_one(e)
+        return e.out
+
+    def refresh_all(self):
+        """one launch for every registered image (call after the optimiser step)"""
+        if not self.enabled or not self.entries:
+            return
+        if self.dirty:
+            import ctypes as C
+            import numpy as np
+
+            class Row(C.Structure):
+                _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("s_r", C.c_int64), ("s_c", C.c_int64),
+                            ("d_r", C.c_int64), ("d_c", C.c_int64), ("mode", C.c_int32), ("pad", C.c_int32)]
+            assert C.sizeof(Row) == _lib.lib().catan_weight_image_bytes()
+            rows = (Row * len(self.entries))()
+            for r, e in zip(rows, self.entries):
+                r.src, r.dst, r.rows, r.cols = e.src.data_ptr(), e.dst_view.data_ptr(), e.src.shape[0], e.src.shape[1]
+                r.s_r, r.s_c, r.d_r, r.d_c, r.mode = e.src.stride(0), e.src.stride(1), e.dst_view.stride(0), e.dst_view.stride(1), e.mode
+            host = torch.from_numpy(np.frombuffer(bytes(rows), dtype=np.uint8).copy())
+            self.table = host.to(self.entries[0].src.device)
+            self.dirty = False
+        _lib.check(_lib.lib().catan_weight_images(_ptr(self.table), len(self.entries), _stream()))
+        for e in self.entries:
+            e.version = e.src._version
+
+
+weight_images = _WeightImages()
+
+
+def bf16_of(w):
+    """w (fp32 parameter or view of one) in bf16: its registered image when there is one, else a cast"""
+    img = weight_images.image(w) if w.dtype == torch.float32 else None
+    return w.to(torch.bfloat16) if img is None else img
+
+
+def bf16_t_of(w):
+    """w^T in bf16, contiguous"""
+    img = weight_images.image(w, transposed=True) if (w.dtype == torch.float32 and w.dim() == 2) else None
+    return w.to(torch.bfloat16).t().contiguous() if img is None else img
+
+
 class _LinearTallSkinny(torch.autograd.Function):
     """y = x @ w.T + b in bf16 (fp32 accumulate, library GEMM); backward: dx by the library, dw / db by the hand-written
     MFMA kernel k_wgrad (csrc/catan_nn.hip) which splits the huge row dimension over the grid."""
@@ -155,8 +241,8 @@ class _LinearTallSkinny(torch.autograd.Function):
     def forward(ctx, x, w, b):
         with torch.autocast("cuda", enabled=False):
             xb = x.to(torch.bfloat16)
-            wb = w.to(torch.bfloat16)
-            bb = None if b is None else b.to(torch.bfloat16)
+            wb = bf16_of(w)
+            bb = None if b is None else bf16_of(b)
             # a wide input whose width is not a multiple of 8 (the opponents' 159 features) is zero-padded: the weight gradient
             # then takes the transposing-read kernel (614 400 x 159 -> 256: 685 us; x 160: 307 us) and the rows are 16-byte aligned
             ctx.pad = pad = (-x.shape[-1] % 8) if x.shape[-1] >= 64 else 0
@@ -165,19 +251,19 @@ class _LinearTallSkinny(torch.autograd.Function):
             y = _linear_rows(xb, wb, bb)
             if y is None:
                 y = torch.nn.functional.linear(xb, wb, bb)
-        ctx.save_for_backward(xb, wb)
+        ctx.save_for_backward(xb, wb, w)
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xb, wb = ctx.saved_tensors
+        xb, wb, w = ctx.saved_tensors
         O, I = wb.shape
         dy2 = dy.reshape(-1, O).to(torch.bfloat16).contiguous()
         x2 = xb.reshape(-1, I).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_rows(dy2, wb.t().contiguous(), None)          # dx[r][i] = sum_o dy[r][o] * w[o][i]
+            dx = _linear_rows(dy2, wb.t().contiguous() if ctx.pad else bf16_t_of(w), None)          # dx[r][i] = sum_o dy[r][o] * w[o][i]
             dx = (dy2 @ wb if dx is None else dx).reshape(xb.shape)
         acc = torch.zeros((O * I + O,), dtype=torch.float32, device=dy.device)          # one fill for dw and db
         dw, db = acc[:O * I].view(O, I), (acc[O * I:] if ctx.has_bias else None)
@@ -541,11 +627,96 @@ def _ln_backward(x, w, b, dy, eps, relu, dres=None):
     return dx, dwb[0], dwb[1]
 
 
+class _TeImages(object):
+    """The training-side images of one tile encoder's parameters in weight_images: the packed weight / vector blocks of
+    catan_tile_encoder_fwd (tile_encoder_pack's layout) and the transposed bf16 weights its backward chain multiplies by."""
+
+    def __init__(self, te):
+        L = _lib.lib()
+        dev = te.first_layer.weight.device
+        self.wts = torch.zeros((L.catan_tile_encoder_weight_elems(),), dtype=torch.bfloat16, device=dev)
+        self.vecs = torch.zeros((L.catan_tile_encoder_vec_elems(),), dtype=torch.float32, device=dev)
+        self.entries = []
+        wo, vo = [0], [0]
+
+        def W(param, rows, cols):                    # a weight block [rows][cols] of the pack, the parameter in its top-left corner
+            blk = self.wts[wo[0]:wo[0] + rows * cols].view(rows, cols)
+            self.entries.append(weight_images.add(param, blk[:param.shape[0], :param.shape[1]], 0, None))
+            wo[0] += rows * cols
+
+        def Wrows(params, rows, cols):               # ... several parameters stacked along the rows (Q, K, V)
+            blk = self.wts[wo[0]:wo[0] + rows * cols].view(rows, cols)
+            r = 0
+            for prm in params:
+                self.entries.append(weight_images.add(prm, blk[r:r + prm.shape[0], :prm.shape[1]], 0, None))
+                r += prm.shape[0]
+            wo[0] += rows * cols
+
+        def V(params, n, mode):                      # a vector block of n floats; mode 2: a Linear bias as bf16 autocast rounds it
+            o = 0
+            for prm in params:
+                self.entries.append(weight_images.add(prm.view(1, -1), self.vecs[vo[0] + o:vo[0] + o + prm.numel()].view(1, -1), mode, None))
+                o += prm.numel()
+            vo[0] += n
+
+        def T(params):                               # transposed bf16 [in][sum of outs]
+            outs = sum(prm.shape[0] for prm in params)
+            buf = torch.empty((params[0].shape[1], outs), dtype=torch.bfloat16, device=dev)
+            c = 0
+            for prm in params:
+                self.entries.append(weight_images.add(prm, buf[:, c:c + prm.shape[0]].t(), 0, None))
+                c += prm.shape[0]
+            return buf
+
+        W(te.first_layer.weight, 64, 64)
+        V([te.first_layer.bias], 64, 2); V([te.norm_2.weight], 64, 1); V([te.norm_2.bias], 64, 1)
+        self.w2t, self.w1t, self.wot, self.wqt = [], [], [], []
+        for layer in te.encoder_layers:
+            mha, ffn = layer.multi_headed_attention, layer.pointwise_net
+            Wrows([n.weight for n in mha.qkv_nets], 192, 64); W(mha.out_proj_net.weight, 64, 64); W(ffn.linear1.weight, 128, 64); W(ffn.linear2.weight, 64, 128)
+            V([layer.sublayers[0].norm.weight], 64, 1); V([layer.sublayers[0].norm.bias], 64, 1)
+            V([n.bias for n in mha.qkv_nets], 192, 2); V([mha.out_proj_net.bias], 64, 2)
+            V([layer.sublayers[1].norm.weight], 64, 1); V([layer.sublayers[1].norm.bias], 64, 1)
+            V([ffn.linear1.bias], 128, 2); V([ffn.linear2.bias], 64, 2)
+            self.w2t.append(T([ffn.linear2.weight])); self.w1t.append(T([ffn.linear1.weight]))
+            self.wot.append(T([mha.out_proj_net.weight])); self.wqt.append(T([n.weight for n in mha.qkv_nets]))
+        W(te.out_proj.weight, 32, 64)
+        V([te.out_proj.bias], 32, 2); V([te.norm.weight], 32, 1); V([te.norm.bias], 32, 1)
+        self.wpt = T([te.out_proj.weight])
+        assert wo[0] == self.wts.numel() and vo[0] == self.vecs.numel()
+        self.stamp = (te.first_layer.weight.data_ptr(), dev)
+
+    def current(self):
+        for e in self.entries:
+            if e.version != e.src._version:
+                weight_images.refresh_one(e)
+        return self
+
+
+_TE_IMAGES = None
+
+
+def _te_images(te):
+    global _TE_IMAGES
+    if _TE_IMAGES is None:
+        import weakref
+        _TE_IMAGES = weakref.WeakKeyDictionary()              # (not on the module: a deepcopy - inference_copy - must not carry them along)
+    im = _TE_IMAGES.get(te)
+    if im is None or im.stamp != (te.first_layer.weight.data_ptr(), te.first_layer.weight.device):
+        im = _TE_IMAGES[te] = _TeImages(te)
+    return im.current()
+
+
 class _TileEncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tiles, te, out_cols, *params):
         import ctypes as C
-        wts, vecs = tile_encoder_pack(te)
+        if weight_images.enabled:
+            im = _te_images(te)
+            wts, vecs = im.wts, im.vecs
+        else:
+            wts, vecs = tile_encoder_pack(te)
+        ctx.te = te
         x = _aligned(tiles.detach().to(torch.bfloat16))
         B = x.shape[0]
         T = B * 19
@@ -571,37 +742,40 @@ class _TileEncoderTrain(torch.autograd.Function):
         B, eps, bf = ctx.B, ctx.eps, torch.bfloat16
         T = B * 19
         g = [None] * len(P)
+        im = _te_images(ctx.te) if weight_images.enabled else None
         with torch.autocast("cuda", enabled=False):
             d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
             dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
-            dx = _rows_product(dp, P[36].to(bf).t().contiguous())                         # [T, 64]
+            dx = _rows_product(dp, im.wpt if im is not None else P[36].to(bf).t().contiguous())   # [T, 64]
             g[36], g[37] = _wgrad(sv["xfin"], dp, True)
             for l in (1, 0):
                 b = 4 + 16 * l
                 xin, n1, qkv, o, xmid, n2, h = (sv[k + str(l)] for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
-                w1, w2 = P[b + 12].to(bf), P[b + 14].to(bf)
+                if im is not None:
+                    w2t, w1t, wot, wqt = im.w2t[l], im.w1t[l], im.wot[l], im.wqt[l]
+                else:
+                    w2t, w1t, wot = P[b + 14].to(bf).t().contiguous(), P[b + 12].to(bf).t().contiguous(), P[b + 8].to(bf).t().contiguous()
+                    wqt = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf).t().contiguous()
                 if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
-                    dh = _rows_product(dx, w2.t().contiguous(), h, MODE_RELU_MASK)        # (dx @ w2) where h > 0
-                    dn2 = _rows_product(dh, w1.t().contiguous())
+                    dh = _rows_product(dx, w2t, h, MODE_RELU_MASK)                        # (dx @ w2) where h > 0
+                    dn2 = _rows_product(dh, w1t)
                     dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
                 else:                           # the same three steps in one pass over the rows (k_ffn_bwd_dx)
                     dh, dxmid = torch.empty_like(h), torch.empty_like(xmid)
                     dl = torch.zeros((2, 64), dtype=torch.float32, device=h.device)
-                    w2t, w1t, lw = w2.t().contiguous(), w1.t().contiguous(), P[b + 10].detach().float().contiguous()     # (named: alive until the launch is queued)
+                    lw = P[b + 10].detach().float().contiguous()                          # (named: alive until the launch is queued)
                     _lib.check(_lib.lib().catan_ffn_bwd_dx(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dh), _ptr(dxmid),
                                                            _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
                     g[b + 10], g[b + 11] = dl[0], dl[1]
                 g[b + 14], g[b + 15] = _wgrad(h, dx, True)
                 g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
-                do = _rows_product(dxmid, P[b + 8].to(bf).t().contiguous())
+                do = _rows_product(dxmid, wot)
                 g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
                 _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
-                wqkv = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf)
                 dwq, dbq = _wgrad(n1, dqkv, True)
                 for k in range(3):
                     g[b + 2 + 2 * k], g[b + 3 + 2 * k] = dwq[64 * k:64 * k + 64], dbq[64 * k:64 * k + 64]
-                wqt = wqkv.t().contiguous()
                 if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
                     dn1 = _rows_product(dqkv, wqt)
                     dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)

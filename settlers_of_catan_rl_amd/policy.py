@@ -413,6 +413,11 @@ class _Branches(object):
 _HEAD_BRANCHES, _OBS_BRANCHES = _Branches(), _Branches()
 
 
+def _cast_w(w, dtype):
+    """a parameter (view) in the compute dtype: the registered bf16 image (nn_kernels.weight_images) when there is one"""
+    return nn_kernels.bf16_of(w) if (dtype == torch.bfloat16 and w.is_cuda) else w.to(dtype)
+
+
 class _SegmentedTrunk(torch.autograd.Function):
     """out_k = x[a_k:b_k] @ w_k.T + bias_k for a list of row segments of ONE gathered trunk tensor x (the heads of
     `_evaluate_compact`: every head sees its own rows).  As separate slices + F.linear the backward of every slice
@@ -426,7 +431,7 @@ class _SegmentedTrunk(torch.autograd.Function):
         ws, bs = wb[:n], wb[n:]
         outs = []
         for (a, b), w, bias in zip(segs, ws, bs):
-            outs.append(F.linear(x[a:b], w.to(x.dtype), bias.to(x.dtype)))
+            outs.append(F.linear(x[a:b], _cast_w(w, x.dtype), _cast_w(bias, x.dtype)))
         ctx.segs = segs
         ctx.save_for_backward(x, *ws)
         return tuple(outs)
@@ -442,7 +447,7 @@ class _SegmentedTrunk(torch.autograd.Function):
                 dws.append(None); dbs.append(None)
                 continue
             g = g.to(x.dtype)
-            contrib = g @ w.to(x.dtype)
+            contrib = g @ _cast_w(w, x.dtype)
             if (a, b) in seen:
                 dx[a:b] += contrib
             else:

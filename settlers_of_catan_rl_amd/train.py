@@ -255,6 +255,7 @@ class PPOTrainer(object):
                     self.bucket.allreduce()
                 torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
                 self.optimiser.step()
+                nn_kernels.weight_images.refresh_all()                                     # every bf16 / transposed / packed image of the new weights: one launch
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))
             self._sync(); t3 = time.perf_counter()
             t_val += t1 - t0; t_gae += t2 - t1; t_opt += t3 - t2

@@ -7,13 +7,16 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd.policy import CatanPolicy
 from settlers_of_catan_rl_amd.rollout import RolloutCollector
 from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
-N, T, STEPS = 65536, 200, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+N, T, STEPS = 65536, int(os.environ.get("T", "200")), int(sys.argv[1]) if len(sys.argv) > 1 else 20
 env = VecCatanEnv(N, seed=0); env.random_rollout(0, 500)
 net = CatanPolicy().cuda()
 col = RolloutCollector(env, net, T, seed=1, autocast_dtype=torch.bfloat16)
 st = col.gather_rollouts()
 class Stop(Exception): pass
-for rnd in range(2):
+for rnd in range(4):
+    import torch.cuda.tunable as tun
+    tun.enable(rnd % 2 == 0)
+    print("TunableOp enabled:", tun.is_enabled())
     tr = PPOTrainer(net, PPOConfig(ppo_epoch=1, num_mini_batch=64), autocast_dtype=torch.bfloat16, seed=3)
     calls = [0]; orig = tr.optimiser.step; t = {}
     def step(*a, **k):
