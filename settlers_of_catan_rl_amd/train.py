@@ -140,6 +140,15 @@ class PPOTrainer(object):
         rec = getattr(self.policy, "include_lstm", False)
         cast = (lambda x: x) if (self.autocast_dtype is not None and f.dtype == self.autocast_dtype) else (lambda x: x.float())
         te_u = board_of_row = None
+        vnet = self.policy
+        if (self.autocast_dtype is not None and f.is_cuda and not rec and hasattr(self.policy, "inference_copy")
+                and getattr(self.policy, "_inference_dtype", None) is None):
+            # the value pass is inference: a copy of the net with its Linear weights already in the autocast dtype, refreshed once per
+            # call (one copy per parameter) - under autocast the fp32 masters were re-cast in every chunk (1 700 launches per pass)
+            if getattr(self, "_value_net", None) is None:
+                self._value_net = self.policy.inference_copy(self.autocast_dtype)
+            self._value_net.load_from(self.policy)
+            vnet = self._value_net
         if self.dedupe_boards and not rec and f.is_cuda and hasattr(self.policy, "observation_module"):
             from . import spec
             key = (st.obs_f.data_ptr(), getattr(st, "generation", None), T1, N)
@@ -151,7 +160,7 @@ class PPOTrainer(object):
             tiles_all = f[:, o:o + 1140]
             for s in range(0, first_rows.numel(), ch):          # the tile encoder on the distinct boards only
                 with self._autocast():
-                    part = self.policy.observation_module.tile_encoder(cast(tiles_all[first_rows[s:s + ch]]).reshape(-1, 19, 60))
+                    part = vnet.observation_module.tile_encoder(cast(nn_kernels.gather_rows(tiles_all, first_rows[s:s + ch])).reshape(-1, 19, 60))
                 if te_u is None:
                     te_u = torch.empty((first_rows.numel(), part.shape[1]), dtype=part.dtype, device=part.device)
                 te_u[s:s + ch] = part
@@ -164,9 +173,9 @@ class PPOTrainer(object):
                     v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(),
                                               (hid[0, s:s + ch], hid[1, s:s + ch]), nt[s:s + ch])
                 elif te_u is not None:
-                    v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(), tile_features=te_u[board_of_row[s:s + ch]])
+                    v = vnet.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long(), tile_features=nn_kernels.gather_rows(te_u, board_of_row[s:s + ch]))
                 else:
-                    v = self.policy.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long())
+                    v = vnet.get_value(cast(f[s:s + ch]), lists[s:s + ch], lens[s:s + ch].long())
             out[s:s + ch] = v[:, 0]
         return self.policy.denormalise(out).reshape(T1, N)
 
