@@ -129,7 +129,7 @@ def ppo_update_record(env, n, rank, world, T, cdist):
     same games: one rollout of T active-seat decisions per game + one PPO update with the reference's 10 epochs x 64
     minibatches, bf16 autocast, fp32 master weights, flat-bucket gradient all-reduce over RCCL when world > 1.  T defaults to
     the reference's 200 (a minibatch has T * n / 64 = 204 800 rows at 65 536 games; ~63 GB of rollout tensors in HBM); two
-    updates are run and the SECOND is reported (the first one also captures the policy pass's hipGraph and warms the allocator)."""
+    three updates are run and the THIRD is reported (see below)."""
     import torch
     from settlers_of_catan_rl_amd.policy import CatanPolicy
     from settlers_of_catan_rl_amd.rollout import RolloutCollector
@@ -139,8 +139,12 @@ def ppo_update_record(env, n, rank, world, T, cdist):
     cdist.broadcast_parameters(net)
     col = RolloutCollector(env, net, T, seed=rank, autocast_dtype=torch.bfloat16)
     tr = PPOTrainer(net, PPOConfig(), autocast_dtype=torch.bfloat16, seed=rank)
-    first = None
-    for u in range(2):          # the second update is the steady state: the first one also captures the policy pass's hipGraph, warms the allocator
+    first, warm = None, []
+    # The THIRD update is reported.  The first captures the policy pass's hipGraph; the first and the second still load GEMM kernels:
+    # a minibatch's row counts (distinct boards, rows per action head) differ from step to step, so the library meets new problem
+    # sizes - and loads the code objects it picks for them - for a few hundred steps on a fresh process (measured per step: 54, 43,
+    # 34, 32, 32 ms over the first five epochs-pairs; 31.8 ms from then on).  Both warm-up updates are in `warmup_updates`.
+    for u in range(3):
         cdist.barrier()
         t0 = time.perf_counter()
         st = col.gather_rollouts()
@@ -151,6 +155,8 @@ def ppo_update_record(env, n, rank, world, T, cdist):
         t2 = time.perf_counter()
         col.after_rollouts()
         rollout_s, update_s = cdist.max_over_ranks(t1 - t0), cdist.max_over_ranks(t2 - t1)
+        if u < 2:
+            warm.append({"rollout_s": rollout_s, "update_s": update_s, "minibatches_s": tr.timings.get("minibatches_s")})
         if u == 0:
             first = {"rollout_s": rollout_s, "update_s": update_s}
     dec = world * n * T
@@ -169,12 +175,12 @@ def ppo_update_record(env, n, rank, world, T, cdist):
             "rollout_s": rollout_s, "update_s": update_s, "env_passes_in_rollout": col.iters, **tr.timings,
             "decisions_per_s": dec / (rollout_s + update_s), "dtype": "bf16 autocast, fp32 master weights",
             "losses": {"value": vl, "action": al, "entropy": el},
-            "first_update": first,
+            "first_update": first, "warmup_updates": warm,
             "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 2 ** 30,
             "note": ("the reference's workload (RL/ppo/arguments.py:48-56: T = 200, 10 epochs x 64 minibatches)" if T == 200 else
                      f"T = {T} instead of the reference's 200 (stated)") +
-                    "; every seat plays the central policy; value = the second update (steady state), the first one (one-time "
-                    "hipGraph capture of the policy pass included) is in first_update"}
+                    "; every seat plays the central policy; value = the third update (steady state); the first (one-time hipGraph "
+                    "capture of the policy pass) and the second (the GEMM library still loading kernels for new row counts) are in warmup_updates"}
 
 
 def main():

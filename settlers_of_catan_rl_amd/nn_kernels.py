@@ -707,6 +707,32 @@ def _te_images(te):
     return im.current()
 
 
+class _TeWorkspace(object):
+    """the one persistent activation workspace of _TileEncoderTrain (grow-only), leased to one forward at a time"""
+    buf, busy = None, False
+
+    class Lease(object):
+        def __init__(self, buf):
+            self.buf, self.live = buf, True
+
+        def release(self):
+            if self.live:
+                self.live = False
+                _TeWorkspace.busy = False
+
+        __del__ = release                       # (a forward whose graph is dropped without a backward gives the workspace back too)
+
+    @classmethod
+    def lease(cls, n, device):
+        if cls.busy or os.environ.get("CATAN_TE_WORKSPACE", "1") == "0":
+            return None
+        if cls.buf is None or cls.buf.device != torch.device(device) or cls.buf.numel() < n:
+            cls.buf = None                      # (free the old one first)
+            cls.buf = torch.empty((int(n * 1.02) + 1024,), dtype=torch.bfloat16, device=device)
+        cls.busy = True
+        return cls.Lease(cls.buf)
+
+
 class _TileEncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tiles, te, out_cols, *params):
@@ -720,7 +746,14 @@ class _TileEncoderTrain(torch.autograd.Function):
         x = _aligned(tiles.detach().to(torch.bfloat16))
         B = x.shape[0]
         T = B * 19
-        buf = torch.empty((T * sum(w for _, w in _TE_SAVES),), dtype=torch.bfloat16, device=x.device)
+        # 3 KB per token = 11 GB at a minibatch's 180 000 boards, and the board count differs from step to step: taken from the
+        # caching allocator every step, the slightly different sizes fragment it (reserved memory grew from 100 to 190 GB in three
+        # updates).  ONE workspace is kept instead and leased to the forward whose backward has not run yet; a second forward
+        # in flight (gradient accumulation) gets a fresh buffer as before.
+        need = T * sum(w for _, w in _TE_SAVES)
+        lease = _TeWorkspace.lease(need, x.device)
+        ctx.lease = lease
+        buf = lease.buf if lease is not None else torch.empty((need,), dtype=torch.bfloat16, device=x.device)
         saves, off = [], 0
         for _, w in _TE_SAVES:
             saves.append(buf[off:off + T * w].view(T, w))
@@ -788,6 +821,8 @@ class _TileEncoderTrain(torch.autograd.Function):
             da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
             dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
             g[0] = dw0[:, :60]
+        if ctx.lease is not None:
+            ctx.lease.release()
         return (None, None, None) + tuple(g)
 
 
