@@ -128,7 +128,7 @@ def ppo_update_record(env, n, rank, world, T, cdist):
     """The metric's second half (BASELINE.json: "PPO wall-clock/update, 1->8 GPU"; workload RL/ppo/arguments.py:48-56) on the
     same games: one rollout of T active-seat decisions per game + one PPO update with the reference's 10 epochs x 64
     minibatches, bf16 autocast, fp32 master weights, flat-bucket gradient all-reduce over RCCL when world > 1.  T defaults to
-    the reference's 200 (a minibatch has T * n / 64 = 204 800 rows at 65 536 games; ~63 GB of rollout tensors in HBM); two
+    the reference's 200 (a minibatch has T * n / 64 = 204 800 rows at 65 536 games; ~63 GB of rollout tensors in HBM);
     three updates are run and the THIRD is reported (see below)."""
     import torch
     from settlers_of_catan_rl_amd.policy import CatanPolicy
@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--no-lockstep", action="store_true", help="skip the lock-step measurement of a deferred run")
     ap.add_argument("--preroll", type=int, default=PREROLL_PASSES, help="untimed passes before --warmup (mixes the games' ages)")
     ap.add_argument("--ppo-steps", type=int, default=200,
-                    help="T of the `ppo_update` sub-record (two rollouts + PPO updates on the same games, the second one reported; "
+                    help="T of the `ppo_update` sub-record (three rollouts + PPO updates on the same games, the third one reported; "
                          "200 = the reference's num_steps, RL/ppo/arguments.py:54-56); 0: skip")
     args = ap.parse_args()
 
