@@ -126,8 +126,14 @@ static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, 
     case 64:
         if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) return lnw_launch<T, 8, 8>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
         return ln_launch<T, 64, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 128: return lnw_launch<T, 2, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 256: return lnw_launch<T, 4, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    // 128 / 256 wide: 8 elements per lane (16-byte accesses for bf16), 16 / 32 lanes per row - with one wave per row a lane moved 4 or 8
+    // bytes per access and the kernels ran at 1.6 TB/s (204 800 x 128: 100 us backward; 16-byte lanes: see profiles/r03_*)
+    case 128:
+        if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) return lnw_launch<T, 8, 16>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+        return lnw_launch<T, 2, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 256:
+        if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) return lnw_launch<T, 8, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+        return lnw_launch<T, 4, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     case 512: return lnw_launch<T, 8, 64>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     default: return fail(CATAN_EINVAL, "catan_layer_norm: unsupported width (built for 16, 25, 32, 64, 128, 256, 512)");
     }
@@ -210,8 +216,8 @@ static int lnw_res_dispatch(const void* x, const float* w, const float* b, const
         hipLaunchKernelGGL((k_lnw_bwd<T, EPL, GL>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, w, b, (const T*)dy, (T*)dx, dw, db, rows, eps, relu, (const T*)dres); } while (0)
     switch (D) {
     case 64: CATAN_LNW_RES(8, 8); break;
-    case 128: CATAN_LNW_RES(2, 64); break;
-    case 256: CATAN_LNW_RES(4, 64); break;
+    case 128: if ((((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dy | (uintptr_t)dres) & 15) == 0) CATAN_LNW_RES(8, 16); else CATAN_LNW_RES(2, 64); break;
+    case 256: if ((((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dy | (uintptr_t)dres) & 15) == 0) CATAN_LNW_RES(8, 32); else CATAN_LNW_RES(4, 64); break;
     case 512: CATAN_LNW_RES(8, 64); break;
     default: return fail(CATAN_EINVAL, "catan_layer_norm_bwd_res: built for the widths 64, 128, 256, 512");
     }
