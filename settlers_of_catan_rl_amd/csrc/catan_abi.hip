@@ -121,7 +121,19 @@ static int ln_dispatch(bool bwd, const void* x, const float* w, const float* b, 
                        long rows, int D, float eps, int relu, hipStream_t st) {
     switch (D) {
     case 16: return ln_launch<T, 16, 16>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
-    case 25: return ln_launch<T, 25, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
+    case 25:
+        if constexpr (sizeof(T) == 2) {      // bf16, enough rows, 16-byte aligned tensors: a lane per row through LDS (k_lnr_*)
+            if (rows >= 4096 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) {
+                long nb = (rows + 255) / 256;
+                if (nb > 2048) nb = 2048;
+                if (!bwd) hipLaunchKernelGGL((k_lnr_fwd<25>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, w, b, (unsigned short*)out, rows, eps, relu);
+                else hipLaunchKernelGGL((k_lnr_bwd<25>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short*)x, w, b, (const unsigned short*)dy,
+                                        (unsigned short*)out, dw, db, rows, eps, relu);
+                HIPCHK(hipGetLastError());
+                return CATAN_OK;
+            }
+        }
+        return ln_launch<T, 25, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     case 32: return ln_launch<T, 32, 32>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);
     case 64:
         if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0) return lnw_launch<T, 8, 8>(bwd, x, w, b, dy, out, dw, db, rows, eps, relu, st);

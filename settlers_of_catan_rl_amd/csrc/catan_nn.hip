@@ -349,6 +349,121 @@ __global__ __launch_bounds__(256) void k_lnw_fwd(const T* __restrict__ x, const 
     }
 }
 
+__device__ __forceinline__ unsigned short f2bf_ln(float v) { const __hip_bfloat16 h = __float2bfloat16(v); return *reinterpret_cast<const unsigned short*>(&h); }
+// LayerNorm over rows whose byte length is not a multiple of 16 (the 25-wide rows of the card-list / tile-output projections: 50 B
+// in bf16), one LANE per row: a workgroup copies 256 consecutive rows - one contiguous, 16-byte aligned span - into LDS with 16-byte
+// accesses, every lane normalises its row there, and the span leaves the same way.  k_ln_fwd / k_ln_bwd spend a lane per ELEMENT
+// (2-byte accesses, 25 of 32 lanes busy): 3.4 M x 25 backward 444 us = 1.2 TB/s.
+template <int D>
+__global__ __launch_bounds__(256) void k_lnr_fwd(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                 unsigned short* __restrict__ y, long rows, float eps, int relu) {
+    constexpr int SPAN = 256 * D;                                   // elements per workgroup pass (a multiple of 8: 16-byte pieces)
+    static_assert(SPAN % 8 == 0, "whole 16-byte pieces");
+    __shared__ __attribute__((aligned(16))) unsigned short sx[SPAN];
+    __shared__ float sw[D], sb[D];
+    if (threadIdx.x < D) { sw[threadIdx.x] = w[threadIdx.x]; sb[threadIdx.x] = bvec[threadIdx.x]; }
+    const long total = rows * D;
+    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+        const long e0 = r0 * D;
+        __syncthreads();
+        for (int c = threadIdx.x; c < SPAN / 8; c += 256) {
+            const long e = e0 + (long)c * 8;
+            if (e + 8 <= total) *reinterpret_cast<uint4*>(sx + c * 8) = *reinterpret_cast<const uint4*>(x + e);
+            else for (int k = 0; k < 8; k++) if (e + k < total) sx[c * 8 + k] = x[e + k];
+        }
+        __syncthreads();
+        if (r0 + threadIdx.x < rows) {
+            unsigned short* row = sx + threadIdx.x * D;
+            float v[D], mean = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; i++) { v[i] = __uint_as_float((unsigned)row[i] << 16); mean += v[i]; }
+            mean *= 1.0f / D;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; i++) { v[i] -= mean; sq += v[i] * v[i]; }
+            const float rstd = rsqrtf(sq * (1.0f / D) + eps);
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                float o = v[i] * rstd * sw[i] + sb[i];
+                if (relu) o = fmaxf(o, 0.f);
+                row[i] = f2bf_ln(o);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < SPAN / 8; c += 256) {
+            const long e = e0 + (long)c * 8;
+            if (e + 8 <= total) *reinterpret_cast<uint4*>(y + e) = *reinterpret_cast<const uint4*>(sx + c * 8);
+            else for (int k = 0; k < 8; k++) if (e + k < total) y[e + k] = sx[c * 8 + k];
+        }
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_lnr_bwd(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                                 const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx, float* __restrict__ dw,
+                                                 float* __restrict__ db, long rows, float eps, int relu) {
+    constexpr int SPAN = 256 * D;
+    __shared__ __attribute__((aligned(16))) unsigned short sx[SPAN];
+    __shared__ __attribute__((aligned(16))) unsigned short sg[SPAN];
+    __shared__ float sw[D], sb[D], saw[D], sab[D];
+    if (threadIdx.x < D) { sw[threadIdx.x] = w[threadIdx.x]; sb[threadIdx.x] = bvec[threadIdx.x]; saw[threadIdx.x] = 0.f; sab[threadIdx.x] = 0.f; }
+    float aw[D], ab[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) { aw[i] = 0.f; ab[i] = 0.f; }
+    const long total = rows * D;
+    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+        const long e0 = r0 * D;
+        __syncthreads();
+        for (int c = threadIdx.x; c < SPAN / 8; c += 256) {
+            const long e = e0 + (long)c * 8;
+            if (e + 8 <= total) {
+                *reinterpret_cast<uint4*>(sx + c * 8) = *reinterpret_cast<const uint4*>(x + e);
+                *reinterpret_cast<uint4*>(sg + c * 8) = *reinterpret_cast<const uint4*>(dy + e);
+            } else for (int k = 0; k < 8; k++) if (e + k < total) { sx[c * 8 + k] = x[e + k]; sg[c * 8 + k] = dy[e + k]; }
+        }
+        __syncthreads();
+        if (r0 + threadIdx.x < rows) {
+            const unsigned short* xr = sx + threadIdx.x * D;
+            unsigned short* gr = sg + threadIdx.x * D;
+            float v[D], g[D], mean = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; i++) { v[i] = __uint_as_float((unsigned)xr[i] << 16); g[i] = __uint_as_float((unsigned)gr[i] << 16); mean += v[i]; }
+            mean *= 1.0f / D;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; i++) { v[i] -= mean; sq += v[i] * v[i]; }
+            const float rstd = rsqrtf(sq * (1.0f / D) + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                v[i] *= rstd;                                          // x_hat
+                if (relu && v[i] * sw[i] + sb[i] <= 0.0f) g[i] = 0.0f;
+                aw[i] += g[i] * v[i]; ab[i] += g[i];
+                g[i] *= sw[i];
+                s1 += g[i]; s2 += g[i] * v[i];
+            }
+            const float m1 = s1 * (1.0f / D), m2 = s2 * (1.0f / D);
+#pragma unroll
+            for (int i = 0; i < D; i++) gr[i] = f2bf_ln(rstd * (g[i] - m1 - v[i] * m2));
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < SPAN / 8; c += 256) {
+            const long e = e0 + (long)c * 8;
+            if (e + 8 <= total) *reinterpret_cast<uint4*>(dx + e) = *reinterpret_cast<const uint4*>(sg + c * 8);
+            else for (int k = 0; k < 8; k++) if (e + k < total) dx[e + k] = sg[c * 8 + k];
+        }
+    }
+    // weight / bias gradients: over the wave with shuffles, over the workgroup in LDS, one atomic per column and workgroup
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        float a = aw[i], b = ab[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&saw[i], a); atomicAdd(&sab[i], b); }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) { atomicAdd(dw + threadIdx.x, saw[threadIdx.x]); atomicAdd(db + threadIdx.x, sab[threadIdx.x]); }
+}
+
 template <class T, int EPL, int GL>
 __global__ __launch_bounds__(256) void k_lnw_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
                                                  const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dw,

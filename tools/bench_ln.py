@@ -10,7 +10,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-for rows, D in ((204800, 128), (614400, 128), (204800, 256), (614400, 256), (204800, 512), (65536, 128), (65536, 256), (196608, 128), (196608, 256)):
+for rows, D in ((204800, 25), (614400, 25), (3412000, 25), (204800, 128), (614400, 128), (204800, 256), (614400, 256), (204800, 512), (65536, 128), (65536, 256), (196608, 128), (196608, 256)):
     ln = torch.nn.LayerNorm(D).cuda()
     x = torch.randn(rows, D, device="cuda").to(torch.bfloat16)
     xg = x.clone().requires_grad_(True)
