@@ -33,6 +33,22 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "unsupported" in err(L.catan_attention_fwd(C.c_void_p(q.data_ptr()), None, C.c_void_p(q.data_ptr()), 4, 7, 2, 8, 0, st))
     assert "unsupported" in err(L.catan_layer_norm_fwd(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()),
                                                        C.c_void_p(q.data_ptr()), 4, 48, 1e-5, 0, 0, st))
+    # round 3's learner / collector entry points: misaligned, odd-sized or missing buffers are refused, nothing is launched
+    P = lambda t: C.c_void_p(t.data_ptr())
+    b16 = torch.zeros((64, 512), device="cuda", dtype=torch.bfloat16)
+    idx = torch.zeros((8,), device="cuda", dtype=torch.int64)
+    assert "even" in err(L.catan_gather_rows(P(b16), 1024, P(idx), 8, P(b16), 1024, 7, st))
+    assert "16-byte" in err(L.catan_expand_rows(P(b16), P(idx), 8, P(b16), 1000, st))
+    assert "16-byte" in err(L.catan_segment_sum_rows(C.c_void_p(b16.data_ptr() + 2), 1024, P(idx), P(idx), 4, P(b16), 1024, st))
+    assert "null or misaligned" in err(L.catan_ffn_bwd_dx(P(b16), None, P(b16), P(b16), P(b16), P(dw), 1e-5, P(b16), P(b16), P(dw), P(dw), 16, st))
+    assert "null or misaligned" in err(L.catan_qkv_bwd_dx(P(b16), P(b16), C.c_void_p(b16.data_ptr() + 8), P(b16), P(dw), 1e-5, P(b16), P(dw), P(dw), 16, st))
+    assert "bad arguments" in err(L.catan_weight_images(None, 3, st)) and "bad arguments" in err(L.catan_weight_images(P(b16), 0, st))
+    saves = (C.c_void_p * 18)(*([b16.data_ptr()] * 17 + [0]))
+    assert "save buffer" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 475, C.cast(saves, C.c_void_p), 4, st))
+    assert "bad arguments" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 400, C.cast(saves, C.c_void_p), 4, st))
+    assert "bad arguments" in err(L.catan_collector_pre(64, 0, P(idx), P(idx), P(idx), P(idx), st))
+    assert "null" in err(L.catan_collector_post(64, 4, *([None] * 21)))
+    assert "bad arguments" in err(L.catan_head_chain(P(b16), 1536, P(b16), P(dw), 1e-5, 12, 0, P(dw), P(dw), P(dw), None, None, None, None, P(idx), P(dw), 64, st))
     with pytest.raises(_lib.CatanHipError):
         _lib.check(L.catan_random_rollout_deferred(env.h, 10, -3, st))
     # the handle is still usable after the failed calls
