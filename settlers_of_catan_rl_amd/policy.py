@@ -50,6 +50,9 @@ def _lin(x, w, b=None):
     return F.linear(x, w, b)
 
 
+_PARTS_MIN_ROWS = 131072
+
+
 def _lin_parts(parts, w, b):
     """Linear over the concatenation of `parts` along the last dim WITHOUT the concatenation: y = sum_k parts[k] @ W[:, cols_k].T
     + b (the reference concatenates - player_modules.py:66-69,109-111, observation_module.py:58-60 - and multiplies once: the
@@ -62,6 +65,20 @@ def _lin_parts(parts, w, b):
             ok = ok or nn_kernels.linear_supported(x, w[:, c:c + x.shape[-1]])
             c += x.shape[-1]
     if not ok:
+        x0 = parts[0]
+        rows = x0.numel() // x0.shape[-1]
+        if (not torch.is_grad_enabled() and x0.is_cuda and x0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and rows >= _PARTS_MIN_ROWS
+                and all(p.dim() == 2 and p.dtype == torch.bfloat16 for p in parts)):
+            # inference at 10^5..10^6 rows: one accumulating product per part instead of concatenation + one product - the rows of the
+            # concatenation are 612 / 562 / 1 974 bytes and the copy kernel moves them at a third of the HBM rate (at 1 M rows:
+            # 2.86 -> 2.13 ms for the final layer, 2.42 -> 1.25 ms for the opponents' module; tools/bench_cat_vs_parts.py)
+            y, c = None, 0
+            for x in parts:
+                n = x.shape[-1]
+                wt = w[:, c:c + n].t()
+                y = (torch.addmm(b, x, wt) if b is not None else torch.mm(x, wt)) if y is None else y.addmm_(x, wt)
+                c += n
+            return y
         return F.linear(torch.cat(parts, -1), w, b)
     y, c = None, 0
     for k, x in enumerate(parts):
