@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 CALIB_BYTES = 256 << 20
-TAIL = 96
+TAIL = int(os.environ.get("PMC_TAIL", "96"))
 out_path = sys.argv[1]
 dirs = sys.argv[2:]
 vals = defaultdict(list)                     # (kernel, counter) -> [(dispatch id, value)]
@@ -20,7 +20,9 @@ for d in dirs:
                 name = row["Kernel_Name"]
                 if "catan::" not in name:
                     continue
-                short = name.split("catan::")[1].split("(")[0].split("<")[0]
+                short = name.split("catan::")[1].split("(")[0]
+                if os.environ.get("PMC_KEEP_TEMPLATE_ARGS") != "1":
+                    short = short.split("<")[0]
                 vals[(short, row["Counter_Name"])].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
 kern = defaultdict(dict)
 for (k, c), lst in vals.items():

@@ -14,6 +14,9 @@ find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_default_kernel_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $REPO/tools/pmc_workload.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $REPO/tools/pmc_workload.py > $OUT/pmc_write.log 2>&1
 python $REPO/tools/pmc_summarise.py $OUT/pmc_summary.json $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_learner_fetch -o pmc -- python $REPO/tools/pmc_learner_workload.py > $OUT/pmc_learner_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_learner_write -o pmc -- python $REPO/tools/pmc_learner_workload.py > $OUT/pmc_learner_write.log 2>&1
+PMC_TAIL=4 PMC_KEEP_TEMPLATE_ARGS=1 python $REPO/tools/pmc_summarise.py $OUT/pmc_learner_summary.json $OUT/pmc_learner_fetch $OUT/pmc_learner_write > $OUT/pmc_learner_summary.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/learner -o learner -- python $REPO/tools/learner_rooflines_workload.py > $OUT/learner_rooflines.json 2> $OUT/learner.err
 find $OUT/learner -name "*kernel_stats.csv" -exec cp {} $OUT/learner_kernels_kernel_stats.csv \;
 STEPS=3 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o train -- python $REPO/tools/pmc_policy_workload.py > $OUT/train.log 2>&1
