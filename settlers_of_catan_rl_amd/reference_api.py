@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as cdist
+from . import nn_kernels
 from . import ppo as ppo_kernels
 from . import spec
 from .policy import CatanPolicy
@@ -728,6 +729,7 @@ class PPO(object):
                 self.bucket.allreduce()
                 nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
                 self.optimiser.step()
+                nn_kernels.weight_images.refresh_all()                                       # the bf16 / transposed / packed images of the new weights: one launch (nothing on the CPU)
                 s = torch.stack((parts[1].detach() * self.value_loss_coef, parts[0].detach(), entropy.detach().float() * self.entropy_coef))
                 sums = s if sums is None else sums + s
                 n_steps += 1
