@@ -1050,3 +1050,43 @@ def test_row_gather_expand_and_segment_sum_kernels(hip_lib):
     ref = torch.zeros(U, W, device="cuda").index_add_(0, inv, dy.float())
     assert gsrc.dtype == torch.bfloat16 and float((gsrc.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
     assert torch.equal(gsrc[counts == 1], dy[order[start[:-1][counts == 1]]])  # single-row boards: the row's own bits
+
+
+def test_weight_images_change_nothing(hip_lib):
+    """nn_kernels.weight_images (persistent bf16 / transposed / packed images of the master weights, refreshed by one launch after
+    the optimiser step) against per-use casts: the same rollout, the same seeds, two PPO updates of three epochs - with a parameter
+    overwritten from outside between them (the version counters must tell).  An image holds exactly what the cast would have
+    produced, so the two nets differ by no more than two runs of the SAME setting do (the weight-gradient and LayerNorm backward
+    kernels add their partial sums with fp32 atomics: a step is reproducible to ~1e-4 of a parameter, not to the bit)."""
+    import copy
+    from settlers_of_catan_rl_amd import nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    torch.manual_seed(0)
+    N, T = 4096, 16
+    env = VecCatanEnv(N, seed=23); env.random_rollout(0, 700)
+    net0 = CatanPolicy().cuda()
+    col = RolloutCollector(env, net0, T, seed=4, autocast_dtype=torch.bfloat16)
+    st = col.gather_rollouts()
+    saved = nn_kernels.weight_images.enabled
+    res = []
+    try:
+        for enabled in (True, False, False):
+            nn_kernels.weight_images.enabled = enabled
+            net = copy.deepcopy(net0)
+            tr = PPOTrainer(net, PPOConfig(ppo_epoch=3, num_mini_batch=2), autocast_dtype=torch.bfloat16, seed=5)
+            tr.update(st)
+            with torch.no_grad():                                  # a change the registry did not make
+                net.observation_module.tile_encoder.out_proj.weight.mul_(1.25)
+                net.action_head_module.action_heads[2].mlp_2.weight.add_(0.01)
+            tr.update(st)
+            res.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+    finally:
+        nn_kernels.weight_images.enabled = saved
+    assert len(nn_kernels.weight_images.entries) > 100
+    noise = float((res[1] - res[2]).abs().max())
+    diff = float((res[0] - res[1]).abs().max())
+    moved = float((res[1] - torch.cat([p.detach().reshape(-1) for p in net0.parameters()])).abs().max())
+    assert moved > 1e-2 and diff <= 4.0 * noise + 1e-6, (diff, noise, moved)
