@@ -1,5 +1,6 @@
+"""Diagnostics (GPU box): k_attn_mfma_fwd / _bwd alone at a minibatch's 204 800 tile sequences (19 tokens, 4 heads x 16)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from settlers_of_catan_rl_amd import nn_kernels
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(204800, 19, 3, 4, 16, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)

@@ -1,3 +1,4 @@
+"""Diagnostics (GPU box): PPOTrainer.compute_values at config 3 (13.2 M observations) over the rows per forward (PPOConfig.value_chunk)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
