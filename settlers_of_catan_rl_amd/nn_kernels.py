@@ -161,8 +161,18 @@ class _WeightImages(object):
         self.entries, self.by_key, self.dirty, self.table = [], {}, True, None
         self.enabled = os.environ.get("CATAN_WEIGHT_IMAGES", "1") != "0"
 
+    MAX_ENTRIES = 8192       # a process that keeps building nets (a test session) starts over instead of growing the table for ever
+
+    def clear(self):
+        """forget every image (they are rebuilt on their next use); the sources of dropped nets are released with them"""
+        global _TE_IMAGES
+        self.entries, self.by_key, self.dirty, self.table = [], {}, True, None
+        _TE_IMAGES = None
+
     def add(self, src2, dst_view, mode, out):
         """src2: 2-D fp32 view of a parameter; dst_view: a view of the image buffer indexed like src2 (any strides)"""
+        if len(self.entries) >= self.MAX_ENTRIES:
+            self.clear()
         e = _WeightImages.Entry()
         e.src, e.dst_view, e.mode, e.out, e.version = src2.detach(), dst_view, mode, out, -1
         self.entries.append(e)
@@ -703,7 +713,11 @@ def _te_images(te):
         _TE_IMAGES = weakref.WeakKeyDictionary()              # (not on the module: a deepcopy - inference_copy - must not carry them along)
     im = _TE_IMAGES.get(te)
     if im is None or im.stamp != (te.first_layer.weight.data_ptr(), te.first_layer.weight.device):
-        im = _TE_IMAGES[te] = _TeImages(te)
+        im = _TeImages(te)
+        if _TE_IMAGES is None:                                # (the registry started over while the images were being registered)
+            import weakref
+            _TE_IMAGES = weakref.WeakKeyDictionary()
+        _TE_IMAGES[te] = im
     return im.current()
 
 
