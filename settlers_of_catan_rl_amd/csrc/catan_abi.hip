@@ -1026,6 +1026,22 @@ int catan_weight_images(const void* table, int32_t n, catan_stream_t stream) {
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
+                  float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
+    if (!dx || !h || !x || !n || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || rows <= 0 ||
+        (((uintptr_t)dx | (uintptr_t)h | (uintptr_t)x | (uintptr_t)n | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dx_out) & 15))
+        return fail(CATAN_EINVAL, "catan_ffn_bwd: null or misaligned argument");
+    // every block ends with 16 640 atomics: several stages of 64 rows per block, at most 512 blocks (the grid rule of wgrad_grid)
+    const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
+    long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
+    const long per = (stages + nb - 1) / nb * FW_ROWS;
+    nb = (rows + per - 1) / per;
+    hipLaunchKernelGGL(k_ffn_bwd_w, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+                       dln_w, dln_b, (long)rows, per);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,

@@ -301,4 +301,200 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_dx(const unsigned short* __rest
     if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
 }
 
+
+// k_ffn_bwd_w: k_ffn_bwd_dx AND the sub-layer's two weight gradients in one pass over the rows.  The weight gradients
+// (catan_linear_wgrad: dW2 = dX^T H, dW1 = dH^T N) re-read dX, H, dH and N from HBM although k_ffn_bwd_dx has three of them on chip:
+// 384 of the 832 bf16 elements the chain moved per token.  Here a workgroup takes 64 token rows per stage: dX, H, X and N are staged
+// in LDS in k_wgrad_tr's sub-tile image (row-major inside 32 x 16 sub-tiles: a row fragment is one 16-byte read, a transposed
+// fragment one ds_read_tr16_b64 pair), every wave takes its 16 rows through k_ffn_bwd_dx's chain - dH goes into an LDS image instead
+// of HBM - and then, over all 64 rows, accumulates its quarter of dW2 (one 16-row tile of the 64 outputs x 128 + 1 columns; the
+// extra column of ones yields db2) and of dW1 (two tiles of the 128 x 64 + 1) on MFMA; the accumulators leave by fp32 atomics at
+// the end, as in k_wgrad_tr.  HBM: dX, H, X, N in, dX' out: 384 elements per token.
+constexpr int FW_ROWS = 64;
+constexpr int FW_IMG64 = 4 * 2 * WG_SUB, FW_IMG65 = 5 * 2 * WG_SUB, FW_IMG128 = 8 * 2 * WG_SUB, FW_IMG129 = 9 * 2 * WG_SUB;   // elements per image
+DEVI int fw_off(int row, int col) { return wg_sub_off(col >> 4, row >> 5) + (row & 31) * 16 + (col & 15); }
+__global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restrict__ dx, const unsigned short* __restrict__ h, const unsigned short* __restrict__ x,
+                                                   const unsigned short* __restrict__ n2, const unsigned short* __restrict__ w2t, const unsigned short* __restrict__ w1t,
+                                                   const float* __restrict__ lnw, float eps, unsigned short* __restrict__ dxo,
+                                                   float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1,
+                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block) {
+    __shared__ __attribute__((aligned(16))) unsigned short sDX[FW_IMG64];      // dX; the rows of dX' replace X below
+    __shared__ __attribute__((aligned(16))) unsigned short sX[FW_IMG64];
+    __shared__ __attribute__((aligned(16))) unsigned short sH[FW_IMG129];      // H and the column of ones
+    __shared__ __attribute__((aligned(16))) unsigned short sN[FW_IMG65];       // N = LayerNorm(X) and the column of ones
+    __shared__ __attribute__((aligned(16))) unsigned short sDH[FW_IMG128];
+    __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * FB_P];
+    __shared__ __attribute__((aligned(16))) unsigned short sW1[64 * FB_P1];
+    __shared__ float sG[2][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
+    if (r_begin >= rows) return;
+    if (tid < 128) (&sG[0][0])[tid] = 0.f;
+    for (int c = tid; c < 128 * 8; c += 256) { const int n = c >> 3, ch = c & 7; *reinterpret_cast<uint4*>(sW2 + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(w2t + n * 64 + ch * 8); }
+    for (int c = tid; c < 64 * 16; c += 256) { const int n = c >> 4, ch = c & 15; *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8); }
+    for (int c = tid; c < FW_IMG129; c += 256) sH[c] = 0;                        // (the ones columns' tiles: everything but column 0 stays zero)
+    for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
+    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    f32x4_t acc2[9], acc1[2][5];
+#pragma unroll
+    for (int b = 0; b < 9; b++) acc2[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc1[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 vdx[2], vx[2], vn[2], vh[4];
+    wg_load<2>(dx, r_begin * 64, rows * 64, 64, vdx, tid);
+    wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
+    wg_load<2>(n2, r_begin * 64, rows * 64, 64, vn, tid);
+    wg_load<4>(h, r_begin * 128, rows * 128, 128, vh, tid);
+    __syncthreads();
+    const int row = 16 * wave + lr;                                             // this lane's token row of the stage (operand layout)
+    for (long r0 = r_begin; r0 < r_end; r0 += FW_ROWS) {
+        wg_store_rows<2>(sDX, 64, vdx, tid);
+        wg_store_rows<2>(sX, 64, vx, tid);
+        wg_store_rows<2>(sN, 64, vn, tid);
+        wg_store_rows<4>(sH, 128, vh, tid);
+        if (tid < FW_ROWS) {
+            const unsigned short one = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;   // bf16 1.0: the bias columns
+            sH[fw_off(tid, 128)] = one; sN[fw_off(tid, 64)] = one;
+        }
+        __syncthreads();
+        if (r0 + FW_ROWS < r_end) {                                              // the next stage's rows fly during this stage
+            wg_load<2>(dx, (r0 + FW_ROWS) * 64, rows * 64, 64, vdx, tid);
+            wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
+            wg_load<2>(n2, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
+            wg_load<4>(h, (r0 + FW_ROWS) * 128, rows * 128, 128, vh, tid);
+        }
+        // ---- dH^T = W2^T . dX^T, masked by H > 0 (this wave's 16 rows), into the dH image
+        bf16x8_t db[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) db[s] = *reinterpret_cast<const bf16x8_t*>(sDX + fw_off(row, 32 * s + 8 * g));
+        unsigned hp[4][4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW2 + (16 * j + lr) * FB_P + 32 * s + 8 * g), db[s], c, 0, 0, 0);
+            const uint2 hv = *reinterpret_cast<const uint2*>(sH + fw_off(row, 16 * j + 4 * g));
+            const unsigned d0 = __uint_as_float(hv.x << 16) > 0.f ? te_to_bf(c[0]) : 0u, d1 = __uint_as_float(hv.x & 0xFFFF0000u) > 0.f ? te_to_bf(c[1]) : 0u;
+            const unsigned d2 = __uint_as_float(hv.y << 16) > 0.f ? te_to_bf(c[2]) : 0u, d3 = __uint_as_float(hv.y & 0xFFFF0000u) > 0.f ? te_to_bf(c[3]) : 0u;
+            const unsigned p0 = d0 | (d1 << 16), p1 = d2 | (d3 << 16);
+            hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
+            *reinterpret_cast<uint2*>(sDH + fw_off(row, 16 * j + 4 * g)) = make_uint2(p0, p1);
+        }
+        // ---- dN = dH . W1: lane holds rows 4 g + r of the wave's 16, column 16 t + lr
+        float dn[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                uint4 au; au.x = hp[s][0]; au.y = hp[s][1]; au.z = hp[s][2]; au.w = hp[s][3];
+                const unsigned short* wr = sW1 + (16 * t + lr) * FB_P1 + 32 * s + 4 * g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(wr), hi = *reinterpret_cast<const uint2*>(wr + 16);
+                uint4 bu; bu.x = lo.x; bu.y = lo.y; bu.z = hi.x; bu.w = hi.y;
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&au), *reinterpret_cast<const bf16x8_t*>(&bu), c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) dn[t][r] = hd_bf(c[r]);
+        }
+        // ---- LayerNorm backward + the residual dX; the result replaces the wave's rows of the X image
+        float xv[4][4], res[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = fw_off(16 * wave + 4 * g + r, 16 * t + lr);
+                xv[t][r] = te_bf(sX[o]); res[t][r] = te_bf(sDX[o]);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float sum = xv[0][r] + xv[1][r] + xv[2][r] + xv[3][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { xv[t][r] -= mean; sq += xv[t][r] * xv[t][r]; }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+            const bool live = r0 + 16 * wave + 4 * g + r < r_end;
+            float gw[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                xv[t][r] *= rstd;
+                const float gy = live ? dn[t][r] : 0.f;
+                aw[t] += gy * xv[t][r]; ab[t] += gy;
+                gw[t] = gy * wl[t];
+                s1 += gw[t]; s2 += gw[t] * xv[t][r];
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                sX[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = te_to_bf(hd_bf(rstd * (gw[t] - m1 - xv[t][r] * m2)) + res[t][r]);
+        }
+        __syncthreads();                                                         // dH image and the dX' rows complete
+        // ---- the stage's rows of dX' leave (16-byte pieces of the image rows)
+        for (int c = tid; c < FW_ROWS * 8; c += 256) {
+            const int rr = c >> 3, ch = c & 7;
+            if (r0 + rr < r_end) *reinterpret_cast<uint4*>(dxo + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(sX + fw_off(rr, ch * 8));
+        }
+        // ---- weight gradients over the stage's 64 rows: dW2 tile `wave` (16 outputs) x 9 column tiles, dW1 tiles 2 wave, 2 wave + 1 x 5
+#pragma unroll
+        for (int ks = 0; ks < FW_ROWS / 32; ks++) {
+            const bf16x8_t a2 = wg_frag_tr(sDX, wave, ks, lane);
+#pragma unroll
+            for (int b = 0; b < 9; b++) acc2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, wg_frag_tr(sH, b, ks, lane), acc2[b], 0, 0, 0);
+            bf16x8_t bn[5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) bn[b] = wg_frag_tr(sN, b, ks, lane);
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const bf16x8_t a1f = wg_frag_tr(sDH, 2 * wave + a, ks, lane);
+#pragma unroll
+                for (int b = 0; b < 5; b++) acc1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1f, bn[b], acc1[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                         // (the next stage overwrites the images)
+    }
+    // ---- accumulators -> global (fp32 atomics; zeroed by the caller)
+#pragma unroll
+    for (int b = 0; b < 9; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int o = wave * 16 + 4 * g + r, i = b * 16 + lr;
+            const float v = acc2[b][r];
+            if (v != 0.0f) { if (i < 128) atomicAdd(&dw2[o * 128 + i], v); else if (i == 128) atomicAdd(&db2[o], v); }
+        }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (2 * wave + a) * 16 + 4 * g + r, i = b * 16 + lr;
+                const float v = acc1[a][b][r];
+                if (v != 0.0f) { if (i < 64) atomicAdd(&dw1[o * 64 + i], v); else if (i == 64) atomicAdd(&db1[o], v); }
+            }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        aw[t] += __shfl_xor(aw[t], 16); aw[t] += __shfl_xor(aw[t], 32);
+        ab[t] += __shfl_xor(ab[t], 16); ab[t] += __shfl_xor(ab[t], 32);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { atomicAdd(&sG[0][16 * t + lr], aw[t]); atomicAdd(&sG[1][16 * t + lr], ab[t]); }
+    }
+    __syncthreads();
+    if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
+}
+
 }  // namespace catan

@@ -803,7 +803,17 @@ class _TileEncoderTrain(torch.autograd.Function):
                 else:
                     w2t, w1t, wot = P[b + 14].to(bf).t().contiguous(), P[b + 12].to(bf).t().contiguous(), P[b + 8].to(bf).t().contiguous()
                     wqt = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf).t().contiguous()
-                if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
+                if os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1":
+                    # k_ffn_bwd_w: the chain below AND both weight gradients in one pass over the rows (dH never leaves the chip)
+                    dxmid = torch.empty_like(xmid)
+                    acc = torch.zeros((64 * 128 + 64 + 128 * 64 + 128 + 128,), dtype=torch.float32, device=h.device)
+                    dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:]
+                    lw = P[b + 10].detach().float().contiguous()
+                    _lib.check(_lib.lib().catan_ffn_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
+                                                        _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
+                    g[b + 14], g[b + 15], g[b + 12], g[b + 13], g[b + 10], g[b + 11] = dw2.view(64, 128), db2, dw1.view(128, 64), db1, dl[:64], dl[64:]
+                    dh = None
+                elif os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
                     dh = _rows_product(dx, w2t, h, MODE_RELU_MASK)                        # (dx @ w2) where h > 0
                     dn2 = _rows_product(dh, w1t)
                     dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
@@ -814,8 +824,9 @@ class _TileEncoderTrain(torch.autograd.Function):
                     _lib.check(_lib.lib().catan_ffn_bwd_dx(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dh), _ptr(dxmid),
                                                            _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
                     g[b + 10], g[b + 11] = dl[0], dl[1]
-                g[b + 14], g[b + 15] = _wgrad(h, dx, True)
-                g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
+                if dh is not None:
+                    g[b + 14], g[b + 15] = _wgrad(h, dx, True)
+                    g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
                 do = _rows_product(dxmid, wot)
                 g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
