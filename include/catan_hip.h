@@ -124,6 +124,11 @@ typedef struct catan_weight_image {
 int32_t catan_weight_image_bytes(void);
 int catan_weight_images(const void* table, int32_t n, catan_stream_t stream);
 
+/* catan_qkv_bwd_dx AND the QKV product's weight gradient in one pass (k_qkv_bwd_w): additionally n [rows][64] = LayerNorm 1's output;
+ * dw float [192][64] and db [192] are ACCUMULATED into (zero first). */
+int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, float eps, void* dx_out, float* dw, float* db,
+                  float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
+
 /* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
  * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
  * catan_gather_rows: dst row j = src row idx[j]; rows of `row_bytes` (even) at any even address and pitch.

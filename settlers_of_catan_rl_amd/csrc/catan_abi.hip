@@ -1042,6 +1042,20 @@ int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, c
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, float eps, void* dx_out, float* dw, float* db,
+                  float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
+    if (!dqkv || !x || !dres || !n || !wt || !ln_w || !dx_out || !dw || !db || !dln_w || !dln_b || rows <= 0 ||
+        (((uintptr_t)dqkv | (uintptr_t)x | (uintptr_t)dres | (uintptr_t)n | (uintptr_t)wt | (uintptr_t)dx_out) & 15))
+        return fail(CATAN_EINVAL, "catan_qkv_bwd: null or misaligned argument");
+    const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
+    long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
+    const long per = (stages + nb - 1) / nb * FW_ROWS;
+    nb = (rows + per - 1) / per;
+    hipLaunchKernelGGL(k_qkv_bwd_w, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
+                       (const unsigned short*)n, (const unsigned short*)wt, ln_w, eps, (unsigned short*)dx_out, dw, db, dln_w, dln_b, (long)rows, per);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_head_weight_elems(void) { return HD_WELEMS; }
 int32_t catan_head_vec_elems(void) { return HD_VELEMS; }
 int catan_head_fwd(const void* pre, int64_t pre_ld, const float* cond, int64_t cond_ld, int32_t ncond, const void* wts, const float* vec, float eps,

@@ -497,4 +497,154 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
 }
 
+
+// k_qkv_bwd_w: k_qkv_bwd_dx AND the QKV product's weight gradient (dWqkv = dQKV^T N, N = LayerNorm 1's output) in one pass, built as
+// k_ffn_bwd_w: 64-row stages, dQKV / X / the residual gradient / N in LDS images, wave w accumulates output tiles 3 w .. 3 w + 2 of
+// the 192 x (64 + 1) gradient.  HBM: dQKV, X, the residual gradient, N in, dX out (the separate weight-gradient kernel read dQKV and N again).
+constexpr int FW_IMG192 = 12 * 2 * WG_SUB;
+__global__ __launch_bounds__(256) void k_qkv_bwd_w(const unsigned short* __restrict__ dqkv, const unsigned short* __restrict__ x, const unsigned short* __restrict__ dres,
+                                                   const unsigned short* __restrict__ n1, const unsigned short* __restrict__ wt, const float* __restrict__ lnw, float eps,
+                                                   unsigned short* __restrict__ dxo, float* __restrict__ dw, float* __restrict__ dbias,
+                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block) {
+    __shared__ __attribute__((aligned(16))) unsigned short sDQ[FW_IMG192];
+    __shared__ __attribute__((aligned(16))) unsigned short sX[FW_IMG64];       // X; the rows of dX replace it below
+    __shared__ __attribute__((aligned(16))) unsigned short sR[FW_IMG64];       // the residual gradient
+    __shared__ __attribute__((aligned(16))) unsigned short sN[FW_IMG65];       // N and the column of ones
+    __shared__ __attribute__((aligned(16))) unsigned short sW[64 * QB_PW];
+    __shared__ float sG[2][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
+    if (r_begin >= rows) return;
+    if (tid < 128) (&sG[0][0])[tid] = 0.f;
+    for (int c = tid; c < 64 * (QB_K / 8); c += 256) {
+        const int n = c / (QB_K / 8), ch = c - n * (QB_K / 8);
+        *reinterpret_cast<uint4*>(sW + n * QB_PW + ch * 8) = *reinterpret_cast<const uint4*>(wt + n * QB_K + ch * 8);
+    }
+    for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
+    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    f32x4_t acc[3][5];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 vq[6], vx[2], vr[2], vn[2];
+    wg_load<6>(dqkv, r_begin * QB_K, rows * QB_K, QB_K, vq, tid);
+    wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
+    wg_load<2>(dres, r_begin * 64, rows * 64, 64, vr, tid);
+    wg_load<2>(n1, r_begin * 64, rows * 64, 64, vn, tid);
+    __syncthreads();
+    const int row = 16 * wave + lr;
+    for (long r0 = r_begin; r0 < r_end; r0 += FW_ROWS) {
+        wg_store_rows<6>(sDQ, QB_K, vq, tid);
+        wg_store_rows<2>(sX, 64, vx, tid);
+        wg_store_rows<2>(sR, 64, vr, tid);
+        wg_store_rows<2>(sN, 64, vn, tid);
+        if (tid < FW_ROWS) sN[fw_off(tid, 64)] = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;
+        __syncthreads();
+        if (r0 + FW_ROWS < r_end) {
+            wg_load<6>(dqkv, (r0 + FW_ROWS) * QB_K, rows * QB_K, QB_K, vq, tid);
+            wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
+            wg_load<2>(dres, (r0 + FW_ROWS) * 64, rows * 64, 64, vr, tid);
+            wg_load<2>(n1, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
+        }
+        // ---- dN = dQKV . Wqkv for this wave's 16 rows
+        float dn[4][4];
+        {
+            bf16x8_t a[QB_K / 32];
+#pragma unroll
+            for (int s = 0; s < QB_K / 32; s++) a[s] = *reinterpret_cast<const bf16x8_t*>(sDQ + fw_off(row, 32 * s + 8 * g));
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                f32x4_t c = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int s = 0; s < QB_K / 32; s++)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], *reinterpret_cast<const bf16x8_t*>(sW + (16 * t + lr) * QB_PW + 32 * s + 8 * g), c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) dn[t][r] = hd_bf(c[r]);
+            }
+        }
+        float xv[4][4], res[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = fw_off(16 * wave + 4 * g + r, 16 * t + lr);
+                xv[t][r] = te_bf(sX[o]); res[t][r] = te_bf(sR[o]);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float sum = xv[0][r] + xv[1][r] + xv[2][r] + xv[3][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { xv[t][r] -= mean; sq += xv[t][r] * xv[t][r]; }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+            const bool live = r0 + 16 * wave + 4 * g + r < r_end;
+            float gw[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                xv[t][r] *= rstd;
+                const float gy = live ? dn[t][r] : 0.f;
+                aw[t] += gy * xv[t][r]; ab[t] += gy;
+                gw[t] = gy * wl[t];
+                s1 += gw[t]; s2 += gw[t] * xv[t][r];
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                sX[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = te_to_bf(hd_bf(rstd * (gw[t] - m1 - xv[t][r] * m2)) + res[t][r]);
+        }
+        __syncthreads();
+        for (int c = tid; c < FW_ROWS * 8; c += 256) {
+            const int rr = c >> 3, ch = c & 7;
+            if (r0 + rr < r_end) *reinterpret_cast<uint4*>(dxo + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(sX + fw_off(rr, ch * 8));
+        }
+        // ---- dWqkv over the stage's 64 rows: output tiles 3 wave .. 3 wave + 2, 5 column tiles (64 + the ones)
+#pragma unroll
+        for (int ks = 0; ks < FW_ROWS / 32; ks++) {
+            bf16x8_t bn[5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) bn[b] = wg_frag_tr(sN, b, ks, lane);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const bf16x8_t af = wg_frag_tr(sDQ, 3 * wave + a, ks, lane);
+#pragma unroll
+                for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bn[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (3 * wave + a) * 16 + 4 * g + r, i = b * 16 + lr;
+                const float v = acc[a][b][r];
+                if (v != 0.0f) { if (i < 64) atomicAdd(&dw[o * 64 + i], v); else if (i == 64) atomicAdd(&dbias[o], v); }
+            }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        aw[t] += __shfl_xor(aw[t], 16); aw[t] += __shfl_xor(aw[t], 32);
+        ab[t] += __shfl_xor(ab[t], 16); ab[t] += __shfl_xor(ab[t], 32);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { atomicAdd(&sG[0][16 * t + lr], aw[t]); atomicAdd(&sG[1][16 * t + lr], ab[t]); }
+    }
+    __syncthreads();
+    if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
+}
+
 }  // namespace catan

@@ -831,10 +831,22 @@ class _TileEncoderTrain(torch.autograd.Function):
                 g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
                 _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
-                dwq, dbq = _wgrad(n1, dqkv, True)
+                fused_w = os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1"
+                if fused_w:                     # k_qkv_bwd_w: the QKV product's weight gradient and the dX chain in one pass over the rows
+                    dx = torch.empty_like(xin)
+                    acc = torch.zeros((192 * 64 + 192 + 128,), dtype=torch.float32, device=xin.device)
+                    dwq, dbq, dl = acc[:12288].view(192, 64), acc[12288:12480], acc[12480:]
+                    lw = P[b].detach().float().contiguous()
+                    _lib.check(_lib.lib().catan_qkv_bwd(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(n1), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dwq), _ptr(dbq),
+                                                        _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
+                    g[b], g[b + 1] = dl[:64], dl[64:]
+                else:
+                    dwq, dbq = _wgrad(n1, dqkv, True)
                 for k in range(3):
                     g[b + 2 + 2 * k], g[b + 3 + 2 * k] = dwq[64 * k:64 * k + 64], dbq[64 * k:64 * k + 64]
-                if os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
+                if fused_w:
+                    pass
+                elif os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
                     dn1 = _rows_product(dqkv, wqt)
                     dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)
                 else:                           # the same two steps in one pass over the rows (k_qkv_bwd_dx)

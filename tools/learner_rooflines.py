@@ -97,7 +97,18 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     dq = torch.randn(tokf, 192, device=dev, generator=g).to(torch.bfloat16); wqt = torch.randn(64, 192, device=dev, generator=g).to(torch.bfloat16)
     us = _time_us(lambda: _lib.check(_lib.lib().catan_qkv_bwd_dx(P(dq), P(xm), P(dxg), P(wqt), P(lw), 1e-5, P(dxo), P(dl[0]), P(dl[1]), tokf, S())), reps=5)
     out.append(_entry("k_qkv_bwd_dx (dQKV Wqkv, LayerNorm backward + residual)", f"{tokf} rows", us, (192 + 64 + 64 + 64) * 2 * tokf, flops=2 * 192 * 64 * tokf))
-    del dxg, hh, xm, dh, dxo, dq
+    # ---- the same chains WITH the sub-layers' weight gradients in the pass (k_ffn_bwd_w, k_qkv_bwd_w: what the update's backward runs)
+    n2 = torch.randn(tokf, 64, device=dev, generator=g).to(torch.bfloat16)
+    accw = torch.zeros(64 * 128 + 64 + 128 * 64 + 128 + 192 * 64 + 192, device=dev)
+    us = _time_us(lambda: _lib.check(_lib.lib().catan_ffn_bwd(P(dxg), P(hh), P(xm), P(n2), P(w2t), P(w1t), P(lw), 1e-5, P(dxo), P(accw[:8192]), P(accw[8192:8256]),
+                                                              P(accw[8256:16448]), P(accw[16448:16576]), P(dl[0]), P(dl[1]), tokf, S())), reps=5)
+    out.append(_entry("k_ffn_bwd_w (k_ffn_bwd_dx + dW2 = dX^T H and dW1 = dH^T N in the same pass)", f"{tokf} rows", us, (64 + 128 + 64 + 64 + 64) * 2 * tokf,
+                      flops=2 * 4 * 64 * 128 * tokf, note="dX, H, X, N in; dX' out; dH stays in LDS"))
+    us = _time_us(lambda: _lib.check(_lib.lib().catan_qkv_bwd(P(dq), P(xm), P(dxg), P(n2), P(wqt), P(lw), 1e-5, P(dxo), P(accw[16576:28864]), P(accw[28864:29056]),
+                                                              P(dl[0]), P(dl[1]), tokf, S())), reps=5)
+    out.append(_entry("k_qkv_bwd_w (k_qkv_bwd_dx + dWqkv = dQKV^T N in the same pass)", f"{tokf} rows", us, (192 + 64 + 64 + 64 + 64) * 2 * tokf,
+                      flops=2 * 2 * 192 * 64 * tokf))
+    del dxg, hh, xm, dh, dxo, dq, n2
     # ---- row movement of a minibatch: the distinct boards' tile features out of the rollout rows (2-byte aligned 3 574-byte rows),
     #      a per-board result spread to the rows, the rows' gradients summed per board
     rows_all = 16 * rows_mb
