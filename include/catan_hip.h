@@ -107,6 +107,12 @@ int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w
  * forward stored it; dw2 float [64][128], db2 [64], dw1 [128][64], db1 [128] are ACCUMULATED into (zero first); dh is not written. */
 int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
                   float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
+/* catan_ffn_bwd plus the backward of the out-projection that produced x (x = x_in + o Wo^T + bo): d_o [rows][64] = dx_out Wo,
+ * dwo float [64][64] and dbo [64] accumulated, from the dx_out rows while they are on chip.  o [rows][64] = the attention output,
+ * wot = Wo^T bf16 [64][64] (k_ffn_bwd_w<true>). */
+int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
+                          float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+                          const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream);
 /* The attention sub-layer's input side x_mid = x + out_proj(attention(qkv(LayerNorm(x)))) (width 64): the gradient of x from dqkv
  * [rows][192] (catan_attention_bwd's output) - (dqkv . Wqkv) through the LayerNorm backward, plus the residual gradient dres = d(x_mid)
  * [rows][64] - in one pass.  wt = Wqkv^T bf16 [64][192]; x [rows][64] = the LayerNorm's input; dln_w / dln_b float [64] ACCUMULATED into. */

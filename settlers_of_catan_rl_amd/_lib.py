@@ -101,6 +101,7 @@ _SIGS = {
     "catan_masked_row_store": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "catan_ffn_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_ffn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_ffn_outproj_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_qkv_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_qkv_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_weight_image_bytes": (C.c_int32, []),

@@ -1036,9 +1036,27 @@ int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, c
     long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
     const long per = (stages + nb - 1) / nb * FW_ROWS;
     nb = (rows + per - 1) / per;
-    hipLaunchKernelGGL(k_ffn_bwd_w, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+    FfnOutProj op = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    hipLaunchKernelGGL(k_ffn_bwd_w<false>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
                        (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
-                       dln_w, dln_b, (long)rows, per);
+                       dln_w, dln_b, (long)rows, per, op);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
+                          float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+                          const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream) {
+    if (!dx || !h || !x || !n || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || !o || !wot || !d_o || !dwo || !dbo || rows <= 0 ||
+        (((uintptr_t)dx | (uintptr_t)h | (uintptr_t)x | (uintptr_t)n | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dx_out | (uintptr_t)o | (uintptr_t)wot | (uintptr_t)d_o) & 15))
+        return fail(CATAN_EINVAL, "catan_ffn_outproj_bwd: null or misaligned argument");
+    const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
+    long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
+    const long per = (stages + nb - 1) / nb * FW_ROWS;
+    nb = (rows + per - 1) / per;
+    FfnOutProj op = { (const unsigned short*)o, (const unsigned short*)wot, (unsigned short*)d_o, dwo, dbo };
+    hipLaunchKernelGGL(k_ffn_bwd_w<true>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+                       dln_w, dln_b, (long)rows, per, op);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -313,11 +313,17 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_dx(const unsigned short* __rest
 constexpr int FW_ROWS = 64;
 constexpr int FW_IMG64 = 4 * 2 * WG_SUB, FW_IMG65 = 5 * 2 * WG_SUB, FW_IMG128 = 8 * 2 * WG_SUB, FW_IMG129 = 9 * 2 * WG_SUB;   // elements per image
 DEVI int fw_off(int row, int col) { return wg_sub_off(col >> 4, row >> 5) + (row & 31) * 16 + (col & 15); }
+// OP: also the backward of the out-projection that FEEDS this sub-layer's input (x = x_in + o Wo^T + bo: the gradient of x is the
+// gradient of that product's output): dO = dX' Wo and dWo = dX'^T O from the dX' rows while they are in LDS - the separate row
+// product and weight-gradient kernels read dX' twice more.  o [rows][64] = the attention output, wot = Wo^T [64 in][64 out],
+// d_o [rows][64] out, dwo [64][64] / dbo [64] accumulated.
+struct FfnOutProj { const unsigned short* o; const unsigned short* wot; unsigned short* d_o; float* dwo; float* dbo; };
+template <bool OP>
 __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restrict__ dx, const unsigned short* __restrict__ h, const unsigned short* __restrict__ x,
                                                    const unsigned short* __restrict__ n2, const unsigned short* __restrict__ w2t, const unsigned short* __restrict__ w1t,
                                                    const float* __restrict__ lnw, float eps, unsigned short* __restrict__ dxo,
                                                    float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1,
-                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block) {
+                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block, FfnOutProj op) {
     __shared__ __attribute__((aligned(16))) unsigned short sDX[FW_IMG64];      // dX; the rows of dX' replace X below
     __shared__ __attribute__((aligned(16))) unsigned short sX[FW_IMG64];
     __shared__ __attribute__((aligned(16))) unsigned short sH[FW_IMG129];      // H and the column of ones
@@ -325,12 +331,18 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     __shared__ __attribute__((aligned(16))) unsigned short sDH[FW_IMG128];
     __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * FB_P];
     __shared__ __attribute__((aligned(16))) unsigned short sW1[64 * FB_P1];
+    __shared__ __attribute__((aligned(16))) unsigned short sO[OP ? FW_IMG65 : 8];        // O and the column of ones
+    __shared__ __attribute__((aligned(16))) unsigned short sWo[OP ? 64 * FB_P : 8];
     __shared__ float sG[2][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
     if (r_begin >= rows) return;
     if (tid < 128) (&sG[0][0])[tid] = 0.f;
+    if (OP) {
+        for (int c = tid; c < 64 * 8; c += 256) { const int n = c >> 3, ch = c & 7; *reinterpret_cast<uint4*>(sWo + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(op.wot + n * 64 + ch * 8); }
+        for (int c = tid; c < FW_IMG65; c += 256) sO[c] = 0;
+    }
     for (int c = tid; c < 128 * 8; c += 256) { const int n = c >> 3, ch = c & 7; *reinterpret_cast<uint4*>(sW2 + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(w2t + n * 64 + ch * 8); }
     for (int c = tid; c < 64 * 16; c += 256) { const int n = c >> 4, ch = c & 15; *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8); }
     for (int c = tid; c < FW_IMG129; c += 256) sH[c] = 0;                        // (the ones columns' tiles: everything but column 0 stays zero)
@@ -345,7 +357,11 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 5; b++) acc1[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    uint4 vdx[2], vx[2], vn[2], vh[4];
+    f32x4_t acco[5];
+#pragma unroll
+    for (int b = 0; b < 5; b++) acco[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 vdx[2], vx[2], vn[2], vh[4], vo[2];
+    if (OP) wg_load<2>(op.o, r_begin * 64, rows * 64, 64, vo, tid);
     wg_load<2>(dx, r_begin * 64, rows * 64, 64, vdx, tid);
     wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
     wg_load<2>(n2, r_begin * 64, rows * 64, 64, vn, tid);
@@ -357,12 +373,15 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
         wg_store_rows<2>(sX, 64, vx, tid);
         wg_store_rows<2>(sN, 64, vn, tid);
         wg_store_rows<4>(sH, 128, vh, tid);
+        if (OP) wg_store_rows<2>(sO, 64, vo, tid);
         if (tid < FW_ROWS) {
             const unsigned short one = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;   // bf16 1.0: the bias columns
             sH[fw_off(tid, 128)] = one; sN[fw_off(tid, 64)] = one;
+            if (OP) sO[fw_off(tid, 64)] = one;
         }
         __syncthreads();
         if (r0 + FW_ROWS < r_end) {                                              // the next stage's rows fly during this stage
+            if (OP) wg_load<2>(op.o, (r0 + FW_ROWS) * 64, rows * 64, 64, vo, tid);
             wg_load<2>(dx, (r0 + FW_ROWS) * 64, rows * 64, 64, vdx, tid);
             wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
             wg_load<2>(n2, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
@@ -462,8 +481,47 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
 #pragma unroll
                 for (int b = 0; b < 5; b++) acc1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1f, bn[b], acc1[a][b], 0, 0, 0);
             }
+            if (OP) {                                                            // dWo tile `wave` (16 outputs) x 5 column tiles (O and the ones)
+                const bf16x8_t ao = wg_frag_tr(sX, wave, ks, lane);
+#pragma unroll
+                for (int b = 0; b < 5; b++) acco[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, wg_frag_tr(sO, b, ks, lane), acco[b], 0, 0, 0);
+            }
+        }
+        if (OP) {
+            // ---- dO = dX' Wo for this wave's 16 rows, through the dX image (every wave has read its dX fragments: barrier first)
+            bf16x8_t ax[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) ax[s2] = *reinterpret_cast<const bf16x8_t*>(sX + fw_off(row, 32 * s2 + 8 * g));
+            f32x4_t co[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                co[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+                    co[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[s2], *reinterpret_cast<const bf16x8_t*>(sWo + (16 * t + lr) * FB_P + 32 * s2 + 8 * g), co[t], 0, 0, 0);
+            }
+            __syncthreads();                                                     // (sDX was an operand of the weight gradients above)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) sDX[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = te_to_bf(co[t][r]);
+            __syncthreads();
+            for (int c = tid; c < FW_ROWS * 8; c += 256) {
+                const int rr = c >> 3, ch = c & 7;
+                if (r0 + rr < r_end) *reinterpret_cast<uint4*>(op.d_o + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(sDX + fw_off(rr, ch * 8));
+            }
         }
         __syncthreads();                                                         // (the next stage overwrites the images)
+    }
+    if (OP) {
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = wave * 16 + 4 * g + r, i = b * 16 + lr;
+                const float v = acco[b][r];
+                if (v != 0.0f) { if (i < 64) atomicAdd(&op.dwo[o * 64 + i], v); else if (i == 64) atomicAdd(&op.dbo[o], v); }
+            }
     }
     // ---- accumulators -> global (fp32 atomics; zeroed by the caller)
 #pragma unroll

@@ -806,11 +806,20 @@ class _TileEncoderTrain(torch.autograd.Function):
                 if os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1":
                     # k_ffn_bwd_w: the chain below AND both weight gradients in one pass over the rows (dH never leaves the chip)
                     dxmid = torch.empty_like(xmid)
-                    acc = torch.zeros((64 * 128 + 64 + 128 * 64 + 128 + 128,), dtype=torch.float32, device=h.device)
-                    dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:]
+                    acc = torch.zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), dtype=torch.float32, device=h.device)
+                    dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:16704]
+                    dwo, dbo = acc[16704:20800], acc[20800:]
                     lw = P[b + 10].detach().float().contiguous()
-                    _lib.check(_lib.lib().catan_ffn_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
-                                                        _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
+                    if os.environ.get("CATAN_TE_BWD_OP", "1") == "1":       # ... and the out-projection's dO and weight gradient from the same rows
+                        do = torch.empty_like(o)
+                        _lib.check(_lib.lib().catan_ffn_outproj_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
+                                                                    _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]),
+                                                                    _ptr(o), _ptr(wot), _ptr(do), _ptr(dwo), _ptr(dbo), T, _stream()))
+                        g[b + 8], g[b + 9] = dwo.view(64, 64), dbo
+                    else:
+                        do = None
+                        _lib.check(_lib.lib().catan_ffn_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
+                                                            _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
                     g[b + 14], g[b + 15], g[b + 12], g[b + 13], g[b + 10], g[b + 11] = dw2.view(64, 128), db2, dw1.view(128, 64), db1, dl[:64], dl[64:]
                     dh = None
                 elif os.environ.get("CATAN_TE_BWD_UNFUSED") == "1":
@@ -827,8 +836,9 @@ class _TileEncoderTrain(torch.autograd.Function):
                 if dh is not None:
                     g[b + 14], g[b + 15] = _wgrad(h, dx, True)
                     g[b + 12], g[b + 13] = _wgrad(n2, dh, True)
-                do = _rows_product(dxmid, wot)
-                g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
+                if dh is not None or do is None:
+                    do = _rows_product(dxmid, wot)
+                    g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
                 _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
                 fused_w = os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1"

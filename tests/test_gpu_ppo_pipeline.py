@@ -990,6 +990,7 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             monkeypatch.setenv("CATAN_TE_TRAIN_UNFUSED", "1" if mode == "unfused" else "0")
             monkeypatch.setenv("CATAN_TE_BWD_UNFUSED", "1" if mode == "fused, backward in separate steps" else "0")
             monkeypatch.setenv("CATAN_TE_BWD_W", "0" if mode == "fused, weight gradients in their own kernels" else "1")
+            monkeypatch.setenv("CATAN_TE_BWD_OP", "0" if mode == "fused, out-projection backward in its own kernels" else "1")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
@@ -1004,7 +1005,11 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         of, gf = run(tiles, "fused")
         oc, gc = run(tiles, "fused, backward in separate steps")      # the pointwise sub-layer's backward as three kernels instead of k_ffn_bwd_dx
         ow, gw_ = run(tiles, "fused, weight gradients in their own kernels")   # k_ffn_bwd_dx + two catan_linear_wgrad instead of k_ffn_bwd_w
-        assert of.shape == (B, 475) and torch.equal(oc, of) and torch.equal(ow, of)
+        oo, go_ = run(tiles, "fused, out-projection backward in its own kernels")   # k_ffn_bwd_w<false> + row product + catan_linear_wgrad
+        assert of.shape == (B, 475) and torch.equal(oc, of) and torch.equal(ow, of) and torch.equal(oo, of)
+        for n in names:
+            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
+            assert float((gf[n] - go_[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - go_[n]).norm()) / scale)
         for n in names:
             scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
             assert float((gf[n] - gc[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - gc[n]).norm()) / scale)
