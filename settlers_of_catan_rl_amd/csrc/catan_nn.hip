@@ -1098,45 +1098,86 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __r
     }
 }
 
+// The backward works from row-major LDS images of Q, K, V, dO (coalesced 16-byte row pieces in, 16-byte stores to LDS) and collects
+// dQ | dK | dV in an LDS image that leaves as whole rows: with every lane fetching ITS row's 16-byte slice per head straight from
+// HBM and storing 8-byte slices back, a sequence cost 49 memory instructions that touch 32 cache lines each.
+template <int D> constexpr int at_rp() { return D + 8; }             // row pitch of an image (elements): 16-byte aligned rows
+template <int L, int D>
+__device__ __forceinline__ void stage_rows(unsigned short* dst, const unsigned short* src, int row_stride, int lane) {
+    constexpr int CH = D / 8;
+    for (int x = lane; x < L * CH; x += 64) {
+        const int j = x / CH, c = x - j * CH;
+        *reinterpret_cast<uint4*>(dst + j * at_rp<D>() + c * 8) = *reinterpret_cast<const uint4*>(src + j * row_stride + c * 8);
+    }
+}
+// A operand of a product that contracts over the image's ROWS: column `col` (this lane's dim), the 8 rows of k-step s for this lane
+// half in the order the probabilities' registers have them (16 s + 4 hf + {0..3}, 16 s + 8 + 4 hf + {0..3}); rows >= L are zeros
+template <int L, int D>
+__device__ __forceinline__ bf16x8_t ld_gather(const unsigned short* col, int s, int hf) {
+    union { bf16x8_t f; unsigned short u[8]; } r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int row = 16 * s + 8 * (e >> 2) + 4 * hf + (e & 3);
+        r.u[e] = row < L ? col[row * at_rp<D>()] : (unsigned short)0;
+    }
+    return r.f;
+}
+// ... the same fragment through gfx950's transposing LDS read (16 dims per head): a 16-lane group hands ds_read_tr16_b64 the
+// addresses of rows base .. base + 3 (lane i: row base + i / 4, dims 4 (i % 4) ..) and lane i gets dim i of those four rows - one
+// instruction per 4-row run instead of four 2-byte reads.  The images have 32 rows (rows >= L are zero).
+__device__ __forceinline__ bf16x8_t ld_gather_tr(const unsigned short* img_head, int rp, int s, int lane) {
+    const int i = lane & 15, hf = lane >> 5;
+    const unsigned short* p = img_head + (16 * s + 4 * hf + (i >> 2)) * rp + (i & 3) * 4;
+    union { bf16x8_t f; wg_s4 h[2]; } r;
+    r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)p);
+    r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(p + 8 * rp));
+    return r.f;
+}
 // dqkv [B][L][3][D] from dout [B][L][D]; the probabilities are recomputed in both orientations (see above)
 template <int L, int H, int HD>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
                                                        const unsigned short* __restrict__ dout, unsigned short* __restrict__ dqkv, long B) {
     constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;      // registers 12..15 = keys / queries 24..31: beyond the sequence when L <= 24
-    __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][D * AT_LP];          // K^T, Q^T, dO^T: [dim][key / query]
+    constexpr int RP = at_rp<D>();
+    constexpr bool TR = HD == 16;                            // transposing LDS reads (whole 16-dim heads)
+    constexpr int IR = TR ? 32 : L;                          // rows of an image (TR: padded with zero rows to 32)
+    __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][IR * RP];            // K, Q, dO row-major: [key / query][dim]
     __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: row max, 1 / row sum, delta
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
     const long b = (long)blockIdx.x * 4 + wv;
     if (b >= B) return;
     unsigned short* kt = Tt[wv][0]; unsigned short* qt = Tt[wv][1]; unsigned short* dot = Tt[wv][2];
-    for (int x = lane; x < 3 * D * AT_LP / 4; x += 64) reinterpret_cast<uint2*>(kt)[x] = make_uint2(0, 0);
-    __builtin_amdgcn_wave_barrier();
     const unsigned short* base = qkv + b * (long)(L * 3 * D);
     const unsigned short* dob = dout + b * (long)(L * D);
     unsigned short* gb = dqkv + b * (long)(L * 3 * D);
-    stage_transposed<L, D>(kt, base + D, 3 * D, lane);
-    stage_transposed<L, D>(qt, base, 3 * D, lane);
-    stage_transposed<L, D>(dot, dob, D, lane);
+    if (TR) {                                                // the zero rows L .. 31 of K, Q, dO (V is read by rows only)
+        for (int x = lane; x < 3 * (IR - L) * RP / 8; x += 64) {
+            const int t = x / ((IR - L) * RP / 8), o = x - t * ((IR - L) * RP / 8);
+            reinterpret_cast<uint4*>(Tt[wv][t] + L * RP)[o] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    stage_rows<L, D>(kt, base + D, 3 * D, lane);
+    stage_rows<L, D>(qt, base, 3 * D, lane);
+    stage_rows<L, D>(dot, dob, D, lane);
     __builtin_amdgcn_wave_barrier();
     const bool rowok = c31 < L;
     const int len = lens ? lens[b] : L;
     const float scale = HD == 16 ? 0.25f : 0.5f;
     float* stat = &Stat[wv][0][0];
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // every head's row fragments are requested up front: with one or two waves per SIMD (the LDS tiles cap the occupancy) a
-    // load issued inside the head loop is ~2 us of exposed latency per head
+    const int rrow = (rowok ? c31 : 0) * RP;                 // this lane's row of the images (rows >= L: zeros below)
     bf16x8_t qr_[H], kr_[H], vr_[H], gr_[H];
 #pragma unroll
     for (int h = 0; h < H; h++) {
-        qr_[h] = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);                         // row c31 of Q, K, V, dO
-        kr_[h] = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
+        qr_[h] = ld_frag<HD>(qt + rrow + h * HD, hf, rowok);                                         // row c31 of Q, K, V, dO
+        kr_[h] = ld_frag<HD>(kt + rrow + h * HD, hf, rowok);
         vr_[h] = ld_frag<HD>(base + (c31 * 3 + 2) * D + h * HD, hf, rowok);
-        gr_[h] = ld_frag<HD>(dob + c31 * D + h * HD, hf, rowok);
+        gr_[h] = ld_frag<HD>(dot + rrow + h * HD, hf, rowok);
     }
 #pragma unroll
     for (int h = 0; h < H; h++) {
         const bf16x8_t qr = qr_[h], kr = kr_[h], vr = vr_[h], gr = gr_[h];
-        const int trow = (h * HD + (c31 % HD)) * AT_LP;                                            // this lane's transposed row (dim d)
+        const int tcol = h * HD + (c31 % HD);                                                      // this lane's dim d: a column of the images
         // ---- lane = query i, registers = keys j
         {
             const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qr, zero16, 0, 0, 0);    // S^T[j][i]
@@ -1164,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             f32x16_t dq = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++)
-                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(kt + trow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(kt + h * HD, RP, s, lane) : ld_gather<L, D>(kt + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
             if (rowok) st_head<HD>(gb + (c31 * 3 + 0) * D + h * HD, dq, hf);
         }
         __builtin_amdgcn_wave_barrier();
@@ -1190,8 +1231,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             f32x16_t dk = zero16, dv = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(qt + trow, s, hf) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
-                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(dot + trow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(qt + h * HD, RP, s, lane) : ld_gather<L, D>(qt + tcol, s, hf)) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(dot + h * HD, RP, s, lane) : ld_gather<L, D>(dot + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
             }
             if (rowok) {
                 st_head<HD>(gb + (c31 * 3 + 1) * D + h * HD, dk, hf);
