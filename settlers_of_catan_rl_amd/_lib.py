@@ -30,10 +30,16 @@ def _sources():
 _HASH_MARK = b"CATAN_BUILD_HASH="
 
 
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one register file; the default allocates them to the AGPR half and
+# copies every element back with v_accvgpr_read before the VALU may touch it: 432 of k_attn_mfma_bwd's ~1 900 instructions)
+BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
 def source_hash():
-    """sha256 over the names and contents of csrc/* and include/catan_hip.h: what the library is built from."""
+    """sha256 over the names and contents of csrc/* and include/catan_hip.h and the compiler flags: what the library is built from."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(BUILD_FLAGS).encode() + b"\0")
     for path in _sources():
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
@@ -60,8 +66,7 @@ def build_library(force=False, verbose=False):
     whenever the hash of the sources differs from the one baked into the binary - file times mean nothing on a fresh checkout
     or on a snapshot copied to the GPU box."""
     want = source_hash()
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           f'-DCATAN_BUILD_HASH_STR="{want}"', "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
+    cmd = ["hipcc"] + BUILD_FLAGS + [f'-DCATAN_BUILD_HASH_STR="{want}"', "-o", LIB_PATH, os.path.join(CSRC, "catan_abi.hip")]
     have = binary_hash()
     if not force and have == want:
         if verbose:
