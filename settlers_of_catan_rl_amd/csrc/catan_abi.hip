@@ -455,7 +455,7 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
     hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
-                       sc.prof ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
+                       sc.prof && e->prof_on != 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;

@@ -1383,6 +1383,8 @@ struct StepCfg { int validate; int dense_reward; double win_reward; double annea
                  double* reward64;              // optional unrounded rewards [n][4] (catan_set_reward_f64_buffer)
                  unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
                  u32* prof_wave; };             // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
+constexpr int LRF_PROF_ROW = 1088, LRF_PROF_ROWS = 2000;   // k_lr_finish's rows of the per-wave buffer ((N / 16 + SORT_PAD_WAVES) rows)
+constexpr int LRH_PROF_ROW = 3088, LRH_PROF_ROWS = 1000;   // k_lr_heavy's: one row per workgroup (its first request)
 constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
                                   // k_reset_list: 3 philox draws per re-deal, 4 re-deals, 5 serial shuffle time
 constexpr int PROF_TOTAL = 2 * PROF_PHASES + 4;   // then 14 sums, 14 counts, 14 maxima of validate+apply per action type
@@ -1457,6 +1459,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
     if constexpr (LR != 0) {
         bool cut = false;
         int holder = 0, hcount = 0;
+        if constexpr (LR == 2) prof_mark(cfg, 2, tprof);
         if (doit && lr_who >= 0) {
             s.spb(lr_who, P_CURLP, len);
             holder = s.b(B_LR_PLAYER); hcount = s.b(B_LR_COUNT);
@@ -1470,6 +1473,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
                 s.sb(B_LR_PLAYER, lr_who + 1); s.sb(B_LR_COUNT, len);
             }
         }
+        if constexpr (LR == 2) prof_mark(cfg, 5, tprof);
         if constexpr (LR == 2) {
         if (__ballot(cut)) {                                               // game.py:880-912 (rare)
             int max_len = len, player = lr_who;
@@ -1500,6 +1504,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
         }
         }
     }
+    if constexpr (LR == 2) prof_mark(cfg, 3, tprof);                       // (k_lr_finish profile: holder logic)
     // ---- done / rewards (wrapper.py:85-112)
     bool want_reset = false;
     if (doit) {
@@ -1545,6 +1550,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
         if (want_reset) pend.busy[s.e] = (u8)pend.stag;
         else if (lr_who >= 0 && clear_busy) pend.busy[s.e] = 0;
     }
+    if constexpr (LR == 2) prof_mark(cfg, 4, tprof);                       // (k_lr_finish profile: done / rewards)
     // ---- next legal-action masks (env/wrapper.py:168-290), from the LDS tile
     if (doit && !want_reset) {
         u32 m[MASK_WORDS];
@@ -2022,14 +2028,18 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
     const u32 count = pend.ctr[4 + fl];
     if (blockIdx.x == 0 && lane == 0 && slow_ctr != nullptr) { atomicAdd(&slow_ctr[0], (unsigned long long)count); atomicAdd(&slow_ctr[2], 1ull); }
     StepCfg cfg2 = cfg;
-    cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
+    cfg2.prof = nullptr;
+    // per-request phase ticks (catan_profile_enable(env, 2)): rows LRF_PROF_ROW.. of the per-wave buffer, one request per workgroup
+    cfg2.prof_wave = cfg.prof_wave != nullptr && blockIdx.x < LRF_PROF_ROWS && count <= gridDim.x && c.N >= 65536 ? cfg.prof_wave + LRF_PROF_ROW * 8 : nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        long long tprof = wall_clock64();
         const u64 rq = pend.req[fl][r];
         const long e = (long)(rq & LR_GAME_MASK);
         const int who = (int)(rq >> 56), edge = (int)((rq >> 40) & 127);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
         __builtin_amdgcn_wave_barrier();
+        prof_mark(cfg2, 0, tprof);
         StL1 s(rec, c.R, c.N, e);
         LrCache lc;
         lc.load(s.P);                                     // (every lane: the same seven words)
@@ -2046,12 +2056,13 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
             continue;
         }
         const int len = lr_apply(lc, who, pl.through, found);
-        long long tprof = 0;
+        prof_mark(cfg2, 1, tprof);
         finish_step<2>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
                        pend.stag < 2 ? 2 : 0, pend.ftag < 2, nullptr, nullptr, &lc);
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
         if (lane == 0) lc.store(s.P);
+        prof_mark(cfg2, 7, tprof);
     }
 }
 
@@ -2082,7 +2093,12 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
     lr_load_nbr(tid < 54 ? tid : 0, nbr_c, nbr_e);
     StepCfg cfg2 = cfg;
     cfg2.prof = nullptr; cfg2.prof_wave = nullptr;
+    // per-workgroup profile of its first request (catan_profile_enable(env, 2)): [0] set-up ticks, [1] rounds, [2] search ticks,
+    // [3] combine + arrival ticks, [4] completion ticks (the last part), [5] split | through << 8 | part << 16, [6] / [7] clock at start / end
+    u32* const hp = cfg.prof_wave != nullptr && blockIdx.x < LRH_PROF_ROWS && c.N >= 65536 ? cfg.prof_wave + (LRH_PROF_ROW + blockIdx.x) * 8 : nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
+        const long long hp_t0 = wall_clock64();
+        u32 hp_rounds = 0;
         const u64 rq = req[r / LR_SPLIT];
         const int part = (int)(r % LR_SPLIT);
         const long game = (long)(rq & LR_GAME_MASK);
@@ -2114,7 +2130,9 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         }
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
+        const long long hp_t1 = wall_clock64();
         while (true) {
+            hp_rounds++;
             for (int it = 0; it < round_iters; it++) dfs_iter(t, G, &path[0][tid], LR_HEAVY_THREADS, hint, q);
             __syncthreads();                       // all pushes of this round are complete
             if (!t.active) {
@@ -2126,6 +2144,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
             if (busy == 0) break;                  // nobody active -> the pool is empty too (idle threads drained it)
             hint = busy < LR_HEAVY_THREADS;
         }
+        const long long hp_t2 = wall_clock64();
         if (t.best > 0) atomicMax(&best_all, (unsigned long long)lr_pack(t.best, t.bseen));
         __syncthreads();
         if (tid == 0) {
@@ -2134,6 +2153,7 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
             is_last = atomicAdd(&pend.arrive[game], 1u) == LR_SPLIT - 1 ? 1 : 0;
         }
         __syncthreads();
+        const long long hp_t3 = wall_clock64();
         if (is_last && tid < 64) {                                     // every part has arrived: complete the step of this game
             StepScratch* scratch = reinterpret_cast<StepScratch*>(&path[0][0]);
             u32* rec = reinterpret_cast<u32*>(reinterpret_cast<char*>(&path[0][0]) + ((sizeof(StepScratch) + 63) & ~size_t(63)));
@@ -2151,6 +2171,12 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
             __builtin_amdgcn_wave_barrier();
             if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + game * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
             if (lane == 0) lc.store(sl.P);
+        }
+        if (hp != nullptr && tid == 0 && r == blockIdx.x) {
+            const long long hp_t4 = wall_clock64();
+            hp[0] = (u32)(hp_t1 - hp_t0); hp[1] = hp_rounds; hp[2] = (u32)(hp_t2 - hp_t1); hp[3] = (u32)(hp_t3 - hp_t2);
+            hp[4] = is_last ? (u32)(hp_t4 - hp_t3) : 0u; hp[5] = LR_SPLIT | ((pl.through ? 1u : 0u) << 8) | ((u32)part << 16);
+            hp[6] = (u32)hp_t0; hp[7] = (u32)hp_t4;
         }
     }
 }
