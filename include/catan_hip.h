@@ -104,14 +104,16 @@ int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w
                      float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
 
 /* catan_ffn_bwd_dx AND the sub-layer's two weight gradients in one pass (k_ffn_bwd_w): additionally n [rows][64] = LayerNorm(x) as the
- * forward stored it; dw2 float [64][128], db2 [64], dw1 [128][64], db1 [128] are ACCUMULATED into (zero first); dh is not written. */
-int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
-                  float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
+ * forward stored it, OR n = NULL and ln_b float [64] = the LayerNorm's bias: the pass recomputes n from x (the forward need not store
+ * it; ln_b may be NULL when n is given); dw2 float [64][128], db2 [64], dw1 [128][64], db1 [128] are ACCUMULATED into (zero first);
+ * dh is not written. */
+int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, const float* ln_b, float eps,
+                  void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
 /* catan_ffn_bwd plus the backward of the out-projection that produced x (x = x_in + o Wo^T + bo): d_o [rows][64] = dx_out Wo,
  * dwo float [64][64] and dbo [64] accumulated, from the dx_out rows while they are on chip.  o [rows][64] = the attention output,
  * wot = Wo^T bf16 [64][64] (k_ffn_bwd_w<true>). */
-int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
-                          float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, const float* ln_b, float eps,
+                          void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
                           const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream);
 /* The attention sub-layer's input side x_mid = x + out_proj(attention(qkv(LayerNorm(x)))) (width 64): the gradient of x from dqkv
  * [rows][192] (catan_attention_bwd's output) - (dqkv . Wqkv) through the LayerNorm backward, plus the residual gradient dres = d(x_mid)
@@ -130,10 +132,11 @@ typedef struct catan_weight_image {
 int32_t catan_weight_image_bytes(void);
 int catan_weight_images(const void* table, int32_t n, catan_stream_t stream);
 
-/* catan_qkv_bwd_dx AND the QKV product's weight gradient in one pass (k_qkv_bwd_w): additionally n [rows][64] = LayerNorm 1's output;
- * dw float [192][64] and db [192] are ACCUMULATED into (zero first). */
-int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, float eps, void* dx_out, float* dw, float* db,
-                  float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
+/* catan_qkv_bwd_dx AND the QKV product's weight gradient in one pass (k_qkv_bwd_w): additionally n [rows][64] = LayerNorm 1's output,
+ * or n = NULL and ln_b = the LayerNorm's bias (n recomputed from x, as catan_ffn_bwd); dw float [192][64] and db [192] are
+ * ACCUMULATED into (zero first). */
+int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, const float* ln_b, float eps, void* dx_out,
+                  float* dw, float* db, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream);
 
 /* Row gathers of the learner (RL/ppo/ppo.py:44-50 builds a minibatch with `[obs[i] for i in indices]`; here the rollout is one
  * (T + 1, N, 1 787) bf16 tensor and a minibatch 204 800 of its 3 574-byte rows).
@@ -360,11 +363,11 @@ typedef struct catan_te_saves {
     void* tiles64;      /* [64]  tile features zero-padded 60 -> 64 (first_layer's input) */
     void* a0;           /* [64]  first_layer output, before LayerNorm + ReLU */
     void* xin[2];       /* [64]  encoder layer input (residual stream) */
-    void* n1[2];        /* [64]  LayerNorm 1 output */
+    void* n1[2];        /* [64]  LayerNorm 1 output; may be NULL (not stored): catan_qkv_bwd recomputes it from xin */
     void* qkv[2];       /* [192] Q | K | V */
     void* o[2];         /* [64]  attention output */
     void* xmid[2];      /* [64]  residual stream after the attention sub-layer */
-    void* n2[2];        /* [64]  LayerNorm 2 output */
+    void* n2[2];        /* [64]  LayerNorm 2 output; may be NULL: catan_ffn_bwd / catan_ffn_outproj_bwd recompute it from xmid */
     void* h[2];         /* [128] relu(linear1) */
     void* xfin;         /* [64]  last layer's output */
     void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */

@@ -105,9 +105,9 @@ _SIGS = {
     "catan_masks_packed_copy": (C.c_int, [_vp, _vp, _vp]),
     "catan_masked_row_store": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "catan_ffn_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
-    "catan_ffn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
-    "catan_ffn_outproj_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
-    "catan_qkv_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_ffn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_ffn_outproj_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_qkv_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_qkv_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_weight_image_bytes": (C.c_int32, []),
     "catan_weight_images": (C.c_int, [_vp, C.c_int32, _vp]),

@@ -1026,9 +1026,9 @@ int catan_weight_images(const void* table, int32_t n, catan_stream_t stream) {
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
-                  float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
-    if (!dx || !h || !x || !n || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || rows <= 0 ||
+int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, const float* ln_b, float eps,
+                  void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
+    if (!dx || !h || !x || (!n && !ln_b) || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || rows <= 0 ||
         (((uintptr_t)dx | (uintptr_t)h | (uintptr_t)x | (uintptr_t)n | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dx_out) & 15))
         return fail(CATAN_EINVAL, "catan_ffn_bwd: null or misaligned argument");
     // every block ends with 16 640 atomics: several stages of 64 rows per block, at most 512 blocks (the grid rule of wgrad_grid)
@@ -1037,16 +1037,19 @@ int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, c
     const long per = (stages + nb - 1) / nb * FW_ROWS;
     nb = (rows + per - 1) / per;
     FfnOutProj op = { nullptr, nullptr, nullptr, nullptr, nullptr };
-    hipLaunchKernelGGL(k_ffn_bwd_w<false>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
-                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+    if (n) hipLaunchKernelGGL((k_ffn_bwd_w<false, false>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+                       dln_w, dln_b, (long)rows, per, op);
+    else hipLaunchKernelGGL((k_ffn_bwd_w<false, true>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
                        dln_w, dln_b, (long)rows, per, op);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dx_out,
-                          float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, const float* ln_b, float eps,
+                          void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
                           const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream) {
-    if (!dx || !h || !x || !n || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || !o || !wot || !d_o || !dwo || !dbo || rows <= 0 ||
+    if (!dx || !h || !x || (!n && !ln_b) || !w2t || !w1t || !ln_w || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || !o || !wot || !d_o || !dwo || !dbo || rows <= 0 ||
         (((uintptr_t)dx | (uintptr_t)h | (uintptr_t)x | (uintptr_t)n | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dx_out | (uintptr_t)o | (uintptr_t)wot | (uintptr_t)d_o) & 15))
         return fail(CATAN_EINVAL, "catan_ffn_outproj_bwd: null or misaligned argument");
     const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
@@ -1054,23 +1057,28 @@ int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const vo
     const long per = (stages + nb - 1) / nb * FW_ROWS;
     nb = (rows + per - 1) / per;
     FfnOutProj op = { (const unsigned short*)o, (const unsigned short*)wot, (unsigned short*)d_o, dwo, dbo };
-    hipLaunchKernelGGL(k_ffn_bwd_w<true>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
-                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+    if (n) hipLaunchKernelGGL((k_ffn_bwd_w<true, false>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+                       dln_w, dln_b, (long)rows, per, op);
+    else hipLaunchKernelGGL((k_ffn_bwd_w<true, true>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
+                       (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
                        dln_w, dln_b, (long)rows, per, op);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, float eps, void* dx_out, float* dw, float* db,
-                  float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
-    if (!dqkv || !x || !dres || !n || !wt || !ln_w || !dx_out || !dw || !db || !dln_w || !dln_b || rows <= 0 ||
+int catan_qkv_bwd(const void* dqkv, const void* x, const void* dres, const void* n, const void* wt, const float* ln_w, const float* ln_b, float eps, void* dx_out,
+                  float* dw, float* db, float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
+    if (!dqkv || !x || !dres || (!n && !ln_b) || !wt || !ln_w || !dx_out || !dw || !db || !dln_w || !dln_b || rows <= 0 ||
         (((uintptr_t)dqkv | (uintptr_t)x | (uintptr_t)dres | (uintptr_t)n | (uintptr_t)wt | (uintptr_t)dx_out) & 15))
         return fail(CATAN_EINVAL, "catan_qkv_bwd: null or misaligned argument");
     const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
     long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
     const long per = (stages + nb - 1) / nb * FW_ROWS;
     nb = (rows + per - 1) / per;
-    hipLaunchKernelGGL(k_qkv_bwd_w, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
-                       (const unsigned short*)n, (const unsigned short*)wt, ln_w, eps, (unsigned short*)dx_out, dw, db, dln_w, dln_b, (long)rows, per);
+    if (n) hipLaunchKernelGGL(k_qkv_bwd_w<false>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
+                       (const unsigned short*)n, (const unsigned short*)wt, ln_w, ln_b, eps, (unsigned short*)dx_out, dw, db, dln_w, dln_b, (long)rows, per);
+    else hipLaunchKernelGGL(k_qkv_bwd_w<true>, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
+                       (const unsigned short*)n, (const unsigned short*)wt, ln_w, ln_b, eps, (unsigned short*)dx_out, dw, db, dln_w, dln_b, (long)rows, per);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -1211,8 +1219,12 @@ int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const f
     if (!tiles || !weights || !vecs || !out || !saves || boards <= 0 || out_pitch < TE_L * TE_OUT) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: bad arguments");
     static_assert(sizeof(catan_te_saves_t) == sizeof(TeSaves), "the header's struct is the kernel's");
     const void* const* ptrs = reinterpret_cast<const void* const*>(saves);
-    for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++)
-        if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer must be set and 16-byte aligned");
+    for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++) {
+        const bool optional = (i >= offsetof(TeSaves, n1) / sizeof(void*) && i < offsetof(TeSaves, n1) / sizeof(void*) + 2) ||
+                              (i >= offsetof(TeSaves, n2) / sizeof(void*) && i < offsetof(TeSaves, n2) / sizeof(void*) + 2);
+        if ((!ptrs[i] && !optional) || ((uintptr_t)ptrs[i] & 15))
+            return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer but n1 / n2 must be set, all 16-byte aligned");
+    }
     TeSaves sv;
     memcpy(&sv, saves, sizeof sv);
     long nb = (boards + TE_G - 1) / TE_G;

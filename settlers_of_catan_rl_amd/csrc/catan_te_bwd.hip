@@ -318,10 +318,13 @@ DEVI int fw_off(int row, int col) { return wg_sub_off(col >> 4, row >> 5) + (row
 // product and weight-gradient kernels read dX' twice more.  o [rows][64] = the attention output, wot = Wo^T [64 in][64 out],
 // d_o [rows][64] out, dwo [64][64] / dbo [64] accumulated.
 struct FfnOutProj { const unsigned short* o; const unsigned short* wot; unsigned short* d_o; float* dwo; float* dbo; };
-template <bool OP>
+// RN: N is not read but recomputed from X (LayerNorm weight lnw, bias lnb: the forward's formula on the statistics the LayerNorm
+// backward forms anyway), so the training forward need not store it: 128 of the 896 bytes per token row this pass read, and 128 of
+// the 1 280 the forward wrote per row and layer.
+template <bool OP, bool RN>
 __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restrict__ dx, const unsigned short* __restrict__ h, const unsigned short* __restrict__ x,
                                                    const unsigned short* __restrict__ n2, const unsigned short* __restrict__ w2t, const unsigned short* __restrict__ w1t,
-                                                   const float* __restrict__ lnw, float eps, unsigned short* __restrict__ dxo,
+                                                   const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, unsigned short* __restrict__ dxo,
                                                    float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1,
                                                    float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block, FfnOutProj op) {
     __shared__ __attribute__((aligned(16))) unsigned short sDX[FW_IMG64];      // dX; the rows of dX' replace X below
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     for (int c = tid; c < 64 * 16; c += 256) { const int n = c >> 4, ch = c & 15; *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8); }
     for (int c = tid; c < FW_IMG129; c += 256) sH[c] = 0;                        // (the ones columns' tiles: everything but column 0 stays zero)
     for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
-    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+    float wl[4], bl[4] = { 0.f, 0.f, 0.f, 0.f }, aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    for (int t = 0; t < 4; t++) { wl[t] = lnw[16 * t + lr]; if (RN) bl[t] = lnb[16 * t + lr]; }
     f32x4_t acc2[9], acc1[2][5];
 #pragma unroll
     for (int b = 0; b < 9; b++) acc2[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -364,14 +367,14 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     if (OP) wg_load<2>(op.o, r_begin * 64, rows * 64, 64, vo, tid);
     wg_load<2>(dx, r_begin * 64, rows * 64, 64, vdx, tid);
     wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
-    wg_load<2>(n2, r_begin * 64, rows * 64, 64, vn, tid);
+    if (!RN) wg_load<2>(n2, r_begin * 64, rows * 64, 64, vn, tid);
     wg_load<4>(h, r_begin * 128, rows * 128, 128, vh, tid);
     __syncthreads();
     const int row = 16 * wave + lr;                                             // this lane's token row of the stage (operand layout)
     for (long r0 = r_begin; r0 < r_end; r0 += FW_ROWS) {
         wg_store_rows<2>(sDX, 64, vdx, tid);
         wg_store_rows<2>(sX, 64, vx, tid);
-        wg_store_rows<2>(sN, 64, vn, tid);
+        if (!RN) wg_store_rows<2>(sN, 64, vn, tid);
         wg_store_rows<4>(sH, 128, vh, tid);
         if (OP) wg_store_rows<2>(sO, 64, vo, tid);
         if (tid < FW_ROWS) {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             if (OP) wg_load<2>(op.o, (r0 + FW_ROWS) * 64, rows * 64, 64, vo, tid);
             wg_load<2>(dx, (r0 + FW_ROWS) * 64, rows * 64, 64, vdx, tid);
             wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
-            wg_load<2>(n2, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
+            if (!RN) wg_load<2>(n2, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
             wg_load<4>(h, (r0 + FW_ROWS) * 128, rows * 128, 128, vh, tid);
         }
         // ---- dH^T = W2^T . dX^T, masked by H > 0 (this wave's 16 rows), into the dH image
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 xv[t][r] *= rstd;
+                if (RN) sN[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = live ? te_to_bf(xv[t][r] * wl[t] + bl[t]) : (unsigned short)0;
                 const float gy = live ? dn[t][r] : 0.f;
                 aw[t] += gy * xv[t][r]; ab[t] += gy;
                 gw[t] = gy * wl[t];
@@ -560,8 +564,10 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
 // k_ffn_bwd_w: 64-row stages, dQKV / X / the residual gradient / N in LDS images, wave w accumulates output tiles 3 w .. 3 w + 2 of
 // the 192 x (64 + 1) gradient.  HBM: dQKV, X, the residual gradient, N in, dX out (the separate weight-gradient kernel read dQKV and N again).
 constexpr int FW_IMG192 = 12 * 2 * WG_SUB;
+template <bool RN>                 // RN: N recomputed from X instead of read (see k_ffn_bwd_w)
 __global__ __launch_bounds__(256) void k_qkv_bwd_w(const unsigned short* __restrict__ dqkv, const unsigned short* __restrict__ x, const unsigned short* __restrict__ dres,
-                                                   const unsigned short* __restrict__ n1, const unsigned short* __restrict__ wt, const float* __restrict__ lnw, float eps,
+                                                   const unsigned short* __restrict__ n1, const unsigned short* __restrict__ wt, const float* __restrict__ lnw,
+                                                   const float* __restrict__ lnb, float eps,
                                                    unsigned short* __restrict__ dxo, float* __restrict__ dw, float* __restrict__ dbias,
                                                    float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block) {
     __shared__ __attribute__((aligned(16))) unsigned short sDQ[FW_IMG192];
@@ -580,9 +586,9 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_w(const unsigned short* __restr
         *reinterpret_cast<uint4*>(sW + n * QB_PW + ch * 8) = *reinterpret_cast<const uint4*>(wt + n * QB_K + ch * 8);
     }
     for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
-    float wl[4], aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+    float wl[4], bl[4] = { 0.f, 0.f, 0.f, 0.f }, aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-    for (int t = 0; t < 4; t++) wl[t] = lnw[16 * t + lr];
+    for (int t = 0; t < 4; t++) { wl[t] = lnw[16 * t + lr]; if (RN) bl[t] = lnb[16 * t + lr]; }
     f32x4_t acc[3][5];
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -592,21 +598,21 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_w(const unsigned short* __restr
     wg_load<6>(dqkv, r_begin * QB_K, rows * QB_K, QB_K, vq, tid);
     wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
     wg_load<2>(dres, r_begin * 64, rows * 64, 64, vr, tid);
-    wg_load<2>(n1, r_begin * 64, rows * 64, 64, vn, tid);
+    if (!RN) wg_load<2>(n1, r_begin * 64, rows * 64, 64, vn, tid);
     __syncthreads();
     const int row = 16 * wave + lr;
     for (long r0 = r_begin; r0 < r_end; r0 += FW_ROWS) {
         wg_store_rows<6>(sDQ, QB_K, vq, tid);
         wg_store_rows<2>(sX, 64, vx, tid);
         wg_store_rows<2>(sR, 64, vr, tid);
-        wg_store_rows<2>(sN, 64, vn, tid);
+        if (!RN) wg_store_rows<2>(sN, 64, vn, tid);
         if (tid < FW_ROWS) sN[fw_off(tid, 64)] = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;
         __syncthreads();
         if (r0 + FW_ROWS < r_end) {
             wg_load<6>(dqkv, (r0 + FW_ROWS) * QB_K, rows * QB_K, QB_K, vq, tid);
             wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
             wg_load<2>(dres, (r0 + FW_ROWS) * 64, rows * 64, 64, vr, tid);
-            wg_load<2>(n1, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
+            if (!RN) wg_load<2>(n1, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
         }
         // ---- dN = dQKV . Wqkv for this wave's 16 rows
         float dn[4][4];
@@ -650,6 +656,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_w(const unsigned short* __restr
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 xv[t][r] *= rstd;
+                if (RN) sN[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = live ? te_to_bf(xv[t][r] * wl[t] + bl[t]) : (unsigned short)0;
                 const float gy = live ? dn[t][r] : 0.f;
                 aw[t] += gy * xv[t][r]; ab[t] += gy;
                 gw[t] = gy * wl[t];

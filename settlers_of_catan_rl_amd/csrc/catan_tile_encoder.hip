@@ -201,11 +201,11 @@ struct TeSaves {
     unsigned short* tiles64;          // [64]: the tile features, zero-padded 60 -> 64 (the first layer's input)
     unsigned short* a0;               // [64]: first_layer output (before its LayerNorm + ReLU)
     unsigned short* xin[2];           // [64]: the layer's input (residual stream)
-    unsigned short* n1[2];            // [64]: LayerNorm 1 output (the QKV product's input)
+    unsigned short* n1[2];            // [64]: LayerNorm 1 output (the QKV product's input); may be null: k_qkv_bwd_w<true> recomputes it from xin
     unsigned short* qkv[2];           // [192]
     unsigned short* o[2];             // [64]: attention output (the out-projection's input)
     unsigned short* xmid[2];          // [64]: residual stream after the attention sub-layer
-    unsigned short* n2[2];            // [64]: LayerNorm 2 output (the FFN's input)
+    unsigned short* n2[2];            // [64]: LayerNorm 2 output (the FFN's input); may be null: k_ffn_bwd_w<., true> recomputes it from xmid
     unsigned short* h[2];             // [128]: relu(linear1)
     unsigned short* xfin;             // [64]: the last layer's output (out_proj's input)
     unsigned short* p;                // [25]: out_proj output (before the final LayerNorm + ReLU)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (SAVE) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl, vl + 64, tid);
             __syncthreads();
-            if (SAVE) te_dump<64>(Nb, TE_PX, sv.n1[l], t0, nt, tid);
+            if (SAVE && sv.n1[l] != nullptr) te_dump<64>(Nb, TE_PX, sv.n1[l], t0, nt, tid);   // (optional: the backward can recompute it)
             te_gemm<64, 192, 0>(Nb, TE_PX, wq, vl + 128, Q, TE_PQ, lane, wave);
             TeW<64, 64> wo; te_fetch<64, 64>(wo, wl + 192 * 64, lane, wave);
             __syncthreads();
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (SAVE) te_dump<64>(X, TE_PX, sv.xmid[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl + 384, vl + 448, tid);
             __syncthreads();
-            if (SAVE) te_dump<64>(Nb, TE_PX, sv.n2[l], t0, nt, tid);
+            if (SAVE && sv.n2[l] != nullptr) te_dump<64>(Nb, TE_PX, sv.n2[l], t0, nt, tid);
             te_gemm<64, 128, 1>(Nb, TE_PX, w1, vl + 512, Q, TE_PH, lane, wave);
             __syncthreads();
             if (SAVE) te_dump<128>(Q, TE_PH, sv.h[l], t0, nt, tid);

@@ -747,6 +747,11 @@ class _TeWorkspace(object):
         return cls.Lease(cls.buf)
 
 
+def _te_backward_fused_w():
+    """The tile encoder's backward runs k_ffn_bwd_w / k_qkv_bwd_w (the default; the toggles select the older chains for tests)."""
+    return os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1"
+
+
 class _TileEncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tiles, te, out_cols, *params):
@@ -764,15 +769,25 @@ class _TileEncoderTrain(torch.autograd.Function):
         # caching allocator every step, the slightly different sizes fragment it (reserved memory grew from 100 to 190 GB in three
         # updates).  ONE workspace is kept instead and leased to the forward whose backward has not run yet; a second forward
         # in flight (gradient accumulation) gets a fresh buffer as before.
-        need = T * sum(w for _, w in _TE_SAVES)
+        # The LayerNorm-1 outputs n1 are NOT stored when the backward runs the one-pass kernels with the weight gradients: k_qkv_bwd_w
+        # recomputes them from the LayerNorm inputs it reads anyway, at no cost (it is HBM-bound: 766 vs 768 us at 3.9 M rows), and
+        # the forward writes 256 B per token less (3.06 -> 2.94 ms at 204 800 boards).  k_ffn_bwd_w can do the same for n2
+        # (CATAN_TE_RECOMPUTE_N=2) but is latency-bound: the extra LDS stores cost it more (1.57 -> 1.76 ms) than the forward gains,
+        # so n2 stays stored.  CATAN_TE_RECOMPUTE_N=0: both stored (tools/bench_te_n_recompute.py).
+        level = int(os.environ.get("CATAN_TE_RECOMPUTE_N", "1")) if _te_backward_fused_w() else 0
+        drop = ("n1_", "n2_")[:level]
+        names = [(n, w) for n, w in _TE_SAVES if not (drop and n.startswith(drop))]
+        need = T * sum(w for _, w in names)
         lease = _TeWorkspace.lease(need, x.device)
         ctx.lease = lease
         buf = lease.buf if lease is not None else torch.empty((need,), dtype=torch.bfloat16, device=x.device)
         saves, off = [], 0
-        for _, w in _TE_SAVES:
+        for _, w in names:
             saves.append(buf[off:off + T * w].view(T, w))
             off += T * w
-        ptrs = (C.c_void_p * len(saves))(*[t.data_ptr() for t in saves])
+        by_name = dict(zip([n for n, _ in names], saves))
+        ptrs = (C.c_void_p * len(_TE_SAVES))(*[by_name[n].data_ptr() if n in by_name else None for n, _ in _TE_SAVES])
+        ctx.save_names = [n for n, _ in names]
         # out_cols > 475: board rows padded with zero columns to whole 16-byte pieces (nn_kernels.expand_rows, aligned GEMM operands)
         out = (torch.empty if out_cols == 475 else torch.zeros)((B, out_cols), dtype=torch.bfloat16, device=x.device)
         _lib.check(_lib.lib().catan_tile_encoder_fwd_train(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), out_cols, C.cast(ptrs, C.c_void_p), B, _stream()))
@@ -783,8 +798,8 @@ class _TileEncoderTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        ns = len(_TE_SAVES)
-        sv = dict(zip([n for n, _ in _TE_SAVES], ctx.saved_tensors[:ns]))
+        ns = len(ctx.save_names)
+        sv = dict(zip(ctx.save_names, ctx.saved_tensors[:ns]))
         P = ctx.saved_tensors[ns:]
         B, eps, bf = ctx.B, ctx.eps, torch.bfloat16
         T = B * 19
@@ -797,28 +812,28 @@ class _TileEncoderTrain(torch.autograd.Function):
             g[36], g[37] = _wgrad(sv["xfin"], dp, True)
             for l in (1, 0):
                 b = 4 + 16 * l
-                xin, n1, qkv, o, xmid, n2, h = (sv[k + str(l)] for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
+                xin, n1, qkv, o, xmid, n2, h = (sv.get(k + str(l)) for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
                 if im is not None:
                     w2t, w1t, wot, wqt = im.w2t[l], im.w1t[l], im.wot[l], im.wqt[l]
                 else:
                     w2t, w1t, wot = P[b + 14].to(bf).t().contiguous(), P[b + 12].to(bf).t().contiguous(), P[b + 8].to(bf).t().contiguous()
                     wqt = torch.cat([P[b + 2], P[b + 4], P[b + 6]], 0).to(bf).t().contiguous()
-                if os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1":
+                if _te_backward_fused_w():
                     # k_ffn_bwd_w: the chain below AND both weight gradients in one pass over the rows (dH never leaves the chip)
                     dxmid = torch.empty_like(xmid)
                     acc = torch.zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), dtype=torch.float32, device=h.device)
                     dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:16704]
                     dwo, dbo = acc[16704:20800], acc[20800:]
-                    lw = P[b + 10].detach().float().contiguous()
+                    lw, lb = P[b + 10].detach().float().contiguous(), P[b + 11].detach().float().contiguous()
                     if os.environ.get("CATAN_TE_BWD_OP", "1") == "1":       # ... and the out-projection's dO and weight gradient from the same rows
                         do = torch.empty_like(o)
-                        _lib.check(_lib.lib().catan_ffn_outproj_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
+                        _lib.check(_lib.lib().catan_ffn_outproj_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2) if n2 is not None else None, _ptr(w2t), _ptr(w1t), _ptr(lw), _ptr(lb), eps, _ptr(dxmid),
                                                                     _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]),
                                                                     _ptr(o), _ptr(wot), _ptr(do), _ptr(dwo), _ptr(dbo), T, _stream()))
                         g[b + 8], g[b + 9] = dwo.view(64, 64), dbo
                     else:
                         do = None
-                        _lib.check(_lib.lib().catan_ffn_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dxmid),
+                        _lib.check(_lib.lib().catan_ffn_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2) if n2 is not None else None, _ptr(w2t), _ptr(w1t), _ptr(lw), _ptr(lb), eps, _ptr(dxmid),
                                                             _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
                     g[b + 14], g[b + 15], g[b + 12], g[b + 13], g[b + 10], g[b + 11] = dw2.view(64, 128), db2, dw1.view(128, 64), db1, dl[:64], dl[64:]
                     dh = None
@@ -841,13 +856,14 @@ class _TileEncoderTrain(torch.autograd.Function):
                     g[b + 8], g[b + 9] = _wgrad(o, dxmid, True)
                 dqkv = torch.empty_like(qkv)
                 _lib.check(_lib.lib().catan_attention_bwd(_ptr(qkv), None, _ptr(do), _ptr(dqkv), B, 19, 4, 16, 1, _stream()))
-                fused_w = os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1"
+                fused_w = _te_backward_fused_w()
                 if fused_w:                     # k_qkv_bwd_w: the QKV product's weight gradient and the dX chain in one pass over the rows
                     dx = torch.empty_like(xin)
                     acc = torch.zeros((192 * 64 + 192 + 128,), dtype=torch.float32, device=xin.device)
                     dwq, dbq, dl = acc[:12288].view(192, 64), acc[12288:12480], acc[12480:]
-                    lw = P[b].detach().float().contiguous()
-                    _lib.check(_lib.lib().catan_qkv_bwd(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(n1), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dwq), _ptr(dbq),
+                    lw, lb = P[b].detach().float().contiguous(), P[b + 1].detach().float().contiguous()
+                    _lib.check(_lib.lib().catan_qkv_bwd(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(n1) if n1 is not None else None, _ptr(wqt), _ptr(lw), _ptr(lb), eps,
+                                                        _ptr(dx), _ptr(dwq), _ptr(dbq),
                                                         _ptr(dl[:64]), _ptr(dl[64:]), T, _stream()))
                     g[b], g[b + 1] = dl[:64], dl[64:]
                 else:

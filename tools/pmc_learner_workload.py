@@ -46,14 +46,14 @@ for _ in range(REPS): _lib.check(L.catan_ffn_bwd_dx(P(dx), P(h), P(xm), P(w2t), 
 dq = torch.randn(tok, 192, device=dev, generator=g).to(torch.bfloat16); wqt = torch.randn(64, 192, device=dev, generator=g).to(torch.bfloat16)
 for _ in range(REPS): _lib.check(L.catan_qkv_bwd_dx(P(dq), P(xm), P(dx), P(wqt), P(lw), 1e-5, P(dxo), P(dl[0]), P(dl[1]), tok, S()))
 # the same chains with the sub-layers' weight gradients (and the out-projection's backward) in the pass: what the update's backward runs
-n2 = torch.randn(tok, 64, device=dev, generator=g).to(torch.bfloat16); oo = torch.randn(tok, 64, device=dev, generator=g).to(torch.bfloat16)
+lb = torch.randn(64, device=dev, generator=g); n2 = torch.randn(tok, 64, device=dev, generator=g).to(torch.bfloat16); oo = torch.randn(tok, 64, device=dev, generator=g).to(torch.bfloat16)
 wot = torch.randn(64, 64, device=dev, generator=g).to(torch.bfloat16); do = torch.empty_like(oo)
 acc = torch.zeros(64 * 128 + 64 + 128 * 64 + 128 + 64 * 64 + 64 + 192 * 64 + 192, device=dev)
 for _ in range(REPS):
-    _lib.check(L.catan_ffn_outproj_bwd(P(dx), P(h), P(xm), P(n2), P(w2t), P(w1t), P(lw), 1e-5, P(dxo), P(acc[:8192]), P(acc[8192:8256]), P(acc[8256:16448]),
+    _lib.check(L.catan_ffn_outproj_bwd(P(dx), P(h), P(xm), P(n2), P(w2t), P(w1t), P(lw), P(lb), 1e-5, P(dxo), P(acc[:8192]), P(acc[8192:8256]), P(acc[8256:16448]),
                                        P(acc[16448:16576]), P(dl[0]), P(dl[1]), P(oo), P(wot), P(do), P(acc[16576:20672]), P(acc[20672:20736]), tok, S()))
 for _ in range(REPS):
-    _lib.check(L.catan_qkv_bwd(P(dq), P(xm), P(dx), P(n2), P(wqt), P(lw), 1e-5, P(dxo), P(acc[20736:33024]), P(acc[33024:33216]), P(dl[0]), P(dl[1]), tok, S()))
+    _lib.check(L.catan_qkv_bwd(P(dq), P(xm), P(dx), None, P(wqt), P(lw), P(lb), 1e-5, P(dxo), P(acc[20736:33024]), P(acc[33024:33216]), P(dl[0]), P(dl[1]), tok, S()))
 del n2, oo, do
 # a weight gradient and a row product at the encoder's shapes
 for _ in range(REPS): nn_kernels.wgrad(h, dx)
