@@ -313,6 +313,78 @@ __global__ __launch_bounds__(256) void k_qkv_bwd_dx(const unsigned short* __rest
 constexpr int FW_ROWS = 64;
 constexpr int FW_IMG64 = 4 * 2 * WG_SUB, FW_IMG65 = 5 * 2 * WG_SUB, FW_IMG128 = 8 * 2 * WG_SUB, FW_IMG129 = 9 * 2 * WG_SUB;   // elements per image
 DEVI int fw_off(int row, int col) { return wg_sub_off(col >> 4, row >> 5) + (row & 31) * 16 + (col & 15); }
+// LayerNorm backward + residual of one token per lane (k_ffn_bwd_w).  The dN product is formed TRANSPOSED
+// (weights as the A operand), so lane (lr, g) holds dN[token lr][16 t + 4 g + i]: a token's 64 columns sit in the four lanes lr,
+// lr + 16, lr + 32, lr + 48 as 4 x 4 CONSECUTIVE columns each - X, the residual gradient and the outgoing dX' (and N, when it is
+// recomputed) move as 8-byte LDS accesses and the row statistics are two xor-shuffles (the row-per-four-lanes layout of
+// k_ffn_bwd_dx takes sixteen 2-byte accesses per image and four shuffles per statistic for each of its four rows): k_ffn_bwd_w<true>
+// 1.56 -> 1.37 ms at 3.9 M rows, and recomputing N costs nothing any more (1.35 ms).  k_qkv_bwd_w keeps the row layout: with 64
+// instead of 16 registers of LayerNorm weights / gradient sums it needs 286 VGPRs and loses its second workgroup per CU (0.77 -> 0.84 ms).
+// xs: the X image (its rows are replaced by dX'); rs: the residual-gradient image; ns: the N image (RN) or nullptr.
+template <bool RN>
+DEVI void fw_ln_bwd_token(unsigned short* xs, const unsigned short* rs, unsigned short* ns, int row, int g, bool live, const float (&dn)[4][4],
+                          const float (&wl)[4][4], const float (&bl)[4][4], float eps, float (&aw)[4][4], float (&ab)[4][4]) {
+    float xv[4][4], res[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int o = fw_off(row, 16 * t + 4 * g);
+        const uint2 ux = *reinterpret_cast<const uint2*>(xs + o), ur = *reinterpret_cast<const uint2*>(rs + o);
+        xv[t][0] = __uint_as_float(ux.x << 16); xv[t][1] = __uint_as_float(ux.x & 0xFFFF0000u);
+        xv[t][2] = __uint_as_float(ux.y << 16); xv[t][3] = __uint_as_float(ux.y & 0xFFFF0000u);
+        res[t][0] = __uint_as_float(ur.x << 16); res[t][1] = __uint_as_float(ur.x & 0xFFFF0000u);
+        res[t][2] = __uint_as_float(ur.y << 16); res[t][3] = __uint_as_float(ur.y & 0xFFFF0000u);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) sum += xv[t][i];
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / 64.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xv[t][i] -= mean; sq += xv[t][i] * xv[t][i]; }
+    sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+    float gw[4][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        unsigned short nb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xv[t][i] *= rstd;
+            if (RN) nb[i] = live ? te_to_bf(xv[t][i] * wl[t][i] + bl[t][i]) : (unsigned short)0;
+            const float gy = live ? dn[t][i] : 0.f;
+            aw[t][i] += gy * xv[t][i]; ab[t][i] += gy;
+            gw[t][i] = gy * wl[t][i];
+            s1 += gw[t][i]; s2 += gw[t][i] * xv[t][i];
+        }
+        if (RN) *reinterpret_cast<uint2*>(ns + fw_off(row, 16 * t + 4 * g)) = make_uint2((unsigned)nb[0] | ((unsigned)nb[1] << 16), (unsigned)nb[2] | ((unsigned)nb[3] << 16));
+    }
+    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+    const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        unsigned short ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ob[i] = te_to_bf(hd_bf(rstd * (gw[t][i] - m1 - xv[t][i] * m2)) + res[t][i]);
+        *reinterpret_cast<uint2*>(xs + fw_off(row, 16 * t + 4 * g)) = make_uint2((unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16));
+    }
+}
+// the LayerNorm weight / bias gradients of that layout: summed over the 16 token lanes, one LDS atomic per column and wave
+DEVI void fw_ln_grads_out(float (&aw)[4][4], float (&ab)[4][4], float (*sG)[64], int lr, int g) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { aw[t][i] += __shfl_xor(aw[t][i], m); ab[t][i] += __shfl_xor(ab[t][i], m); }
+            if (lr == 0) { atomicAdd(&sG[0][16 * t + 4 * g + i], aw[t][i]); atomicAdd(&sG[1][16 * t + 4 * g + i], ab[t][i]); }
+        }
+}
 // OP: also the backward of the out-projection that FEEDS this sub-layer's input (x = x_in + o Wo^T + bo: the gradient of x is the
 // gradient of that product's output): dO = dX' Wo and dWo = dX'^T O from the dX' rows while they are in LDS - the separate row
 // product and weight-gradient kernels read dX' twice more.  o [rows][64] = the attention output, wot = Wo^T [64 in][64 out],
@@ -350,9 +422,11 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     for (int c = tid; c < 64 * 16; c += 256) { const int n = c >> 4, ch = c & 15; *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8); }
     for (int c = tid; c < FW_IMG129; c += 256) sH[c] = 0;                        // (the ones columns' tiles: everything but column 0 stays zero)
     for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
-    float wl[4], bl[4] = { 0.f, 0.f, 0.f, 0.f }, aw[4] = { 0.f, 0.f, 0.f, 0.f }, ab[4] = { 0.f, 0.f, 0.f, 0.f };
+    float wl[4][4], bl[4][4], aw[4][4], ab[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) { wl[t] = lnw[16 * t + lr]; if (RN) bl[t] = lnb[16 * t + lr]; }
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wl[t][i] = lnw[16 * t + 4 * g + i]; bl[t][i] = RN ? lnb[16 * t + 4 * g + i] : 0.f; aw[t][i] = 0.f; ab[t][i] = 0.f; }
     f32x4_t acc2[9], acc1[2][5];
 #pragma unroll
     for (int b = 0; b < 9; b++) acc2[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -408,7 +482,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
             *reinterpret_cast<uint2*>(sDH + fw_off(row, 16 * j + 4 * g)) = make_uint2(p0, p1);
         }
-        // ---- dN = dH . W1: lane holds rows 4 g + r of the wave's 16, column 16 t + lr
+        // ---- dN^T = W1^T . dH^T (the weights as the A operand again): lane holds token `row`, columns 16 t + 4 g + i
         float dn[4][4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -419,51 +493,13 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
                 const unsigned short* wr = sW1 + (16 * t + lr) * FB_P1 + 32 * s + 4 * g;
                 const uint2 lo = *reinterpret_cast<const uint2*>(wr), hi = *reinterpret_cast<const uint2*>(wr + 16);
                 uint4 bu; bu.x = lo.x; bu.y = lo.y; bu.z = hi.x; bu.w = hi.y;
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&au), *reinterpret_cast<const bf16x8_t*>(&bu), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&bu), *reinterpret_cast<const bf16x8_t*>(&au), c, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) dn[t][r] = hd_bf(c[r]);
+            for (int i = 0; i < 4; i++) dn[t][i] = hd_bf(c[i]);
         }
         // ---- LayerNorm backward + the residual dX; the result replaces the wave's rows of the X image
-        float xv[4][4], res[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int o = fw_off(16 * wave + 4 * g + r, 16 * t + lr);
-                xv[t][r] = te_bf(sX[o]); res[t][r] = te_bf(sDX[o]);
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float sum = xv[0][r] + xv[1][r] + xv[2][r] + xv[3][r];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
-            const float mean = sum * (1.f / 64.f);
-            float sq = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; t++) { xv[t][r] -= mean; sq += xv[t][r] * xv[t][r]; }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m);
-            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
-            const bool live = r0 + 16 * wave + 4 * g + r < r_end;
-            float gw[4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                xv[t][r] *= rstd;
-                if (RN) sN[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = live ? te_to_bf(xv[t][r] * wl[t] + bl[t]) : (unsigned short)0;
-                const float gy = live ? dn[t][r] : 0.f;
-                aw[t] += gy * xv[t][r]; ab[t] += gy;
-                gw[t] = gy * wl[t];
-                s1 += gw[t]; s2 += gw[t] * xv[t][r];
-            }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-            const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                sX[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = te_to_bf(hd_bf(rstd * (gw[t] - m1 - xv[t][r] * m2)) + res[t][r]);
-        }
+        fw_ln_bwd_token<RN>(sX, sDX, RN ? sN : nullptr, row, g, r0 + row < r_end, dn, wl, bl, eps, aw, ab);
         __syncthreads();                                                         // dH image and the dX' rows complete
         // ---- the stage's rows of dX' leave (16-byte pieces of the image rows)
         for (int c = tid; c < FW_ROWS * 8; c += 256) {
@@ -546,15 +582,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
                 const float v = acc1[a][b][r];
                 if (v != 0.0f) { if (i < 64) atomicAdd(&dw1[o * 64 + i], v); else if (i == 64) atomicAdd(&db1[o], v); }
             }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        aw[t] += __shfl_xor(aw[t], 16); aw[t] += __shfl_xor(aw[t], 32);
-        ab[t] += __shfl_xor(ab[t], 16); ab[t] += __shfl_xor(ab[t], 32);
-    }
-    if (g == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) { atomicAdd(&sG[0][16 * t + lr], aw[t]); atomicAdd(&sG[1][16 * t + lr], ab[t]); }
-    }
+    fw_ln_grads_out(aw, ab, sG, lr, g);
     __syncthreads();
     if (tid < 64) { atomicAdd(dlnw + tid, sG[0][tid]); atomicAdd(dlnb + tid, sG[1][tid]); }
 }

@@ -769,12 +769,11 @@ class _TileEncoderTrain(torch.autograd.Function):
         # caching allocator every step, the slightly different sizes fragment it (reserved memory grew from 100 to 190 GB in three
         # updates).  ONE workspace is kept instead and leased to the forward whose backward has not run yet; a second forward
         # in flight (gradient accumulation) gets a fresh buffer as before.
-        # The LayerNorm-1 outputs n1 are NOT stored when the backward runs the one-pass kernels with the weight gradients: k_qkv_bwd_w
-        # recomputes them from the LayerNorm inputs it reads anyway, at no cost (it is HBM-bound: 766 vs 768 us at 3.9 M rows), and
-        # the forward writes 256 B per token less (3.06 -> 2.94 ms at 204 800 boards).  k_ffn_bwd_w can do the same for n2
-        # (CATAN_TE_RECOMPUTE_N=2) but is latency-bound: the extra LDS stores cost it more (1.57 -> 1.76 ms) than the forward gains,
-        # so n2 stays stored.  CATAN_TE_RECOMPUTE_N=0: both stored (tools/bench_te_n_recompute.py).
-        level = int(os.environ.get("CATAN_TE_RECOMPUTE_N", "1")) if _te_backward_fused_w() else 0
+        # The LayerNorm outputs n1 / n2 are NOT stored when the backward runs the one-pass kernels with the weight gradients: k_qkv_bwd_w
+        # and k_ffn_bwd_w recompute them from the LayerNorm inputs they read anyway (at no cost: 754 vs 769 us and 1.35 vs 1.37 ms at
+        # 3.9 M rows), and the forward writes 512 B per token less (3.04 -> 2.76 ms at 204 800 boards).  CATAN_TE_RECOMPUTE_N=1: only n1
+        # recomputed, 0: both stored and read (tools/bench_te_n_recompute.py, the tests).
+        level = int(os.environ.get("CATAN_TE_RECOMPUTE_N", "2")) if _te_backward_fused_w() else 0
         drop = ("n1_", "n2_")[:level]
         names = [(n, w) for n, w in _TE_SAVES if not (drop and n.startswith(drop))]
         need = T * sum(w for _, w in names)

@@ -991,7 +991,7 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             monkeypatch.setenv("CATAN_TE_BWD_UNFUSED", "1" if mode == "fused, backward in separate steps" else "0")
             monkeypatch.setenv("CATAN_TE_BWD_W", "0" if mode == "fused, weight gradients in their own kernels" else "1")
             monkeypatch.setenv("CATAN_TE_BWD_OP", "0" if mode == "fused, out-projection backward in its own kernels" else "1")
-            monkeypatch.setenv("CATAN_TE_RECOMPUTE_N", {"fused, LayerNorm outputs stored": "0", "fused, LayerNorm outputs recomputed": "2"}.get(mode, "1"))
+            monkeypatch.setenv("CATAN_TE_RECOMPUTE_N", {"fused, LayerNorm outputs stored": "0", "fused, LayerNorm-2 outputs stored": "1"}.get(mode, "2"))
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
@@ -1007,10 +1007,10 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         oc, gc = run(tiles, "fused, backward in separate steps")      # the pointwise sub-layer's backward as three kernels instead of k_ffn_bwd_dx
         ow, gw_ = run(tiles, "fused, weight gradients in their own kernels")   # k_ffn_bwd_dx + two catan_linear_wgrad instead of k_ffn_bwd_w
         oo, go_ = run(tiles, "fused, out-projection backward in its own kernels")   # k_ffn_bwd_w<false> + row product + catan_linear_wgrad
-        # the default backward recomputes the LayerNorm-1 outputs n1 from their inputs (k_qkv_bwd_w<true>) and reads the stored n2;
-        # here the forward stores both and the passes read them / stores neither and both passes recompute (k_ffn_bwd_w<., true>)
+        # the default backward recomputes the LayerNorm outputs n1 / n2 from their inputs (k_qkv_bwd_w<true>, k_ffn_bwd_w<., true>);
+        # here the forward stores both and the passes read them / stores n2 only
         on, gn = run(tiles, "fused, LayerNorm outputs stored")
-        on2, gn2 = run(tiles, "fused, LayerNorm outputs recomputed")
+        on2, gn2 = run(tiles, "fused, LayerNorm-2 outputs stored")
         assert of.shape == (B, 475) and torch.equal(oc, of) and torch.equal(ow, of) and torch.equal(oo, of) and torch.equal(on, of) and torch.equal(on2, of)
         for n in names:
             scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())

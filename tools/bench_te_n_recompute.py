@@ -27,7 +27,7 @@ def time_us(fn, reps=8):
     return a.elapsed_time(b) / reps * 1e3
 
 
-for level, what in (("0", "n1 and n2 stored"), ("1", "n2 stored (the default)"), ("2", "neither stored")):
+for level, what in (("0", "n1 and n2 stored"), ("1", "n2 stored"), ("2", "neither stored (the default)")):
     os.environ["CATAN_TE_RECOMPUTE_N"] = level
     with torch.autocast("cuda", dtype=torch.bfloat16):
         us = time_us(lambda: nn_kernels.tile_encoder_train(te, tiles))

@@ -77,12 +77,12 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     macs = 19 * (64 * 64 + 2 * (64 * 192 + 64 * 64 + 64 * 128 + 128 * 64) + 64 * 32) + 2 * 4 * 2 * 32 * 32 * 16
     out.append(_entry("k_tile_encoder_fwd (whole tile encoder, inference)", f"{boards} boards", us, (2280 + 950) * boards, flops=2 * macs * boards,
                       note="VALU / L2-latency bound (LayerNorm, softmax, epilogues), not HBM- or MFMA-bound: DESIGN.md 4.5 (iv)"))
-    # ---- the same kernel as the TRAINING forward: it also stores what the backward kernels read (1 401 bf16 per token: 53 KB per board;
-    #      the LayerNorm-1 outputs are recomputed by k_qkv_bwd_w instead)
+    # ---- the same kernel as the TRAINING forward: it also stores what the backward kernels read (1 273 bf16 per token: 48 KB per board;
+    #      the LayerNorm outputs n1 / n2 are recomputed by the backward passes instead)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         us = _time_us(lambda: nn_kernels.tile_encoder_train(te, tiles), reps=5)
     out.append(_entry("k_tile_encoder_fwd<SAVE> (training forward: + the activations the backward reads)", f"{boards} boards", us,
-                      (2280 + 950 + 19 * 1401 * 2) * boards, flops=2 * macs * boards, note="includes the per-step re-pack of the encoder's weights (~60 small launches)"))
+                      (2280 + 950 + 19 * 1273 * 2) * boards, flops=2 * macs * boards, note="includes the per-step re-pack of the encoder's weights (~60 small launches)"))
     del tiles
     # ---- the backward of the encoder's sub-layers up to the weight gradients, one pass each (csrc/catan_te_bwd.hip)
     tokf = boards * 19
@@ -103,13 +103,13 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     wot = torch.randn(64, 64, device=dev, generator=g).to(torch.bfloat16)
     do, lb = torch.empty_like(oo), torch.randn(64, device=dev, generator=g)
     accw = torch.zeros(64 * 128 + 64 + 128 * 64 + 128 + 192 * 64 + 192 + 64 * 64 + 64, device=dev)
-    # (the update's configuration: n2 stored and read by the pointwise pass; n1 = NULL: recomputed from X in the QKV pass)
-    us = _time_us(lambda: _lib.check(_lib.lib().catan_ffn_outproj_bwd(P(dxg), P(hh), P(xm), P(n2), P(w2t), P(w1t), P(lw), P(lb), 1e-5, P(dxo), P(accw[:8192]),
+    # (the update's configuration: n = NULL - the LayerNorm outputs are recomputed from X in the passes, the forward does not store them)
+    us = _time_us(lambda: _lib.check(_lib.lib().catan_ffn_outproj_bwd(P(dxg), P(hh), P(xm), None, P(w2t), P(w1t), P(lw), P(lb), 1e-5, P(dxo), P(accw[:8192]),
                                                                       P(accw[8192:8256]), P(accw[8256:16448]), P(accw[16448:16576]), P(dl[0]), P(dl[1]),
                                                                       P(oo), P(wot), P(do), P(accw[29056:33152]), P(accw[33152:33216]), tokf, S())), reps=5)
     out.append(_entry("k_ffn_bwd_w<out-projection> (k_ffn_bwd_dx + dW2, dW1 + the out-projection's dO, dWo in the same pass)", f"{tokf} rows", us,
-                      (64 + 128 + 64 + 64 + 64 + 64 + 64) * 2 * tokf, flops=(2 * 4 * 64 * 128 + 2 * 2 * 64 * 64) * tokf,
-                      note="dX, H, X, N, O in; dX', dO out; dH stays in LDS"))
+                      (64 + 128 + 64 + 64 + 64 + 64) * 2 * tokf, flops=(2 * 4 * 64 * 128 + 2 * 2 * 64 * 64) * tokf,
+                      note="dX, H, X, O in; dX', dO out; dH and N stay in LDS"))
     us = _time_us(lambda: _lib.check(_lib.lib().catan_qkv_bwd(P(dq), P(xm), P(dxg), None, P(wqt), P(lw), P(lb), 1e-5, P(dxo), P(accw[16576:28864]), P(accw[28864:29056]),
                                                               P(dl[0]), P(dl[1]), tokf, S())), reps=5)
     out.append(_entry("k_qkv_bwd_w<N recomputed> (k_qkv_bwd_dx + dWqkv = dQKV^T N in the same pass)", f"{tokf} rows", us, (192 + 64 + 64 + 64) * 2 * tokf,

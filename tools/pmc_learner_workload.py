@@ -50,7 +50,7 @@ lb = torch.randn(64, device=dev, generator=g); n2 = torch.randn(tok, 64, device=
 wot = torch.randn(64, 64, device=dev, generator=g).to(torch.bfloat16); do = torch.empty_like(oo)
 acc = torch.zeros(64 * 128 + 64 + 128 * 64 + 128 + 64 * 64 + 64 + 192 * 64 + 192, device=dev)
 for _ in range(REPS):
-    _lib.check(L.catan_ffn_outproj_bwd(P(dx), P(h), P(xm), P(n2), P(w2t), P(w1t), P(lw), P(lb), 1e-5, P(dxo), P(acc[:8192]), P(acc[8192:8256]), P(acc[8256:16448]),
+    _lib.check(L.catan_ffn_outproj_bwd(P(dx), P(h), P(xm), None, P(w2t), P(w1t), P(lw), P(lb), 1e-5, P(dxo), P(acc[:8192]), P(acc[8192:8256]), P(acc[8256:16448]),
                                        P(acc[16448:16576]), P(dl[0]), P(dl[1]), P(oo), P(wot), P(do), P(acc[16576:20672]), P(acc[20672:20736]), tok, S()))
 for _ in range(REPS):
     _lib.check(L.catan_qkv_bwd(P(dq), P(xm), P(dx), None, P(wqt), P(lw), P(lb), 1e-5, P(dxo), P(acc[20736:33024]), P(acc[33024:33216]), P(dl[0]), P(dl[1]), tok, S()))
