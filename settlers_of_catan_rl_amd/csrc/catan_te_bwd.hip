@@ -500,6 +500,29 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
         }
         // ---- LayerNorm backward + the residual dX; the result replaces the wave's rows of the X image
         fw_ln_bwd_token<RN>(sX, sDX, RN ? sN : nullptr, row, g, r0 + row < r_end, dn, wl, bl, eps, aw, ab);
+        if (OP) {
+            // ---- dO = dX' Wo for this wave's 16 rows, from the rows of dX' the wave has just written (its stores fly during the weight gradients)
+            __builtin_amdgcn_wave_barrier();
+            bf16x8_t ax[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) ax[s2] = *reinterpret_cast<const bf16x8_t*>(sX + fw_off(row, 32 * s2 + 8 * g));
+            f32x4_t co[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                co[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+                    co[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sWo + (16 * t + lr) * FB_P + 32 * s2 + 8 * g), ax[s2], co[t], 0, 0, 0);
+            }
+            // (transposed product: the lane holds token `row`, columns 16 t + 4 g + i - 8-byte stores straight to HBM, a token's 128 bytes
+            //  from its four lanes; no image, no barrier)
+            if (r0 + row < r_end) {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    *reinterpret_cast<uint2*>(op.d_o + (r0 + row) * 64 + 16 * t + 4 * g) = make_uint2((unsigned)te_to_bf(co[t][0]) | ((unsigned)te_to_bf(co[t][1]) << 16),
+                                                                                                    (unsigned)te_to_bf(co[t][2]) | ((unsigned)te_to_bf(co[t][3]) << 16));
+            }
+        }
         __syncthreads();                                                         // dH image and the dX' rows complete
         // ---- the stage's rows of dX' leave (16-byte pieces of the image rows)
         for (int c = tid; c < FW_ROWS * 8; c += 256) {
@@ -525,30 +548,6 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
                 const bf16x8_t ao = wg_frag_tr(sX, wave, ks, lane);
 #pragma unroll
                 for (int b = 0; b < 5; b++) acco[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, wg_frag_tr(sO, b, ks, lane), acco[b], 0, 0, 0);
-            }
-        }
-        if (OP) {
-            // ---- dO = dX' Wo for this wave's 16 rows, through the dX image (every wave has read its dX fragments: barrier first)
-            bf16x8_t ax[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) ax[s2] = *reinterpret_cast<const bf16x8_t*>(sX + fw_off(row, 32 * s2 + 8 * g));
-            f32x4_t co[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                co[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s2 = 0; s2 < 2; s2++)
-                    co[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[s2], *reinterpret_cast<const bf16x8_t*>(sWo + (16 * t + lr) * FB_P + 32 * s2 + 8 * g), co[t], 0, 0, 0);
-            }
-            __syncthreads();                                                     // (sDX was an operand of the weight gradients above)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) sDX[fw_off(16 * wave + 4 * g + r, 16 * t + lr)] = te_to_bf(co[t][r]);
-            __syncthreads();
-            for (int c = tid; c < FW_ROWS * 8; c += 256) {
-                const int rr = c >> 3, ch = c & 7;
-                if (r0 + rr < r_end) *reinterpret_cast<uint4*>(op.d_o + (r0 + rr) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(sDX + fw_off(rr, ch * 8));
             }
         }
         __syncthreads();                                                         // (the next stage overwrites the images)
