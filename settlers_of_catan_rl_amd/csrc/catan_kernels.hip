@@ -500,6 +500,18 @@ struct DfsQueue { u64* seen; unsigned short* cd; int* n; int cap; };
 struct LrGraph { const u64* adj; u64 blk; int sw_v; };            // adj[v] = 0 for a blocked corner; blk = blocked corners
 typedef unsigned short lrstk_t;   // stack entry: vertex | sibling << 6 | mode << 12 (0 none left, 1 one sibling, 2 re-derive) | phase-0 level << 14
 
+// A lane's best path so far: the longest, and among equally long ones the one with the LARGEST vertex mask.  The tie-break makes the
+// result of a search - len << 54 | vertex mask, maximised over all lanes - independent of which lane walks which subtree: every
+// longest path is some lane's candidate, so the maximum is the same whatever the work sharing did.  (With "first found" per lane
+// the cached vertex set of tier 2 depended on the order in which its waves popped the pool; lengths were exact either way, but
+// which later settlements invalidate the cache - and with that which requests overflow into tier 2 - differed from run to run:
+// 7-11 of 65 536 games ended a deferred rollout a window or two of decisions apart, tools/deferred_reproducible.py.)
+// TIE = false (tier 1, one wave: its work sharing through LDS is deterministic already): "first found" - the equal-length case
+// comes up at most leaves, and the extra compare cost the DFS step 10 % (k_lr_finish 47 -> 52 us, deferred 1.16 -> 1.115 G steps/s).
+template <bool TIE>
+DEVI void dfs_consider(Dfs& t, int len, u64 seen) {
+    if (len > t.best || (TIE && len == t.best && seen > t.bseen)) { t.best = len; t.bseen = seen; }
+}
 DEVI bool lrq_push(const DfsQueue& q, u64 seen, int vertex, int depth) {
     const int qi = atomicAdd(q.n, 1);
     if (qi < q.cap) { q.seen[qi] = seen; q.cd[qi] = (unsigned short)(vertex | (depth << 8)); return true; }
@@ -508,6 +520,7 @@ DEVI bool lrq_push(const DfsQueue& q, u64 seen, int vertex, int depth) {
 }
 // One DFS step of one lane: (at most) one backtrack followed by one descend attempt.  path: this lane's column (entry for
 // level d at path[d * stride]).
+template <bool TIE>
 DEVI void dfs_iter(Dfs& t, const LrGraph& G, lrstk_t* path, int stride, bool donate, const DfsQueue& q) {
     if (!t.active) return;
     if (t.cand == 0) {
@@ -531,7 +544,7 @@ DEVI void dfs_iter(Dfs& t, const LrGraph& G, lrstk_t* path, int stride, bool don
     const int nph = sw ? 1 : t.ph;
     const bool ablk = sw ? (((G.blk >> t.cur) & 1) != 0) : t.ablk;
     const u64 nseen = t.seen | (1ull << v);
-    if (nph == 1 && t.d + 1 > t.best && !(ablk && ((G.blk >> v) & 1))) { t.best = t.d + 1; t.bseen = nseen; }
+    if (nph == 1 && t.d + 1 >= t.best + (TIE ? 0 : 1) && !(ablk && ((G.blk >> v) & 1))) dfs_consider<TIE>(t, t.d + 1, nseen);
     const u64 a = (G.adj[v] & ~nseen) | (nph == 0 ? LR_SW : 0ull);
     if (a) {
         if (t.cand && donate) {                         // give the untaken siblings (<= 2 corners, and / or the crossing) away
@@ -542,14 +555,14 @@ DEVI void dfs_iter(Dfs& t, const LrGraph& G, lrstk_t* path, int stride, bool don
                     cc = 0;
                     const bool ab = ((G.blk >> t.cur) & 1) != 0;
                     const u64 sseen = t.seen;            // (v is in it already)
-                    if (t.d + 1 > t.best && !(ab && ((G.blk >> G.sw_v) & 1))) { t.best = t.d + 1; t.bseen = sseen; }
+                    if (t.d + 1 >= t.best + (TIE ? 0 : 1) && !(ab && ((G.blk >> G.sw_v) & 1))) dfs_consider<TIE>(t, t.d + 1, sseen);
                     if (G.adj[G.sw_v] & ~sseen) all &= lrq_push(q, sseen | LRQ_PH1 | (ab ? LRQ_ABLK : 0ull), G.sw_v, t.d + 1);
                 } else {
                     const int sb = __ffsll((long long)cc) - 1;
                     cc &= cc - 1;
                     const u64 sseen = t.seen | (1ull << sb);
                     if (t.ph == 1) {
-                        if (t.d + 1 > t.best && !(t.ablk && ((G.blk >> sb) & 1))) { t.best = t.d + 1; t.bseen = sseen; }
+                        if (t.d + 1 >= t.best + (TIE ? 0 : 1) && !(t.ablk && ((G.blk >> sb) & 1))) dfs_consider<TIE>(t, t.d + 1, sseen);
                         if (G.adj[sb] & ~sseen) all &= lrq_push(q, sseen | LRQ_PH1 | (t.ablk ? LRQ_ABLK : 0ull), sb, t.d + 1);
                     } else all &= lrq_push(q, sseen, sb, t.d + 1);      // an arm tip can always cross
                 }
@@ -575,6 +588,7 @@ DEVI void dfs_take(Dfs& t, const LrGraph& G, u64 seen, int cd) {
 // the (code >> 2l & 3)-th candidate of that level (corners ascending, the crossing last: at most 4 moves per level), then owns
 // the subtree below (base = its depth).  Every prefix node's own path length is counted by all lanes that pass it (a
 // maximum: harmless); a code that names a move which does not exist leaves its lane idle (it will take shared work).
+template <bool TIE>
 DEVI void dfs_walk_prefix(Dfs& t, const LrGraph& G, int code, int levels) {
     for (int l = 0; l < levels && t.active; l++) {
         u64 cc = t.cand;
@@ -585,7 +599,7 @@ DEVI void dfs_walk_prefix(Dfs& t, const LrGraph& G, int code, int levels) {
         const int nph = sw ? 1 : t.ph;
         const bool ablk = sw ? (((G.blk >> t.cur) & 1) != 0) : t.ablk;
         const u64 nseen = t.seen | (1ull << v);
-        if (nph == 1 && t.d + 1 > t.best && !(ablk && ((G.blk >> v) & 1))) { t.best = t.d + 1; t.bseen = nseen; }
+        if (nph == 1 && t.d + 1 >= t.best + (TIE ? 0 : 1) && !(ablk && ((G.blk >> v) & 1))) dfs_consider<TIE>(t, t.d + 1, nseen);
         t.cur = v; t.seen = nseen; t.d++; t.ph = nph; t.ablk = ablk;
         t.cand = (G.adj[v] & ~nseen) | (nph == 0 ? LR_SW : 0ull);
         if (t.cand == 0) t.active = false;
@@ -709,14 +723,14 @@ DEVI u64 lr_wave_search(u64 R, u32 RH, u64 BL, bool through, int u, int v, LrWav
     __builtin_amdgcn_wave_barrier();
     const LrGraph G{ L.adj, BL, v };
     Dfs t;
-    if (through) { dfs_seed_through(t, true, u, v, L.adj[u]); dfs_walk_prefix(t, G, lane, 3); }     // 4^3 prefixes = the 64 lanes
+    if (through) { dfs_seed_through(t, true, u, v, L.adj[u]); dfs_walk_prefix<false>(t, G, lane, 3); }     // 4^3 prefixes = the 64 lanes
     else dfs_seed_full(t, lane, myadj);
     u64 idle = __ballot(!t.active);
     int it = 0;
     bool overflow = false;
     while (true) {
-        dfs_iter(t, G, &L.path[0][lane], 64, idle != 0, q);
-        dfs_iter(t, G, &L.path[0][lane], 64, idle != 0, q);
+        dfs_iter<false>(t, G, &L.path[0][lane], 64, idle != 0, q);
+        dfs_iter<false>(t, G, &L.path[0][lane], 64, idle != 0, q);
         idle = __ballot(!t.active);
         const int qn = L.qn;
         if (idle == ~0ull && qn <= 0) break;
@@ -2121,19 +2135,19 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
         if (pl.through) {                                  // 4^5 prefixes = the 1 024 threads of part 0; with >= 4 parts: 4^6 over parts 0..3
             const bool wide = LR_SPLIT >= 4;
             dfs_seed_through(t, wide ? part < 4 : part == 0, pl.u, pl.v, adj[pl.u]);
-            dfs_walk_prefix(t, G, wide ? part * LR_HEAVY_THREADS + tid : tid, wide ? 6 : 5);
+            dfs_walk_prefix<true>(t, G, wide ? part * LR_HEAVY_THREADS + tid : tid, wide ? 6 : 5);
         } else {                                           // start corner tid % 54 (this part's share), 16 two-level prefixes each
             const int st = tid % 54, code = tid / 54;
             dfs_seed_full(t, st, adj[st]);
             t.active = t.active && code < 16 && ((u32)st % LR_SPLIT) == (u32)part;
-            dfs_walk_prefix(t, G, code, 2);
+            dfs_walk_prefix<true>(t, G, code, 2);
         }
         const DfsQueue q{ pool_seen, pool_cd, &pool_n, LR_POOL };
         bool hint = true;
         const long long hp_t1 = wall_clock64();
         while (true) {
             hp_rounds++;
-            for (int it = 0; it < round_iters; it++) dfs_iter(t, G, &path[0][tid], LR_HEAVY_THREADS, hint, q);
+            for (int it = 0; it < round_iters; it++) dfs_iter<true>(t, G, &path[0][tid], LR_HEAVY_THREADS, hint, q);
             __syncthreads();                       // all pushes of this round are complete
             if (!t.active) {
                 const int qi = atomicSub(&pool_n, 1) - 1;

@@ -78,6 +78,28 @@ def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, s
     assert ob.games.value > 0
 
 
+def test_deferred_rollout_is_reproducible(hip_lib):
+    """Two deferred rollouts of the same environment (seed, passes, window) end in the same records with the same decision
+    counts - also when many longest-road requests overflow into tier 2 (tier-1 budget 4), whose waves share work through a pool
+    in whatever order they get to it: the cached longest path is the one with the largest vertex mask among the longest
+    (dfs_consider<true>), not the first one some lane happened to find - with that, 7-11 of 65 536 games used to end a rollout a
+    window or two of decisions apart (which later requests overflow depends on the cached vertex set)."""
+    import torch
+    for n, iters, window, budget in ((16384, 1500, 32, 4), (4096, 1200, 8, 12)):
+        outs = []
+        for rep in range(2):
+            env = _env(n, 3)
+            env.set_lr_budgets(16, budget)
+            env.random_rollout_deferred(iters, window)
+            torch.cuda.synchronize()
+            outs.append((env.export_state().cpu(), env.policy_counters().cpu(), env.slow_path_counts()))
+            del env
+        assert outs[0][2][1] > 0                                       # (tier 2 was in use)
+        assert torch.equal(outs[0][1], outs[1][1]), (n, int((outs[0][1] != outs[1][1]).sum()))
+        assert torch.equal(outs[0][0], outs[1][0]), (n, int((outs[0][0] != outs[1][0]).any(1).sum()))
+        assert outs[0][2] == outs[1][2]
+
+
 def test_step_api_rewards_and_done(oracle, hip_lib):
     """Per-step API: device sampler -> catan_step; rewards/done/deciding player against the oracle."""
     import torch
