@@ -1398,9 +1398,9 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
                        float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl) {
     constexpr int NACC = GROUP <= 3 ? 64 : GROUP == 4 ? 96 : GROUP == 5 ? 48 : 24;
     constexpr int OFF_S = 0, OFF_V = CS_H * CS_V * CS_V, OFF_W = OFF_V + CS_V * CS_D, OFF_B = OFF_W + CS_D * CS_D;
-    __shared__ CardTables T;
+    __shared__ CardTables Tshared;
     __shared__ float G[144];
-    for (int i = threadIdx.x; i < CS_NPAR; i += 256) reinterpret_cast<float*>(&T)[i] = params[i];
+    for (int i = threadIdx.x; i < CS_NPAR; i += 256) reinterpret_cast<float*>(&Tshared)[i] = params[i];
     if (threadIdx.x < 144) G[threadIdx.x] = 0.f;
     __syncthreads();
     const bool lead = (threadIdx.x & 63) == 0;
@@ -1434,6 +1434,11 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
 #pragma unroll
                 for (int q = 0; q < CS_V; q++) ca = (q == a) ? cnt[q] : ca;
                 if (ca == 0.f) continue;
+                // (an opaque zero offset per class: without it the compiler hoists the whole parameter block - 400 LDS values - out of
+                //  the loops into registers: every slice compiled to 512 VGPRs, V and S spilled 1.4-1.7 KB, and each reload sat on the lane's serial chain)
+                int toff = 0;
+                asm volatile("" : "+v"(toff));
+                const CardTables& T = *reinterpret_cast<const CardTables*>(reinterpret_cast<const char*>(&Tshared) + toff);
                 float p[CS_H][CS_V], attn[CS_D], xhat[CS_D], rep[CS_D], rstd;
                 cs_class_fwd(T, logc, a, eps, p, attn, xhat, rstd, rep);
                 // LayerNorm backward (drep = count * dy)
