@@ -1259,8 +1259,11 @@ int catan_card_summary_bwd(const void* ids, int id_bytes, int64_t pitch, const i
     if (card_summary_check(ids, id_bytes, pitch, lens, params, rows) || !dout || !dparams || (n_unkeyed && !only_unkeyed))
         return fail(CATAN_EINVAL, "catan_card_summary_bwd: bad arguments");
     const int rpl = rows >= 65536 ? 4 : 1;                 // lists per lane: few rows (the pattern table) want all the lanes they can get
-    const dim3 grid((unsigned)((rows + 256 * rpl - 1) / (256 * rpl)), 7);
-    hipLaunchKernelGGL(k_card_summary_bwd, grid, dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, dout, dparams, (long)rows, only_unkeyed, rpl, n_unkeyed);
+    const int nb = (int)((rows + 256 * rpl - 1) / (256 * rpl));
+    const int row_blocks = rows < 65536 ? nb : 0;          // ... and one query class per workgroup (CS_V x nb workgroups per slice)
+    const dim3 grid((unsigned)(row_blocks > 0 ? CS_V * nb : nb), 7);
+    hipLaunchKernelGGL(k_card_summary_bwd, grid, dim3(256), 0, S(stream), ids, id_bytes, (long)pitch, lens, params, eps, dout, dparams, (long)rows, only_unkeyed, rpl, n_unkeyed,
+                       row_blocks);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1395,7 +1395,7 @@ DEVI float cs_wave_sum(float v) {
 template <int GROUP>
 DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
                        const float* __restrict__ params, float eps, const float* __restrict__ dout,
-                       float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl) {
+                       float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl, int row_blocks) {
     constexpr int NACC = GROUP <= 3 ? 64 : GROUP == 4 ? 96 : GROUP == 5 ? 48 : 24;
     constexpr int OFF_S = 0, OFF_V = CS_H * CS_V * CS_V, OFF_W = OFF_V + CS_V * CS_D, OFF_B = OFF_W + CS_D * CS_D;
     __shared__ CardTables Tshared;
@@ -1404,16 +1404,21 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
     if (threadIdx.x < 144) G[threadIdx.x] = 0.f;
     __syncthreads();
     const bool lead = (threadIdx.x & 63) == 0;
-    const long stride = (long)gridDim.x * 256;
+    // row_blocks > 0 (few rows: the pattern table): the grid is CS_V x row_blocks workgroups and a workgroup takes ONE query class
+    // of its rows - with 4 860 lists on 19 x 7 workgroups the launch lasts as long as one lane's chain over the six classes;
+    // row_blocks = 0: every lane walks the classes of its lists
+    const int bx = row_blocks > 0 ? (int)blockIdx.x % row_blocks : (int)blockIdx.x;
+    const int a_only = row_blocks > 0 ? (int)blockIdx.x / row_blocks : -1;
+    const long stride = (long)(row_blocks > 0 ? row_blocks : gridDim.x) * 256;
     constexpr int A_OUTER = GROUP == 6 ? CS_V : 1;
 #pragma unroll 1
-    for (int ao = 0; ao < A_OUTER; ao++) {
+    for (int ao = (GROUP == 6 && a_only >= 0 ? a_only : 0); ao < (GROUP == 6 && a_only >= 0 ? a_only + 1 : A_OUTER); ao++) {
         float acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; i++) acc[i] = 0.f;
 #pragma unroll 1
         for (int it = 0; it < rpl; it++) {
-            const long r = (long)blockIdx.x * 256 + threadIdx.x + it * stride;
+            const long r = (long)bx * 256 + threadIdx.x + it * stride;
             if (r >= rows) break;
             if (only_unkeyed != nullptr && only_unkeyed[r] >= 0) continue;      // this list went through its pattern
             float cnt[CS_V], logc[CS_V], dy[CS_D];
@@ -1429,7 +1434,7 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
 #pragma unroll
             for (int a = 0; a < CS_V; a++) logc[a] = cnt[a] > 0.f ? __logf(cnt[a]) : -INFINITY;
 #pragma unroll 1
-            for (int a = (GROUP == 6 ? ao : 0); a < (GROUP == 6 ? ao + 1 : CS_V); a++) {
+            for (int a = (GROUP == 6 ? ao : (a_only >= 0 ? a_only : 0)); a < (GROUP == 6 ? ao + 1 : (a_only >= 0 ? a_only + 1 : CS_V)); a++) {
                 float ca = 0.f;
 #pragma unroll
                 for (int q = 0; q < CS_V; q++) ca = (q == a) ? cnt[q] : ca;
@@ -1502,16 +1507,16 @@ DEVI void cs_bwd_group(const void* __restrict__ ids, int esz, long pitch, const 
 __global__ __launch_bounds__(256) void k_card_summary_bwd(const void* __restrict__ ids, int esz, long pitch, const int* __restrict__ lens,
                                                           const float* __restrict__ params, float eps, const float* __restrict__ dout,
                                                           float* __restrict__ dparams, long rows, const int* __restrict__ only_unkeyed, int rpl,
-                                                          const int* __restrict__ n_unkeyed) {
+                                                          const int* __restrict__ n_unkeyed, int row_blocks) {
     if (n_unkeyed != nullptr && *n_unkeyed == 0) return;      // (uniform) every list went through its pattern
     switch (blockIdx.y) {
-    case 0: cs_bwd_group<0>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    case 1: cs_bwd_group<1>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    case 2: cs_bwd_group<2>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    case 3: cs_bwd_group<3>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    case 4: cs_bwd_group<4>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    case 5: cs_bwd_group<5>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
-    default: cs_bwd_group<6>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl); break;
+    case 0: cs_bwd_group<0>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    case 1: cs_bwd_group<1>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    case 2: cs_bwd_group<2>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    case 3: cs_bwd_group<3>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    case 4: cs_bwd_group<4>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    case 5: cs_bwd_group<5>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
+    default: cs_bwd_group<6>(ids, esz, pitch, lens, params, eps, dout, dparams, rows, only_unkeyed, rpl, row_blocks); break;
     }
 }
 
