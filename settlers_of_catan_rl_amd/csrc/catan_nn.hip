@@ -1125,12 +1125,14 @@ __device__ __forceinline__ bf16x8_t ld_gather(const unsigned short* col, int s, 
 // ... the same fragment through gfx950's transposing LDS read (16 dims per head): a 16-lane group hands ds_read_tr16_b64 the
 // addresses of rows base .. base + 3 (lane i: row base + i / 4, dims 4 (i % 4) ..) and lane i gets dim i of those four rows - one
 // instruction per 4-row run instead of four 2-byte reads.  The images have 32 rows (rows >= L are zero).
-__device__ __forceinline__ bf16x8_t ld_gather_tr(const unsigned short* img_head, int rp, int s, int lane) {
+// hi: the row offset of the second run (8; 0 where those rows lie beyond the image - their coefficients are exact zeros, any
+// finite rows do).
+__device__ __forceinline__ bf16x8_t ld_gather_tr(const unsigned short* img_head, int rp, int s, int lane, int hi = 8) {
     const int i = lane & 15, hf = lane >> 5;
     const unsigned short* p = img_head + (16 * s + 4 * hf + (i >> 2)) * rp + (i & 3) * 4;
     union { bf16x8_t f; wg_s4 h[2]; } r;
     r.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)p);
-    r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(p + 8 * rp));
+    r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(p + hi * rp));
     return r.f;
 }
 // dqkv [B][L][3][D] from dout [B][L][D]; the probabilities are recomputed in both orientations (see above)
@@ -1140,7 +1142,10 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;      // registers 12..15 = keys / queries 24..31: beyond the sequence when L <= 24
     constexpr int RP = at_rp<D>();
     constexpr bool TR = HD == 16;                            // transposing LDS reads (whole 16-dim heads)
-    constexpr int IR = TR ? 32 : L;                          // rows of an image (TR: padded with zero rows to 32)
+    // rows of an image (TR: padded with zero rows).  L <= 24: 24 rows - the products' rows 24..31 meet the probabilities' registers
+    // 12..15, exact zeros, so their fragments re-read rows 16..23 (HI1 = 0): 43 instead of 57 KB of LDS = three workgroups per CU
+    constexpr int IR = TR ? (L <= 24 ? 24 : 32) : L;
+    constexpr int HI1 = IR == 24 ? 0 : 8;                    // second 4-row run of k-step 1
     __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][IR * RP];            // K, Q, dO row-major: [key / query][dim]
     __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: row max, 1 / row sum, delta
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
@@ -1205,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             f32x16_t dq = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++)
-                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(kt + h * HD, RP, s, lane) : ld_gather<L, D>(kt + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(kt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(kt + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
             if (rowok) st_head<HD>(gb + (c31 * 3 + 0) * D + h * HD, dq, hf);
         }
         __builtin_amdgcn_wave_barrier();
@@ -1231,8 +1236,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             f32x16_t dk = zero16, dv = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(qt + h * HD, RP, s, lane) : ld_gather<L, D>(qt + tcol, s, hf)) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
-                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(dot + h * HD, RP, s, lane) : ld_gather<L, D>(dot + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(qt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(qt + tcol, s, hf)) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(dot + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(dot + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
             }
             if (rowok) {
                 st_head<HD>(gb + (c31 * 3 + 1) * D + h * HD, dk, hf);
