@@ -657,9 +657,12 @@ void orc_masks(const OrcEnv* e, float* m) {
     }
 }
 
-/* "mask bit set" legality used by validate mode: every head relevant to the chosen type must be unmasked,
- * plus the ownership check of game.py:455-466 for ProposeTrade (masks for heads 6/7/8 are all ones). */
-int orc_action_is_legal(const OrcEnv* e, const int32_t* a) {
+static int head_to_res(int h) { return h + 1; }                             /* wrapper.py:414-426 */
+
+/* "would a mask-sampling policy ever emit it": every head relevant to the chosen type is unmasked, plus the ownership
+ * check of game.py:455-466 for ProposeTrade (masks for heads 6/7/8 are all ones).  A strict SUBSET of what validate mode
+ * accepts (orc_action_is_legal below); tests use it to tell in-mask from out-of-mask accepted actions. */
+int orc_action_in_masks(const OrcEnv* e, const int32_t* a) {
     float m[ORC_MASK_WORDS];
     orc_masks(e, m);
     int t = a[0];
@@ -687,6 +690,154 @@ int orc_action_is_legal(const OrcEnv* e, const int32_t* a) {
     case T_STEAL: return a[6] >= 0 && a[6] < 3 && m[M6 + 3 + a[6]] > 0;
     case T_DISCARD: return a[17] >= 0 && a[17] < 5 && m[M11 + a[17]] > 0;
     default: return 1;
+    }
+}
+
+
+/* Validate mode = EnvWrapper.step with validate_actions=True (env/wrapper.py:36-41, the wrapper's default):
+ * `_translate_action` (env/wrapper.py:114-166, :414-426, :440-486) followed by `Game.validate_action`
+ * (game/game.py:264-525), restated branch by branch.  1 = the reference applies the action; 0 = the reference raises
+ * (RuntimeError from a `False, msg` verdict; ValueError / KeyError / IndexError / TypeError from a head value outside
+ * its range, from the bare `return False` of game.py:490 or from falling off the end for an unknown type) and leaves the
+ * game untouched.  This is NOT "the mask bit is set": the reference accepts, and applies, actions its masks never offer -
+ *   MoveRobber onto ANY tile whenever can_move_robber (game.py:483-490; the mask wants a building on the tile,
+ *     wrapper.py:308-320), also before the dice are rolled (Knight played first: the pre-roll mask has no MoveRobber);
+ *   ProposeTrade past max_proposed_trades_per_turn and with nothing offered (the limit and `total > 0` live only in the
+ *     mask, wrapper.py:283-289);
+ *   RollDice while a Road Building card is being played out (game.py:491-500 never looks at
+ *     must_use_development_card_ability);
+ *   the dummy edge during road building although a real edge is free (game.py:325-328; mask: wrapper.py:336-338);
+ *   Year of Plenty with an empty bank / for a resource the bank lacks, Monopoly on any resource (game.py:403-414 vs
+ *     wrapper.py:368-388, :226-228);
+ *   everything past max_actions_per_turn (mask only, wrapper.py:233-234).
+ * The one deliberate restriction of the DOMAIN: a head value below zero is rejected here, whereas Python would wrap a
+ * negative corner / edge / tile index around the reference's lists (and then store the negative number in the game state);
+ * negative values are not part of the MultiDiscrete action space.  Values at or above a head's size raise in the
+ * reference and are rejected here. */
+int orc_action_is_legal(const OrcEnv* e, const int32_t* a) {
+    const OrcTopology* T = orc_topology();
+    const int type = a[0];
+    if (type < 0 || type > 12) return 0;                       /* no branch matches: validate_action returns None -> TypeError */
+    const int pid = e->players_go;                             /* game.py:277 */
+    const OrcPlayer* pl = &e->pl[pid];
+    /* ---- _translate_action: what raises there, whatever the state (wrapper.py:114-166) */
+    int give_cnt[6] = { 0, 0, 0, 0, 0, 0 };
+    switch (type) {
+    case T_STEAL: if (a[6] < 0 || a[6] > 2) return 0; break;                                   /* :130-138 */
+    case T_PLAYDEV:                                                                            /* :140-147 */
+        if (a[4] == C_MONO && (a[15] < 0 || a[15] > 4)) return 0;
+        if (a[4] == C_YOP && (a[15] < 0 || a[15] > 4 || a[16] < 0 || a[16] > 4)) return 0;
+        break;
+    case T_EXCHANGE: if (a[15] < 0 || a[15] > 4 || a[16] < 0 || a[16] > 4) return 0; break;    /* :148-150 */
+    case T_PROPOSE:                                                                            /* :440-486 */
+        if (a[6] < 0 || a[6] > 2) return 0;
+        for (int i = 0; i < 4; i++) { int v = a[7 + i]; if (v == 0) break; if (v < 0 || v > 5) return 0; give_cnt[v]++; }
+        for (int i = 0; i < 4; i++) { int v = a[11 + i]; if (v == 0) break; if (v < 0 || v > 5) return 0; }
+        break;
+    case T_RESPOND: if (a[5] < 0 || a[5] > 1) return 0; break;                                 /* :156-162 */
+    case T_DISCARD: if (a[17] < 0 || a[17] > 4) return 0; break;                               /* :163-164 */
+    default: break;
+    }
+    /* ---- validate_action (game.py:279-303): the discard phase comes first */
+    if (e->need_discard) {
+        if (type != T_DISCARD) return 0;
+        const OrcPlayer* d = &e->pl[e->to_discard[0]];
+        const int tot = total_res(d);
+        if (tot <= 7) return 0;                                /* :285-286 raises ValueError (unreachable: the list only holds > 7) */
+        if (tot - 1 < 7) return 0;                             /* :292 */
+        return d->res[head_to_res(a[17])] > 0;                 /* :295-300 */
+    }
+    if (type == T_DISCARD) return 0;                           /* :302-303 */
+    switch (type) {
+    case T_SETTLE: {                                                                           /* :305-323 */
+        if (e->must_respond) return 0;
+        if (!e->dice_rolled && !e->initial_phase) return 0;
+        if (e->must_use_dev || e->just_moved_robber) return 0;
+        if (!e->initial_phase) {                                                               /* can_buy_settlement :186-193 */
+            if (e->settlements_left[pid] <= 0) return 0;
+            if (!(pl->res[R_WHEAT] > 0 && pl->res[R_WOOD] > 0 && pl->res[R_BRICK] > 0 && pl->res[R_SHEEP] > 0)) return 0;
+        }
+        if (a[1] < 0 || a[1] >= 54) return 0;                                                  /* IndexError */
+        if (!can_place_settlement(e, a[1], pid, e->initial_phase)) return 0;
+        if (e->initial_phase)
+            return e->init_settlements[pid] == 0 || (e->init_settlements[pid] == 1 && e->init_roads[pid] == 1);
+        return 1;
+    }
+    case T_ROAD: {                                                                             /* :324-357 */
+        if (e->rb_active) {                                                                    /* :325-332: nothing else is looked at */
+            if (a[2] == 72) return 1;
+            if (a[2] < 0 || a[2] > 72) return 0;
+            return can_place_road(e, a[2], pid, 0, -1);
+        }
+        if (e->must_respond) return 0;
+        if (!e->dice_rolled && !e->initial_phase) return 0;
+        if (e->must_use_dev || e->just_moved_robber) return 0;
+        if (!e->initial_phase && !(pl->res[R_WOOD] > 0 && pl->res[R_BRICK] > 0)) return 0;     /* can_buy_road :214-220 */
+        if (a[2] < 0 || a[2] >= 72) return 0;                  /* 72 -> None -> `edges[None]` TypeError (:342-343); > 72 IndexError */
+        if (!can_place_road(e, a[2], pid, 0, -1)) return 0;
+        if (e->initial_phase) {
+            if (e->init_settlements[pid] == 1 && e->init_roads[pid] == 0) return 1;
+            if (e->init_settlements[pid] == 2 && e->init_roads[pid] == 1)
+                return can_place_road(e, a[2], pid, 1, e->init_second_corner[pid]);
+            return 0;
+        }
+        return 1;
+    }
+    case T_CITY: {                                                                             /* :358-376 */
+        if (e->must_respond || e->initial_phase || !e->dice_rolled || e->must_use_dev || e->just_moved_robber) return 0;
+        if (!(e->cities_left[pid] > 0 && pl->res[R_WHEAT] > 1 && pl->res[R_ORE] > 2)) return 0; /* can_buy_city :234-238 */
+        if (a[1] < 0 || a[1] >= 54) return 0;
+        return e->corner_bld[a[1]] == 1 && e->corner_owner[a[1]] == pid;
+    }
+    case T_BUYDEV:                                                                             /* :377-393 */
+        if (e->must_respond || e->initial_phase || !e->dice_rolled || e->must_use_dev || e->just_moved_robber) return 0;
+        if (!(pl->res[R_WHEAT] > 0 && pl->res[R_SHEEP] > 0 && pl->res[R_ORE] > 0)) return 0;    /* :179-184 */
+        return e->pile_len > 0;
+    case T_PLAYDEV: {                                                                          /* :394-415 */
+        if (e->must_respond || e->played_dev || e->initial_phase || e->just_moved_robber) return 0;
+        if (a[4] < 0 || a[4] > 4) return 0;                                                    /* not `in hidden_cards` */
+        const int k = card_count(pl->hidden, pl->n_hidden, a[4]);
+        if (k <= 0) return 0;
+        if (k == e->bought_this_turn[a[4]]) return 0;                                          /* :405-406 */
+        return 1;                                              /* no look at the bank, the dice or the resource heads */
+    }
+    case T_EXCHANGE: {                                                                         /* :416-443 */
+        if (e->must_respond || e->initial_phase || !e->dice_rolled || e->must_use_dev || e->just_moved_robber) return 0;
+        const int give = head_to_res(a[15]), want = head_to_res(a[16]);
+        int rate = 4;                                                                          /* wrapper.py:428-438 */
+        if (pl->harbours[give]) rate = 2; else if (pl->harbours[0]) rate = 3;
+        return pl->res[give] >= rate && e->bank[want] > 0;
+    }
+    case T_PROPOSE:                                                                            /* :444-466 */
+        if (e->must_respond || e->initial_phase || !e->dice_rolled || e->must_use_dev || e->just_moved_robber) return 0;
+        for (int r = 1; r <= 5; r++) if (pl->res[r] < give_cnt[r]) return 0;
+        return 1;                                              /* no per-turn limit, an empty offer is fine */
+    case T_RESPOND: {                                                                          /* :467-482 */
+        if (!e->must_respond) return 0;
+        if (a[5] == 1) return 1;
+        int chk[6];
+        for (int r = 0; r <= 5; r++) chk[r] = e->pl[e->trade_target].res[r];
+        for (int i = 0; i < e->trade_n_recv; i++) if (--chk[e->trade_recv[i]] < 0) return 0;
+        return 1;
+    }
+    case T_ROBBER:                                                                             /* :483-490 */
+        if (e->must_respond || e->must_use_dev) return 0;
+        if (!e->can_move_robber) return 0;                     /* bare `return False` -> TypeError in wrapper.py:39 */
+        return a[3] >= 0 && a[3] < 19;                         /* any tile; >= 19: IndexError at game.py:624, before any change */
+    case T_ROLL:                                                                               /* :491-500 */
+        return !(e->must_respond || e->initial_phase || e->dice_rolled || e->just_moved_robber);
+    case T_ENDTURN:                                                                            /* :501-512 */
+        return !(e->must_respond || e->initial_phase || !e->dice_rolled || e->must_use_dev || e->just_moved_robber);
+    case T_STEAL: {                                                                            /* :513-525 */
+        if (e->must_respond || !e->just_moved_robber) return 0;
+        const int victim = player_at_label(e, pid, a[6]);
+        for (int k = 0; k < 6; k++) {
+            const int c = T->tile_corner[e->robber_tile][k];
+            if (e->corner_bld[c] && e->corner_owner[c] == victim) return 1;
+        }
+        return 0;
+    }
+    default: return 0;
     }
 }
 
@@ -736,7 +887,6 @@ static void update_players_go(OrcEnv* e, int left) {
 static void pay(OrcEnv* e, OrcPlayer* pl, int r, int n) {                   /* resource -> bank with visible clamp */
     pl->res[r] -= n; pl->vis[r] = max0(pl->vis[r] - n); e->bank[r] += n;
 }
-static int head_to_res(int h) { return h + 1; }                             /* wrapper.py:414-426 */
 
 /* ref: env/wrapper.py:36-50 (step), :114-166 (_translate_action), game/game.py:527-815 (apply_action),
  * env/wrapper.py:85-112 (_get_done_and_rewards).  reward4 is indexed by PlayerId-1. */

@@ -44,6 +44,7 @@ def lib():
         L.orc_game_reset.argtypes = [vp]
         L.orc_masks.argtypes = [vp, f32p]
         L.orc_action_is_legal.argtypes = [vp, i32p]; L.orc_action_is_legal.restype = C.c_int
+        L.orc_action_in_masks.argtypes = [vp, i32p]; L.orc_action_in_masks.restype = C.c_int
         L.orc_step.argtypes = [vp, i32p, f32p, C.POINTER(C.c_int)]; L.orc_step.restype = C.c_int
         L.orc_deciding_player.argtypes = [vp]; L.orc_deciding_player.restype = C.c_int
         L.orc_obs.argtypes = [vp, f32p, i32p, i32p, i32p]
