@@ -144,35 +144,31 @@ DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
     }
 }
 
-// k_step's stage-in: besides the hot records, the ACTION rows (72 B) and packed MASK rows (44 of 64 B) of the wave's 64
-// arbitrary games.  Read lane-per-game, each of those 29 words is a load instruction that touches 64 different cache
-// lines (measured: 25 us + 8 us per wave, most of k_step); read row-wise - 7 games x 9 lanes x 8 B and 21 games x 3
-// lanes x 16 B per instruction - every line is requested once.  The words go through the (still empty) tile to the
-// owning lane's registers before the state is written into it; all global loads are issued up front.
+// k_step's stage-in: besides the hot records, the ACTION rows (72 B) of the wave's 64 arbitrary games.  Read
+// lane-per-game, each of those 18 words is a load instruction that touches 64 different cache lines (measured: 25 us per
+// wave, most of k_step); read row-wise - 7 games x 9 lanes x 8 B per instruction - every line is requested once.  The
+// words go through the (still empty) tile to the owning lane's registers before the state is written into it; all global
+// loads are issued up front.  (Until round 4 the previous MASK rows came in the same way, 44 of 64 B per game, for a
+// "mask bit set" validation; validate mode now restates Game.validate_action from the state - action_valid - and the
+// step no longer reads its own previous output.)
 // EST = false: the nine estimate chunks (7..15) are left out - the wave's action type neither reads nor writes them
 // (propose, end_turn, robber, knight / victory point / road building cards: 40 % of the waves) - 19 chunks, 3 games per pass.
 template <bool EST, int G = 64>
-DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, const u32* __restrict__ mpk, int e, int lane,
-                       int (&a)[ACTION_WORDS], u32 (&m)[MASK_WORDS]) {
+DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, int e, int lane,
+                       int (&a)[ACTION_WORDS]) {
     constexpr int TSG = G + 1;
     constexpr int NCH = EST ? 28 : 19, GP = 64 / NCH, NP = (G + GP - 1) / GP;
-    constexpr int NPA = (G + 6) / 7, NPM = (G + 20) / 21;
+    constexpr int NPA = (G + 6) / 7;
     const int gi = lane / NCH, q0 = lane - NCH * gi, q = (EST || q0 < 7) ? q0 : q0 + 9;
     const bool act = lane < GP * NCH;
-    const int ag = lane / 9, aq = lane - 9 * ag, mg = lane / 3, mq = lane - 3 * mg;
-    uint4 v[NP], mv[NPM];
+    const int ag = lane / 9, aq = lane - 9 * ag;
+    uint4 v[NP];
     uint2 av[NPA];
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
         const int g = p * 7 + ag, eg = __shfl(e, g & 63);
         av[p] = make_uint2(0, 0);
         if (lane < 63 && g < G && eg >= 0) av[p] = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
-    }
-#pragma unroll
-    for (int p = 0; p < NPM; p++) {
-        const int g = p * 21 + mg, eg = __shfl(e, g & 63);
-        mv[p] = make_uint4(0, 0, 0, 0);
-        if (lane < 63 && g < G && eg >= 0) mv[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * mq);
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -185,20 +181,10 @@ DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restri
         const int g = p * 7 + ag;
         if (lane < 63 && g < G) { tile[(2 * aq) * TSG + g] = av[p].x; tile[(2 * aq + 1) * TSG + g] = av[p].y; }
     }
-#pragma unroll
-    for (int p = 0; p < NPM; p++) {
-        const int g = p * 21 + mg;
-        if (lane < 63 && g < G) {
-            u32* t = tile + (ACTION_WORDS + 4 * mq) * TSG + g;
-            t[0] = mv[p].x; t[TSG] = mv[p].y; t[2 * TSG] = mv[p].z; t[3 * TSG] = mv[p].w;
-        }
-    }
     __builtin_amdgcn_wave_barrier();
     const int sl = lane < G ? lane : G - 1;               // (lanes >= G carry no game: they read slot G-1 and are never used)
 #pragma unroll
     for (int i = 0; i < ACTION_WORDS; i++) a[i] = (int)tile[i * TSG + sl];
-#pragma unroll
-    for (int i = 0; i < MASK_WORDS; i++) m[i] = tile[(ACTION_WORDS + i) * TSG + sl];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -1194,30 +1180,34 @@ __global__ __launch_bounds__(256) void k_masked_row_store(unsigned char* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ step
-// "mask bit set" legality (validate mode): every head relevant to the chosen type must be unmasked, plus the
-// ownership check of game/game.py:455-466 for ProposeTrade.
+// Validate mode = EnvWrapper.step with validate_actions=True (env/wrapper.py:36-41, the wrapper's default):
+// `_translate_action` (wrapper.py:114-166, :414-426, :440-486) + `Game.validate_action` (game/game.py:264-525), restated
+// branch by branch FROM THE STATE - not "the mask bit is set": the reference accepts, and applies, actions its masks never
+// offer (MoveRobber onto any tile whenever can_move_robber, also before the roll; ProposeTrade past the per-turn limit or
+// with nothing offered; RollDice while a Road Building card is played out; the dummy edge although a real one is free;
+// Year of Plenty / Monopoly whatever the bank holds; everything past max_actions_per_turn).  false = the reference raises
+// and the game stays untouched.  Head values below zero are rejected (Python would wrap a negative list index: not part of
+// the action space); values at or above a head's size raise in the reference.  Same rule: oracle `orc_action_is_legal`;
+// pinned by tests/golden/validate_cases.npz and tools/fuzz_validate_vs_ref.py.  The action type is wave-uniform in k_step
+// (sorted bins), so the switch does not diverge.
 template <class S>
-DEVI bool action_legal(const S& s, const u32 (&m)[MASK_WORDS], const int (&a)[ACTION_WORDS]) {
-    auto bit = [&](int i) { return (m[i >> 5] >> (i & 31)) & 1u; };
-    int t = a[0];
-    if (t < 0 || t > 12 || !bit(M0 + t)) return false;
-    switch (t) {
-    case T_SETTLE: return a[1] >= 0 && a[1] < 54 && bit(M1 + a[1]);
-    case T_CITY: return a[1] >= 0 && a[1] < 54 && bit(M1 + 54 + a[1]);
-    case T_ROAD: return a[2] >= 0 && a[2] <= 72 && bit(M2 + a[2]);
-    case T_ROBBER: return a[3] >= 0 && a[3] < 19 && bit(M3 + a[3]);
-    case T_PLAYDEV:
-        if (a[4] < 0 || a[4] > 4 || !bit(M4 + a[4])) return false;
-        if (a[4] == C_MONO) return a[15] >= 0 && a[15] < 5 && bit(M9 + 10 + a[15]);
-        if (a[4] == C_YOP) return a[15] >= 0 && a[15] < 5 && a[16] >= 0 && a[16] < 5 && bit(M9 + 15 + a[15]) && bit(M10 + a[16]);
-        return true;
-    case T_EXCHANGE: return a[15] >= 0 && a[15] < 5 && a[16] >= 0 && a[16] < 5 && bit(M9 + a[15]) && bit(M10 + a[16]);
-    case T_PROPOSE: {
+DEVI bool action_valid(const S& s, const int (&a)[ACTION_WORDS]) {
+    const int t = a[0];
+    if (t < 0 || t > 12) return false;                                     // validate_action falls off its end -> TypeError
+    // ---- what raises in _translate_action, whatever the state
+    int cnt[5] = { 0, 0, 0, 0, 0 };
+    if (t == T_STEAL && (a[6] < 0 || a[6] > 2)) return false;              // wrapper.py:130-138
+    if (t == T_PLAYDEV) {                                                  // :140-147
+        if (a[4] == C_MONO && (a[15] < 0 || a[15] > 4)) return false;
+        if (a[4] == C_YOP && (a[15] < 0 || a[15] > 4 || a[16] < 0 || a[16] > 4)) return false;
+    }
+    if (t == T_EXCHANGE && (a[15] < 0 || a[15] > 4 || a[16] < 0 || a[16] > 4)) return false;   // :148-150
+    if (t == T_PROPOSE) {                                                  // :440-486 (entries behind the first 0 are never read)
         if (a[6] < 0 || a[6] > 2) return false;
-        int cnt[5] = { 0, 0, 0, 0, 0 };
         bool stop = false;
+#pragma unroll
         for (int i = 0; i < 4; i++) {
-            int v = a[7 + i];
+            const int v = a[7 + i];
             if (v == 0) stop = true;
             if (!stop) {
                 if (v < 0 || v > 5) return false;
@@ -1226,16 +1216,120 @@ DEVI bool action_legal(const S& s, const u32 (&m)[MASK_WORDS], const int (&a)[AC
             }
         }
         stop = false;
-        for (int i = 0; i < 4; i++) { int v = a[11 + i]; if (v == 0) stop = true; if (!stop && (v < 0 || v > 5)) return false; }
-        int pid = s.b(B_GO);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int v = a[11 + i]; if (v == 0) stop = true; if (!stop && (v < 0 || v > 5)) return false; }
+    }
+    if (t == T_RESPOND && (a[5] < 0 || a[5] > 1)) return false;            // :156-162
+    if (t == T_DISCARD && (a[17] < 0 || a[17] > 4)) return false;          // :163-164
+    // ---- validate_action: the discard phase first (game.py:279-303)
+    const int flags = s.flags();
+    const int pid = s.b(B_GO);
+    if (s.b(B_NDISC) > 0) {
+        if (t != T_DISCARD) return false;
+        const int d = s.b(B_DISC);
+        if (s.total(d) <= 7) return false;                                 // :285-286 raises (unreachable: the list only holds > 7)
+        return s.res(d, a[17]) > 0;                                        // :292-300 (one card at a time: never "too many")
+    }
+    if (t == T_DISCARD) return false;
+    const bool initial = (flags & F_INITIAL) != 0, rolled = (flags & F_ROLLED) != 0;
+    const bool respond = (flags & F_MUST_RESPOND) != 0, use_dev = (flags & F_MUST_USE_DEV) != 0, just = (flags & F_JUST_ROBBER) != 0;
+    // "must respond / roll first / play out the card / steal first": the builds, the purchase, exchange, proposal, EndTurn
+    const bool blocked = respond || !rolled || use_dev || just;
+    switch (t) {
+    case T_SETTLE: {                                                       // :305-323
+        if (respond || (!rolled && !initial) || use_dev || just) return false;
+        if (!initial) {                                                    // can_buy_settlement :186-193
+            if (s.pb(pid, P_SLEFT) <= 0) return false;
+            if (!(s.res(pid, R_WHEAT) > 0 && s.res(pid, R_WOOD) > 0 && s.res(pid, R_BRICK) > 0 && s.res(pid, R_SHEEP) > 0)) return false;
+        }
+        if (a[1] < 0 || a[1] >= 54) return false;
+        Boards b;
+        load_boards(s, pid, b);
+        if (!((settle_spots(b, initial) >> a[1]) & 1)) return false;       // corner.py:24-39
+        if (initial) { const int k = s.pb(pid, P_ISET); return k == 0 || (k == 1 && s.pb(pid, P_IROAD) == 1); }
+        return true;
+    }
+    case T_ROAD: {                                                         // :324-357
+        const bool rb = (flags & F_RB_ACTIVE) != 0;
+        if (rb && a[2] == 72) return true;                                 // :325-328: the dummy edge, nothing else is looked at
+        if (!rb) {
+            if (respond || (!rolled && !initial) || use_dev || just) return false;
+            if (!initial && !(s.res(pid, R_WOOD) > 0 && s.res(pid, R_BRICK) > 0)) return false;   // can_buy_road :214-220
+        }
+        if (a[2] < 0 || a[2] >= 72) return false;                          // 72 without road building: `edges[None]` TypeError
+        Boards b;
+        load_boards(s, pid, b);
+        u64 lo; u32 hi;                                                    // edge.py:23-42 without after_second_settlement
+        topo_edges_at(b.own_bld | (topo_touched(b.own_rlo, b.own_rhi) & ~b.occ), lo, hi);
+        lo &= ~b.all_rlo; hi &= ~b.all_rhi & 0xFFu;
+        const int ed = a[2];
+        if (!(ed < 64 ? (lo >> ed) & 1 : (hi >> (ed - 64)) & 1)) return false;
+        if (rb || !initial) return true;
+        const int k = s.pb(pid, P_ISET), r = s.pb(pid, P_IROAD);
+        if (k == 1 && r == 0) return true;
+        if (k == 2 && r == 1) {                                            // :347-352: next to the second settlement
+            const int sc = s.pb(pid, P_ISECOND);
+            if (sc >= 54) return false;
+            u64 l2; u32 h2;
+            topo_edges_at(1ull << sc, l2, h2);
+            return ed < 64 ? (l2 >> ed) & 1 : (h2 >> (ed - 64)) & 1;
+        }
+        return false;
+    }
+    case T_CITY:                                                           // :358-376
+        if (blocked || initial) return false;
+        if (!(s.pb(pid, P_CLEFT) > 0 && s.res(pid, R_WHEAT) > 1 && s.res(pid, R_ORE) > 2)) return false;   // can_buy_city :234-238
+        if (a[1] < 0 || a[1] >= 54) return false;
+        return (s.settle(pid) >> a[1]) & 1;
+    case T_BUYDEV:                                                         // :377-393
+        if (blocked || initial) return false;
+        if (!(s.res(pid, R_WHEAT) > 0 && s.res(pid, R_SHEEP) > 0 && s.res(pid, R_ORE) > 0)) return false;
+        return s.b(B_PILE_LEN) > 0;
+    case T_PLAYDEV: {                                                      // :394-415: no look at the bank, the dice or the resource heads
+        if (respond || (flags & F_PLAYED_DEV) || initial || just) return false;
+        if (a[4] < 0 || a[4] > 4) return false;
+        const int k = s.pb(pid, P_HCNT + a[4]);
+        return k > 0 && k != s.b(B_BOUGHT + a[4]);                         // :403-406
+    }
+    case T_EXCHANGE: {                                                     // :416-443, wrapper.py:428-438
+        if (blocked || initial) return false;
+        const int hb = s.pb(pid, P_HARB);
+        const int rate = ((hb >> (a[15] + 1)) & 1) ? 2 : ((hb & 1) ? 3 : 4);
+        return s.res(pid, a[15]) >= rate && s.b(B_BANK + a[16]) > 0;
+    }
+    case T_PROPOSE: {                                                      // :444-466: no per-turn limit, an empty offer is fine
+        if (blocked || initial) return false;
 #pragma unroll
         for (int k = 0; k < 5; k++) if (s.res(pid, k) < cnt[k]) return false;
         return true;
     }
-    case T_RESPOND: return a[5] >= 0 && a[5] < 2 && bit(M5 + a[5]);
-    case T_STEAL: return a[6] >= 0 && a[6] < 3 && bit(M6 + 3 + a[6]);
-    case T_DISCARD: return a[17] >= 0 && a[17] < 5 && bit(M11 + a[17]);
-    default: return true;
+    case T_RESPOND: {                                                      // :467-482
+        if (!respond) return false;
+        if (a[5] == 1) return true;
+        const int tgt = s.b(B_TRADE_TGT), nr = s.b(B_TRADE_NR);
+        int need[5] = { 0, 0, 0, 0, 0 };
+        for (int i = 0; i < 4; i++) if (i < nr) {
+            const int r = s.b(B_TRADE_RECV + i) - 1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) need[k] += (k == r) ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (need[k] > s.res(tgt, k)) return false;
+        return true;
+    }
+    case T_ROBBER:                                                         // :483-490: ANY tile; tile >= 19: IndexError at game.py:624
+        if (respond || use_dev || !(flags & F_CAN_ROBBER)) return false;
+        return a[3] >= 0 && a[3] < 19;
+    case T_ROLL:                                                           // :491-500 (must_use_development_card_ability is not looked at)
+        return !(respond || initial || rolled || just);
+    case T_ENDTURN:                                                        // :501-512
+        return !(blocked || initial);
+    case T_STEAL: {                                                        // :513-525
+        if (respond || !just) return false;
+        const int victim = player_at_label(s.b(B_ORDER), s.b(B_SEATOF), pid, a[6]);
+        return ((s.settle(victim) | s.city(victim)) & topo_tile_corners(s.b(B_ROBBER))) != 0;
+    }
+    default: return false;
     }
 }
 
@@ -1587,7 +1681,7 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // masks - and the tile is written back once.  With 65 536 games there is exactly one wave per SIMD, so the launch
 // time is the dependent-latency chain of a single wave: LDS (~64 cycles) instead of HBM/L2 (~200-900 cycles) per hop.
 // actions: int32 [n][18]; reward: float [n][4] (index PlayerId-1); done: u8 [n]; err: [1] invalid-action
-// counter; mpk: packed masks [N][16], read for validation, rewritten with the masks of the new state.
+// counter; mpk: packed masks [N][16], rewritten with the masks of the new state (validation restates Game.validate_action from the state).
 // G = games per wave (64, 32 or 16; lanes >= G carry no game and only help with the row-wise transfers): with G < 64 there
 // are 64 / G waves per SIMD at 65 536 games, each with a tile of ROWS_HOT x (G + 1) words, so that one wave's transfers
 // overlap the others' dependent-instruction chains (with one wave per SIMD the HBM is idle while the step computes).
@@ -1633,20 +1727,19 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
     int a[ACTION_WORDS];
-    u32 m_in[MASK_WORDS];
     // what the wave's action type can touch (wave-uniform: sorted, padded bins): bitboards are written by settle / road /
     // city only; the estimates are read and written by the resource-moving types only
     const bool t_board = type == T_SETTLE || type == T_ROAD || type == T_CITY;
     const bool t_est = t_board || type == T_BUYDEV || bin == 12 + C_YOP || bin == 12 + C_MONO || type == T_EXCHANGE || type == T_RESPOND ||
                        type == T_ROLL || type == T_STEAL || type == T_DISCARD;
     const bool w_board = __ballot(type >= 0 && t_board) != 0, w_est = __ballot(type >= 0 && t_est) != 0;
-    if (w_est) stage_in_all<true, G>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
-    else stage_in_all<false, G>(tile, c.R, actions, mpk, type >= 0 ? (int)e : -1, lane, a, m_in);
+    if (w_est) stage_in_all<true, G>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a);
+    else stage_in_all<false, G>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a);
     __builtin_amdgcn_wave_barrier();
     StG s(tile + (lane < G ? lane : G - 1), c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
     bool rejected = false;
-    if (cfg.validate && type >= 0 && !action_legal(s, m_in, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
+    if (cfg.validate && type >= 0 && !action_valid(s, a)) { atomicAdd(err, 1u); type = -1; rejected = true; }
     if (rejected) {                                   // an illegal action leaves the game untouched (reward 0, not done)
         *reinterpret_cast<float4*>(reward + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cfg.reward64) { double2* r64 = reinterpret_cast<double2*>(cfg.reward64 + e * 4); r64[0] = make_double2(0.0, 0.0); r64[1] = make_double2(0.0, 0.0); }
@@ -1905,7 +1998,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         stop = false;
         for (int i = 0; i < 4; i++) { int v = a[11 + i]; if (v <= 0 || v > 5) stop = true; s.sb(B_TRADE_RECV + i, stop ? 0 : v); if (!stop) nr++; }
         s.sb(B_TRADE_NG, ng); s.sb(B_TRADE_NR, nr);
-        s.sb(B_TRADES, s.b(B_TRADES) + 1);
+        s.sb(B_TRADES, min(s.b(B_TRADES) + 1, 255));        // a byte: validate mode accepts proposals past the mask's limit (saturates)
         break;
     }
     case T_RESPOND: {                                                      // game.py:751-784

@@ -339,7 +339,7 @@ class EnvWrapper(object):
         reward, done = self.vec.step(torch.from_numpy(flat).view(1, spec.ACTION_WORDS))
         self._cache = None
         if self.validate_actions and self.vec.invalid_action_count() != bad0:
-            raise RuntimeError("invalid action (its legal-action mask bit is clear)")   # reference env/wrapper.py:38-41
+            raise RuntimeError("invalid action (Game.validate_action rejects it; game/game.py:264-525)")   # reference env/wrapper.py:38-41
         r = self.vec.reward64[0].cpu().numpy()
         rew = {pid: float(r[pid - 1]) for pid in (1, 2, 3, 4)}
         return self._get_obs(), rew, bool(done[0].item()), {"log": None}

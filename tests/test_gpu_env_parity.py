@@ -246,7 +246,9 @@ def test_full_size_lockstep_all_games_parity(oracle, hip_lib, dense):
 
 def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
     """SURVEY a4 (Game.validate_action, game/game.py:264-525, env/wrapper.py:38-41): random LEGAL and ILLEGAL 18-word actions
-    on 4 096 games of mixed ages -> the HIP path accepts exactly the actions `orc_action_is_legal` accepts; a rejected
+    on 4 096 games of mixed ages -> the HIP path accepts exactly the actions `orc_action_is_legal` accepts (the oracle's
+    restatement of validate_action, itself pinned to the reference by tests/golden/validate_cases.npz and
+    tools/fuzz_validate_vs_ref.py; NOT "mask bit set": some accepted actions are outside every mask); a rejected
     action leaves the game untouched (state, masks), pays no reward, is counted; the accepted ones advance the games exactly as
     the oracle does.  Corruptions: another action type, and / or random values (in and out of range) in the sub-heads."""
     import ctypes as C
@@ -258,7 +260,7 @@ def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
     ob.run_random(300, want_blobs=False)
     rng = np.random.default_rng(99)
     hi = np.array([13, 54, 73, 19, 5, 2, 3, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5])          # exclusive upper bound of every action word
-    rejected_total, accepted_total, legal_after_corruption = 0, 0, 0
+    rejected_total, accepted_total, legal_after_corruption, out_of_mask = 0, 0, 0, 0
     i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
     for rnd in range(24):
         a = env.sample_random_actions(300 + rnd).cpu().numpy().astype(np.int32)
@@ -277,6 +279,7 @@ def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
             e, ai = ob.env_ptr(i), np.ascontiguousarray(a[i])
             want_ok[i] = bool(ob.L.orc_action_is_legal(e, ai.ctypes.data_as(i32p)))
             if want_ok[i]:
+                out_of_mask += int(ai[0] != 6 and not ob.L.orc_action_in_masks(e, ai.ctypes.data_as(i32p)))
                 d = C.c_int(0)
                 ob.L.orc_step(e, ai.ctypes.data_as(i32p), orew[i].ctypes.data_as(f32p), C.byref(d))
                 odone[i] = bool(d.value)
@@ -297,3 +300,4 @@ def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
         assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks()), rnd
         rejected_total += n_rej; accepted_total += int(want_ok.sum())
     assert rejected_total > 20000 and accepted_total > 20000 and legal_after_corruption > 500, (rejected_total, accepted_total, legal_after_corruption)
+    assert out_of_mask > 100, out_of_mask          # accepted AND applied although no mask offers them (MoveRobber onto an empty tile, ...)

@@ -106,3 +106,69 @@ def test_randomise_uncertainty_golden_and_oracle(oracle, hip_lib):
     assert len(bad) == 0, f"{len(bad)} games differ; game {bad[0]} ctrl {ctrl[bad[0]]}:\n" + spec.describe_state_diff(want[bad[0]], out[bad[0]])
     assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
     assert env.inconsistent_deal_count() == 0
+
+
+def test_validate_cases_vs_reference(hip_lib):
+    """SURVEY a4 on the device - validate mode against the REFERENCE's own verdicts (tests/golden/validate_cases.npz, generated
+    by tools/gen_golden.py from `_translate_action` + `Game.validate_action`, game/game.py:264-525): 8 800 probe actions in 720
+    reference states; the HIP step must accept exactly what the reference accepts - incl. the ~500 actions NO mask offers
+    (MoveRobber onto an empty tile, ProposeTrade past the limit, RollDice during road building, the dummy edge, ...) - leave
+    rejected games untouched, and for every accepted probe end in the reference's state / masks / rewards / done."""
+    import torch
+    g = {k: v for k, v in gu.load("validate_cases.npz").items()}
+    acc, inm = g["case_accept"].astype(bool), g["case_in_masks"].astype(bool)
+    assert len(acc) > 8000 and (acc & ~inm).sum() > 400
+    blob_at = {int(c): k for k, c in enumerate(g["post_blob_case"])}
+    st_of = g["case_state"]
+    groups = {}
+    for c in range(len(acc)):
+        si = int(st_of[c])
+        groups.setdefault((int(g["state_trades"][si]), int(g["state_max_actions"][si]), int(g["state_seed"][si]), int(g["state_env"][si])), []).append(c)
+    assert len(groups) == 4
+    checked_oom = 0
+    for (tr, ma, seed, env_id), cases in groups.items():
+        kw = dict(max_proposed_trades_per_turn=None if tr < 0 else tr, max_actions_per_turn=None if ma < 0 else ma, auto_reset=False)
+        cases = np.array(cases)
+        draws = acc[cases] & np.isin(g["case_action"][cases, 0], (9, 11))          # RollDice / StealResource draw from the game's stream
+        # (1) everything that draws nothing: one game per case
+        batch = cases[~draws]
+        env = _env(len(batch), seed, env_id0=env_id, **kw)
+        r64 = env.enable_reward64()
+        before = g["states"][st_of[batch]].astype(np.int32)
+        env.import_state(before)
+        rew, done = env.step(torch.from_numpy(g["case_action"][batch].astype(np.int32)))
+        assert env.invalid_action_count() == int((~acc[batch]).sum())
+        after = env.export_state().cpu().numpy()
+        masks = env.get_action_masks().cpu().numpy()
+        decide = env.deciding_player().cpu().numpy()
+        rew64, done = r64.cpu().numpy(), done.cpu().numpy().astype(bool)
+        for j, c in enumerate(batch):
+            a = g["case_action"][c].tolist()
+            if not acc[c]:
+                assert np.array_equal(after[j], before[j]), f"case {c} {a}: a rejected action changed the game\n" + spec.describe_state_diff(before[j], after[j])
+                assert not rew64[j].any() and not done[j], c
+                continue
+            if c in blob_at:
+                want = g["post_blobs"][blob_at[c]].astype(np.int32)
+                assert np.array_equal(after[j], want), f"case {c} {a}:\n" + spec.describe_state_diff(want, after[j])
+                checked_oom += 1
+            assert gu.crc(after[j]) == int(g["post_crc"][c]), (c, a)
+            assert np.array_equal(masks[j], gu.unpack_masks(g["post_masks"][c])), (c, a)
+            assert np.array_equal(rew64[j], g["post_reward64"][c]) and done[j] == bool(g["post_done"][c]), (c, a)
+            assert int(decide[j]) == int(g["post_deciding"][c]), (c, a)
+        # (2) the accepted dice rolls and steals, on the game whose Philox stream the reference used
+        one = _env(1, seed, env_id0=env_id, **kw)
+        r64 = one.enable_reward64()
+        for c in cases[draws]:
+            one.import_state(g["states"][st_of[c]].astype(np.int32)[None])
+            _, done = one.step(torch.from_numpy(g["case_action"][c].astype(np.int32))[None])
+            post = one.export_state()[0].cpu().numpy()
+            if c in blob_at:
+                want = g["post_blobs"][blob_at[c]].astype(np.int32)
+                assert np.array_equal(post, want), f"case {c}:\n" + spec.describe_state_diff(want, post)
+                checked_oom += 1
+            assert gu.crc(post) == int(g["post_crc"][c]), c
+            assert np.array_equal(one.get_action_masks()[0].cpu().numpy(), gu.unpack_masks(g["post_masks"][c])), c
+            assert np.array_equal(r64[0].cpu().numpy(), g["post_reward64"][c]) and bool(done[0].item()) == bool(g["post_done"][c]), c
+        assert one.invalid_action_count() == 0
+    assert checked_oom > 400

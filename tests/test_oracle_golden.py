@@ -176,3 +176,38 @@ def test_randomise_uncertainty_golden(oracle):
         e.randomise_uncertainty(int(ctrl))
         out = e.export()
         assert np.array_equal(out, after), spec.describe_state_diff(after, out)
+
+
+def test_validate_cases(oracle):
+    """SURVEY a4 - validate mode = `_translate_action` + `Game.validate_action` (game/game.py:264-525), the wrapper's default
+    (env/wrapper.py:13,38-41): the reference's own accept / reject on 8 800 probe actions (all 13 types; in-range, out-of-range,
+    targeted) in 720 of its states, and - for every accepted probe, incl. the ~500 that NO mask offers (MoveRobber onto an
+    empty tile, ProposeTrade past the limit, RollDice during road building, the dummy edge, ...) - its state / masks / rewards /
+    done afterwards."""
+    g = {k: v for k, v in gu.load("validate_cases.npz").items()}       # (an NpzFile decompresses on every access)
+    acc, inm = g["case_accept"].astype(bool), g["case_in_masks"].astype(bool)
+    assert len(acc) > 8000 and (acc & ~inm).sum() > 400 and (~acc).sum() > 4000
+    blob_at = {int(c): k for k, c in enumerate(g["post_blob_case"])}
+    for c in range(len(acc)):
+        si = int(g["case_state"][c])
+        tr, ma = int(g["state_trades"][si]), int(g["state_max_actions"][si])
+        e = oracle.OracleEnv(int(g["state_seed"][si]), int(g["state_env"][si]))
+        e.set_config(max_trades_per_turn=None if tr < 0 else tr, max_actions_per_turn=None if ma < 0 else ma)
+        e.import_(g["states"][si].astype(np.int32))
+        a = g["case_action"][c]
+        assert e.is_legal(a) == bool(acc[c]), (c, a.tolist(), bool(acc[c]))
+        ai = np.ascontiguousarray(a, dtype=np.int32)
+        in_masks = bool(e.L.orc_action_in_masks(e.p, oracle._p(ai, oracle.C.c_int32)))
+        if int(a[0]) != 6:
+            assert in_masks == bool(inm[c]), (c, a.tolist())
+        if not acc[c]:
+            continue
+        rew, done = e.step(a)
+        post = e.export()
+        if c in blob_at:
+            want = g["post_blobs"][blob_at[c]].astype(np.int32)
+            assert np.array_equal(post, want), f"case {c} {a.tolist()}:\n" + spec.describe_state_diff(want, post)
+        assert gu.crc(post) == int(g["post_crc"][c]), (c, a.tolist())
+        assert np.array_equal(e.masks(), gu.unpack_masks(g["post_masks"][c])), c
+        assert np.array_equal(e.last_reward64(), g["post_reward64"][c]) and done == bool(g["post_done"][c]), c
+        assert e.deciding_player() == int(g["post_deciding"][c]), c

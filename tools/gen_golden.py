@@ -10,6 +10,8 @@
                       actions + crc32 of the state at every step (config 1 known-answer test for the oracle MT mode)
   longest_road.npz    (edge_owner, corner_owner, player) -> Game.get_longest_path, harvested from play + adversarial
   gae_ppo.npz         BatchProcessor GAE / PPO loss values computed with the reference's torch code
+  validate_cases.npz  validate mode (Game.validate_action): states x probe actions -> the reference's accept / reject and,
+                      for accepted ones, its state crc / masks / rewards / done afterwards (incl. actions outside the masks)
 """
 import os
 import sys
@@ -733,6 +735,105 @@ def gen_forward_search(n_ucb_roots=3):
             "bytes": os.path.getsize(os.path.join(OUT, "forward_search.npz"))}
 
 
+def _in_masks(masks, a):
+    """would a policy that samples every head from the reference's masks ever emit `a`? (the head -> mask-row rules of
+    RL/models/build_agent_model.py:113-127; heads 6 row 0, 7 and 8 are all ones: the give list is checked against the hand)"""
+    m = [np.asarray(x) for x in masks]
+    t = int(a[0])
+    if not (0 <= t <= 12) or m[0][t] <= 0:
+        return False
+
+    def ok(row, i, n):
+        return 0 <= int(i) < n and row[int(i)] > 0
+    if t == 0: return ok(m[1][0], a[1], 54)
+    if t == 2: return ok(m[1][1], a[1], 54)
+    if t == 1: return ok(m[2], a[2], 73)
+    if t == 8: return ok(m[3], a[3], 19)
+    if t == 4:
+        if not ok(m[4], a[4], 5): return False
+        if a[4] == 4: return ok(m[9][2], a[15], 5)
+        if a[4] == 2: return ok(m[9][3], a[15], 5) and ok(m[10], a[16], 5)
+        return True
+    if t == 5: return ok(m[9][0], a[15], 5) and ok(m[10], a[16], 5)
+    if t == 7: return ok(m[5], a[5], 2)
+    if t == 11: return ok(m[6][1], a[6], 3)
+    if t == 12: return ok(m[11], a[17], 5)
+    return True      # types without sub-heads; ProposeTrade's lists are left to the verdict itself
+
+
+def gen_validate_cases(seed=61, n_states=720, every=31):
+    """validate_cases.npz - SURVEY a4: `EnvWrapper.step` with validate_actions=True (the default; env/wrapper.py:36-42) =
+    `_translate_action` + `Game.validate_action` (game/game.py:264-525) + `apply_action`.  States are harvested from reference
+    games in which some steps are ACCEPTED OUT-OF-MASK actions (so the states only those reach are present); per state a
+    set of probe actions (tools/fuzz_validate_vs_ref.py: sampled, random, perturbed, out-of-range, targeted) with the
+    reference's verdict and, for every accepted probe, what the reference's state / masks / rewards / done look like after
+    it.  Two wrapper configurations: the defaults, and (max_proposed_trades_per_turn=None, max_actions_per_turn=6)."""
+    import fuzz_validate_vs_ref as fv
+    states, st_trades, st_maxact, st_seed, st_env = [], [], [], [], []
+    c_state, c_action, c_accept, c_inmask, c_kind = [], [], [], [], []
+    p_crc, p_masks, p_rew64, p_done, p_decide, p_blob_idx, p_blobs = [], [], [], [], [], [], []
+    kinds = ["sampled", "random", "perturbed", "out_of_range", "robber_any_tile", "roll_in_road_building", "dummy_edge",
+             "propose", "end_turn", "play_owned_card"]
+    for cfg_i, (trades, max_actions) in enumerate([(4, None), (None, 6)]):
+        for env_id in range(2):
+            rng = np.random.default_rng(seed * 1009 + cfg_i * 17 + env_id)
+            ref = rh.RefEnv(seed, 10 * cfg_i + env_id, max_proposed_trades_per_turn=trades, max_actions_per_turn=max_actions)
+            ref.reset()
+            t = 0
+            while sum(1 for x in st_env if x == 10 * cfg_i + env_id) < n_states // 4:
+                base = rh.random_legal_action(ref.masks(), ref.env, rng)
+                probes = fv.probes_for(rng, base, 4, ref)
+                verdicts = [fv.ref_verdict(ref, a) for _, a in probes]
+                masks_now = ref.masks()
+                # kept: states right after an out-of-mask step, states with an accepted out-of-mask probe, and every `every`-th one
+                has_exotic = any(v and not _in_masks(masks_now, a) for (_, a), v in zip(probes, verdicts))
+                if t % every == 0 or getattr(ref, "_exotic", False) or has_exotic:
+                    si = len(states)
+                    blob = ref.state_blob()
+                    states.append(blob); st_trades.append(-1 if trades is None else trades)
+                    st_maxact.append(-1 if max_actions is None else max_actions); st_seed.append(seed); st_env.append(10 * cfg_i + env_id)
+                    for (kind, a), v in zip(probes, verdicts):
+                        c_state.append(si); c_action.append(a.astype(np.int32)); c_accept.append(int(v))
+                        c_inmask.append(int(_in_masks(masks_now, a) and (v or int(a[0]) != 6))); c_kind.append(kinds.index(kind))   # ProposeTrade: the give list must be owned
+                        if v:
+                            cp = ref.clone()
+                            _, rew, done = cp.step(a)
+                            pb = cp.state_blob()
+                            p_crc.append(crc(pb)); p_masks.append(pack_masks(rh.masks_flat(cp.masks())))
+                            p_rew64.append(cp.last_reward64.copy()); p_done.append(int(done)); p_decide.append(cp.deciding_player())
+                            if not c_inmask[-1]:
+                                p_blob_idx.append(len(c_state) - 1); p_blobs.append(pb)
+                            assert np.array_equal(ref.state_blob(), blob)
+                        else:
+                            p_crc.append(0); p_masks.append(np.zeros(41, dtype=np.uint8)); p_rew64.append(np.zeros(4)); p_done.append(0); p_decide.append(0)
+                # the game's real step: now and then an accepted action from outside the masks
+                exotic = [a for (k, a), v in zip(probes, verdicts) if v and not _in_masks(masks_now, a)]
+                ref._exotic = False
+                a = base
+                if exotic and rng.random() < 0.35:
+                    a = exotic[int(rng.integers(0, len(exotic)))]
+                    ref._exotic = True
+                _, _, done = ref.step(a)
+                if done:
+                    ref.reset()
+                t += 1
+    c_accept = np.array(c_accept, dtype=np.uint8); c_inmask = np.array(c_inmask, dtype=np.uint8)
+    assert not (c_inmask & (1 - c_accept)).any(), "an in-mask action the reference rejects"
+    np.savez_compressed(
+        os.path.join(OUT, "validate_cases.npz"), kinds=np.array(kinds),
+        states=np.array(states, dtype=np.int16), state_trades=np.array(st_trades, dtype=np.int8), state_max_actions=np.array(st_maxact, dtype=np.int8),
+        state_seed=np.array(st_seed, dtype=np.int32), state_env=np.array(st_env, dtype=np.int32),
+        case_state=np.array(c_state, dtype=np.int32), case_action=np.array(c_action, dtype=np.int32), case_accept=c_accept,
+        case_in_masks=c_inmask, case_kind=np.array(c_kind, dtype=np.uint8),
+        post_crc=np.array(p_crc, dtype=np.uint32), post_masks=np.array(p_masks, dtype=np.uint8), post_reward64=np.array(p_rew64, dtype=np.float64),
+        post_done=np.array(p_done, dtype=np.uint8), post_deciding=np.array(p_decide, dtype=np.int8),
+        post_blob_case=np.array(p_blob_idx, dtype=np.int32), post_blobs=np.array(p_blobs, dtype=np.int16))
+    oom = (c_accept == 1) & (c_inmask == 0)
+    ca = np.array(c_action)
+    return dict(states=len(states), cases=len(c_state), accepted=int(c_accept.sum()), accepted_out_of_mask=int(oom.sum()),
+                out_of_mask_by_type={int(t): int(((ca[:, 0] == t) & oom).sum()) for t in range(13) if ((ca[:, 0] == t) & oom).any()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rollout":
         print("rollout_small (games complete, pre-advance, first-game lengths):", gen_rollout_small()); sys.exit(0)
@@ -753,6 +854,8 @@ if __name__ == "__main__":
         print("policy_small", gen_policy_small()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gae_ppo":
         gen_gae_ppo(); print("gae/ppo"); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "validate":
+        print("validate_cases", gen_validate_cases()); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "league":
         gen_league(); print("league"); sys.exit(0)
     gen_topology(); print("topology")
@@ -771,4 +874,5 @@ if __name__ == "__main__":
     print("eval_small", gen_eval_small())
     print("policy_small", gen_policy_small())
     print("forward_search", gen_forward_search())
+    print("validate_cases", gen_validate_cases())
     os.system(f"ls -la {OUT}; du -sh {OUT}")

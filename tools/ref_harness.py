@@ -131,6 +131,17 @@ class RefEnv(object):
             self.last_obs = self.env.reset()
         return self.last_obs
 
+    def clone(self):
+        """an independent copy (deep copy of the whole wrapper: the reference's own restore_state leaves e.g. a harbour
+        gained since the save in place, game.py:1093-1205, so it cannot serve as an undo)"""
+        import copy
+        c = RefEnv.__new__(RefEnv)
+        c.env = copy.deepcopy(self.env)
+        c.stream = PhiloxStream(0, 0)
+        c.stream.key, c.stream.env, c.stream.stream, c.stream.draws = self.stream.key, self.stream.env, self.stream.stream, self.stream.draws
+        c.last_obs = self.last_obs
+        return c
+
     def masks(self):
         return self.env.get_action_masks()
 
