@@ -438,7 +438,8 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     u32* bins = e->pend.ctr + 16 + NBINS * e->pend.bsel;
     if (!have_hist) {                                     // (the rollout loops sort inside k_sample_random)
-        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists, e->pend.ctr + 4, 12);
+        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists, e->pend.ctr + 4, 12,
+                           sc.validate ? e->err : (u32*)nullptr);
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
     }
     switch (e->step_games) {

@@ -2418,13 +2418,17 @@ DEVI void sort_append(long e, bool valid, int bin, u32* hist, u32* base, u32* __
     if (valid) lists[(long)bin * N + base[bin] + rank] = (i32)e;
 }
 // the sort for caller-supplied actions (catan_step); the rollout loops do it inside k_sample_random
+// err (validate mode, else null): an action type above 12 is an invalid action (no branch of validate_action matches,
+// game/game.py:264-525) - counted here, the game then sits in the no-op bin; a NEGATIVE type is the C ABI's explicit no-op
+// (a frozen game of a rollout), not an error.
 __global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict__ actions, u32* __restrict__ bins, i32* __restrict__ lists,
-                                                    u32* __restrict__ zero_me, int zero_n) {
+                                                    u32* __restrict__ zero_me, int zero_n, u32* __restrict__ err) {
     __shared__ u32 hist[NBINS], base[NBINS];
     if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (zero_me != nullptr && e < zero_n) zero_me[e] = 0;
+    if (err != nullptr && e < c.n && actions[e * ACTION_WORDS] > 12) atomicAdd(err, 1u);
     sort_append(e, e < c.n, e < c.n ? action_bin(c, actions, e) : BIN_NOOP, hist, base, bins, lists, c.N);
 }
 constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
