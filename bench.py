@@ -174,6 +174,8 @@ def ppo_update_record(env, n, rank, world, T, cdist):
             "minibatch_rows": n * T // tr.cfg.num_mini_batch, "active_seat_decisions_per_update": dec,
             "rollout_s": rollout_s, "update_s": update_s, "env_passes_in_rollout": col.iters, **tr.timings,
             "decisions_per_s": dec / (rollout_s + update_s), "dtype": "bf16 autocast, fp32 master weights",
+            # world > 1: the flat 7.7 MB gradient bucket, one RCCL all-reduce (ReduceOp.AVG) per optimiser step, timed with events
+            "allreduce_s_per_step": (tr.timings["allreduce_s"] / (tr.cfg.ppo_epoch * tr.cfg.num_mini_batch) if "allreduce_s" in tr.timings else None),
             "losses": {"value": vl, "action": al, "entropy": el},
             "first_update": first, "warmup_updates": warm,
             "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 2 ** 30,
@@ -250,6 +252,7 @@ def main():
         env_steps = world * my_steps
     timed_passes = args.steps * reps
     bad = env.invalid_action_count()
+    devices = cdist.device_identities()                       # (a collective: every rank calls it)
 
     lockstep = None
     if args.window > 0 and not args.no_lockstep:
@@ -340,8 +343,11 @@ def main():
             "timed_s": dt, "preroll_passes": max(args.preroll, 64), "ms_per_step": dt / timed_passes * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 (integer bitboards)",
             "data": "synthetic (random-seed boards, uniform-random legal policy on device)",
-            "config": {"workload": "configs[1]: 65 536 parallel envs per GPU, random policy, step+mask only, "
-                                   "bit-exact vs CPU oracle", "games_per_gpu": n, "validate_actions": not args.no_validate,
+            "config": {"workload": ("configs[1]: 65 536 parallel envs per GPU, random policy, step+mask only, bit-exact vs CPU oracle" if world == 1 else
+                                    f"configs[3]: {world * n} envs sharded across {world} x MI355X ({n} per GPU, global game ids), PPO with one flat "
+                                    f"gradient all-reduce per optimiser step (`ppo_update`); `value` = configs[1]'s random-policy step+mask rate "
+                                    f"summed over the {world} shards"),
+                       "games_per_gpu": n, "games_total": world * n, "validate_actions": not args.no_validate,
                        "auto_reset": True, "parallelism": f"games sharded over {world} GPU(s), no collective",
                        "schedule": (f"deferred, window {args.window}: slow-path games sit out; value = executed env steps / time"
                                     if args.window > 0 else "lock-step: every game steps in every pass"),
@@ -349,6 +355,9 @@ def main():
                                        f"untimed pre-roll passes + --warmup"},
             "env_steps_executed": env_steps, "active_fraction": env_steps / (world * n * timed_passes),
             "invalid_actions": bad,
+            # who ran: one record per rank (all-gathered), the collective backend the learner's all-reduce uses
+            "world": world, "backend": (torch.distributed.get_backend() if world > 1 else None), "ranks": devices,
+            "distinct_devices": len({(d["host"], d["uuid"] or d["pci_bus_id"] or d["device"]) for d in devices}),
             "roofline": roofline,
         }
         if lockstep is not None:

@@ -62,6 +62,37 @@ def sum_over_ranks(value, device=None):
     return _reduce(value, dist.ReduceOp.SUM, device)
 
 
+def allreduce_mean_(flat, group=None):
+    """In-place mean over the ranks of `group`.  RCCL (backend "nccl") averages inside the collective (ReduceOp.AVG: one launch,
+    no separate divide pass over the bucket); gloo has no AVG, so the CPU test-suite takes sum + divide."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, group=group)
+        flat /= dist.get_world_size(group)
+
+
+def device_identities():
+    """One record per rank - host, local device index, the device's name, UUID / PCI bus id - all-gathered, so that a bench
+    line can SHOW that N ranks ran on N distinct GPUs (and over which backend)."""
+    import socket
+    me = {"rank": int(os.environ.get("RANK", "0")), "host": socket.gethostname(), "device": None, "name": None, "uuid": None, "pci_bus_id": None}
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        me.update(device=i, name=pr.name)
+        for key in ("uuid", "pci_bus_id"):
+            try:
+                me[key] = str(getattr(pr, key))
+            except Exception:
+                pass
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
+
+
 class GradBucket(object):
     """One persistent flat gradient buffer for a FIXED parameter list (1.93 M parameters = 7.7 MB fp32: a single bucket;
     xGMI rings are per-link bound, so one large message beats many small ones).
@@ -116,8 +147,7 @@ class GradBucket(object):
         if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
             return
         self.check()
-        dist.all_reduce(self.flat, group=self.group)
-        self.flat /= dist.get_world_size(self.group)
+        allreduce_mean_(self.flat, self.group)
 
 
 def allreduce_flat_grads(params, world=None):
@@ -130,8 +160,11 @@ def allreduce_flat_grads(params, world=None):
     if not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size() if world is None else world
+    if world is None or world == dist.get_world_size():
+        allreduce_mean_(flat)
+    else:
+        dist.all_reduce(flat)
+        flat /= world
     off = 0
     for p in params:
         n = p.numel()

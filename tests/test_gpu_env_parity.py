@@ -301,3 +301,34 @@ def test_validate_mode_accepts_and_rejects_like_the_oracle(oracle, hip_lib):
         rejected_total += n_rej; accepted_total += int(want_ok.sum())
     assert rejected_total > 20000 and accepted_total > 20000 and legal_after_corruption > 500, (rejected_total, accepted_total, legal_after_corruption)
     assert out_of_mask > 100, out_of_mask          # accepted AND applied although no mask offers them (MoveRobber onto an empty tile, ...)
+
+
+def test_shard_invariance_through_work(hip_lib):
+    """games are partitioned by GLOBAL game id and nothing else is shared, so 8 shards of 8 192 games
+    (`env_id0 = 8 192 r`, what rank r of an 8-GPU job holds) must be, game for game, the one 65 536-game env - not just after
+    reset but after WORK: 600 lock-step random-policy steps (auto-reset, slow path, speculative re-deals) and then a deferred
+    rollout of 1 536 passes (window 32: busy games, tier-2 windows), state blobs, masks and per-game decision counters."""
+    import torch
+    seed, n, shards = 17, 65536, 8
+    per = n // shards
+    whole = _env(n, seed)
+    whole.random_rollout(0, 600)
+    parts = []
+    for r in range(shards):
+        e = _env(per, seed, env_id0=per * r)
+        e.random_rollout(0, 600)
+        parts.append(e)
+    got = torch.cat([e.export_state() for e in parts]).cpu().numpy()
+    _assert_blobs_equal(got, whole.export_state().cpu().numpy(), "8 x 8 192 games vs 65 536 after 600 lock-step steps")
+    assert torch.equal(torch.cat([e.get_action_masks() for e in parts]), whole.get_action_masks())
+    whole.set_policy_counters(); whole.random_rollout_deferred(1536, 32)
+    for e in parts:
+        e.set_policy_counters(); e.random_rollout_deferred(1536, 32)
+    cw = whole.policy_counters().cpu().numpy()
+    cp = torch.cat([e.policy_counters() for e in parts]).cpu().numpy()
+    assert np.array_equal(cp, cw), f"{int((cp != cw).sum())} games took a different number of decisions in their shard"
+    assert 0.85 * 1536 < cw.mean() < 1536
+    got = torch.cat([e.export_state() for e in parts]).cpu().numpy()
+    _assert_blobs_equal(got, whole.export_state().cpu().numpy(), "8 x 8 192 games vs 65 536 after a deferred rollout")
+    assert torch.equal(torch.cat([e.get_action_masks() for e in parts]), whole.get_action_masks())
+    assert whole.invalid_action_count() == 0 and all(e.invalid_action_count() == 0 for e in parts)

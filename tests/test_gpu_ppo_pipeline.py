@@ -262,6 +262,71 @@ def test_rollout_with_league_opponents(hip_lib):
     assert torch.allclose(lp[:, 0], st.action_log_probs.reshape(T * N), atol=2e-4)
 
 
+def test_league_reference_draws_on_device(hip_lib):
+    """SURVEY f2 on the device, against the REFERENCE's draws (tests/golden/league.npz = `update_opponent_policies` run on a
+    fake manager, RL/ppo/update_opponent_policies.py:13-43): League.sample / League.assign on a real collector give every
+    worker (group of 5 games) exactly the three snapshots the reference gave that process, policy slot by policy slot; then
+    the collector's GROUPED inference (one batched forward per distinct net in play) on real observations equals PER-NET
+    inference: the (action, log-prob) of every game is what the net the reference assigned to the deciding seat produces for
+    that row - and not what the central policy would."""
+    import golden_util as gu
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    from settlers_of_catan_rl_amd.league import League, get_prob_dist
+    g = gu.load("league.npz")
+    for n in g["sizes"]:
+        assert np.allclose(get_prob_dist(int(n)), g[f"p_{int(n)}"], rtol=0, atol=1e-15)
+    seed, nproc, npol = 0, 7, 40
+    want = g[f"draw_{seed}_{nproc}_{npol}"]                          # [process][policy slot - 1] -> snapshot id
+    torch.manual_seed(4)
+    N = nproc * 5
+    env = VecCatanEnv(N, seed=13)
+    env.random_rollout(0, 400)
+    base = CatanPolicy().cuda()
+    lg = League(envs_per_worker=5, seed=seed)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    sd0 = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    for k in range(npol):                                            # 40 distinct snapshots (the deque keeps CPU copies)
+        with torch.no_grad():
+            for name, p in base.named_parameters():
+                p.copy_(sd0[name] + 0.02 * (k + 1) * torch.randn(p.shape, device="cuda", generator=gen))
+        lg.add(base)
+    base.load_state_dict(sd0)
+    col = RolloutCollector(env, base, 4, seed=3)
+    distinct = lg.assign(col, lambda: CatanPolicy().cuda())
+    assert np.array_equal(distinct, np.unique(want))
+    per_game = distinct[col.opp_index.cpu().numpy()]                 # snapshot id per (game, opponent slot)
+    assert np.array_equal(per_game, np.repeat(want, 5, axis=0)), "a worker's games must share the three snapshots the reference drew for it"
+    # grouped inference == per-net inference on those groups
+    f, lists, lens = env.get_obs()
+    masks = env.get_action_masks()
+    deciding = env.deciding_player().long()
+    pol = col.policy_of_pid[torch.arange(N, device="cuda"), deciding - 1]
+    assert int((pol > 0).sum()) > N // 3 and int((pol == 0).sum()) > 0
+    actions, logp = col._act(f, lists, lens, masks, pol)
+    nets = {}
+    checked_other = 0
+    for i in range(N):
+        slot = int(pol[i])
+        sid = -1 if slot == 0 else int(per_game[i, slot - 1])
+        if sid not in nets:
+            net = base
+            if sid >= 0:
+                net = CatanPolicy().cuda().eval()
+                net.load_state_dict(lg.earlier[sid])
+            nets[sid] = net
+        row = (f[i:i + 1].float(), lists[i:i + 1], lens[i:i + 1].long(), masks[i:i + 1], actions[i:i + 1])
+        with torch.no_grad():
+            lp = nets[sid].evaluate_actions(*row)[1]
+            assert abs(float(lp) - float(logp[i])) < 2e-4, (i, slot, sid, float(lp), float(logp[i]))
+            if sid >= 0:
+                other = base.evaluate_actions(*row)[1]
+                checked_other += int(abs(float(other) - float(logp[i])) > 1e-3)
+    assert checked_other > (N // 3) // 2, checked_other              # the routing matters: the central net scores those rows differently
+    assert env.invalid_action_count() == 0
+
+
 def test_evaluation_protocol_on_device(hip_lib):
     """run_evaluation_protocol on the HIP env (two random-init nets, sampled actions, the offline evaluator's draw cap to
     bound the run): every action legal, statistics well-formed, capped games reported as draws."""
