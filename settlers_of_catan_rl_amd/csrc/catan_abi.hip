@@ -296,6 +296,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.ctr, CTR_WORDS * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[0], (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[1], (size_t)e->N * sizeof(u64));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.req[2], (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->f_done, (size_t)e->n);
     // HIP multiplexes streams onto 4 hardware queues; streams that share a queue serialise.  Caller's stream + side +
@@ -318,7 +319,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.lists, (size_t)NBINS * e->N * sizeof(i32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.lists, (size_t)3 * NBINS * e->N * sizeof(i32));   // three sets (fused-sampling rollouts)
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, EV_SYNC);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
@@ -343,7 +344,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
-    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1;
+    HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
     e->ctx.key0 = (u32)seed; e->ctx.key1 = (u32)(seed >> 32);
@@ -370,6 +372,7 @@ void catan_destroy(catan_env_t* e) {
     if (e->pend.ctr) hipFree(e->pend.ctr);
     if (e->pend.req[0]) hipFree(e->pend.req[0]);
     if (e->pend.req[1]) hipFree(e->pend.req[1]);
+    if (e->pend.req[2]) hipFree(e->pend.req[2]);
     if (e->f_reward) hipFree(e->f_reward);
     if (e->f_done) hipFree(e->f_done);
     if (e->fstream[0]) hipStreamDestroy(e->fstream[0]);
@@ -438,9 +441,15 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     u32* bins = e->pend.ctr + 16 + NBINS * e->pend.bsel;
     if (!have_hist) {                                     // (the rollout loops sort inside k_sample_random)
-        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists, e->pend.ctr + 4, 12,
-                           sc.validate ? e->err : (u32*)nullptr);
+        hipLaunchKernelGGL(k_classify, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, bins, e->pend.lists + (size_t)e->pend.bsel * NBINS * e->N,
+                           e->pend.ctr + 4, 12, sc.validate ? e->err : (u32*)nullptr);
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    }
+    if (e->pend.sample) {                                 // fused-sampling rollouts: actions from / to the side rows (64 games per wave)
+        hipLaunchKernelGGL((k_step<64, true>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        HIPCHK(hipGetLastError());
+        return CATAN_OK;
     }
     switch (e->step_games) {
     case 16: hipLaunchKernelGGL(k_step<16>, dim3(blocks(e->N, 16) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
@@ -455,7 +464,9 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
 static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    static const int grid_env = getenv("CATAN_LR_GRID") ? atoi(getenv("CATAN_LR_GRID")) : 0;       // (diagnostics)
+    const int grid = grid_env > 0 ? grid_env : LR_GRID;
+    hipLaunchKernelGGL(k_lr_finish, dim3(grid), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on != 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -480,7 +491,7 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
             HIPCHK(hipEventRecord(e->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
             hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 1),
-                               (const i32*)e->pend.resets[sa][0], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u);
+                               (const i32*)e->pend.resets[sa][0], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u, e->pend);
             HIPCHK(hipEventRecord(e->ev_join, e->side));
         }
     }
@@ -499,7 +510,7 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
         } else {
             HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
             hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, st, e->ctx, e->mpk, max_trades, (const u32*)(sctr + 2),
-                               (const i32*)e->pend.resets[sa][1], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u);
+                               (const i32*)e->pend.resets[sa][1], busy, sc.prof, (const u32*)nullptr, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr, 0u, e->pend);
         }
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
@@ -510,15 +521,16 @@ constexpr int EV_PER_STEP = 10;
 // sample_step != nullptr: the random policy draws the actions first (into `actions`), fused with the sort's histogram
 static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr,
                      const uint32_t* sample_step = nullptr) {
-    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.brel = -1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     // the step's first kernel zeroes the slow-path list counters (ctr[4..15]) and k_step the count set of the NEXT sort, so a
     // memset is only needed after anything else used the counters (creation, a deferred rollout)
     if (!e->ctr_clean) { HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st)); e->ctr_clean = 1; e->lock_parity = 0; }
-    e->pend.bsel = e->lock_parity; e->lock_parity ^= 1;
+    e->pend.bsel = e->lock_parity; e->pend.bclear = e->lock_parity ^ 1; e->lock_parity ^= 1;
     if (sample_step)
         hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
-                           (u32*)nullptr, (u8*)nullptr, 0, 0, e->pend.ctr + 4, 12, e->pend.ctr + 16 + NBINS * e->pend.bsel, e->pend.lists);
+                           (u32*)nullptr, (u8*)nullptr, 0, 0, e->pend.ctr + 4, 12, e->pend.ctr + 16 + NBINS * e->pend.bsel,
+                           e->pend.lists + (size_t)e->pend.bsel * NBINS * e->N);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
     if (r == CATAN_OK && e->cfg.auto_reset) {                    // the games that ended in k_step: re-dealt on the side stream from here on
         HIPCHK(hipEventRecord(e->ev_fork, st));
@@ -527,7 +539,7 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
         e->spec_epoch++;
         hipLaunchKernelGGL(k_reset_list, dim3(RESET_GRID), dim3(64), 0, e->side, e->ctx, e->mpk, limits_of(e),
                            (const u32*)(e->pend.ctr + 8 + 1), (const i32*)e->pend.resets[0][0], e->pend.busy, step_cfg(e).prof,
-                           (const u32*)(e->pend.ctr + 6), (const u64*)e->pend.spec, e->spec_state, e->spec_mpk, e->spec_epoch);
+                           (const u32*)(e->pend.ctr + 6), (const u64*)e->pend.spec, e->spec_state, e->spec_mpk, e->spec_epoch, e->pend);
         HIPCHK(hipEventRecord(e->ev_join, e->side));
     }
     if (r == CATAN_OK) r = enqueue_tier1(e, reward, done, st, ev, 0, e->lr_budget[0]);
@@ -644,9 +656,10 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
     return CATAN_OK;
 }
 
-// One iteration of the deferred rollout (schedule above).  Iteration `it` uses tier-1 request list it & 1 with tag
+// Round 1-3 form of the deferred iteration (CATAN_DEFERRED_LEGACY=1, kept for A/B measurements): a sampling + sorting kernel
+// in front of every k_step, busy tags cleared by it.  Iteration `it` uses tier-1 request list it & 1 with tag
 // 2 + (it & 1); window w = it / window uses slot w & 1 with tag 4 + (w & 1).
-static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
     const int fa = (int)(it & 1);
     e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
     const int64_t w = it / window;
@@ -658,11 +671,11 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         if (w >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));     // the slow path of window w-2 is complete
         HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
     }
-    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa;
+    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa; e->pend.bclear = fa ^ 1; e->pend.sample = 0; e->pend.brel = -1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
                        e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa, 1,
-                       e->pend.ctr + 16 + NBINS * fa, e->pend.lists);
+                       e->pend.ctr + 16 + NBINS * fa, e->pend.lists + (size_t)fa * NBINS * e->N);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
@@ -682,6 +695,67 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
             if (w >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa ^ 1], 0));
             hipLaunchKernelGGL(k_release_tags, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy);
             e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+        }
+    }
+    return r;
+}
+
+// One iteration of the deferred rollout (schedule above), fused-sampling form (round 4): the main stream runs ONE kernel per
+// pass.  k_step takes each game's action from the game's side row, and for every game it completes it draws the next action
+// from the new masks and appends the game to the next pass's lists; a game on the slow path is simply in no list until the
+// kernel that completes its step (k_lr_finish: the pass after next; tier 2 / re-deal: the window after next, through the
+// window's release list) has drawn its next action and enqueued it.  Every draw is a pure function of (game, decision index,
+// state), so the games' trajectories are the lock-step ones whoever draws.  Three sets of bin counts / lists / tier-1 request
+// lists rotate (pass % 3): k_step(t) reads set t, appends to set t + 1 and zeroes set t + 2, which k_lr_finish(t) and
+// k_step(t + 1) then fill.
+static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+    static const bool legacy = getenv("CATAN_DEFERRED_LEGACY") != nullptr && atoi(getenv("CATAN_DEFERRED_LEGACY")) != 0;
+    if (legacy) return deferred_iter_legacy(e, it, iters, window, st, ev);
+    const int fa = (int)(it & 1), r3 = (int)(it % 3);
+    e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
+    const int64_t w = it / window;
+    const int sa = (int)(w & 1);
+    const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
+    u32* bins = e->pend.ctr + 16 + NBINS * r3;
+    i32* lists = e->pend.lists + (size_t)r3 * NBINS * e->N;
+    if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-2 is complete (its games are in this pass's lists)
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
+    if (it == 0) {
+        HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+        hipLaunchKernelGGL(k_sample_first, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->mpk, (const u32*)e->pctr, bins, lists);
+    } else if (opens) {
+        if (w >= 2) {                                                       // the slow path of window w-2 is complete: its games play again
+            HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));
+            hipLaunchKernelGGL(k_release_window, dim3(64), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, (const u32*)(e->pend.ctr + 11 + 4 * sa),
+                               (const i32*)e->pend.resets[sa][2], bins, lists);
+        }
+        HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
+    }
+    e->pend.fa = r3; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa;
+    e->pend.bsel = r3; e->pend.bnext = (r3 + 1) % 3; e->pend.bclear = (r3 + 2) % 3; e->pend.sample = 1;
+    e->pend.brel = (r3 + 2) % 3;                               // tier 1 of this pass: its games return in pass it + 2
+    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
+    if (r != CATAN_OK) return r;
+    static const bool t1_serial = getenv("CATAN_T1_SERIAL") != nullptr;     // (diagnostics: tier 1 on the main stream, no overlap)
+    hipStream_t fs = t1_serial ? st : e->fstream[fa];
+    HIPCHK(hipEventRecord(e->ev_fready[fa], st));
+    HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[fa], 0));
+    r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, r3, e->lr_budget[1]);
+    if (r != CATAN_OK) return r;
+    HIPCHK(hipEventRecord(e->ev_fdone[fa], fs));
+    if (closes) {
+        // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
+        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa], 0));
+        if (it >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa ^ 1], 0));
+        e->pend.brel = -1;                                     // tier 2 / re-deals: into the window's release list
+        r = enqueue_slow(e, e->s_reward, e->s_done, e->sstream, ev, LR_HEAVY_GRID_DEFERRED);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_sdone[sa], e->sstream));
+        if (last) {                                   // the call returns with every step complete and no game left waiting
+            HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));
+            if (w >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa ^ 1], 0));
+            hipLaunchKernelGGL(k_finish_rollout, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, e->pctr, e->pend.busy);
+            e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0;
         }
     }
     return r;

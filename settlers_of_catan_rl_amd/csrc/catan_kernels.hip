@@ -153,22 +153,32 @@ DEVI void stage_out(const u32* tile, u32* __restrict__ R, int e, int lane) {
 // step no longer reads its own previous output.)
 // EST = false: the nine estimate chunks (7..15) are left out - the wave's action type neither reads nor writes them
 // (propose, end_turn, robber, knight / victory point / road building cards: 40 % of the waves) - 19 chunks, 3 games per pass.
-template <bool EST, int G = 64>
+// ROW = true (fused-sampling rollouts): the action is the one the game's previous step drew into its SIDE ROW (words 12..29,
+// with the game's decision counter in word 30: five 16-byte chunks, 12 games per instruction) instead of a caller's array.
+template <bool EST, int G = 64, bool ROW = false>
 DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restrict__ actions, int e, int lane,
-                       int (&a)[ACTION_WORDS]) {
+                       int (&a)[ACTION_WORDS], const u32* __restrict__ mpk = nullptr, u32* dctr = nullptr) {
     constexpr int TSG = G + 1;
     constexpr int NCH = EST ? 28 : 19, GP = 64 / NCH, NP = (G + GP - 1) / GP;
-    constexpr int NPA = (G + 6) / 7;
+    constexpr int NPA = ROW ? (G + 11) / 12 : (G + 6) / 7;
     const int gi = lane / NCH, q0 = lane - NCH * gi, q = (EST || q0 < 7) ? q0 : q0 + 9;
     const bool act = lane < GP * NCH;
-    const int ag = lane / 9, aq = lane - 9 * ag;
+    const int ag = ROW ? lane / 5 : lane / 9, aq = ROW ? lane - 5 * ag : lane - 9 * ag;
     uint4 v[NP];
-    uint2 av[NPA];
+    uint4 av[NPA];
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
-        const int g = p * 7 + ag, eg = __shfl(e, g & 63);
-        av[p] = make_uint2(0, 0);
-        if (lane < 63 && g < G && eg >= 0) av[p] = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
+        av[p] = make_uint4(0, 0, 0, 0);
+        if constexpr (ROW) {
+            const int g = p * 12 + ag, eg = __shfl(e, g & 63);
+            if (lane < 60 && g < G && eg >= 0) av[p] = *reinterpret_cast<const uint4*>(mpk + (long)eg * MPK_STRIDE + ROW_ACT + 4 * aq);
+        } else {
+            const int g = p * 7 + ag, eg = __shfl(e, g & 63);
+            if (lane < 63 && g < G && eg >= 0) {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(actions + (long)eg * ACTION_WORDS + 2 * aq);
+                av[p].x = t2.x; av[p].y = t2.y;
+            }
+        }
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -178,13 +188,22 @@ DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restri
     }
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
-        const int g = p * 7 + ag;
-        if (lane < 63 && g < G) { tile[(2 * aq) * TSG + g] = av[p].x; tile[(2 * aq + 1) * TSG + g] = av[p].y; }
+        if constexpr (ROW) {
+            const int g = p * 12 + ag;
+            if (lane < 60 && g < G) {
+                u32* t = tile + (4 * aq) * TSG + g;
+                t[0] = av[p].x; t[TSG] = av[p].y; t[2 * TSG] = av[p].z; t[3 * TSG] = av[p].w;
+            }
+        } else {
+            const int g = p * 7 + ag;
+            if (lane < 63 && g < G) { tile[(2 * aq) * TSG + g] = av[p].x; tile[(2 * aq + 1) * TSG + g] = av[p].y; }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     const int sl = lane < G ? lane : G - 1;               // (lanes >= G carry no game: they read slot G-1 and are never used)
 #pragma unroll
     for (int i = 0; i < ACTION_WORDS; i++) a[i] = (int)tile[i * TSG + sl];
+    if constexpr (ROW) *dctr = tile[ACTION_WORDS * TSG + sl];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -192,6 +211,32 @@ DEVI void stage_in_all(u32* tile, const u32* __restrict__ R, const i32* __restri
         if (act && g < G) {
             u32* t = tile + (4 * q) * TSG + g;
             t[0] = v[p].x; t[TSG] = v[p].y; t[2 * TSG] = v[p].z; t[3 * TSG] = v[p].w;
+        }
+    }
+}
+// fused-sampling rollouts: the whole side row of the games with e >= 0 - new masks, the action drawn for the game's next
+// step, its decision counter - through the (free again) tile: 8 lanes x 16 B per game, full 128 B lines
+template <int G = 64>
+DEVI void stage_out_row(u32* tile, u32* __restrict__ mpk, int e, int lane, const u32 (&m)[MASK_WORDS], const int (&an)[ACTION_WORDS], u32 dctr) {
+    constexpr int TSG = G + 1;
+    if (lane < G) {
+#pragma unroll
+        for (int i = 0; i < MASK_WORDS; i++) tile[i * TSG + lane] = m[i];
+        tile[MASK_WORDS * TSG + lane] = 0;
+#pragma unroll
+        for (int i = 0; i < ACTION_WORDS; i++) tile[(ROW_ACT + i) * TSG + lane] = (u32)an[i];
+        tile[ROW_CTR * TSG + lane] = dctr;
+        tile[ROW_TAG * TSG + lane] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int rg = lane >> 3, rq = lane & 7;
+#pragma unroll
+    for (int p = 0; p < (G + 7) / 8; p++) {
+        const int g = p * 8 + rg, eg = __shfl(e, g & 63);
+        if (g < G && eg >= 0) {
+            const u32* t = tile + (4 * rq) * TSG + g;
+            uint4 val; val.x = t[0]; val.y = t[TSG]; val.z = t[2 * TSG]; val.w = t[3 * TSG];
+            *reinterpret_cast<uint4*>(mpk + (long)eg * MPK_STRIDE + 4 * rq) = val;
         }
     }
 }
@@ -1179,6 +1224,109 @@ __global__ __launch_bounds__(256) void k_masked_row_store(unsigned char* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ random policy
+// position of the nth (0-based) set bit of v, -1 if there is none: branch-free rank search by halves (the peel-off loop
+// `v &= v - 1` ran max-over-lanes(nth) times per wave - up to 70 for an edge pick - in a kernel bound by exactly that)
+DEVI int nth_set(u64 v, int nth) {
+    if (nth >= __popcll(v)) return -1;
+    int pos = 0;
+    u32 w = (u32)v;
+    int c = __popc(w);
+    if (nth >= c) { nth -= c; w = (u32)(v >> 32); pos = 32; }
+    c = __popc(w & 0xFFFFu); if (nth >= c) { nth -= c; w >>= 16; pos += 16; }
+    c = __popc(w & 0xFFu);   if (nth >= c) { nth -= c; w >>= 8;  pos += 8; }
+    c = __popc(w & 0xFu);    if (nth >= c) { nth -= c; w >>= 4;  pos += 4; }
+    c = __popc(w & 0x3u);    if (nth >= c) { nth -= c; w >>= 2;  pos += 2; }
+    if (nth >= (int)(w & 1u)) pos += 1;
+    return pos;
+}
+DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * k) >> 32)-th
+    int k = __popcll(v);
+    if (k == 0) return 0;
+    return nth_set(v, (int)__umulhi(w, (u32)k));
+}
+// DESIGN.md "random policy": philox stream 1, blocks 2*step_idx and 2*step_idx+1 -> words w0..w7
+// pctr == nullptr: every game draws with the caller's step_idx (lock-step rollouts).  Otherwise game e draws with its own
+// decision counter pctr[e] (advanced here) and a busy game gets the no-op action: its trajectory does not depend on when
+// it is scheduled (deferred rollouts).
+// A busy game whose tag equals tag_now or tag_now2 (>= 2) is released here: its step was completed on a side stream, which
+// the caller has joined before this launch.
+// Returns the sampled action type (-1: busy game, no action).
+template <class S>
+DEVI int sample_random(const Ctx& c, const S& s, const u32 (&m)[MASK_WORDS], u32 step_idx, int (&a)[ACTION_WORDS],
+                       u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2) {
+#pragma unroll
+    for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
+    if (pctr != nullptr) {
+        const u32 own = pctr[s.e];                          // loaded next to the busy byte: one memory round trip, not two
+        int b = busy[s.e];
+        if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
+        if (b) { a[0] = -1; return -1; }
+        step_idx = own;
+        pctr[s.e] = step_idx + 1;
+    }
+    u64 id = c.env_id0 + (u64)s.e;
+    u32 w[8];
+    {
+        u32 o[4];
+        philox4x32_10(2 * step_idx, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
+        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+    }
+    int t = pick64(getr<M0, 13>(m), w[0]);
+    a[0] = t;
+    switch (t) {
+    case T_SETTLE: a[1] = pick64(getr<M1, 54>(m), w[1]); break;
+    case T_CITY: a[1] = pick64(getr<M1 + 54, 54>(m), w[1]); break;
+    case T_ROAD: {
+        u64 lo = getr<M2, 64>(m), hi = getr<M2 + 64, 9>(m);
+        int k = __popcll(lo) + __popcll(hi);
+        int nth = k ? (int)__umulhi(w[1], (u32)k) : 0;
+        int nlo = __popcll(lo);
+        a[2] = k == 0 ? 0 : (nth < nlo ? nth_set(lo, nth) : 64 + nth_set(hi, nth - nlo));
+        break;
+    }
+    case T_ROBBER: a[3] = pick64(getr<M3, 19>(m), w[1]); break;
+    case T_PLAYDEV:
+        a[4] = pick64(getr<M4, 5>(m), w[1]);
+        if (a[4] == C_MONO) a[15] = pick64(getr<M9 + 10, 5>(m), w[2]);
+        else if (a[4] == C_YOP) { a[15] = pick64(getr<M9 + 15, 5>(m), w[2]); a[16] = pick64(getr<M10, 5>(m), w[3]); }
+        break;
+    case T_EXCHANGE: a[15] = pick64(getr<M9, 5>(m), w[1]); a[16] = pick64(getr<M10, 5>(m), w[2]); break;
+    case T_PROPOSE: {
+        {
+            u32 o[4];
+            philox4x32_10(2 * step_idx + 1, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
+            w[4] = o[0]; w[5] = o[1]; w[6] = o[2]; w[7] = o[3];
+        }
+        int pid = s.b(B_GO);
+        int hand[5], tot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { hand[r] = s.res(pid, r); tot += hand[r]; }
+        a[6] = (int)__umulhi(w[1], 3u);
+        int n_give = 1 + (int)(w[2] & 1u), n_recv = 1 + (int)((w[2] >> 1) & 1u);
+        if (n_give > tot) n_give = tot;
+#pragma unroll
+        for (int i = 0; i < 2; i++) if (i < n_give) {
+            int nth = (int)__umulhi(w[3 + i], (u32)tot), r = 0;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 5; k++) if (!found) { if (nth < hand[k]) { r = k; found = true; } else nth -= hand[k]; }
+            a[7 + i] = r + 1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) hand[k] -= (k == r) ? 1 : 0;
+            tot--;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) if (i < n_recv) a[11 + i] = 1 + (int)__umulhi(w[5 + i], 5u);
+        break;
+    }
+    case T_RESPOND: a[5] = pick64(getr<M5, 2>(m), w[1]); break;
+    case T_STEAL: a[6] = pick64(getr<M6 + 3, 3>(m), w[1]); break;
+    case T_DISCARD: a[17] = pick64(getr<M11, 5>(m), w[1]); break;
+    default: break;
+    }
+    return t;
+}
 // ------------------------------------------------------------------------------------------------ step
 // Validate mode = EnvWrapper.step with validate_actions=True (env/wrapper.py:36-41, the wrapper's default):
 // `_translate_action` (wrapper.py:114-166, :414-426, :440-486) + `Game.validate_action` (game/game.py:264-525), restated
@@ -1529,16 +1677,28 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
-struct Pending { u32* ctr; u64* req[2]; u64* heavy[2]; u8* type; u8* who; u64* len; u32* arrive; i32* resets[2][3]; u8* busy;
+struct Pending { u32* ctr; u64* req[3]; u64* heavy[2]; u8* type; u8* who; u64* len; u32* arrive; i32* resets[2][3]; u8* busy;
                  u64* spec;                 // lock-step steps: the longest-road requests of games that this step may end (ctr[6])
-                 i32* lists;                // the sort: game ids per action-type bin, [NBINS][N] (bin b, rank r at b * N + r)
-                 int bsel;                  // which of the two bin-count sets (ctr[16 + NBINS * bsel ..]) this pass uses
-                 int fa, ftag, sa, stag; };
-constexpr int CTR_WORDS = 64;
+                 i32* lists;                // the sort: game ids per action-type bin, three sets of [NBINS][N] (set s, bin b, rank r at (s * NBINS + b) * N + r)
+                 int bsel;                  // which bin-count set (ctr[16 + NBINS * bsel ..]) and list set this pass reads
+                 int bclear;                // the set whose counts k_step zeroes for a later pass (lock-step: the other of two; fused-sampling rollouts: pass + 2 of three)
+                 int fa, ftag, sa, stag;
+                 // Fused-sampling deferred rollouts (sample != 0): whoever completes a game's step - k_step for most, k_lr_finish, the
+                 // tier-2 completion or the re-deal for the rest - draws the game's NEXT action from the new masks (random policy, the
+                 // game's own decision counter) into the game's side row and enqueues the game for the pass it plays again in: no
+                 // sampling / sorting kernel is left on the critical path, and a game that is not in a pass's lists simply does not
+                 // play in it (no busy tags to clear).
+                 int sample;
+                 int bnext;                 // k_step: the set the games it completes are appended to (the next pass)
+                 int brel;                  // slow-path completions: >= 0 the set of the pass their games return in (tier 1: pass + 2);
+                                            // < 0: the window's release list resets[sa][2] (tier 2 / re-deals: k_release_window enqueues them)
+               };
+constexpr int CTR_WORDS = 96;
+DEVI int lrq_ctr(int fl) { return fl < 2 ? 4 + fl : 7; }     // length of tier-1 request list fl (three lists in fused-sampling rollouts)
 // Sort bins: 0..12 = the action types, 13..16 = play_dev with card 1..4 (card 0 stays in bin T_PLAYDEV: the five cards run
 // five different code paths, and the launch lasts as long as its slowest wave), NBINS-1 = no-op / busy / padding.
 constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
-static_assert(16 + 2 * NBINS <= CTR_WORDS, "two sets of bin counts live in ctr[16 ..]");
+static_assert(16 + 3 * NBINS <= CTR_WORDS, "three sets of bin counts live in ctr[16 ..]");
 DEVI int bin_of(int t, int card) {
     if (t < 0 || t > 12) return BIN_NOOP;
     if (t != T_PLAYDEV) return t;
@@ -1546,6 +1706,30 @@ DEVI int bin_of(int t, int card) {
     return card >= 1 ? 12 + card : t;
 }
 DEVI int type_of_bin(int bin) { return bin <= 12 ? bin : (bin < BIN_NOOP ? T_PLAYDEV : -1); }
+
+// Fused-sampling rollouts, ONE lane (the slow-path completions: k_lr_finish, the tier-2 completion, the re-deal): the game's
+// next action from its new masks `m` - random policy, decision index = the counter in the game's side row (k_step advanced it
+// when it applied the action whose step completes here) - written into the side row, and the game enqueued: into bin set
+// pend.brel (the pass it returns in), or into the window's release list (k_release_window enqueues those).
+template <class S>
+DEVI void sample_enqueue_lane(const Ctx& c, const S& s, const u32 (&m)[MASK_WORDS], const Pending& pend, u32* __restrict__ mpk) {
+    const long e = s.e;
+    u32* row = mpk + e * MPK_STRIDE;
+    int a[ACTION_WORDS];
+    const int t = sample_random(c, s, m, row[ROW_CTR], a, (u32*)nullptr, (u8*)nullptr, 0, 0);
+    uint4* dst = reinterpret_cast<uint4*>(row + ROW_ACT);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dst[i] = make_uint4((u32)a[4 * i], (u32)a[4 * i + 1], (u32)a[4 * i + 2], (u32)a[4 * i + 3]);
+    *reinterpret_cast<uint2*>(row + ROW_ACT + 16) = make_uint2((u32)a[16], (u32)a[17]);
+    if (pend.brel >= 0) {
+        const int bin = bin_of(t, a[4]);
+        const u32 rank = atomicAdd(&pend.ctr[16 + NBINS * pend.brel + bin], 1u);
+        pend.lists[((long)pend.brel * NBINS + bin) * c.N + rank] = (i32)e;
+    } else {
+        const u32 rank = atomicAdd(&pend.ctr[11 + 4 * pend.sa], 1u);
+        pend.resets[pend.sa][2][rank] = (i32)e;
+    }
+}
 
 struct StepCfg;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev);
@@ -1685,7 +1869,10 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // G = games per wave (64, 32 or 16; lanes >= G carry no game and only help with the row-wise transfers): with G < 64 there
 // are 64 / G waves per SIMD at 65 536 games, each with a tile of ROWS_HOT x (G + 1) words, so that one wave's transfers
 // overlap the others' dependent-instruction chains (with one wave per SIMD the HBM is idle while the step computes).
-template <int G>
+// SAMPLE (fused-sampling deferred rollouts): the action comes from the game's side row, the step advances the game's decision
+// counter, and for every game it completes it draws the NEXT action from the new masks (still in registers) and appends the
+// game to the next pass's bin lists - the sampler / sort kernel and its re-read of the masks are gone from the pass.
+template <int G, bool SAMPLE = false>
 __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
@@ -1694,7 +1881,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     __shared__ u32 tile[ROWS_HOT * TSG];
     __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
     const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * (pend.bsel ^ 1) + lane] = 0;     // the next pass's bin counts
+    if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
+    if (SAMPLE && blockIdx.x == 0 && lane == 0) pend.ctr[lrq_ctr((pend.fa + 1) % 3)] = 0;     // ... and the next pass's tier-1 request list (its last reader is done)
     // Wave w takes the sorted positions 64w .. 64w+63.  The sort is never materialised: the sampler / k_classify left the
     // game ids in one list per bin, every bin occupies ceil(count / 64) waves (type-pure waves), and a wave finds its bin
     // and offset from the 18 counts.
@@ -1711,7 +1899,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     }
     if (bin < 0) return;                                   // behind the last bin
     const int rnk = first + lane;
-    const long e = (lane < G && rnk < cnt) ? (long)pend.lists[(long)bin * c.N + rnk] : 0x7fffffffL;
+    const long e = (lane < G && rnk < cnt) ? (long)pend.lists[((long)pend.bsel * NBINS + bin) * c.N + rnk] : 0x7fffffffL;
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     const bool live = e < c.n;
     // the last bin = explicit no-op (negative type: frozen game) or a busy game (the sampler gives those the no-op): none
@@ -1733,8 +1921,9 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const bool t_est = t_board || type == T_BUYDEV || bin == 12 + C_YOP || bin == 12 + C_MONO || type == T_EXCHANGE || type == T_RESPOND ||
                        type == T_ROLL || type == T_STEAL || type == T_DISCARD;
     const bool w_board = __ballot(type >= 0 && t_board) != 0, w_est = __ballot(type >= 0 && t_est) != 0;
-    if (w_est) stage_in_all<true, G>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a);
-    else stage_in_all<false, G>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a);
+    u32 dctr = 0;                                           // SAMPLE: the game's decision counter (side row)
+    if (w_est) stage_in_all<true, G, SAMPLE>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a, mpk, &dctr);
+    else stage_in_all<false, G, SAMPLE>(tile, c.R, actions, type >= 0 ? (int)e : -1, lane, a, mpk, &dctr);
     __builtin_amdgcn_wave_barrier();
     StG s(tile + (lane < G ? lane : G - 1), c.R, c.N, e);
     prof_mark(cfg, 0, tprof);
@@ -2067,7 +2256,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int len = lr_len_now;
     const bool pending = lr_who >= 0 && !lr_inline;
     if (pending) {
-        const u32 slot = atomicAdd(&pend.ctr[4 + pend.fa], 1u);
+        const u32 slot = atomicAdd(&pend.ctr[lrq_ctr(pend.fa)], 1u);
         pend.req[pend.fa][slot] = (u64)e | ((u64)lr_edge << 40) | ((u64)lr_who << 56);
         if (pend.stag < 2) {                               // lock-step: a game whose completion can end it (longest road: +2 points for
             bool may_end = false;                          // one player) gets a speculative successor (k_reset_list)
@@ -2092,13 +2281,40 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     bool have_masks = false;
     finish_step<1>(c, s, (StepScratch*)nullptr, cfg, lane, type >= 0 && !pending, type, lr_inline ? lr_who : -1, len, reward, done, mpk, tprof, nbr_c, nbr_e,
                    pend, 0, false, m_new, &have_masks);
-    // ---- write the tile back, then the new mask rows through the tile
+    // ---- SAMPLE: the next action of every game completed here (random policy, decision index = the advanced counter), and
+    // the game's place in the next pass's lists: per bin one atomic by the first lane that drew it, ranks from the ballots
+    int an[ACTION_WORDS] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    if constexpr (SAMPLE) {
+        const long long t_s0 = cfg.prof_wave ? clock_fenced() : 0;
+        if (type >= 0) dctr++;                              // the action was applied: one more decision of this game
+        int nb = -1;
+        if (have_masks) nb = bin_of(sample_random(c, s, m_new, dctr, an, (u32*)nullptr, (u8*)nullptr, 0, 0), an[4]);
+        else if (type >= 0) mpk[e * MPK_STRIDE + ROW_CTR] = dctr;    // (slow path / re-deal: the completing kernel draws with this counter)
+        const long long t_s1 = cfg.prof_wave ? clock_fenced() : 0;
+        u32 rank = 0, cntb = 0;
+        int leader = 0;
+#pragma unroll
+        for (int b = 0; b < NBINS - 1; b++) {
+            const u64 mk = __ballot(nb == b);
+            if (nb == b) { rank = (u32)__popcll(mk & ((1ull << lane) - 1)); cntb = (u32)__popcll(mk); leader = __ffsll((long long)mk) - 1; }
+        }
+        u32 base = 0;
+        if (nb >= 0 && lane == leader) base = atomicAdd(&pend.ctr[16 + NBINS * pend.bnext + nb], cntb);
+        base = __shfl(base, leader);
+        if (nb >= 0) pend.lists[((long)pend.bnext * NBINS + nb) * c.N + base + rank] = (i32)e;
+        if (cfg.prof_wave != nullptr) {                     // slot 4 (SAMPLE): the draw | the append << 16
+            const long long t_s2 = clock_fenced();
+            if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 4] = ((u32)(t_s1 - t_s0) & 0xFFFFu) | ((u32)(t_s2 - t_s1) << 16);
+        }
+    }
+    // ---- write the tile back, then the new mask rows (SAMPLE: the whole side rows) through the tile
     __builtin_amdgcn_wave_barrier();
     if (w_board) stage_out<28, 0, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     else if (w_est) stage_out<21, 7, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     else stage_out<12, 16, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     __builtin_amdgcn_wave_barrier();
-    stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
+    if constexpr (SAMPLE) stage_out_row<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new, an, dctr);
+    else stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
 }
 
@@ -2132,7 +2348,7 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
     const int lane = threadIdx.x;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    const u32 count = pend.ctr[4 + fl];
+    const u32 count = pend.ctr[lrq_ctr(fl)];
     if (blockIdx.x == 0 && lane == 0 && slow_ctr != nullptr) { atomicAdd(&slow_ctr[0], (unsigned long long)count); atomicAdd(&slow_ctr[2], 1ull); }
     StepCfg cfg2 = cfg;
     cfg2.prof = nullptr;
@@ -2164,8 +2380,15 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         }
         const int len = lr_apply(lc, who, pl.through, found);
         prof_mark(cfg2, 1, tprof);
+        u32 mn[MASK_WORDS];
+        bool mv = false;
         finish_step<2>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
-                       pend.stag < 2 ? 2 : 0, pend.ftag < 2, nullptr, nullptr, &lc);
+                       pend.stag < 2 ? 2 : 0, pend.ftag < 2, pend.sample ? mn : nullptr, pend.sample ? &mv : nullptr, &lc);
+        if (mv) {                                         // fused-sampling rollouts (lane 0, the game goes on): masks, next action, its place in the pass it returns in
+#pragma unroll
+            for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = mn[i];
+            sample_enqueue_lane(c, s, mn, pend, mpk);
+        }
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
         if (lane == 0) lc.store(s.P);
@@ -2273,8 +2496,15 @@ __global__ __launch_bounds__(LR_HEAVY_THREADS) void k_lr_heavy(Ctx c, const u32*
             lr_load_nbr(lane, nc, ne);
             const int len = lr_apply(lc, pid, pl.through, found);
             long long tprof = 0;
+            u32 mn[MASK_WORDS];
+            bool mv = false;
             finish_step<2>(c, sl, scratch, cfg2, lane, lane == 0, (int)pend.type[game] - 1, pid, len, reward, done, mpk, tprof, nc, ne, pend,
-                           1, pend.stag < 2, nullptr, nullptr, &lc);
+                           1, pend.stag < 2, pend.sample ? mn : nullptr, pend.sample ? &mv : nullptr, &lc);
+            if (mv) {                                     // fused-sampling rollouts: as in k_lr_finish (pend.brel < 0: the window's release list)
+#pragma unroll
+                for (int i = 0; i < MASK_WORDS; i++) mpk[game * MPK_STRIDE + i] = mn[i];
+                sample_enqueue_lane(c, sl, mn, pend, mpk);
+            }
             __builtin_amdgcn_wave_barrier();
             if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + game * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
             if (lane == 0) lc.store(sl.P);
@@ -2294,13 +2524,64 @@ __global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ 
     if (e < c.N && busy[e] >= 2) busy[e] = 0;
 }
 
+// ---- fused-sampling deferred rollouts: the three small kernels around the loop
+// first pass of a call: every game's first action (decision index pctr[e], which is NOT advanced: k_step counts a decision when
+// it applies it) into its side row, the counter next to it, the game into bin set 0
+__global__ __launch_bounds__(BLOCK) void k_sample_first(Ctx c, u32* __restrict__ mpk, const u32* __restrict__ pctr, u32* __restrict__ bins,
+                                                       i32* __restrict__ lists) {
+    __shared__ u32 hist[NBINS], base[NBINS];
+    if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
+    int bin = BIN_NOOP;
+    if (s.e < c.n) {
+        u32* row = mpk + s.e * MPK_STRIDE;
+        u32 m[MASK_WORDS];
+#pragma unroll
+        for (int i = 0; i < MASK_WORDS; i++) m[i] = row[i];
+        int a[ACTION_WORDS];
+        const u32 d = pctr[s.e];
+        bin = bin_of(sample_random(c, s, m, d, a, (u32*)nullptr, (u8*)nullptr, 0, 0), a[4]);
+        uint4* dst = reinterpret_cast<uint4*>(row + ROW_ACT);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = make_uint4((u32)a[4 * i], (u32)a[4 * i + 1], (u32)a[4 * i + 2], (u32)a[4 * i + 3]);
+        dst[4] = make_uint4((u32)a[16], (u32)a[17], d, 0u);
+    }
+    // (sort_append, defined further down, inlined: the block's games appended to the per-bin lists)
+    u32 rank = 0;
+    const bool valid = s.e < c.n;
+    if (valid) rank = atomicAdd(&hist[bin], 1u);
+    __syncthreads();
+    if (threadIdx.x < NBINS) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (valid) lists[(long)bin * c.N + base[bin] + rank] = (i32)s.e;
+}
+// opening of window w + 2: the games whose step the slow path of window w completed (tier 2, re-deals) sit in that window's
+// release list with their next action already in their side rows - enqueue them for this pass
+__global__ __launch_bounds__(BLOCK) void k_release_window(Ctx c, const u32* __restrict__ mpk, const u32* __restrict__ count_p, const i32* __restrict__ list,
+                                                         u32* __restrict__ bins, i32* __restrict__ lists) {
+    const u32 count = *count_p;
+    for (u32 r = blockIdx.x * BLOCK + threadIdx.x; r < count; r += gridDim.x * BLOCK) {
+        const long e = list[r];
+        const u32* row = mpk + e * MPK_STRIDE;
+        const int bin = bin_of((int)row[ROW_ACT], (int)row[ROW_ACT + 4]);
+        lists[(long)bin * c.N + atomicAdd(&bins[bin], 1u)] = (i32)e;
+    }
+}
+// end of a call: the decision counters back into the handle's array (catan_policy_counters), every slow-path tag cleared
+__global__ __launch_bounds__(BLOCK) void k_finish_rollout(Ctx c, const u32* __restrict__ mpk, u32* __restrict__ pctr, u8* __restrict__ busy) {
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e < c.n) pctr[e] = mpk[e * MPK_STRIDE + ROW_CTR];
+    if (e < c.N) busy[e] = 0;
+}
+
 // One wave resets one game: the 64 lanes generate the game's next RND_WORDS Philox draws into LDS, lane 0 runs the
 // (inherently serial) shuffles of Board.reset / Game.reset on the game's hot record held linearly in LDS, then computes
 // the masks of the fresh game.
 // dstR != nullptr: a SPECULATIVE re-deal - the fresh record (and its masks, through `mpk`) go to the shadow arrays, the game
 // itself is only read (its stream position).  k_install_list copies the shadow over the game if the game did end.
 DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, Limits lim, u8* busy,
-                           unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr) {
+                           unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr, const Pending* pend = nullptr) {
     u32* const outR = dstR ? dstR : c.R;
     __builtin_amdgcn_wave_barrier();
     if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
@@ -2337,6 +2618,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
             compute_masks(s, m, lim);
 #pragma unroll
             for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = m[i];
+            if (pend != nullptr && pend->sample) sample_enqueue_lane(c, s, m, *pend, mpk);   // fused-sampling rollouts: the fresh game's first action
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -2351,12 +2633,12 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
 __global__ __launch_bounds__(64) void k_reset_list(Ctx c, u32* __restrict__ mpk, Limits lim, const u32* __restrict__ count_p,
                                                    const i32* __restrict__ list, u8* __restrict__ busy, unsigned long long* prof,
                                                    const u32* __restrict__ spec_count_p, const u64* __restrict__ spec_list,
-                                                   u32* __restrict__ specR, u32* __restrict__ spec_mpk, u32 epoch) {
+                                                   u32* __restrict__ specR, u32* __restrict__ spec_mpk, u32 epoch, Pending pend) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     __shared__ ResetScratch sc;
     const u32 count = *count_p, scount = spec_list ? *spec_count_p : 0u;
     for (u32 r = blockIdx.x; r < count + scount; r += gridDim.x) {
-        if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, lim, busy, prof);
+        if (r < count) wave_reset_game(c, list[r], rec, sc, threadIdx.x, mpk, lim, busy, prof, nullptr, &pend);
         else {
             const long e = (long)(spec_list[r - count] & 0x00FFFFFFFFFFFFFFull);
             wave_reset_game(c, e, rec, sc, threadIdx.x, spec_mpk, lim, nullptr, nullptr, specR);
@@ -2381,11 +2663,8 @@ __global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mp
             continue;
         }
         if (lane < REC / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(specR + e * REC)[lane];
-        if (lane < MPK_STRIDE / 4) {
-            uint4 v = reinterpret_cast<const uint4*>(spec_mpk + e * MPK_STRIDE)[lane];
-            if (lane == MPK_STRIDE / 4 - 1) v.w = 0;                                      // (the tag word is not part of the masks)
-            reinterpret_cast<uint4*>(mpk + e * MPK_STRIDE)[lane] = v;
-        }
+        if (lane < 3)                                                                     // (words 0..11: the masks; the rest of the side row is the game's own)
+            reinterpret_cast<uint4*>(mpk + e * MPK_STRIDE)[lane] = reinterpret_cast<const uint4*>(spec_mpk + e * MPK_STRIDE)[lane];
         if (lane == 0 && busy != nullptr) busy[e] = 0;
     }
 }
@@ -2433,108 +2712,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict
 }
 constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
 
-// ------------------------------------------------------------------------------------------------ random policy
-// position of the nth (0-based) set bit of v, -1 if there is none: branch-free rank search by halves (the peel-off loop
-// `v &= v - 1` ran max-over-lanes(nth) times per wave - up to 70 for an edge pick - in a kernel bound by exactly that)
-DEVI int nth_set(u64 v, int nth) {
-    if (nth >= __popcll(v)) return -1;
-    int pos = 0;
-    u32 w = (u32)v;
-    int c = __popc(w);
-    if (nth >= c) { nth -= c; w = (u32)(v >> 32); pos = 32; }
-    c = __popc(w & 0xFFFFu); if (nth >= c) { nth -= c; w >>= 16; pos += 16; }
-    c = __popc(w & 0xFFu);   if (nth >= c) { nth -= c; w >>= 8;  pos += 8; }
-    c = __popc(w & 0xFu);    if (nth >= c) { nth -= c; w >>= 4;  pos += 4; }
-    c = __popc(w & 0x3u);    if (nth >= c) { nth -= c; w >>= 2;  pos += 2; }
-    if (nth >= (int)(w & 1u)) pos += 1;
-    return pos;
-}
-DEVI int pick64(u64 v, u32 w) {       // uniform pick among set bits: the ((w * k) >> 32)-th
-    int k = __popcll(v);
-    if (k == 0) return 0;
-    return nth_set(v, (int)__umulhi(w, (u32)k));
-}
-// DESIGN.md "random policy": philox stream 1, blocks 2*step_idx and 2*step_idx+1 -> words w0..w7
-// pctr == nullptr: every game draws with the caller's step_idx (lock-step rollouts).  Otherwise game e draws with its own
-// decision counter pctr[e] (advanced here) and a busy game gets the no-op action: its trajectory does not depend on when
-// it is scheduled (deferred rollouts).
-// A busy game whose tag equals tag_now or tag_now2 (>= 2) is released here: its step was completed on a side stream, which
-// the caller has joined before this launch.
-// Returns the sampled action type (-1: busy game, no action).
-DEVI int sample_random(const Ctx& c, const St& s, const u32 (&m)[MASK_WORDS], u32 step_idx, int (&a)[ACTION_WORDS],
-                       u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2) {
-#pragma unroll
-    for (int i = 0; i < ACTION_WORDS; i++) a[i] = 0;
-    if (pctr != nullptr) {
-        const u32 own = pctr[s.e];                          // loaded next to the busy byte: one memory round trip, not two
-        int b = busy[s.e];
-        if (b >= 2 && (b == tag_now || b == tag_now2)) { busy[s.e] = 0; b = 0; }
-        if (b) { a[0] = -1; return -1; }
-        step_idx = own;
-        pctr[s.e] = step_idx + 1;
-    }
-    u64 id = c.env_id0 + (u64)s.e;
-    u32 w[8];
-    {
-        u32 o[4];
-        philox4x32_10(2 * step_idx, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
-        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
-    }
-    int t = pick64(getr<M0, 13>(m), w[0]);
-    a[0] = t;
-    switch (t) {
-    case T_SETTLE: a[1] = pick64(getr<M1, 54>(m), w[1]); break;
-    case T_CITY: a[1] = pick64(getr<M1 + 54, 54>(m), w[1]); break;
-    case T_ROAD: {
-        u64 lo = getr<M2, 64>(m), hi = getr<M2 + 64, 9>(m);
-        int k = __popcll(lo) + __popcll(hi);
-        int nth = k ? (int)__umulhi(w[1], (u32)k) : 0;
-        int nlo = __popcll(lo);
-        a[2] = k == 0 ? 0 : (nth < nlo ? nth_set(lo, nth) : 64 + nth_set(hi, nth - nlo));
-        break;
-    }
-    case T_ROBBER: a[3] = pick64(getr<M3, 19>(m), w[1]); break;
-    case T_PLAYDEV:
-        a[4] = pick64(getr<M4, 5>(m), w[1]);
-        if (a[4] == C_MONO) a[15] = pick64(getr<M9 + 10, 5>(m), w[2]);
-        else if (a[4] == C_YOP) { a[15] = pick64(getr<M9 + 15, 5>(m), w[2]); a[16] = pick64(getr<M10, 5>(m), w[3]); }
-        break;
-    case T_EXCHANGE: a[15] = pick64(getr<M9, 5>(m), w[1]); a[16] = pick64(getr<M10, 5>(m), w[2]); break;
-    case T_PROPOSE: {
-        {
-            u32 o[4];
-            philox4x32_10(2 * step_idx + 1, 1u, (u32)id, (u32)(id >> 32), c.key0, c.key1, o);
-            w[4] = o[0]; w[5] = o[1]; w[6] = o[2]; w[7] = o[3];
-        }
-        int pid = s.b(B_GO);
-        int hand[5], tot = 0;
-#pragma unroll
-        for (int r = 0; r < 5; r++) { hand[r] = s.res(pid, r); tot += hand[r]; }
-        a[6] = (int)__umulhi(w[1], 3u);
-        int n_give = 1 + (int)(w[2] & 1u), n_recv = 1 + (int)((w[2] >> 1) & 1u);
-        if (n_give > tot) n_give = tot;
-#pragma unroll
-        for (int i = 0; i < 2; i++) if (i < n_give) {
-            int nth = (int)__umulhi(w[3 + i], (u32)tot), r = 0;
-            bool found = false;
-#pragma unroll
-            for (int k = 0; k < 5; k++) if (!found) { if (nth < hand[k]) { r = k; found = true; } else nth -= hand[k]; }
-            a[7 + i] = r + 1;
-#pragma unroll
-            for (int k = 0; k < 5; k++) hand[k] -= (k == r) ? 1 : 0;
-            tot--;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) if (i < n_recv) a[11 + i] = 1 + (int)__umulhi(w[5 + i], 5u);
-        break;
-    }
-    case T_RESPOND: a[5] = pick64(getr<M5, 2>(m), w[1]); break;
-    case T_STEAL: a[6] = pick64(getr<M6 + 3, 3>(m), w[1]); break;
-    case T_DISCARD: a[17] = pick64(getr<M11, 5>(m), w[1]); break;
-    default: break;
-    }
-    return t;
-}
+// ------------------------------------------------------------------------------------------------ random policy (kernel)
 // bins != nullptr: also the histogram of the counting sort (k_classify_hist fused in; rollout loops) and the per-game
 // action types for k_classify_scatter.  (Staging the mask / action rows through LDS with coalesced transfers was tried:
 // 2.5 us slower - the kernel is bound by its divergent sampling chain, not by the row accesses.)

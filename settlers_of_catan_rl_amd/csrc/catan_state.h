@@ -11,7 +11,7 @@
 // tile[word][slot] (row stride 65 words: odd, so both the transposing writes and the lane-per-game reads are bank
 // conflict free).  Lane-per-game kernels that touch little state (masks, sampler, export) address the records directly.
 // 676 B of the 704 are used (the reference-like int32 form of the same state is 736 words = 2944 B, spec.py).
-// The per-game side buffers are game-major too: actions int32 [n][18], rewards float [n][4], packed masks u32 [N][16].
+// The per-game side buffers are game-major too: actions int32 [n][18], rewards float [n][4], side rows u32 [N][32] (masks + next action).
 //
 // Players are indexed by pid0 = PlayerId-1 (0 White, 1 Blue, 2 Orange, 3 Red; reference game/enums.py:8-12).
 // Resources r0 = Resource-1 (0 Brick, 1 Wood, 2 Ore, 3 Sheep, 4 Wheat; game/enums.py:22-28).
@@ -99,7 +99,12 @@ constexpr int ROWS_HOT = NW + B_HOT / 4;    // 112 words = 7 cache lines
 constexpr int NROWS = NW + NB / 4;          // 169 words used
 constexpr int REC = 176;                    // words per game record (704 B = 11 cache lines)
 constexpr int TS = 65;                      // LDS tile row stride in words (odd: conflict-free transposition)
-constexpr int MPK_STRIDE = 16;              // packed masks: 11 words used of a 64 B line per game
+// Per-game SIDE ROW (128 B = one aligned L2 line, two HBM bursts): the packed masks and - inside the deferred rollouts, where the
+// step samples the game's next action itself - that action and the game's decision counter, so that a stepping wave fetches
+// one line per game next to the record and writes it back whole:
+//   words 0..10 packed masks (325 bits)   11 zero   12..29 the next action (18 words)   30 decision counter   31 shadow tag
+constexpr int MPK_STRIDE = 32;
+constexpr int ROW_ACT = 12, ROW_CTR = 30, ROW_TAG = 31;
 constexpr int STATE_BYTES_PER_GAME = REC * 4;
 static_assert(NROWS * 4 == 676 && ROWS_HOT == 112 && ROWS_HOT * 4 % 64 == 0 && REC >= NROWS && REC * 4 % 64 == 0,
               "restate DESIGN.md byte table when the layout changes");
@@ -119,6 +124,7 @@ enum { R_BRICK = 0, R_WOOD = 1, R_ORE = 2, R_SHEEP = 3, R_WHEAT = 4 };
 constexpr int M0 = 0, M1 = 13, M2 = 175, M3 = 248, M4 = 267, M5 = 272, M6 = 274, M7 = 283, M8 = 289, M9 = 295,
               M10 = 315, M11 = 320, MASK_BITS = 325, MASK_WORDS = 11;
 constexpr int ACTION_WORDS = 18;
+static_assert(ROW_ACT % 4 == 0 && ROW_ACT >= MASK_WORDS && ROW_ACT + ACTION_WORDS == ROW_CTR && ROW_TAG == MPK_STRIDE - 1, "side-row layout");
 constexpr int STATE_WORDS = 736;   // canonical int32 blob (spec.py)
 constexpr int OBS_FLOATS = 1787;
 
