@@ -1,0 +1,56 @@
+/*
+ * catan_hip_tuning.h - scheduling knobs, counters and profilers of the env kernels in libcatan_hip.so.  Benchmarks, sweeps and
+ * diagnostics only (bench.py, tools): results never depend on any of them, and nothing a reference-side binding needs is
+ * declared here (that is catan_hip.h).
+ */
+#ifndef CATAN_HIP_TUNING_H
+#define CATAN_HIP_TUNING_H
+
+#include "catan_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scheduling knob of k_step (results do not depend on it): games per wave, 64 / 32 / 16.  With fewer games per wave there are
+ * 2 / 4 waves per SIMD at 65 536 games, so that one wave's record transfers overlap the other waves' dependent-instruction
+ * chains.  Default DEFAULT_STEP_WAVE_GAMES (csrc/catan_abi.hip), or the environment variable CATAN_STEP_WAVE_GAMES at creation. */
+int catan_set_step_wave_games(catan_env_t* env, int32_t games);
+/* tier-1 longest-road search budget (iterations) before a request is handed to tier 2: lock-step / deferred mode */
+int catan_set_lr_budgets(catan_env_t* env, int32_t lockstep, int32_t deferred);
+/* cumulative slow-path counters since creation (synchronises the stream): out3 = { longest-road requests handled by tier 1
+ * (k_lr_finish), requests handed on to tier 2 (k_lr_heavy), k_lr_finish launches } - bench.py derives the bytes a launch moves */
+int catan_slow_path_counts(catan_env_t* env, catan_stream_t stream, uint64_t* out3);
+/* tier-2 longest-road search: iterations per bulk-synchronous round (work is re-shared between rounds): lock-step / deferred */
+int catan_set_lr_rounds(catan_env_t* env, int32_t lockstep, int32_t deferred);
+
+/* the rollout loops with a hipEvent around every kernel launch (recorded on the stream the kernel runs on); window <= 0: the
+ * lock-step loop (step_idx0 as in catan_random_rollout), window > 0: the deferred loop (step_idx0 ignored).  kernel_ms is a HOST
+ * float[5] receiving the summed milliseconds of k_sample_random (which also sorts the games by action type), k_step,
+ * k_lr_finish, k_lr_heavy, k_reset_list / k_install_list (bench.py roofline). */
+int catan_random_rollout_timed(catan_env_t* env, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms);
+/* diagnostics of the lock-step step: finished games whose speculatively dealt successor was missing and which
+ * were re-dealt on the critical path instead; expected 0 (k_step's may-end filter is a superset of the games a step can end) */
+int64_t catan_missed_speculation_count(catan_env_t* env, catan_stream_t stream);
+
+/* diagnostics: copies `bytes` (multiple of 16) device to device with one kernel (k_calib_copy) - a launch with exactly
+ * known HBM traffic, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md) */
+int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t stream);
+
+/* phase profile (diagnostics): enable (zeroes the counters) / read.  out16 (62 words) = 8 sums then 8 maxima, 4 tier-1
+ * counters, then per action type (14) the sum / count / maximum of k_step's validate+apply time.
+ * Slots 0, 1, 2, 6, 7: k_step phases per wave in 100 MHz wall-clock ticks (stage-in, validate+apply, request push,
+ * done/reward+masks, write-back); slots 3, 4, 5: k_reset_list (philox draws, re-deals, serial shuffle ticks);
+ * tools/phase_profile.py prints them. */
+int catan_profile_enable(catan_env_t* env, int on);
+int catan_profile_read(catan_env_t* env, uint64_t* out16);
+/* catan_profile_enable(env, 2): contention-free variant for k_step - every wave stores its own phase durations of the LAST
+ * launch; out: HOST uint32 [ceil(n/256)*4 + 17][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = sort bin + 1: bins
+ * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort) */
+int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CATAN_HIP_TUNING_H */

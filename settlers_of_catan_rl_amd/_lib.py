@@ -1,4 +1,5 @@
-"""ctypes binding of libcatan_hip.so (the C ABI declared in include/catan_hip.h).
+"""ctypes binding of libcatan_hip.so (the C ABI declared in include/catan_hip.h; the net's kernels in catan_hip_nn.h, knobs and
+profilers in catan_hip_tuning.h).
 
 There is NO CPU fallback: if the shared library is missing or there is no HIP device the calls raise.
 """
@@ -23,7 +24,8 @@ class CatanCfg(C.Structure):
 
 def _sources():
     out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))]
-    out.append(os.path.join(os.path.dirname(PKG_DIR), "include", "catan_hip.h"))
+    inc = os.path.join(os.path.dirname(PKG_DIR), "include")
+    out += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
     return out
 
 
@@ -36,7 +38,7 @@ BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 
 def source_hash():
-    """sha256 over the names and contents of csrc/* and include/catan_hip.h and the compiler flags: what the library is built from."""
+    """sha256 over the names and contents of csrc/* and include/*.h and the compiler flags: what the library is built from."""
     import hashlib
     h = hashlib.sha256()
     h.update(" ".join(BUILD_FLAGS).encode() + b"\0")
@@ -181,7 +183,7 @@ _SIGS = {
 
 
 def declared_symbols():
-    """Every entry point include/catan_hip.h declares (the CPU test-suite checks the built .so exports them)."""
+    """Every entry point include/*.h declares (the CPU test-suite checks the built .so exports them)."""
     return sorted(_SIGS)
 
 

@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/catan_hip.h"
+#include "../../include/catan_hip_nn.h"
+#include "../../include/catan_hip_tuning.h"
 #include "catan_kernels.hip"
 #include "catan_obs.hip"
 #include "catan_ppo.hip"
@@ -319,7 +321,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.lists, (size_t)3 * NBINS * e->N * sizeof(i32));   // three sets (fused-sampling rollouts)
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.lists, (size_t)BIN_SETS * NBINS * e->N * sizeof(i32));   // BIN_SETS sets (fused-sampling rollouts)
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fork, EV_SYNC);
     if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_join, EV_SYNC);
@@ -344,7 +346,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
-    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1;
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
     HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
     e->ctx.R = (u32*)e->state;
     e->ctx.N = e->N; e->ctx.n = e->n;
@@ -711,14 +713,25 @@ static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int w
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
     static const bool legacy = getenv("CATAN_DEFERRED_LEGACY") != nullptr && atoi(getenv("CATAN_DEFERRED_LEGACY")) != 0;
     if (legacy) return deferred_iter_legacy(e, it, iters, window, st, ev);
-    const int fa = (int)(it & 1), r3 = (int)(it % 3);
+    // Tier 1 is forked once per GROUP of P passes (P = 2): a k_lr_finish launch lasts as long as its slowest search (~45 us next
+    // to k_step) whatever the number of requests, the launches of consecutive groups serialise on one side stream, and the games
+    // of group g return in the first pass of group g + 2 - with P = 1 the chain k_step -> k_lr_finish -> k_step two passes later
+    // and the side stream's throughput bound the pass at ~(k_step + k_lr_finish) / 2; with P = 2 neither does.
+    // S = P + 2 sets of bin counts / lists rotate: k_step(t) reads set t % S, appends to set (t + 1) % S and empties set
+    // (t - 1) % S (its reader is done), which k_lr_finish(g) - launched behind the last pass of group g - and the k_steps before
+    // pass (g + 2) P then fill.  Three tier-1 request lists rotate by group.
+    static const int P = (getenv("CATAN_T1_PERIOD") && atoi(getenv("CATAN_T1_PERIOD")) == 1) ? 1 : 2;
+    const int S = P + 2;
+    const int64_t g = it / P;
+    const int ga = (int)(g & 1), gl = (int)(g % 3), rs = (int)(it % S);
+    const bool gfirst = it % P == 0, glast = (it + 1) % P == 0;
     e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
     const int64_t w = it / window;
     const int sa = (int)(w & 1);
     const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
-    u32* bins = e->pend.ctr + 16 + NBINS * r3;
-    i32* lists = e->pend.lists + (size_t)r3 * NBINS * e->N;
-    if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-2 is complete (its games are in this pass's lists)
+    u32* bins = e->pend.ctr + 16 + NBINS * rs;
+    i32* lists = e->pend.lists + (size_t)rs * NBINS * e->N;
+    if (gfirst && g >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[ga], 0));   // tier 1 of group g-2 is complete (its games are in this pass's lists)
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     if (it == 0) {
         HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
@@ -731,22 +744,27 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         }
         HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
     }
-    e->pend.fa = r3; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa;
-    e->pend.bsel = r3; e->pend.bnext = (r3 + 1) % 3; e->pend.bclear = (r3 + 2) % 3; e->pend.sample = 1;
-    e->pend.brel = (r3 + 2) % 3;                               // tier 1 of this pass: its games return in pass it + 2
+    e->pend.fa = gl; e->pend.ftag = 2 + ga; e->pend.sa = sa; e->pend.stag = 4 + sa;
+    e->pend.bsel = rs; e->pend.bnext = (rs + 1) % S; e->pend.bclear = (rs + S - 1) % S; e->pend.sample = 1;
+    e->pend.lrq_clear = glast ? (gl + 1) % 3 : -1;             // the next group's request list (read last by tier 1 of group g-2: complete)
+    e->pend.brel = (int)(((g + 2) * P) % S);                   // tier 1 of this group: its games return in the first pass of group g + 2
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
-    static const bool t1_serial = getenv("CATAN_T1_SERIAL") != nullptr;     // (diagnostics: tier 1 on the main stream, no overlap)
-    hipStream_t fs = t1_serial ? st : e->fstream[fa];
-    HIPCHK(hipEventRecord(e->ev_fready[fa], st));
-    HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[fa], 0));
-    r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, r3, e->lr_budget[1]);
-    if (r != CATAN_OK) return r;
-    HIPCHK(hipEventRecord(e->ev_fdone[fa], fs));
+    if (glast || last) {
+        static const bool t1_serial = getenv("CATAN_T1_SERIAL") != nullptr;     // (diagnostics: tier 1 on the main stream, no overlap)
+        hipStream_t fs = t1_serial ? st : e->fstream[ga];
+        HIPCHK(hipEventRecord(e->ev_fready[ga], st));
+        HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[ga], 0));
+        static const int t1_delay = getenv("CATAN_T1_DELAY_US") ? atoi(getenv("CATAN_T1_DELAY_US")) : 0;
+        if (t1_delay > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, fs, t1_delay * 100);
+        r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[1]);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_fdone[ga], fs));
+    }
     if (closes) {
         // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
-        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa], 0));
-        if (it >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa ^ 1], 0));
+        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[ga], 0));
+        if (g >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[ga ^ 1], 0));
         e->pend.brel = -1;                                     // tier 2 / re-deals: into the window's release list
         r = enqueue_slow(e, e->s_reward, e->s_done, e->sstream, ev, LR_HEAVY_GRID_DEFERRED);
         if (r != CATAN_OK) return r;
@@ -842,7 +860,8 @@ int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps
         float ms = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms, v[5], v[0])); kernel_ms[0] += ms;      // k_sample_random (sampling + sort lists)
         HIPCHK(hipEventElapsedTime(&ms, v[0], v[2])); kernel_ms[1] += ms;      // k_step
-        HIPCHK(hipEventElapsedTime(&ms, v[8], v[6])); kernel_ms[2] += ms;      // k_lr_finish
+        if (hipEventElapsedTime(&ms, v[8], v[6]) == hipSuccess) kernel_ms[2] += ms;   // k_lr_finish (deferred loop: launched once per group of passes)
+        else (void)hipGetLastError();
         if (!slow[s]) continue;
         HIPCHK(hipEventElapsedTime(&ms, v[9], v[3])); kernel_ms[3] += ms;      // k_lr_heavy
         HIPCHK(hipEventElapsedTime(&ms, v[7], v[4])); kernel_ms[4] += ms;      // k_reset_list / k_install_list (wait for the side stream + second pass)

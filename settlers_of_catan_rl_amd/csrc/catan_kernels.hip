@@ -1689,16 +1689,18 @@ struct Pending { u32* ctr; u64* req[3]; u64* heavy[2]; u8* type; u8* who; u64* l
                  // sampling / sorting kernel is left on the critical path, and a game that is not in a pass's lists simply does not
                  // play in it (no busy tags to clear).
                  int sample;
+                 int lrq_clear;             // k_step: the tier-1 request list to empty for the passes that follow (-1: none)
                  int bnext;                 // k_step: the set the games it completes are appended to (the next pass)
                  int brel;                  // slow-path completions: >= 0 the set of the pass their games return in (tier 1: pass + 2);
                                             // < 0: the window's release list resets[sa][2] (tier 2 / re-deals: k_release_window enqueues them)
                };
 constexpr int CTR_WORDS = 96;
+constexpr int BIN_SETS = 4;                  // bin-count / list sets (fused-sampling rollouts rotate period + 2 of them)
 DEVI int lrq_ctr(int fl) { return fl < 2 ? 4 + fl : 7; }     // length of tier-1 request list fl (three lists in fused-sampling rollouts)
 // Sort bins: 0..12 = the action types, 13..16 = play_dev with card 1..4 (card 0 stays in bin T_PLAYDEV: the five cards run
 // five different code paths, and the launch lasts as long as its slowest wave), NBINS-1 = no-op / busy / padding.
 constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
-static_assert(16 + 3 * NBINS <= CTR_WORDS, "three sets of bin counts live in ctr[16 ..]");
+static_assert(16 + BIN_SETS * NBINS <= CTR_WORDS, "the sets of bin counts live in ctr[16 ..]");
 DEVI int bin_of(int t, int card) {
     if (t < 0 || t > 12) return BIN_NOOP;
     if (t != T_PLAYDEV) return t;
@@ -1882,7 +1884,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
-    if (SAMPLE && blockIdx.x == 0 && lane == 0) pend.ctr[lrq_ctr((pend.fa + 1) % 3)] = 0;     // ... and the next pass's tier-1 request list (its last reader is done)
+    if (SAMPLE && blockIdx.x == 0 && lane == 0 && pend.lrq_clear >= 0) pend.ctr[lrq_ctr(pend.lrq_clear)] = 0;   // ... and the next group's tier-1 request list (its last reader is done)
     // Wave w takes the sorted positions 64w .. 64w+63.  The sort is never materialised: the sampler / k_classify left the
     // game ids in one list per bin, every bin occupies ceil(count / 64) waves (type-pure waves), and a wave finds its bin
     // and offset from the 18 counts.
@@ -2284,6 +2286,8 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     // ---- SAMPLE: the next action of every game completed here (random policy, decision index = the advanced counter), and
     // the game's place in the next pass's lists: per bin one atomic by the first lane that drew it, ranks from the ballots
     int an[ACTION_WORDS] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    u32 abase = 0, arank = 0;
+    int aleader = 0, anb = -1;
     if constexpr (SAMPLE) {
         const long long t_s0 = cfg.prof_wave ? clock_fenced() : 0;
         if (type >= 0) dctr++;                              // the action was applied: one more decision of this game
@@ -2298,11 +2302,10 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
             const u64 mk = __ballot(nb == b);
             if (nb == b) { rank = (u32)__popcll(mk & ((1ull << lane) - 1)); cntb = (u32)__popcll(mk); leader = __ffsll((long long)mk) - 1; }
         }
-        u32 base = 0;
-        if (nb >= 0 && lane == leader) base = atomicAdd(&pend.ctr[16 + NBINS * pend.bnext + nb], cntb);
-        base = __shfl(base, leader);
-        if (nb >= 0) pend.lists[((long)pend.bnext * NBINS + nb) * c.N + base + rank] = (i32)e;
-        if (cfg.prof_wave != nullptr) {                     // slot 4 (SAMPLE): the draw | the append << 16
+        // (the atomic's round trip - device scope: ~2 us - runs under the write-back of the records below; its result is used after it)
+        if (nb >= 0 && lane == leader) abase = atomicAdd(&pend.ctr[16 + NBINS * pend.bnext + nb], cntb);
+        arank = rank; aleader = leader; anb = nb;
+        if (cfg.prof_wave != nullptr) {                     // slot 4 (SAMPLE): the draw | the ranking << 16
             const long long t_s2 = clock_fenced();
             if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 4] = ((u32)(t_s1 - t_s0) & 0xFFFFu) | ((u32)(t_s2 - t_s1) << 16);
         }
@@ -2313,6 +2316,10 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     else if (w_est) stage_out<21, 7, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     else stage_out<12, 16, G>(tile, c.R, (type >= 0 || rejected) ? (int)e : -1, lane);
     __builtin_amdgcn_wave_barrier();
+    if constexpr (SAMPLE) {
+        abase = __shfl(abase, aleader);
+        if (anb >= 0) pend.lists[((long)pend.bnext * NBINS + anb) * c.N + abase + arank] = (i32)e;
+    }
     if constexpr (SAMPLE) stage_out_row<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new, an, dctr);
     else stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
@@ -2567,6 +2574,13 @@ __global__ __launch_bounds__(BLOCK) void k_release_window(Ctx c, const u32* __re
         const int bin = bin_of((int)row[ROW_ACT], (int)row[ROW_ACT + 4]);
         lists[(long)bin * c.N + atomicAdd(&bins[bin], 1u)] = (i32)e;
     }
+}
+// (scheduling aid) one wave that lasts `ticks` of the 100 MHz wall clock: in front of k_lr_finish on its side stream it gives the
+// k_step launched at the same moment a head start, so that all of k_step's workgroups are resident (one wave per SIMD) before
+// the one-game-per-wave searches take the rest of the LDS - otherwise k_step's workgroups trickle in behind them
+__global__ void k_delay(int ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 // end of a call: the decision counters back into the handle's array (catan_policy_counters), every slow-path tag cleared
 __global__ __launch_bounds__(BLOCK) void k_finish_rollout(Ctx c, const u32* __restrict__ mpk, u32* __restrict__ pctr, u8* __restrict__ busy) {

@@ -1,5 +1,6 @@
-"""CPU-side checks of the product library: it builds, loads, and exports every symbol include/catan_hip.h
-declares.  No compute calls (there is no GPU here)."""
+"""CPU-side checks of the product library: it builds, loads, and exports every symbol include/*.h declares (catan_hip.h = the
+drop-in boundary; catan_hip_nn.h = the net's kernels; catan_hip_tuning.h = knobs and profilers).  No compute calls (there is no
+GPU here)."""
 import ctypes as C
 import os
 import re
@@ -9,14 +10,24 @@ from settlers_of_catan_rl_amd import _lib, spec
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(catan_[a-z_0-9]+)\s*\(", hdr))
+
+
 def test_header_symbols_exported():
-    hdr = open(os.path.join(ROOT, "include", "catan_hip.h")).read()
-    names = set(re.findall(r"\b(catan_[a-z_0-9]+)\s*\(", hdr))
-    assert names, "no declarations found"
+    per = {h: _declared(h) for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h")}
+    assert set(per) == {"catan_hip.h", "catan_hip_nn.h", "catan_hip_tuning.h"} and all(per.values())
+    names = set().union(*per.values())
     L = _lib.lib()
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
     assert set(_lib.declared_symbols()) <= names
+    # the boundary header stays the boundary: no net kernel, no knob, no profiler in it
+    assert len(per["catan_hip.h"]) < 50, sorted(per["catan_hip.h"])
+    for n in per["catan_hip.h"]:
+        assert not re.search(r"profile|calib|_set_lr_|wave_games|_timed|attention|layer_norm|linear_|tile_encoder|head_|card_|lstm|ffn_|qkv_", n), n
 
 
 def test_layout_constants_agree():
