@@ -33,10 +33,12 @@ sys.path.insert(0, ROOT)
 # DESIGN.md "Roofline"): the minimum live set an ideal kernel must move, not what the kernel happens to touch.
 ALGO_BYTES = {
     "k_sample_random": 44 + 5 + 72 + 4,             # packed masks + own hand + action out + the sort's list entry
-    # fused step: action in (72) + packed masks in/out (44 + 44) + reward/done out (17) + the HOT record read
-    # (112 words x 4 B = 448) + the part of it that an ideal kernel must write back (hands, estimates, control block,
-    # one bitboard word: ~40 words x 4 B = 160)
-    "k_step": 72 + 44 + 44 + 17 + 448 + 160,
+    # fused step: action in (72) + packed masks out (44) + reward/done out (17) + the HOT record read (112 words x 4 B = 448) + the
+    # part of it that an ideal kernel must write back (40 words x 4 B = 160: counters, control block, two hands, nine estimate
+    # words, one bitboard).  static_assert-ed against the layout in csrc/catan_state.h (STEP_ALGO_BYTES) and checked against the
+    # library at run time (catan_step_algorithmic_bytes).  Rounds 1-3 also read the previous masks (44): validate mode now
+    # restates Game.validate_action from the state.
+    "k_step": 72 + 44 + 17 + 448 + 160,
     "k_lr_finish": 0,                               # slow path: priced per REQUEST below (LR_REQUEST_BYTES), not per game
     "k_lr_heavy": 0,
     "k_reset_list": 0,
@@ -47,7 +49,7 @@ ALGO_BYTES = {
 LR_REQUEST_BYTES = 448 + 448 + 28 + 28 + 44 + 17
 FAST_PATH = ("k_sample_random", "k_step")     # the kernels on the timed loop's critical path
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round.sh)
 
 
 def cpu_baseline(sample_envs=16384, sample_steps=2048):
@@ -215,6 +217,8 @@ def main():
 
     from settlers_of_catan_rl_amd.env import VecCatanEnv
 
+    from settlers_of_catan_rl_amd import _lib as _clib
+    assert _clib.lib().catan_step_algorithmic_bytes() == ALGO_BYTES["k_step"], "bench.py's byte table and csrc/catan_state.h disagree"
     env_id0, n = cdist.shard(rank, args.envs)                # global game ids: results do not depend on `world`
     env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0, validate_actions=not args.no_validate, auto_reset=True)
 

@@ -49,6 +49,16 @@ int catan_profile_read(catan_env_t* env, uint64_t* out16);
  * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort) */
 int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
 
+/* Algorithmic HBM bytes of one fused env step per stepped game, from the static_assert-ed layout constants of csrc/catan_state.h
+ * (action row in, hot record in, masks + reward + done out, the ideal write-back): bench.py's roofline numerator. */
+int32_t catan_step_algorithmic_bytes(void);
+/* Which form of the deferred rollout loop catan_random_rollout_deferred runs (results are identical, game for game):
+ *   0 (default)  a sampling + sorting kernel in front of every k_step (rounds 1-3)
+ *   1            fused sampling (round 4): k_step draws each completed game's next action into its side row and enqueues it for
+ *                the next pass; tier 1 forks once per two passes.  Measured at parity: the pass is bound by the
+ *                SIMD time of k_step + the path searches, not by the launches on the main stream. */
+int catan_set_deferred_fused(catan_env_t* env, int32_t on);
+
 #ifdef __cplusplus
 }
 #endif

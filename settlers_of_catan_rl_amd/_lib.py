@@ -146,6 +146,8 @@ _SIGS = {
     "catan_policy_counters": (C.c_int, [_vp, _vp, _vp]),
     "catan_set_policy_counters": (C.c_int, [_vp, _vp, _vp]),
     "catan_set_lr_budgets": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "catan_set_deferred_fused": (C.c_int, [_vp, C.c_int32]),
+    "catan_step_algorithmic_bytes": (C.c_int32, []),
     "catan_set_step_wave_games": (C.c_int, [_vp, C.c_int32]),
     "catan_set_lr_rounds": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "catan_slow_path_counts": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),

@@ -47,6 +47,7 @@ struct catan_env {
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
     int lr_round[2];      // tier-2 iterations per bulk-synchronous round: [0] lock-step, [1] deferred
+    int deferred_fused;   // catan_set_deferred_fused (CATAN_DEFERRED_FUSED at creation)
     int step_games;       // games per k_step wave: 64, 32 or 16 (catan_set_step_wave_games; CATAN_STEP_WAVE_GAMES at creation)
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
     hipEvent_t ev_fork, ev_join;
@@ -345,6 +346,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
+    if (const char* df = getenv("CATAN_DEFERRED_FUSED")) e->deferred_fused = atoi(df) != 0;
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
     HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
@@ -466,9 +468,7 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
 static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    static const int grid_env = getenv("CATAN_LR_GRID") ? atoi(getenv("CATAN_LR_GRID")) : 0;       // (diagnostics)
-    const int grid = grid_env > 0 ? grid_env : LR_GRID;
-    hipLaunchKernelGGL(k_lr_finish, dim3(grid), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on != 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -658,8 +658,8 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
     return CATAN_OK;
 }
 
-// Round 1-3 form of the deferred iteration (CATAN_DEFERRED_LEGACY=1, kept for A/B measurements): a sampling + sorting kernel
-// in front of every k_step, busy tags cleared by it.  Iteration `it` uses tier-1 request list it & 1 with tag
+// The deferred iteration in its round 1-3 form (the default: catan_set_deferred_fused): a sampling + sorting kernel in front of
+// every k_step, busy tags cleared by it.  Iteration `it` uses tier-1 request list it & 1 with tag
 // 2 + (it & 1); window w = it / window uses slot w & 1 with tag 4 + (w & 1).
 static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
     const int fa = (int)(it & 1);
@@ -711,8 +711,7 @@ static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int w
 // lists rotate (pass % 3): k_step(t) reads set t, appends to set t + 1 and zeroes set t + 2, which k_lr_finish(t) and
 // k_step(t + 1) then fill.
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
-    static const bool legacy = getenv("CATAN_DEFERRED_LEGACY") != nullptr && atoi(getenv("CATAN_DEFERRED_LEGACY")) != 0;
-    if (legacy) return deferred_iter_legacy(e, it, iters, window, st, ev);
+    if (!e->deferred_fused) return deferred_iter_legacy(e, it, iters, window, st, ev);
     // Tier 1 is forked once per GROUP of P passes (P = 2): a k_lr_finish launch lasts as long as its slowest search (~45 us next
     // to k_step) whatever the number of requests, the launches of consecutive groups serialise on one side stream, and the games
     // of group g return in the first pass of group g + 2 - with P = 1 the chain k_step -> k_lr_finish -> k_step two passes later
@@ -751,12 +750,10 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     if (glast || last) {
-        static const bool t1_serial = getenv("CATAN_T1_SERIAL") != nullptr;     // (diagnostics: tier 1 on the main stream, no overlap)
+        static const bool t1_serial = getenv("CATAN_T1_SERIAL") != nullptr;     // (diagnostics: tier 1 on the main stream, no overlap: k_step alone)
         hipStream_t fs = t1_serial ? st : e->fstream[ga];
         HIPCHK(hipEventRecord(e->ev_fready[ga], st));
         HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[ga], 0));
-        static const int t1_delay = getenv("CATAN_T1_DELAY_US") ? atoi(getenv("CATAN_T1_DELAY_US")) : 0;
-        if (t1_delay > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, fs, t1_delay * 100);
         r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[1]);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_fdone[ga], fs));
@@ -807,6 +804,12 @@ int catan_set_step_wave_games(catan_env_t* e, int32_t games) {
     return CATAN_OK;
 }
 
+int32_t catan_step_algorithmic_bytes(void) { return STEP_ALGO_BYTES; }
+int catan_set_deferred_fused(catan_env_t* e, int32_t on) {
+    if (!e) return fail(CATAN_EINVAL, "catan_set_deferred_fused: null handle");
+    e->deferred_fused = on != 0;
+    return CATAN_OK;
+}
 int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
     if (!e || lockstep < 1 || deferred < 1) return fail(CATAN_EINVAL, "catan_set_lr_budgets: bad arguments");
     e->lr_budget[0] = lockstep; e->lr_budget[1] = deferred;

@@ -2575,13 +2575,6 @@ __global__ __launch_bounds__(BLOCK) void k_release_window(Ctx c, const u32* __re
         lists[(long)bin * c.N + atomicAdd(&bins[bin], 1u)] = (i32)e;
     }
 }
-// (scheduling aid) one wave that lasts `ticks` of the 100 MHz wall clock: in front of k_lr_finish on its side stream it gives the
-// k_step launched at the same moment a head start, so that all of k_step's workgroups are resident (one wave per SIMD) before
-// the one-game-per-wave searches take the rest of the LDS - otherwise k_step's workgroups trickle in behind them
-__global__ void k_delay(int ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
-}
 // end of a call: the decision counters back into the handle's array (catan_policy_counters), every slow-path tag cleared
 __global__ __launch_bounds__(BLOCK) void k_finish_rollout(Ctx c, const u32* __restrict__ mpk, u32* __restrict__ pctr, u8* __restrict__ busy) {
     const long e = (long)blockIdx.x * BLOCK + threadIdx.x;

@@ -98,6 +98,7 @@ static_assert(B_HOT % 4 == 0 && NB % 4 == 0, "byte fields are packed four per wo
 constexpr int ROWS_HOT = NW + B_HOT / 4;    // 112 words = 7 cache lines
 constexpr int NROWS = NW + NB / 4;          // 169 words used
 constexpr int REC = 176;                    // words per game record (704 B = 11 cache lines)
+constexpr int ACTION_WORDS_C = 18;           // (= ACTION_WORDS below)
 constexpr int TS = 65;                      // LDS tile row stride in words (odd: conflict-free transposition)
 // Per-game SIDE ROW (128 B = one aligned L2 line, two HBM bursts): the packed masks and - inside the deferred rollouts, where the
 // step samples the game's next action itself - that action and the game's decision counter, so that a stepping wave fetches
@@ -106,6 +107,18 @@ constexpr int TS = 65;                      // LDS tile row stride in words (odd
 constexpr int MPK_STRIDE = 32;
 constexpr int ROW_ACT = 12, ROW_CTR = 30, ROW_TAG = 31;
 constexpr int STATE_BYTES_PER_GAME = REC * 4;
+// ALGORITHMIC HBM bytes of one fused env step per stepped game (bench.py roofline): what an ideal k_step must move.
+//   in : the action row (18 words), the HOT record (ROWS_HOT words)
+//   out: the packed masks (11 words), reward float[4] + done byte, and the part of the record a step really changes -
+//        the three counters (W_RNG, W_TURN, W_ACTIONS), the control block (robber .. winner: bytes B_ROBBER .. B_PLAYER-1),
+//        two players' blocks (a trade / steal / monopoly moves cards between two hands), one (observer x label) set of
+//        estimate words per observer of the acting player (3 x 3) and one 64-bit bitboard (a placement)
+constexpr int WB_CONTROL_WORDS = (B_PLAYER - B_ROBBER + 3) / 4;
+constexpr int WB_PLAYER_WORDS = (PB + 3) / 4;
+constexpr int IDEAL_WRITEBACK_WORDS = 3 + WB_CONTROL_WORDS + 2 * WB_PLAYER_WORDS + 9 + 2;
+constexpr int STEP_ALGO_BYTES = ACTION_WORDS_C * 4 + ROWS_HOT * 4 + 11 * 4 + 17 + IDEAL_WRITEBACK_WORDS * 4;
+static_assert(WB_CONTROL_WORDS == 12 && WB_PLAYER_WORDS == 7 && IDEAL_WRITEBACK_WORDS == 40 && STEP_ALGO_BYTES == 741,
+              "restate bench.py / DESIGN.md 6 when the layout changes (round 4: the step no longer reads its previous masks: 785 -> 741)");
 static_assert(NROWS * 4 == 676 && ROWS_HOT == 112 && ROWS_HOT * 4 % 64 == 0 && REC >= NROWS && REC * 4 % 64 == 0,
               "restate DESIGN.md byte table when the layout changes");
 
@@ -124,6 +137,7 @@ enum { R_BRICK = 0, R_WOOD = 1, R_ORE = 2, R_SHEEP = 3, R_WHEAT = 4 };
 constexpr int M0 = 0, M1 = 13, M2 = 175, M3 = 248, M4 = 267, M5 = 272, M6 = 274, M7 = 283, M8 = 289, M9 = 295,
               M10 = 315, M11 = 320, MASK_BITS = 325, MASK_WORDS = 11;
 constexpr int ACTION_WORDS = 18;
+static_assert(ACTION_WORDS == ACTION_WORDS_C, "action words");
 static_assert(ROW_ACT % 4 == 0 && ROW_ACT >= MASK_WORDS && ROW_ACT + ACTION_WORDS == ROW_CTR && ROW_TAG == MPK_STRIDE - 1, "side-row layout");
 constexpr int STATE_WORDS = 736;   // canonical int32 blob (spec.py)
 constexpr int OBS_FLOATS = 1787;

@@ -157,6 +157,10 @@ class VecCatanEnv(object):
         c = None if counters is None else torch.as_tensor(counters, device=self.device).to(torch.int32).contiguous()
         _lib.check(self.L.catan_set_policy_counters(self.h, _ptr(c), _stream()))
 
+    def set_deferred_fused(self, on):
+        """which form of the deferred loop runs (include/catan_hip_tuning.h): results are identical, game for game"""
+        _lib.check(self.L.catan_set_deferred_fused(self.h, int(bool(on))))
+
     def set_lr_budgets(self, lockstep, deferred):
         _lib.check(self.L.catan_set_lr_budgets(self.h, int(lockstep), int(deferred)))
 

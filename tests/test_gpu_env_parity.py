@@ -56,12 +56,14 @@ def test_random_rollout_state_parity(oracle, hip_lib, n, steps, seed):
     assert env.missed_speculation_count() == 0
 
 
-@pytest.mark.parametrize("n,iters,window,seed", [(1024, 3000, 8, 0), (300, 1500, 1, 5), (4096, 2500, 32, 9)])
-def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, seed):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n,iters,window,seed", [(1024, 3000, 8, 0), (300, 1500, 1, 5), (4096, 2500, 32, 9), (2048, 1777, 5, 4)])
+def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, seed, fused):
     """The deferred loop lets games that need the slow path sit out until their window closes.  Every game must still
     follow its lock-step trajectory: after the rollout, game i has taken counters[i] decisions and its state (and masks)
     must equal the oracle's after exactly that many decisions of the same policy stream."""
     env = _env(n, seed)
+    env.set_deferred_fused(fused)       # both forms of the loop (catan_hip_tuning.h): the sampler kernel, or k_step drawing the next action itself
     ob = oracle.OracleBatch(n, seed)
     total = np.zeros(n, dtype=np.int64)
     for chunk in (window + 3, iters - window - 3):              # two calls: the counters continue across calls
@@ -85,10 +87,11 @@ def test_deferred_rollout_is_reproducible(hip_lib):
     (dfs_consider<true>), not the first one some lane happened to find - with that, 7-11 of 65 536 games used to end a rollout a
     window or two of decisions apart (which later requests overflow depends on the cached vertex set)."""
     import torch
-    for n, iters, window, budget in ((16384, 1500, 32, 4), (4096, 1200, 8, 12)):
+    for n, iters, window, budget, fused in ((16384, 1500, 32, 4, False), (4096, 1200, 8, 12, False), (16384, 1500, 32, 4, True)):
         outs = []
         for rep in range(2):
             env = _env(n, 3)
+            env.set_deferred_fused(fused)
             env.set_lr_budgets(16, budget)
             env.random_rollout_deferred(iters, window)
             torch.cuda.synchronize()
@@ -321,9 +324,15 @@ def test_shard_invariance_through_work(hip_lib):
     got = torch.cat([e.export_state() for e in parts]).cpu().numpy()
     _assert_blobs_equal(got, whole.export_state().cpu().numpy(), "8 x 8 192 games vs 65 536 after 600 lock-step steps")
     assert torch.equal(torch.cat([e.get_action_masks() for e in parts]), whole.get_action_masks())
-    whole.set_policy_counters(); whole.random_rollout_deferred(1536, 32)
+    for fused in (False, True):
+        _shard_deferred(whole, parts, fused)
+
+
+def _shard_deferred(whole, parts, fused):
+    import torch
+    whole.set_deferred_fused(fused); whole.set_policy_counters(); whole.random_rollout_deferred(1536, 32)
     for e in parts:
-        e.set_policy_counters(); e.random_rollout_deferred(1536, 32)
+        e.set_deferred_fused(fused); e.set_policy_counters(); e.random_rollout_deferred(1536, 32)
     cw = whole.policy_counters().cpu().numpy()
     cp = torch.cat([e.policy_counters() for e in parts]).cpu().numpy()
     assert np.array_equal(cp, cw), f"{int((cp != cw).sum())} games took a different number of decisions in their shard"

@@ -1,3 +1,5 @@
+"""Diagnostics: the deferred loop in both forms (CATAN_DEFERRED_FUSED=0/1 at creation), us per pass, executed steps per second, per-kernel event times.
+TAG / WINDOW / BUDGET from the environment."""
 import time, torch, sys, os
 sys.path.insert(0, "/root/repo")
 from settlers_of_catan_rl_amd.env import VecCatanEnv
