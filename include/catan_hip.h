@@ -78,6 +78,31 @@ int catan_reset(catan_env_t* env, const uint8_t* reset_mask, catan_stream_t stre
  * finished games; then the next legal-action masks are refreshed (kept packed inside the handle). */
 int catan_step(catan_env_t* env, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream);
 
+/* EnvWrapper.step(action) for collectors that advance every env independently (RL/ppo/game_manager.py:78-113: each env of a
+ * worker steps on its own; nothing there waits for the slowest env).  catan_step completes every game's step before it returns -
+ * its duration is that of the slowest longest-road search or re-deal among n games.  catan_step_deferred applies the same
+ * actions, but a game whose step needs that slow path (Game.update_longest_road after a road / settlement, game/game.py:864-919;
+ * the reset of a finished game) completes it on side streams while the other games go on, and WAITS meanwhile:
+ *     status[g] = CATAN_STEP_COMPLETE  reward[g][4] / done[g] are the result of the game's last applied action (for a game that
+ *                                      waited: the action it was given when it started waiting), its state, masks and
+ *                                      observation are current, and it takes actions[g] of the next call;
+ *     status[g] = CATAN_STEP_WAITING   the step is still being completed: reward / done are 0, the game's state must not be
+ *                                      read, and actions[g] of the next call is ignored (not counted as invalid).
+ * Each game goes through exactly the states catan_step would take it through for the same sequence of applied actions; only
+ * the interleaving between games differs (tests/test_gpu_env_parity.py).  Which games wait, and for how long, is fixed by the
+ * schedule (`window` calls per slow-path window: a longest-road game returns after 2 calls, a game that needed the second
+ * search tier or a reset after 1-2 windows), never by kernel timing: a sequence is reproducible.
+ * A sequence of calls (same window, same stream) is closed by catan_step_flush, which completes every outstanding step:
+ * status CATAN_STEP_COMPLETE + reward / done for the games that were waiting, CATAN_STEP_NONE (reward / done 0) for the others.
+ * While a sequence is open, catan_step / reset / state_export / state_import / random_rollout* / randomise_uncertainty
+ * return CATAN_EINVAL; catan_masks / obs / obs_rows / deciding_seat are valid for the games that are not waiting.
+ * With catan_set_reward_f64_buffer the unrounded rewards of a game are written when its step completes (read them for
+ * CATAN_STEP_COMPLETE games only).  status: uint8 [n]. */
+enum { CATAN_STEP_COMPLETE = 0, CATAN_STEP_WAITING = 1, CATAN_STEP_NONE = 2 };
+int catan_step_deferred(catan_env_t* env, const int32_t* actions, int32_t window, float* reward, uint8_t* done, uint8_t* status,
+                        catan_stream_t stream);
+int catan_step_flush(catan_env_t* env, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream);
+
 /* EnvWrapper.get_action_masks(): env/wrapper.py:168-290, batched float32 [n][325]. */
 int catan_masks(catan_env_t* env, float* out_masks, catan_stream_t stream);
 /* the same masks as 325-bit strings: uint32 [n][pitch], pitch = 16 words (bit i of the flat mask = word i>>5, bit i&31) */

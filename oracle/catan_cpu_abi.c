@@ -21,6 +21,12 @@ struct catan_env {
     OrcEnv* envs;
     int64_t invalid;
     double* reward64;
+    /* catan_step_deferred / catan_step_flush */
+    int64_t d_it; int32_t d_window;
+    int32_t* wait;      /* [n] calls a game still waits (0: not waiting) */
+    float* held_r;      /* [n][4] / [n]: the withheld result of a waiting game's step */
+    uint8_t* held_d;
+    double* held_r64;   /* [n][4] */
 };
 
 static _Thread_local const char* g_err = "";
@@ -61,11 +67,13 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     *out = e;
     return CATAN_OK;
 }
-void catan_destroy(catan_env_t* e) { if (e) { free(e->envs); free(e); } }
+void catan_destroy(catan_env_t* e) { if (e) { free(e->envs); free(e->wait); free(e->held_r); free(e->held_d); free(e->held_r64); free(e); } }
 
+#define NOT_DEFERRED(e, msg) do { if ((e) && (e)->d_it > 0) return fail(CATAN_EINVAL, msg ": a deferred step sequence is open (call catan_step_flush first)"); } while (0)
 int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
     (void)stream;
     if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
+    NOT_DEFERRED(e, "catan_reset");
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < e->n; i++) if (!reset_mask || reset_mask[i]) orc_game_reset(&e->envs[i]);
     return CATAN_OK;
@@ -74,6 +82,7 @@ int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
     (void)stream;
     if (!e || !actions || !reward || !done) return fail(CATAN_EINVAL, "catan_step: null argument");
+    NOT_DEFERRED(e, "catan_step");
     int64_t bad = 0;
 #pragma omp parallel for schedule(static) reduction(+ : bad)
     for (int64_t i = 0; i < e->n; i++) {
@@ -90,6 +99,76 @@ int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* d
         if (d && e->cfg.auto_reset) orc_game_reset(&e->envs[i]);
     }
     e->invalid += bad;
+    return CATAN_OK;
+}
+
+/* The deferred step protocol of include/catan_hip.h on the CPU.  The oracle has no slow path to overlap with anything, so every
+ * step is applied at once; what this implementation reproduces is the PROTOCOL a caller has to handle: the result of a step
+ * that placed a road or a settlement is withheld for one more call, that of a step that ended the game until the call before the
+ * one that opens the window after next (the device library's schedule; there, which longest-road updates wait depends on its path cache), and a
+ * waiting game ignores the actions it is passed.  Unlike on the device the state of a waiting game is already current here. */
+int catan_step_deferred(catan_env_t* e, const int32_t* actions, int32_t window, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !actions || !reward || !done || !status || window <= 0) return fail(CATAN_EINVAL, "catan_step_deferred: bad arguments");
+    if (e->d_it > 0 && window != e->d_window) return fail(CATAN_EINVAL, "catan_step_deferred: window and stream must stay the same between two flushes");
+    if (!e->wait) {
+        e->wait = (int32_t*)calloc((size_t)e->n, sizeof(int32_t)); e->held_r = (float*)calloc((size_t)e->n * 4, sizeof(float));
+        e->held_d = (uint8_t*)calloc((size_t)e->n, 1); e->held_r64 = (double*)calloc((size_t)e->n * 4, sizeof(double));
+        if (!e->wait || !e->held_r || !e->held_d || !e->held_r64) return fail(CATAN_ENOMEM, "catan_step_deferred: out of memory");
+    }
+    const int64_t it = e->d_it;
+    e->d_window = window;
+    /* calls from this one to the one that opens the window after next */
+    const int32_t to_window = (int32_t)((it / window + 2) * window - it);
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t i = 0; i < e->n; i++) {
+        const int32_t* a = actions + i * 18;
+        float* r = reward + i * 4;
+        r[0] = r[1] = r[2] = r[3] = 0.0f; done[i] = 0;
+        if (e->wait[i] > 0) {                                             /* waiting: the action is ignored */
+            if (--e->wait[i] > 0) { status[i] = CATAN_STEP_WAITING; continue; }
+            memcpy(r, e->held_r + i * 4, 4 * sizeof(float)); done[i] = e->held_d[i];
+            if (e->reward64) memcpy(e->reward64 + i * 4, e->held_r64 + i * 4, 4 * sizeof(double));
+            status[i] = CATAN_STEP_COMPLETE;
+            continue;
+        }
+        status[i] = CATAN_STEP_COMPLETE;
+        if (e->reward64) memset(e->reward64 + i * 4, 0, 4 * sizeof(double));
+        if (a[0] < 0) continue;                                           /* explicit no-op */
+        if (e->cfg.validate_actions && !orc_action_is_legal(&e->envs[i], a)) { bad++; continue; }
+        int d = 0;
+        float rr[4];
+        orc_step(&e->envs[i], a, rr, &d);
+        const int slow = d ? to_window - 1 : ((a[0] == 0 || a[0] == 1) ? 1 : 0);   /* BuildSettlement 0 / BuildRoad 1: Game.update_longest_road */
+        if (slow > 0) {
+            memcpy(e->held_r + i * 4, rr, sizeof rr); e->held_d[i] = (uint8_t)(d != 0);
+            orc_last_reward64(&e->envs[i], e->held_r64 + i * 4);
+            e->wait[i] = slow; status[i] = CATAN_STEP_WAITING;
+        } else {
+            memcpy(r, rr, sizeof rr);
+            if (e->reward64) orc_last_reward64(&e->envs[i], e->reward64 + i * 4);
+        }
+        if (d && e->cfg.auto_reset) orc_game_reset(&e->envs[i]);
+    }
+    e->invalid += bad;
+    e->d_it = it + 1;
+    return CATAN_OK;
+}
+
+int catan_step_flush(catan_env_t* e, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream) {
+    (void)stream;
+    if (!e || !reward || !done || !status) return fail(CATAN_EINVAL, "catan_step_flush: null argument");
+    for (int64_t i = 0; i < e->n; i++) {
+        float* r = reward + i * 4;
+        r[0] = r[1] = r[2] = r[3] = 0.0f; done[i] = 0; status[i] = CATAN_STEP_NONE;
+        if (e->wait && e->wait[i] > 0) {
+            memcpy(r, e->held_r + i * 4, 4 * sizeof(float)); done[i] = e->held_d[i];
+            if (e->reward64) memcpy(e->reward64 + i * 4, e->held_r64 + i * 4, 4 * sizeof(double));
+            e->wait[i] = 0; status[i] = CATAN_STEP_COMPLETE;
+        }
+    }
+    e->d_it = 0;
     return CATAN_OK;
 }
 
@@ -128,6 +207,7 @@ int catan_obs(catan_env_t* e, float* out_f, int32_t* out_lists, int32_t* out_len
 int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
     (void)stream;
     if (!e || !blob || cnt <= 0) return fail(CATAN_EINVAL, "catan_state_export: bad arguments");
+    NOT_DEFERRED(e, "catan_state_export");
     int32_t tmp[ORC_STATE_WORDS];
     for (int64_t k = 0; k < cnt; k++) {
         const int64_t i = env_idx ? env_idx[k] : k;
@@ -140,6 +220,7 @@ int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, in
 int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
     (void)stream;
     if (!e || !blob || cnt <= 0) return fail(CATAN_EINVAL, "catan_state_import: bad arguments");
+    NOT_DEFERRED(e, "catan_state_import");
     int32_t tmp[ORC_STATE_WORDS];
     for (int64_t k = 0; k < cnt; k++) {
         const int64_t i = env_idx ? env_idx[k] : k;
@@ -153,6 +234,7 @@ int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_i
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     (void)stream;
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
+    NOT_DEFERRED(e, "catan_randomise_uncertainty");
     for (int64_t i = 0; i < e->n; i++)
         if (controlling_player[i] >= 1 && controlling_player[i] <= 4) orc_randomise_uncertainty(&e->envs[i], controlling_player[i]);
     return CATAN_OK;

@@ -1412,6 +1412,36 @@ int64_t orc_batch_run_random_counts(OrcEnv* envs, int64_t n, uint64_t seed, uint
     return total;
 }
 
+/* One decision of the games with play[i] != 0: the random policy's action number counts[i] (drawn from the game's own masks) is
+ * written to actions[i] and applied (reward[i][4] as float and as the unrounded doubles, done[i]; a finished game is reset),
+ * counts[i] is advanced; the other games are left alone (actions[i] zeroed).  A host-side policy stub + shadow env for callers
+ * that supply the actions themselves (tests of catan_step_deferred, where the set of playing games changes from call to call). */
+int64_t orc_batch_play(OrcEnv* envs, int64_t n, uint64_t seed, uint64_t env_id0, uint32_t* counts, const uint8_t* play, int32_t* actions,
+                       float* reward, double* reward64, uint8_t* done, int n_threads) {
+    int64_t played = 0;
+    orc_topology();
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : played)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        int32_t* a = actions + i * ORC_ACTION_WORDS;
+        memset(a, 0, ORC_ACTION_WORDS * sizeof(int32_t));
+        if (!play[i]) continue;
+        float m[ORC_MASK_WORDS];
+        int d = 0;
+        orc_masks(&envs[i], m);
+        orc_sample_action(&envs[i], seed, env_id0 + (uint64_t)i, counts[i], m, a);
+        orc_step(&envs[i], a, reward + i * 4, &d);
+        orc_last_reward64(&envs[i], reward64 + i * 4);
+        done[i] = (uint8_t)(d != 0);
+        if (d) orc_game_reset(&envs[i]);
+        counts[i]++; played++;
+    }
+    (void)n_threads;
+    return played;
+}
+
 /* ====================================================================== forward search: randomise_uncertainty */
 /* ref: game/game.py:1207-1282.  Re-deals everything the controlling player cannot see: the dev-card pile and the other
  * players' hidden cards are pooled, shuffled (np.random.shuffle) and dealt back (popped from the right end, players in dict

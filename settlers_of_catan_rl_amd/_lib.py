@@ -101,6 +101,8 @@ _SIGS = {
     "catan_num_envs": (C.c_int64, [_vp]),
     "catan_reset": (C.c_int, [_vp, _vp, _vp]),
     "catan_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "catan_step_deferred": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "catan_step_flush": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "catan_masks": (C.c_int, [_vp, _vp, _vp]),
     "catan_masks_packed": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "catan_expand_masks": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),

@@ -59,6 +59,10 @@ struct catan_env {
     hipEvent_t ev_sdone[2];
     float* s_reward;      // outputs of the completions that run on sstream (scratch)
     u8* s_done;
+    // catan_step_deferred / catan_step_flush: the deferred schedule for caller-supplied actions
+    int64_t d_it;         // calls since the last flush (0: no deferred sequence is open)
+    int d_window;         // its window length
+    hipStream_t d_stream; // ... and the caller's stream (one stream per sequence)
 };
 
 constexpr int DEFAULT_STEP_WAVE_GAMES = 64;   // games per k_step wave (catan_set_step_wave_games)
@@ -406,8 +410,11 @@ void catan_destroy(catan_env_t* e) {
     delete e;
 }
 
+static int deferred_open_error(const catan_env_t* e, const char* what);
+#define NOT_DEFERRED(e, what) do { int r_ = deferred_open_error(e, what); if (r_ != CATAN_OK) return r_; } while (0)
 int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
     if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
+    NOT_DEFERRED(e, "catan_reset");
     hipLaunchKernelGGL(k_reset, dim3((unsigned)(e->N < 16384 ? e->N : 16384)), dim3(64), 0, S(stream), e->ctx, reset_mask);
     HIPCHK(hipGetLastError());
     return launch_masks(e, S(stream));
@@ -551,6 +558,7 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
 
 int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, catan_stream_t stream) {
     if (!e || !actions || !reward || !done) return fail(CATAN_EINVAL, "catan_step: null argument");
+    NOT_DEFERRED(e, "catan_step");
     return step_impl(e, const_cast<int32_t*>(actions), reward, done, S(stream));
 }
 
@@ -616,6 +624,7 @@ int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* acti
 
 int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
     if (!e || !blob || cnt <= 0 || (!env_idx && cnt > e->n)) return fail(CATAN_EINVAL, "catan_state_export: bad arguments");
+    NOT_DEFERRED(e, "catan_state_export");
     hipLaunchKernelGGL(k_export, dim3(blocks(cnt, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, (const long*)env_idx, (long)cnt, blob);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -623,6 +632,7 @@ int catan_state_export(catan_env_t* e, int32_t* blob, const int64_t* env_idx, in
 
 int catan_state_import(catan_env_t* e, const int32_t* blob, const int64_t* env_idx, int64_t cnt, catan_stream_t stream) {
     if (!e || !blob || cnt <= 0 || (!env_idx && cnt > e->n)) return fail(CATAN_EINVAL, "catan_state_import: bad arguments");
+    NOT_DEFERRED(e, "catan_state_import");
     hipLaunchKernelGGL(k_import, dim3(blocks(cnt, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, (const long*)env_idx, (long)cnt, blob);
     HIPCHK(hipGetLastError());
     return launch_masks(e, S(stream));
@@ -650,6 +660,7 @@ int64_t catan_invalid_action_count(catan_env_t* e, catan_stream_t stream) {
 
 int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, catan_stream_t stream) {
     if (!e || steps < 0) return fail(CATAN_EINVAL, "catan_random_rollout: bad arguments");
+    NOT_DEFERRED(e, "catan_random_rollout");
     for (int64_t s = 0; s < steps; s++) {
         const uint32_t step_idx = step_idx0 + (uint32_t)s;
         int r = step_impl(e, e->scratch_actions, e->scratch_reward, e->scratch_done, S(stream), nullptr, &step_idx);
@@ -778,10 +789,91 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
 
 int catan_random_rollout_deferred(catan_env_t* e, int64_t iters, int32_t window, catan_stream_t stream) {
     if (!e || iters < 0 || window <= 0) return fail(CATAN_EINVAL, "catan_random_rollout_deferred: bad arguments");
+    NOT_DEFERRED(e, "catan_random_rollout_deferred");
     for (int64_t it = 0; it < iters; it++) {
         int r = deferred_iter(e, it, iters, window, S(stream), nullptr);
         if (r != CATAN_OK) return r;
     }
+    return CATAN_OK;
+}
+
+// ---- the deferred schedule for caller-supplied actions.  Call `it` of a sequence is iteration `it` of deferred_iter_legacy with
+// k_classify_deferred in the sampler's place; what differs is WHEN the waiting games are released: at the end of the call before
+// the one they play in again (k_deliver), not at its start - the caller needs their completed state (observation, masks) to choose
+// the action it passes to that call.  Every kernel writes a step's reward / done into the handle's result rows (f_reward /
+// f_done: one row per game, written by whichever kernel completes the game's step); k_deliver hands them over.
+static int deferred_open_error(const catan_env_t* e, const char* what) {
+    if (e && e->d_it > 0) return fail(CATAN_EINVAL, std::string(what) + ": a deferred step sequence is open (call catan_step_flush first)");
+    return CATAN_OK;
+}
+int catan_step_deferred(catan_env_t* e, const int32_t* actions, int32_t window, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream) {
+    if (!e || !actions || !reward || !done || !status || window <= 0) return fail(CATAN_EINVAL, "catan_step_deferred: bad arguments");
+    hipStream_t st = S(stream);
+    if (e->d_it > 0 && (window != e->d_window || st != e->d_stream))
+        return fail(CATAN_EINVAL, "catan_step_deferred: window and stream must stay the same between two flushes");
+    const int64_t it = e->d_it;
+    const int fa = (int)(it & 1);
+    const int64_t w = it / window;
+    const int sa = (int)(w & 1);
+    const bool opens = it % window == 0, closes = (it + 1) % window == 0;
+    e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
+    e->d_window = window; e->d_stream = st;
+    // (tier 1 of call it-2 and, when this call opens window w, the slow path of window w-2 were joined at the end of call it-1)
+    if (it == 0) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    else if (opens) HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
+    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa; e->pend.bclear = fa ^ 1; e->pend.sample = 0; e->pend.brel = -1;
+    hipLaunchKernelGGL(k_classify_deferred, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, actions, (const u8*)e->pend.busy, e->pend.ctr + 16 + NBINS * fa,
+                       e->pend.lists + (size_t)fa * NBINS * e->N, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa, 1, e->cfg.validate_actions ? e->err : (u32*)nullptr);
+    int r = enqueue_fast(e, actions, e->f_reward, e->f_done, st, nullptr, true);
+    if (r != CATAN_OK) return r;
+    HIPCHK(hipEventRecord(e->ev_fready[fa], st));
+    HIPCHK(hipStreamWaitEvent(e->fstream[fa], e->ev_fready[fa], 0));
+    r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[fa], nullptr, fa, e->lr_budget[1]);
+    if (r != CATAN_OK) return r;
+    HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[fa]));
+    if (closes) {                                              // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
+        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa], 0));
+        if (it >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa ^ 1], 0));
+        r = enqueue_slow(e, e->f_reward, e->f_done, e->sstream, nullptr, LR_HEAVY_GRID_DEFERRED);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_sdone[sa], e->sstream));
+    }
+    // what call it+1 needs: tier 1 of call it-1 complete (its games play again), and - if it opens window w' >= 2 - the slow path of w'-2
+    const int64_t nit = it + 1, nw = nit / window;
+    const bool nopens = nit % window == 0;
+    if (nit >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[nit & 1], 0));
+    if (nopens && nw >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[nw & 1], 0));
+    hipLaunchKernelGGL(k_deliver, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy, nit >= 2 ? 2 + (int)(nit & 1) : 0, (nopens && nw >= 2) ? 4 + (int)(nw & 1) : 0, 0,
+                       (const float*)e->f_reward, (const u8*)e->f_done, reward, done, status);
+    HIPCHK(hipGetLastError());
+    e->d_it = nit;
+    return CATAN_OK;
+}
+
+int catan_step_flush(catan_env_t* e, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream) {
+    if (!e || !reward || !done || !status) return fail(CATAN_EINVAL, "catan_step_flush: null argument");
+    hipStream_t st = S(stream);
+    const int64_t it = e->d_it;
+    if (it > 0) {
+        if (st != e->d_stream) return fail(CATAN_EINVAL, "catan_step_flush: not the stream of the open sequence");
+        const int window = e->d_window;
+        const int64_t lw = (it - 1) / window;                  // the window of the last call
+        if (it % window != 0) {                                // ... is still open: close it (its pend.sa / stag are still set)
+            HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[0], 0));
+            if (it >= 2) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[1], 0));
+            int r = enqueue_slow(e, e->f_reward, e->f_done, e->sstream, nullptr, LR_HEAVY_GRID_DEFERRED);
+            if (r != CATAN_OK) return r;
+            HIPCHK(hipEventRecord(e->ev_sdone[lw & 1], e->sstream));
+        }
+        HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[0], 0));
+        if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[1], 0));
+        HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[lw & 1], 0));
+        if (lw >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[(lw & 1) ^ 1], 0));
+    }
+    hipLaunchKernelGGL(k_deliver, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy, 0, 0, 1, (const float*)e->f_reward, (const u8*)e->f_done, reward, done, status);
+    HIPCHK(hipGetLastError());
+    e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0;
+    e->d_it = 0;
     return CATAN_OK;
 }
 
@@ -1216,6 +1308,7 @@ int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const flo
 
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
+    NOT_DEFERRED(e, "catan_randomise_uncertainty");
     hipLaunchKernelGGL(k_randomise_uncertainty, dim3(blocks(e->n, 64)), dim3(64), 0, S(stream), e->ctx, controlling_player, e->mpk, e->err,
                        100000, limits_of(e));
     HIPCHK(hipGetLastError());

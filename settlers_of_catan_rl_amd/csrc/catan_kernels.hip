@@ -2717,6 +2717,39 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Ctx c, const i32* __restrict
     if (err != nullptr && e < c.n && actions[e * ACTION_WORDS] > 12) atomicAdd(err, 1u);
     sort_append(e, e < c.n, e < c.n ? action_bin(c, actions, e) : BIN_NOOP, hist, base, bins, lists, c.N);
 }
+// ... and for caller-supplied actions under the deferred schedule (catan_step_deferred): a game still waiting for the slow path
+// is in NO list (its action is ignored; k_step must not touch its result row, which a side stream may be writing).
+__global__ __launch_bounds__(BLOCK) void k_classify_deferred(Ctx c, const i32* __restrict__ actions, const u8* __restrict__ busy, u32* __restrict__ bins,
+                                                             i32* __restrict__ lists, u32* __restrict__ zero_me, int zero_n, u32* __restrict__ err) {
+    __shared__ u32 hist[NBINS], base[NBINS];
+    if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (zero_me != nullptr && e < zero_n) zero_me[e] = 0;
+    const bool plays = e < c.n && busy[e] == 0;
+    if (err != nullptr && plays && actions[e * ACTION_WORDS] > 12) atomicAdd(err, 1u);
+    sort_append(e, plays, plays ? action_bin(c, actions, e) : BIN_NOOP, hist, base, bins, lists, c.N);
+}
+// End of a catan_step_deferred call (the side work whose games return in the NEXT call has been joined): those games are
+// released (tags tag_a / tag_b; release_all: catan_step_flush), and every game that is not waiting any more hands its step's
+// result - written into the handle's result rows by whichever kernel completed the step - to the caller.
+//   status 0: step complete (reward / done valid, state and masks current); 1: waiting (reward / done zero);
+//   flush only: 2 = nothing was outstanding for this game (reward / done zero).
+__global__ __launch_bounds__(BLOCK) void k_deliver(Ctx c, u8* __restrict__ busy, int tag_a, int tag_b, int release_all, const float* __restrict__ res_reward,
+                                                   const u8* __restrict__ res_done, float* __restrict__ reward, u8* __restrict__ done, u8* __restrict__ status) {
+    const long e = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= c.n) return;
+    int b = busy[e];
+    const bool was_waiting = b != 0;
+    if (b != 0 && (release_all || (b >= 2 && (b == tag_a || b == tag_b)))) { busy[e] = 0; b = 0; }
+    const bool deliver = b == 0 && (!release_all || was_waiting);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    u8 d = 0;
+    if (deliver) { r = *reinterpret_cast<const float4*>(res_reward + e * 4); d = res_done[e]; }
+    *reinterpret_cast<float4*>(reward + e * 4) = r;
+    done[e] = d;
+    status[e] = b != 0 ? 1 : (deliver ? 0 : 2);
+}
 constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per bin (the no-op bin comes last)
 
 // ------------------------------------------------------------------------------------------------ random policy (kernel)

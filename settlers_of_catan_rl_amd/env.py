@@ -91,6 +91,29 @@ class VecCatanEnv(object):
         _lib.check(self.L.catan_step(self.h, _ptr(a), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.reward, self.done
 
+    STEP_COMPLETE, STEP_WAITING, STEP_NONE = 0, 1, 2       # include/catan_hip.h
+
+    def step_deferred(self, actions, window=32):
+        """catan_step_deferred (include/catan_hip.h): the same actions as `step`, but a game whose step needs the slow path
+        (longest road, re-deal) completes it on side streams and WAITS meanwhile.  Returns (reward, done, status): status[g] == 0:
+        reward / done are the result of game g's last applied action and its state is current; 1: game g is waiting (its entry
+        of the next call's actions is ignored, its state must not be read).  `step_flush()` closes the sequence."""
+        a = actions if (actions.dtype == torch.int32 and actions.is_contiguous() and actions.device == self.device) else \
+            actions.to(device=self.device, dtype=torch.int32).contiguous()
+        assert a.shape == (self.n, spec.ACTION_WORDS), a.shape
+        if getattr(self, "status", None) is None:
+            self.status = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.catan_step_deferred(self.h, _ptr(a), int(window), _ptr(self.reward), _ptr(self.done), _ptr(self.status), _stream()))
+        return self.reward, self.done, self.status
+
+    def step_flush(self):
+        """catan_step_flush: completes every outstanding deferred step.  status 0: a game that was waiting (reward / done valid);
+        2: nothing was outstanding for it."""
+        if getattr(self, "status", None) is None:
+            self.status = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.catan_step_flush(self.h, _ptr(self.reward), _ptr(self.done), _ptr(self.status), _stream()))
+        return self.reward, self.done, self.status
+
     def get_action_masks(self, out=None):
         """float32 [n][325]; slice with spec.MASK_OFFSETS / MASK_SHAPES for the 12 heads."""
         if out is None:

@@ -15,7 +15,8 @@ CPU_LIB = os.path.join(ROOT, "oracle", "libcatan_cpu.so")
 ENTRY_POINTS = ["catan_cfg_default", "catan_state_words", "catan_mask_words", "catan_action_words", "catan_obs_floats", "catan_create", "catan_destroy",
                 "catan_last_error", "catan_build_hash", "catan_num_envs", "catan_reset", "catan_step", "catan_masks", "catan_deciding_seat",
                 "catan_players_turn_sim", "catan_obs", "catan_state_export", "catan_state_import", "catan_randomise_uncertainty",
-                "catan_set_reward_annealing", "catan_set_reward_f64_buffer", "catan_invalid_action_count", "catan_sample_random_actions"]
+                "catan_set_reward_annealing", "catan_set_reward_f64_buffer", "catan_invalid_action_count", "catan_sample_random_actions",
+                "catan_step_deferred", "catan_step_flush"]
 
 
 def cpu_lib():
@@ -29,7 +30,8 @@ def cpu_lib():
     for name, args in (("catan_reset", [vp, vp, vp]), ("catan_step", [vp] * 5), ("catan_masks", [vp] * 3), ("catan_deciding_seat", [vp] * 3),
                        ("catan_obs", [vp] * 5), ("catan_state_export", [vp, vp, vp, C.c_int64, vp]), ("catan_state_import", [vp, vp, vp, C.c_int64, vp]),
                        ("catan_randomise_uncertainty", [vp] * 3), ("catan_sample_random_actions", [vp, C.c_uint32, vp, vp]),
-                       ("catan_set_reward_annealing", [vp, C.c_double])):
+                       ("catan_set_reward_annealing", [vp, C.c_double]), ("catan_set_reward_f64_buffer", [vp, vp]),
+                       ("catan_step_deferred", [vp, vp, C.c_int32, vp, vp, vp, vp]), ("catan_step_flush", [vp] * 5)):
         getattr(L, name).argtypes = args
     L.catan_invalid_action_count.argtypes = [vp, vp]; L.catan_invalid_action_count.restype = C.c_int64
     return L
@@ -81,6 +83,127 @@ def drive(L, n, seed, steps, alloc, to_numpy, stream=None, dense=False, illegal_
     out["masks_after_import"] = to_numpy(masks).copy()
     L.catan_destroy(h2); L.catan_destroy(h)
     return out
+
+
+def drive_deferred(L, oracle, n, seed, calls, window, alloc, to_numpy, stream=None, dense=False, illegal_every=11, flush_every=0):
+    """The deferred step protocol of include/catan_hip.h (catan_step_deferred / catan_step_flush) with caller-supplied actions: a
+    host-side policy stub draws, for every game that is not waiting, the uniform-random legal action number `k` of that game
+    (k = the game's own decision count) from the masks the LIBRARY reports - orc_sample_action, the rule of the bench's random
+    policy - so the action a game is given does not depend on when it is scheduled.  An oracle shadow of every game applies the
+    same actions; checked as the calls go: a waiting game reports zero reward / done, every result that is delivered equals the
+    shadow's for the action it belongs to (float rewards, the unrounded doubles, done), the masks and deciding seats of the
+    games that are not waiting equal the shadow's, illegal actions (every `illegal_every`-th call, games 0 .. n/8) and no-ops are
+    handled as catan_step handles them, and after the flush the exported states equal the shadow's word for word.
+    Returns counts for the caller's own asserts."""
+    import numpy as np
+    cfg = CatanCfg()
+    L.catan_cfg_default(C.byref(cfg))
+    cfg.dense_reward = int(dense)
+    h = C.c_void_p()
+    env_id0 = 500
+    assert L.catan_create(C.byref(h), 0, n, seed, env_id0, C.byref(cfg)) == 0, L.catan_last_error()
+    p = lambda b: C.c_void_p(b.data_ptr())
+    st = C.c_void_p(stream) if stream is not None else None
+    acts = alloc((n, 18), np.int32); rew = alloc((n, 4), np.float32); done = alloc((n,), np.uint8); status = alloc((n,), np.uint8)
+    r64 = alloc((n, 4), np.float64)
+    masks = alloc((n, 325), np.float32); seat = alloc((n,), np.int32); blob = alloc((736, n), np.int32)
+    assert L.catan_set_reward_f64_buffer(h, p(r64)) == 0
+    ob = oracle.OracleBatch(n, seed, env_id0=env_id0)
+    ob.set_config(dense_reward=dense)
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    cnt = np.zeros(n, dtype=np.int64)                  # decisions drawn per game
+    waiting = np.zeros(n, dtype=bool)
+    expect = {}                                        # game -> (reward, reward64, done) of its outstanding step
+    stats = dict(applied=0, waited=0, delivered_late=0, finished=0, rejected=0, flushes=0, max_wait=0)
+    wait_len = np.zeros(n, dtype=np.int64)
+
+    def check_delivered(i, r, d, r6):
+        er, er6, ed = expect.pop(i)
+        assert np.array_equal(r, er) and bool(d) == ed and np.array_equal(r6, er6), (i, r, er, d, ed)
+
+    def check_views():
+        assert L.catan_masks(h, p(masks), st) == 0 and L.catan_deciding_seat(h, p(seat), st) == 0
+        m, s_ = to_numpy(masks), to_numpy(seat)
+        om = ob.masks()
+        ok = ~waiting
+        assert np.array_equal(m[ok], om[ok])
+        assert np.array_equal(s_[ok], np.array([ob.L.orc_deciding_player(ob.env_ptr(i)) for i in range(n)])[ok])
+        return m
+
+    m = check_views()
+    for t in range(calls):
+        a = np.zeros((n, 18), dtype=np.int32)
+        corrupt = illegal_every and t % illegal_every == illegal_every - 1
+        for i in range(n):
+            if waiting[i]:
+                a[i, 0] = 3 + (t + i) % 9             # whatever: the library must ignore it
+                continue
+            ai = np.zeros(18, dtype=np.int32)
+            ob.L.orc_sample_action(ob.env_ptr(i), seed + 7, env_id0 + i, int(cnt[i]), m[i].ctypes.data_as(f32p), ai.ctypes.data_as(i32p))
+            if corrupt and i < max(1, n // 8):
+                ai[0] = 9 if t % 2 else 10           # RollDice / EndTurn whatever the phase: mostly illegal
+            if corrupt and i == n - 1:
+                ai[0] = -1                             # explicit no-op
+            a[i] = ai
+            er, er6, ed = np.zeros(4, dtype=np.float32), np.zeros(4, dtype=np.float64), False
+            if ai[0] >= 0 and ob.L.orc_action_is_legal(ob.env_ptr(i), ai.ctypes.data_as(i32p)):
+                d = C.c_int(0)
+                ob.L.orc_step(ob.env_ptr(i), ai.ctypes.data_as(i32p), er.ctypes.data_as(f32p), C.byref(d))
+                ob.L.orc_last_reward64(ob.env_ptr(i), er6.ctypes.data_as(C.POINTER(C.c_double)))
+                ed = bool(d.value)
+                if ed:
+                    ob.L.orc_game_reset(ob.env_ptr(i)); stats["finished"] += 1
+                cnt[i] += 1; stats["applied"] += 1
+            elif ai[0] >= 0:
+                stats["rejected"] += 1
+                cnt[i] += 1                            # (the draw was spent; the next one differs)
+            expect[i] = (er, er6, ed)
+        _fill(acts, a)
+        assert L.catan_step_deferred(h, p(acts), window, p(rew), p(done), p(status), st) == 0, L.catan_last_error()
+        r, d, s_, r6 = to_numpy(rew).copy(), to_numpy(done).copy(), to_numpy(status).copy(), to_numpy(r64).copy()
+        assert set(np.unique(s_)) <= {0, 1}
+        for i in range(n):
+            if s_[i] == 1:
+                assert not r[i].any() and d[i] == 0, (t, i)
+                assert i in expect                     # a waiting game has an outstanding step
+                if not waiting[i]: stats["waited"] += 1
+                wait_len[i] += 1
+            else:
+                if waiting[i]: stats["delivered_late"] += 1
+                stats["max_wait"] = max(stats["max_wait"], int(wait_len[i])); wait_len[i] = 0
+                check_delivered(i, r[i], d[i], r6[i])
+        waiting = s_ == 1
+        m = check_views()
+        if flush_every and t % flush_every == flush_every - 1:
+            assert L.catan_step_flush(h, p(rew), p(done), p(status), st) == 0
+            r, d, s_, r6 = to_numpy(rew).copy(), to_numpy(done).copy(), to_numpy(status).copy(), to_numpy(r64).copy()
+            for i in range(n):
+                assert s_[i] == (0 if waiting[i] else 2), (t, i, s_[i])
+                if waiting[i]: check_delivered(i, r[i], d[i], r6[i])
+                else: assert not r[i].any() and d[i] == 0
+            waiting[:] = False; wait_len[:] = 0
+            stats["flushes"] += 1
+            m = check_views()
+            assert L.catan_state_export(h, p(blob), None, n, st) == 0
+            assert np.array_equal(to_numpy(blob).T, ob.export()), f"states after the flush of call {t}"
+    # an open sequence refuses the lock-step entry points; the flush closes it
+    if calls and not (flush_every and calls % flush_every == 0):
+        assert L.catan_step(h, p(acts), p(rew), p(done), st) != 0 and b"catan_step_flush" in L.catan_last_error()
+        assert L.catan_state_export(h, p(blob), None, n, st) != 0
+    assert L.catan_step_flush(h, p(rew), p(done), p(status), st) == 0
+    r, d, s_, r6 = to_numpy(rew).copy(), to_numpy(done).copy(), to_numpy(status).copy(), to_numpy(r64).copy()
+    for i in range(n):
+        assert s_[i] == (0 if waiting[i] else 2)
+        if waiting[i]: check_delivered(i, r[i], d[i], r6[i])
+    assert not expect
+    waiting[:] = False
+    check_views()
+    assert L.catan_state_export(h, p(blob), None, n, st) == 0
+    assert np.array_equal(to_numpy(blob).T, ob.export()), "states after the final flush"
+    stats["invalid"] = int(L.catan_invalid_action_count(h, st))
+    stats["decisions"] = cnt.copy()
+    L.catan_destroy(h)
+    return stats
 
 
 def _fill(buf, arr):

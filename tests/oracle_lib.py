@@ -58,6 +58,9 @@ def lib():
         u32p = C.POINTER(C.c_uint32)
         L.orc_batch_run_random_counts.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, u32p, u32p, i32p, i64p, C.c_int]
         L.orc_batch_run_random_counts.restype = C.c_int64
+        L.orc_batch_play.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint64, u32p, C.POINTER(C.c_uint8), i32p, f32p, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_uint8), C.c_int]
+        L.orc_batch_play.restype = C.c_int64
         L.orc_randomise_uncertainty.argtypes = [vp, C.c_int]
         L.orc_randomise_uncertainty.restype = C.c_int
         L.orc_gae.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int64, C.c_double, C.c_double, f32p, f32p]
@@ -195,6 +198,11 @@ class OracleBatch(object):
                                            _p(start, C.c_uint32) if start is not None else None, _p(counts, C.c_uint32),
                                            _p(blobs, C.c_int32), C.byref(self.games), n_threads)
         return blobs
+
+    def play(self, counts, play, actions, reward, reward64, done, n_threads=0):
+        """orc_batch_play: one decision (number counts[i], advanced) of the games with play[i]; fills actions / reward / reward64 / done rows"""
+        return self.L.orc_batch_play(self.p, self.n, self.seed, self.env_id0, _p(counts, C.c_uint32), _p(play, C.c_uint8), _p(actions, C.c_int32),
+                                     _p(reward, C.c_float), _p(reward64, C.c_double), _p(done, C.c_uint8), n_threads)
 
     def export(self):
         blobs = np.zeros((self.n, STATE_WORDS), dtype=np.int32)

@@ -83,3 +83,15 @@ def test_libcatan_cpu_exports_the_env_abi_and_equals_the_oracle_batch(oracle):
                 b.L.orc_game_reset(b.env_ptr(i))
     assert np.array_equal(b.export(), out["blob"].T)
     assert np.array_equal(b.masks(), out["masks_after_import"])
+
+
+def test_deferred_step_protocol_on_libcatan_cpu(oracle):
+    """catan_step_deferred / catan_step_flush through the shared caller (tests/cpu_abi_driver.py: drive_deferred): a host-side
+    policy stub supplies the actions, games wait and say so, every delivered result and every readable view equals the oracle
+    shadow's, the flushed states equal it word for word.  The same caller runs on libcatan_hip.so under -m gpu."""
+    import cpu_abi_driver as drv
+    L = drv.cpu_lib()
+    for n, seed, calls, window, dense, flush_every in ((48, 3, 700, 8, False, 0), (32, 4, 500, 1, True, 97), (40, 6, 450, 32, False, 150)):
+        st = drv.drive_deferred(L, oracle, n, seed, calls, window, lambda s, d: drv.HostBuf(s, d), lambda b: b.a, dense=dense, flush_every=flush_every)
+        assert st["waited"] > 0 and st["delivered_late"] > 0 and st["rejected"] > 0 and st["invalid"] == st["rejected"]
+        assert st["applied"] > 0.5 * n * calls

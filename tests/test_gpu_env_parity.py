@@ -341,3 +341,67 @@ def _shard_deferred(whole, parts, fused):
     _assert_blobs_equal(got, whole.export_state().cpu().numpy(), "8 x 8 192 games vs 65 536 after a deferred rollout")
     assert torch.equal(torch.cat([e.get_action_masks() for e in parts]), whole.get_action_masks())
     assert whole.invalid_action_count() == 0 and all(e.invalid_action_count() == 0 for e in parts)
+
+
+def test_deferred_step_protocol_on_libcatan_hip(oracle, hip_lib):
+    """catan_step_deferred / catan_step_flush with CALLER-SUPPLIED actions, through the same caller that runs on libcatan_cpu.so
+    (tests/cpu_abi_driver.py: drive_deferred): a host-side policy stub keyed by each game's own decision count, an oracle shadow per
+    game; every delivered reward (float and unrounded double) / done, the masks and deciding seats of every game that is not
+    waiting, illegal actions and no-ops, the refusal of lock-step calls while a sequence is open, and the flushed states."""
+    import torch
+    import cpu_abi_driver as drv
+    from settlers_of_catan_rl_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    tdt = {np.int32: torch.int32, np.float32: torch.float32, np.uint8: torch.uint8, np.float64: torch.float64}
+    alloc = lambda s, d: torch.zeros(s, dtype=tdt[d], device="cuda")
+    to_np = lambda b: (torch.cuda.synchronize(), b.cpu().numpy())[1]
+    for n, seed, calls, window, dense, flush_every in ((192, 3, 900, 8, False, 0), (128, 4, 600, 1, True, 97), (160, 6, 700, 32, False, 250)):
+        s = drv.drive_deferred(_lib.lib(), oracle, n, seed, calls, window, alloc, to_np, stream=st, dense=dense, flush_every=flush_every)
+        assert s["waited"] > 0 and s["delivered_late"] > 0 and s["rejected"] > 0 and s["invalid"] == s["rejected"]
+        assert s["applied"] > 0.5 * n * calls and s["finished"] >= 0
+
+
+def test_full_size_deferred_step_with_caller_supplied_actions(oracle, hip_lib):
+    """65 536 games through catan_step_deferred with the actions coming from OUTSIDE the library: the oracle batch (OpenMP) is the
+    policy stub and the shadow env in one (orc_batch_play: action number counts[g] of game g, drawn from the shadow's masks, for
+    the games that are not waiting).  Every delivered reward / done of every call equals the shadow's, waiting games report
+    zeros, the masks of the games that are not waiting are the shadow's (every 40th call), and after the flush all 65 536
+    states and decision counts agree - every game on its lock-step trajectory whatever the interleaving."""
+    import torch
+    n, seed, calls, window = 65536, 21, 420, 32
+    env = _env(n, seed)
+    r64 = env.enable_reward64()
+    ob = oracle.OracleBatch(n, seed)
+    counts = np.zeros(n, dtype=np.uint32)
+    waiting = np.zeros(n, dtype=bool)
+    acts = np.zeros((n, 18), dtype=np.int32)
+    exp_r = np.zeros((n, 4), dtype=np.float32); exp_r64 = np.zeros((n, 4), dtype=np.float64); exp_d = np.zeros(n, dtype=np.uint8)
+    waited = late = applied = 0
+    for t in range(calls):
+        play = (~waiting).astype(np.uint8)
+        applied += ob.play(counts, play, acts, exp_r, exp_r64, exp_d)           # (rows of waiting games keep their outstanding result)
+        rew, done, status = env.step_deferred(torch.from_numpy(acts).cuda(), window)
+        torch.cuda.synchronize()
+        s = status.cpu().numpy(); r = rew.cpu().numpy(); d = done.cpu().numpy(); r6 = r64.cpu().numpy()
+        w = s == 1
+        assert set(np.unique(s)) <= {0, 1}
+        assert not r[w].any() and not d[w].any(), t
+        ok = ~w
+        assert np.array_equal(r[ok], exp_r[ok]) and np.array_equal(d[ok], exp_d[ok]) and np.array_equal(r6[ok], exp_r64[ok]), t
+        waited += int((w & ~waiting).sum()); late += int((ok & waiting).sum())
+        waiting = w
+        if t % 40 == 39:
+            m = env.get_action_masks().cpu().numpy()
+            assert np.array_equal(m[ok], ob.masks()[ok]), t
+    rew, done, status = env.step_flush()
+    s = status.cpu().numpy(); r = rew.cpu().numpy(); d = done.cpu().numpy(); r6 = r64.cpu().numpy()
+    assert np.array_equal(s == 0, waiting) and np.array_equal(s == 2, ~waiting)
+    assert np.array_equal(r[waiting], exp_r[waiting]) and np.array_equal(d[waiting], exp_d[waiting]) and np.array_equal(r6[waiting], exp_r64[waiting])
+    assert not r[~waiting].any() and not d[~waiting].any()
+    _assert_blobs_equal(env.export_state().cpu().numpy(), ob.export(), "all 65 536 games after 420 deferred calls + flush")
+    assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+    assert env.invalid_action_count() == 0
+    assert waited > 0.03 * applied and late > 0.9 * waited and applied > 0.85 * n * calls, (waited, late, applied)
+    # the sequence is closed: the lock-step entry points work again, and a second sequence starts clean
+    env.random_rollout(0, 3)
+    assert env.invalid_action_count() == 0
