@@ -126,12 +126,16 @@ int catan_expand_masks(const uint32_t* packed, int64_t rows, int32_t pitch_words
  * turn (doubles), the append of the active seat's action / log-prob / packed action mask, of rewards and terminal masks into the
  * (T(+2), n, .) rollout tensors, finished games, and which games append their NEXT observation where (sel, t_obs: the inputs of
  * catan_obs_rows).  counters4: int64 [4][n] = n_obs, n_msk, n_act, n_rew; flags4: uint8 [4][n] = done_since, pending_obs, live
- * (from pre), sel (out); reward64 may be NULL (then `reward` is summed). */
+ * (from pre), sel (out); reward64 may be NULL (then `reward` is summed).
+ * With catan_step_deferred: waiting_before = the status array the previous call returned (all zero before the first), status =
+ * the one this call returned; the action / log-prob / mask append of a decision happens in the iteration that passes the action
+ * to the env, everything that needs the step's result in the iteration that delivers it.  Both NULL with catan_step. */
 int catan_collector_pre(int64_t n, int32_t T, const int64_t* n_obs, const int64_t* actions, int32_t* a_env, uint8_t* live, catan_stream_t stream);
 int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc, uint8_t* flags4, float* term, int64_t* t_obs, const int64_t* active_pid,
                          const int32_t* deciding, const int32_t* n_deciding, const int64_t* actions, const float* logp, const int32_t* pmasks,
                          const float* reward, const double* reward64, const uint8_t* done, int64_t* st_actions, float* st_logp, int32_t* st_amasks,
-                         float* st_rewards, float* st_masks, int64_t* n_complete, catan_stream_t stream);
+                         float* st_rewards, float* st_masks, int64_t* n_complete, const uint8_t* waiting_before, const uint8_t* status,
+                         catan_stream_t stream);
 
 /* deciding player (discarder > trade target > players_go): env/wrapper.py:53-58, RL/ppo/game_manager.py:152-159.
  * out: int32 [n], PlayerId 1..4 */
@@ -189,6 +193,14 @@ int catan_obs(catan_env_t* env, float* out_f, int32_t* out_lists, int32_t* out_l
  * group may be NULL.  Replaces catan_obs + a cast + catan_masked_row_store of round 2. */
 int catan_obs_rows(catan_env_t* env, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
                    int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, catan_stream_t stream);
+
+/* catan_obs_rows / catan_masks for a LIST of games (a collector that no longer evaluates its finished games: dense row j = the
+ * observation / masks of game games[j], int32 [n_rows], n_rows <= n; a negative id = an unused row).  The rollout-storage rows
+ * (rows_*, t_idx, sel: indexed by GAME as in catan_obs_rows) are written for the listed games only.  While a deferred sequence is
+ * open, the mask row of a waiting game is a placeholder (only EndTurn legal) in catan_masks and catan_masks_of alike. */
+int catan_obs_rows_of(catan_env_t* env, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                      int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, const int32_t* games, int64_t n_rows, catan_stream_t stream);
+int catan_masks_of(catan_env_t* env, float* out_masks, const int32_t* games, int64_t n_rows, catan_stream_t stream);
 
 /* Game.get_longest_path(player): game/game.py:843-862 for players[i] (PlayerId) in game i -> out[i].  Diagnostic/test
  * entry; inside catan_step the same search runs as part of update_longest_road. */

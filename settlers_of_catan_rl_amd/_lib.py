@@ -119,7 +119,7 @@ _SIGS = {
     "catan_expand_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_segment_sum_rows": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_collector_pre": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
-    "catan_collector_post": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 21),
+    "catan_collector_post": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 23),
     "catan_deciding_seat": (C.c_int, [_vp, _vp, _vp]),
     "catan_sample_random_actions": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "catan_state_export": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
@@ -130,6 +130,8 @@ _SIGS = {
     "catan_random_rollout": (C.c_int, [_vp, C.c_uint32, C.c_int64, _vp]),
     "catan_obs": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "catan_obs_rows": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catan_obs_rows_of": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_masks_of": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "catan_longest_path": (C.c_int, [_vp, _vp, _vp, _vp]),
     "catan_gae_workspace_doubles": (C.c_int64, [C.c_int64]),
     "catan_gae": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),

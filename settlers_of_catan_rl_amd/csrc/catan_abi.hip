@@ -565,7 +565,10 @@ int catan_step(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* d
 int catan_masks(catan_env_t* e, float* out, catan_stream_t stream) {
     if (!e || !out) return fail(CATAN_EINVAL, "catan_masks: null argument");
     long total = e->n * MASK_BITS;
-    hipLaunchKernelGGL(k_expand_masks, dim3(blocks(total, BLOCK)), dim3(BLOCK), 0, S(stream), e->mpk, e->N, e->n, out);
+    if (e->d_it > 0)                     // an open deferred sequence: a waiting game's row is the placeholder (only EndTurn), never a half-written mask
+        hipLaunchKernelGGL(k_expand_masks_of, dim3(blocks(total, BLOCK)), dim3(BLOCK), 0, S(stream), (const u32*)e->mpk, (const i32*)nullptr, (long)e->n, (long)e->n, (const u8*)e->pend.busy, out);
+    else
+        hipLaunchKernelGGL(k_expand_masks, dim3(blocks(total, BLOCK)), dim3(BLOCK), 0, S(stream), e->mpk, e->N, e->n, out);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -970,22 +973,40 @@ int catan_obs(catan_env_t* e, float* out_f, int32_t* out_lists, int32_t* out_len
     static const bool v1 = getenv("CATAN_OBS_V1") != nullptr;          // (the round-1 kernel, kept for A/B timing)
     if (v1) hipLaunchKernelGGL(k_obs, dim3(blocks(e->N, 64)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens);
     else hipLaunchKernelGGL((k_obs_rows<ObsF32, OBS_OG>), dim3(blocks(e->n, OBS_OG)), dim3(64), 0, S(stream), e->ctx, out_f, out_lists, out_lens,
-                            (float*)nullptr, (signed char*)nullptr, (signed char*)nullptr, (const long long*)nullptr, (const u8*)nullptr);
+                            (float*)nullptr, (signed char*)nullptr, (signed char*)nullptr, (const long long*)nullptr, (const u8*)nullptr, (const i32*)nullptr, (long)e->n);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
 
+static int obs_rows_impl(catan_env_t* e, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                         int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, const int32_t* games, int64_t n_rows, catan_stream_t stream);
 int catan_obs_rows(catan_env_t* e, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
                    int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, catan_stream_t stream) {
+    return obs_rows_impl(e, bf16, dense_f, dense_lists, dense_lens, rows_f, rows_lists, rows_lens, t_idx, sel, nullptr, e ? e->n : 0, stream);
+}
+int catan_obs_rows_of(catan_env_t* e, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                      int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, const int32_t* games, int64_t n_rows, catan_stream_t stream) {
+    if (!e || !games || n_rows <= 0 || n_rows > e->n) return fail(CATAN_EINVAL, "catan_obs_rows_of: bad game list");
+    return obs_rows_impl(e, bf16, dense_f, dense_lists, dense_lens, rows_f, rows_lists, rows_lens, t_idx, sel, games, n_rows, stream);
+}
+int catan_masks_of(catan_env_t* e, float* out, const int32_t* games, int64_t n_rows, catan_stream_t stream) {
+    if (!e || !out || !games || n_rows <= 0 || n_rows > e->n) return fail(CATAN_EINVAL, "catan_masks_of: bad arguments");
+    hipLaunchKernelGGL(k_expand_masks_of, dim3(blocks(n_rows * MASK_BITS, BLOCK)), dim3(BLOCK), 0, S(stream), (const u32*)e->mpk, games, (long)n_rows, (long)e->n,
+                       e->d_it > 0 ? (const u8*)e->pend.busy : (const u8*)nullptr, out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+static int obs_rows_impl(catan_env_t* e, int32_t bf16, void* dense_f, int32_t* dense_lists, int32_t* dense_lens, void* rows_f, int8_t* rows_lists,
+                         int8_t* rows_lens, const int64_t* t_idx, const uint8_t* sel, const int32_t* games, int64_t n_rows, catan_stream_t stream) {
     if (!e || (!dense_f && !rows_f)) return fail(CATAN_EINVAL, "catan_obs_rows: no output");
     if ((dense_lists == nullptr) != (dense_lens == nullptr) || (rows_lists == nullptr) != (rows_lens == nullptr))
         return fail(CATAN_EINVAL, "catan_obs_rows: lists and lens come together");
     if (rows_f && (!t_idx || !sel)) return fail(CATAN_EINVAL, "catan_obs_rows: row stores need t_idx and sel");
     if ((rows_lists && !rows_f) || (dense_lists && !dense_f)) return fail(CATAN_EINVAL, "catan_obs_rows: lists without their observation rows");
     static const int og = getenv("CATAN_OBS_OG") ? atoi(getenv("CATAN_OBS_OG")) : OBS_OG;      // (A/B: games per wave 16 / 8 / 4)
-    const dim3 grid(blocks(e->n, og == 16 ? 16 : og == 4 ? 4 : 8));
+    const dim3 grid(blocks(n_rows, og == 16 ? 16 : og == 4 ? 4 : 8));
 #define CATAN_OBS_LAUNCH(OT, CT, G) hipLaunchKernelGGL((k_obs_rows<OT, G>), grid, dim3(64), 0, S(stream), e->ctx, (CT*)dense_f, dense_lists, dense_lens, \
-                                                       (CT*)rows_f, (signed char*)rows_lists, (signed char*)rows_lens, (const long long*)t_idx, sel)
+                                                       (CT*)rows_f, (signed char*)rows_lists, (signed char*)rows_lens, (const long long*)t_idx, sel, games, (long)n_rows)
     if (bf16) { if (og == 16) CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 16); else if (og == 4) CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 4); else CATAN_OBS_LAUNCH(ObsBF16, unsigned short, 8); }
     else { if (og == 16) CATAN_OBS_LAUNCH(ObsF32, float, 16); else if (og == 4) CATAN_OBS_LAUNCH(ObsF32, float, 4); else CATAN_OBS_LAUNCH(ObsF32, float, 8); }
 #undef CATAN_OBS_LAUNCH
@@ -1134,7 +1155,7 @@ int catan_collector_pre(int64_t n, int32_t T, const int64_t* n_obs, const int64_
 int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc, uint8_t* flags4, float* term, int64_t* t_obs, const int64_t* active_pid,
                          const int32_t* deciding, const int32_t* n_deciding, const int64_t* actions, const float* logp, const int32_t* pmasks,
                          const float* reward, const double* reward64, const uint8_t* done, int64_t* st_actions, float* st_logp, int32_t* st_amasks,
-                         float* st_rewards, float* st_masks, int64_t* n_complete, catan_stream_t stream) {
+                         float* st_rewards, float* st_masks, int64_t* n_complete, const uint8_t* waiting_before, const uint8_t* status, catan_stream_t stream) {
     if (n <= 0 || T <= 0 || !counters4 || !racc || !flags4 || !term || !t_obs || !active_pid || !deciding || !n_deciding || !actions || !logp || !pmasks ||
         !reward || !done || !st_actions || !st_logp || !st_amasks || !st_rewards || !st_masks || !n_complete)
         return fail(CATAN_EINVAL, "catan_collector_post: null argument");
@@ -1148,6 +1169,8 @@ int catan_collector_post(int64_t n, int32_t T, int64_t* counters4, double* racc,
     a.reward = reward; a.reward64 = reward64; a.done = done;
     a.st_actions = (long long*)st_actions; a.st_logp = st_logp; a.st_amasks = st_amasks; a.st_rewards = st_rewards; a.st_masks = st_masks;
     a.n_complete = (long long*)n_complete;
+    if ((waiting_before == nullptr) != (status == nullptr)) return fail(CATAN_EINVAL, "catan_collector_post: waiting_before and status come together");
+    a.waiting_before = waiting_before; a.status = status;
     hipLaunchKernelGGL(k_collector_post, dim3(blocks(n, 256)), dim3(256), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return CATAN_OK;

@@ -35,6 +35,9 @@ struct CollectorArgs {
     float* st_rewards; float* st_masks;                      // [T + 2][n]
     long long* n_complete;           // [1]: finished games, accumulated
     i32* a_env;                      // pre: int32 [n][18] for catan_step
+    // catan_step_deferred (both null: catan_step - every game's step is complete when the post kernel runs)
+    const u8* waiting_before;        // [n]: the game was waiting when the step was called (its action was ignored)
+    const u8* status;                // [n]: CATAN_STEP_COMPLETE 0 / CATAN_STEP_WAITING 1 after the call
 };
 
 __global__ __launch_bounds__(256) void k_collector_pre(CollectorArgs a) {
@@ -57,18 +60,14 @@ __global__ __launch_bounds__(256) void k_collector_post(CollectorArgs a) {
         const int T = a.T;
         const long n = a.n;
         const bool live = a.live[g] != 0;
-        done = a.done[g] != 0 && live;
-        if (live) a.term[g] = done ? 0.0f : 1.0f;                            // :97
+        // Under the deferred schedule the two halves of the bookkeeping of one decision may run in different iterations: the append
+        // of the action (:102-105) when the env CONSUMES it, everything that needs the step's result (:91-97, :106-136) when the env
+        // DELIVERS it (the game waited in between: it took no other action and appended nothing).  catan_step: both at once.
+        const bool consumed = live && (a.waiting_before == nullptr || a.waiting_before[g] == 0);
+        const bool delivered = live && (a.status == nullptr || a.status[g] == 0);
         const int ap = (int)a.active_pid[g];
-        double r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            r[k] = a.racc[g * 4 + k];
-            if (live) r[k] += a.reward64 != nullptr ? a.reward64[g * 4 + k] : (double)a.reward[g * 4 + k];   // :94-95
-        }
         long long n_act = a.n_act[g];
-        const bool was_active = a.deciding[g] == ap && live;                 // :102-105
-        if (was_active) {
+        if (consumed && a.deciding[g] == ap) {                               // :102-105
             const long t = n_act < T - 1 ? n_act : T - 1;
             const long long* src = a.actions + g * 18;
             long long* dst = a.st_actions + (t * n + g) * 18;
@@ -82,44 +81,56 @@ __global__ __launch_bounds__(256) void k_collector_post(CollectorArgs a) {
             n_act += 1;
             a.n_act[g] = n_act;
         }
-        const bool next_active = a.n_deciding[g] == ap && live;
-        bool done_since = a.done_since[g] != 0;
-        // :106-110 (not done: uses the post-step deciding player) and :112-118 (done: exactly one reward is appended)
-        const bool app = (done ? true : (next_active && n_act > 0 && !done_since)) && live;
-        if (app) {
-            long long n_rew = a.n_rew[g];
-            const long t = n_rew < T + 1 ? n_rew : T + 1;
-            a.st_rewards[t * n + g] = (float)r[ap - 1];                      // process_batch.py:63: one rounding
-            a.n_rew[g] = n_rew + 1;
-            r[ap - 1] = 0.0;
-        }
-        long long n_msk = a.n_msk[g];
-        if (done) {                                                          // :112-124
-            const long t = n_msk < T + 1 ? n_msk : T + 1;
-            a.st_masks[t * n + g] = 0.0f;
-            n_msk += 1;
-            done_since = false;
+        bool sel = false;
+        if (delivered) {
+            done = a.done[g] != 0;
+            a.term[g] = done ? 0.0f : 1.0f;                                  // :97
+            double r[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = 0.0;
-        }
-        const bool add_mask = next_active && !done && !done_since;           // :128-136
-        if (add_mask) {
-            const long t = n_msk < T + 1 ? n_msk : T + 1;
-            a.st_masks[t * n + g] = 1.0f;
-            n_msk += 1;
-        }
-        a.n_msk[g] = n_msk;
-        done_since = next_active ? false : (done ? true : done_since);
-        a.done_since[g] = done_since ? 1 : 0;
+            for (int k = 0; k < 4; k++)
+                r[k] = a.racc[g * 4 + k] + (a.reward64 != nullptr ? a.reward64[g * 4 + k] : (double)a.reward[g * 4 + k]);   // :94-95
+            const bool next_active = a.n_deciding[g] == ap;
+            bool done_since = a.done_since[g] != 0;
+            // :106-110 (not done: uses the post-step deciding player) and :112-118 (done: exactly one reward is appended)
+            const bool app = done ? true : (next_active && n_act > 0 && !done_since);
+            if (app) {
+                long long n_rew = a.n_rew[g];
+                const long t = n_rew < T + 1 ? n_rew : T + 1;
+                a.st_rewards[t * n + g] = (float)r[ap - 1];                  // process_batch.py:63: one rounding
+                a.n_rew[g] = n_rew + 1;
+                r[ap - 1] = 0.0;
+            }
+            long long n_msk = a.n_msk[g];
+            if (done) {                                                      // :112-124
+                const long t = n_msk < T + 1 ? n_msk : T + 1;
+                a.st_masks[t * n + g] = 0.0f;
+                n_msk += 1;
+                done_since = false;
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.racc[g * 4 + k] = r[k];
-        a.pending_obs[g] = next_active ? 1 : 0;
-        // the next iteration's observation append (catan_obs_rows): the active seat's, while the game still misses observations
-        const long long n_obs = a.n_obs[g];
-        const bool s = next_active && n_obs < T + 1;
-        a.sel[g] = s ? 1 : 0;
-        a.t_obs[g] = n_obs < T ? n_obs : T;
-        if (s) a.n_obs[g] = n_obs + 1;
+                for (int k = 0; k < 4; k++) r[k] = 0.0;
+            }
+            const bool add_mask = next_active && !done && !done_since;       // :128-136
+            if (add_mask) {
+                const long t = n_msk < T + 1 ? n_msk : T + 1;
+                a.st_masks[t * n + g] = 1.0f;
+                n_msk += 1;
+            }
+            a.n_msk[g] = n_msk;
+            done_since = next_active ? false : (done ? true : done_since);
+            a.done_since[g] = done_since ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) a.racc[g * 4 + k] = r[k];
+            a.pending_obs[g] = next_active ? 1 : 0;
+            // the next iteration's observation append (catan_obs_rows): the active seat's, while the game still misses observations
+            const long long n_obs = a.n_obs[g];
+            sel = next_active && n_obs < T + 1;
+            a.t_obs[g] = n_obs < T ? n_obs : T;
+            if (sel) a.n_obs[g] = n_obs + 1;
+        } else {
+            a.pending_obs[g] = 0;
+            a.t_obs[g] = 0;
+        }
+        a.sel[g] = sel ? 1 : 0;
     }
     const unsigned long long b = __ballot(done);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(a.n_complete), (unsigned long long)__popcll(b));

@@ -1199,6 +1199,22 @@ __global__ __launch_bounds__(BLOCK) void k_expand_masks(const u32* __restrict__ 
     out[i] = (float)((mpk[e * pitch + (j >> 5)] >> (j & 31)) & 1u);
 }
 
+// ... for a list of games (games == nullptr: row j = game j): row j = the masks of game games[j].  A game that is waiting for its
+// deferred step (busy != nullptr) or a negative id gets the placeholder row "only EndTurn is legal": whatever a policy draws from
+// it is well-formed, and catan_step_deferred ignores it.
+__global__ __launch_bounds__(BLOCK) void k_expand_masks_of(const u32* __restrict__ mpk, const i32* __restrict__ games, long rows, long n, const u8* __restrict__ busy,
+                                                           float* __restrict__ out) {
+    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= rows * MASK_BITS) return;
+    const long r = i / MASK_BITS;
+    const int j = (int)(i - r * MASK_BITS);
+    const long e = games != nullptr ? (long)games[r] : r;
+    float v;
+    if (e < 0 || e >= n || (busy != nullptr && busy[e] != 0)) v = j == M0 + T_ENDTURN ? 1.0f : 0.0f;
+    else v = (float)((mpk[e * MPK_STRIDE + (j >> 5)] >> (j & 31)) & 1u);
+    out[i] = v;
+}
+
 // the first 11 words (325 bits) of every game's packed mask row, contiguous: what the rollout storage keeps per decision
 __global__ __launch_bounds__(BLOCK) void k_copy_masks11(const u32* __restrict__ mpk, long n, u32* __restrict__ out) {
     const long i = (long)blockIdx.x * BLOCK + threadIdx.x;

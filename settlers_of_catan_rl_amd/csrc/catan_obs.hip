@@ -317,7 +317,7 @@ template <class O, int OG>
 __global__ __launch_bounds__(64) void k_obs_rows(Ctx c, typename O::T* __restrict__ dense_f, i32* __restrict__ dense_lists, i32* __restrict__ dense_lens,
                                                   typename O::T* __restrict__ rows_f, signed char* __restrict__ rows_lists,
                                                   signed char* __restrict__ rows_lens, const long long* __restrict__ t_idx,
-                                                  const u8* __restrict__ sel) {
+                                                  const u8* __restrict__ sel, const i32* __restrict__ games, long n_rows) {
     constexpr int LPG = 64 / OG, TILE_B = OG * OBS_FLOATS;
     static_assert(LPG == 4 || LPG == 8 || LPG == 16, "four, eight or sixteen lanes per game");
     __shared__ __attribute__((aligned(16))) u8 codes[TILE_B + 32];
@@ -326,10 +326,13 @@ __global__ __launch_bounds__(64) void k_obs_rows(Ctx c, typename O::T* __restric
     __shared__ u8 tcn[19 * 6];
     __shared__ __attribute__((aligned(16))) u32 rec[OG * REC];          // the records of the wave's games (hot part + ordered card lists), linear
     const int lane = threadIdx.x, gi = lane / LPG, r = lane % LPG;
+    // dense row g0 + j is the observation of game gm(j): the row number itself, or games[g0 + j] (catan_obs_rows_of: a caller
+    // that evaluates only some of the games); a negative / out-of-range id is an empty slot
     const long g0 = (long)blockIdx.x * OG;
-    const long g = g0 + gi;
-    int my_sel = 0; long long my_t = 0;                     // lane j < OG: does game g0 + j append its row, and at which step
-    if (rows_f != nullptr && lane < OG && g0 + lane < c.n) { my_sel = sel[g0 + lane]; my_t = t_idx[g0 + lane]; }
+    long my_game = -1;                                      // lane j < OG: the game of slot j
+    if (lane < OG && g0 + lane < n_rows) { my_game = games != nullptr ? (long)games[g0 + lane] : g0 + lane; if (my_game >= c.n) my_game = -1; }
+    int my_sel = 0; long long my_t = 0;                     // ... does it append its row, and at which step
+    if (rows_f != nullptr && my_game >= 0) { my_sel = sel[my_game]; my_t = t_idx[my_game]; }
     {   // the records (704 B each) with 16-byte loads, all in flight at once; meanwhile zero the code tile (16-byte LDS
         // stores) and copy the tile-corner table to LDS (per-lane indices below)
         constexpr int CH = REC / 4, NV = (OG * CH + 63) / 64;                 // 44 chunks per record
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(64) void k_obs_rows(Ctx c, typename O::T* __restric
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int k = i * 64 + lane, gg = k / CH, ch = k - gg * CH;
-            const long ge = g0 + gg < c.N ? g0 + gg : c.N - 1;                 // padding games are valid records
+            long ge = __shfl(my_game, gg < OG ? gg : 0);
+            if (ge < 0) ge = c.N - 1;                                          // empty slots read a valid record (padding games are)
             v[i] = make_uint4(0, 0, 0, 0);
             if (k < OG * CH) v[i] = reinterpret_cast<const uint4*>(c.R + ge * REC)[ch];
         }
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(64) void k_obs_rows(Ctx c, typename O::T* __restric
     }
     __syncthreads();
     // ---- write-out
-    const int ng = (int)min((long)OG, c.n - g0);             // real games of this wave
+    const int ng = (int)min((long)OG, n_rows - g0);          // rows of this wave
     if (ng <= 0) return;
     if (dense_f != nullptr) obs_write_span<O>(codes, 0, dense_f + g0 * OBS_FLOATS, ng * OBS_FLOATS, lane);
     if (dense_lists != nullptr) {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(64) void k_obs_rows(Ctx c, typename O::T* __restric
     }
     if (rows_f != nullptr) {
         for (int j = 0; j < ng; j++) {
-            const long gj = g0 + j;
+            const long gj = __shfl(my_game, j);
             if (!__shfl(my_sel, j)) continue;              // (uniform)
             const long rw = (long)__shfl(my_t, j) * c.n + gj;
             obs_write_span<O>(codes, j * OBS_FLOATS, rows_f + rw * OBS_FLOATS, OBS_FLOATS, lane);

@@ -93,7 +93,7 @@ class VecCatanEnv(object):
 
     STEP_COMPLETE, STEP_WAITING, STEP_NONE = 0, 1, 2       # include/catan_hip.h
 
-    def step_deferred(self, actions, window=32):
+    def step_deferred(self, actions, window=32, status_out=None):
         """catan_step_deferred (include/catan_hip.h): the same actions as `step`, but a game whose step needs the slow path
         (longest road, re-deal) completes it on side streams and WAITS meanwhile.  Returns (reward, done, status): status[g] == 0:
         reward / done are the result of game g's last applied action and its state is current; 1: game g is waiting (its entry
@@ -101,10 +101,12 @@ class VecCatanEnv(object):
         a = actions if (actions.dtype == torch.int32 and actions.is_contiguous() and actions.device == self.device) else \
             actions.to(device=self.device, dtype=torch.int32).contiguous()
         assert a.shape == (self.n, spec.ACTION_WORDS), a.shape
-        if getattr(self, "status", None) is None:
-            self.status = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
-        _lib.check(self.L.catan_step_deferred(self.h, _ptr(a), int(window), _ptr(self.reward), _ptr(self.done), _ptr(self.status), _stream()))
-        return self.reward, self.done, self.status
+        if status_out is None:
+            if getattr(self, "status", None) is None:
+                self.status = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+            status_out = self.status
+        _lib.check(self.L.catan_step_deferred(self.h, _ptr(a), int(window), _ptr(self.reward), _ptr(self.done), _ptr(status_out), _stream()))
+        return self.reward, self.done, status_out
 
     def step_flush(self):
         """catan_step_flush: completes every outstanding deferred step.  status 0: a game that was waiting (reward / done valid);
@@ -114,10 +116,14 @@ class VecCatanEnv(object):
         _lib.check(self.L.catan_step_flush(self.h, _ptr(self.reward), _ptr(self.done), _ptr(self.status), _stream()))
         return self.reward, self.done, self.status
 
-    def get_action_masks(self, out=None):
-        """float32 [n][325]; slice with spec.MASK_OFFSETS / MASK_SHAPES for the 12 heads."""
+    def get_action_masks(self, out=None, games=None):
+        """float32 [n][325]; slice with spec.MASK_OFFSETS / MASK_SHAPES for the 12 heads.  games (int32 [k]): catan_masks_of - row j
+        = the masks of game games[j] (the first k rows of `out`)."""
         if out is None:
-            out = torch.empty((self.n, spec.MASK_WORDS), dtype=torch.float32, device=self.device)
+            out = torch.empty((self.n if games is None else games.numel(), spec.MASK_WORDS), dtype=torch.float32, device=self.device)
+        if games is not None:
+            _lib.check(self.L.catan_masks_of(self.h, _ptr(out), _ptr(games), games.numel(), _stream()))
+            return out
         _lib.check(self.L.catan_masks(self.h, _ptr(out), _stream()))
         return out
 
@@ -230,9 +236,9 @@ class VecCatanEnv(object):
         from . import obs as _obs
         return _obs.get_obs(self, out)
 
-    def get_obs_rows(self, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True):
+    def get_obs_rows(self, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True, games=None):
         from . import obs as _obs
-        return _obs.get_obs_rows(self, dtype, out, rows, t, sel, dense)
+        return _obs.get_obs_rows(self, dtype, out, rows, t, sel, dense, games)
 
     def longest_path(self, players):
         """Game.get_longest_path for PlayerId players[i] of game i (diagnostic/test entry)."""

@@ -28,19 +28,21 @@ def get_obs(vec, out=None):
     return f, lists, lens
 
 
-def get_obs_rows(vec, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True):
+def get_obs_rows(vec, dtype=torch.float32, out=None, rows=None, t=None, sel=None, dense=True, games=None):
     """catan_obs_rows: the observations of all games in ONE pass, as the dense matrix for the policy (`out` = (f [n][1787] of
     `dtype` float32 / bfloat16, int32 lists, int32 lens) or None to allocate; dense=False: no dense output) and - for the games
     with sel[g] - appended to the rollout storage `rows` = (obs_f [steps][n][1787] of `dtype`, int8 lists [steps][n][5][25],
-    int8 lens [steps][n][5]) at step t[g] (int64).  -> (f, lists, lens) or None."""
+    int8 lens [steps][n][5]) at step t[g] (int64).  games (int32 [k], k <= n): catan_obs_rows_of - dense row j is game games[j]
+    (only the first k rows of `out` are written) and only the listed games append.  -> (f, lists, lens) or None."""
     if dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("observations are written as float32 or bfloat16")
     f = lists = lens = None
     if dense:
         if out is None:
-            f = torch.empty((vec.n, spec.OBS_FLOATS), dtype=dtype, device=vec.device)
-            lists = torch.empty((vec.n, 5, spec.OBS_LIST_PAD), dtype=torch.int32, device=vec.device)
-            lens = torch.empty((vec.n, 5), dtype=torch.int32, device=vec.device)
+            k = vec.n if games is None else games.numel()
+            f = torch.empty((k, spec.OBS_FLOATS), dtype=dtype, device=vec.device)
+            lists = torch.empty((k, 5, spec.OBS_LIST_PAD), dtype=torch.int32, device=vec.device)
+            lens = torch.empty((k, 5), dtype=torch.int32, device=vec.device)
         else:
             f, lists, lens = out
             if f.dtype != dtype or lists.dtype != torch.int32 or lens.dtype != torch.int32 or not (f.is_contiguous() and lists.is_contiguous() and lens.is_contiguous()):
@@ -53,6 +55,12 @@ def get_obs_rows(vec, dtype=torch.float32, out=None, rows=None, t=None, sel=None
         t = t.to(torch.int64).contiguous()
         sel = (sel.view(torch.uint8) if sel.dtype == torch.bool else sel.to(torch.uint8)).contiguous()    # (bool is one byte, 0 / 1: no copy)
     p = lambda x: None if x is None else _ptr(x)
+    if games is not None:
+        if games.dtype != torch.int32 or not games.is_contiguous() or games.numel() > vec.n:
+            raise ValueError("games = contiguous int32 game ids, at most n of them")
+        _lib.check(vec.L.catan_obs_rows_of(vec.h, int(dtype == torch.bfloat16), p(f), p(lists), p(lens), p(rf), p(rl), p(rn), p(t) if rows is not None else None,
+                                           p(sel) if rows is not None else None, p(games), games.numel(), _stream()))
+        return (f, lists, lens) if dense else None
     _lib.check(vec.L.catan_obs_rows(vec.h, int(dtype == torch.bfloat16), p(f), p(lists), p(lens), p(rf), p(rl), p(rn), p(t) if rows is not None else None,
                                     p(sel) if rows is not None else None, _stream()))
     return (f, lists, lens) if dense else None

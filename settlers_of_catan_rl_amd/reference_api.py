@@ -361,10 +361,11 @@ class SubProcGameManager(object):
     Keyword-only extras (all optional): device, seed (Philox key of the games; global game ids start at `env_id0`, by
     default rank * number of games so that sharding over ranks does not change any game), env_factory(n) (tests),
     make_policy() (architecture of the acting nets), autocast_dtype, env_kwargs (EnvWrapper's keyword arguments),
-    self_play=True (every seat plays the central policy: no opponent nets; update_policy with policy_id 1..3 is refused)."""
+    self_play=True (every seat plays the central policy: no opponent nets; update_policy with policy_id 1..3 is refused),
+    collector_kwargs (rollout.RolloutCollector's: deferred_window, act_buckets)."""
 
     def __init__(self, game_manager_fns, start_method=None, *, device=_UNSET, seed=_UNSET, env_id0=None, env_factory=_UNSET,
-                 make_policy=_UNSET, autocast_dtype=_UNSET, env_kwargs=_UNSET, self_play=_UNSET):
+                 make_policy=_UNSET, autocast_dtype=_UNSET, env_kwargs=_UNSET, self_play=_UNSET, collector_kwargs=None):
         device, seed, env_factory = _default("device", device), _default("seed", seed), _default("env_factory", env_factory)
         make_policy, autocast_dtype = _default("make_policy", make_policy), _default("autocast_dtype", autocast_dtype)
         env_kwargs, self_play = _default("env_kwargs", env_kwargs), _default("self_play", self_play)
@@ -398,7 +399,7 @@ class SubProcGameManager(object):
         self._opp_sd = [[None] * 3 for _ in specs]
         self._default_opp = [] if self.self_play else [self._make_policy().to(self.device).eval() for _ in range(3)]
         self._opp_dirty = not self.self_play
-        self.collector = RolloutCollector(self.env, self.central, self.num_steps, seed=seed, autocast_dtype=autocast_dtype)
+        self.collector = RolloutCollector(self.env, self.central, self.num_steps, seed=seed, autocast_dtype=autocast_dtype, **(collector_kwargs or {}))
         self._carry_pending = False
 
     # ---- vec_gather_experience.py:104-118

@@ -67,10 +67,17 @@ def pack_action_masks(m):
 class RolloutCollector(object):
     GRAPH_ACT_MIN_GAMES = 8192
 
-    def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None, graph_act=None):
+    def __init__(self, env, policy, num_steps, opponents=None, seed=0, autocast_dtype=None, graph_act=None, deferred_window=None, act_buckets=None):
         """policy: central net (policy 0); opponents: list of up to 3 nets for policy slots 1..3 of every game (None =
-        every seat plays the central policy).  A league (league.League.assign) installs per-game opponents instead."""
+        every seat plays the central policy).  A league (league.League.assign) installs per-game opponents instead.
+        deferred_window: step the env with catan_step_deferred (window of that many iterations) instead of catan_step - the
+        reference's workers advance every env independently (game_manager.py:78-113), and so do the games here: one whose step
+        needs the slow path waits for it while the others go on (device collector only; None / 0 = catan_step).
+        act_buckets: row counts of the captured policy passes (graph_act): once the games that still miss observations fit a
+        smaller bucket, only they are evaluated (None = N, N/2, ... N/16 with graph_act, else N only)."""
         self.env, self.policy, self.T = env, policy, num_steps
+        self.deferred_window = int(deferred_window) if deferred_window else 0
+        self.act_buckets = None if act_buckets is None else tuple(sorted(set(int(b) for b in act_buckets) | {env.n}))
         self.N, self.device = env.n, env.device
         if torch.device(self.device).type == "cuda":
             from . import nn_kernels
@@ -175,7 +182,14 @@ class RolloutCollector(object):
         self.n_obs += sel.long()
 
     fused_bookkeeping = True   # False: the tensor-operation form of the bookkeeping below (what the kernels are tested against)
-    CHECK_EVERY = 8      # env iterations between two host reads of "every game has its T + 1 observations" (iterations past that point are no-ops)
+    CHECK_EVERY = 8      # (tensor-operation form) env iterations between two host reads of "every game has its T + 1 observations"
+    LIVE_LAG = 2         # (device collector) the host looks at the live-game count of this many iterations ago: no host wait per iteration
+
+    def _bucket_list(self):
+        if self.act_buckets is not None:
+            return self.act_buckets
+        N = self.N
+        return tuple(sorted({N} | {N >> k for k in range(1, 5) if (N >> k) >= 1024})) if self.graph_act else (N,)
 
     @torch.no_grad()
     def gather_rollouts(self, max_iters=None):
@@ -208,6 +222,19 @@ class RolloutCollector(object):
             a_env = torch.empty((N, spec.ACTION_WORDS), dtype=torch.int32, device=dev)
             live8, sel_next = fl[2], fl[3]
             first = True
+            deferred = bool(self.deferred_window) and hasattr(env, "step_deferred")
+            if deferred:             # status of the previous / of this catan_step_deferred call (alternating)
+                stat, sk = torch.zeros((2, N), dtype=torch.uint8, device=dev), 0
+            # Only the games that still miss observations are evaluated once they fit a smaller captured policy pass: `games` is
+            # the list of those games as of the last bucket change (a superset of them afterwards: a game that has frozen since
+            # just gets the no-op), row j of the policy pass is game games[j].
+            buckets = self._bucket_list() if ((self.graph_act or self.act_buckets is not None) and not self.opponent_nets and not self.recurrent) else (N,)
+            B, games, games_l, cnt = N, None, None, N
+            act_full = logp_full = None
+            RING = self.LIVE_LAG + 2
+            live_pin = torch.empty(RING, dtype=torch.int64).pin_memory() if dev != "cpu" and torch.device(dev).type == "cuda" else torch.empty(RING, dtype=torch.int64)
+            live_ev = [torch.cuda.Event() for _ in range(RING)]
+            live_bound = N
         while True:
             if fused_book:
                 if first:
@@ -215,33 +242,71 @@ class RolloutCollector(object):
                     t_obs = self.n_obs.clamp(max=T)
                 else:
                     sel, t_obs = sel_next, t_next       # written by catan_collector_post, which also counted the appends in n_obs
-                f, lists, lens = env.get_obs_rows(st.obs_f.dtype, out=obs_out, rows=(st.obs_f, st.lists, st.lens), t=t_obs, sel=sel)
+                # the live-game count of LIVE_LAG iterations ago (an upper bound of today's: frozen games stay frozen)
+                j = iters - self.LIVE_LAG
+                if j >= 1:
+                    live_ev[j % RING].synchronize()
+                    live_bound = int(live_pin[j % RING])
+                done_all = live_bound == 0
+                newB = next(b for b in buckets if b >= max(live_bound, 1))
+                if newB < B and not done_all:
+                    live_now = self.n_obs < T + 1       # (host read: at most len(buckets) - 1 times per rollout)
+                    games_l = live_now.nonzero(as_tuple=True)[0]
+                    # a game that froze since the count was taken would lose the append of its last observation if it were dropped
+                    # from the list before this iteration's catan_obs_rows: keep the selected ones
+                    games_l = (live_now | sel.bool()).nonzero(as_tuple=True)[0]
+                    if games_l.numel() <= newB:
+                        games, cnt, B = games_l.to(torch.int32).contiguous(), int(games_l.numel()), newB
+                        obs_out = mask_out = None
+                        if act_full is None:
+                            act_full = torch.zeros((N, spec.ACTION_WORDS), dtype=torch.int64, device=dev)
+                            logp_full = torch.zeros((N,), dtype=torch.float32, device=dev)
+                oo = None if obs_out is None else tuple(x[:cnt] for x in obs_out)
+                f, lists, lens = env.get_obs_rows(st.obs_f.dtype, out=oo, rows=(st.obs_f, st.lists, st.lens), t=t_obs, sel=sel, games=games) \
+                    if games is not None else env.get_obs_rows(st.obs_f.dtype, out=obs_out, rows=(st.obs_f, st.lists, st.lens), t=t_obs, sel=sel)
                 if first:
                     self.n_obs += sel.long()
                     first = False
                 if max_iters is not None and iters >= max_iters:
                     break
-                if iters % self.CHECK_EVERY == 0 and bool((self.n_obs >= T + 1).all()):
+                if done_all:
                     break
                 iters += 1
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 deciding = env.deciding_player()                                                # :79
-                masks = env.get_action_masks(mask_out) if mask_out is not None else env.get_action_masks()   # :83
+                if games is not None:
+                    masks = env.get_action_masks(None if mask_out is None else mask_out[:cnt], games=games)
+                else:
+                    masks = env.get_action_masks(mask_out) if mask_out is not None else env.get_action_masks()   # :83
                 pol = self.policy_of_pid[ar, deciding.long() - 1] if self.opponent_nets else None
-                actions, logp = self._act(f, lists, lens, masks, pol)                           # :85-89
+                actions, logp = self._act(f, lists, lens, masks, pol, games=games)              # :85-89
                 if obs_out is None and self._graphed is not None and not self.opponent_nets:
-                    bufs = self._graphed.static_inputs(N)
+                    bufs = self._graphed.static_inputs(B)
                     if bufs is not None and bufs[0].dtype == st.obs_f.dtype and bufs[1].dtype == torch.int32 and bufs[2].dtype == torch.int32:
                         obs_out, mask_out = bufs[:3], bufs[3]
+                if games is not None:                   # back to one row per game (the games outside the list are frozen: no-ops)
+                    act_full.index_copy_(0, games_l, actions)
+                    logp_full.index_copy_(0, games_l, logp)
+                    actions, logp = act_full, logp_full
                 actions, logp = actions.contiguous(), logp.contiguous()
                 _lib.check(L.catan_collector_pre(N, T, P(self.n_obs), P(actions), P(a_env), P(live8), stream))
                 n_live_iters += live8.any()
                 pmasks = env.get_action_masks_packed()                                          # (before the step replaces them)
-                reward, done = env.step(a_env)                                                  # :91 (auto-reset == :113)
+                if deferred:
+                    wb, so = stat[sk], stat[sk ^ 1]
+                    reward, done, _ = env.step_deferred(a_env, self.deferred_window, status_out=so)
+                    sk ^= 1
+                else:
+                    wb = so = None
+                    reward, done = env.step(a_env)                                              # :91 (auto-reset == :113)
                 n_deciding = env.deciding_player()
                 _lib.check(L.catan_collector_post(N, T, P(self._cnt), P(self.racc), P(fl), P(term), P(t_next), P(self.active_pid), P(deciding), P(n_deciding),
                                                   P(actions), P(logp), P(pmasks), P(reward), P(self.reward64) if self.reward64 is not None else None, P(done),
-                                                  P(st.actions), P(st.action_log_probs), P(st.action_masks), P(st.rewards), P(st.masks), P(n_complete), stream))
+                                                  P(st.actions), P(st.action_log_probs), P(st.action_masks), P(st.rewards), P(st.masks), P(n_complete),
+                                                  P(wb) if deferred else None, P(so) if deferred else None, stream))
+                slot = iters % RING
+                live_pin[slot].copy_((self.n_obs < T + 1).sum(), non_blocking=True)
+                live_ev[slot].record()
                 continue
             if fused_obs:
                 sel = self.pending_obs & (self.n_obs < T + 1)
@@ -307,6 +372,18 @@ class RolloutCollector(object):
                                           torch.where(done & live, torch.ones_like(self.done_since), self.done_since))
             self.pending_obs = next_active
         if fused_book:
+            if deferred:
+                # the steps that are still outstanding (none when every game has frozen; some after `max_iters`): completed by the
+                # flush, their results booked as in the loop, the observations they make the active seat's appended
+                reward, done, so = env.step_flush()
+                ones = torch.ones(N, dtype=torch.uint8, device=dev)
+                deciding = n_deciding = env.deciding_player()
+                _lib.check(L.catan_collector_post(N, T, P(self._cnt), P(self.racc), P(fl), P(term), P(t_next), P(self.active_pid), P(deciding), P(n_deciding),
+                                                  P(actions) if iters else P(a_env), P(logp) if iters else P(term), P(env.get_action_masks_packed()), P(reward),
+                                                  P(self.reward64) if self.reward64 is not None else None, P(done),
+                                                  P(st.actions), P(st.action_log_probs), P(st.action_masks), P(st.rewards), P(st.masks), P(n_complete),
+                                                  P(ones), P(so), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                env.get_obs_rows(st.obs_f.dtype, rows=(st.obs_f, st.lists, st.lens), t=t_next, sel=sel_next, dense=False)
             # (the loop left after an observation append: sel / pending_obs of the flags are consumed)
             self.done_since = fl[0].bool()
             self.pending_obs = torch.zeros(N, dtype=torch.bool, device=dev)
@@ -315,7 +392,7 @@ class RolloutCollector(object):
         self.iters = int(n_live_iters) if max_iters is None else iters
         return st
 
-    def _act(self, f, lists, lens, masks, pol, deciding=None, term=None, live=None):
+    def _act(self, f, lists, lens, masks, pol, deciding=None, term=None, live=None, games=None):
         """One batched forward per distinct net in play: net 0 = central policy, net 1 + k = opponent_nets[k].
         With an LSTM policy the deciding seat's state goes in (multiplied by the previous step's terminal mask, :81,85-89)
         and its new state is kept for the games that really step."""
@@ -337,13 +414,15 @@ class RolloutCollector(object):
         for idx, net in groups:
             args = (f, lists, lens, masks) if idx is None else (f[idx], lists[idx], lens[idx], masks[idx])
             kw = {"generator": self.sample_gen}
+            if games is not None and getattr(net, "wants_games", False):
+                kw["games"] = games                      # (test policies keyed by game: row j of this pass is game games[j])
             if self.recurrent:
                 sel = slice(None) if idx is None else idx
                 kw.update(hidden=(h_in[sel], c_in[sel]), nonterminal=term[sel])
             if idx is None and self.graph_act and not self.recurrent:
                 if self._graphed is None or self._graphed.policy is not net:
                     from .forward_search import GraphedAct
-                    self._graphed = GraphedAct(net, buckets=(N,), autocast_dtype=self.autocast_dtype, generator=self.sample_gen)
+                    self._graphed = GraphedAct(net, buckets=self._bucket_list(), autocast_dtype=self.autocast_dtype, generator=self.sample_gen)
                 res = self._graphed(f, lists, lens, masks, with_logp=True, clone=False)
             elif self.autocast_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):

@@ -18,6 +18,21 @@ class CountingEnv(object):
         self.steps_taken += (actions[:, 0] >= 0).cpu().long()
         return self.env.step(actions)
 
+    def step_deferred(self, actions, window=32, status_out=None):
+        """a waiting game's action is ignored by the env: not a step of that game"""
+        waiting = getattr(self, "_waiting", None)
+        took = (actions[:, 0] >= 0).cpu()
+        if waiting is not None:
+            took &= ~waiting
+        self.steps_taken += took.long()
+        r, d, s = self.env.step_deferred(actions, window, status_out=status_out)
+        self._waiting = (s == 1).cpu()
+        return r, d, s
+
+    def step_flush(self):
+        self._waiting = None
+        return self.env.step_flush()
+
     def __getattr__(self, name):
         return getattr(self.env, name)
 
@@ -47,9 +62,14 @@ class ReplayPolicy(object):
     def load_reference_state_dict(self, sd):
         pass
 
-    def act(self, f, lists, lens, masks, generator=None, deterministic=False, **_kw):
+    wants_games = True      # (the collector may evaluate a list of games instead of all of them: row j = game games[j])
+
+    def act(self, f, lists, lens, masks, generator=None, deterministic=False, games=None, **_kw):
         k = torch.minimum(self.cenv.steps_taken, self.lens)
-        a = self.table[torch.arange(self.cenv.n), k].to(f.device)
+        a = self.table[torch.arange(self.cenv.n), k]
+        if games is not None:
+            a = a[games.cpu().long()]
+        a = a.to(f.device)
         return torch.zeros(a.shape[0], 1, device=f.device), a, scripted_log_prob(a)[:, None].to(f.device)
 
 
@@ -68,7 +88,7 @@ def pre_advance(env, pre_len, pre_actions):
         assert not bool(done.any())
 
 
-def check_rollout_fixture(make_env):
+def check_rollout_fixture(make_env, collector_kwargs=None):
     """make_env(n, seed) -> freshly created batched env with auto-reset.  Drives `reference_api.SubProcGameManager` +
     `BatchProcessor` over it and compares every rollout with the tensors of the reference's GamesAndPoliciesManager +
     BatchProcessor (verbatim layouts).  Returns (manager, batch processor, last rollouts handle)."""
@@ -81,7 +101,7 @@ def check_rollout_fixture(make_env):
     cenv = CountingEnv(env)
     traces = [np.concatenate([g[f"r{r}_trace_{i}"] for r in range(R)]) for i in range(n)]
     mgr = ra.SubProcGameManager([ra.make_game_manager(n, T)], env_factory=lambda n_: cenv,
-                                make_policy=lambda: ReplayPolicy(cenv, traces), self_play=True, autocast_dtype=None)
+                                make_policy=lambda: ReplayPolicy(cenv, traces), self_play=True, autocast_dtype=None, collector_kwargs=collector_kwargs)
     col = mgr.collector
     col.active_pid[:] = torch.from_numpy(g["active_pid"].astype(np.int64)).to(col.active_pid.device)
     col.reset()                                           # game_manager.py:35-59 on the adopted positions

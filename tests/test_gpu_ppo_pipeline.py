@@ -1009,6 +1009,8 @@ def test_fused_collector_bookkeeping_equals_the_tensor_form(hip_lib):
         col.fused_bookkeeping = fused
         cols.append(col)
     for rnd in range(2):
+        for c in cols:                   # (the two forms notice "every game is frozen" a different number of no-op iterations late: the
+            c.sample_gen.manual_seed(40 + rnd)   # policy passes of those iterations draw from the generator too)
         sts = [c.gather_rollouts() for c in cols]
         a, b = cols
         assert a.iters == b.iters and sts[0].games_complete == sts[1].games_complete, (a.iters, b.iters, sts[0].games_complete, sts[1].games_complete)
