@@ -69,20 +69,20 @@ def _same(a, b, what):
 
 def test_deferred_and_bucketed_collectors_equal_the_lockstep_one(hip_lib):
     n, T, seed, gathers = 1536, 12, 5, 3
-    base = _run(n, T, seed, gathers)
+    base = _run(n, T, seed, gathers, deferred_window=0)
     assert sum(int((s["masks"] == 0).sum()) for s in base) >= 0 and base[-1]["games_complete"] >= 0
-    for ckw in (dict(deferred_window=4), dict(deferred_window=1), dict(act_buckets=(n // 8, n // 4, n // 2)),
+    for ckw in (dict(), dict(deferred_window=1), dict(deferred_window=0, act_buckets=(n // 8, n // 4, n // 2)),
                 dict(deferred_window=8, act_buckets=(n // 16, n // 4))):
         got = _run(n, T, seed, gathers, **ckw)
         _same(base, got, ckw)
-        if "deferred_window" in ckw:
+        if ckw.get("deferred_window", 4):
             assert got[0]["iters"] >= base[0]["iters"]            # waiting games take part in more iterations
 
 
 def test_rollout_fixture_on_the_deferred_and_bucketed_collector(hip_lib):
     """tests/golden/rollout_small.npz (the reference manager's own rollouts) through catan_step_deferred and through policy passes
     over game lists: every tensor of every rollout is still the reference's."""
-    for ckw in (dict(deferred_window=3), dict(deferred_window=2, act_buckets=(1, 2, 4)), dict(act_buckets=(2, 3))):
+    for ckw in (dict(deferred_window=0), dict(deferred_window=3), dict(deferred_window=2, act_buckets=(1, 2, 4)), dict(deferred_window=0, act_buckets=(2, 3))):
         envs = []
         rf.check_rollout_fixture(lambda n, seed: envs.append(_hip_env(n, seed)) or envs[-1], collector_kwargs=ckw)
         assert envs[0].invalid_action_count() == 0

@@ -145,5 +145,20 @@ class _Recorder(object):
                 self.trace[j].append(a[j].astype(np.int32))
         return self.env.step(actions)
 
+    def step_deferred(self, actions, window=32, status_out=None):
+        """(the collector's default on the device) a waiting game ignores the action it is passed: not part of its trace"""
+        a = actions[self.idx].cpu().numpy()
+        w = getattr(self, "_waiting", None)
+        for j in range(len(self.trace)):
+            if a[j, 0] >= 0 and not (w is not None and w[j]):
+                self.trace[j].append(a[j].astype(np.int32))
+        r, d, s = self.env.step_deferred(actions, window, status_out=status_out)
+        self._waiting = (s[self.idx] == 1).cpu().numpy()
+        return r, d, s
+
+    def step_flush(self):
+        self._waiting = None
+        return self.env.step_flush()
+
     def __getattr__(self, name):
         return getattr(self.env, name)
