@@ -272,6 +272,45 @@ def main():
         lockstep = {"value": world * n * ls_passes / ls_dt, "unit": "env-steps/s", "steps": args.steps, "reps": ls_reps,
                     "timed_s": ls_dt, "ms_per_step": ls_dt / ls_passes * 1e3}
 
+    # The same games through the boundary's step entry points with CALLER-SUPPLIED actions (what a collector or a search calls:
+    # include/catan_hip.h catan_step / catan_step_deferred; the value above is the library's own loop around the same kernels).
+    # The policy stub is the library's sampler writing into a caller-owned buffer: one more launch per pass, no host read.
+    step_api = None
+    if args.window > 0 and not args.no_lockstep:
+        acts = torch.empty((n, 18), dtype=torch.int32, device="cuda")
+        api_passes = max(1024, args.steps // 2)
+        def api_loop(deferred, passes, base):
+            for k in range(passes):
+                env.sample_random_actions(base + k, out=acts)
+                if deferred:
+                    env.step_deferred(acts, args.window)
+                else:
+                    env.step(acts)
+        api_loop(True, 256, step_idx); step_idx += 256
+        env.step_flush()
+        cdist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        api_loop(True, api_passes, step_idx); step_idx += api_passes
+        torch.cuda.synchronize(); cdist.barrier()
+        d_dt = cdist.max_over_ranks(time.perf_counter() - t0)
+        act_cnt = torch.zeros((), dtype=torch.int64, device="cuda")          # the share of games that step in a call: counted over 256 more (untimed) calls
+        for k in range(256):
+            env.sample_random_actions(step_idx + k, out=acts)
+            env.step_deferred(acts, args.window)
+            act_cnt += (env.status == 0).sum()
+        step_idx += 256
+        waiting_now = 1.0 - float(act_cnt) / (256.0 * n)
+        env.step_flush()
+        cdist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        api_loop(False, api_passes // 4, step_idx); step_idx += api_passes // 4
+        torch.cuda.synchronize(); cdist.barrier()
+        l_dt = cdist.max_over_ranks(time.perf_counter() - t0)
+        step_api = {"passes": api_passes, "window": args.window,
+                    "catan_step_deferred_us_per_call": d_dt / api_passes * 1e6, "waiting_fraction": waiting_now,
+                    "catan_step_deferred_env_steps_per_s": world * n * (1.0 - waiting_now) * api_passes / d_dt,
+                    "catan_step_us_per_call": l_dt / (api_passes // 4) * 1e6, "catan_step_env_steps_per_s": world * n * (api_passes // 4) / l_dt,
+                    "note": "catan_sample_random_actions (global step index: a policy stub) + the step call per pass, actions in a caller-owned "
+                            "buffer; the deferred rate = games x (share of games whose step completes in a call, counted over 256 further calls) / time per call"}
+
     out = None
     kms = None
     if rank == 0:
@@ -366,6 +405,8 @@ def main():
         }
         if lockstep is not None:
             out["lockstep"] = lockstep
+        if step_api is not None:
+            out["step_api"] = step_api
         if ppo is not None:
             out["roofline_learner"] = ppo.pop("roofline_learner", None)
             out["ppo_update"] = ppo

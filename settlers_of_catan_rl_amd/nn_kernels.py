@@ -61,6 +61,54 @@ def supported(L, H, HD):
 LN_WIDTHS = {16, 25, 32, 64, 128, 256, 512}
 
 
+class _GradArena(object):
+    """The zero-initialised fp32 accumulators of the backward kernels (weight / bias gradients summed over row blocks with
+    atomics) as slices of ONE buffer that is cleared by ONE fill per optimiser step: as ~100 `torch.zeros` calls they were ~100
+    launches of ~3.5 us each in every minibatch step (profiles/r04_update_step_ops.txt).  `begin_step()` (PPOTrainer, before a
+    step's forward) clears what the previous step used and rewinds; outside a step - or past the end of the buffer, which then
+    grows for the next step - `zeros` is `torch.zeros`.  The slices become the parameters' `.grad` (autograd takes them over):
+    they are read by the optimiser before the next `begin_step`, which is the contract of `GradBucket.zero()` as well."""
+
+    def __init__(self):
+        self.buf, self.off, self.used, self.need, self.active = None, 0, 0, 0, False
+        self.enabled = True                              # (A/B switch: tools/ab_step_switches.py)
+
+    def begin_step(self, device):
+        if not self.enabled:
+            self.active = False
+            return
+        want = max(self.need + self.need // 4, 1 << 20)
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < want:
+            self.buf = torch.zeros(want, dtype=torch.float32, device=device)
+        elif self.used:
+            self.buf[:self.used].zero_()
+        self.off, self.used, self.need, self.active = 0, 0, 0, True
+
+    def end_step(self):
+        self.used, self.active = self.off, False
+
+    def zeros(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 127) & ~127                              # 512-byte aligned slices, like the allocator's blocks (the kernels' atomics run by cache line)
+        self.need += n_al
+        if not self.active or self.buf is None or self.buf.device != torch.device(device) or self.off + n_al > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        self.used = self.off
+        return v
+
+
+grad_arena = _GradArena()
+
+
+def grad_zeros(shape, device):
+    """a zeroed fp32 accumulator for a backward kernel (see _GradArena)"""
+    return grad_arena.zeros(tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),), device)
+
+
 class _SmallLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, relu):
@@ -82,7 +130,7 @@ class _SmallLayerNorm(torch.autograd.Function):
         rows = x.numel() // D
         dy = _aligned(dy.to(x.dtype))
         dx = torch.empty_like(x)
-        dwb = torch.zeros((2, D), dtype=torch.float32, device=x.device)      # one fill for both accumulators
+        dwb = grad_zeros((2, D), x.device)      # both accumulators
         dw, db = dwb[0], dwb[1]
         _lib.check(_lib.lib().catan_layer_norm_bwd(_ptr(x), _ptr(wf), _ptr(bf), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), rows, D,
                                                    float(ctx.eps), int(ctx.relu), int(x.dtype == torch.bfloat16), _stream()))
@@ -113,7 +161,7 @@ class _PreNorm(torch.autograd.Function):
         D = x.shape[-1]
         rows = x.numel() // D
         dx = torch.empty_like(x)
-        dwb = torch.zeros((2, D), dtype=torch.float32, device=x.device)
+        dwb = grad_zeros((2, D), x.device)
         L = _lib.lib()
         if dy is None:
             return dres, None, None, None
@@ -275,7 +323,7 @@ class _LinearTallSkinny(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_rows(dy2, wb.t().contiguous() if ctx.pad else bf16_t_of(w), None)          # dx[r][i] = sum_o dy[r][o] * w[o][i]
             dx = (dy2 @ wb if dx is None else dx).reshape(xb.shape)
-        acc = torch.zeros((O * I + O,), dtype=torch.float32, device=dy.device)          # one fill for dw and db
+        acc = grad_zeros((O * I + O,), dy.device)          # dw and db
         dw, db = acc[:O * I].view(O, I), (acc[O * I:] if ctx.has_bias else None)
         _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))
         if ctx.pad:
@@ -307,7 +355,7 @@ def _linear_rows(x, w, b, aux=None, mode=MODE_NONE):
 
 def _wgrad(x2, dy2, has_bias):
     O, I = dy2.shape[1], x2.shape[1]
-    acc = torch.zeros((O * I + O,), dtype=torch.float32, device=dy2.device)             # one fill for dw and db
+    acc = grad_zeros((O * I + O,), dy2.device)             # dw and db
     dw, db = acc[:O * I].view(O, I), (acc[O * I:] if has_bias else None)
     _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))
     return dw, db
@@ -626,7 +674,7 @@ def _ln_backward(x, w, b, dy, eps, relu, dres=None):
     """-> (dx, dw, db) of LayerNorm (+ ReLU) over the last dim of bf16 x [rows, D]; dres: a second gradient of x added in"""
     rows, D = x.shape
     dx = torch.empty_like(x)
-    dwb = torch.zeros((2, D), dtype=torch.float32, device=x.device)
+    dwb = grad_zeros((2, D), x.device)
     wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
     L = _lib.lib()
     if dres is None:
@@ -820,7 +868,7 @@ class _TileEncoderTrain(torch.autograd.Function):
                 if _te_backward_fused_w():
                     # k_ffn_bwd_w: the chain below AND both weight gradients in one pass over the rows (dH never leaves the chip)
                     dxmid = torch.empty_like(xmid)
-                    acc = torch.zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), dtype=torch.float32, device=h.device)
+                    acc = grad_zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), h.device)
                     dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:16704]
                     dwo, dbo = acc[16704:20800], acc[20800:]
                     lw, lb = P[b + 10].detach().float().contiguous(), P[b + 11].detach().float().contiguous()
@@ -842,7 +890,7 @@ class _TileEncoderTrain(torch.autograd.Function):
                     dxmid, g[b + 10], g[b + 11] = _ln_backward(xmid, P[b + 10], P[b + 11], dn2, eps, False, dres=dx)
                 else:                           # the same three steps in one pass over the rows (k_ffn_bwd_dx)
                     dh, dxmid = torch.empty_like(h), torch.empty_like(xmid)
-                    dl = torch.zeros((2, 64), dtype=torch.float32, device=h.device)
+                    dl = grad_zeros((2, 64), h.device)
                     lw = P[b + 10].detach().float().contiguous()                          # (named: alive until the launch is queued)
                     _lib.check(_lib.lib().catan_ffn_bwd_dx(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(w2t), _ptr(w1t), _ptr(lw), eps, _ptr(dh), _ptr(dxmid),
                                                            _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
@@ -858,7 +906,7 @@ class _TileEncoderTrain(torch.autograd.Function):
                 fused_w = _te_backward_fused_w()
                 if fused_w:                     # k_qkv_bwd_w: the QKV product's weight gradient and the dX chain in one pass over the rows
                     dx = torch.empty_like(xin)
-                    acc = torch.zeros((192 * 64 + 192 + 128,), dtype=torch.float32, device=xin.device)
+                    acc = grad_zeros((192 * 64 + 192 + 128,), xin.device)
                     dwq, dbq, dl = acc[:12288].view(192, 64), acc[12288:12480], acc[12480:]
                     lw, lb = P[b].detach().float().contiguous(), P[b + 1].detach().float().contiguous()
                     _lib.check(_lib.lib().catan_qkv_bwd(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(n1) if n1 is not None else None, _ptr(wqt), _ptr(lw), _ptr(lb), eps,
@@ -876,7 +924,7 @@ class _TileEncoderTrain(torch.autograd.Function):
                     dx, g[b], g[b + 1] = _ln_backward(xin, P[b], P[b + 1], dn1, eps, False, dres=dxmid)
                 else:                           # the same two steps in one pass over the rows (k_qkv_bwd_dx)
                     dx = torch.empty_like(xin)
-                    dl = torch.zeros((2, 64), dtype=torch.float32, device=xin.device)
+                    dl = grad_zeros((2, 64), xin.device)
                     lw = P[b].detach().float().contiguous()
                     _lib.check(_lib.lib().catan_qkv_bwd_dx(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
                     g[b], g[b + 1] = dl[0], dl[1]
@@ -1067,11 +1115,11 @@ class _CardSummary(torch.autograd.Function):
     def backward(ctx, dout):
         ids, lens, p, keys = ctx.saved_tensors
         L = _lib.lib()
-        dparams = torch.zeros_like(p)
+        dparams = grad_zeros(tuple(p.shape), p.device) if p.dtype == torch.float32 else torch.zeros_like(p)
         d = dout.contiguous().float()
         pid, plen = _pattern_lists(ids.device)
         reps = 8 if ids.shape[0] >= 32768 else 1
-        dpat = torch.zeros((reps, pid.shape[0], 16), dtype=torch.float32, device=ids.device)
+        dpat = grad_zeros((reps, pid.shape[0], 16), ids.device)
         n_unkeyed = torch.zeros((1,), dtype=torch.int32, device=ids.device)
         _lib.check(L.catan_card_pattern_sum(_ptr(keys), _ptr(d), _ptr(dpat), reps, _ptr(n_unkeyed), ids.shape[0], _stream()))
         dpat = dpat.sum(0) if reps > 1 else dpat[0]

@@ -253,6 +253,8 @@ class PPOTrainer(object):
                                                    cfg.clip_param, cfg.value_loss_coef,
                                                    value_normaliser=(pol.VALUE_MEAN, pol.VALUE_STD))     # ppo.py:46-63
                 self.bucket.zero()
+                if dev.type == "cuda":
+                    nn_kernels.grad_arena.begin_step(dev)                                  # the backward kernels' accumulators: one fill per step
                 (loss - ent * cfg.entropy_coef).backward()                                 # ppo.py:66
                 if timed_allreduce:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -264,6 +266,7 @@ class PPOTrainer(object):
                     self.bucket.allreduce()
                 torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
                 self.optimiser.step()
+                nn_kernels.grad_arena.end_step()
                 nn_kernels.weight_images.refresh_all()                                     # every bf16 / transposed / packed image of the new weights: one launch
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))
             self._sync(); t3 = time.perf_counter()

@@ -18,7 +18,8 @@ tr = PPOTrainer(net, PPOConfig(ppo_epoch=1, num_mini_batch=64), autocast_dtype=t
 class Stop(Exception): pass
 calls = [0]
 orig = tr.optimiser.step
-prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True)
+prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(os.environ.get('STACKS')),
+               experimental_config=(torch._C._profiler._ExperimentalConfig(verbose=True) if os.environ.get('STACKS') else None))
 NS = 4
 def step(*a, **k):
     r = orig(*a, **k)
@@ -58,3 +59,17 @@ by = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswit
 by.sort(key=lambda e: -e.self_device_time_total)
 for e in by[:70]:
     print("%-28s %8.1f us/step x%.1f  %s" % (e.key[:28], e.self_device_time_total / NS, e.count / NS, str(e.input_shapes)[:170]))
+
+if os.environ.get("STACKS"):
+    print("---- small launches (copy_ / fill_ / add_ / add / mul / zero_) by the first frame inside the package (device us per step, calls per step)")
+    agg = {}
+    for e in prof.key_averages(group_by_stack_n=12):
+        if e.key not in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::mul", "aten::zero_", "aten::cat", "aten::sum", "aten::index"):
+            continue
+        fr = next((f for f in e.stack if "settlers_of_catan_rl_amd" in f), e.stack[0] if e.stack else "?")
+        fr = fr.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/settlers_of_catan_rl_amd/", "")
+        k = (e.key, fr[:110])
+        a = agg.setdefault(k, [0.0, 0])
+        a[0] += e.self_device_time_total; a[1] += e.count
+    for (key, fr), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:90]:
+        print("%-12s %8.1f us/step x%6.1f  %s" % (key, t / NS, c / NS, fr))
