@@ -100,6 +100,11 @@ int catan_layer_norm_bwd_res(const void* x, const float* w, const float* b, cons
 int catan_linear_wgrad_supported(int64_t rows, int in_features, int out_features);
 int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int64_t rows, int in_features, int out_features,
                        catan_stream_t stream);
+/* The same for a list of layers (a HOST array) in as few launches as their tile shapes allow: the action heads' first layers of a PPO
+ * minibatch see only the rows whose action type uses the head (10^3..10^4 each), and a launch per (head, 128-column slice of the
+ * 512-wide trunk) is all ramp and tail.  Every problem as catan_linear_wgrad takes it (dw / db accumulated into). */
+typedef struct { const void* x; const void* dy; float* dw; float* db; int64_t rows; int32_t in_features, out_features; } catan_wgrad_problem_t;
+int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n, catan_stream_t stream);
 
 /* y[r][n] = sum_k x[r][k] * w[n][k] (+ bias[n]) for huge row counts and small widths (forward and input-gradient GEMMs of
  * the same layers as catan_linear_wgrad): x [rows][in], w [out][in], bias [out] or NULL, y [rows][out], all bfloat16

@@ -16,6 +16,12 @@ class CatanHipError(RuntimeError):
     pass
 
 
+class CatanWgradProblem(C.Structure):
+    """catan_wgrad_problem_t (include/catan_hip_nn.h)"""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("rows", C.c_int64),
+                ("in_features", C.c_int32), ("out_features", C.c_int32)]
+
+
 class CatanCfg(C.Structure):
     _fields_ = [("max_proposed_trades_per_turn", C.c_int32), ("dense_reward", C.c_int32), ("validate_actions", C.c_int32),
                 ("auto_reset", C.c_int32), ("win_reward", C.c_double), ("reward_annealing_factor", C.c_double),
@@ -185,6 +191,7 @@ _SIGS = {
     "catan_missed_speculation_count": (C.c_int64, [_vp, _vp]),
     "catan_linear_wgrad_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "catan_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "catan_linear_wgrad_grouped": (C.c_int, [C.POINTER(CatanWgradProblem), C.c_int32, _vp]),
 }
 
 

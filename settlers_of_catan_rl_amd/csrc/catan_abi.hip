@@ -211,6 +211,22 @@ static int wgrad_dispatch_it(int it, const void* x, const void* dy, float* dw, f
     return fail(CATAN_EINVAL, "catan_linear_wgrad: in_features + 1 > 160");
 }
 
+template <int OTW, int IT>
+static int wgrad_launch_grouped(const WgBatch& b, long blocks, hipStream_t st) {
+    hipLaunchKernelGGL((k_wgrad_tr_grouped<OTW, IT>), dim3((unsigned)blocks), dim3(256), 0, st, b);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+static int wgrad_launch_grouped_dispatch(int otw, int itc, const WgBatch& b, long blocks, hipStream_t st) {
+#define CATAN_WG_CASE(A, B) if (otw == A && itc == B) return wgrad_launch_grouped<A, B>(b, blocks, st)
+    CATAN_WG_CASE(1, 2); CATAN_WG_CASE(1, 5); CATAN_WG_CASE(1, 10);
+    CATAN_WG_CASE(2, 2); CATAN_WG_CASE(2, 5); CATAN_WG_CASE(2, 10);
+    CATAN_WG_CASE(3, 2); CATAN_WG_CASE(3, 5); CATAN_WG_CASE(3, 10);
+    CATAN_WG_CASE(4, 2); CATAN_WG_CASE(4, 5); CATAN_WG_CASE(4, 10);
+#undef CATAN_WG_CASE
+    return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: no kernel for this tile shape");
+}
+
 template <int KS>
 static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void* b, void* y, long R, int K, int N, const void* aux, int mode, hipStream_t st) {
     long nb = ((R + 15) / 16 + 3) / 4;
@@ -1129,6 +1145,56 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
     case 3: return wgrad_dispatch_it<3>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
     default: return wgrad_dispatch_it<4>(it, x, dy, dw, db, rows, in_features, out_features, S(stream));
     }
+}
+
+// catan_linear_wgrad for a list of problems (host array) with as few launches as their tile shapes allow: units of the same
+// (output tile, input tile) template share launches of up to WG_MAX_UNITS units; a problem the transposing-read kernel does not take
+// (widths that are not multiples of 8) is launched on its own as before.
+int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n, catan_stream_t stream) {
+    if (!problems || n <= 0) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad arguments");
+    struct Unit { WgUnit u; int otw, itc; long nb; };
+    std::vector<Unit> units;
+    for (int p = 0; p < n; p++) {
+        const catan_wgrad_problem_t& q = problems[p];
+        if (!q.x || !q.dy || !q.dw || !catan_linear_wgrad_supported(q.rows, q.in_features, q.out_features))
+            return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad problem / unsupported widths");
+        if (((uintptr_t)q.x | (uintptr_t)q.dy) & 15) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: x and dy must be 16-byte aligned");
+        const int I = q.in_features, O = q.out_features;
+        const int otw = ((O + 15) / 16 + 3) / 4;
+        if (wgrad_sliced(I, O)) {
+            for (int c0 = 0; c0 < I; c0 += 128) {
+                const int W = I - c0 < 128 ? I - c0 : 128;
+                Unit t; long per;
+                wgrad_grid(q.rows, W, O, t.nb, per);
+                t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, c0 == 0 ? q.db : nullptr, (long)q.rows, per, (long)I, W, O, c0, 0 };
+                t.otw = otw; t.itc = 10;
+                units.push_back(t);
+            }
+        } else if ((I & 7) == 0 && (O & 7) == 0) {
+            const int it = (I + 1 + 15) / 16;
+            Unit t; long per;
+            wgrad_grid(q.rows, I, O, t.nb, per);
+            t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, q.db, (long)q.rows, per, 0L, I, O, 0, 0 };
+            t.otw = otw; t.itc = it <= 2 ? 2 : (it <= 5 ? 5 : 10);
+            units.push_back(t);
+        } else {
+            int r = catan_linear_wgrad(q.x, q.dy, q.dw, q.db, q.rows, I, O, stream);
+            if (r != CATAN_OK) return r;
+        }
+    }
+    std::vector<char> done(units.size(), 0);
+    for (size_t a = 0; a < units.size(); a++) {
+        if (done[a]) continue;
+        WgBatch b; b.n = 0; long blocks = 0;
+        for (size_t c = a; c < units.size(); c++) {
+            if (done[c] || units[c].otw != units[a].otw || units[c].itc != units[a].itc) continue;
+            if (b.n == WG_MAX_UNITS) break;
+            b.u[b.n] = units[c].u; b.u[b.n].block0 = (int)blocks; blocks += units[c].nb; b.n++; done[c] = 1;
+        }
+        int r = wgrad_launch_grouped_dispatch(units[a].otw, units[a].itc, b, blocks, S(stream));
+        if (r != CATAN_OK) return r;
+    }
+    return CATAN_OK;
 }
 
 static int head_launch(const HeadArgs& a, hipStream_t st) {

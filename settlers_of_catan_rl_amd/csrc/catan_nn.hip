@@ -679,9 +679,9 @@ __device__ __forceinline__ void wg_load_cols(const unsigned short* __restrict__ 
     }
 }
 template <int OTW, int IT>
-__global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
-                                                  float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
-                                                  long ldx = 0, int col0 = 0) {
+__device__ __forceinline__ void wgrad_tr_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                              float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
+                                              long ldx, int col0, long bid) {
     // ldx != 0: X is a column slice - columns col0 .. col0 + I - 1 of a matrix with leading dimension ldx, and dW the same
     // columns of a weight gradient with that leading dimension (the layers wider than one launch covers are done in slices)
     constexpr int XC = IT * 16, YC = OTW * 4 * 16;           // padded column counts
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restri
     __shared__ __attribute__((aligned(16))) unsigned short Xs[XE];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[YE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_begin = bid * rows_per_block;
     const long r_end = r_begin + rows_per_block < R ? r_begin + rows_per_block : R;
     if (r_begin >= R) return;
     for (int x = tid; x < XE; x += 256) Xs[x] = 0;
@@ -743,6 +743,26 @@ __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restri
             }
 }
 
+template <int OTW, int IT>
+__global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                                  float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
+                                                  long ldx = 0, int col0 = 0) {
+    wgrad_tr_body<OTW, IT>(X, dY, dW, db, R, I, O, rows_per_block, ldx, col0, (long)blockIdx.x);
+}
+// Several weight gradients of the same tile shape in ONE launch (catan_linear_wgrad_grouped): the action heads' first layers see a
+// few thousand to a few ten thousand rows each (the rows whose action type uses the head), and a launch per (head, column slice) -
+// 44 of them per minibatch step - is all ramp and tail.  A unit = one (problem, column slice); its blocks follow the previous unit's.
+constexpr int WG_MAX_UNITS = 28;
+struct WgUnit { const unsigned short* X; const unsigned short* dY; float* dW; float* db; long R; long per; long ldx; int I, O, col0, block0; };
+struct WgBatch { WgUnit u[WG_MAX_UNITS]; int n; };
+template <int OTW, int IT>
+__global__ __launch_bounds__(256) void k_wgrad_tr_grouped(WgBatch b) {
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.n; i++) if ((int)blockIdx.x >= b.u[i].block0) k = i;
+    const WgUnit& u = b.u[k];
+    wgrad_tr_body<OTW, IT>(u.X, u.dY, u.dW, u.db, u.R, u.I, u.O, u.per, u.ldx, u.col0, (long)blockIdx.x - u.block0);
+}
 
 // ------------------------------------------------------------------------------------------------ tall-skinny linear (forward / dX)
 // y[r][n] = sum_k x[r][k] * W[n][k] (+ b[n]) for huge row counts and small widths (K = in <= 128 and a multiple of 8,

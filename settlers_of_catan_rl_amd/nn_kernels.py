@@ -361,6 +361,23 @@ def _wgrad(x2, dy2, has_bias):
     return dw, db
 
 
+def wgrad_grouped(pairs, has_bias=True):
+    """[(x2 [rows_k, I_k], dy2 [rows_k, O_k]) bf16] -> [(dW_k fp32 [O_k, I_k], db_k [O_k])] through catan_linear_wgrad_grouped: problems of
+    the same tile shape share launches (the heads' first layers on their row segments: 44 launches -> 2)."""
+    import ctypes as C
+    probs = (_lib.CatanWgradProblem * len(pairs))()
+    keep, out = [], []
+    for k, (x2, dy2) in enumerate(pairs):
+        x2, dy2 = _aligned(x2), _aligned(dy2.to(torch.bfloat16))
+        O, I = dy2.shape[1], x2.shape[1]
+        acc = grad_zeros((O * I + O,), dy2.device)
+        dw, db = acc[:O * I].view(O, I), (acc[O * I:] if has_bias else None)
+        probs[k] = _lib.CatanWgradProblem(x2.data_ptr(), dy2.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, x2.shape[0], I, O)
+        keep.append((x2, dy2)); out.append((dw, db))
+    _lib.check(_lib.lib().catan_linear_wgrad_grouped(probs, len(pairs), _stream()))
+    return out
+
+
 def wgrad_supported(rows, in_features, out_features):
     return bool(_lib.lib().catan_linear_wgrad_supported(rows, in_features, out_features))
 
@@ -845,6 +862,13 @@ class _TileEncoderTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        # The saved activations are views of the ONE shared workspace, which autograd's version counters do not track: once this
+        # backward has given the lease back, a later forward may overwrite them.  A second backward over the same graph
+        # (retain_graph=True) would then silently compute gradients from another step's activations: refuse it.
+        if getattr(ctx, "consumed", False) and getattr(ctx, "lease", None) is not None:
+            raise RuntimeError("_TileEncoderTrain: second backward over a forward whose activation workspace has been released "
+                               "(retain_graph is not supported with the shared workspace; set CATAN_TE_WORKSPACE=0)")
+        ctx.consumed = True
         ns = len(ctx.save_names)
         sv = dict(zip(ctx.save_names, ctx.saved_tensors[:ns]))
         P = ctx.saved_tensors[ns:]

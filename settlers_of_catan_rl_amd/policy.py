@@ -458,10 +458,11 @@ class _SegmentedTrunk(torch.autograd.Function):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         dx = torch.empty_like(x)
         seen = set()
-        dws, dbs = [], []
-        for (a, b), w, g in zip(ctx.segs, ws, douts):
+        n = len(ctx.segs)
+        dws, dbs = [None] * n, [None] * n
+        grouped = []                                            # (segment index, x rows, dy): their weight gradients in shared launches
+        for k, ((a, b), w, g) in enumerate(zip(ctx.segs, ws, douts)):
             if g is None:
-                dws.append(None); dbs.append(None)
                 continue
             g = g.to(x.dtype)
             contrib = g @ _cast_w(w, x.dtype)
@@ -471,16 +472,26 @@ class _SegmentedTrunk(torch.autograd.Function):
                 dx[a:b] = contrib
                 seen.add((a, b))
             if x.is_cuda and x.dtype == torch.bfloat16 and b - a >= 4096 and nn_kernels.wgrad_supported(b - a, x.shape[1], g.shape[1]):
-                dw, db = nn_kernels.wgrad(x[a:b], g)        # MFMA weight-gradient kernel (column slices of the 512-wide trunk)
-                dws.append(dw.to(w.dtype)); dbs.append(db)
+                grouped.append((k, x[a:b], g))                  # MFMA weight-gradient kernel (column slices of the 512-wide trunk)
             else:
-                dws.append((g.t() @ x[a:b]).to(w.dtype))
-                dbs.append(g.float().sum(0))
+                dws[k] = (g.t() @ x[a:b]).to(w.dtype)
+                dbs[k] = g.float().sum(0)
+        if grouped:
+            if GROUPED_WGRAD:
+                for (k, _, _), (dw, db) in zip(grouped, nn_kernels.wgrad_grouped([(xs, g) for _, xs, g in grouped])):
+                    dws[k], dbs[k] = dw.to(ws[k].dtype), db
+            else:
+                for k, xs, g in grouped:
+                    dw, db = nn_kernels.wgrad(xs, g)
+                    dws[k], dbs[k] = dw.to(ws[k].dtype), db
         for (a, b) in ctx.segs:
             if (a, b) not in seen:
                 dx[a:b] = 0
                 seen.add((a, b))
         return (dx, None) + tuple(dws) + tuple(dbs)
+
+
+GROUPED_WGRAD = True        # (A/B switch, tools/ab_step_switches.py)
 
 
 class _ActionHeads(nn.Module):
@@ -527,11 +538,11 @@ class _ActionHeads(nn.Module):
         step - even behind an event - holds the host at the start of every step until the device has finished the previous one, and
         the ~1 500 launches of a step then go out with the device waiting for each of them (the step is host-paced from there on).
         actions_all [rows, 18]; perm: the epoch's permutation.  -> list of (perm_k, ends_k (host list), None)"""
-        a = actions_all[perm[:num_mini_batch * mbs]]
-        typ, card = a[:, 0].view(num_mini_batch, mbs), a[:, 4].view(num_mini_batch, mbs)
+        rows = perm[:num_mini_batch * mbs]                  # (only the two columns the key is made of are gathered, not all 18)
+        typ, card = actions_all[:, 0][rows].view(num_mini_batch, mbs), actions_all[:, 4][rows].view(num_mini_batch, mbs)
         key = typ * 8 + torch.where(typ == T_PLAYDEV, card.clamp(0, 7), torch.zeros_like(card))
         order = torch.argsort(key, dim=1, stable=True)
-        counts = torch.zeros((num_mini_batch, 13 * 8), dtype=torch.int64, device=a.device)
+        counts = torch.zeros((num_mini_batch, 13 * 8), dtype=torch.int64, device=typ.device)
         counts.scatter_add_(1, key, torch.ones_like(key))
         ends = torch.cumsum(counts, 1).tolist()
         return [(order[k], ends[k], None) for k in range(num_mini_batch)]

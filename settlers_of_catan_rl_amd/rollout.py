@@ -22,9 +22,16 @@ from . import spec
 
 class RolloutStorage(object):
     """The tensors `BatchProcessor` holds after `process_rollouts` (process_batch.py:37-104), device resident."""
+    _tokens = iter(range(1, 1 << 62))
+
+    def invalidate(self):
+        """the contents changed by other means than gather_rollouts (a loaded rollout, an in-place edit): consumers that cache
+        per-rollout derived data (PPOTrainer's distinct boards) key on (token, generation) and recompute"""
+        self.generation += 1
 
     def __init__(self, T, N, device, obs_dtype=torch.float32, lstm_size=0):
         self.T, self.N = T, N
+        self.token = next(RolloutStorage._tokens)      # process-unique: a later storage at the same address is another rollout
         # process_batch.py:53-59: the active seat's LSTM state (h, c) entering each of its stored decisions
         self.hidden = torch.zeros((2, T + 1, N, lstm_size), dtype=torch.float32, device=device) if lstm_size else None
         self.obs_f = torch.zeros((T + 1, N, spec.OBS_FLOATS), dtype=obs_dtype, device=device)

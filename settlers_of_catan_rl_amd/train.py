@@ -99,8 +99,9 @@ class PPOTrainer(object):
         o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
         tiles = st.obs_f[:, :, o:o + 1140]
         new = torch.ones((T1, N), dtype=torch.bool, device=tiles.device)
-        for t0 in range(1, T1, 16):                            # (chunked: the comparison materialises a [t, N, 1140] mask)
-            t1 = min(T1, t0 + 16)
+        step = max(1, min(16, (256 << 20) // max(1, N * 1140)))   # (chunked by bytes: the comparison materialises a [t, N, 1140] mask, <= 256 MB)
+        for t0 in range(1, T1, step):
+            t1 = min(T1, t0 + step)
             new[t0:t1] = (tiles[t0:t1] != tiles[t0 - 1:t1 - 1]).any(-1)
         flat = new.reshape(-1)
         first_rows = flat.nonzero(as_tuple=True)[0]
@@ -151,8 +152,8 @@ class PPOTrainer(object):
             vnet = self._value_net
         if self.dedupe_boards and not rec and f.is_cuda and hasattr(self.policy, "observation_module"):
             from . import spec
-            key = (st.obs_f.data_ptr(), getattr(st, "generation", None), T1, N)
-            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None:
+            key = (getattr(st, "token", None), getattr(st, "generation", None), T1, N)
+            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None or getattr(st, "token", None) is None:
                 self._runs = self.board_runs(st)                # once per rollout: the storage does not change between the epochs
                 self._runs_key = key
             first_rows, board_of_row = self._runs
@@ -198,8 +199,8 @@ class PPOTrainer(object):
         dedupe = bool(self.dedupe_boards and not rec and dev.type == "cuda" and hasattr(pol, "observation_module") and mbs >= self.dedupe_min_rows)
         if dedupe:
             from . import spec
-            key = (st.obs_f.data_ptr(), getattr(st, "generation", None), T + 1, N)
-            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None:
+            key = (getattr(st, "token", None), getattr(st, "generation", None), T + 1, N)
+            if getattr(self, "_runs_key", None) != key or getattr(st, "generation", None) is None or getattr(st, "token", None) is None:
                 self._runs = self.board_runs(st)
                 self._runs_key = key
             first_rows, board_of_row = self._runs

@@ -195,6 +195,30 @@ def test_linear_wgrad_kernel_vs_torch(hip_lib, R, I, O):
     assert float((db.double() - ref_b).abs().max()) < 2e-5 * float(ref_b.abs().max()) + 1e-3
 
 
+def test_grouped_linear_wgrad_equals_the_single_launches(hip_lib):
+    """catan_linear_wgrad_grouped: a mixed list of layers - sliced 512-wide inputs on ragged row segments (the heads' first layers),
+    plain widths of three tile shapes, widths that are not multiples of 8 (launched on their own), with and without a bias
+    gradient, more units than one launch holds - against fp32 torch and bit-for-bit against catan_linear_wgrad problem by problem
+    (same blocks, same atomics order within a problem is not guaranteed: compared with a tolerance of a few ULPs of the sums)."""
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(1820, 512, 128), (6101, 512, 128), (37138, 512, 128), (40142, 512, 128), (13073, 512, 128), (4097, 512, 128), (16298, 512, 128),
+              (36842, 512, 128), (12858, 512, 128), (3085, 512, 128), (4007, 512, 128), (20000, 128, 64), (70001, 64, 192), (33333, 152, 256),
+              (5000, 6, 16), (100001, 64, 128), (777, 168, 8), (30001, 256, 256), (9000, 16, 48)]
+    xs = [(torch.randn((R, I), device="cuda", generator=g) * torch.linspace(0.5, 2.0, I, device="cuda")).to(torch.bfloat16) for R, I, O in shapes]
+    dys = [(torch.randn((R, O), device="cuda", generator=g) * torch.linspace(2.0, 0.25, O, device="cuda") + 0.1).to(torch.bfloat16) for R, I, O in shapes]
+    got = nn_kernels.wgrad_grouped(list(zip(xs, dys)))
+    for (R, I, O), x, dy, (dw, db) in zip(shapes, xs, dys, got):
+        ref_w = dy.double().t() @ x.double()
+        ref_b = dy.double().sum(0)
+        assert float((dw.double() - ref_w).abs().max()) < 2e-5 * float(ref_w.abs().max()) + 1e-3, (R, I, O)
+        assert float((db.double() - ref_b).abs().max()) < 2e-5 * float(ref_b.abs().max()) + 1e-3, (R, I, O)
+        one_w, one_b = nn_kernels.wgrad(x, dy)
+        assert float((dw - one_w).abs().max()) <= 1e-5 * float(ref_w.abs().max()) + 1e-4, (R, I, O)
+    got_nb = nn_kernels.wgrad_grouped(list(zip(xs[:3], dys[:3])), has_bias=False)
+    assert all(db is None for _, db in got_nb) and all(torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-3) for a, b in zip(got_nb, got[:3]))
+
+
 def test_policy_grads_with_wgrad_kernel_match_library_path(hip_lib, monkeypatch):
     """The net's parameter gradients under bf16 autocast: tall-skinny Linear layers through k_wgrad vs through F.linear."""
     from settlers_of_catan_rl_amd.env import VecCatanEnv

@@ -26,7 +26,10 @@ def set_tuned(on):
     tun.enable(on)
 
 
-SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned}
+def set_grouped(on): pol_mod.GROUPED_WGRAD = on
+
+
+SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped}
 if hasattr(pol_mod, "TRUNK_WINDOWS"):
     SW["trunk_windows"] = set_trunk
 
