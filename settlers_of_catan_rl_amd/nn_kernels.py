@@ -104,6 +104,48 @@ class _GradArena(object):
 grad_arena = _GradArena()
 
 
+class _WgradQueue(object):
+    """Weight gradients that wait for the end of the backward pass (PPOTrainer: `begin()` before `loss.backward()`, `flush()`
+    right after it).  A tall-skinny layer's weight gradient over 10^4..10^5 rows is a launch of ramp and tail; nothing reads it before
+    the optimiser step, so the backward only queues (x, dy, parameter) and ONE grouped launch per tile shape
+    (catan_linear_wgrad_grouped) accumulates all of them - into whatever buffer the parameter's `.grad` is by then: the backward
+    hands autograd a zero tensor for a parameter that has no `.grad` yet (autograd keeps it or copies it: either way `.grad` exists
+    at the flush) and nothing for one that has (the flat bucket's view under several ranks, or an earlier use of a shared layer)."""
+
+    def __init__(self):
+        self.items, self.active, self.enabled = [], False, True
+
+    def begin(self):
+        self.items, self.active = [], bool(self.enabled)
+
+    def take(self, x2, dy2, w, b):
+        """queue dW += dy2^T x2, db += column sums of dy2 for the leaf parameters w, b; -> what the backward returns for them"""
+        self.items.append((x2, dy2, w, b))
+        rw = None if w.grad is not None else grad_zeros(tuple(w.shape), w.device)
+        rb = None if (b is None or b.grad is not None) else grad_zeros(tuple(b.shape), b.device)
+        return rw, rb
+
+    def accepts(self, w, b):
+        ok = lambda p: p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous()
+        return self.active and ok(w) and (b is None or ok(b))
+
+    def flush(self):
+        items, self.items, self.active = self.items, [], False
+        if not items:
+            return
+        probs = (_lib.CatanWgradProblem * len(items))()
+        for k, (x2, dy2, w, b) in enumerate(items):
+            gw, gb = w.grad, (None if b is None else b.grad)
+            if gw is None or gw.dtype != torch.float32 or not gw.is_contiguous() or (b is not None and (gb is None or gb.dtype != torch.float32 or not gb.is_contiguous())):
+                raise RuntimeError("deferred weight gradient: the parameter has no fp32 contiguous .grad at the flush")
+            probs[k] = _lib.CatanWgradProblem(x2.data_ptr(), dy2.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                              x2.shape[0], x2.shape[1], dy2.shape[1])
+        _lib.check(_lib.lib().catan_linear_wgrad_grouped(probs, len(items), _stream()))
+
+
+wgrad_queue = _WgradQueue()
+
+
 def grad_zeros(shape, device):
     """a zeroed fp32 accumulator for a backward kernel (see _GradArena)"""
     return grad_arena.zeros(tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),), device)
@@ -309,13 +351,14 @@ class _LinearTallSkinny(torch.autograd.Function):
             y = _linear_rows(xb, wb, bb)
             if y is None:
                 y = torch.nn.functional.linear(xb, wb, bb)
-        ctx.save_for_backward(xb, wb, w)
+        ctx.save_for_backward(xb, wb, w, *(() if b is None else (b,)))
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xb, wb, w = ctx.saved_tensors
+        xb, wb, w = ctx.saved_tensors[:3]
+        b = ctx.saved_tensors[3] if ctx.has_bias else None
         O, I = wb.shape
         dy2 = dy.reshape(-1, O).to(torch.bfloat16).contiguous()
         x2 = xb.reshape(-1, I).contiguous()
@@ -323,6 +366,8 @@ class _LinearTallSkinny(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_rows(dy2, wb.t().contiguous() if ctx.pad else bf16_t_of(w), None)          # dx[r][i] = sum_o dy[r][o] * w[o][i]
             dx = (dy2 @ wb if dx is None else dx).reshape(xb.shape)
+        if not ctx.pad and wgrad_queue.accepts(w, b) and not ((x2.data_ptr() | dy2.data_ptr()) & 15):
+            return (dx,) + wgrad_queue.take(x2, dy2, w, b)      # the weight gradient joins the grouped launch at the end of the backward pass
         acc = grad_zeros((O * I + O,), dy.device)          # dw and db
         dw, db = acc[:O * I].view(O, I), (acc[O * I:] if ctx.has_bias else None)
         _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))

@@ -256,7 +256,11 @@ class PPOTrainer(object):
                 self.bucket.zero()
                 if dev.type == "cuda":
                     nn_kernels.grad_arena.begin_step(dev)                                  # the backward kernels' accumulators: one fill per step
-                (loss - ent * cfg.entropy_coef).backward()                                 # ppo.py:66
+                    nn_kernels.wgrad_queue.begin()                                         # tall-skinny weight gradients: grouped launches after the backward
+                try:
+                    (loss - ent * cfg.entropy_coef).backward()                             # ppo.py:66
+                finally:
+                    nn_kernels.wgrad_queue.flush()
                 if timed_allreduce:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()

@@ -253,6 +253,49 @@ def test_policy_grads_with_wgrad_kernel_match_library_path(hip_lib, monkeypatch)
         assert float((g1[k] - g0[k]).norm()) / den < 5e-2, k     # bf16 activations; the kernel path keeps dw in fp32
 
 
+def test_deferred_weight_gradients_equal_the_immediate_ones(hip_lib):
+    """nn_kernels.wgrad_queue (PPOTrainer's steps): the tall-skinny layers' weight gradients queued during the backward pass and
+    accumulated by grouped launches after it - into a `.grad` autograd created from the zero tensor it was handed (`.grad = None`
+    before the backward: one rank), and into a pre-assigned buffer (the flat bucket's views under several ranks) - equal the
+    gradients of the same backward with every weight gradient launched where it arises (fp32 sums in another order)."""
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd import nn_kernels
+    torch.manual_seed(1)
+    B = 16384
+    env = VecCatanEnv(B, seed=3)
+    env.random_rollout(0, 400)
+    f, lists, lens = env.get_obs()
+    masks = env.get_action_masks()
+    lens = lens.long()
+    net = CatanPolicy().cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, a, _ = net.act(f, lists, lens, masks, generator=torch.Generator(device="cuda").manual_seed(0))
+
+    def grads(mode):
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p) if mode == "preassigned" else None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            v, lp, ent = net.evaluate_actions(f, lists, lens, masks, a)
+        if mode != "immediate":
+            nn_kernels.wgrad_queue.begin()
+        (v.float().mean() + lp.float().mean() - 0.01 * ent).backward()
+        queued = len(nn_kernels.wgrad_queue.items)
+        nn_kernels.wgrad_queue.flush()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}, queued
+
+    g0, q0 = grads("immediate")
+    assert q0 == 0
+    for mode in ("deferred", "preassigned"):
+        g1, q1 = grads(mode)
+        assert q1 >= 20, q1                                          # (the layers really went through the queue)
+        assert g0.keys() == g1.keys()
+        floor = 1e-6 * max(float(g.norm()) for g in g0.values())
+        for k in g0:
+            assert float((g1[k] - g0[k]).norm()) <= 2e-5 * float(g0[k].norm()) + floor, (mode, k, float((g1[k] - g0[k]).norm()), float(g0[k].norm()))
+    assert not nn_kernels.wgrad_queue.active and not nn_kernels.wgrad_queue.items
+
+
 def test_rollout_with_league_opponents(hip_lib):
     """Per-worker league opponents (league.League.assign -> grouped inference in the collector): a rollout + update runs,
     no illegal action reaches the env, and with snapshots identical to the central policy the stored log-probs are those

@@ -29,7 +29,10 @@ def set_tuned(on):
 def set_grouped(on): pol_mod.GROUPED_WGRAD = on
 
 
-SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped}
+def set_deferred(on): nn_kernels.wgrad_queue.enabled = on
+
+
+SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred}
 if hasattr(pol_mod, "TRUNK_WINDOWS"):
     SW["trunk_windows"] = set_trunk
 
