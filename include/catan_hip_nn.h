@@ -103,7 +103,11 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
 /* The same for a list of layers (a HOST array) in as few launches as their tile shapes allow: the action heads' first layers of a PPO
  * minibatch see only the rows whose action type uses the head (10^3..10^4 each), and a launch per (head, 128-column slice of the
  * 512-wide trunk) is all ramp and tail.  Every problem as catan_linear_wgrad takes it (dw / db accumulated into). */
-typedef struct { const void* x; const void* dy; float* dw; float* db; int64_t rows; int32_t in_features, out_features; } catan_wgrad_problem_t;
+typedef struct {
+    const void* x; const void* dy; float* dw; float* db; int64_t rows; int32_t in_features, out_features;
+    int32_t dw_ld, dw_col0;      /* dw_ld != 0: dw points at a wider gradient [out][dw_ld] and the layer's columns are dw_col0 .. dw_col0 + in - 1 of it
+                                  * (a layer on a column slice of a parameter accumulates straight into the parameter's gradient); 0, 0: dw is [out][in] */
+} catan_wgrad_problem_t;
 int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n, catan_stream_t stream);
 
 /* y[r][n] = sum_k x[r][k] * w[n][k] (+ bias[n]) for huge row counts and small widths (forward and input-gradient GEMMs of

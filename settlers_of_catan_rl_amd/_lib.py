@@ -19,7 +19,7 @@ class CatanHipError(RuntimeError):
 class CatanWgradProblem(C.Structure):
     """catan_wgrad_problem_t (include/catan_hip_nn.h)"""
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("rows", C.c_int64),
-                ("in_features", C.c_int32), ("out_features", C.c_int32)]
+                ("in_features", C.c_int32), ("out_features", C.c_int32), ("dw_ld", C.c_int32), ("dw_col0", C.c_int32)]
 
 
 class CatanCfg(C.Structure):

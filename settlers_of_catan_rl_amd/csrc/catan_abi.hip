@@ -212,13 +212,14 @@ static int wgrad_dispatch_it(int it, const void* x, const void* dy, float* dw, f
 }
 
 template <int OTW, int IT>
-static int wgrad_launch_grouped(const WgBatch& b, long blocks, hipStream_t st) {
-    hipLaunchKernelGGL((k_wgrad_tr_grouped<OTW, IT>), dim3((unsigned)blocks), dim3(256), 0, st, b);
+static int wgrad_launch_grouped(bool tr, const WgBatch& b, long blocks, hipStream_t st) {
+    if (tr) hipLaunchKernelGGL((k_wgrad_tr_grouped<OTW, IT>), dim3((unsigned)blocks), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((k_wgrad_grouped<OTW, IT>), dim3((unsigned)blocks), dim3(256), 0, st, b);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-static int wgrad_launch_grouped_dispatch(int otw, int itc, const WgBatch& b, long blocks, hipStream_t st) {
-#define CATAN_WG_CASE(A, B) if (otw == A && itc == B) return wgrad_launch_grouped<A, B>(b, blocks, st)
+static int wgrad_launch_grouped_dispatch(bool tr, int otw, int itc, const WgBatch& b, long blocks, hipStream_t st) {
+#define CATAN_WG_CASE(A, B) if (otw == A && itc == B) return wgrad_launch_grouped<A, B>(tr, b, blocks, st)
     CATAN_WG_CASE(1, 2); CATAN_WG_CASE(1, 5); CATAN_WG_CASE(1, 10);
     CATAN_WG_CASE(2, 2); CATAN_WG_CASE(2, 5); CATAN_WG_CASE(2, 10);
     CATAN_WG_CASE(3, 2); CATAN_WG_CASE(3, 5); CATAN_WG_CASE(3, 10);
@@ -1152,7 +1153,7 @@ int catan_linear_wgrad(const void* x, const void* dy, float* dw, float* db, int6
 // (widths that are not multiples of 8) is launched on its own as before.
 int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n, catan_stream_t stream) {
     if (!problems || n <= 0) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad arguments");
-    struct Unit { WgUnit u; int otw, itc; long nb; };
+    struct Unit { WgUnit u; int otw, itc; bool tr; long nb; };
     std::vector<Unit> units;
     for (int p = 0; p < n; p++) {
         const catan_wgrad_problem_t& q = problems[p];
@@ -1160,38 +1161,38 @@ int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n,
             return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad problem / unsupported widths");
         if (((uintptr_t)q.x | (uintptr_t)q.dy) & 15) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: x and dy must be 16-byte aligned");
         const int I = q.in_features, O = q.out_features;
+        if (q.dw_ld < 0 || q.dw_col0 < 0 || (q.dw_ld != 0 && q.dw_col0 + I > q.dw_ld)) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad dw window");
+        const long ldw = q.dw_ld ? q.dw_ld : I;
         const int otw = ((O + 15) / 16 + 3) / 4;
+        Unit t; long per;
+        t.otw = otw;
         if (wgrad_sliced(I, O)) {
             for (int c0 = 0; c0 < I; c0 += 128) {
                 const int W = I - c0 < 128 ? I - c0 : 128;
-                Unit t; long per;
                 wgrad_grid(q.rows, W, O, t.nb, per);
-                t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, c0 == 0 ? q.db : nullptr, (long)q.rows, per, (long)I, W, O, c0, 0 };
-                t.otw = otw; t.itc = 10;
+                t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, c0 == 0 ? q.db : nullptr, (long)q.rows, per, (long)I, ldw, W, O, c0, q.dw_col0 + c0, 0, 0 };
+                t.itc = 10; t.tr = true;
                 units.push_back(t);
             }
-        } else if ((I & 7) == 0 && (O & 7) == 0) {
-            const int it = (I + 1 + 15) / 16;
-            Unit t; long per;
-            wgrad_grid(q.rows, I, O, t.nb, per);
-            t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, q.db, (long)q.rows, per, 0L, I, O, 0, 0 };
-            t.otw = otw; t.itc = it <= 2 ? 2 : (it <= 5 ? 5 : 10);
-            units.push_back(t);
-        } else {
-            int r = catan_linear_wgrad(q.x, q.dy, q.dw, q.db, q.rows, I, O, stream);
-            if (r != CATAN_OK) return r;
+            continue;
         }
+        const int it = (I + 1 + 15) / 16;
+        wgrad_grid(q.rows, I, O, t.nb, per);
+        t.u = WgUnit{ (const unsigned short*)q.x, (const unsigned short*)q.dy, q.dw, q.db, (long)q.rows, per, 0L, ldw, I, O, 0, q.dw_col0, 0, 0 };
+        t.itc = it <= 2 ? 2 : (it <= 5 ? 5 : 10);
+        t.tr = (I & 7) == 0 && (O & 7) == 0;               // 16 B vectors never straddle a row: the transposing-read kernel
+        units.push_back(t);
     }
     std::vector<char> done(units.size(), 0);
     for (size_t a = 0; a < units.size(); a++) {
         if (done[a]) continue;
         WgBatch b; b.n = 0; long blocks = 0;
         for (size_t c = a; c < units.size(); c++) {
-            if (done[c] || units[c].otw != units[a].otw || units[c].itc != units[a].itc) continue;
+            if (done[c] || units[c].otw != units[a].otw || units[c].itc != units[a].itc || units[c].tr != units[a].tr) continue;
             if (b.n == WG_MAX_UNITS) break;
             b.u[b.n] = units[c].u; b.u[b.n].block0 = (int)blocks; blocks += units[c].nb; b.n++; done[c] = 1;
         }
-        int r = wgrad_launch_grouped_dispatch(units[a].otw, units[a].itc, b, blocks, S(stream));
+        int r = wgrad_launch_grouped_dispatch(units[a].tr, units[a].otw, units[a].itc, b, blocks, S(stream));
         if (r != CATAN_OK) return r;
     }
     return CATAN_OK;

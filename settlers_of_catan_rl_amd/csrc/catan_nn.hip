@@ -569,15 +569,19 @@ __device__ __forceinline__ void wg_store(unsigned short* T, int W, const uint4 (
     }
 }
 
+// ldw / colw: dW is the column window colw .. colw + I - 1 of a weight gradient with leading dimension ldw (0: dW is [O][I]) - a layer
+// that multiplies a few conditioning columns with a column slice of a wider weight accumulates straight into the parameter's gradient.
 template <int OTW, int IT>
-__global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
-                                               float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block) {
+__device__ __forceinline__ void wgrad_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                           float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
+                                           long ldw_, int colw, long bid) {
     constexpr int XC = IT * 16, YC = OTW * 4 * 16;           // padded column counts
     constexpr int NX = (WG_KT * XC / 8 + 255) / 256, NY = (WG_KT * YC / 8 + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned short Xt[XC * WG_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Yt[YC * WG_LD];
+    const long ldw = ldw_ ? ldw_ : I;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_begin = bid * rows_per_block;
     const long r_end = r_begin + rows_per_block < R ? r_begin + rows_per_block : R;
     if (r_begin >= R) return;
     for (int x = tid; x < XC * WG_LD; x += 256) Xt[x] = 0;
@@ -626,10 +630,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict_
                 const int o = (wave * OTW + a) * 16 + 4 * (lane >> 4) + r, i = b * 16 + (lane & 15);
                 const float v = acc[a][b][r];
                 if (o < O && v != 0.0f) {
-                    if (i < I) atomicAdd(&dW[(long)o * I + i], v);
+                    if (i < I) atomicAdd(&dW[(long)o * ldw + colw + i], v);
                     else if (i == I && db != nullptr) atomicAdd(&db[o], v);
                 }
             }
+}
+template <int OTW, int IT>
+__global__ __launch_bounds__(256) void k_wgrad(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                               float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block) {
+    wgrad_body<OTW, IT>(X, dY, dW, db, R, I, O, rows_per_block, 0L, 0, (long)blockIdx.x);
 }
 
 
@@ -681,13 +690,13 @@ __device__ __forceinline__ void wg_load_cols(const unsigned short* __restrict__ 
 template <int OTW, int IT>
 __device__ __forceinline__ void wgrad_tr_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
                                               float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
-                                              long ldx, int col0, long bid) {
+                                              long ldx, int col0, long ldw_, int colw, long bid) {
     // ldx != 0: X is a column slice - columns col0 .. col0 + I - 1 of a matrix with leading dimension ldx, and dW the same
     // columns of a weight gradient with that leading dimension (the layers wider than one launch covers are done in slices)
     constexpr int XC = IT * 16, YC = OTW * 4 * 16;           // padded column counts
     constexpr int NX = (WG_KT * XC / 8 + 255) / 256, NY = (WG_KT * YC / 8 + 255) / 256;
     constexpr int XE = IT * (WG_KT / 32) * WG_SUB, YE = OTW * 4 * (WG_KT / 32) * WG_SUB;
-    const long ldw = ldx ? ldx : I;
+    const long ldw = ldw_ ? ldw_ : I;                         // (dW window: see wgrad_body)
     __shared__ __attribute__((aligned(16))) unsigned short Xs[XE];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[YE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,7 +746,7 @@ __device__ __forceinline__ void wgrad_tr_body(const unsigned short* __restrict__
                 const int o = (wave * OTW + a) * 16 + 4 * (lane >> 4) + r, i = b * 16 + (lane & 15);
                 const float v = acc[a][b][r];
                 if (o < O && v != 0.0f) {
-                    if (i < I) atomicAdd(&dW[(long)o * ldw + col0 + i], v);
+                    if (i < I) atomicAdd(&dW[(long)o * ldw + colw + i], v);
                     else if (i == I && db != nullptr) atomicAdd(&db[o], v);
                 }
             }
@@ -747,13 +756,13 @@ template <int OTW, int IT>
 __global__ __launch_bounds__(256) void k_wgrad_tr(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
                                                   float* __restrict__ dW, float* __restrict__ db, long R, int I, int O, long rows_per_block,
                                                   long ldx = 0, int col0 = 0) {
-    wgrad_tr_body<OTW, IT>(X, dY, dW, db, R, I, O, rows_per_block, ldx, col0, (long)blockIdx.x);
+    wgrad_tr_body<OTW, IT>(X, dY, dW, db, R, I, O, rows_per_block, ldx, col0, ldx, col0, (long)blockIdx.x);     // (a column slice of X goes to the same columns of dW)
 }
 // Several weight gradients of the same tile shape in ONE launch (catan_linear_wgrad_grouped): the action heads' first layers see a
 // few thousand to a few ten thousand rows each (the rows whose action type uses the head), and a launch per (head, column slice) -
 // 44 of them per minibatch step - is all ramp and tail.  A unit = one (problem, column slice); its blocks follow the previous unit's.
-constexpr int WG_MAX_UNITS = 28;
-struct WgUnit { const unsigned short* X; const unsigned short* dY; float* dW; float* db; long R; long per; long ldx; int I, O, col0, block0; };
+constexpr int WG_MAX_UNITS = 24;
+struct WgUnit { const unsigned short* X; const unsigned short* dY; float* dW; float* db; long R; long per; long ldx; long ldw; int I, O, col0, colw, block0, pad_; };
 struct WgBatch { WgUnit u[WG_MAX_UNITS]; int n; };
 template <int OTW, int IT>
 __global__ __launch_bounds__(256) void k_wgrad_tr_grouped(WgBatch b) {
@@ -761,7 +770,15 @@ __global__ __launch_bounds__(256) void k_wgrad_tr_grouped(WgBatch b) {
 #pragma unroll 1
     for (int i = 1; i < b.n; i++) if ((int)blockIdx.x >= b.u[i].block0) k = i;
     const WgUnit& u = b.u[k];
-    wgrad_tr_body<OTW, IT>(u.X, u.dY, u.dW, u.db, u.R, u.I, u.O, u.per, u.ldx, u.col0, (long)blockIdx.x - u.block0);
+    wgrad_tr_body<OTW, IT>(u.X, u.dY, u.dW, u.db, u.R, u.I, u.O, u.per, u.ldx, u.col0, u.ldw, u.colw, (long)blockIdx.x - u.block0);
+}
+template <int OTW, int IT>
+__global__ __launch_bounds__(256) void k_wgrad_grouped(WgBatch b) {      // widths that are not multiples of 8 (k_wgrad's staging)
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.n; i++) if ((int)blockIdx.x >= b.u[i].block0) k = i;
+    const WgUnit& u = b.u[k];
+    wgrad_body<OTW, IT>(u.X, u.dY, u.dW, u.db, u.R, u.I, u.O, u.per, u.ldw, u.colw, (long)blockIdx.x - u.block0);
 }
 
 // ------------------------------------------------------------------------------------------------ tall-skinny linear (forward / dX)

@@ -118,12 +118,26 @@ class _WgradQueue(object):
     def begin(self):
         self.items, self.active = [], bool(self.enabled)
 
-    def take(self, x2, dy2, w, b):
-        """queue dW += dy2^T x2, db += column sums of dy2 for the leaf parameters w, b; -> what the backward returns for them"""
-        self.items.append((x2, dy2, w, b))
-        rw = None if w.grad is not None else grad_zeros(tuple(w.shape), w.device)
+    def take(self, x2, dy2, w, b, col0=None):
+        """queue dW += dy2^T x2, db += column sums of dy2 for the leaf parameters w, b; -> what the backward returns for them.
+        col0 is not None: the layer multiplied with the column slice w[:, col0 : col0 + I] of the parameter w (the heads' conditioning
+        columns): the product goes straight into those columns of w's gradient and the slice's own gradient is None (no full-size
+        zero tensor + copy + add per use)."""
+        self.items.append((x2, dy2, w, b, col0))
+        rw = None if (col0 is not None or w.grad is not None) else grad_zeros(tuple(w.shape), w.device)
         rb = None if (b is None or b.grad is not None) else grad_zeros(tuple(b.shape), b.device)
         return rw, rb
+
+    @staticmethod
+    def column_window(w):
+        """(parameter, first column) when w is a column slice `param[:, c0:c1]` of a leaf fp32 parameter, else None"""
+        base = getattr(w, "_base", None)
+        if base is None or w.dim() != 2 or base.dim() != 2 or not (base.is_leaf and base.requires_grad and base.dtype == torch.float32 and base.is_contiguous()):
+            return None
+        if w.stride() != base.stride() or w.shape[0] != base.shape[0]:
+            return None
+        off = w.storage_offset() - base.storage_offset()
+        return (base, off) if 0 <= off and off + w.shape[1] <= base.shape[1] else None
 
     def accepts(self, w, b):
         ok = lambda p: p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous()
@@ -134,12 +148,14 @@ class _WgradQueue(object):
         if not items:
             return
         probs = (_lib.CatanWgradProblem * len(items))()
-        for k, (x2, dy2, w, b) in enumerate(items):
+        for k, (x2, dy2, w, b, col0) in enumerate(items):
+            if w.grad is None and col0 is not None:
+                w.grad = torch.zeros_like(w)               # (no other use of the parameter produced a gradient in this pass)
             gw, gb = w.grad, (None if b is None else b.grad)
             if gw is None or gw.dtype != torch.float32 or not gw.is_contiguous() or (b is not None and (gb is None or gb.dtype != torch.float32 or not gb.is_contiguous())):
                 raise RuntimeError("deferred weight gradient: the parameter has no fp32 contiguous .grad at the flush")
             probs[k] = _lib.CatanWgradProblem(x2.data_ptr(), dy2.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
-                                              x2.shape[0], x2.shape[1], dy2.shape[1])
+                                              x2.shape[0], x2.shape[1], dy2.shape[1], 0 if col0 is None else w.shape[1], 0 if col0 is None else col0)
         _lib.check(_lib.lib().catan_linear_wgrad_grouped(probs, len(items), _stream()))
 
 
@@ -353,6 +369,7 @@ class _LinearTallSkinny(torch.autograd.Function):
                 y = torch.nn.functional.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb, w, *(() if b is None else (b,)))
         ctx.has_bias = b is not None
+        ctx.window = wgrad_queue.column_window(w) if (not pad and not w.is_leaf) else None
         return y
 
     @staticmethod
@@ -366,8 +383,11 @@ class _LinearTallSkinny(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_rows(dy2, wb.t().contiguous() if ctx.pad else bf16_t_of(w), None)          # dx[r][i] = sum_o dy[r][o] * w[o][i]
             dx = (dy2 @ wb if dx is None else dx).reshape(xb.shape)
-        if not ctx.pad and wgrad_queue.accepts(w, b) and not ((x2.data_ptr() | dy2.data_ptr()) & 15):
-            return (dx,) + wgrad_queue.take(x2, dy2, w, b)      # the weight gradient joins the grouped launch at the end of the backward pass
+        if not ctx.pad and not ((x2.data_ptr() | dy2.data_ptr()) & 15):
+            if wgrad_queue.accepts(w, b):
+                return (dx,) + wgrad_queue.take(x2, dy2, w, b)      # the weight gradient joins the grouped launch at the end of the backward pass
+            if ctx.window is not None and wgrad_queue.accepts(ctx.window[0], b):
+                return (dx,) + wgrad_queue.take(x2, dy2, ctx.window[0], b, col0=ctx.window[1])
         acc = grad_zeros((O * I + O,), dy.device)          # dw and db
         dw, db = acc[:O * I].view(O, I), (acc[O * I:] if ctx.has_bias else None)
         _lib.check(_lib.lib().catan_linear_wgrad(_ptr(x2), _ptr(dy2), _ptr(dw), _ptr(db), x2.shape[0], I, O, _stream()))

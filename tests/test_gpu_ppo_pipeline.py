@@ -1072,7 +1072,7 @@ def test_fused_collector_bookkeeping_equals_the_tensor_form(hip_lib):
     for fused in (True, False):
         env = VecCatanEnv(N, seed=5, dense_reward=True)
         env.random_rollout(0, 1500)                      # late game: some games end inside the rollout
-        col = RolloutCollector(env, net, T, seed=3, graph_act=False)
+        col = RolloutCollector(env, net, T, seed=3, graph_act=False, deferred_window=0)    # (catan_step in both: the sampled actions depend on the iteration a game plays in)
         col.fused_bookkeeping = fused
         cols.append(col)
     for rnd in range(2):
