@@ -49,7 +49,15 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "save buffer" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 475, C.cast(saves, C.c_void_p), 4, st))
     assert "bad arguments" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 400, C.cast(saves, C.c_void_p), 4, st))
     assert "bad arguments" in err(L.catan_collector_pre(64, 0, P(idx), P(idx), P(idx), P(idx), st))
-    assert "null" in err(L.catan_collector_post(64, 4, *([None] * 21)))
+    assert "null" in err(L.catan_collector_post(64, 4, *([None] * 23)))
+    # round 4: the deferred step, the game-list views, the grouped weight gradients
+    u8 = torch.zeros((64,), device="cuda", dtype=torch.uint8)
+    assert "bad arguments" in err(L.catan_step_deferred(env.h, None, 4, P(dw), P(u8), P(u8), st))
+    assert "bad arguments" in err(L.catan_step_deferred(env.h, P(idx), 0, P(dw), P(u8), P(u8), st))
+    assert "null" in err(L.catan_step_flush(env.h, None, P(u8), P(u8), st))
+    assert "bad" in err(L.catan_masks_of(env.h, P(dw), None, 4, st))
+    assert "bad game list" in err(L.catan_obs_rows_of(env.h, 0, P(dw), None, None, None, None, None, None, None, None, 4, st))
+    assert "bad arguments" in err(L.catan_linear_wgrad_grouped(None, 3, st))
     assert "bad arguments" in err(L.catan_head_chain(P(b16), 1536, P(b16), P(dw), 1e-5, 12, 0, P(dw), P(dw), P(dw), None, None, None, None, P(idx), P(dw), 64, st))
     with pytest.raises(_lib.CatanHipError):
         _lib.check(L.catan_random_rollout_deferred(env.h, 10, -3, st))
