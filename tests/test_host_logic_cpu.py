@@ -1,0 +1,63 @@
+"""Host-side logic added in round 4 that needs no device: the gradient-accumulator arena, the deferred weight-gradient queue's
+bookkeeping (which parameters it accepts, column windows of a parameter), the collector's policy-pass buckets."""
+import torch
+
+from settlers_of_catan_rl_amd import nn_kernels
+
+
+def test_grad_arena_slices_are_zero_aligned_and_recycled():
+    a = nn_kernels._GradArena()
+    z = a.zeros((3, 5), "cpu")                          # outside a step: plain zeros
+    assert z.shape == (3, 5) and not z.any() and a.buf is None
+    a.begin_step("cpu")
+    x = a.zeros((7,), "cpu"); y = a.zeros((2, 64), "cpu")
+    assert x.data_ptr() % 16 == 0 and (y.data_ptr() - x.data_ptr()) % 512 == 0 and y.data_ptr() != x.data_ptr()
+    assert x.untyped_storage().data_ptr() == a.buf.untyped_storage().data_ptr()
+    x += 3.0; y += 1.0
+    a.end_step()
+    a.begin_step("cpu")                                 # the next step starts from zeros again, in the same memory
+    x2 = a.zeros((7,), "cpu")
+    assert x2.data_ptr() == x.data_ptr() and not x2.any()
+    big = a.zeros((a.buf.numel() + 1,), "cpu")          # past the end: falls back, and the buffer grows for the next step
+    assert big.untyped_storage().data_ptr() != a.buf.untyped_storage().data_ptr() and not big.any()
+    n0 = a.buf.numel()
+    a.end_step(); a.begin_step("cpu")
+    assert a.buf.numel() > n0
+    a.enabled = False
+    a.begin_step("cpu")
+    assert not a.active
+
+
+def test_wgrad_queue_accepts_leaf_parameters_and_column_windows_only():
+    q = nn_kernels._WgradQueue()
+    w = torch.nn.Parameter(torch.randn(8, 20)); b = torch.nn.Parameter(torch.randn(8))
+    assert not q.accepts(w, b)                          # inactive outside a trainer step
+    q.begin()
+    assert q.accepts(w, b) and q.accepts(w, None)
+    assert not q.accepts(w * 2, b) and not q.accepts(w.detach(), b) and not q.accepts(torch.nn.Parameter(w.data.double()), None)
+    assert not q.accepts(torch.nn.Parameter(torch.randn(20, 8)).t(), None)       # not contiguous
+    win = q.column_window(w[:, 12:])
+    assert win is not None and win[0] is w and win[1] == 12
+    assert q.column_window(w[:, :5])[1] == 0
+    assert q.column_window(w[2:, 3:]) is None and q.column_window(w.t()) is None and q.column_window(w) is None
+    assert q.column_window((w * 1.0)[:, 3:]) is None    # a slice of a non-leaf
+    # a parameter without .grad is handed a zero tensor (autograd makes it the .grad), one with .grad and a window are handed nothing
+    x2, dy2 = torch.zeros(4, 20), torch.zeros(4, 8)
+    rw, rb = q.take(x2, dy2, w, b)
+    assert rw.shape == w.shape and rb.shape == b.shape and not rw.any()
+    w.grad = torch.zeros_like(w)
+    assert q.take(x2, dy2, w, b)[0] is None and q.take(x2[:, :8], dy2, w, None, col0=12) == (None, None)
+    assert len(q.items) == 3
+    q.items, q.active = [], False                       # (flush needs the device library)
+
+
+def test_collector_buckets():
+    from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    c = RolloutCollector.__new__(RolloutCollector)
+    c.N, c.graph_act, c.act_buckets = 65536, True, None
+    b = c._bucket_list()
+    assert b[-1] == 65536 and b[0] >= 1024 and list(b) == sorted(set(b)) and 49152 in b and 32768 in b and 1536 in b
+    c.graph_act = False
+    assert c._bucket_list() == (65536,)
+    c.act_buckets = (4096, 65536)
+    assert c._bucket_list() == (4096, 65536)

@@ -17,7 +17,7 @@ N, T = 65536, int(os.environ.get("T", "200"))
 env = VecCatanEnv(N, seed=0); env.random_rollout(0, 500)
 net = CatanPolicy().cuda()
 col = RolloutCollector(env, net, T, seed=1, autocast_dtype=torch.bfloat16)
-buckets = col._bucket_list()
+buckets = col._bucket_list() if not os.environ.get('VALUES_ONLY') else ()
 st = col.gather_rollouts()
 tr = PPOTrainer(net, PPOConfig(), autocast_dtype=torch.bfloat16, seed=3)
 
