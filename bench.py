@@ -76,7 +76,7 @@ def cpu_baseline(sample_envs=16384, sample_steps=2048):
     }
 
 
-def live_pmc_traffic(kernel, timeout_s=240):
+def live_pmc_traffic(kernel, timeout_s=180):
     """HBM bytes per launch of `kernel`, MEASURED NOW: the two counter passes MI355X_MICROARCH.md prescribes (rocprofv3 --pmc
     FETCH_SIZE, then --pmc WRITE_SIZE; never combined with a trace domain) over tools/pmc_workload.py - the same 65 536 games
     after the same kind of pre-roll, plus k_calib_copy launches of exactly known traffic that calibrate the counter units -

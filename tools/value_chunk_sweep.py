@@ -11,7 +11,7 @@ env = VecCatanEnv(N, seed=0); env.random_rollout(0, 500)
 net = CatanPolicy().cuda()
 col = RolloutCollector(env, net, T, seed=1, autocast_dtype=torch.bfloat16)
 st = col.gather_rollouts()
-for ch in (131072, 262144, 524288, 1048576):
+for ch in (65536, 131072, 204800, 262144, 524288, 1048576):
     tr = PPOTrainer(net, PPOConfig(value_chunk=ch), autocast_dtype=torch.bfloat16, seed=3)
     tr.compute_values(st); torch.cuda.synchronize()
     t0 = time.perf_counter()
