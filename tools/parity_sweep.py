@@ -34,4 +34,29 @@ for seed, n, steps, kw in big + [(101, 2048, 1500, {}), (202, 1000, 2500, dict(d
         print(f"deferred W={window} seed {seed}: {'OK' if same else 'MISMATCH'} ({int(cnt.sum())} decisions)", flush=True)
         bad += not same
     assert env.invalid_action_count() == 0
+    # catan_step_deferred with caller-supplied actions (round 4): the oracle batch is the policy stub and the shadow env; every
+    # delivered reward / done of every call and the flushed states are compared
+    calls = min(steps, 300 if n >= 32768 else 600)        # (every call is a host round trip through the oracle batch: bounded)
+    for window in (4, 32):
+        env = VecCatanEnv(n, seed=seed, **kw)
+        ob = oracle_lib.OracleBatch(n, seed)
+        ob.set_config(max_trades_per_turn=okw.get("max_proposed_trades_per_turn", 4), dense_reward=okw.get("dense_reward", False))
+        counts = np.zeros(n, dtype=np.uint32); waiting = np.zeros(n, dtype=bool)
+        acts = np.zeros((n, 18), dtype=np.int32)
+        er = np.zeros((n, 4), dtype=np.float32); er64 = np.zeros((n, 4), dtype=np.float64); ed = np.zeros(n, dtype=np.uint8)
+        same, applied = True, 0
+        for t in range(calls):
+            applied += ob.play(counts, (~waiting).astype(np.uint8), acts, er, er64, ed)
+            rew, done, status = env.step_deferred(torch.from_numpy(acts).cuda(), window)
+            s_ = status.cpu().numpy(); w = s_ == 1
+            r_, d_ = rew.cpu().numpy(), done.cpu().numpy()
+            same &= not r_[w].any() and not d_[w].any() and np.array_equal(r_[~w], er[~w]) and np.array_equal(d_[~w], ed[~w])
+            waiting = w
+        rew, done, status = env.step_flush()
+        r_, d_ = rew.cpu().numpy(), done.cpu().numpy()
+        same &= np.array_equal(r_[waiting], er[waiting]) and np.array_equal(d_[waiting], ed[waiting])
+        same &= np.array_equal(env.export_state().cpu().numpy(), ob.export()) and np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+        same &= env.invalid_action_count() == 0
+        print(f"catan_step_deferred W={window} seed {seed} n {n} calls {calls} {kw}: {'OK' if same else 'MISMATCH'} ({applied} applied actions from outside the library)", flush=True)
+        bad += not same
 sys.exit(1 if bad else 0)
