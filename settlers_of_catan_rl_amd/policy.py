@@ -492,6 +492,7 @@ class _SegmentedTrunk(torch.autograd.Function):
 
 
 GROUPED_WGRAD = True        # (A/B switch, tools/ab_step_switches.py)
+RECURRENT_BATCHED = True    # (A/B switch) the trade heads' four steps as one pass when the actions are given
 
 
 class _ActionHeads(nn.Module):
@@ -633,6 +634,8 @@ class _ActionHeads(nn.Module):
     def _recurrent(self, head, pre, fixed, cur_res, from_hand, acts, deterministic, generator):
         """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask.
         pre: the head's trunk contribution (constant over the four steps); fixed: conditioning columns before `out` or None."""
+        if acts is not None and RECURRENT_BATCHED:
+            return self._recurrent_given(head, pre, fixed, cur_res, from_hand, acts)
         B, x = pre.shape[0], pre
         out = torch.zeros(B, 6, device=x.device, dtype=torch.float32)
         res = cur_res.clone()
@@ -666,6 +669,30 @@ class _ActionHeads(nn.Module):
             chosen.append(a)
             out = torch.cat((torch.zeros_like(out[:, :1]), out[:, 1:]), 1)     # column 0 ("stop") never feeds back; no host constant
         return out, torch.stack(chosen, 1), logp_sum, ent_sum
+
+    def _recurrent_given(self, head, pre, fixed, cur_res, from_hand, acts):
+        """`_recurrent` for GIVEN actions (the PPO update) in ONE pass over 4 B rows instead of four passes over B: with the picks known,
+        every step's conditioning columns (`out`: how often each resource was picked before, column 0 cleared), hand (`res`: the start
+        hand minus the earlier picks, clamped at 0 step by step = clamped once) and mask are functions of acts[:, :i] alone - the
+        recurrence of action_heads_module.py:258-329 only exists while sampling.  Same values as the loop (rows are independent; the
+        step's log-prob / entropy count only behind a non-stop pick, :306-312); a quarter of its launches, forward and backward."""
+        B = pre.shape[0]
+        onehot = F.one_hot(acts[:, :4], 6).float()                                   # [B, 4, 6]
+        before = torch.cumsum(onehot, 1) - onehot                                     # picks before step i
+        res = torch.clamp(cur_res[:, None, :] - before, min=0)                        # [B, 4, 6]
+        mask = (res > 0).float() if from_hand else torch.ones_like(res)
+        first0 = (cur_res.sum(-1) == 0).float()                                       # step 0: "stop" only with an empty hand
+        mask = torch.cat((torch.cat((first0[:, None, None], torch.ones(B, 3, 1, device=pre.device)), 1), mask[:, :, 1:]), 2)
+        out = torch.cat((torch.zeros(B, 4, 1, device=pre.device), before[:, :, 1:]), 2)          # column 0 ("stop") never feeds back
+        steps = lambda t: t.transpose(0, 1).reshape((4 * B,) + t.shape[2:])           # step-major rows: [step 0 rows, step 1 rows, ...]
+        cond = steps(out) if fixed is None else torch.cat((fixed.repeat(4, 1), steps(out)), -1)
+        _, lp, ent = _categorical(head.logits(pre.repeat(4, 1), cond), steps(mask), steps(acts[:, :4]), False, None)
+        keep = torch.cat((torch.ones(B, 1, device=pre.device), (acts[:, :3] > 0).float()), 1)    # a step counts only behind a non-stop pick
+        logp_sum = (lp.reshape(4, B).t() * keep).sum(1)
+        ent_sum = (ent.reshape(4, B).t() * keep).sum(1)
+        total = before[:, 3] + onehot[:, 3]
+        out_final = torch.cat((torch.zeros(B, 1, device=pre.device), total[:, 1:]), 1)
+        return out_final, acts[:, :4], logp_sum, ent_sum
 
     def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None, grouping=None):
         """main [B,512] (+ lstm_size with the LSTM); masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.

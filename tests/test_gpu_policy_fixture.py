@@ -37,7 +37,7 @@ def test_policy_fixture_fp32_with_hip_kernels(hip_lib, monkeypatch, which):
     calls = _count_kernel_calls(monkeypatch)
     dev = pf.check_policy_fixture(gu.load("policy_small.npz"), which, "cuda", tol=1e-5, grad_tol=1e-4)
     print(which, "fp32 deviations from the reference net:", dev, "kernel calls:", calls)
-    assert calls.get("small_attention", 0) >= 4 and calls.get("small_layer_norm", 0) >= 20 and calls.get("masked_categorical", 0) >= 18, calls
+    assert calls.get("small_attention", 0) >= 4 and calls.get("small_layer_norm", 0) >= 20 and calls.get("masked_categorical", 0) >= 12, calls      # (12 = act: 18 head evaluations as chained kernels elsewhere; evaluate: type + 9 heads + the two trade heads, one pass each)
     if which == "lstm":
         assert calls.get("lstm_cell", 0) >= 1 + 5, calls
 
@@ -55,4 +55,4 @@ def test_policy_fixture_bf16_autocast(hip_lib, monkeypatch, which):
                                   min_argmax_agreement=0.95)
     assert dev["act_type_agreement"] == 1.0, dev
     print(which, "bf16 deviations from the reference net:", dev, "kernel calls:", calls)
-    assert calls.get("small_layer_norm", 0) >= 10 and calls.get("masked_categorical", 0) >= 18, calls
+    assert calls.get("small_layer_norm", 0) >= 10 and calls.get("masked_categorical", 0) >= 12, calls      # (12 = act: 18 head evaluations as chained kernels elsewhere; evaluate: type + 9 heads + the two trade heads, one pass each)

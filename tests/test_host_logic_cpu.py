@@ -61,3 +61,44 @@ def test_collector_buckets():
     assert c._bucket_list() == (65536,)
     c.act_buckets = (4096, 65536)
     assert c._bucket_list() == (4096, 65536)
+
+
+def test_recurrent_trade_heads_in_one_pass_equal_the_four_step_loop():
+    """policy._ActionHeads._recurrent_given (the PPO update: the picks are given, so the four steps of the give / receive heads are one
+    pass over 4 B rows) against the step-by-step loop: conditioning columns, hands, masks, the "counts only behind a non-stop pick"
+    rule, with and without the hand masks and the fixed conditioning columns, stop picks at every position, empty hands."""
+    from settlers_of_catan_rl_amd import policy as P
+    torch.manual_seed(3)
+    heads = P._ActionHeads(512)
+    B = 257
+    for hi, from_hand, with_fixed in ((7, True, False), (8, False, True)):
+        head = heads.action_heads[hi]
+        pre = torch.randn(B, 128)
+        fixed = torch.randint(0, 3, (B, 6)).float() if with_fixed else None
+        cur = torch.randint(0, 4, (B, 6)).float() * 0.125 * 8
+        cur[:9] = 0                                                 # empty hands
+        acts = torch.randint(0, 6, (B, 4))
+        acts[torch.rand(B) < 0.3, 1] = 0                            # early stops
+        acts[torch.rand(B) < 0.2, 0] = 0
+        P.RECURRENT_BATCHED = False
+        try:
+            o0, c0, lp0, e0 = heads._recurrent(head, pre, fixed, cur, from_hand, acts, False, None)
+        finally:
+            P.RECURRENT_BATCHED = True
+        o1, c1, lp1, e1 = heads._recurrent(head, pre, fixed, cur, from_hand, acts, False, None)
+        assert torch.equal(o0, o1) and torch.equal(c0, c1)
+        fin = torch.isfinite(lp0)
+        assert torch.equal(fin, torch.isfinite(lp1))                # (an illegal given pick has log-prob -inf on both sides)
+        assert torch.allclose(lp0[fin], lp1[fin], atol=2e-6, rtol=1e-6) and torch.allclose(e0, e1, atol=2e-6, rtol=1e-6, equal_nan=True)
+        # gradients through both forms
+        for form in (False, True):
+            P.RECURRENT_BATCHED = form
+            heads.zero_grad()
+            pr = pre.clone().requires_grad_(True)
+            _, _, lp, e = heads._recurrent(head, pr, fixed, cur, from_hand, acts, False, None)
+            (torch.where(torch.isfinite(lp), lp, torch.zeros_like(lp)).sum() + 0.1 * torch.nan_to_num(e).sum()).backward()
+            g = [pr.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
+            if not form:
+                g_loop = g
+        P.RECURRENT_BATCHED = True
+        assert len(g) == len(g_loop) and all(torch.allclose(a, b, atol=1e-4, rtol=1e-4) for a, b in zip(g, g_loop))

@@ -32,7 +32,10 @@ def set_grouped(on): pol_mod.GROUPED_WGRAD = on
 def set_deferred(on): nn_kernels.wgrad_queue.enabled = on
 
 
-SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred}
+def set_recurrent(on): pol_mod.RECURRENT_BATCHED = on
+
+
+SW = {"grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred, "recurrent_batched": set_recurrent}
 if hasattr(pol_mod, "TRUNK_WINDOWS"):
     SW["trunk_windows"] = set_trunk
 
