@@ -206,6 +206,13 @@ int32_t catan_head_state_floats(void);
 int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const float* vec, float eps, int32_t head_id, int32_t step, float* state,
                      const float* maskmat, const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* u,
                      int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream);
+/* The same pass in ONE launch: a workgroup takes its 256 rows through all eighteen evaluations with the chained state in LDS (the rows are
+ * independent).  pre_all: bfloat16 [B][pre_ld >= 1536], head h's trunk product in columns 128 h .. 128 h + 127; wts12 / vec12: HOST arrays
+ * of the twelve heads' device packs; u18: HOST array of eighteen device rows of B uniforms in the chain's order, or NULL (arg-max).
+ * Identical results to the eighteen catan_head_chain calls for the same uniforms. */
+int catan_head_chain_all(const void* pre_all, int64_t pre_ld, const void* const* wts12, const float* const* vec12, float eps, const float* maskmat,
+                         const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* const* u18,
+                         int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream);
 
 /* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
  * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card

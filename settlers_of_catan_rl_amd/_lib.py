@@ -179,6 +179,7 @@ _SIGS = {
     "catan_head_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_head_state_floats": (C.c_int32, []),
     "catan_head_chain": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_head_chain_all": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), C.POINTER(_vp), C.c_float, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _vp, C.c_int64, _vp]),
     "catan_card_summary_params": (C.c_int32, []),
     "catan_card_summary_patterns": (C.c_int32, []),
     "catan_card_pattern_sum": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int64, _vp]),

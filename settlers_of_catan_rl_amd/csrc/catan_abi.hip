@@ -1394,6 +1394,33 @@ int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const flo
     a.forced = (const long long*)forced; a.actions = (long long*)actions; a.logp_out = logp_out;
     return head_launch(a, S(stream));
 }
+// the whole chain in one launch (k_heads_all).  wts12 / vec12: HOST arrays of the twelve heads' device packs; u18: HOST array of the
+// eighteen evaluations' device uniform rows in the chain's order (head 0; 1, 2, 3; 5, 6, 11; 4, 9, 10; 7 x 4; 8 x 4), or NULL (arg-max)
+int catan_head_chain_all(const void* pre_all, int64_t pre_ld, const void* const* wts12, const float* const* vec12, float eps, const float* maskmat,
+                         const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* const* u18,
+                         int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream) {
+    static const int KS[12] = { 13, 54, 73, 19, 5, 2, 3, 6, 6, 5, 5, 5 }, NC[12] = { 0, 2, 0, 0, 0, 32, 2, 6, 12, 4, 9, 0 };
+    static const int ORDER[HD_EVS][2] = { {0, 0}, {1, 0}, {2, 0}, {3, 0}, {5, 0}, {6, 0}, {11, 0}, {4, 0}, {9, 0}, {10, 0},
+                                          {7, 0}, {7, 1}, {7, 2}, {7, 3}, {8, 0}, {8, 1}, {8, 2}, {8, 3} };
+    if (!pre_all || !wts12 || !vec12 || !maskmat || !cur_res || !trade || !custom || !actions || !logp_out || B <= 0 || pre_ld % 8 != 0 || pre_ld < 12 * 128 ||
+        ((uintptr_t)pre_all & 15) != 0)
+        return fail(CATAN_EINVAL, "catan_head_chain_all: bad arguments");
+    for (int h = 0; h < 12; h++) if (!wts12[h] || !vec12[h]) return fail(CATAN_EINVAL, "catan_head_chain_all: missing head pack");
+    HeadArgs a;
+    memset(&a, 0, sizeof a);
+    a.eps = eps; a.B = B; a.maskmat = maskmat; a.cur_res = cur_res; a.trade = trade; a.custom = custom;
+    a.forced = (const long long*)forced; a.actions = (long long*)actions; a.logp_out = logp_out; a.pre_ld = pre_ld;
+    HeadEvs evs;
+    evs.n = HD_EVS;
+    for (int k = 0; k < HD_EVS; k++) {
+        const int h = ORDER[k][0];
+        if (u18 && !u18[k]) return fail(CATAN_EINVAL, "catan_head_chain_all: missing uniforms");
+        evs.e[k] = HeadEv{ (const unsigned short*)pre_all + 128 * h, (const unsigned short*)wts12[h], vec12[h], u18 ? u18[k] : nullptr, KS[h], NC[h], h, ORDER[k][1] };
+    }
+    hipLaunchKernelGGL(k_heads_all, dim3(blocks(B, HD_ROWS)), dim3(HD_THREADS), 0, S(stream), a, evs);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 
 
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {

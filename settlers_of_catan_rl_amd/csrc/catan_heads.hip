@@ -194,17 +194,24 @@ DEVI void hd_commit(const HeadArgs& a, long row, float* st, int act, float lp, f
 }
 
 
-template <int KT>
-__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sW2[128 * HD_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned short sW3[KT * 16 * HD_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
-    __shared__ float sV[HD_VELEMS];
-    __shared__ __attribute__((aligned(16))) unsigned short sLg[HD_WAVES][16 * HD_LG];   // a tile's logits (bf16, as the unfused path rounds them)
-    __shared__ float sCond[HD_WAVES][HD_RT][16][HD_NCP];     // chained mode: the rows' conditioning columns and log-prob factors
-    __shared__ float sCnt[HD_WAVES][HD_RT][16];
-    __shared__ __attribute__((aligned(16))) float sState[HD_WAVES][HD_RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
-    const bool chained = a.state != nullptr;
+// the kernels' LDS: one head's weights, a tile's logits, the rows' conditioning columns and chained state
+struct HeadShared {
+    __attribute__((aligned(16))) unsigned short sW2[128 * HD_PITCH];
+    __attribute__((aligned(16))) unsigned short sW3[5 * 16 * HD_PITCH];
+    __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
+    float sV[HD_VELEMS];
+    __attribute__((aligned(16))) unsigned short sLg[HD_WAVES][16 * HD_LG];   // a tile's logits (bf16, as the unfused path rounds them)
+    float sCond[HD_WAVES][HD_RT][16][HD_NCP];     // chained mode: the rows' conditioning columns and log-prob factors
+    float sCnt[HD_WAVES][HD_RT][16];
+    __attribute__((aligned(16))) float sState[HD_WAVES][HD_RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
+};
+// One head evaluation of a workgroup's 256 rows.  ALL (k_heads_all: every evaluation of a policy pass in one launch): the rows' chained
+// state lives in sh.sState from one evaluation to the next - it is neither read from nor written to a.state.
+template <int KT, bool ALL>
+DEVI void hd_eval(const HeadArgs& a, HeadShared& sh) {
+    auto& sW2 = sh.sW2; auto& sW3 = sh.sW3; auto& sW1 = sh.sW1; auto& sV = sh.sV; auto& sLg = sh.sLg; auto& sCond = sh.sCond; auto& sCnt = sh.sCnt;
+    auto& sState = sh.sState;
+    const bool chained = ALL || a.state != nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
     const int rr = lane >> 2, part = lane & 3, c0 = part * 20;   // the categorical's split: four lanes per row, 20 columns each
     // Everything a wave's row tiles need from HBM is requested before the weights are staged: the trunk products, the rows' state,
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
         const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
 #pragma unroll
         for (int s = 0; s < 4; s++) xr[tt][s] = *reinterpret_cast<const uint4*>(a.pre + row * a.pre_ld + s * 32 + g * 8);
-        if (chained) {
+        if (chained && !ALL) {
             const float4* src = reinterpret_cast<const float4*>(a.state + grow * HD_STATE + part * 8);
             sr[tt][0] = src[0]; sr[tt][1] = src[1];
         }
@@ -242,10 +249,12 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
     unsigned short* lg = sLg[wave];
     u32 mkb[HD_RT];                                                  // the rows' mask entries of this lane's 20 columns, as bits
     if (chained) {
+        if (!ALL) {
 #pragma unroll
-        for (int tt = 0; tt < HD_RT; tt++) {
-            float4* dst = reinterpret_cast<float4*>(&sState[wave][tt][rr][part * 8]);
-            dst[0] = sr[tt][0]; dst[1] = sr[tt][1];
+            for (int tt = 0; tt < HD_RT; tt++) {
+                float4* dst = reinterpret_cast<float4*>(&sState[wave][tt][rr][part * 8]);
+                dst[0] = sr[tt][0]; dst[1] = sr[tt][1];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 16 * HD_RT) {                                       // one lane per row: conditioning columns, log-prob factor
@@ -448,10 +457,43 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (chained && row0 + rr < a.B) {                              // the rows' state goes back for the next evaluation
+        if (chained && !ALL && row0 + rr < a.B) {                      // the rows' state goes back for the next evaluation
             float4* dst = reinterpret_cast<float4*>(a.state + (row0 + rr) * HD_STATE + part * 8);
             const float4* src = reinterpret_cast<const float4*>(&sState[wave][tt][rr][part * 8]);
             dst[0] = src[0]; dst[1] = src[1];
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
+    __shared__ HeadShared sh;
+    hd_eval<KT, false>(a, sh);
+}
+// Every head evaluation of a policy pass - head 0; 1, 2, 3; 5, 6, 11; 4, 9, 10; 7 and 8 with four steps each - in ONE launch: the rows are
+// independent, so a workgroup takes its 256 rows through all of them, re-staging one head's weights (64 KB from L2) per evaluation, with
+// the rows' chained state in LDS throughout.  Same arithmetic as eighteen launches of k_head_fwd (each 30 us of mostly ramp, tail and
+// two exposed round trips for 5-10 us of work): identical actions and log-probs for the same uniforms.
+constexpr int HD_EVS = 18;
+struct HeadEv { const unsigned short* pre; const unsigned short* wts; const float* vec; const float* u; int K, ncond, head_id, step; };
+struct HeadEvs { HeadEv e[HD_EVS]; int n; };
+__global__ __launch_bounds__(HD_THREADS) void k_heads_all(HeadArgs a, HeadEvs evs) {
+    __shared__ HeadShared sh;
+    {
+        float* z = &sh.sState[0][0][0][0];
+        for (int i = threadIdx.x; i < HD_WAVES * HD_RT * 16 * HD_STATE; i += HD_THREADS) z[i] = 0.0f;
+    }
+    for (int k = 0; k < evs.n; k++) {
+        __syncthreads();                                     // the previous evaluation is done with the weights (and the state is zeroed)
+        HeadArgs b = a;
+        const HeadEv& e = evs.e[k];
+        b.pre = e.pre; b.wts = e.wts; b.vec = e.vec; b.u = e.u; b.K = e.K; b.ncond = e.ncond; b.head_id = e.head_id; b.step = e.step;
+        switch ((b.K + 15) / 16) {
+        case 1: hd_eval<1, true>(b, sh); break;
+        case 2: hd_eval<2, true>(b, sh); break;
+        case 3: hd_eval<3, true>(b, sh); break;
+        case 4: hd_eval<4, true>(b, sh); break;
+        default: hd_eval<5, true>(b, sh); break;
         }
     }
 }

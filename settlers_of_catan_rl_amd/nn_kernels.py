@@ -1111,6 +1111,9 @@ def head_sample(head, trunk_dim, pre, cond, mask, deterministic=False, generator
     return action, logp
 
 
+HEADS_ONE_LAUNCH = False     # True: the eighteen evaluations in ONE launch (catan_head_chain_all) - bit-identical, and measured SLOWER at
+                             # 65 536 rows (640 vs 560 us; equal at 4 096-16 384: tools/bench_head_chain.py): an evaluation is ~25 us of
+                             # in-kernel dependent latency whatever the row count, not launch overhead, so nothing is won by removing launches
 HEAD_CHAIN_ORDER = ((0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (6, 0), (11, 0), (4, 0), (9, 0), (10, 0),
                     (7, 0), (7, 1), (7, 2), (7, 3), (8, 0), (8, 1), (8, 2), (8, 3))       # (head, step): the order of the pass's 18 draws
 
@@ -1155,6 +1158,15 @@ def heads_chain(heads, trunk_dim, pre_all, masks, cur_res, trade, deterministic=
             us = [u_all[k] for k in range(len(HEAD_CHAIN_ORDER))]
     custom = head5_custom_pack(heads[5])
     st = _stream()
+    if HEADS_ONE_LAUNCH and pre_all.stride(0) >= 12 * 128 and pre_all.stride(1) == 1 and len({float(h.norm.eps) for h in heads}) == 1:
+        import ctypes as C
+        packs = [head_pack(heads[h], trunk_dim) for h in range(12)]
+        w12 = (C.c_void_p * 12)(*[p[0].data_ptr() for p in packs])
+        v12 = (C.c_void_p * 12)(*[p[1].data_ptr() for p in packs])
+        u18 = None if us is None else (C.c_void_p * len(HEAD_CHAIN_ORDER))(*[u.data_ptr() for u in us])
+        _lib.check(L.catan_head_chain_all(_ptr(pre_all), pre_all.stride(0), w12, v12, float(heads[0].norm.eps), _ptr(masks), _ptr(cur_res), _ptr(trade),
+                                          _ptr(custom), _ptr(forced), u18, _ptr(actions), _ptr(logp), B, st))
+        return actions, logp
     for k, (h, step) in enumerate(HEAD_CHAIN_ORDER):
         wts, vec = head_pack(heads[h], trunk_dim)
         pre = pre_all[:, 128 * h:128 * (h + 1)]

@@ -963,6 +963,43 @@ def test_value_reevaluation_encodes_distinct_boards_only(hip_lib):
         col.after_rollouts()
 
 
+def test_head_chain_in_one_launch_equals_the_eighteen_launches(hip_lib):
+    """catan_head_chain_all (k_heads_all: a workgroup takes its rows through all eighteen head evaluations, the chained state in LDS)
+    against eighteen catan_head_chain launches: the same uniforms give bit-identical actions and joint log-probs - arg-max and sampled,
+    with and without forced types, on a ragged row count and on one that leaves partial tiles."""
+    from settlers_of_catan_rl_amd import policy as P, nn_kernels
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    torch.manual_seed(0)
+    for B in (8192 + 5, 300):
+        env = VecCatanEnv(B, seed=34); env.random_rollout(0, 1100)
+        f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
+        net = P.CatanPolicy().cuda()
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        net = net.inference_copy(torch.bfloat16)
+        legal_types = masks[:, :13] > 0
+        forced = torch.where(torch.rand(B, device="cuda") < 0.5, torch.multinomial(legal_types.float(), 1).squeeze(1), torch.full((B,), -1, device="cuda"))
+
+        def act_pass(one_launch, deterministic, cond):
+            nn_kernels.HEADS_ONE_LAUNCH = one_launch
+            try:
+                gg = torch.Generator(device="cuda").manual_seed(7)
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    return net.act(f, lists, lens, masks, deterministic=deterministic, generator=gg, condition_on_action_type=cond)
+            finally:
+                nn_kernels.HEADS_ONE_LAUNCH = False
+        kinds = set()
+        for deterministic in (True, False):
+            for cond in (None, forced):
+                v1, a1, lp1 = act_pass(True, deterministic, cond)
+                v0, a0, lp0 = act_pass(False, deterministic, cond)
+                assert torch.equal(v1, v0) and torch.equal(a1, a0), (B, deterministic, cond is not None, int((a1 != a0).any(1).sum()))
+                assert torch.equal(lp1, lp0) and torch.isfinite(lp1).all()
+                kinds |= set(a1[:, 0].tolist())
+        assert len(kinds) >= (11 if B > 1000 else 5), kinds
+
+
 def test_chained_heads_equal_the_glued_heads(hip_lib):
     """nn_kernels.heads_chain (the twelve heads' glue inside the fused head kernels: type-conditional mask rows, conditioning
     columns, log-prob masks, the trade heads' lists, condition_on_action_type) against the same kernels with the glue as torch ops:
