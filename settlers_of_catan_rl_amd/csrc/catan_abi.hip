@@ -228,6 +228,23 @@ static int wgrad_launch_grouped_dispatch(bool tr, int otw, int itc, const WgBatc
     return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: no kernel for this tile shape");
 }
 
+template <int RT, int WAVES>
+static int head_launch_cfg(const HeadArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)((a.B + WAVES * RT * 16 - 1) / (WAVES * RT * 16))), block(WAVES * 64);
+    switch ((a.K + 15) / 16) {
+    case 1: hipLaunchKernelGGL((k_head_fwd<1, RT, WAVES>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_head_fwd<2, RT, WAVES>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_head_fwd<3, RT, WAVES>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_head_fwd<4, RT, WAVES>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((k_head_fwd<5, RT, WAVES>), grid, block, 0, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+static int head_launch(const HeadArgs& a, hipStream_t st) {
+    return a.B <= HD_NARROW_MAX_ROWS ? head_launch_cfg<HD_RT_NARROW, HD_WAVES_NARROW>(a, st) : head_launch_cfg<HD_RT_WIDE, HD_WAVES_WIDE>(a, st);
+}
+
 template <int KS>
 static int linrows_dispatch_nt(int nt, const void* x, const void* w, const void* b, void* y, long R, int K, int N, const void* aux, int mode, hipStream_t st) {
     long nb = ((R + 15) / 16 + 3) / 4;
@@ -1198,18 +1215,6 @@ int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n,
     return CATAN_OK;
 }
 
-static int head_launch(const HeadArgs& a, hipStream_t st) {
-    const dim3 grid(blocks(a.B, HD_ROWS));
-    switch ((a.K + 15) / 16) {
-    case 1: hipLaunchKernelGGL(k_head_fwd<1>, grid, dim3(HD_THREADS), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_head_fwd<2>, grid, dim3(HD_THREADS), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_head_fwd<3>, grid, dim3(HD_THREADS), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_head_fwd<4>, grid, dim3(HD_THREADS), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_head_fwd<5>, grid, dim3(HD_THREADS), 0, st, a); break;
-    }
-    HIPCHK(hipGetLastError());
-    return CATAN_OK;
-}
 int catan_collector_pre(int64_t n, int32_t T, const int64_t* n_obs, const int64_t* actions, int32_t* a_env, uint8_t* live, catan_stream_t stream) {
     if (n <= 0 || T <= 0 || !n_obs || !actions || !a_env || !live) return fail(CATAN_EINVAL, "catan_collector_pre: bad arguments");
     CollectorArgs a;
@@ -1417,7 +1422,10 @@ int catan_head_chain_all(const void* pre_all, int64_t pre_ld, const void* const*
         if (u18 && !u18[k]) return fail(CATAN_EINVAL, "catan_head_chain_all: missing uniforms");
         evs.e[k] = HeadEv{ (const unsigned short*)pre_all + 128 * h, (const unsigned short*)wts12[h], vec12[h], u18 ? u18[k] : nullptr, KS[h], NC[h], h, ORDER[k][1] };
     }
-    hipLaunchKernelGGL(k_heads_all, dim3(blocks(B, HD_ROWS)), dim3(HD_THREADS), 0, S(stream), a, evs);
+    if (B <= HD_NARROW_MAX_ROWS)
+        hipLaunchKernelGGL((k_heads_all<HD_RT_NARROW, HD_WAVES_NARROW>), dim3(blocks(B, HD_WAVES_NARROW * HD_RT_NARROW * 16)), dim3(HD_WAVES_NARROW * 64), 0, S(stream), a, evs);
+    else
+        hipLaunchKernelGGL((k_heads_all<HD_RT_WIDE, HD_WAVES_WIDE>), dim3(blocks(B, HD_WAVES_WIDE * HD_RT_WIDE * 16)), dim3(HD_WAVES_WIDE * 64), 0, S(stream), a, evs);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

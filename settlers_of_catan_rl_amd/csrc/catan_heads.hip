@@ -23,9 +23,13 @@ namespace catan {
 
 constexpr int HD_PITCH = 136;            // LDS row pitch of the weight matrices (bf16 elements): 272 B, 16-byte aligned, conflict-free fragments
 constexpr int HD_LG = 84;                // floats per logits row in LDS (row groups 16 banks apart)
-constexpr int HD_RT = 2, HD_WAVES = 8;   // row tiles per wave, waves per workgroup (two per SIMD)
-constexpr int HD_THREADS = HD_WAVES * 64;
-constexpr int HD_ROWS = HD_WAVES * HD_RT * 16;
+// Row tiles per wave x waves per workgroup.  An evaluation is ~20-25 us of dependent latency whatever the row count (weights to LDS, the
+// state / mask round trips, the tile's chain); one workgroup per CU fits in LDS.  WIDE (2 x 8: 256 rows per workgroup, two waves per SIMD)
+// covers 65 536 rows with one workgroup per CU; NARROW (1 x 12: 192 rows, three waves per SIMD, one tile each) shortens the chain per wave -
+// 440 -> 345 us per eighteen evaluations at 4 096 rows, 490 -> 385 us at 16 384 - but would need 342 workgroups at 65 536 rows (800 us):
+// the launcher picks NARROW up to HD_NARROW_MAX_ROWS rows (the forward search's thinning batches, the rollout's tail).
+constexpr int HD_RT_WIDE = 2, HD_WAVES_WIDE = 8, HD_RT_NARROW = 1, HD_WAVES_NARROW = 12;
+constexpr long HD_NARROW_MAX_ROWS = 49152;                 // 256 workgroups of 192 rows
 constexpr int HD_NCP = 32;               // conditioning columns, padded
 constexpr int HD_KP = 80;                // output columns, padded (73 road edges)
 constexpr int HD_WELEMS = 128 * 128 + HD_KP * 128 + HD_NCP * 128;      // packed bf16: W2 [128][128], W3 [80][128], W1e^T [32][128]
@@ -195,20 +199,22 @@ DEVI void hd_commit(const HeadArgs& a, long row, float* st, int act, float lp, f
 
 
 // the kernels' LDS: one head's weights, a tile's logits, the rows' conditioning columns and chained state
+template <int RT, int WAVES>
 struct HeadShared {
     __attribute__((aligned(16))) unsigned short sW2[128 * HD_PITCH];
     __attribute__((aligned(16))) unsigned short sW3[5 * 16 * HD_PITCH];
     __attribute__((aligned(16))) unsigned short sW1[HD_NCP * 128];
     float sV[HD_VELEMS];
-    __attribute__((aligned(16))) unsigned short sLg[HD_WAVES][16 * HD_LG];   // a tile's logits (bf16, as the unfused path rounds them)
-    float sCond[HD_WAVES][HD_RT][16][HD_NCP];     // chained mode: the rows' conditioning columns and log-prob factors
-    float sCnt[HD_WAVES][HD_RT][16];
-    __attribute__((aligned(16))) float sState[HD_WAVES][HD_RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
+    __attribute__((aligned(16))) unsigned short sLg[WAVES][16 * HD_LG];   // a tile's logits (bf16, as the unfused path rounds them)
+    float sCond[WAVES][RT][16][HD_NCP];     // chained mode: the rows' conditioning columns and log-prob factors
+    float sCnt[WAVES][RT][16];
+    __attribute__((aligned(16))) float sState[WAVES][RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
 };
 // One head evaluation of a workgroup's 256 rows.  ALL (k_heads_all: every evaluation of a policy pass in one launch): the rows' chained
 // state lives in sh.sState from one evaluation to the next - it is neither read from nor written to a.state.
-template <int KT, bool ALL>
-DEVI void hd_eval(const HeadArgs& a, HeadShared& sh) {
+template <int KT, bool ALL, int RT, int WAVES>
+DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
+    constexpr int HD_RT = RT, HD_WAVES = WAVES, HD_THREADS = WAVES * 64, HD_ROWS = WAVES * RT * 16;
     auto& sW2 = sh.sW2; auto& sW3 = sh.sW3; auto& sW1 = sh.sW1; auto& sV = sh.sV; auto& sLg = sh.sLg; auto& sCond = sh.sCond; auto& sCnt = sh.sCnt;
     auto& sState = sh.sState;
     const bool chained = ALL || a.state != nullptr;
@@ -465,10 +471,10 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared& sh) {
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
-    __shared__ HeadShared sh;
-    hd_eval<KT, false>(a, sh);
+template <int KT, int RT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_head_fwd(HeadArgs a) {
+    __shared__ HeadShared<RT, WAVES> sh;
+    hd_eval<KT, false, RT, WAVES>(a, sh);
 }
 // Every head evaluation of a policy pass - head 0; 1, 2, 3; 5, 6, 11; 4, 9, 10; 7 and 8 with four steps each - in ONE launch: the rows are
 // independent, so a workgroup takes its 256 rows through all of them, re-staging one head's weights (64 KB from L2) per evaluation, with
@@ -477,11 +483,12 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_fwd(HeadArgs a) {
 constexpr int HD_EVS = 18;
 struct HeadEv { const unsigned short* pre; const unsigned short* wts; const float* vec; const float* u; int K, ncond, head_id, step; };
 struct HeadEvs { HeadEv e[HD_EVS]; int n; };
-__global__ __launch_bounds__(HD_THREADS) void k_heads_all(HeadArgs a, HeadEvs evs) {
-    __shared__ HeadShared sh;
+template <int RT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_heads_all(HeadArgs a, HeadEvs evs) {
+    __shared__ HeadShared<RT, WAVES> sh;
     {
         float* z = &sh.sState[0][0][0][0];
-        for (int i = threadIdx.x; i < HD_WAVES * HD_RT * 16 * HD_STATE; i += HD_THREADS) z[i] = 0.0f;
+        for (int i = threadIdx.x; i < WAVES * RT * 16 * HD_STATE; i += WAVES * 64) z[i] = 0.0f;
     }
     for (int k = 0; k < evs.n; k++) {
         __syncthreads();                                     // the previous evaluation is done with the weights (and the state is zeroed)
@@ -489,11 +496,11 @@ __global__ __launch_bounds__(HD_THREADS) void k_heads_all(HeadArgs a, HeadEvs ev
         const HeadEv& e = evs.e[k];
         b.pre = e.pre; b.wts = e.wts; b.vec = e.vec; b.u = e.u; b.K = e.K; b.ncond = e.ncond; b.head_id = e.head_id; b.step = e.step;
         switch ((b.K + 15) / 16) {
-        case 1: hd_eval<1, true>(b, sh); break;
-        case 2: hd_eval<2, true>(b, sh); break;
-        case 3: hd_eval<3, true>(b, sh); break;
-        case 4: hd_eval<4, true>(b, sh); break;
-        default: hd_eval<5, true>(b, sh); break;
+        case 1: hd_eval<1, true, RT, WAVES>(b, sh); break;
+        case 2: hd_eval<2, true, RT, WAVES>(b, sh); break;
+        case 3: hd_eval<3, true, RT, WAVES>(b, sh); break;
+        case 4: hd_eval<4, true, RT, WAVES>(b, sh); break;
+        default: hd_eval<5, true, RT, WAVES>(b, sh); break;
         }
     }
 }

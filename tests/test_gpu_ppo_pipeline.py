@@ -970,7 +970,7 @@ def test_head_chain_in_one_launch_equals_the_eighteen_launches(hip_lib):
     from settlers_of_catan_rl_amd import policy as P, nn_kernels
     from settlers_of_catan_rl_amd.env import VecCatanEnv
     torch.manual_seed(0)
-    for B in (8192 + 5, 300):
+    for B in (8192 + 5, 300, 49152 + 700):      # (the narrow and the wide configuration of the head kernel: <= / > 49 152 rows)
         env = VecCatanEnv(B, seed=34); env.random_rollout(0, 1100)
         f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
         net = P.CatanPolicy().cuda()
@@ -1008,7 +1008,11 @@ def test_chained_heads_equal_the_glued_heads(hip_lib):
     from settlers_of_catan_rl_amd import policy as P, nn_kernels
     from settlers_of_catan_rl_amd.env import VecCatanEnv
     torch.manual_seed(0)
-    B = 8192 + 5
+    for B in (8192 + 5, 49152 + 333):           # (the narrow and the wide configuration of the head kernel)
+        _chained_vs_glued(P, nn_kernels, VecCatanEnv, B)
+
+
+def _chained_vs_glued(P, nn_kernels, VecCatanEnv, B):
     env = VecCatanEnv(B, seed=33); env.random_rollout(0, 1100)
     f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
     net = P.CatanPolicy().cuda()
