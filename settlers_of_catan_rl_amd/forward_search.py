@@ -242,17 +242,36 @@ def simulate(env, policy, ctrl, init_actions, max_depth=20, gamma=0.999, determi
         if init_hidden is not None:
             hid[:, ar, ctrl - 1] = init_hidden.to(dev).float()                              # worker.py:73
         graphed = None
+    # (device env with the game-list views: see the loop)
+    lists_of_games = (not rec) and hasattr(env, "get_obs_rows") and hasattr(env, "L") and getattr(env, "device", None) is not None and torch.device(env.device).type == "cuda"
     while True:
         live = active & (agent_actions < D)                                                 # worker.py:81
         if not bool(live.any()):
             break
         players_go = env.players_turn_sim().long()                                          # :82, 146-151
-        f, lists, lens = env.get_obs()
-        masks = env.get_action_masks()
         # only the simulations still running need a decision (the batch thins out as lines reach max_depth or end)
         idx = live.nonzero(as_tuple=True)[0]
         sub = idx.numel() < n
-        args = (f[idx], lists[idx], lens[idx].long(), masks[idx]) if sub else (f, lists, lens.long(), masks)
+        if lists_of_games and graphed is not None and idx.numel() <= graphed.buckets[-1]:
+            # the observations and masks of the LIVE games only, straight into the captured pass's input buffers (catan_obs_rows_of /
+            # catan_masks_of; bf16 under bf16 autocast: every value is a multiple of 1/8): all games' fp32 observations + a gather of
+            # the live rows + the net's cast + the copy into the graph's buffers were 15 % of a batch of root decisions
+            games = idx.to(torch.int32)
+            nl = int(idx.numel())
+            B = next(b for b in graphed.buckets if nl <= b)
+            bufs = graphed.static_inputs(B)
+            odt = autocast_dtype if autocast_dtype in (torch.bfloat16,) else torch.float32
+            if bufs is not None and bufs[0].dtype == odt and bufs[1].dtype == torch.int32 and bufs[2].dtype == torch.int32 and bufs[3].dtype == torch.float32:
+                f, lists, lens = env.get_obs_rows(odt, out=tuple(x[:nl] for x in bufs[:3]), games=games)
+                masks = env.get_action_masks(bufs[3][:nl], games=games)
+            else:
+                f, lists, lens = env.get_obs_rows(odt, games=games)
+                masks = env.get_action_masks(games=games)
+            args = (f, lists, lens, masks)
+        else:
+            f, lists, lens = env.get_obs()
+            masks = env.get_action_masks()
+            args = (f[idx], lists[idx], lens[idx].long(), masks[idx]) if sub else (f, lists, lens.long(), masks)
         kw = {}
         if rec:
             seat = players_go[idx] - 1
