@@ -507,7 +507,7 @@ class ForwardSearch(object):
         if torch.cuda.is_available() and next(policy.parameters()).is_cuda:
             from . import nn_kernels
             nn_kernels.use_tuned_gemms()
-        self.graphed = GraphedAct(policy, buckets=(512, 4096, 16384, 32768, 65536), autocast_dtype=autocast_dtype) if use_graphs else None
+        self.graphed = GraphedAct(policy, buckets=(512, 4096, 16384, 32768, 49152, 65536), autocast_dtype=autocast_dtype) if use_graphs else None
         self.sims_run = 0
         self._rng_word = spec.STATE_OFFSETS["rng_draws"][0]
 
