@@ -163,6 +163,19 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     dy = torch.randn(tok, 128, device=dev, generator=g).to(torch.bfloat16)
     out.append(_entry("k_wgrad_tr (dW = dY^T X, 128 x 64)", f"{tok} rows", _time_us(lambda: nn_kernels.wgrad(x64, dy), reps=5), (64 + 128) * 2 * tok, flops=2 * 64 * 128 * tok))
     del dy, w, b
+    # ---- the heads' first layers on their row segments (a minibatch step: eleven segments of the gathered 512-wide trunk rows, 128 outputs
+    #      each): one launch per (segment, 128-column slice) = 44 launches, against catan_linear_wgrad_grouped (2 launches)
+    seg_rows = (1820, 6101, 4007, 3085, 37138, 40142, 36842, 36842, 13073, 12858, 16298)
+    xs = [torch.randn(r_, 512, device=dev, generator=g).to(torch.bfloat16) for r_ in seg_rows]
+    dys = [torch.randn(r_, 128, device=dev, generator=g).to(torch.bfloat16) for r_ in seg_rows]
+    seg_bytes = sum(r_ * (512 + 128) * 2 for r_ in seg_rows); seg_flops = sum(2 * r_ * 512 * 128 for r_ in seg_rows)
+    big = [(x_, d_) for x_, d_ in zip(xs, dys) if x_.shape[0] >= 4096]
+    us_single = _time_us(lambda: [nn_kernels.wgrad(x_, d_) for x_, d_ in big], reps=5)
+    us_grouped = _time_us(lambda: nn_kernels.wgrad_grouped(big), reps=5)
+    gb = sum(x_.shape[0] * (512 + 128) * 2 for x_, _ in big); gf = sum(2 * x_.shape[0] * 512 * 128 for x_, _ in big)
+    out.append(_entry("k_wgrad_tr_grouped (the heads' first layers on their row segments: 7 segments x 4 column slices in 2 launches)", f"{sum(x_.shape[0] for x_, _ in big)} rows in {len(big)} segments",
+                      us_grouped, gb, flops=gf, note=f"the same products as one launch per (segment, slice): {us_single:.0f} us in {4 * len(big)} launches; dY is read once per 128-column slice of X (the algorithmic bytes count it once)"))
+    del xs, dys, big
     ln = torch.nn.LayerNorm(64).to(dev)
     xg = x64.clone().requires_grad_(True)
     y = nn_kernels.small_layer_norm(xg, ln, False)
