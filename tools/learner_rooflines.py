@@ -173,7 +173,7 @@ def learner_rooflines(env, net, T=200, rows_mb=204800):
     us_single = _time_us(lambda: [nn_kernels.wgrad(x_, d_) for x_, d_ in big], reps=5)
     us_grouped = _time_us(lambda: nn_kernels.wgrad_grouped(big), reps=5)
     gb = sum(x_.shape[0] * (512 + 128) * 2 for x_, _ in big); gf = sum(2 * x_.shape[0] * 512 * 128 for x_, _ in big)
-    out.append(_entry("k_wgrad_tr_grouped (the heads' first layers on their row segments: 7 segments x 4 column slices in 2 launches)", f"{sum(x_.shape[0] for x_, _ in big)} rows in {len(big)} segments",
+    out.append(_entry("k_wgrad_tr_grouped (the heads' first layers on their row segments, 4 column slices each, in 2 launches)", f"{sum(x_.shape[0] for x_, _ in big)} rows in {len(big)} segments",
                       us_grouped, gb, flops=gf, note=f"the same products as one launch per (segment, slice): {us_single:.0f} us in {4 * len(big)} launches; dY is read once per 128-column slice of X (the algorithmic bytes count it once)"))
     del xs, dys, big
     ln = torch.nn.LayerNorm(64).to(dev)
