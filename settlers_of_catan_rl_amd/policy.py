@@ -50,7 +50,8 @@ def _lin(x, w, b=None):
     return F.linear(x, w, b)
 
 
-_PARTS_MIN_ROWS = 131072
+_PARTS_MIN_ROWS = 8192       # (inference: per-part accumulating products instead of concatenation + one product; tools/bench_parts_threshold.py:
+                              #  the captured pass 2 065 -> 2 035 us at 65 536 rows, 1 233 -> 1 206 at 32 768, 908 -> 899 at 16 384)
 
 
 def _lin_parts(parts, w, b):
