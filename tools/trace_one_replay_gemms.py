@@ -17,3 +17,8 @@ for r in win:
     if d >= 15:
         print("%8.1f us at %8.1f  grid %s wg %s q %s  %s" % (d, (int(r["Start_Timestamp"]) - t0) / 1e3, "x".join(r.get(c, "?") for c in cols if "Grid" in c),
                                                           "x".join(r.get(c, "?") for c in cols if "Workgroup" in c), r.get("Queue_Id", "?"), r["Kernel_Name"][:90]))
+
+print("---- all kernels of the replay by start time (us, start, queue, name)")
+for r in win:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print("%7.1f %8.1f q%s %s" % (d, (int(r["Start_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"][:110]))
