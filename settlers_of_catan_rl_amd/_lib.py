@@ -40,7 +40,13 @@ _HASH_MARK = b"CATAN_BUILD_HASH="
 
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one register file; the default allocates them to the AGPR half and
 # copies every element back with v_accvgpr_read before the VALU may touch it: 432 of k_attn_mfma_bwd's ~1 900 instructions)
-BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# -fno-slp-vectorize: no packed-f32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere.  They issue at the rate of the two
+# scalar instructions they replace (MI355X_MICROARCH.md), and next to v_cvt_pk_bf16_f32 they produced a timing-dependent wrong result:
+# k_tile_encoder_fwd's LayerNorm with its bf16 pairs converted by one v_cvt_pk_bf16_f32 each gave, with two workgroups per CU, wrong
+# rows for the tokens of a wave's lanes 48..63 in ~0.6 % of the boards, differently on every run (the same source built
+# with this flag is bit-stable, and tests/test_gpu_ppo_pipeline.py::test_fused_tile_encoder_forward_vs_unfused is the check)
+BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
+               "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def source_hash():

@@ -1040,10 +1040,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr int AT_LP = 36;                                   // LDS pitch of a transposed row (32 keys / queries + pad)
 
 __device__ __forceinline__ unsigned short f2bf(float x) { const __hip_bfloat16 h = __float2bfloat16(x); return *reinterpret_cast<const unsigned short*>(&h); }
+// two floats -> one register of two bf16 (a in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32.  (Written per element -
+// f2bf(a) | f2bf(b) << 16 - the compiler pairs the conversions of elements (0, 2) and (1, 3) of a group of four and re-interleaves
+// the halves with and / shift / two or_sdwa: six instructions per four elements instead of two.)
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+typedef float f32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf(float a, float b) {
+    const f32pair_t f = {a, b};
+    union { bf16pair_t h; unsigned u; } r;
+    r.h = __builtin_convertvector(f, bf16pair_t);
+    return r.u;
+}
 __device__ __forceinline__ bf16x8_t pack_bf8(const float* v) {
-    union { bf16x8_t f; unsigned short u[8]; } r;
+    union { bf16x8_t f; unsigned u[4]; } r;
 #pragma unroll
-    for (int t = 0; t < 8; t++) r.u[t] = f2bf(v[t]);
+    for (int t = 0; t < 4; t++) r.u[t] = pk_bf(v[2 * t], v[2 * t + 1]);
     return r.f;
 }
 __device__ __forceinline__ bf16x8_t zero_bf8() { union { bf16x8_t f; uint4 u; } r; r.u = make_uint4(0, 0, 0, 0); return r.f; }
@@ -1079,10 +1090,10 @@ __device__ __forceinline__ void stage_transposed(unsigned short* dst, const unsi
 template <int HD>
 __device__ __forceinline__ void st_head(unsigned short* head, const f32x16_t& c, int hf) {
     if constexpr (HD == 16) {
-        *reinterpret_cast<uint2*>(head + 4 * hf) = make_uint2(f2bf(c[0]) | ((unsigned)f2bf(c[1]) << 16), f2bf(c[2]) | ((unsigned)f2bf(c[3]) << 16));
-        *reinterpret_cast<uint2*>(head + 8 + 4 * hf) = make_uint2(f2bf(c[4]) | ((unsigned)f2bf(c[5]) << 16), f2bf(c[6]) | ((unsigned)f2bf(c[7]) << 16));
+        *reinterpret_cast<uint2*>(head + 4 * hf) = make_uint2(pk_bf(c[0], c[1]), pk_bf(c[2], c[3]));
+        *reinterpret_cast<uint2*>(head + 8 + 4 * hf) = make_uint2(pk_bf(c[4], c[5]), pk_bf(c[6], c[7]));
     } else {
-        if (hf == 0) *reinterpret_cast<uint2*>(head) = make_uint2(f2bf(c[0]) | ((unsigned)f2bf(c[1]) << 16), f2bf(c[2]) | ((unsigned)f2bf(c[3]) << 16));
+        if (hf == 0) *reinterpret_cast<uint2*>(head) = make_uint2(pk_bf(c[0], c[1]), pk_bf(c[2], c[3]));
     }
 }
 

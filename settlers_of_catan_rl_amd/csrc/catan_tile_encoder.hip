@@ -45,10 +45,7 @@ DEVI void te_load8(const unsigned short* p, float* o) {
     o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xFFFF0000u);
 }
 DEVI void te_store8(unsigned short* p, const float* v) {
-    uint4 u;
-    u.x = (unsigned)te_to_bf(v[0]) | ((unsigned)te_to_bf(v[1]) << 16); u.y = (unsigned)te_to_bf(v[2]) | ((unsigned)te_to_bf(v[3]) << 16);
-    u.z = (unsigned)te_to_bf(v[4]) | ((unsigned)te_to_bf(v[5]) << 16); u.w = (unsigned)te_to_bf(v[6]) | ((unsigned)te_to_bf(v[7]) << 16);
-    *reinterpret_cast<uint4*>(p) = u;
+    *reinterpret_cast<uint4*>(p) = make_uint4(pk_bf(v[0], v[1]), pk_bf(v[2], v[3]), pk_bf(v[4], v[5]), pk_bf(v[6], v[7]));
 }
 
 // the weight fragments (and bias values) of this wave's column tiles nt = wave, wave + 4, ... of one layer: fetched from L2 one
@@ -85,27 +82,27 @@ DEVI void te_gemm(const unsigned short* A, int pa, const TeW<K, N>& w, const flo
 #pragma unroll
         for (int mj = 0; mj < TE_MT / TE_MP; mj++) {
             const int mt = m0 + mj;
-            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            // the product is formed TRANSPOSED (weights as the A operand): the lane holds token mt * 16 + (lane & 15) and the four
+            // consecutive output columns nt * 16 + 4 * (lane >> 4) + r - one 8-byte LDS access per tile instead of four 2-byte ones
+            unsigned short* o = out + (mt * 16 + lr) * po + nt * 16 + 4 * (lane >> 4);
+            // the bias (MODE 2: + the residual) is the accumulator's initial value: the first MFMA takes it as its C operand
+            f32x4_t acc = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+            if (MODE == 2) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                acc[0] += __uint_as_float(old.x << 16); acc[1] += __uint_as_float(old.x & 0xFFFF0000u);
+                acc[2] += __uint_as_float(old.y << 16); acc[3] += __uint_as_float(old.y & 0xFFFF0000u);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const uint4 u = *reinterpret_cast<const uint4*>(A + (mt * 16 + lr) * pa + ks * 32 + lk);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[i][ks], *reinterpret_cast<const bf16x8_t*>(&u), acc, 0, 0, 0);
             }
-            // the product is formed TRANSPOSED (weights as the A operand): the lane holds token mt * 16 + (lane & 15) and the four
-            // consecutive output columns nt * 16 + 4 * (lane >> 4) + r - one 8-byte LDS access per tile instead of four 2-byte ones
-            unsigned short* o = out + (mt * 16 + lr) * po + nt * 16 + 4 * (lane >> 4);
-            float v[4] = { acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w };
+            float v[4] = { acc[0], acc[1], acc[2], acc[3] };
             if (MODE == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
             }
-            if (MODE == 2) {
-                const uint2 old = *reinterpret_cast<const uint2*>(o);
-                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xFFFF0000u);
-                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xFFFF0000u);
-            }
-            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)te_to_bf(v[0]) | ((unsigned)te_to_bf(v[1]) << 16),
-                                                      (unsigned)te_to_bf(v[2]) | ((unsigned)te_to_bf(v[3]) << 16));
+            *reinterpret_cast<uint2*>(o) = make_uint2(pk_bf(v[0], v[1]), pk_bf(v[2], v[3]));
         }
     }
 }
@@ -154,42 +151,47 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
     const int hf = lane >> 5, c31 = lane & 31;
     const bool rowok = c31 < TE_L;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // V^T fragments through gfx950's transposing LDS read (ld_gather_tr, catan_nn.hip): a 16-lane group hands the instruction rows
+    // base .. base + 3 of the token-major V slice and lane i gets dim i of those four keys.  Keys 0..15 are rows of this board; of
+    // keys 16..31 only 16..18 are: the others carry probability 0 exactly and must only be FINITE, so their rows are clamped to the
+    // board's last token (rows past it belong to the next board - or, for the group's last board, to whatever follows the array).
+    const int i15 = lane & 15;
+    const int vrow0 = 4 * hf + (i15 >> 2), vcol = (i15 & 3) * 4;
+    const int vrow1 = 16 + vrow0 < TE_L ? 16 + vrow0 : TE_L - 1;
     for (int bh = wave; bh < TE_G * TE_H; bh += TE_W) {
         const int g = bh >> 2, h = bh & 3;
         const unsigned short* base = qkv + g * TE_L * TE_PQ + h * TE_HD;
         const bf16x8_t ka = ld_frag<TE_HD>(base + c31 * TE_PQ + TE_D, hf, rowok);
         const bf16x8_t qb = ld_frag<TE_HD>(base + c31 * TE_PQ, hf, rowok);
-        // V^T: row d = c31 & 15; the keys of k-step s for this lane half are 16 s + 4 hf + {0..3} and 16 s + 8 + 4 hf + {0..3}
-        union { bf16x8_t f; unsigned short u[8]; } va[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                int key = 16 * s + 8 * (e >> 2) + 4 * hf + (e & 3);
-                key = key < TE_L ? key : TE_L - 1;                                   // weight 0 there; the row only has to be finite
-                va[s].u[e] = base[key * TE_PQ + 2 * TE_D + (c31 & 15)];
-            }
+        const unsigned short* vb = base + 2 * TE_D + vcol;
+        union { bf16x8_t f; wg_s4 q[2]; } va[2];
+        va[0].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(vb + vrow0 * TE_PQ));
+        va[0].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(vb + (vrow0 + 8) * TE_PQ));
+        va[1].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(vb + vrow1 * TE_PQ));
+        va[1].q[1] = va[1].q[0];                                                   // keys 24..31: probability 0
         const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);     // S^T[j][i]
         constexpr int NR = TE_L <= 24 ? 12 : 16;                                   // registers 12..15 = keys 24..31: never valid
         float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            p[r] = j < TE_L ? st[r] * 0.25f : -INFINITY;                             // 1 / sqrt(16)
+            p[r] = j < TE_L ? st[r] : -INFINITY;
             mx = fmaxf(mx, p[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // exp((s - max) / sqrt(16)) as one multiply and v_exp_f32 (2^x); the 1 / sum goes onto the 8 output registers, not the 12 p
+        constexpr float C = 0.25f * 1.44269504088896340736f;
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+        for (int r = 0; r < NR; r++) { p[r] = __builtin_amdgcn_exp2f((p[r] - mx) * C); sum += p[r]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
-#pragma unroll
-        for (int r = 0; r < NR; r++) p[r] *= inv;
         f32x16_t ot = zero16;
 #pragma unroll
         for (int s = 0; s < 2; s++)
             ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < TE_HD ? va[s].f : zero_bf8(), pack_bf8(p + 8 * s), ot, 0, 0, 0);   // O^T[d][i]
+#pragma unroll
+        for (int r = 0; r < 8; r++) ot[r] *= inv;
         if (rowok) st_head<TE_HD>(out + (g * TE_L + c31) * TE_PX + h * TE_HD, ot, hf);
     }
 }
