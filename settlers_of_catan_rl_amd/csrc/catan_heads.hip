@@ -383,9 +383,8 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xa[s], c, 0, 0, 0);
             }
             const int n0 = 16 * j + 4 * g;
-            const unsigned h0 = te_to_bf(c[0] + b2[n0]), h1 = te_to_bf(c[1] + b2[n0 + 1]), h2 = te_to_bf(c[2] + b2[n0 + 2]), h3 = te_to_bf(c[3] + b2[n0 + 3]);
-            hp[j >> 1][(j & 1) * 2] = h0 | (h1 << 16);
-            hp[j >> 1][(j & 1) * 2 + 1] = h2 | (h3 << 16);
+            hp[j >> 1][(j & 1) * 2] = pk_bf(c[0] + b2[n0], c[1] + b2[n0 + 1]);
+            hp[j >> 1][(j & 1) * 2 + 1] = pk_bf(c[2] + b2[n0 + 2], c[3] + b2[n0 + 3]);
         }
         // ---- logits = h . W3^T + b3, the contraction index in the order the lanes hold h: k = 32 s + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3}
 #pragma unroll

@@ -21,6 +21,18 @@ template <class T> __device__ __forceinline__ void st_f(T* p, float v);
 template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
 
+// two floats -> one register of two bf16 (a in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32.  (Written per element -
+// f2bf(a) | f2bf(b) << 16 - the compiler pairs the conversions of elements (0, 2) and (1, 3) of a group of four and re-interleaves
+// the halves with and / shift / two or_sdwa: six instructions per four elements instead of two.)
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
+typedef float f32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf(float a, float b) {
+    const f32pair_t f = {a, b};
+    union { bf16pair_t h; unsigned u; } r;
+    r.h = __builtin_convertvector(f, bf16pair_t);
+    return r.u;
+}
+
 // LDS rows are kept in the storage type (bf16 inputs: half the LDS, twice the blocks per CU) with a 16 B aligned pitch; a head
 // slice (HD = 4 or 16 consecutive elements) is fetched with 8 / 16 B LDS reads and widened in registers.
 template <class T> struct LdsRow;
@@ -306,8 +318,7 @@ template <> struct RowVec<float, 2> {
 template <int EPL> struct RowVec<__hip_bfloat16, EPL> {
     static __device__ __forceinline__ float rounded(float a) { return __bfloat162float(__float2bfloat16(a)); }
     static __device__ __forceinline__ unsigned pack(float a, float b) {
-        const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
-        return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+        return pk_bf(a, b);
     }
     static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[EPL]) {
         unsigned w[EPL / 2];
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(256) void k_linear_rows(const unsigned short* __res
                         if (mode == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }                       // ReLU
                         else if (mode == 2) { lo += alo; hi += ahi; }                                        // + residual
                         else { lo = alo > 0.f ? lo : 0.f; hi = ahi > 0.f ? hi : 0.f; }                      // ReLU backward: aux = the ReLU's output
-                        vw[i] = (unsigned)f2bf_nn(lo) | ((unsigned)f2bf_nn(hi) << 16);
+                        vw[i] = pk_bf(lo, hi);
                     }
                 }
                 *reinterpret_cast<uint4*>(y + (r0 + row) * (long)N + ch * 8) = v;
@@ -1040,17 +1051,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr int AT_LP = 36;                                   // LDS pitch of a transposed row (32 keys / queries + pad)
 
 __device__ __forceinline__ unsigned short f2bf(float x) { const __hip_bfloat16 h = __float2bfloat16(x); return *reinterpret_cast<const unsigned short*>(&h); }
-// two floats -> one register of two bf16 (a in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32.  (Written per element -
-// f2bf(a) | f2bf(b) << 16 - the compiler pairs the conversions of elements (0, 2) and (1, 3) of a group of four and re-interleaves
-// the halves with and / shift / two or_sdwa: six instructions per four elements instead of two.)
-typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
-typedef float f32pair_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_bf(float a, float b) {
-    const f32pair_t f = {a, b};
-    union { bf16pair_t h; unsigned u; } r;
-    r.h = __builtin_convertvector(f, bf16pair_t);
-    return r.u;
-}
 __device__ __forceinline__ bf16x8_t pack_bf8(const float* v) {
     union { bf16x8_t f; unsigned u[4]; } r;
 #pragma unroll
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     constexpr int IR = TR ? (L <= 24 ? 24 : 32) : L;
     constexpr int HI1 = IR == 24 ? 0 : 8;                    // second 4-row run of k-step 1
     __shared__ __attribute__((aligned(16))) unsigned short Tt[4][3][IR * RP];            // K, Q, dO row-major: [key / query][dim]
-    __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: row max, 1 / row sum, delta
+    __shared__ __attribute__((aligned(16))) float Stat[4][3][32];                        // per query: -max scale log2(e), 1 / row sum, delta
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
     const long b = (long)blockIdx.x * 4 + wv;
     if (b >= B) return;
@@ -1231,6 +1231,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     for (int h = 0; h < H; h++) {
         const bf16x8_t qr = qr_[h], kr = kr_[h], vr = vr_[h], gr = gr_[h];
         const int tcol = h * HD + (c31 % HD);                                                      // this lane's dim d: a column of the images
+        f32x16_t dq_keep;
         // ---- lane = query i, registers = keys j
         {
             const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qr, zero16, 0, 0, 0);    // S^T[j][i]
@@ -1239,27 +1240,29 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                p[r] = j < len ? st[r] * scale : -INFINITY;
+                p[r] = j < len ? st[r] : -INFINITY;
                 mx = fmaxf(mx, p[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // exp(scale (s - max)) = 2^(s C - max C): one fma and v_exp_f32 per probability; 1 / sum by v_rcp_f32
+            const float C = scale * 1.44269504088896340736f, mc = -mx * C;
             float sum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
+            for (int r = 0; r < NR; r++) { p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], C, mc)); sum += p[r]; }
             sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
             float delta = 0.0f;
 #pragma unroll
             for (int r = 0; r < NR; r++) { p[r] *= inv; delta += p[r] * dpt[r]; }
             delta += __shfl_xor(delta, 32);
-            if (hf == 0) { stat[c31] = mx; stat[32 + c31] = inv; stat[64 + c31] = delta; }
+            if (hf == 0) { stat[c31] = mc; stat[32 + c31] = inv; stat[64 + c31] = delta; }
 #pragma unroll
             for (int r = 0; r < NR; r++) p[r] = p[r] * (dpt[r] - delta) * scale;                     // dS^T[j][i]
             f32x16_t dq = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++)
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(kt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(kt + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
-            if (rowok) st_head<HD>(gb + (c31 * 3 + 0) * D + h * HD, dq, hf);
+            dq_keep = dq;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lane = key j, registers = queries i
@@ -1267,6 +1270,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             const f32x16_t s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kr, zero16, 0, 0, 0);     // S[i][j]
             const f32x16_t dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr, vr, zero16, 0, 0, 0);     // dP[i][j] = sum_d dO[i][d] V[j][d]
             const bool keyok = c31 < len;                       // a masked key has probability 0 for every query
+            const float C2 = scale * 1.44269504088896340736f;
             float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ds[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q4 = 0; q4 < NR / 4; q4++) {                    // registers 4 q4 .. 4 q4 + 3 <-> queries 8 q4 + 4 hf .. + 3
@@ -1277,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int r = 4 * q4 + e;
-                    p[r] = keyok ? __expf(s2[r] * scale - mm[e]) * ii[e] : 0.0f;
+                    p[r] = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[r], C2, mm[e])) * ii[e] : 0.0f;   // mm = -max C (the query's)
                     ds[r] = p[r] * (dp[r] - dd[e]) * scale;
                 }
             }
@@ -1287,12 +1291,24 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(qt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(qt + tcol, s, hf)) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
                 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(dot + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(dot + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
             }
+            // head h's columns of the Q, K and dO images are dead now (this lane's fragments of them are in registers): dQ, dK, dV of the
+            // head take their place, and the three images leave as whole rows below - 8-byte slices stored straight to dqkv were 24 store
+            // instructions per sequence that each touched up to 38 cache lines
             if (rowok) {
-                st_head<HD>(gb + (c31 * 3 + 1) * D + h * HD, dk, hf);
-                st_head<HD>(gb + (c31 * 3 + 2) * D + h * HD, dv, hf);
+                st_head<HD>(qt + rrow + h * HD, dq_keep, hf);
+                st_head<HD>(kt + rrow + h * HD, dk, hf);
+                st_head<HD>(dot + rrow + h * HD, dv, hf);
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    {
+        constexpr int CH = D / 8;                                                // 16-byte pieces per image row
+        for (int x = lane; x < L * 3 * CH; x += 64) {
+            const int j = x / (3 * CH), c = x - j * (3 * CH), img = c / CH, cc = c - img * CH;
+            const unsigned short* src = (img == 0 ? qt : img == 1 ? kt : dot) + j * RP + cc * 8;
+            *reinterpret_cast<uint4*>(gb + j * 3 * D + c * 8) = *reinterpret_cast<const uint4*>(src);
+        }
     }
 }
 

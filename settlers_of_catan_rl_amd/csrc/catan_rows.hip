@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void k_segment_sum16(const uint4* __restrict__
         uint4 o;
         if (j1 - j0 == 1) o = dy[order[j0] * dy_pitch + c];                  // (one row: its bits, not a round trip through fp32 - the same value)
         else {
-            o.x = (unsigned)te_to_bf(acc[0]) | ((unsigned)te_to_bf(acc[1]) << 16); o.y = (unsigned)te_to_bf(acc[2]) | ((unsigned)te_to_bf(acc[3]) << 16);
-            o.z = (unsigned)te_to_bf(acc[4]) | ((unsigned)te_to_bf(acc[5]) << 16); o.w = (unsigned)te_to_bf(acc[6]) | ((unsigned)te_to_bf(acc[7]) << 16);
+            o = make_uint4(pk_bf(acc[0], acc[1]), pk_bf(acc[2], acc[3]), pk_bf(acc[4], acc[5]), pk_bf(acc[6], acc[7]));
         }
         out[e] = o;
     }

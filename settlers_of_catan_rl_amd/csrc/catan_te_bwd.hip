@@ -91,9 +91,8 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_dx(const unsigned short* __rest
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW2 + (16 * j + lr) * FB_P + 32 * s + 8 * g), db[s], c, 0, 0, 0);
             const unsigned h01 = hv[j].x, h23 = hv[j].y;
             // (H is a ReLU output: > 0 <=> its bf16 bits are neither +0 nor negative; the unfused kernel tests the value)
-            const unsigned d0 = __uint_as_float(h01 << 16) > 0.f ? te_to_bf(c[0]) : 0u, d1 = __uint_as_float(h01 & 0xFFFF0000u) > 0.f ? te_to_bf(c[1]) : 0u;
-            const unsigned d2 = __uint_as_float(h23 << 16) > 0.f ? te_to_bf(c[2]) : 0u, d3 = __uint_as_float(h23 & 0xFFFF0000u) > 0.f ? te_to_bf(c[3]) : 0u;
-            const unsigned p0 = d0 | (d1 << 16), p1 = d2 | (d3 << 16);
+            const unsigned p0 = pk_bf(__uint_as_float(h01 << 16) > 0.f ? c[0] : 0.f, __uint_as_float(h01 & 0xFFFF0000u) > 0.f ? c[1] : 0.f);
+            const unsigned p1 = pk_bf(__uint_as_float(h23 << 16) > 0.f ? c[2] : 0.f, __uint_as_float(h23 & 0xFFFF0000u) > 0.f ? c[3] : 0.f);
             hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
             if (r0 + lr < rows) *reinterpret_cast<uint2*>(dh + row * 128 + 16 * j + 4 * g) = make_uint2(p0, p1);
         }
@@ -476,9 +475,8 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             for (int s = 0; s < 2; s++)
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW2 + (16 * j + lr) * FB_P + 32 * s + 8 * g), db[s], c, 0, 0, 0);
             const uint2 hv = *reinterpret_cast<const uint2*>(sH + fw_off(row, 16 * j + 4 * g));
-            const unsigned d0 = __uint_as_float(hv.x << 16) > 0.f ? te_to_bf(c[0]) : 0u, d1 = __uint_as_float(hv.x & 0xFFFF0000u) > 0.f ? te_to_bf(c[1]) : 0u;
-            const unsigned d2 = __uint_as_float(hv.y << 16) > 0.f ? te_to_bf(c[2]) : 0u, d3 = __uint_as_float(hv.y & 0xFFFF0000u) > 0.f ? te_to_bf(c[3]) : 0u;
-            const unsigned p0 = d0 | (d1 << 16), p1 = d2 | (d3 << 16);
+            const unsigned p0 = pk_bf(__uint_as_float(hv.x << 16) > 0.f ? c[0] : 0.f, __uint_as_float(hv.x & 0xFFFF0000u) > 0.f ? c[1] : 0.f);
+            const unsigned p1 = pk_bf(__uint_as_float(hv.y << 16) > 0.f ? c[2] : 0.f, __uint_as_float(hv.y & 0xFFFF0000u) > 0.f ? c[3] : 0.f);
             hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
             *reinterpret_cast<uint2*>(sDH + fw_off(row, 16 * j + 4 * g)) = make_uint2(p0, p1);
         }
@@ -519,8 +517,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             if (r0 + row < r_end) {
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    *reinterpret_cast<uint2*>(op.d_o + (r0 + row) * 64 + 16 * t + 4 * g) = make_uint2((unsigned)te_to_bf(co[t][0]) | ((unsigned)te_to_bf(co[t][1]) << 16),
-                                                                                                    (unsigned)te_to_bf(co[t][2]) | ((unsigned)te_to_bf(co[t][3]) << 16));
+                    *reinterpret_cast<uint2*>(op.d_o + (r0 + row) * 64 + 16 * t + 4 * g) = make_uint2(pk_bf(co[t][0], co[t][1]), pk_bf(co[t][2], co[t][3]));
             }
         }
         __syncthreads();                                                         // dH image and the dX' rows complete

@@ -143,6 +143,41 @@ DEVI void te_layer_norm(const unsigned short* src, int ps, unsigned short* dst, 
 #pragma unroll
     for (int i = 0; i < E; i += 8) te_store8(dst + t * pd + e0 + i, x + i);
 }
+// The final LayerNorm(25) + ReLU, written straight to the output rows (token t of the group -> board t / 19, columns 25 (t % 19) ..):
+// the rows are 50 bytes long and start on 2-byte boundaries, so the stores are 2 bytes wide whoever issues them - from here they
+// cost no LDS round trip, no barrier and no index arithmetic per element.
+DEVI void te_final_norm(const unsigned short* src, int ps, const float* w, const float* b, unsigned short* __restrict__ out, long out_pitch, int ntok, int tid) {
+    constexpr int D = TE_OUT, DP = (D + 7) & ~7, E = DP / TE_LT;
+    static_assert(E % 8 == 0 && TE_TOK * TE_LT <= TE_THREADS, "one pass");
+    const int t = tid / TE_LT, e0 = (tid % TE_LT) * E;
+    if (t >= ntok) return;
+    float x[E], mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; i += 8) te_load8(src + t * ps + e0 + i, x + i);
+#pragma unroll
+    for (int i = 0; i < E; i++) if (e0 + i < D) mean += x[i];
+#pragma unroll
+    for (int m = 1; m < TE_LT; m <<= 1) mean += __shfl_xor(mean, m);
+    mean *= 1.f / D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; i++) { const float c = x[i] - mean; if (e0 + i < D) var += c * c; }
+#pragma unroll
+    for (int m = 1; m < TE_LT; m <<= 1) var += __shfl_xor(var, m);
+    const float rstd = rsqrtf(var * (1.f / D) + 1e-5f);
+    const int g = t / TE_L;
+    unsigned short* o = out + g * out_pitch + (t - g * TE_L) * D + e0;
+    const float4* w4 = reinterpret_cast<const float4*>(w + e0);
+    const float4* b4 = reinterpret_cast<const float4*>(b + e0);
+#pragma unroll
+    for (int i = 0; i < E; i += 4) {
+        const float4 wv = w4[i >> 2], bv = b4[i >> 2];
+        const float ww[4] = { wv.x, wv.y, wv.z, wv.w }, bb[4] = { bv.x, bv.y, bv.z, bv.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e0 + i + k < D) o[i + k] = te_to_bf(fmaxf((x[i + k] - mean) * rstd * ww[k] + bb[k], 0.f));
+    }
+}
 // 4-head attention inside every board: qkv rows [token][3][head][16] -> out rows [token][head * 16 + d].  One (board, head) per
 // wave pass, on v_mfma_f32_32x32x16_bf16 exactly as k_attn_mfma_fwd (catan_nn.hip) does it: S^T = K Q^T lands with lane = query
 // column and the keys down the registers, so the softmax is in-lane plus one xor-32 exchange, and the probabilities are already
@@ -179,13 +214,14 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
             mx = fmaxf(mx, p[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // exp((s - max) / sqrt(16)) as one multiply and v_exp_f32 (2^x); the 1 / sum goes onto the 8 output registers, not the 12 p
+        // exp((s - max) / sqrt(16)) as one fma and v_exp_f32 (2^x); the 1 / sum (v_rcp_f32) goes onto the 8 output registers, not the 12 p
         constexpr float C = 0.25f * 1.44269504088896340736f;
+        const float mc = -mx * C;
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < NR; r++) { p[r] = __builtin_amdgcn_exp2f((p[r] - mx) * C); sum += p[r]; }
+        for (int r = 0; r < NR; r++) { p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], C, mc)); sum += p[r]; }
         sum += __shfl_xor(sum, 32);
-        const float inv = 1.f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         f32x16_t ot = zero16;
 #pragma unroll
         for (int s = 0; s < 2; s++)
@@ -308,15 +344,9 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const int t = c / TE_OUT, i = c - t * TE_OUT;
                 sv.p[(t0 + t) * TE_OUT + i] = Q[t * TE_PX + i];
             }
-            __syncthreads();                                                     // (the LayerNorm below is in place)
         }
-        te_layer_norm<TE_OUT, true>(Q, TE_PX, Q, TE_PX, V + TE_VP + 32, V + TE_VP + 64, tid);
-        __syncthreads();
         // (out_pitch elements per board, 19 x 25 of them written: the training path pads the board rows to whole 16-byte pieces)
-        for (int c = tid; c < nb * TE_L * TE_OUT; c += TE_THREADS) {
-            const int t = c / TE_OUT, i = c - t * TE_OUT, g = t / TE_L;
-            out[(g0 + g) * out_pitch + (t - g * TE_L) * TE_OUT + i] = Q[t * TE_PX + i];
-        }
+        te_final_norm(Q, TE_PX, V + TE_VP + 32, V + TE_VP + 64, out + g0 * out_pitch, out_pitch, nb * TE_L, tid);
     }
 }
 
