@@ -1037,18 +1037,17 @@ __global__ __launch_bounds__(256) void k_categorical_bwd(const float* __restrict
 // kernels above spend 115 k FMAs per tile sequence in the backward and ran 4-5x off the HBM floor (config-3 minibatch: 19 of
 // 86 ms in attention).  One wave = one sequence,
 // one v_mfma_f32_32x32x16_bf16 per product, everything TRANSPOSED so that no operand ever changes lanes:
-//   S^T = K Q^T           A = K rows j, B = Q rows i: both 16-byte global loads (lane = row, 8 of the 16 head dims per half)
+//   S^T = K Q^T           A = K rows j, B = Q rows i: 16-byte reads of the lane's row of the LDS image (8 of the 16 head dims per half)
 //   C layout of a 32x32 product: lane holds column (lane & 31) and rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15
 //   -> a lane owns query i and sixteen of the 32 (padded) keys: the softmax over keys is in-lane plus ONE xor-32 exchange
 //   O^T = V^T P^T         B = P^T straight from those registers: the contraction index may be permuted freely as long as A
 //                         uses the same permutation - k-step s, half h, element t  <->  key 16 s + 4 h + t (t < 4),
-//                         16 s + 8 + 4 h + (t - 4) (t >= 4), i.e. registers 8 s .. 8 s + 7; A = V^T rows d read from an LDS
-//                         copy of V transposed per head as two 8-byte runs
-//   O^T lands as lane = query i, rows = head dims: two 8-byte stores per head.
+//                         16 s + 8 + 4 h + (t - 4) (t >= 4), i.e. registers 8 s .. 8 s + 7; A = V^T rows d through the transposing
+//                         LDS read of the token-major V columns (ds_read_b64_tr_b16: four keys' dim d per instruction)
+//   O^T lands as lane = query i, rows = head dims: two 8-byte LDS stores per head into the image; whole rows leave.
 // The backward adds the same products in the other orientation (lane = key j) for dK / dV, exchanging only the per-query
 // softmax statistics through LDS.
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-constexpr int AT_LP = 36;                                   // LDS pitch of a transposed row (32 keys / queries + pad)
 
 __device__ __forceinline__ unsigned short f2bf(float x) { const __hip_bfloat16 h = __float2bfloat16(x); return *reinterpret_cast<const unsigned short*>(&h); }
 __device__ __forceinline__ bf16x8_t pack_bf8(const float* v) {
@@ -1067,25 +1066,6 @@ __device__ __forceinline__ bf16x8_t ld_frag(const unsigned short* head, int hf, 
     else { if (ok && hf == 0) r.v[0] = *reinterpret_cast<const uint2*>(head); }
     return r.f;
 }
-// A operand from a transposed LDS row: the two 4-element runs of k-step s for this lane half
-__device__ __forceinline__ bf16x8_t ld_runs(const unsigned short* row, int s, int hf) {
-    union { bf16x8_t f; uint2 u[2]; } r;
-    r.u[0] = *reinterpret_cast<const uint2*>(row + 16 * s + 4 * hf);
-    r.u[1] = *reinterpret_cast<const uint2*>(row + 16 * s + 8 + 4 * hf);
-    return r.f;
-}
-// stage one of q / k / v / dout of a sequence transposed: dst[dim][j] (j < L written; the rest stays zero)
-template <int L, int D>
-__device__ __forceinline__ void stage_transposed(unsigned short* dst, const unsigned short* src, int row_stride, int lane) {
-    constexpr int CH = D / 8;
-    for (int x = lane; x < L * CH; x += 64) {
-        const int j = x / CH, c = x - j * CH;                  // row j, 8-element chunk c
-        const uint4 u = *reinterpret_cast<const uint4*>(src + j * row_stride + c * 8);
-        const unsigned w[4] = { u.x, u.y, u.z, u.w };
-#pragma unroll
-        for (int e = 0; e < 8; e++) dst[(c * 8 + e) * AT_LP + j] = (unsigned short)(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu);
-    }
-}
 // rows d < HD of a [d][col] product sit in registers 0..7 (HD = 16: d = 4 hf + r, 8 + 4 hf + (r - 4)) or 0..3 of half 0 (HD = 4)
 template <int HD>
 __device__ __forceinline__ void st_head(unsigned short* head, const f32x16_t& c, int hf) {
@@ -1094,55 +1074,6 @@ __device__ __forceinline__ void st_head(unsigned short* head, const f32x16_t& c,
         *reinterpret_cast<uint2*>(head + 8 + 4 * hf) = make_uint2(pk_bf(c[4], c[5]), pk_bf(c[6], c[7]));
     } else {
         if (hf == 0) *reinterpret_cast<uint2*>(head) = make_uint2(pk_bf(c[0], c[1]), pk_bf(c[2], c[3]));
-    }
-}
-
-template <int L, int H, int HD>
-__global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
-                                                       unsigned short* __restrict__ out, long B) {
-    constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;
-    static_assert(L <= 32 && D % 8 == 0 && (HD == 16 || HD == 4), "one 32x32 tile per product");
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[4][D * AT_LP];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
-    const long b = (long)blockIdx.x * 4 + wv;
-    if (b >= B) return;
-    unsigned short* vt = Vt[wv];
-    for (int x = lane; x < D * AT_LP / 4; x += 64) reinterpret_cast<uint2*>(vt)[x] = make_uint2(0, 0);
-    __builtin_amdgcn_wave_barrier();
-    const unsigned short* base = qkv + b * (long)(L * 3 * D);
-    stage_transposed<L, D>(vt, base + 2 * D, 3 * D, lane);
-    __builtin_amdgcn_wave_barrier();
-    const bool rowok = c31 < L;
-    const int len = lens ? lens[b] : L;
-    const float scale = HD == 16 ? 0.25f : 0.5f;               // 1 / sqrt(HD)
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int h = 0; h < H; h++) {
-        const bf16x8_t ka = ld_frag<HD>(base + (c31 * 3 + 1) * D + h * HD, hf, rowok);
-        const bf16x8_t qb = ld_frag<HD>(base + (c31 * 3 + 0) * D + h * HD, hf, rowok);
-        const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);   // S^T[j][i]
-        // registers 12..15 hold keys 24..31: beyond every key when L <= 24 (the 19-token tile sequences) - not computed
-        float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            p[r] = j < len ? st[r] * scale : -INFINITY;
-            mx = fmaxf(mx, p[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < NR; r++) { p[r] = __expf(p[r] - mx); sum += p[r]; }
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int r = 0; r < NR; r++) p[r] *= inv;
-        f32x16_t ot = zero16;
-        const unsigned short* vrow = vt + (h * HD + (c31 % HD)) * AT_LP;
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? ld_runs(vrow, s, hf) : zero_bf8(), pack_bf8(p + 8 * s), ot, 0, 0, 0);   // O^T[d][i]
-        if (rowok) st_head<HD>(out + (b * L + c31) * (long)D + h * HD, ot, hf);
     }
 }
 
@@ -1183,6 +1114,91 @@ __device__ __forceinline__ bf16x8_t ld_gather_tr(const unsigned short* img_head,
     r.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(p + hi * rp));
     return r.f;
 }
+// The forward: the sequence's whole [L][3][D] block (contiguous in qkv) is staged row-major into an LDS image with coalesced 16-byte
+// loads; the K / Q fragments are 16-byte LDS reads of the lane's row, the V^T fragments come through the transposing LDS read (HD = 16)
+// or 2-byte gathers (HD = 4); head h's output replaces the (dead) Q columns of head h in the image, and the L x D result leaves as
+// whole rows.  (Every lane fetching its row's 16-byte slices per head from HBM and storing 8-byte slices back was 8 + 8 memory
+// instructions per sequence that each touched up to 38 cache lines: 0.74 ms per 204 800 sequences.)
+template <int L, int H, int HD>
+__global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
+                                                       unsigned short* __restrict__ out, long B) {
+    constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;
+    static_assert(L <= 32 && D % 8 == 0 && (HD == 16 || HD == 4), "one 32x32 tile per product");
+    constexpr bool TR = HD == 16;                            // transposing LDS reads (whole 16-dim heads)
+    constexpr int RP = 3 * D + 8;                            // row pitch of the image (elements): 16-byte aligned rows
+    constexpr int IR = TR ? (L <= 24 ? 24 : 32) : L;         // rows of the image (TR: zero rows behind the sequence, see k_attn_mfma_bwd)
+    constexpr int HI1 = IR == 24 ? 0 : 8;
+    __shared__ __attribute__((aligned(16))) unsigned short Img[4][IR * RP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, hf = lane >> 5, c31 = lane & 31;
+    const long b = (long)blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    unsigned short* img = Img[wv];
+    if (TR) for (int x = lane; x < (IR - L) * RP / 8; x += 64) reinterpret_cast<uint4*>(img + L * RP)[x] = make_uint4(0, 0, 0, 0);
+    const unsigned short* base = qkv + b * (long)(L * 3 * D);
+    constexpr int CR = 3 * D / 8;                            // 16-byte pieces per row
+    for (int x = lane; x < L * CR; x += 64) {
+        const int j = x / CR, c = x - j * CR;
+        *reinterpret_cast<uint4*>(img + j * RP + c * 8) = *reinterpret_cast<const uint4*>(base + (long)x * 8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool rowok = c31 < L;
+    const int len = lens ? lens[b] : L;
+    const float C = (HD == 16 ? 0.25f : 0.5f) * 1.44269504088896340736f;          // 1 / sqrt(HD), in the exponent of 2^x
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int rrow = (rowok ? c31 : 0) * RP;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        const bf16x8_t ka = ld_frag<HD>(img + rrow + D + h * HD, hf, rowok);
+        const bf16x8_t qb = ld_frag<HD>(img + rrow + h * HD, hf, rowok);
+        bf16x8_t va[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if constexpr (TR) va[s] = ld_gather_tr(img + 2 * D + h * HD, RP, s, lane, s == 1 ? HI1 : 8);
+            else {
+                union { bf16x8_t f; unsigned short u[8]; } r;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int row = 16 * s + 8 * (e >> 2) + 4 * hf + (e & 3);
+                    r.u[e] = row < L ? img[row * RP + 2 * D + h * HD + (c31 % HD)] : (unsigned short)0;
+                }
+                va[s] = r.f;
+            }
+        }
+        const f32x16_t st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qb, zero16, 0, 0, 0);   // S^T[j][i]
+        // registers 12..15 hold keys 24..31: beyond every key when L <= 24 (the 19-token tile sequences) - not computed
+        float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            p[r] = j < len ? st[r] : -INFINITY;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mc = -mx * C;
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NR; r++) { p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], C, mc)); sum += p[r]; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        f32x16_t ot = zero16;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? va[s] : zero_bf8(), pack_bf8(p + 8 * s), ot, 0, 0, 0);   // O^T[d][i]
+#pragma unroll
+        for (int r = 0; r < 8; r++) ot[r] *= inv;
+        if (rowok) st_head<HD>(img + rrow + h * HD, ot, hf);           // over head h's Q columns: every lane holds its fragment of them
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        constexpr int CH = D / 8;
+        unsigned short* ob = out + b * (long)(L * D);
+        for (int x = lane; x < L * CH; x += 64) {
+            const int j = x / CH, c = x - j * CH;
+            *reinterpret_cast<uint4*>(ob + j * D + c * 8) = *reinterpret_cast<const uint4*>(img + j * RP + c * 8);
+        }
+    }
+}
+
 // dqkv [B][L][3][D] from dout [B][L][D]; the probabilities are recomputed in both orientations (see above)
 template <int L, int H, int HD>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
