@@ -77,5 +77,18 @@ for _ in range(REPS):
     y = nn_kernels.expand_rows(srcu, inv, order, start)
     dy = torch.randn_like(y) if dy is None else dy
     torch.autograd.grad(y, srcu, dy)
+# the attention kernels (19 x 19, 4 heads x 16: 7 296 B of qkv in, 2 432 B out per sequence; backward: + dout in, dqkv out) and the
+# inference tile encoder (2 280 B in, 950 B out per board)
+del srcu, y, dy
+qkv = torch.randn(rows_mb, 19, 3, 4, 16, device=dev, generator=g).to(torch.bfloat16).requires_grad_(True)
+go = None
+for _ in range(REPS):
+    o = nn_kernels.small_attention(qkv)
+    go = torch.randn_like(o) if go is None else go
+    torch.autograd.grad(o, qkv, go)
+del qkv, o, go
+tiles = (torch.rand(rows_mb, 19, 60, device=dev, generator=g) < 0.1).to(torch.bfloat16)
+with torch.no_grad():
+    for _ in range(REPS): nn_kernels.tile_encoder_forward(te, tiles)
 torch.cuda.synchronize()
 print("pmc learner workload done")
