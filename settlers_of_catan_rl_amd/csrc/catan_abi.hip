@@ -87,13 +87,15 @@ static int attn_dispatch(bool bwd, const void* qkv, const int* lens, const void*
     if (L == 19 && H == 4 && HD == 16) {
         unsigned nb = (unsigned)((B + 2) / 3);
         if (mfma && !bwd) hipLaunchKernelGGL((k_attn_mfma_fwd<19, 4, 16>), dim3(nb4), dim3(256), 0, st, q16, lens, (unsigned short*)out, B);
-        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<19, 4, 16>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (mfma && lens) hipLaunchKernelGGL((k_attn_mfma_bwd<19, 4, 16, true>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<19, 4, 16, false>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
         else if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
         else hipLaunchKernelGGL((k_attn_bwd<T, 19, 4, 16>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
     } else if (L == 25 && H == 4 && HD == 4) {
         unsigned nb = (unsigned)((B + 1) / 2);
         if (mfma && !bwd) hipLaunchKernelGGL((k_attn_mfma_fwd<25, 4, 4>), dim3(nb4), dim3(256), 0, st, q16, lens, (unsigned short*)out, B);
-        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<25, 4, 4>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (mfma && lens) hipLaunchKernelGGL((k_attn_mfma_bwd<25, 4, 4, true>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
+        else if (mfma) hipLaunchKernelGGL((k_attn_mfma_bwd<25, 4, 4, false>), dim3(nb4), dim3(256), 0, st, q16, lens, (const unsigned short*)dout, (unsigned short*)out, B);
         else if (!bwd) hipLaunchKernelGGL((k_attn_fwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (T*)out, B);
         else hipLaunchKernelGGL((k_attn_bwd<T, 25, 4, 4>), dim3(nb), dim3(64), 0, st, q, lens, (const T*)dout, (T*)out, B);
     } else return fail(CATAN_EINVAL, "catan_attention: unsupported (L, heads, head_dim); built for (19,4,16) and (25,4,4)");

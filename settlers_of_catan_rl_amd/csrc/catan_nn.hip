@@ -1200,7 +1200,10 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(const unsigned short* __r
 }
 
 // dqkv [B][L][3][D] from dout [B][L][D]; the probabilities are recomputed in both orientations (see above)
-template <int L, int H, int HD>
+// LENS = false: no key mask (lens == nullptr): the length is the constant L - the masks of the keys behind the sequence fold away, and the
+// key lanes >= L need no zeroing at all (their dK / dV columns are never stored).  The 1 / sqrt(HD) of dS is a power of two: it is applied to
+// the 8 output registers of dQ / dK instead of the 12 dS values, bit-identically.
+template <int L, int H, int HD, bool LENS>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __restrict__ qkv, const int* __restrict__ lens,
                                                        const unsigned short* __restrict__ dout, unsigned short* __restrict__ dqkv, long B) {
     constexpr int D = H * HD, NR = L <= 24 ? 12 : 16;      // registers 12..15 = keys / queries 24..31: beyond the sequence when L <= 24
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
     stage_rows<L, D>(dot, dob, D, lane);
     __builtin_amdgcn_wave_barrier();
     const bool rowok = c31 < L;
-    const int len = lens ? lens[b] : L;
+    const int len = LENS ? lens[b] : L;
     const float scale = HD == 16 ? 0.25f : 0.5f;
     float* stat = &Stat[wv][0][0];
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1273,11 +1276,13 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
             delta += __shfl_xor(delta, 32);
             if (hf == 0) { stat[c31] = mc; stat[32 + c31] = inv; stat[64 + c31] = delta; }
 #pragma unroll
-            for (int r = 0; r < NR; r++) p[r] = p[r] * (dpt[r] - delta) * scale;                     // dS^T[j][i]
+            for (int r = 0; r < NR; r++) p[r] = p[r] * (dpt[r] - delta);                             // dS^T[j][i] / scale
             f32x16_t dq = zero16;
 #pragma unroll
             for (int s = 0; s < 2; s++)
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(kt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(kt + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dq, 0, 0, 0);   // dQ^T[d][i]
+#pragma unroll
+            for (int r = 0; r < 8; r++) dq[r] *= scale;
             dq_keep = dq;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1285,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
         {
             const f32x16_t s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kr, zero16, 0, 0, 0);     // S[i][j]
             const f32x16_t dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr, vr, zero16, 0, 0, 0);     // dP[i][j] = sum_d dO[i][d] V[j][d]
-            const bool keyok = c31 < len;                       // a masked key has probability 0 for every query
+            const bool keyok = !LENS || c31 < len;              // a masked key has probability 0 for every query
             const float C2 = scale * 1.44269504088896340736f;
             float p[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ds[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1298,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
                 for (int e = 0; e < 4; e++) {
                     const int r = 4 * q4 + e;
                     p[r] = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[r], C2, mm[e])) * ii[e] : 0.0f;   // mm = -max C (the query's)
-                    ds[r] = p[r] * (dp[r] - dd[e]) * scale;
+                    ds[r] = p[r] * (dp[r] - dd[e]);
                 }
             }
             f32x16_t dk = zero16, dv = zero16;
@@ -1307,6 +1312,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd(const unsigned short* __r
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(qt + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(qt + tcol, s, hf)) : zero_bf8(), pack_bf8(ds + 8 * s), dk, 0, 0, 0);   // dK^T[d][j]
                 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c31 < HD ? (TR ? ld_gather_tr(dot + h * HD, RP, s, lane, s == 1 ? HI1 : 8) : ld_gather<L, D>(dot + tcol, s, hf)) : zero_bf8(), pack_bf8(p + 8 * s), dv, 0, 0, 0);   // dV^T[d][j]
             }
+#pragma unroll
+            for (int r = 0; r < 8; r++) dk[r] *= scale;
             // head h's columns of the Q, K and dO images are dead now (this lane's fragments of them are in registers): dQ, dK, dV of the
             // head take their place, and the three images leave as whole rows below - 8-byte slices stored straight to dqkv were 24 store
             // instructions per sequence that each touched up to 38 cache lines
