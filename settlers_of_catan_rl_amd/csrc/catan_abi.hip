@@ -1280,6 +1280,25 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges, void* out,
+                              int64_t row_bytes, catan_stream_t stream) {
+    if (!dy || !perm || !ranges || !out || n_perm <= 0 || n_ranges < 0 || n_ranges > SR_MAX || row_bytes <= 0 || (row_bytes & 15) ||
+        (((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dy_pitch_bytes) & 15) || dy_pitch_bytes < row_bytes)
+        return fail(CATAN_EINVAL, "catan_scatter_rows_ranges: at most 16 ranges; rows are whole 16-byte pieces at 16-byte aligned addresses");
+    ScatterRanges rg;
+    rg.n = n_ranges;
+    for (int k = 0; k < SR_MAX; k++) { rg.a[k] = 0; rg.b[k] = 0; rg.off[k] = 0; }
+    for (int k = 0; k < n_ranges; k++) {
+        rg.a[k] = ranges[3 * k]; rg.b[k] = ranges[3 * k + 1]; rg.off[k] = ranges[3 * k + 2];
+        if (rg.a[k] < 0 || rg.b[k] < rg.a[k] || rg.b[k] > n_perm || rg.off[k] < 0) return fail(CATAN_EINVAL, "catan_scatter_rows_ranges: a range outside the permutation");
+    }
+    const int chunks = (int)(row_bytes / 16);
+    const long total = n_perm * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;
+    hipLaunchKernelGGL(k_scatter_ranges16, dim3((unsigned)nb), dim3(256), 0, S(stream), (const uint4*)dy, (long)(dy_pitch_bytes / 16), (const long long*)perm, (long)n_perm, rg,
+                       (uint4*)out, chunks);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int catan_ffn_bwd_dx(const void* dx, const void* h, const void* x, const void* w2t, const void* w1t, const float* ln_w, float eps, void* dh, void* dx_out,
                      float* dln_w, float* dln_b, int64_t rows, catan_stream_t stream) {
     if (!dx || !h || !x || !w2t || !w1t || !ln_w || !dh || !dx_out || !dln_w || !dln_b || rows <= 0 ||

@@ -721,6 +721,40 @@ def expand_rows(src, inv, order=None, start=None):
     return src[inv]
 
 
+class _GatherRanges(torch.autograd.Function):
+    """out = src[idx] where idx is the concatenation of the ranges perm[a:b] (`ranges`: host list of (a, b, off), off = where the range
+    starts in idx); backward: catan_scatter_rows_ranges - one pass over dy instead of index_put's sort + accumulate."""
+
+    @staticmethod
+    def forward(ctx, src, perm, idx, ranges):
+        ctx.save_for_backward(perm)
+        ctx.ranges, ctx.U = ranges, src.shape[0]
+        return gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        perm, = ctx.saved_tensors
+        if dy.stride(1) != 1 or (dy.stride(0) * 2) % 16 or dy.data_ptr() % 16:
+            dy = dy.contiguous()
+        dsrc = torch.empty((ctx.U, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+        flat = (C.c_int64 * (3 * len(ctx.ranges)))(*[int(v) for r in ctx.ranges for v in r])
+        _lib.check(_lib.lib().catan_scatter_rows_ranges(_ptr(dy), dy.stride(0) * 2, _ptr(perm), ctx.U, C.cast(flat, C.c_void_p), len(ctx.ranges), _ptr(dsrc),
+                                                         dy.shape[1] * 2, _stream()))
+        return dsrc, None, None, None
+
+
+GATHER_RANGES = True          # (A/B switch)
+
+
+def gather_ranges(src, perm, idx, ranges):
+    """src[idx] for idx = cat(perm[a:b] for (a, b, off) in ranges) with the ranges-aware backward on the GPU (bf16 rows of whole
+    16-byte pieces, perm a permutation of all of src's rows, at most 16 ranges); plain indexing otherwise"""
+    if (GATHER_RANGES and src.is_cuda and src.dim() == 2 and src.dtype == torch.bfloat16 and (src.shape[1] * 2) % 16 == 0 and src.is_contiguous()
+            and perm.dtype == torch.int64 and perm.numel() == src.shape[0] and 0 < len(ranges) <= 16 and torch.is_grad_enabled() and src.requires_grad):
+        return _GatherRanges.apply(src, perm.contiguous(), idx, tuple(ranges))
+    return src[idx]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The tile encoder's TRAINING forward as the one fused kernel (k_tile_encoder_fwd<SAVE>): the minibatch steps of a PPO update
 # spent 5.5 of their 41 ms in the encoder's forward as ~20 kernels that each stream a [boards x 19, 64..192] activation tensor

@@ -1205,6 +1205,38 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             assert d_f <= max(2.0 * d_u, 0.05), (B, n, d_f, d_u)
 
 
+def test_gather_of_permutation_ranges_backward(hip_lib):
+    """nn_kernels.gather_ranges (forward: the row gather; backward: catan_scatter_rows_ranges) against plain indexing under autograd:
+    the heads' row lists are ranges of one permutation, a row sits in 0..3 of them.  Rows with one contribution are bit-equal; sums
+    agree with the fp32 sum of the bf16 rows rounded once."""
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n, W in ((1000, 512), (40961, 512), (777, 128)):
+        perm = torch.randperm(n, device="cuda", generator=g)
+        cuts = sorted(torch.randint(0, n, (6,), generator=torch.Generator().manual_seed(n)).tolist())
+        spans = [(cuts[0], cuts[2]), (cuts[1], cuts[3]), (cuts[1], cuts[2]), (cuts[4], cuts[5]), (cuts[5], cuts[5]), (0, cuts[0] // 2)]
+        ranges, off = [], 0
+        for a, b in spans:
+            if b > a:
+                ranges.append((a, b, off)); off += b - a
+        idx = torch.cat([perm[a:b] for a, b, _ in ranges])
+        src = torch.randn(n, W, device="cuda", generator=g).to(torch.bfloat16)
+        dy = torch.randn(idx.numel(), W, device="cuda", generator=g).to(torch.bfloat16)
+        a1 = src.clone().requires_grad_(True)
+        y1 = nn_kernels.gather_ranges(a1, perm, idx, ranges)
+        assert type(y1.grad_fn).__name__ == "_GatherRangesBackward" and torch.equal(y1, src[idx])
+        g1, = torch.autograd.grad(y1, a1, dy)
+        ref = torch.zeros(n, W, device="cuda", dtype=torch.float32).index_add_(0, idx, dy.float())
+        cnt = torch.bincount(idx, minlength=n)
+        assert int(cnt.max()) == 3 or n < 2000
+        assert torch.equal(g1, ref.to(torch.bfloat16)), (n, W)
+        assert not bool(g1[cnt == 0].any())
+        # a column window of a wider gradient is read in place
+        wide = torch.randn(idx.numel(), W + 64, device="cuda", generator=g).to(torch.bfloat16)
+        g2, = torch.autograd.grad(nn_kernels.gather_ranges(a1, perm, idx, ranges), a1, wide[:, 32:32 + W])
+        assert torch.equal(g2, torch.zeros(n, W, device="cuda").index_add_(0, idx, wide[:, 32:32 + W].float()).to(torch.bfloat16))
+
+
 def test_row_gather_expand_and_segment_sum_kernels(hip_lib):
     """catan_gather_rows / catan_expand_rows / catan_segment_sum_rows against torch indexing: 2-byte aligned rows of odd word counts
     taken out of a wider matrix (the rollout's 3 574-byte bf16 rows), into a column window of a wider destination; the per-board
