@@ -74,10 +74,12 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
 /* The backward of a gather whose index list is a concatenation of ranges of a permutation (the action heads' rows of a PPO minibatch:
  * action_heads_module.py:61-160 evaluates a head on the rows of its action types; here the rows are sorted by type once and every
  * head takes one or two runs of that order): out row perm[p] = the sum (fp32, rounded to bf16) of the bf16 rows dy[off_k + p - a_k]
- * over the ranges a_k <= p < b_k, zeros for a row in no range.  ranges: HOST array of n_ranges <= 16 triples (a, b, off); perm: a
- * permutation of 0 .. n_perm - 1 (device); rows of whole 16-byte pieces, dy's rows dy_pitch_bytes apart. */
-int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges, void* out,
-                              int64_t row_bytes, catan_stream_t stream);
+ * over the ranges a_k <= p < b_k, plus the rows perm[p] of add0 / add1 (either may be NULL: the gradients that the source tensor's other
+ * consumers produced, [n_perm][row] contiguous - autograd would add them in two more passes), zeros for a row with no term.
+ * ranges: HOST array of n_ranges <= 16 triples (a, b, off); perm: a permutation of 0 .. n_perm - 1 (device); rows of whole
+ * 16-byte pieces, dy's rows dy_pitch_bytes apart. */
+int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges,
+                              const void* add0, const void* add1, void* out, int64_t row_bytes, catan_stream_t stream);
 
 /* Fused small-sequence multi-head attention of the policy net (RL/models/multi_headed_attention.py:25-54 as used by
  * tile_encoder.py:41-60 with L=19, 4 heads x 16 and by player_modules.py:55-69 with L<=25, 4 heads x 4).

@@ -1280,10 +1280,10 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
-int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges, void* out,
-                              int64_t row_bytes, catan_stream_t stream) {
+int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges,
+                              const void* add0, const void* add1, void* out, int64_t row_bytes, catan_stream_t stream) {
     if (!dy || !perm || !ranges || !out || n_perm <= 0 || n_ranges < 0 || n_ranges > SR_MAX || row_bytes <= 0 || (row_bytes & 15) ||
-        (((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dy_pitch_bytes) & 15) || dy_pitch_bytes < row_bytes)
+        (((uintptr_t)dy | (uintptr_t)out | (uintptr_t)dy_pitch_bytes | (uintptr_t)add0 | (uintptr_t)add1) & 15) || dy_pitch_bytes < row_bytes)
         return fail(CATAN_EINVAL, "catan_scatter_rows_ranges: at most 16 ranges; rows are whole 16-byte pieces at 16-byte aligned addresses");
     ScatterRanges rg;
     rg.n = n_ranges;
@@ -1295,7 +1295,7 @@ int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int6
     const int chunks = (int)(row_bytes / 16);
     const long total = n_perm * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;
     hipLaunchKernelGGL(k_scatter_ranges16, dim3((unsigned)nb), dim3(256), 0, S(stream), (const uint4*)dy, (long)(dy_pitch_bytes / 16), (const long long*)perm, (long)n_perm, rg,
-                       (uint4*)out, chunks);
+                       (const uint4*)add0, (const uint4*)add1, (uint4*)out, chunks);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

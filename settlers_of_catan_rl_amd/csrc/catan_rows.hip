@@ -59,12 +59,14 @@ __global__ __launch_bounds__(256) void k_segment_sum16(const uint4* __restrict__
 
 // The backward of a gather whose index list is a concatenation of RANGES of a permutation (the heads' rows of a minibatch: perm = the rows
 // sorted by action type, every head takes one or two contiguous runs of it, a row appears in at most three lists): out row perm[p] = the
-// sum (fp32, rounded to bf16) of the rows dy[off_k + p - a_k] over the ranges a_k <= p < b_k, zeros for a row in no range.  Autograd's
+// sum (fp32, rounded to bf16) of the rows dy[off_k + p - a_k] over the ranges a_k <= p < b_k (+ add0 / add1 rows perm[p]), zeros for a row
+// with no term.  Autograd's
 // index_put sorts the 2 x 10^5 indices again in every step (0.32 ms); this is one pass over dy and out.
 constexpr int SR_MAX = 16;
 struct ScatterRanges { int n; long a[SR_MAX], b[SR_MAX], off[SR_MAX]; };
 __global__ __launch_bounds__(256) void k_scatter_ranges16(const uint4* __restrict__ dy, long dy_pitch, const long long* __restrict__ perm, long n_perm,
-                                                          ScatterRanges rg, uint4* __restrict__ out, int chunks) {
+                                                          ScatterRanges rg, const uint4* __restrict__ add0, const uint4* __restrict__ add1,
+                                                          uint4* __restrict__ out, int chunks) {
     const long total = n_perm * chunks;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long p = e / chunks; const int c = (int)(e - p * chunks);
@@ -80,8 +82,16 @@ __global__ __launch_bounds__(256) void k_scatter_ranges16(const uint4* __restric
             acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xFFFF0000u);
             acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xFFFF0000u);
         }
+        // add0 / add1 (optional): further gradients of the SAME rows (the source tensor's other consumers), [n_perm][chunks] like out
+        const long o = perm[p] * chunks + c;
+        if (add0) { const uint4 v = add0[o]; one = v; hits++;
+            acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xFFFF0000u); acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xFFFF0000u); acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xFFFF0000u); }
+        if (add1) { const uint4 v = add1[o]; one = v; hits++;
+            acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xFFFF0000u); acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xFFFF0000u); acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xFFFF0000u); }
         // (one row: its bits, not a round trip through fp32 - the same value)
-        out[perm[p] * chunks + c] = hits == 1 ? one : make_uint4(pk_bf(acc[0], acc[1]), pk_bf(acc[2], acc[3]), pk_bf(acc[4], acc[5]), pk_bf(acc[6], acc[7]));
+        out[o] = hits == 1 ? one : make_uint4(pk_bf(acc[0], acc[1]), pk_bf(acc[2], acc[3]), pk_bf(acc[4], acc[5]), pk_bf(acc[6], acc[7]));
     }
 }
 

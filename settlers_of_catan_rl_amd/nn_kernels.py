@@ -721,6 +721,18 @@ def expand_rows(src, inv, order=None, start=None):
     return src[inv]
 
 
+def _scatter_ranges(dy, perm, ranges, U, add0=None, add1=None):
+    if dy.stride(1) != 1 or (dy.stride(0) * 2) % 16 or dy.data_ptr() % 16:
+        dy = dy.contiguous()
+    adds = [None if a is None else a.to(dy.dtype).contiguous() for a in (add0, add1)]
+    dsrc = torch.empty((U, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+    flat = (C.c_int64 * (3 * len(ranges)))(*[int(v) for r in ranges for v in r])
+    _lib.check(_lib.lib().catan_scatter_rows_ranges(_ptr(dy), dy.stride(0) * 2, _ptr(perm), U, C.cast(flat, C.c_void_p), len(ranges),
+                                                     None if adds[0] is None else _ptr(adds[0]), None if adds[1] is None else _ptr(adds[1]), _ptr(dsrc),
+                                                     dy.shape[1] * 2, _stream()))
+    return dsrc
+
+
 class _GatherRanges(torch.autograd.Function):
     """out = src[idx] where idx is the concatenation of the ranges perm[a:b] (`ranges`: host list of (a, b, off), off = where the range
     starts in idx); backward: catan_scatter_rows_ranges - one pass over dy instead of index_put's sort + accumulate."""
@@ -734,25 +746,51 @@ class _GatherRanges(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         perm, = ctx.saved_tensors
-        if dy.stride(1) != 1 or (dy.stride(0) * 2) % 16 or dy.data_ptr() % 16:
-            dy = dy.contiguous()
-        dsrc = torch.empty((ctx.U, dy.shape[1]), dtype=dy.dtype, device=dy.device)
-        flat = (C.c_int64 * (3 * len(ctx.ranges)))(*[int(v) for r in ctx.ranges for v in r])
-        _lib.check(_lib.lib().catan_scatter_rows_ranges(_ptr(dy), dy.stride(0) * 2, _ptr(perm), ctx.U, C.cast(flat, C.c_void_p), len(ctx.ranges), _ptr(dsrc),
-                                                         dy.shape[1] * 2, _stream()))
-        return dsrc, None, None, None
+        return _scatter_ranges(dy, perm, ctx.ranges, ctx.U), None, None, None
 
 
-GATHER_RANGES = True          # (A/B switch)
+class _FanOutGatherRanges(torch.autograd.Function):
+    """(src, src, src[idx]): the source tensor leaves through the function for its two other consumers as well, so the function is
+    its ONLY consumer and forms its whole gradient - the gathered rows' sums plus the two consumers' gradients - in the one pass of
+    catan_scatter_rows_ranges instead of autograd adding full-size tensors twice afterwards."""
+
+    @staticmethod
+    def forward(ctx, src, perm, idx, ranges):
+        ctx.save_for_backward(perm)
+        ctx.ranges, ctx.U, ctx.W = ranges, src.shape[0], src.shape[1]
+        return src.view_as(src), src.view_as(src), gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, g0, g1, dy):
+        perm, = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros((1, ctx.W), dtype=(g0 if g0 is not None else g1).dtype, device=perm.device)
+            return _scatter_ranges(dy, perm, (), ctx.U, g0, g1), None, None, None
+        return _scatter_ranges(dy, perm, ctx.ranges, ctx.U, g0, g1), None, None, None
+
+
+GATHER_RANGES = True          # (A/B switches)
+FANOUT_GATHER = True
+
+
+def _gather_ranges_ok(src, perm, ranges):
+    return (GATHER_RANGES and src.is_cuda and src.dim() == 2 and src.dtype == torch.bfloat16 and (src.shape[1] * 2) % 16 == 0 and src.is_contiguous()
+            and perm.dtype == torch.int64 and perm.numel() == src.shape[0] and 0 < len(ranges) <= 16 and torch.is_grad_enabled() and src.requires_grad)
 
 
 def gather_ranges(src, perm, idx, ranges):
     """src[idx] for idx = cat(perm[a:b] for (a, b, off) in ranges) with the ranges-aware backward on the GPU (bf16 rows of whole
     16-byte pieces, perm a permutation of all of src's rows, at most 16 ranges); plain indexing otherwise"""
-    if (GATHER_RANGES and src.is_cuda and src.dim() == 2 and src.dtype == torch.bfloat16 and (src.shape[1] * 2) % 16 == 0 and src.is_contiguous()
-            and perm.dtype == torch.int64 and perm.numel() == src.shape[0] and 0 < len(ranges) <= 16 and torch.is_grad_enabled() and src.requires_grad):
+    if _gather_ranges_ok(src, perm, ranges):
         return _GatherRanges.apply(src, perm.contiguous(), idx, tuple(ranges))
     return src[idx]
+
+
+def fanout_gather_ranges(src, perm, idx, ranges):
+    """-> (src, src, src[idx]) for a tensor with exactly these three consumers (see _FanOutGatherRanges); (src, src, gather) otherwise"""
+    if FANOUT_GATHER and _gather_ranges_ok(src, perm, ranges):
+        return _FanOutGatherRanges.apply(src, perm.contiguous(), idx, tuple(ranges))
+    return src, src, gather_ranges(src, perm, idx, ranges)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -549,11 +549,11 @@ class _ActionHeads(nn.Module):
         ends = torch.cumsum(counts, 1).tolist()
         return [(order[k], ends[k], None) for k in range(num_mini_batch)]
 
-    def _evaluate_compact(self, main, m, cur_res, trade, actions, grouping=None):
+    def _evaluate_compact(self, main, m, cur_res, trade, actions, grouping=None, value_fn=None):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
         typ, card = actions[:, 0], actions[:, 4]
         pre_of = lambda i, x: _lin(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
-        _, logp0, e0 = _categorical(H[0].logits(pre_of(0, main)), m[:, MO[0]:MO[0] + 13], typ, False, None)
+        type_head = lambda x: _categorical(H[0].logits(pre_of(0, x)), m[:, MO[0]:MO[0] + 13], typ, False, None)
         # one sort by (type, card of a played development card) and one host read give every head's rows
         perm, ends, ev = grouping if grouping is not None else self.start_grouping(actions)
         if ev is not None:
@@ -569,6 +569,8 @@ class _ActionHeads(nn.Module):
         # ONE gather of the trunk rows (and of the mask / action rows) for all heads: its backward is one scatter-add
         order = [i for i in sets if sets[i].numel()]
         if not order:
+            self.last_value = value_fn(main) if value_fn is not None else None
+            _, logp0, e0 = type_head(main)
             return actions.clone(), logp0, e0.sum() / B
         all_rows = torch.cat([sets[i] for i in order])
         # the same lists as ranges of perm, (a, b, where the range starts in all_rows): the gather's backward sums a row's <= 3 gradients
@@ -583,7 +585,17 @@ class _ActionHeads(nn.Module):
             for a_, b_ in sets_r[i]:
                 if b_ > a_:
                     pieces.append((a_, b_, off)); off += b_ - a_
-        mg = nn_kernels.gather_ranges(main, perm, all_rows, pieces) if off == all_rows.numel() else main[all_rows]
+        # `main` has three consumers - the type head, the value head (value_fn), this gather: with all three behind ONE autograd node its
+        # gradient is formed in the gather's backward pass (nn_kernels.fanout_gather_ranges) instead of two more full-size adds
+        m_type = m_val = main
+        if off != all_rows.numel():
+            mg = main[all_rows]
+        elif value_fn is not None:
+            m_type, m_val, mg = nn_kernels.fanout_gather_ranges(main, perm, all_rows, pieces)
+        else:
+            mg = nn_kernels.gather_ranges(main, perm, all_rows, pieces)
+        self.last_value = value_fn(m_val) if value_fn is not None else None
+        _, logp0, e0 = type_head(m_type)
         mm_g, ag = m[all_rows], actions[all_rows]
         at, off = {}, 0
         for i in order:
@@ -708,13 +720,14 @@ class _ActionHeads(nn.Module):
         out_final = torch.cat((torch.zeros(B, 1, device=pre.device), total[:, 1:]), 1)
         return out_final, acts[:, :4], logp_sum, ent_sum
 
-    def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None, grouping=None):
+    def forward(self, main, masks, cur_res, trade, actions=None, deterministic=False, generator=None, forced_type=None, grouping=None, value_fn=None):
         """main [B,512] (+ lstm_size with the LSTM); masks [B,325]; cur_res [B,6]; trade [B,12]; actions int64 [B,18] or None.
         forced_type int64 [B] or None: rows with a value >= 0 take that action type instead of sampling the type head
         (`condition_on_action_type`, action_heads_module.py:37-48: the type head is skipped, its output is the one-hot).
         -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
         if actions is not None and forced_type is None and self.compact_evaluate and main.shape[0] >= self.compact_min_rows:
-            return self._evaluate_compact(main, masks, cur_res, trade, actions, grouping)
+            return self._evaluate_compact(main, masks, cur_res, trade, actions, grouping, value_fn)
+        self.last_value = value_fn(main) if value_fn is not None else None      # (value_fn: the caller's other consumer of `main`, see _evaluate_compact)
         B, dev = main.shape[0], main.device
         H = self.action_heads
         given = (lambda i: None) if actions is None else (lambda i: actions[:, i])
@@ -939,9 +952,10 @@ class CatanPolicy(nn.Module):
         ahm = self.action_head_module
         if grouping is None or not ahm.wants_grouping(obs_f.shape[0], actions):
             grouping = ahm.start_grouping(actions) if ahm.wants_grouping(obs_f.shape[0], actions) else None    # (before the long forward)
-        value, main, hidden = self.base(obs_f, lists, lens, hidden, nonterminal, tile_dedupe=tile_dedupe)
+        main, hidden = self._main(obs_f, lists, lens, hidden, nonterminal, tile_dedupe=tile_dedupe)
         cur_res, trade = self._custom(obs_f)
-        _, logp, entropy = ahm(main, masks.float(), cur_res, trade, actions, grouping=grouping)
+        _, logp, entropy = ahm(main, masks.float(), cur_res, trade, actions, grouping=grouping, value_fn=self._value)
+        value, ahm.last_value = ahm.last_value, None
         return (value, logp[:, None], entropy, hidden) if self.include_lstm else (value, logp[:, None], entropy)
 
     def get_value(self, obs_f, lists, lens, hidden=None, nonterminal=None, tile_features=None):

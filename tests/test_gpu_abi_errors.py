@@ -41,8 +41,8 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "16-byte" in err(L.catan_expand_rows(P(b16), P(idx), 8, P(b16), 1000, st))
     assert "16-byte" in err(L.catan_segment_sum_rows(C.c_void_p(b16.data_ptr() + 2), 1024, P(idx), P(idx), 4, P(b16), 1024, st))
     rng3 = (C.c_int64 * 3)(0, 9, 0)
-    assert "16 ranges" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 17, P(b16), 1024, st))
-    assert "outside the permutation" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 1, P(b16), 1024, st))
+    assert "16 ranges" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 17, None, None, P(b16), 1024, st))
+    assert "outside the permutation" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 1, None, None, P(b16), 1024, st))
     assert "null or misaligned" in err(L.catan_ffn_bwd_dx(P(b16), None, P(b16), P(b16), P(b16), P(dw), 1e-5, P(b16), P(b16), P(dw), P(dw), 16, st))
     assert "null or misaligned" in err(L.catan_qkv_bwd_dx(P(b16), P(b16), C.c_void_p(b16.data_ptr() + 8), P(b16), P(dw), 1e-5, P(b16), P(dw), P(dw), 16, st))
     assert "null or misaligned" in err(L.catan_ffn_bwd(P(b16), P(b16), P(b16), None, P(b16), P(b16), P(dw), None, 1e-5, P(b16), P(dw), P(dw), P(dw), P(dw), P(dw), P(dw), 16, st))

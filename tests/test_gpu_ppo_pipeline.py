@@ -1231,6 +1231,17 @@ def test_gather_of_permutation_ranges_backward(hip_lib):
         assert int(cnt.max()) == 3 or n < 2000
         assert torch.equal(g1, ref.to(torch.bfloat16)), (n, W)
         assert not bool(g1[cnt == 0].any())
+        # the source's two other consumers through the same node: their gradients join in the same pass (fp32 sum, rounded once)
+        a2 = src.clone().requires_grad_(True)
+        x0, x1, y2 = nn_kernels.fanout_gather_ranges(a2, perm, idx, ranges)
+        assert type(y2.grad_fn).__name__ == "_FanOutGatherRangesBackward" and torch.equal(y2, src[idx]) and torch.equal(x0, src) and torch.equal(x1, src)
+        e0 = torch.randn(n, W, device="cuda", generator=g).to(torch.bfloat16); e1 = torch.randn(n, W, device="cuda", generator=g).to(torch.bfloat16)
+        g3, = torch.autograd.grad([x0, x1, y2], a2, [e0, e1, dy])
+        ref3 = ref + e0.float() + e1.float()
+        assert float((g3.float() - ref3).abs().max()) <= 0.04 and float((g3 != ref3.to(torch.bfloat16)).float().mean()) < 1e-3
+        x0, x1, y2 = nn_kernels.fanout_gather_ranges(a2, perm, idx, ranges)
+        g4, = torch.autograd.grad([x0.float().sum() * 0 + x1.float().mul(e1.float()).sum() + y2.float().sum() * 0], a2)      # only one consumer has a non-zero gradient
+        assert torch.allclose(g4.float(), e1.float(), atol=1e-2)
         # a column window of a wider gradient is read in place
         wide = torch.randn(idx.numel(), W + 64, device="cuda", generator=g).to(torch.bfloat16)
         g2, = torch.autograd.grad(nn_kernels.gather_ranges(a1, perm, idx, ranges), a1, wide[:, 32:32 + W])
