@@ -71,6 +71,10 @@ int catan_gather_rows(const void* src, int64_t src_pitch_bytes, const int64_t* i
 int catan_expand_rows(const void* src, const int64_t* inv, int64_t n, void* out, int64_t row_bytes, catan_stream_t stream);
 int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t* order, const int64_t* start, int64_t segments, void* out, int64_t row_bytes,
                            catan_stream_t stream);
+/* out row r = srcs[0] row r | srcs[1] row r | ... (observation_module.py:58-60: the trunk input is the concatenation of the tile encoding and
+ * the player modules' outputs).  srcs, row_bytes: HOST arrays of n <= 4 device pointers / row sizes (whole 16-byte pieces, contiguous
+ * rows); out's rows lie out_pitch_bytes apart. */
+int catan_concat_rows(const void* const* srcs, const int64_t* row_bytes, int n, void* out, int64_t out_pitch_bytes, int64_t rows, catan_stream_t stream);
 /* The backward of a gather whose index list is a concatenation of ranges of a permutation (the action heads' rows of a PPO minibatch:
  * action_heads_module.py:61-160 evaluates a head on the rows of its action types; here the rows are sorted by type once and every
  * head takes one or two runs of that order): out row perm[p] = the sum (fp32, rounded to bf16) of the bf16 rows dy[off_k + p - a_k]

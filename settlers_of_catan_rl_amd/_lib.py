@@ -130,6 +130,7 @@ _SIGS = {
     "catan_gather_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp]),
     "catan_expand_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_segment_sum_rows": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
+    "catan_concat_rows": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int64, _vp]),
     "catan_scatter_rows_ranges": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_collector_pre": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "catan_collector_post": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 23),

@@ -1280,6 +1280,24 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_concat_rows(const void* const* srcs, const int64_t* row_bytes, int n, void* out, int64_t out_pitch_bytes, int64_t rows, catan_stream_t stream) {
+    if (!srcs || !row_bytes || !out || n < 1 || n > CC_MAX || rows <= 0 || (((uintptr_t)out | (uintptr_t)out_pitch_bytes) & 15))
+        return fail(CATAN_EINVAL, "catan_concat_rows: 1..4 sources; rows are whole 16-byte pieces at 16-byte aligned addresses");
+    ConcatSrc cs;
+    cs.n = n;
+    int total = 0;
+    for (int k = 0; k < CC_MAX; k++) { cs.src[k] = nullptr; cs.chunks[k] = 0; cs.first[k] = 0; }
+    for (int k = 0; k < n; k++) {
+        if (!srcs[k] || row_bytes[k] <= 0 || (row_bytes[k] & 15) || ((uintptr_t)srcs[k] & 15))
+            return fail(CATAN_EINVAL, "catan_concat_rows: 1..4 sources; rows are whole 16-byte pieces at 16-byte aligned addresses");
+        cs.src[k] = (const uint4*)srcs[k]; cs.chunks[k] = (int)(row_bytes[k] / 16); cs.first[k] = total; total += cs.chunks[k];
+    }
+    if ((long)total * 16 > out_pitch_bytes) return fail(CATAN_EINVAL, "catan_concat_rows: the sources' rows exceed the output pitch");
+    const long pieces = rows * total, nb = (pieces + 255) / 256 < 65536 ? (pieces + 255) / 256 : 65536;
+    hipLaunchKernelGGL(k_concat_rows16, dim3((unsigned)nb), dim3(256), 0, S(stream), cs, (uint4*)out, (long)rows, total, (int)(out_pitch_bytes / 16));
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges,
                               const void* add0, const void* add1, void* out, int64_t row_bytes, catan_stream_t stream) {
     if (!dy || !perm || !ranges || !out || n_perm <= 0 || n_ranges < 0 || n_ranges > SR_MAX || row_bytes <= 0 || (row_bytes & 15) ||

@@ -721,6 +721,41 @@ def expand_rows(src, inv, order=None, start=None):
     return src[inv]
 
 
+class _ConcatRows(torch.autograd.Function):
+    """torch.cat(parts, -1) of 2-D bf16 tensors whose rows are whole 16-byte pieces, by catan_concat_rows; backward: the column windows of
+    the gradient (views, as cat's own backward hands out)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        parts = [p.contiguous() for p in parts]
+        ctx.widths = [p.shape[1] for p in parts]
+        rows, W = parts[0].shape[0], sum(ctx.widths)
+        out = torch.empty((rows, W), dtype=parts[0].dtype, device=parts[0].device)
+        srcs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        rb = (C.c_int64 * len(parts))(*[w * 2 for w in ctx.widths])
+        _lib.check(_lib.lib().catan_concat_rows(C.cast(srcs, C.c_void_p), C.cast(rb, C.c_void_p), len(parts), _ptr(out), W * 2, rows, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        out, c = [], 0
+        for w in ctx.widths:
+            out.append(dy[:, c:c + w]); c += w
+        return tuple(out)
+
+
+CONCAT_ROWS = True            # (A/B switch)
+
+
+def concat_rows(parts):
+    """torch.cat(parts, -1); on the GPU for 2..4 bf16 matrices of equal row count whose rows are whole 16-byte pieces: one kernel at the
+    HBM rate"""
+    if (CONCAT_ROWS and 2 <= len(parts) <= 4 and all(p.is_cuda and p.dim() == 2 and p.dtype == torch.bfloat16 and (p.shape[1] * 2) % 16 == 0
+                                                      and p.shape[0] == parts[0].shape[0] for p in parts) and parts[0].shape[0] > 0):
+        return _ConcatRows.apply(*parts)
+    return torch.cat(parts, -1)
+
+
 def _scatter_ranges(dy, perm, ranges, U, add0=None, add1=None):
     if dy.stride(1) != 1 or (dy.stride(0) * 2) % 16 or dy.data_ptr() % 16:
         dy = dy.contiguous()

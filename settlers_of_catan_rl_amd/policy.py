@@ -312,7 +312,7 @@ class _ObservationModule(nn.Module):
             # decides for these widths; the pad columns meet zero weights)
             w = self.final_layer.weight
             wp = torch.cat((w[:, :475], w.new_zeros((w.shape[0], te_pad)), w[:, 475:]), 1)
-            return _ln(self.norm, F.linear(torch.cat((te, cp, op.reshape(B, 3 * 128)), -1), wp, self.final_layer.bias), relu=True)
+            return _ln(self.norm, F.linear(nn_kernels.concat_rows((te, cp, op.reshape(B, 3 * 128))), wp, self.final_layer.bias), relu=True)
         return _ln(self.norm, _lin_parts((te, cp, op.reshape(B, 3 * 128)), self.final_layer.weight, self.final_layer.bias), relu=True)
 
 

@@ -40,6 +40,9 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "even" in err(L.catan_gather_rows(P(b16), 1024, P(idx), 8, P(b16), 1024, 7, st))
     assert "16-byte" in err(L.catan_expand_rows(P(b16), P(idx), 8, P(b16), 1000, st))
     assert "16-byte" in err(L.catan_segment_sum_rows(C.c_void_p(b16.data_ptr() + 2), 1024, P(idx), P(idx), 4, P(b16), 1024, st))
+    srcs2 = (C.c_void_p * 2)(b16.data_ptr(), b16.data_ptr() + 2); rb2 = (C.c_int64 * 2)(1024, 1024)
+    assert "16-byte" in err(L.catan_concat_rows(C.cast(srcs2, C.c_void_p), C.cast(rb2, C.c_void_p), 2, P(b16), 2048, 8, st))
+    assert "1..4 sources" in err(L.catan_concat_rows(C.cast(srcs2, C.c_void_p), C.cast(rb2, C.c_void_p), 5, P(b16), 2048, 8, st))
     rng3 = (C.c_int64 * 3)(0, 9, 0)
     assert "16 ranges" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 17, None, None, P(b16), 1024, st))
     assert "outside the permutation" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 1, None, None, P(b16), 1024, st))

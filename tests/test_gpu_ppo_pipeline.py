@@ -1205,6 +1205,23 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             assert d_f <= max(2.0 * d_u, 0.05), (B, n, d_f, d_u)
 
 
+def test_concat_rows_kernel(hip_lib):
+    """nn_kernels.concat_rows (catan_concat_rows) against torch.cat, values and gradients (the trunk input's 480 | 128 | 384 columns)."""
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows, widths in ((4099, (480, 128, 384)), (1, (8, 8)), (70001, (64, 8, 16, 40))):
+        parts = [torch.randn(rows, w, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True) for w in widths]
+        y = nn_kernels.concat_rows(parts)
+        assert type(y.grad_fn).__name__ == "_ConcatRowsBackward" and torch.equal(y, torch.cat(parts, -1))
+        dy = torch.randn_like(y)
+        gs = torch.autograd.grad(y, parts, dy)
+        c = 0
+        for w, gk in zip(widths, gs):
+            assert torch.equal(gk, dy[:, c:c + w]); c += w
+    odd = [torch.randn(5, 12, device="cuda").to(torch.bfloat16), torch.randn(5, 8, device="cuda").to(torch.bfloat16)]      # 24-byte rows: torch.cat
+    assert torch.equal(nn_kernels.concat_rows(odd), torch.cat(odd, -1))
+
+
 def test_gather_of_permutation_ranges_backward(hip_lib):
     """nn_kernels.gather_ranges (forward: the row gather; backward: catan_scatter_rows_ranges) against plain indexing under autograd:
     the heads' row lists are ranges of one permutation, a row sits in 0..3 of them.  Rows with one contribution are bit-equal; sums
