@@ -117,6 +117,59 @@ def live_pmc_traffic(kernel, timeout_s=180):
         shutil.rmtree(out, ignore_errors=True)
 
 
+# ---- the line is printed even when the run does not finish: whatever rank 0 has measured so far, with a `status`
+# that says how far it got and why it stopped.  A peer that dies makes torch.distributed.run SIGTERM the others: rank 0 prints then.
+PARTIAL = {"metric": "Catan env-steps/sec at 65k parallel games", "value": None, "unit": "env-steps/s", "status": "started", "stage": "start"}
+_EMITTED = [False]
+
+
+def emit(status=None):
+    if _EMITTED[0] or int(os.environ.get("RANK", "0")) != 0:
+        return
+    _EMITTED[0] = True
+    if status is not None:
+        PARTIAL["status"] = status
+    try:
+        from settlers_of_catan_rl_amd import dist as cdist
+        PARTIAL.setdefault("dist_init", cdist.INIT_REPORT)
+        if PARTIAL.get("status") != "ok":
+            PARTIAL.setdefault("rccl_log_rank0", cdist.rccl_log_tail())
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(PARTIAL) + "\n")
+    sys.stdout.flush()
+
+
+def stage(name):
+    PARTIAL["stage"] = name
+
+
+def _watch_sigterm():
+    """SIGTERM -> the line, even while the main thread sits inside a collective or a device synchronize (a Python-level handler
+    would only run once that call returns): the C-level handler writes the signal number to a pipe (signal.set_wakeup_fd), a
+    helper thread reads it and prints."""
+    import signal
+    import threading
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+    signal.signal(signal.SIGTERM, lambda signum, frame: None)
+
+    def watch():
+        while True:
+            b = os.read(r, 1)
+            if b and b[0] == signal.SIGTERM:
+                msg = (f"terminated by SIGTERM during stage '{PARTIAL.get('stage')}' (under torch.distributed.run: a peer rank failed or "
+                       f"the launcher timed out; the peer's traceback is on stderr)")
+                try:
+                    emit(msg)
+                except Exception:
+                    sys.stdout.write(json.dumps({"metric": PARTIAL.get("metric"), "value": PARTIAL.get("value"), "unit": "env-steps/s", "status": msg}) + "\n")
+                    sys.stdout.flush()
+                os._exit(1)
+    threading.Thread(target=watch, daemon=True, name="bench-sigterm").start()
+
+
 PREROLL_PASSES = 8192        # untimed deferred passes before --warmup: several game lengths, so that the games' ages are mixed
 MIN_TIMED_S = 0.30           # the timed region is `reps` x --steps passes, reps chosen so that it lasts at least this long
 
@@ -213,7 +266,11 @@ def main():
     from settlers_of_catan_rl_amd import dist as cdist
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     # backend "nccl" == RCCL over xGMI; CATAN_DIST_BACKEND=gloo lets two ranks share one GPU (smoke test of this code path)
+    stage("init_process_group + allreduce_selfcheck")
     rank, local_rank, world = cdist.init_from_env(backend=os.environ.get("CATAN_DIST_BACKEND") or None)
+    PARTIAL.update(n_gpus=world, steps=args.steps, warmup=args.warmup, world=world,
+                   backend=(torch.distributed.get_backend() if world > 1 else None), dist_init=cdist.INIT_REPORT)
+    stage("create env")
 
     from settlers_of_catan_rl_amd.env import VecCatanEnv
 
@@ -226,12 +283,14 @@ def main():
     # placement: every road goes through the longest-road slow path) is not the steady state.  Several game lengths of
     # deferred passes spread the games' ages; its duration also sizes the timed region.
     W = args.window if args.window > 0 else 32
+    stage("pre-roll")
     cdist.barrier()
     t0 = time.perf_counter()
     env.random_rollout_deferred(max(args.preroll, 64), W)
     cdist.barrier()
     pre_pass_s = cdist.max_over_ranks((time.perf_counter() - t0) / max(args.preroll, 64))
     step_idx = 1 << 20                                        # lock-step passes index the policy stream by a global step number
+    stage("timed region")
 
     if args.window > 0:
         reps = _reps_for(pre_pass_s, args.steps)
@@ -256,7 +315,12 @@ def main():
         env_steps = world * my_steps
     timed_passes = args.steps * reps
     bad = env.invalid_action_count()
+    PARTIAL.update(value=env_steps / dt, ms_per_step=dt / timed_passes * 1e3, timed_s=dt, timed_passes=timed_passes, higher_is_better=True,
+                   scaling="weak", env_steps_executed=env_steps, invalid_actions=bad, status="timed region done; later stages incomplete")
+    stage("device identities (all_gather_object)")
     devices = cdist.device_identities()                       # (a collective: every rank calls it)
+    PARTIAL["ranks"] = devices
+    stage("lock-step / step_api measurements")
 
     lockstep = None
     if args.window > 0 and not args.no_lockstep:
@@ -322,7 +386,9 @@ def main():
     step_idx += 512
     ppo = None
     if args.ppo_steps > 0:
+        stage("ppo_update (3 rollouts + PPO updates with the gradient all-reduce)")
         ppo = ppo_update_record(env, n, rank, world, args.ppo_steps, cdist)
+    stage("assembling the line")
     if ppo is not None and rank != 0:
         ppo.pop("roofline_learner", None)
     if rank == 0:
@@ -413,11 +479,25 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
-    if world > 1:
-        cdist.finalize()
     if rank == 0:
-        print(json.dumps(out))
+        out["status"] = "ok"
+        out["dist_init"] = cdist.INIT_REPORT
+        PARTIAL.clear(); PARTIAL.update(out)
+        emit()                                               # (before the final barrier: a peer that hangs there cannot take the line with it)
+    if world > 1:
+        stage("finalize")
+        cdist.finalize()
 
 
 if __name__ == "__main__":
-    main()
+    if int(os.environ.get("RANK", "0")) == 0:
+        _watch_sigterm()
+    try:
+        main()
+    except BaseException as e:
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        emit(f"failed during stage '{PARTIAL.get('stage')}': {type(e).__name__}: {str(e)[:600]}")
+        os._exit(1)

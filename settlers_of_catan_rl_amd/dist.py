@@ -12,20 +12,168 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device_index=None):
-    """Reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world)."""
+INIT_REPORT = {"attempts": [], "backend": None, "selfcheck": None}     # what init_from_env did (bench.py copies it into its line)
+_side_store = None
+
+
+def _rccl_log_path():
+    return os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", __import__("socket").gethostname()).replace("%p", str(os.getpid()))
+
+
+def rccl_log_tail(max_bytes=1500):
+    """The tail of this rank's RCCL log (NCCL_DEBUG=WARN into NCCL_DEBUG_FILE, set by init_from_env): '' when RCCL had nothing to say."""
+    path = _rccl_log_path()
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+        return blob[-max_bytes:].decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def _agreement_store(rank, world, timeout_s):
+    """A TCPStore of our own next to the rendezvous one (MASTER_PORT + 23, or CATAN_SIDE_PORT): the ranks tell each other how an
+    init attempt went WITHOUT a collective, so that all of them move to the next attempt together."""
+    global _side_store
+    if _side_store is None:
+        from datetime import timedelta
+        port = int(os.environ.get("CATAN_SIDE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 23))
+        _side_store = dist.TCPStore(os.environ["MASTER_ADDR"], port, world, is_master=(rank == 0), timeout=timedelta(seconds=timeout_s),
+                                    wait_for_workers=False)
+    return _side_store
+
+
+def _agree(store, tag, rank, world, ok, msg, timeout_s):
+    """-> (every rank said ok, [(rank, what it said) for the others])"""
+    from datetime import timedelta
+    if store is None:
+        return ok, ([] if ok else [(rank, msg)])
+    store.set(f"{tag}/{rank}", "ok" if ok else ("fail: " + msg)[:400])
+    keys = [f"{tag}/{r}" for r in range(world)]
+    try:
+        store.wait(keys, timedelta(seconds=timeout_s))
+    except Exception as e:
+        return False, [(-1, f"no word from some rank within {timeout_s:.0f} s ({type(e).__name__})")]
+    said = [(r, store.get(k).decode("utf-8", "replace")) for r, k in enumerate(keys)]
+    bad = [(r, v) for r, v in said if v != "ok"]
+    return not bad, bad
+
+
+def allreduce_selfcheck(timeout_s=60.0, device=None):
+    """Before anything is timed: the collectives the learner uses, on tiny inputs whose results are known - the SUM of (rank + 1),
+    the mean of a vector filled with the rank through allreduce_mean_ (ReduceOp.AVG on RCCL), and an all-gather of the ranks.  A
+    wrong result or a collective that does not finish within `timeout_s` raises.  -> dict for the bench line."""
+    import time
+    from datetime import timedelta
+    w, r = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    t0 = time.perf_counter()
+
+    def finish(work, what):
+        if work is not None and not work.wait(timedelta(seconds=timeout_s)):
+            raise RuntimeError(f"selfcheck: {what} did not complete")
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    a = torch.full((8,), float(r + 1), dtype=torch.float32, device=device)
+    finish(dist.all_reduce(a, async_op=True), "all_reduce(SUM)")
+    if not bool((a == w * (w + 1) / 2.0).all()):
+        raise RuntimeError(f"selfcheck: all_reduce(SUM) of rank + 1 gave {a.tolist()} on rank {r}, expected {w * (w + 1) / 2.0}")
+    b = torch.full((1024,), float(r), dtype=torch.float32, device=device)
+    allreduce_mean_(b)
+    finish(None, "all_reduce(AVG)")
+    if not bool(((b - (w - 1) / 2.0).abs() < 1e-6).all()):
+        raise RuntimeError(f"selfcheck: mean over ranks gave {float(b[0])} on rank {r}, expected {(w - 1) / 2.0}")
+    g = [torch.zeros((2,), dtype=torch.int64, device=device) for _ in range(w)]
+    finish(dist.all_gather(g, torch.tensor([r, 7 * r + 1], dtype=torch.int64, device=device), async_op=True), "all_gather")
+    if [int(x[0]) for x in g] != list(range(w)) or any(int(x[1]) != 7 * i + 1 for i, x in enumerate(g)):
+        raise RuntimeError(f"selfcheck: all_gather gave {[x.tolist() for x in g]} on rank {r}")
+    return {"ok": True, "world": w, "backend": dist.get_backend(), "device": str(device), "seconds": time.perf_counter() - t0,
+            "checked": ["all_reduce SUM of rank + 1", "allreduce_mean_ (ReduceOp.AVG on RCCL) of rank", "all_gather of ranks"]}
+
+
+def _drop_process_group():
+    if dist.is_initialized():
+        for name in ("_abort_process_group",):               # (a communicator that failed half-way may not destroy cleanly)
+            fn = getattr(dist.distributed_c10d, name, None)
+            if fn is not None:
+                try:
+                    fn()
+                    return
+                except Exception:
+                    pass
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+_attempt_hook = None          # tests: called as hook(attempt_number, rank) right after init_process_group of an attempt; may raise
+
+
+def init_from_env(backend=None, device_index=None, timeout_s=None, selfcheck=True, plan=None):
+    """Reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world).
+
+    The first multi-GPU run cannot be rehearsed on a one-GPU box, so it must not be able to fail silently: an attempt is
+    init_process_group with a `timeout_s` time-out (CATAN_DIST_TIMEOUT_S, default 120) followed by `allreduce_selfcheck`; the ranks
+    tell each other over a side TCPStore how it went (no collective), and if ANY of them failed all of them drop the group and take
+    the next attempt together: "nccl" (= RCCL) bound eagerly to this rank's device -> "nccl" without `device_id` (lazy communicator)
+    -> "gloo" (host-staged: slow but it yields a line that says so).  An explicit `backend` is tried alone.  What happened is in
+    INIT_REPORT; RCCL's warnings go to a per-rank file (`rccl_log_tail`)."""
+    from datetime import timedelta
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
-        kw = {}
-        if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank if device_index is None else device_index)
-        dist.init_process_group(backend, **kw)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/catan_rccl_%h_%p.log")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("CATAN_DIST_TIMEOUT_S", "120"))
+        have_gpu = torch.cuda.is_available()
+        dev = torch.device("cuda", local_rank if device_index is None else device_index) if have_gpu else None
+        if plan is not None:
+            plan = [(be, dev if (bind and be == "nccl") else None) for be, bind in plan]     # [(backend, bind to the device eagerly)]
+        elif backend is not None:
+            plan = [(backend, dev if backend == "nccl" else None)]
+        elif have_gpu:
+            plan = [("nccl", dev), ("nccl", None), ("gloo", None)]   # "nccl" is RCCL on ROCm
+        else:
+            plan = [("gloo", None)]
+        store = None
+        if len(plan) > 1 or selfcheck:
+            try:
+                store = _agreement_store(rank, world, timeout_s)
+            except Exception as e:                                   # no side store: a single attempt, errors propagate
+                INIT_REPORT["attempts"].append({"side_store": f"unavailable ({type(e).__name__}: {e})"})
+                plan = plan[:1]
+        for k, (be, device_id) in enumerate(plan):
+            rec = {"backend": be, "device_id": None if device_id is None else str(device_id), "timeout_s": timeout_s}
+            ok, msg, chk = True, "", None
+            try:
+                kw = {"timeout": timedelta(seconds=timeout_s)}
+                if device_id is not None:
+                    kw["device_id"] = device_id
+                if store is not None:          # every attempt rendezvouses over the side store under its own prefix: a second attempt
+                    kw.update(store=dist.PrefixStore(f"catan/pg/{k}", store), rank=rank, world_size=world)   # never meets the first one's keys or server
+                dist.init_process_group(be, **kw)
+                if _attempt_hook is not None:
+                    _attempt_hook(k, rank)
+                if selfcheck:
+                    chk = allreduce_selfcheck(min(timeout_s, 60.0))
+            except Exception as e:
+                ok, msg = False, f"{type(e).__name__}: {e}"
+            all_ok, bad = _agree(store, f"catan/init/{k}", rank, world, ok, msg, timeout_s + 90.0)
+            rec.update(ok=all_ok, this_rank=("ok" if ok else msg[:400]), failing_ranks=[(r, v[:200]) for r, v in bad][:8])
+            INIT_REPORT["attempts"].append(rec)
+            if all_ok:
+                INIT_REPORT.update(backend=be, selfcheck=chk)
+                break
+            _drop_process_group()
+        else:
+            raise RuntimeError(f"no collective backend came up on {world} ranks: {INIT_REPORT['attempts']}")
     return rank, local_rank, world
 
 
@@ -88,6 +236,7 @@ def device_identities():
                 pass
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return [me]
+    me["rccl_log"] = rccl_log_tail(600)          # NCCL_DEBUG=WARN output of this rank so far ('' = nothing to report)
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, me)
     return out

@@ -86,3 +86,44 @@ def test_n_rank_sharding_and_reductions(world):
     for i, g in enumerate(out["grads"]):
         assert np.allclose(g, np.mean([r + 1 + i for r in range(world)]))
     assert out["tmax"] == float(world) and out["tsum"] == world * (world + 1) / 2.0
+
+
+def _init_worker(rank, world, port, q, fail_rank):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CATAN_DIST_TIMEOUT_S="15")
+    sys.path.insert(0, ROOT)
+    from settlers_of_catan_rl_amd import dist as cdist
+
+    def hook(attempt, r):                       # the first attempt "fails" on ONE rank only: the others must follow it to the second
+        if attempt == 0 and r == fail_rank:
+            raise RuntimeError("simulated communicator failure")
+    cdist._attempt_hook = hook
+    r, lr, w = cdist.init_from_env(plan=[("gloo", False), ("gloo", False)])
+    rep = cdist.INIT_REPORT
+    again = cdist.allreduce_selfcheck(timeout_s=30.0)
+    t = torch.tensor([float(r)])
+    cdist.allreduce_mean_(t)
+    q.put((rank, [a.get("ok") for a in rep["attempts"]], rep["attempts"][0]["failing_ranks"], rep["selfcheck"]["ok"], again["ok"], float(t)))
+    cdist.finalize()
+
+
+def test_init_retries_on_every_rank_when_one_rank_fails_and_selfcheck_runs():
+    """an init attempt that fails on ONE rank makes ALL ranks drop the group and take the next attempt (agreed over
+    the side TCPStore, no collective), the self-check (SUM / mean / all-gather with known results) runs before anything is timed, and
+    INIT_REPORT says what happened."""
+    world, fail_rank = 3, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, oks, failing, chk_ok, again_ok, mean in got:
+        assert oks == [False, True], (rank, oks)
+        said = dict((f[0], f[1]) for f in failing)       # (the other ranks' self-check timed out waiting for the failed one: they report too)
+        assert "simulated" in said[fail_rank], said
+        assert chk_ok and again_ok and abs(mean - (world - 1) / 2.0) < 1e-9

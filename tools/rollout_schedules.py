@@ -9,12 +9,23 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd.policy import CatanPolicy
 from settlers_of_catan_rl_amd.rollout import RolloutCollector
 
+if os.environ.get("CATAN_NO_BRANCHES"):       # the policy pass captured as ONE chain (no forked streams inside the hipGraph)
+    from settlers_of_catan_rl_amd import policy as _pol
+    _pol._Branches.enabled = False
 N = int(os.environ.get("GAMES", "65536")); T = int(os.environ.get("T", "200"))
 torch.manual_seed(0)
 net = CatanPolicy().cuda()
-configs = [("all games, catan_step", dict(act_buckets=(N,))), ("halving buckets, catan_step", dict(act_buckets=tuple(N >> k for k in range(5)))), ("buckets, catan_step", dict()),
+H = tuple(N >> k for k in range(5))
+configs = [("all games, catan_step", dict(act_buckets=(N,), deferred_window=0)), ("halving buckets, catan_step", dict(act_buckets=H, deferred_window=0)),
+           ("buckets, catan_step", dict(deferred_window=0)),
            ("buckets, deferred W=4", dict(deferred_window=4)), ("buckets, deferred W=8", dict(deferred_window=8)),
            ("buckets, deferred W=2", dict(deferred_window=2))]
+if os.environ.get("ASWAS"):      # round 4's keyword arguments (its first three lines ran the default deferred_window = 4 under a "catan_step" label)
+    configs = [("all games, W=4 (r4 label: catan_step)", dict(act_buckets=(N,))), ("halving buckets, W=4 (r4 label: catan_step)", dict(act_buckets=H)),
+               ("buckets, W=4 (r4 label: catan_step)", dict())] + configs[3:]
+if os.environ.get("CONFIGS"):    # e.g. CONFIGS=2,2,2,3: which of them, in which order
+    configs = [configs[int(i)] for i in os.environ["CONFIGS"].split(",")]
+GATHERS = int(os.environ.get("GATHERS", "3"))
 only = os.environ.get("ONLY")
 for name, kw in configs:
     if only and only not in name:
@@ -23,7 +34,7 @@ for name, kw in configs:
     env.random_rollout(0, 600)
     col = RolloutCollector(env, net, T, seed=0, autocast_dtype=torch.bfloat16, **kw)
     out = []
-    for u in range(3):
+    for u in range(GATHERS):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         st = col.gather_rollouts()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
