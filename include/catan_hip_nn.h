@@ -37,6 +37,13 @@ int catan_ffn_bwd(const void* dx, const void* h, const void* x, const void* n, c
 int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const void* n, const void* w2t, const void* w1t, const float* ln_w, const float* ln_b, float eps,
                           void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
                           const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream);
+/* catan_ffn_outproj_bwd with the FFN's hidden activation RECOMPUTED instead of read: h = relu(LayerNorm(x) w1^T + b1) from the rows of x
+ * the pass stages anyway (w1 bf16 [128][64] row-major and b1 float [128], as the forward kernel reads them: the W1 block / b1 slice of
+ * catan_tile_encoder_fwd's packed parameters), so the training forward need not store h (catan_te_saves_t.h[l] = NULL).  The LayerNorm
+ * output is always recomputed (ln_b required). */
+int catan_ffn_outproj_bwd_rh(const void* dx, const void* x, const void* w2t, const void* w1t, const void* w1, const float* b1, const float* ln_w, const float* ln_b, float eps,
+                             void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+                             const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream);
 /* The attention sub-layer's input side x_mid = x + out_proj(attention(qkv(LayerNorm(x)))) (width 64): the gradient of x from dqkv
  * [rows][192] (catan_attention_bwd's output) - (dqkv . Wqkv) through the LayerNorm backward, plus the residual gradient dres = d(x_mid)
  * [rows][64] - in one pass.  wt = Wqkv^T bf16 [64][192]; x [rows][64] = the LayerNorm's input; dln_w / dln_b float [64] ACCUMULATED into. */
@@ -53,6 +60,20 @@ typedef struct catan_weight_image {
 } catan_weight_image_t;
 int32_t catan_weight_image_bytes(void);
 int catan_weight_images(const void* table, int32_t n, catan_stream_t stream);
+
+/* The optimiser step of PPO.update - `nn.utils.clip_grad_norm_(parameters, max_grad_norm)` then `optim.Adam.step()` (RL/ppo/ppo.py:23,
+ * 67-68) - over all parameters in two launches (sum of squared gradients per chunk; norm, clip coefficient and Adam update per chunk).
+ * tensors: n_tensors rows {p, m, v} ON THE DEVICE (fp32, 16-byte aligned); chunks: n_chunks rows ON THE DEVICE, chunk i = elements
+ * [offset, offset + count) of tensor `tensor`, count <= catan_adam_chunk_elements(), offset a multiple of 4; grads: n_tensors device
+ * pointers ON THE DEVICE (this step's gradient of every tensor; null = the tensor takes no step, as torch skips a parameter without
+ * gradient); partial: n_chunks doubles of scratch.  max_norm <= 0: no clipping.  bias_correction1 = 1 - beta1^t, bias_correction2_sqrt
+ * = sqrt(1 - beta2^t) for the step number t (computed by the caller in double, as torch does on the host).  norm_out (may be null):
+ * the total gradient norm before clipping.  Deterministic: the partial sums are added in index order. */
+typedef struct catan_adam_tensor { float* p; float* m; float* v; } catan_adam_tensor_t;
+typedef struct catan_adam_chunk { int32_t tensor; int32_t count; int64_t offset; } catan_adam_chunk_t;
+int32_t catan_adam_chunk_elements(void);
+int catan_adam_step(const void* tensors, const void* chunks, int32_t n_chunks, const void* grads, void* partial, float max_norm, float lr, float beta1,
+                    float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, float* norm_out, catan_stream_t stream);
 
 /* catan_qkv_bwd_dx AND the QKV product's weight gradient in one pass (k_qkv_bwd_w): additionally n [rows][64] = LayerNorm 1's output,
  * or n = NULL and ln_b = the LayerNorm's bias (n recomputed from x, as catan_ffn_bwd); dw float [192][64] and db [192] are
@@ -186,7 +207,7 @@ typedef struct catan_te_saves {
     void* o[2];         /* [64]  attention output */
     void* xmid[2];      /* [64]  residual stream after the attention sub-layer */
     void* n2[2];        /* [64]  LayerNorm 2 output; may be NULL: catan_ffn_bwd / catan_ffn_outproj_bwd recompute it from xmid */
-    void* h[2];         /* [128] relu(linear1) */
+    void* h[2];         /* [128] relu(linear1); may be NULL: catan_ffn_outproj_bwd_rh recomputes it */
     void* xfin;         /* [64]  last layer's output */
     void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */
 } catan_te_saves_t;

@@ -48,6 +48,9 @@ int catan_profile_read(catan_env_t* env, uint64_t* out16);
  * launch; out: HOST uint32 [ceil(n/256)*4 + 17][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = sort bin + 1: bins
  * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort) */
 int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
+/* catan_profile_enable(env, 3): as 2, but slot 2 = the wave's START time (low 32 bits of the 100 MHz wall clock at entry; the
+ * phases 0, 1, 6, 7 follow it back to back) and slot 3 = where the wave ran (HW_REG_HW_ID bits 0..27 | HW_REG_XCC_ID << 28):
+ * the launch's timeline - dispatch ramp, waves that share a SIMD, the tail (tools/step_timeline.py). */
 
 /* Algorithmic HBM bytes of one fused env step per stepped game, from the static_assert-ed layout constants of csrc/catan_state.h
  * (action row in, hot record in, masks + reward + done out, the ideal write-back): bench.py's roofline numerator. */

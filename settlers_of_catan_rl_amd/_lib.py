@@ -123,10 +123,13 @@ _SIGS = {
     "catan_ffn_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_ffn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_ffn_outproj_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_ffn_outproj_bwd_rh": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_qkv_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_qkv_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_weight_image_bytes": (C.c_int32, []),
     "catan_weight_images": (C.c_int, [_vp, C.c_int32, _vp]),
+    "catan_adam_chunk_elements": (C.c_int32, []),
+    "catan_adam_step": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "catan_gather_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp]),
     "catan_expand_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "catan_segment_sum_rows": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),

@@ -19,6 +19,7 @@
 #include "catan_collector.hip"
 #include "catan_rows.hip"
 #include "catan_te_bwd.hip"
+#include "catan_optim.hip"
 
 using namespace catan;
 
@@ -462,7 +463,8 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.annealing = e->cfg.reward_annealing_factor; sc.lim = limits_of(e); sc.auto_reset = e->cfg.auto_reset;
     sc.reward64 = e->reward64;
     sc.prof = e->prof_on ? e->prof : nullptr;
-    sc.prof_wave = e->prof_on == 2 ? e->prof_wave : nullptr;
+    sc.prof_wave = e->prof_on >= 2 ? e->prof_wave : nullptr;
+    sc.prof_timeline = e->prof_on == 3;
     return sc;
 }
 // One env step = the games listed by action type (k_sample_random / k_classify), then k_step (fused: apply + done/reward +
@@ -512,7 +514,7 @@ static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
     hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
-                       sc.prof && e->prof_on != 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
+                       sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -1341,6 +1343,19 @@ int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const vo
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int32_t catan_adam_chunk_elements(void) { return OPT_CHUNK; }
+int catan_adam_step(const void* tensors, const void* chunks, int32_t n_chunks, const void* grads, void* partial, float max_norm, float lr, float beta1,
+                    float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, float* norm_out, catan_stream_t stream) {
+    static_assert(sizeof(AdamTensor) == sizeof(catan_adam_tensor_t) && sizeof(AdamChunk) == sizeof(catan_adam_chunk_t), "the header's structs are the kernels'");
+    if (!tensors || !chunks || !grads || !partial || n_chunks <= 0 || !(bias_correction1 > 0.f) || !(bias_correction2_sqrt > 0.f))
+        return fail(CATAN_EINVAL, "catan_adam_step: bad arguments");
+    AdamHyper h = { max_norm, lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt, max_norm > 0.f ? 1 : 0 };
+    hipLaunchKernelGGL(k_grad_sumsq, dim3((unsigned)n_chunks), dim3(OPT_BLOCK), 0, S(stream), (const AdamChunk*)chunks, (const float* const*)grads, (double*)partial);
+    hipLaunchKernelGGL(k_adam_step, dim3((unsigned)n_chunks), dim3(OPT_BLOCK), 0, S(stream), (const AdamTensor*)tensors, (const AdamChunk*)chunks, (int)n_chunks,
+                       (const float* const*)grads, (const double*)partial, h, norm_out);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int32_t catan_weight_image_bytes(void) { return (int32_t)sizeof(WeightImage); }
 int catan_weight_images(const void* table, int32_t n, catan_stream_t stream) {
     if (!table || n <= 0) return fail(CATAN_EINVAL, "catan_weight_images: bad arguments");
@@ -1386,6 +1401,24 @@ int catan_ffn_outproj_bwd(const void* dx, const void* h, const void* x, const vo
     else hipLaunchKernelGGL((k_ffn_bwd_w<true, true>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)h, (const unsigned short*)x,
                        (const unsigned short*)n, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
                        dln_w, dln_b, (long)rows, per, op);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_ffn_outproj_bwd_rh(const void* dx, const void* x, const void* w2t, const void* w1t, const void* w1, const float* b1, const float* ln_w, const float* ln_b, float eps,
+                             void* dx_out, float* dw2, float* db2, float* dw1, float* db1, float* dln_w, float* dln_b,
+                             const void* o, const void* wot, void* d_o, float* dwo, float* dbo, int64_t rows, catan_stream_t stream) {
+    if (!dx || !x || !w2t || !w1t || !w1 || !b1 || !ln_w || !ln_b || !dx_out || !dw2 || !db2 || !dw1 || !db1 || !dln_w || !dln_b || !o || !wot || !d_o || !dwo || !dbo || rows <= 0 ||
+        (((uintptr_t)dx | (uintptr_t)x | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)w1 | (uintptr_t)dx_out | (uintptr_t)o | (uintptr_t)wot | (uintptr_t)d_o) & 15))
+        return fail(CATAN_EINVAL, "catan_ffn_outproj_bwd_rh: null or misaligned argument");
+    const long stages = (rows + FW_ROWS - 1) / FW_ROWS;
+    long nb = stages / 16 < 1 ? 1 : (stages / 16 < 512 ? stages / 16 : 512);
+    const long per = (stages + nb - 1) / nb * FW_ROWS;
+    nb = (rows + per - 1) / per;
+    FfnOutProj op = { (const unsigned short*)o, (const unsigned short*)wot, (unsigned short*)d_o, dwo, dbo };
+    FfnRecomputeH rh = { (const unsigned short*)w1, b1 };
+    hipLaunchKernelGGL((k_ffn_bwd_w<true, true, true>), dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dx, (const unsigned short*)nullptr, (const unsigned short*)x,
+                       (const unsigned short*)nullptr, (const unsigned short*)w2t, (const unsigned short*)w1t, ln_w, ln_b, eps, (unsigned short*)dx_out, dw2, db2, dw1, db1,
+                       dln_w, dln_b, (long)rows, per, op, rh);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
@@ -1575,9 +1608,10 @@ int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const f
     const void* const* ptrs = reinterpret_cast<const void* const*>(saves);
     for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++) {
         const bool optional = (i >= offsetof(TeSaves, n1) / sizeof(void*) && i < offsetof(TeSaves, n1) / sizeof(void*) + 2) ||
-                              (i >= offsetof(TeSaves, n2) / sizeof(void*) && i < offsetof(TeSaves, n2) / sizeof(void*) + 2);
+                              (i >= offsetof(TeSaves, n2) / sizeof(void*) && i < offsetof(TeSaves, n2) / sizeof(void*) + 2) ||
+                              (i >= offsetof(TeSaves, h) / sizeof(void*) && i < offsetof(TeSaves, h) / sizeof(void*) + 2);
         if ((!ptrs[i] && !optional) || ((uintptr_t)ptrs[i] & 15))
-            return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer but n1 / n2 must be set, all 16-byte aligned");
+            return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer but n1 / n2 / h must be set, all 16-byte aligned");
     }
     TeSaves sv;
     memcpy(&sv, saves, sizeof sv);

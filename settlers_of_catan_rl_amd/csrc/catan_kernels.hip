@@ -1654,7 +1654,9 @@ DEVI void update_largest_army(const S& s) {
 struct StepCfg { int validate; int dense_reward; double win_reward; double annealing; Limits lim; int auto_reset;
                  double* reward64;              // optional unrounded rewards [n][4] (catan_set_reward_f64_buffer)
                  unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
-                 u32* prof_wave; };             // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
+                 u32* prof_wave;                // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
+                 int prof_timeline; };          // ... with slot 2 = the wave's START (low 32 bits of the 100 MHz wall clock) and slot 3 = where it ran
+                                                //     (HW_ID | XCC_ID << 28) instead of the request-push time and the validate / switch split
 constexpr int LRF_PROF_ROW = 1088, LRF_PROF_ROWS = 2000;   // k_lr_finish's rows of the per-wave buffer ((N / 16 + SORT_PAD_WAVES) rows)
 constexpr int LRH_PROF_ROW = 3088, LRH_PROF_ROWS = 1000;   // k_lr_heavy's: one row per workgroup (its first request)
 constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
@@ -1664,7 +1666,7 @@ constexpr int PROF_WORDS = PROF_TOTAL + 42;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     if (cfg.prof_wave != nullptr) {                 // contention-free variant (k_step only): one slot per wave and phase
         const long long t = wall_clock64();
-        if ((threadIdx.x & 63) == 0) cfg.prof_wave[(long)blockIdx.x * 8 + phase] = (u32)(t - t_prev);
+        if ((threadIdx.x & 63) == 0 && !(cfg.prof_timeline && phase == 2)) cfg.prof_wave[(long)blockIdx.x * 8 + phase] = (u32)(t - t_prev);
         t_prev = wall_clock64();
         return;
     }
@@ -1919,6 +1921,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int rnk = first + lane;
     const long e = (lane < G && rnk < cnt) ? (long)pend.lists[((long)pend.bsel * NBINS + bin) * c.N + rnk] : 0x7fffffffL;
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
+    if (cfg.prof_wave != nullptr && cfg.prof_timeline && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 2] = (u32)tprof;
     const bool live = e < c.n;
     // the last bin = explicit no-op (negative type: frozen game) or a busy game (the sampler gives those the no-op): none
     // of them touches its record
@@ -2339,6 +2342,12 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     if constexpr (SAMPLE) stage_out_row<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new, an, dctr);
     else stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     prof_mark(cfg, 7, tprof);
+    if (cfg.prof_wave != nullptr && cfg.prof_timeline) {
+        u32 hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 3] = (hw & 0x0FFFFFFFu) | ((xcc & 15u) << 28);
+    }
 }
 
 constexpr u64 LR_GAME_MASK = (1ull << 40) - 1;             // request: game | new edge (127: none) << 40 | pid0 << 56

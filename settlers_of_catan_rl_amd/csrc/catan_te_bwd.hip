@@ -373,6 +373,35 @@ DEVI void fw_ln_bwd_token(unsigned short* xs, const unsigned short* rs, unsigned
         *reinterpret_cast<uint2*>(xs + fw_off(row, 16 * t + 4 * g)) = make_uint2((unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16));
     }
 }
+// LayerNorm FORWARD of one token per lane in the same layout (RH: the FFN's input N is needed before the chain starts, to recompute
+// H = relu(N W1^T + b1)): N = ((x - mean) rstd) w + b rounded to bf16 as the forward kernel's te_layer_norm stores it; a dead row gives 0.
+DEVI void fw_ln_fwd_token(const unsigned short* xs, unsigned short* ns, int row, int g, bool live, const float (&wl)[4][4], const float (&bl)[4][4], float eps) {
+    float xv[4][4], sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint2 ux = *reinterpret_cast<const uint2*>(xs + fw_off(row, 16 * t + 4 * g));
+        xv[t][0] = __uint_as_float(ux.x << 16); xv[t][1] = __uint_as_float(ux.x & 0xFFFF0000u);
+        xv[t][2] = __uint_as_float(ux.y << 16); xv[t][3] = __uint_as_float(ux.y & 0xFFFF0000u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) sum += xv[t][i];
+    }
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / 64.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xv[t][i] -= mean; sq += xv[t][i] * xv[t][i]; }
+    sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) y[i] = live ? xv[t][i] * rstd * wl[t][i] + bl[t][i] : 0.f;
+        *reinterpret_cast<uint2*>(ns + fw_off(row, 16 * t + 4 * g)) = make_uint2(pk_bf(y[0], y[1]), pk_bf(y[2], y[3]));
+    }
+}
 // the LayerNorm weight / bias gradients of that layout: summed over the 16 token lanes, one LDS atomic per column and wave
 DEVI void fw_ln_grads_out(float (&aw)[4][4], float (&ab)[4][4], float (*sG)[64], int lr, int g) {
 #pragma unroll
@@ -392,12 +421,20 @@ struct FfnOutProj { const unsigned short* o; const unsigned short* wot; unsigned
 // RN: N is not read but recomputed from X (LayerNorm weight lnw, bias lnb: the forward's formula on the statistics the LayerNorm
 // backward forms anyway), so the training forward need not store it: 128 of the 896 bytes per token row this pass read, and 128 of
 // the 1 280 the forward wrote per row and layer.
-template <bool OP, bool RN>
+// RH: H is not read either but recomputed - H = relu(N W1^T + b1) from the recomputed N, one more 16 x 64 x 128 product per wave and
+// stage (w1 = W1 [128][64] row-major as the forward reads it, b1 [128] as the forward adds it) - so the training forward need not
+// store its widest activation: 256 of the 1 024 bytes per token and layer it wrote, and 256 of the 768 this pass read.
+struct FfnRecomputeH { const unsigned short* w1; const float* b1; };
+template <bool OP, bool RN, bool RH = false>
 __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restrict__ dx, const unsigned short* __restrict__ h, const unsigned short* __restrict__ x,
                                                    const unsigned short* __restrict__ n2, const unsigned short* __restrict__ w2t, const unsigned short* __restrict__ w1t,
                                                    const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, unsigned short* __restrict__ dxo,
                                                    float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dw1, float* __restrict__ db1,
-                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block, FfnOutProj op) {
+                                                   float* __restrict__ dlnw, float* __restrict__ dlnb, long rows, long rows_per_block, FfnOutProj op,
+                                                   FfnRecomputeH rh = FfnRecomputeH{nullptr, nullptr}) {
+    static_assert(!RH || RN, "H is recomputed from the recomputed N");
+    __shared__ __attribute__((aligned(16))) unsigned short sW1n[RH ? 128 * FB_P : 8];   // W1 [128][64] (RH)
+    __shared__ __attribute__((aligned(16))) float sB1[RH ? 128 : 4];
     __shared__ __attribute__((aligned(16))) unsigned short sDX[FW_IMG64];      // dX; the rows of dX' replace X below
     __shared__ __attribute__((aligned(16))) unsigned short sX[FW_IMG64];
     __shared__ __attribute__((aligned(16))) unsigned short sH[FW_IMG129];      // H and the column of ones
@@ -419,6 +456,10 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     }
     for (int c = tid; c < 128 * 8; c += 256) { const int n = c >> 3, ch = c & 7; *reinterpret_cast<uint4*>(sW2 + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(w2t + n * 64 + ch * 8); }
     for (int c = tid; c < 64 * 16; c += 256) { const int n = c >> 4, ch = c & 15; *reinterpret_cast<uint4*>(sW1 + n * FB_P1 + ch * 8) = *reinterpret_cast<const uint4*>(w1t + n * 128 + ch * 8); }
+    if (RH) {
+        for (int c = tid; c < 128 * 8; c += 256) { const int n = c >> 3, ch = c & 7; *reinterpret_cast<uint4*>(sW1n + n * FB_P + ch * 8) = *reinterpret_cast<const uint4*>(rh.w1 + n * 64 + ch * 8); }
+        if (tid < 128) sB1[tid] = rh.b1[tid];
+    }
     for (int c = tid; c < FW_IMG129; c += 256) sH[c] = 0;                        // (the ones columns' tiles: everything but column 0 stays zero)
     for (int c = tid; c < FW_IMG65; c += 256) sN[c] = 0;
     float wl[4][4], bl[4][4], aw[4][4], ab[4][4];
@@ -441,14 +482,14 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
     wg_load<2>(dx, r_begin * 64, rows * 64, 64, vdx, tid);
     wg_load<2>(x, r_begin * 64, rows * 64, 64, vx, tid);
     if (!RN) wg_load<2>(n2, r_begin * 64, rows * 64, 64, vn, tid);
-    wg_load<4>(h, r_begin * 128, rows * 128, 128, vh, tid);
+    if (!RH) wg_load<4>(h, r_begin * 128, rows * 128, 128, vh, tid);
     __syncthreads();
     const int row = 16 * wave + lr;                                             // this lane's token row of the stage (operand layout)
     for (long r0 = r_begin; r0 < r_end; r0 += FW_ROWS) {
         wg_store_rows<2>(sDX, 64, vdx, tid);
         wg_store_rows<2>(sX, 64, vx, tid);
         if (!RN) wg_store_rows<2>(sN, 64, vn, tid);
-        wg_store_rows<4>(sH, 128, vh, tid);
+        if (!RH) wg_store_rows<4>(sH, 128, vh, tid);
         if (OP) wg_store_rows<2>(sO, 64, vo, tid);
         if (tid < FW_ROWS) {
             const unsigned short one = (r0 + tid < r_end) ? (unsigned short)0x3F80 : (unsigned short)0;   // bf16 1.0: the bias columns
@@ -461,7 +502,28 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             wg_load<2>(dx, (r0 + FW_ROWS) * 64, rows * 64, 64, vdx, tid);
             wg_load<2>(x, (r0 + FW_ROWS) * 64, rows * 64, 64, vx, tid);
             if (!RN) wg_load<2>(n2, (r0 + FW_ROWS) * 64, rows * 64, 64, vn, tid);
-            wg_load<4>(h, (r0 + FW_ROWS) * 128, rows * 128, 128, vh, tid);
+            if (!RH) wg_load<4>(h, (r0 + FW_ROWS) * 128, rows * 128, 128, vh, tid);
+        }
+        uint2 hreg[8];
+        if (RH) {
+            // ---- N = LayerNorm(X) for this wave's 16 rows, then H^T = W1 . N^T + b1, ReLU: transposed product, so the lane ends up with
+            //      H[token `row`][16 j + 4 g + i] - the positions whose dH it forms below - and writes them into the H image for dW2
+            fw_ln_fwd_token(sX, sN, row, g, r0 + row < r_end, wl, bl, eps);
+            __builtin_amdgcn_wave_barrier();
+            bf16x8_t nb[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) nb[s] = *reinterpret_cast<const bf16x8_t*>(sN + fw_off(row, 32 * s + 8 * g));
+            const bool live_row = r0 + row < r_end;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float4 bv = *reinterpret_cast<const float4*>(sB1 + 16 * j + 4 * g);
+                f32x4_t c = { bv.x, bv.y, bv.z, bv.w };
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW1n + (16 * j + lr) * FB_P + 32 * s + 8 * g), nb[s], c, 0, 0, 0);
+                hreg[j] = live_row ? make_uint2(pk_bf(fmaxf(c[0], 0.f), fmaxf(c[1], 0.f)), pk_bf(fmaxf(c[2], 0.f), fmaxf(c[3], 0.f))) : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(sH + fw_off(row, 16 * j + 4 * g)) = hreg[j];
+            }
         }
         // ---- dH^T = W2^T . dX^T, masked by H > 0 (this wave's 16 rows), into the dH image
         bf16x8_t db[2];
@@ -474,7 +536,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
 #pragma unroll
             for (int s = 0; s < 2; s++)
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(sW2 + (16 * j + lr) * FB_P + 32 * s + 8 * g), db[s], c, 0, 0, 0);
-            const uint2 hv = *reinterpret_cast<const uint2*>(sH + fw_off(row, 16 * j + 4 * g));
+            const uint2 hv = RH ? hreg[j] : *reinterpret_cast<const uint2*>(sH + fw_off(row, 16 * j + 4 * g));
             const unsigned p0 = pk_bf(__uint_as_float(hv.x << 16) > 0.f ? c[0] : 0.f, __uint_as_float(hv.x & 0xFFFF0000u) > 0.f ? c[1] : 0.f);
             const unsigned p1 = pk_bf(__uint_as_float(hv.y << 16) > 0.f ? c[2] : 0.f, __uint_as_float(hv.y & 0xFFFF0000u) > 0.f ? c[3] : 0.f);
             hp[j >> 1][(j & 1) * 2] = p0; hp[j >> 1][(j & 1) * 2 + 1] = p1;
@@ -497,7 +559,7 @@ __global__ __launch_bounds__(256) void k_ffn_bwd_w(const unsigned short* __restr
             for (int i = 0; i < 4; i++) dn[t][i] = hd_bf(c[i]);
         }
         // ---- LayerNorm backward + the residual dX; the result replaces the wave's rows of the X image
-        fw_ln_bwd_token<RN>(sX, sDX, RN ? sN : nullptr, row, g, r0 + row < r_end, dn, wl, bl, eps, aw, ab);
+        fw_ln_bwd_token<RN && !RH>(sX, sDX, (RN && !RH) ? sN : nullptr, row, g, r0 + row < r_end, dn, wl, bl, eps, aw, ab);   // (RH: N is in its image already)
         if (OP) {
             // ---- dO = dX' Wo for this wave's 16 rows, from the rows of dX' the wave has just written (its stores fly during the weight gradients)
             __builtin_amdgcn_wave_barrier();

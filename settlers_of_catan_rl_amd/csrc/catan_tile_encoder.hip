@@ -244,7 +244,7 @@ struct TeSaves {
     unsigned short* o[2];             // [64]: attention output (the out-projection's input)
     unsigned short* xmid[2];          // [64]: residual stream after the attention sub-layer
     unsigned short* n2[2];            // [64]: LayerNorm 2 output (the FFN's input); may be null: k_ffn_bwd_w<., true> recomputes it from xmid
-    unsigned short* h[2];             // [128]: relu(linear1)
+    unsigned short* h[2];             // [128]: relu(linear1); may be null: k_ffn_bwd_w<., true, true> recomputes it from the recomputed n2
     unsigned short* xfin;             // [64]: the last layer's output (out_proj's input)
     unsigned short* p;                // [25]: out_proj output (before the final LayerNorm + ReLU)
 };
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (SAVE && sv.n2[l] != nullptr) te_dump<64>(Nb, TE_PX, sv.n2[l], t0, nt, tid);
             te_gemm<64, 128, 1>(Nb, TE_PX, w1, vl + 512, Q, TE_PH, lane, wave);
             __syncthreads();
-            if (SAVE) te_dump<128>(Q, TE_PH, sv.h[l], t0, nt, tid);
+            if (SAVE && sv.h[l] != nullptr) te_dump<128>(Q, TE_PH, sv.h[l], t0, nt, tid);   // (optional: catan_ffn_outproj_bwd_rh recomputes it)
             te_gemm<128, 64, 2>(Q, TE_PH, w2, vl + 640, X, TE_PX, lane, wave);
             __syncthreads();
         }

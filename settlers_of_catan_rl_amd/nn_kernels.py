@@ -143,6 +143,10 @@ class _WgradQueue(object):
         ok = lambda p: p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous()
         return self.active and ok(w) and (b is None or ok(b))
 
+    def drop(self):
+        """forget what was queued (the backward pass failed: its gradients are not wanted)"""
+        self.items, self.active = [], False
+
     def flush(self):
         items, self.items, self.active = self.items, [], False
         if not items:
@@ -1012,6 +1016,12 @@ class _TileEncoderTrain(torch.autograd.Function):
         # recomputed, 0: both stored and read (tools/bench_te_n_recompute.py, the tests).
         level = int(os.environ.get("CATAN_TE_RECOMPUTE_N", "2")) if _te_backward_fused_w() else 0
         drop = ("n1_", "n2_")[:level]
+        # ... and neither is the FFN's hidden activation h (the widest one: 256 of the 1 024 bytes per token and layer): k_ffn_bwd_w<., true, true>
+        # recomputes it from the recomputed n2 - one more 16 x 64 x 128 product per wave and stage (CATAN_TE_RECOMPUTE_H=0: stored and read)
+        ctx.recompute_h = level == 2 and os.environ.get("CATAN_TE_RECOMPUTE_H", "1") == "1" and os.environ.get("CATAN_TE_BWD_OP", "1") == "1"
+        if ctx.recompute_h:
+            drop = drop + ("h",)
+            ctx.packed = (wts, vecs)
         names = [(n, w) for n, w in _TE_SAVES if not (drop and n.startswith(drop))]
         need = T * sum(w for _, w in names)
         lease = _TeWorkspace.lease(need, x.device)
@@ -1064,11 +1074,20 @@ class _TileEncoderTrain(torch.autograd.Function):
                 if _te_backward_fused_w():
                     # k_ffn_bwd_w: the chain below AND both weight gradients in one pass over the rows (dH never leaves the chip)
                     dxmid = torch.empty_like(xmid)
-                    acc = grad_zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), h.device)
+                    acc = grad_zeros((64 * 128 + 64 + 128 * 64 + 128 + 128 + 64 * 64 + 64,), xmid.device)
                     dw2, db2, dw1, db1, dl = acc[:8192], acc[8192:8256], acc[8256:16448], acc[16448:16576], acc[16576:16704]
                     dwo, dbo = acc[16704:20800], acc[20800:]
                     lw, lb = P[b + 10].detach().float().contiguous(), P[b + 11].detach().float().contiguous()
-                    if os.environ.get("CATAN_TE_BWD_OP", "1") == "1":       # ... and the out-projection's dO and weight gradient from the same rows
+                    if h is None:                                           # (recompute_h) ... h recomputed from the rows of xmid, with the out-projection's backward
+                        do = torch.empty_like(o)
+                        wts, vecs = ctx.packed                              # the forward's packed parameters: W1 [128][64] and b1 [128] of layer l
+                        w1 = wts[4096 + 32768 * l + 16384:4096 + 32768 * l + 16384 + 8192]
+                        b1 = vecs[192 + 704 * l + 512:192 + 704 * l + 640]
+                        _lib.check(_lib.lib().catan_ffn_outproj_bwd_rh(_ptr(dx), _ptr(xmid), _ptr(w2t), _ptr(w1t), _ptr(w1), _ptr(b1), _ptr(lw), _ptr(lb), eps, _ptr(dxmid),
+                                                                       _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]),
+                                                                       _ptr(o), _ptr(wot), _ptr(do), _ptr(dwo), _ptr(dbo), T, _stream()))
+                        g[b + 8], g[b + 9] = dwo.view(64, 64), dbo
+                    elif os.environ.get("CATAN_TE_BWD_OP", "1") == "1":     # ... and the out-projection's dO and weight gradient from the same rows
                         do = torch.empty_like(o)
                         _lib.check(_lib.lib().catan_ffn_outproj_bwd(_ptr(dx), _ptr(h), _ptr(xmid), _ptr(n2) if n2 is not None else None, _ptr(w2t), _ptr(w1t), _ptr(lw), _ptr(lb), eps, _ptr(dxmid),
                                                                     _ptr(dw2), _ptr(db2), _ptr(dw1), _ptr(db1), _ptr(dl[:64]), _ptr(dl[64:]),

@@ -387,13 +387,22 @@ class _Branches(object):
     the stream a branch is enqueued on differs.  Off under autograd and on the CPU."""
     N_SIDE = 3
     enabled = True
+    # NOT inside a stream capture (round 5).  A hipGraph with parallel branches is launched by the HIP runtime on internal streams of
+    # its own, chosen by a search that skips the streams sharing the launch stream's hardware queue - and that search has no bound:
+    # which queue a new stream lands on depends on every stream the process has created and destroyed before (each env handle creates
+    # three), and when too few of the graph's streams are on another queue hipGraphLaunch reads past the end of the vector and the
+    # process dies with SIGSEGV inside libamdhip64 (tools/rollout_schedules.py's fourth env + collector in round 4; reproduced with a
+    # native backtrace, gone with single-chain graphs or DEBUG_HIP_FORCE_GRAPH_QUEUES=1: profiles/r05_graph_launch_segv.txt).  A
+    # captured policy pass is therefore ONE chain; the branches cost 0.12 s of a 2.3 s rollout at 65 536 games (same file).
+    in_graphs = False
 
     def __init__(self):
         self.side = None
         self.active = False
 
     def fork(self, ref):
-        self.active = bool(self.enabled and ref.is_cuda and not torch.is_grad_enabled())
+        self.active = bool(self.enabled and ref.is_cuda and not torch.is_grad_enabled()
+                           and (self.in_graphs or not torch.cuda.is_current_stream_capturing()))
         if not self.active:
             return self
         if self.side is None or self.side[0].device != ref.device:

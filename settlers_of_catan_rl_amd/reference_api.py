@@ -696,7 +696,8 @@ class PPO(object):
         self.value_loss_coef, self.entropy_coef = args.value_loss_coef, args.entropy_coef_start
         self.max_grad_norm, self.recompute_returns = args.max_grad_norm, getattr(args, "recompute_returns", True)
         self.gamma, self.gae_lambda = args.gamma, args.gae_lambda
-        self.optimiser = torch.optim.Adam(actor_critic.parameters(), lr=args.lr, eps=args.eps)
+        from .optim import FusedAdam
+        self.optimiser = FusedAdam(actor_critic.parameters(), lr=args.lr, eps=args.eps)         # ppo.py:23 (Adam; the clip of :67 rides in its step)
         self.bucket = cdist.GradBucket(actor_critic.parameters(), assign_when_single_rank=True)     # persistent flat gradient buffer (one all-reduce per step)
         self.timings = {}
 
@@ -728,8 +729,7 @@ class PPO(object):
                 self.bucket.zero()
                 (loss - entropy * self.entropy_coef).backward()                              # ppo.py:66
                 self.bucket.allreduce()
-                nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-                self.optimiser.step()
+                self.optimiser.step(self.max_grad_norm)                                      # ppo.py:67-68
                 nn_kernels.weight_images.refresh_all()                                       # the bf16 / transposed / packed images of the new weights: one launch (nothing on the CPU)
                 s = torch.stack((parts[1].detach() * self.value_loss_coef, parts[0].detach(), entropy.detach().float() * self.entropy_coef))
                 sums = s if sums is None else sums + s

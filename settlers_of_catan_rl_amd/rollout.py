@@ -206,6 +206,20 @@ class RolloutCollector(object):
     @torch.no_grad()
     def gather_rollouts(self, max_iters=None):
         """game_manager.py:69-140.  Returns the storage (first T(+1) entries per game are the rollout)."""
+        try:
+            return self._gather_rollouts(max_iters)
+        except BaseException:
+            # an error inside the loop (a policy that raises, out of memory) must not leave a catan_step_deferred sequence open:
+            # every later step / reset / export of the env would be refused until someone flushed it
+            flush = getattr(self.env, "step_flush", None)
+            if flush is not None and self.deferred_window:
+                try:
+                    flush()
+                except Exception:
+                    pass
+            raise
+
+    def _gather_rollouts(self, max_iters=None):
         env, st, T, N, dev = self.env, self.storage, self.T, self.N, self.device
         ar = self._ar = torch.arange(N, device=dev)
         if self._shadow is not None:
@@ -456,6 +470,14 @@ class RolloutCollector(object):
             self.hid[0, ar_all, seat] = torch.where(keep, new_h, h_in)                     # :89
             self.hid[1, ar_all, seat] = torch.where(keep, new_c, c_in)
         return actions, logp
+
+    def close(self):
+        """Drops what the collector holds on the device - the captured policy passes (hipGraphs and their pools), the acting copy of
+        the net and the rollout storage - without waiting for the garbage collector; the collector cannot be used afterwards."""
+        if self._graphed is not None:
+            self._graphed.graphs.clear()
+        self._graphed = self._shadow = self.storage = None
+        self.opponent_nets = []
 
     # game_manager.py:142-150
     def after_rollouts(self):

@@ -69,7 +69,8 @@ class PPOTrainer(object):
         if next(policy.parameters()).is_cuda:
             from . import nn_kernels
             nn_kernels.use_tuned_gemms()           # library GEMMs: tuned solution per shape (tunableop_gfx950.csv)
-        self.optimiser = torch.optim.Adam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)   # ppo.py:23
+        from .optim import FusedAdam
+        self.optimiser = FusedAdam(policy.parameters(), lr=self.cfg.lr, eps=self.cfg.eps)           # ppo.py:23 (+ the clip of :67 in its step)
         # gradients live in one persistent flat buffer with a fixed layout (dist.GradBucket): the all-reduce of a step is one
         # collective on that buffer, and zeroing the gradients is one memset
         self.bucket = cdist.GradBucket(policy.parameters(), assign_when_single_rank=True)
@@ -259,8 +260,10 @@ class PPOTrainer(object):
                     nn_kernels.wgrad_queue.begin()                                         # tall-skinny weight gradients: grouped launches after the backward
                 try:
                     (loss - ent * cfg.entropy_coef).backward()                             # ppo.py:66
-                finally:
-                    nn_kernels.wgrad_queue.flush()
+                except BaseException:
+                    nn_kernels.wgrad_queue.drop()      # (a flush here could raise in turn and hide the backward's own error)
+                    raise
+                nn_kernels.wgrad_queue.flush()
                 if timed_allreduce:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -269,8 +272,7 @@ class PPOTrainer(object):
                     ar_events.append((e0, e1))
                 else:
                     self.bucket.allreduce()
-                torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)        # ppo.py:67
-                self.optimiser.step()
+                self.optimiser.step(cfg.max_grad_norm)                                     # ppo.py:67-68: clip_grad_norm_ + Adam, two launches (optim.FusedAdam)
                 nn_kernels.grad_arena.end_step()
                 nn_kernels.weight_images.refresh_all()                                     # every bf16 / transposed / packed image of the new weights: one launch
                 sums += torch.stack((parts[0], parts[1], ent.detach().float()))

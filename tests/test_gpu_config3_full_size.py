@@ -25,7 +25,7 @@ from settlers_of_catan_rl_amd import spec
 
 pytestmark = pytest.mark.gpu
 
-LOGP_ROLLOUT_VS_LEARNER_TOL = 0.08       # |stored log-prob - evaluate_actions| of a composite action, bf16 autocast on both sides
+LOGP_ROLLOUT_VS_LEARNER_TOL = 0.02       # |stored log-prob - evaluate_actions| of a composite action, bf16 autocast on both sides
 
 
 class DeviceRecorder(object):
@@ -220,22 +220,25 @@ def test_config3_full_size_default_collector_two_rollouts_sampled_oracle_parity(
 
 
 def test_four_full_size_collector_sets_in_one_process(hip_lib):
-    """tools/rollout_schedules.py of round 4 died (SIGSEGV) building its FOURTH 65 536-game env + collector + 63 GB storage in one
-    process.  Four sets, each used for a rollout of T = 200 and dropped, device memory back to where it was after every set."""
+    """tools/rollout_schedules.py of round 4 died (SIGSEGV inside hipGraphLaunch) at its FOURTH 65 536-game env + collector + storage in
+    one process.  The same sequence - one captured policy pass, the halving buckets, the default buckets twice - each set used for a
+    rollout of T = 200 and dropped; device memory returns to where it was.  (The captured passes are single-chain graphs now:
+    policy._Branches.in_graphs)"""
     from settlers_of_catan_rl_amd.env import VecCatanEnv
-    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    from settlers_of_catan_rl_amd.policy import CatanPolicy, _Branches
     from settlers_of_catan_rl_amd.rollout import RolloutCollector
+    assert not _Branches.in_graphs
     n, T = 65536, 200
     torch.manual_seed(0)
     net = CatanPolicy().cuda()
     torch.cuda.synchronize()
     used = []
-    for k in range(4):
-        env = VecCatanEnv(n, seed=k)
+    for k, kw in enumerate((dict(act_buckets=(n,)), dict(act_buckets=tuple(n >> j for j in range(5))), dict(), dict(deferred_window=4))):
+        env = VecCatanEnv(n, seed=0)
         env.random_rollout(0, 600)
-        col = RolloutCollector(env, net, T, seed=k, autocast_dtype=torch.bfloat16)
+        col = RolloutCollector(env, net, T, seed=0, autocast_dtype=torch.bfloat16, **kw)
         st = col.gather_rollouts()
-        assert bool((col.n_obs == T + 1).all()) and env.invalid_action_count() == 0
+        assert bool((col.n_obs == T + 1).all()) and env.invalid_action_count() == 0, k
         col.after_rollouts()
         col.close()
         env.close()
@@ -244,4 +247,4 @@ def test_four_full_size_collector_sets_in_one_process(hip_lib):
         torch.cuda.empty_cache()
         free, total = torch.cuda.mem_get_info()
         used.append((total - free) / 2 ** 30)
-    assert max(used) - min(used) < 2.0, used                                # GB: nothing of a set stays behind
+    assert max(used) - min(used) < 3.0, used                                # GB: nothing of a set stays behind
