@@ -209,6 +209,9 @@ def ppo_update_record(env, n, rank, world, T, cdist):
         cdist.barrier()
         t2 = time.perf_counter()
         col.after_rollouts()
+        import math
+        if not all(math.isfinite(x) for x in (vl, al, el)):          # an update on NaNs does no real work: its time must not be reported
+            raise RuntimeError(f"non-finite PPO losses in update {u}: value {vl}, action {al}, entropy {el}")
         rollout_s, update_s = cdist.max_over_ranks(t1 - t0), cdist.max_over_ranks(t2 - t1)
         if u < 2:
             warm.append({"rollout_s": rollout_s, "update_s": update_s, "minibatches_s": tr.timings.get("minibatches_s")})

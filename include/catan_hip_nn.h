@@ -61,6 +61,16 @@ typedef struct catan_weight_image {
 int32_t catan_weight_image_bytes(void);
 int catan_weight_images(const void* table, int32_t n, catan_stream_t stream);
 
+/* The weight gradient of a WIDE linear layer over many rows (the observation trunk's 992 -> 512 product, RL/models/observation_module.py:58-63, in the
+ * backward of RL/ppo/ppo.py:66): dw [out][dw_ld] (fp32; columns < in) = dy^T x, db [out] (may be NULL) = the column sums of dy; x bf16
+ * [rows][in], dy bf16 [rows][out], in a multiple of 8, out a multiple of 128, both 16-byte aligned.  accumulate != 0: added to what dw / db
+ * hold, else they are overwritten.  workspace: catan_wgrad_big_workspace_floats(rows, in, out) floats of scratch (the row groups' partial tiles,
+ * added in index order: the result does not depend on the order in which workgroups finish).  128 x 128 output tiles, the workgroups that share
+ * a row slice placed in one XCD so that the slice is read from HBM once (csrc/catan_wgrad_big.hip). */
+int64_t catan_wgrad_big_workspace_floats(int64_t rows, int in_features, int out_features);
+int catan_linear_wgrad_big(const void* x, const void* dy, float* dw, int64_t dw_ld, float* db, float* workspace, int64_t rows, int in_features,
+                           int out_features, int accumulate, catan_stream_t stream);
+
 /* The optimiser step of PPO.update - `nn.utils.clip_grad_norm_(parameters, max_grad_norm)` then `optim.Adam.step()` (RL/ppo/ppo.py:23,
  * 67-68) - over all parameters in two launches (sum of squared gradients per chunk; norm, clip coefficient and Adam update per chunk).
  * tensors: n_tensors rows {p, m, v} ON THE DEVICE (fp32, 16-byte aligned); chunks: n_chunks rows ON THE DEVICE, chunk i = elements

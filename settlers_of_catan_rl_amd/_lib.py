@@ -45,8 +45,57 @@ _HASH_MARK = b"CATAN_BUILD_HASH="
 # k_tile_encoder_fwd's LayerNorm with its bf16 pairs converted by one v_cvt_pk_bf16_f32 each gave, with two workgroups per CU, wrong
 # rows for the tokens of a wave's lanes 48..63 in ~0.6 % of the boards, differently on every run (the same source built
 # with this flag is bit-stable, and tests/test_gpu_ppo_pipeline.py::test_fused_tile_encoder_forward_vs_unfused is the check)
+# -target-feature -packed-fp32-ops (round 5): the SLP flag only stops ONE source of those instructions; the load / store vectoriser and the
+# DAG combiner produced them too (llvm-objdump of the round-4 library: 12 v_pk_mul_f32 in each k_obs_rows<fp32>, one v_pk_add_f32 beside three
+# v_cvt_pk_bf16_f32 in k_lnw_bwd<bf16, 2, 64> - the very combination that misbehaved).  With the target feature off the back end cannot
+# select them at all, whoever asks; `check_no_packed_f32` disassembles every freshly built library and refuses one that has any.  (The host
+# half of the compilation does not know the feature: its three "not a recognized feature" notes are dropped from the compiler's output.)
 BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize",
-               "-mllvm", "-amdgpu-mfma-vgpr-form"]
+               "-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+LLVM_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def device_code_object(path=None):
+    """The gfx950 code object embedded in the library (clang offload bundle: magic, entry table, blobs) -> bytes"""
+    import struct
+    with open(LIB_PATH if path is None else path, "rb") as f:
+        blob = f.read()
+    i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    if i < 0:
+        raise CatanHipError("no offload bundle in the library")
+    n = struct.unpack_from("<Q", blob, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, sz, tl = struct.unpack_from("<QQQ", blob, off)
+        triple = blob[off + 24:off + 24 + tl].decode()
+        off += 24 + tl
+        if "gfx950" in triple:
+            return blob[i + o:i + o + sz]
+    raise CatanHipError("no gfx950 code object in the library")
+
+
+def check_no_packed_f32(path=None):
+    """Disassembles the library's device code and raises if any packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+    is in it: next to v_cvt_pk_bf16_f32 they gave a timing-dependent wrong result in k_tile_encoder_fwd, and the packed
+    conversion is used by every bf16 kernel of the net.  -> the number of v_cvt_pk_bf16_f32 found (informational); None without llvm-objdump."""
+    import re
+    import tempfile
+    if not os.path.exists(LLVM_OBJDUMP):
+        return None
+    with tempfile.NamedTemporaryFile(suffix=".co", dir="/tmp") as tmp:
+        tmp.write(device_code_object(path))
+        tmp.flush()
+        text = subprocess.run([LLVM_OBJDUMP, "-d", tmp.name], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode("ascii", "replace")
+    fn, bad = "?", {}
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            fn = m.group(1)
+        elif re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+            bad[fn] = bad.get(fn, 0) + 1
+    if bad:
+        raise CatanHipError("packed-fp32 VALU instructions in the library (see _lib.BUILD_FLAGS): " + ", ".join(f"{k}: {v}" for k, v in sorted(bad.items())[:8]))
+    return len(re.findall(r"\bv_cvt_pk_bf16_f32\b", text))
 
 
 def source_hash():
@@ -88,9 +137,17 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     if verbose:
         print(f"compiling (binary hash {have}, source hash {want}): " + " ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = "\n".join(l for l in r.stdout.decode("utf-8", "replace").splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l)
+    if out.strip():
+        print(out)
+    if r.returncode != 0:
+        raise CatanHipError(f"hipcc failed with exit code {r.returncode}")
     if binary_hash() != want:
         raise CatanHipError("the freshly built libcatan_hip.so does not carry the source hash")
+    n_cvt = check_no_packed_f32()
+    if verbose and n_cvt is not None:
+        print(f"disassembly: no v_pk_*_f32, {n_cvt} v_cvt_pk_bf16_f32")
     if verbose:
         print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH)} bytes)")
     return LIB_PATH
@@ -128,6 +185,8 @@ _SIGS = {
     "catan_qkv_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, C.c_int64, _vp]),
     "catan_weight_image_bytes": (C.c_int32, []),
     "catan_weight_images": (C.c_int, [_vp, C.c_int32, _vp]),
+    "catan_wgrad_big_workspace_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "catan_linear_wgrad_big": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp]),
     "catan_adam_chunk_elements": (C.c_int32, []),
     "catan_adam_step": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "catan_gather_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp]),

@@ -20,6 +20,7 @@
 #include "catan_rows.hip"
 #include "catan_te_bwd.hip"
 #include "catan_optim.hip"
+#include "catan_wgrad_big.hip"
 
 using namespace catan;
 
@@ -44,6 +45,7 @@ struct catan_env {
     Pending pend;         // tier-2 longest-road hand-off (device arrays)
     unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
     int prof_on;
+    int step_wpb;         // waves per k_step workgroup (4: one workgroup per CU, a SIMD per wave; 1: one-wave workgroups)
     u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
     int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
@@ -388,6 +390,11 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
     if (const char* df = getenv("CATAN_DEFERRED_FUSED")) e->deferred_fused = atoi(df) != 0;
+    // one-wave workgroups by default.  Four waves per workgroup (CATAN_STEP_WAVES_PER_BLOCK=4: one 116 KB workgroup per CU, a SIMD per wave) was
+    // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
+    // previous pass hold LDS on most CUs, so a 116 KB workgroup often has to wait for a CU where the 29 KB one-wave workgroup fits at once
+    e->step_wpb = 1;
+    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : 1;
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
     HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
@@ -495,7 +502,8 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
     }
     if (e->pend.sample) {                                 // fused-sampling rollouts: actions from / to the side rows (64 games per wave)
-        hipLaunchKernelGGL((k_step<64, true>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        if (e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, true, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else hipLaunchKernelGGL((k_step<64, true>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipGetLastError());
         return CATAN_OK;
@@ -503,7 +511,10 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     switch (e->step_games) {
     case 16: hipLaunchKernelGGL(k_step<16>, dim3(blocks(e->N, 16) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
     case 32: hipLaunchKernelGGL(k_step<32>, dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
-    default: hipLaunchKernelGGL(k_step<64>, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
+    default:
+        if (e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, false, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else hipLaunchKernelGGL(k_step<64>, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        break;
     }
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     HIPCHK(hipGetLastError());
@@ -1340,6 +1351,30 @@ int catan_qkv_bwd_dx(const void* dqkv, const void* x, const void* dres, const vo
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_qkv_bwd_dx, dim3((unsigned)nb), dim3(256), 0, S(stream), (const unsigned short*)dqkv, (const unsigned short*)x, (const unsigned short*)dres,
                        (const unsigned short*)wt, ln_w, eps, (unsigned short*)dx_out, dln_w, dln_b, (long)rows);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int64_t catan_wgrad_big_workspace_floats(int64_t rows, int in_features, int out_features) {
+    if (rows <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    const int tiles_i = (in_features + 1 + WB_T - 1) / WB_T;
+    const int groups = 8 * (rows >= 8 * 2 * 4096 ? 2 : 1);
+    return (int64_t)groups * out_features * tiles_i * WB_T;
+}
+int catan_linear_wgrad_big(const void* x, const void* dy, float* dw, int64_t dw_ld, float* db, float* workspace, int64_t rows, int in_features,
+                           int out_features, int accumulate, catan_stream_t stream) {
+    if (!x || !dy || !dw || !workspace || rows <= 0 || in_features < 8 || (in_features & 7) || out_features < WB_T || (out_features % WB_T) || dw_ld < in_features ||
+        (((uintptr_t)x | (uintptr_t)dy) & 15))
+        return fail(CATAN_EINVAL, "catan_linear_wgrad_big: bad arguments (in a multiple of 8, out a multiple of 128, 16-byte aligned operands)");
+    const int tiles_o = out_features / WB_T, tiles_i = (in_features + 1 + WB_T - 1) / WB_T;
+    const int groups = 8 * (rows >= 8 * 2 * 4096 ? 2 : 1);                 // row groups: one per XCD, two when every group still has >= 4 096 rows
+    long per = (rows + groups - 1) / groups;
+    per = (per + WG_KT - 1) / WG_KT * WG_KT;
+    const long nblocks = (long)groups * tiles_o * tiles_i;
+    hipLaunchKernelGGL(k_wgrad_big, dim3((unsigned)nblocks), dim3(256), 0, S(stream), (const unsigned short*)x, (const unsigned short*)dy, workspace, (long)rows,
+                       in_features, out_features, per, tiles_o, tiles_i);
+    const long n = (long)out_features * (in_features + 1);
+    hipLaunchKernelGGL(k_wgrad_big_reduce, dim3(blocks(n, 256)), dim3(256), 0, S(stream), (const float*)workspace, groups, out_features, in_features, tiles_i * WB_T,
+                       dw, (long)dw_ld, db, accumulate);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -1666,7 +1666,8 @@ constexpr int PROF_WORDS = PROF_TOTAL + 42;
 DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
     if (cfg.prof_wave != nullptr) {                 // contention-free variant (k_step only): one slot per wave and phase
         const long long t = wall_clock64();
-        if ((threadIdx.x & 63) == 0 && !(cfg.prof_timeline && phase == 2)) cfg.prof_wave[(long)blockIdx.x * 8 + phase] = (u32)(t - t_prev);
+        if ((threadIdx.x & 63) == 0 && !(cfg.prof_timeline && phase == 2))
+            cfg.prof_wave[((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + phase] = (u32)(t - t_prev);
         t_prev = wall_clock64();
         return;
     }
@@ -1892,23 +1893,30 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // SAMPLE (fused-sampling deferred rollouts): the action comes from the game's side row, the step advances the game's decision
 // counter, and for every game it completes it draws the NEXT action from the new masks (still in registers) and appends the
 // game to the next pass's bin lists - the sampler / sort kernel and its re-read of the masks are gone from the pass.
-template <int G, bool SAMPLE = false>
-__global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
+// WPB waves per workgroup, every wave with a tile of its own and no workgroup-level synchronisation.  WPB = 4 (the default for 64 games
+// per wave): the hardware spreads a workgroup's waves over the four SIMDs of its CU and the 116 KB of LDS admit one workgroup per CU,
+// so every working wave has a SIMD to itself.  As 1 041 one-wave workgroups the dispatcher used 800 of the 1 024 SIMDs and put two to
+// four waves on 208 of them (tools/step_timeline.py, profiles/r05_k_step_timeline.txt): the launch lasted as long as those.
+template <int G, bool SAMPLE = false, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
     constexpr int TSG = G + 1;
     typedef StLT<TSG> StG;
-    __shared__ u32 tile[ROWS_HOT * TSG];
-    __shared__ u64 tct[20];                                 // corner mask per tile: a per-lane tile index costs one LDS read
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
-    if (SAMPLE && blockIdx.x == 0 && lane == 0 && pend.lrq_clear >= 0) pend.ctr[lrq_ctr(pend.lrq_clear)] = 0;   // ... and the next group's tier-1 request list (its last reader is done)
+    __shared__ u32 tile_all[WPB][ROWS_HOT * TSG];
+    __shared__ u64 tct_all[WPB][20];                        // corner mask per tile: a per-lane tile index costs one LDS read
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wv = (int)blockIdx.x * WPB + wib;             // this wave's position among the sorted waves
+    u32* const tile = tile_all[wib];
+    u64* const tct = tct_all[wib];
+    if (wv == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
+    if (SAMPLE && wv == 0 && lane == 0 && pend.lrq_clear >= 0) pend.ctr[lrq_ctr(pend.lrq_clear)] = 0;   // ... and the next group's tier-1 request list (its last reader is done)
     // Wave w takes the sorted positions 64w .. 64w+63.  The sort is never materialised: the sampler / k_classify left the
     // game ids in one list per bin, every bin occupies ceil(count / 64) waves (type-pure waves), and a wave finds its bin
     // and offset from the 18 counts.
     int bin = -1, cnt = 0, first = 0;
     {
-        const int pos = (int)blockIdx.x * G;
+        const int pos = wv * G;
         int start = 0;
 #pragma unroll
         for (int k = 0; k < NBINS; k++) {
@@ -1921,7 +1929,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     const int rnk = first + lane;
     const long e = (lane < G && rnk < cnt) ? (long)pend.lists[((long)pend.bsel * NBINS + bin) * c.N + rnk] : 0x7fffffffL;
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
-    if (cfg.prof_wave != nullptr && cfg.prof_timeline && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 2] = (u32)tprof;
+    if (cfg.prof_wave != nullptr && cfg.prof_timeline && lane == 0) cfg.prof_wave[(long)wv * 8 + 2] = (u32)tprof;
     const bool live = e < c.n;
     // the last bin = explicit no-op (negative type: frozen game) or a busy game (the sampler gives those the no-op): none
     // of them touches its record
@@ -2071,7 +2079,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         u32 tk[3] = { 0, 0, 0 };
         int roll = roll_dice(s, rng, order, seatof, tct, cfg.prof_wave ? tk : nullptr);
         if (cfg.prof_wave != nullptr && lane == 0)          // slot 4: dice draws | tile scan + bank << 10 | hands + estimates << 20
-            cfg.prof_wave[(long)blockIdx.x * 8 + 4] = (tk[0] & 1023u) | ((tk[1] & 1023u) << 10) | ((tk[2] & 1023u) << 20);
+            cfg.prof_wave[(long)wv * 8 + 4] = (tk[0] & 1023u) | ((tk[1] & 1023u) << 10) | ((tk[2] & 1023u) << 20);
         s.sw(W_RNG, rng.draws);
         flags |= F_ROLLED;
         if (roll == 7) flags |= F_CAN_ROBBER;
@@ -2259,11 +2267,11 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
     }
     if (cfg.prof_wave != nullptr) {                         // slot 3: before the switch (validate, clamps) | the switch << 16; slot 4: unused
         const long long t_sw1 = clock_fenced();
-        if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 3] = ((u32)(t_sw0 - tprof) & 0xFFFFu) | ((u32)(t_sw1 - t_sw0) << 16);
+        if (lane == 0) cfg.prof_wave[(long)wv * 8 + 3] = ((u32)(t_sw0 - tprof) & 0xFFFFu) | ((u32)(t_sw1 - t_sw0) << 16);
     }
     if (type >= 0 && type != T_RESPOND && type != T_ENDTURN && type != T_DISCARD) s.sw(W_ACTIONS, s.w(W_ACTIONS) + 1);   // game.py:809-810
 
-    if (cfg.prof_wave != nullptr && lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 5] = (u32)(type >= 0 ? bin + 1 : 0);   // slot 5: sort bin + 1
+    if (cfg.prof_wave != nullptr && lane == 0) cfg.prof_wave[(long)wv * 8 + 5] = (u32)(type >= 0 ? bin + 1 : 0);   // slot 5: sort bin + 1
     if (cfg.prof != nullptr && cfg.prof_wave == nullptr && lane == 0) {   // per action type: time of validate+apply
         const int t0 = live ? actions[e * ACTION_WORDS] : 13;
         const int tb = (t0 < 0 || t0 > 12) ? 13 : t0;
@@ -2326,7 +2334,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         arank = rank; aleader = leader; anb = nb;
         if (cfg.prof_wave != nullptr) {                     // slot 4 (SAMPLE): the draw | the ranking << 16
             const long long t_s2 = clock_fenced();
-            if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 4] = ((u32)(t_s1 - t_s0) & 0xFFFFu) | ((u32)(t_s2 - t_s1) << 16);
+            if (lane == 0) cfg.prof_wave[(long)wv * 8 + 4] = ((u32)(t_s1 - t_s0) & 0xFFFFu) | ((u32)(t_s2 - t_s1) << 16);
         }
     }
     // ---- write the tile back, then the new mask rows (SAMPLE: the whole side rows) through the tile
@@ -2346,7 +2354,7 @@ __global__ __launch_bounds__(64) void k_step(Ctx c, const i32* __restrict__ acti
         u32 hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (lane == 0) cfg.prof_wave[(long)blockIdx.x * 8 + 3] = (hw & 0x0FFFFFFFu) | ((xcc & 15u) << 28);
+        if (lane == 0) cfg.prof_wave[(long)wv * 8 + 3] = (hw & 0x0FFFFFFFu) | ((xcc & 15u) << 28);
     }
 }
 

@@ -430,6 +430,59 @@ def _wgrad(x2, dy2, has_bias):
     return dw, db
 
 
+_WGRAD_BIG_WS = {}
+WGRAD_BIG = True        # (tools/ab_step_switches.py)
+
+
+def wgrad_big_supported(rows, in_features, out_features):
+    return WGRAD_BIG and rows >= 16384 and in_features % 8 == 0 and in_features >= 256 and out_features % 128 == 0
+
+
+def wgrad_big(x2, dy2, has_bias=True):
+    """x2 [rows, I], dy2 [rows, O] bf16 -> (dW fp32 [O, I], db fp32 [O] or None) through catan_linear_wgrad_big: 128 x 128 output tiles, the
+    row groups' partial tiles added in index order (deterministic)."""
+    import ctypes as C
+    rows, I, O = x2.shape[0], x2.shape[1], dy2.shape[1]
+    L = _lib.lib()
+    need = int(L.catan_wgrad_big_workspace_floats(rows, I, O))
+    key = (x2.device, _stream().value)
+    ws = _WGRAD_BIG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_BIG_WS[key] = torch.empty(need, dtype=torch.float32, device=x2.device)
+    out = torch.empty(O * I + O, dtype=torch.float32, device=x2.device)
+    dw, db = out[:O * I].view(O, I), (out[O * I:] if has_bias else None)
+    _lib.check(L.catan_linear_wgrad_big(_ptr(_aligned(x2)), _ptr(_aligned(dy2)), _ptr(dw), I, _ptr(db) if has_bias else None, _ptr(ws), rows, I, O, 0, _stream()))
+    return dw, db
+
+
+class _LinearBigWgrad(torch.autograd.Function):
+    """y = x @ w.T + b (bf16, the library's GEMM) for a wide layer over many rows; backward: dX by the library, dW / db by k_wgrad_big (the
+    library's split-K weight gradient of the trunk's [512 x R] . [R x 992] runs at 13 % of the MFMA peak).  w may be any tensor autograd
+    tracks (the trunk passes its weight with five zero columns spliced in): its gradient comes back in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        with torch.autocast("cuda", enabled=False):
+            xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+            y = torch.nn.functional.linear(xb, wb, None if b is None else b.to(torch.bfloat16))
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        with torch.autocast("cuda", enabled=False):
+            dy2 = dy.reshape(-1, wb.shape[0]).to(torch.bfloat16).contiguous()
+            dx = (dy2 @ wb).view(xb.shape) if ctx.needs_input_grad[0] else None
+            dw, db = wgrad_big(xb.reshape(-1, xb.shape[-1]), dy2, ctx.has_bias)
+        return dx, dw, db
+
+
+def linear_big(x, w, b):
+    return _LinearBigWgrad.apply(x, w, b)
+
+
 def wgrad_grouped(pairs, has_bias=True):
     """[(x2 [rows_k, I_k], dy2 [rows_k, O_k]) bf16] -> [(dW_k fp32 [O_k, I_k], db_k [O_k])] through catan_linear_wgrad_grouped: problems of
     the same tile shape share launches (the heads' first layers on their row segments: 44 launches -> 2)."""
@@ -1016,9 +1069,11 @@ class _TileEncoderTrain(torch.autograd.Function):
         # recomputed, 0: both stored and read (tools/bench_te_n_recompute.py, the tests).
         level = int(os.environ.get("CATAN_TE_RECOMPUTE_N", "2")) if _te_backward_fused_w() else 0
         drop = ("n1_", "n2_")[:level]
-        # ... and neither is the FFN's hidden activation h (the widest one: 256 of the 1 024 bytes per token and layer): k_ffn_bwd_w<., true, true>
-        # recomputes it from the recomputed n2 - one more 16 x 64 x 128 product per wave and stage (CATAN_TE_RECOMPUTE_H=0: stored and read)
-        ctx.recompute_h = level == 2 and os.environ.get("CATAN_TE_RECOMPUTE_H", "1") == "1" and os.environ.get("CATAN_TE_BWD_OP", "1") == "1"
+        # CATAN_TE_RECOMPUTE_H=1: the FFN's hidden activation h (the widest one: 256 of the 1 024 bytes per token and layer) is not stored either:
+        # k_ffn_bwd_w<., true, true> recomputes it from the recomputed n2 - one more 16 x 64 x 128 product per wave and stage.  OFF by default:
+        # measured at config 3's minibatch (tools/ab_step_switches.py, profiles/r05_ab_recompute_h.txt) the step is 22.12 ms with h stored
+        # and 22.25 ms with h recomputed - the pass is not bound by the bytes it reads, the product costs what the 9.7 KB per board save
+        ctx.recompute_h = level == 2 and os.environ.get("CATAN_TE_RECOMPUTE_H", "0") == "1" and os.environ.get("CATAN_TE_BWD_OP", "1") == "1"
         if ctx.recompute_h:
             drop = drop + ("h",)
             ctx.packed = (wts, vecs)

@@ -15,6 +15,7 @@ import torch
 class FusedAdam(object):
     """`torch.optim.Adam(params, lr, betas, eps)` (no weight decay, no amsgrad) + gradient-norm clipping in `step(max_grad_norm)`.
     `param_groups[0]["lr"]` is read at every step (train_loop's linear decay writes it, as RL/robust_train.py:67-72 does)."""
+    RING = 8
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params if p.requires_grad]
@@ -59,8 +60,13 @@ class FusedAdam(object):
             "sig": tuple(p.data_ptr() for p in self.params),
             "tensors": torch.from_numpy(tens.view(np.uint8).reshape(-1)).to(dev),
             "chunks": torch.from_numpy(ch.view(np.uint8).reshape(-1).copy()).to(dev), "n_chunks": len(chunks),
-            "grads_host": torch.zeros(len(self.params), dtype=torch.int64).pin_memory(),
-            "grads": torch.zeros(len(self.params), dtype=torch.int64, device=dev),
+            # this step's gradient addresses travel through a RING of pinned host rows (the host runs several steps ahead of the device: one
+            # row would be rewritten for step k + 1 before the copy engine has read step k's - the kernel would then take step k + 1's
+            # gradient buffers, not yet written: round 5, found as NaN losses in the third update of bench.py) - a row is reused only
+            # after the event recorded behind its copy has completed
+            "grads_host": torch.zeros((self.RING, len(self.params)), dtype=torch.int64).pin_memory(),
+            "grads": torch.zeros((self.RING, len(self.params)), dtype=torch.int64, device=dev),
+            "events": [None] * self.RING, "slot": 0,
             "partial": torch.zeros(len(chunks), dtype=torch.float64, device=dev),
             "norm": torch.zeros(1, dtype=torch.float32, device=dev),
         }
@@ -88,7 +94,10 @@ class FusedAdam(object):
         if self._tables is None or self._tables["sig"] != tuple(p.data_ptr() for p in self.params):
             self._build_tables()
         t = self._tables
-        host = t["grads_host"]
+        k = t["slot"] = (t["slot"] + 1) % self.RING
+        if t["events"][k] is not None:
+            t["events"][k].synchronize()                      # the copy (and the step) that last used this row is done
+        host = t["grads_host"][k]
         for i, p in enumerate(self.params):
             gr = p.grad
             if gr is None:
@@ -97,10 +106,13 @@ class FusedAdam(object):
             if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.data_ptr() % 16:
                 gr = p.grad = gr.float().contiguous().clone()
             host[i] = gr.data_ptr()
-        t["grads"].copy_(host, non_blocking=True)
+        t["grads"][k].copy_(host, non_blocking=True)
         P = lambda x: C.c_void_p(x.data_ptr())
-        _lib.check(_lib.lib().catan_adam_step(P(t["tensors"]), P(t["chunks"]), t["n_chunks"], P(t["grads"]), P(t["partial"]), clip, lr, b1, b2, eps,
+        _lib.check(_lib.lib().catan_adam_step(P(t["tensors"]), P(t["chunks"]), t["n_chunks"], P(t["grads"][k]), P(t["partial"]), clip, lr, b1, b2, eps,
                                               bc1, bc2_sqrt, P(t["norm"]), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if t["events"][k] is None:
+            t["events"][k] = torch.cuda.Event()
+        t["events"][k].record()
         self.last_norm = t["norm"]
         # the kernel wrote the parameters behind autograd's back: bump their version counters as an in-place torch update would (caches of
         # derived data are keyed on them: nn_kernels.tile_encoder_pack, weight_images, an inference copy's refresh)

@@ -312,7 +312,10 @@ class _ObservationModule(nn.Module):
             # decides for these widths; the pad columns meet zero weights)
             w = self.final_layer.weight
             wp = torch.cat((w[:, :475], w.new_zeros((w.shape[0], te_pad)), w[:, 475:]), 1)
-            return _ln(self.norm, F.linear(nn_kernels.concat_rows((te, cp, op.reshape(B, 3 * 128))), wp, self.final_layer.bias), relu=True)
+            xcat = nn_kernels.concat_rows((te, cp, op.reshape(B, 3 * 128)))
+            if xcat.is_cuda and torch.is_grad_enabled() and xcat.dtype == torch.bfloat16 and nn_kernels.wgrad_big_supported(B, wp.shape[1], wp.shape[0]):
+                return _ln(self.norm, nn_kernels.linear_big(xcat, wp, self.final_layer.bias), relu=True)     # weight gradient: k_wgrad_big
+            return _ln(self.norm, F.linear(xcat, wp, self.final_layer.bias), relu=True)
         return _ln(self.norm, _lin_parts((te, cp, op.reshape(B, 3 * 128)), self.final_layer.weight, self.final_layer.bias), relu=True)
 
 

@@ -111,3 +111,9 @@ def test_library_is_built_without_packed_f32_valu():
     from settlers_of_catan_rl_amd import _lib
     assert "-fno-slp-vectorize" in _lib.BUILD_FLAGS
     assert "--offload-arch=gfx950" in _lib.BUILD_FLAGS
+    # ... and the flag alone was not enough (round 5: other passes emitted v_pk_mul_f32 / v_pk_add_f32 too): the back end's packed-fp32 feature is
+    # off, and the library AS BUILT is disassembled - no such instruction anywhere, while the packed bf16 conversion is everywhere
+    assert "-packed-fp32-ops" in _lib.BUILD_FLAGS
+    _lib.build_library()
+    n = _lib.check_no_packed_f32()
+    assert n is None or n > 1000, n

@@ -43,7 +43,7 @@ def _run(device, steps=50, clip=0.5):
 def _check(net, ref, norms, mine):
     assert any(a > 0.5 for a, _ in norms) and any(a < 0.5 for a, _ in norms), "the test is meant to clip in some steps only"
     for a, b in norms:
-        assert abs(a - b) <= 1e-5 * max(1.0, a), (a, b)
+        assert abs(a - b) <= 5e-5 * max(1.0, a), (a, b)        # (torch's norm of norms is an fp32 sum; the kernel's partial sums are added in fp64)
     for (k, p), q in zip(net.named_parameters(), ref.parameters()):
         assert float((p - q).abs().max()) < 1e-6, (k, float((p - q).abs().max()))
     assert all(float(m.abs().max()) == 0.0 for m, p in zip(mine._m, mine.params) if p.grad is None)        # no gradient: no step, as torch
@@ -80,5 +80,5 @@ def test_fused_adam_on_the_policy_net_one_ppo_step(hip_lib):
             p.grad, q.grad = gr, gr.clone()
         tn = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
         theirs.step(); mine.step(0.5)
-        assert abs(float(tn) - float(mine.last_norm)) <= 1e-5 * float(tn)
+        assert abs(float(tn) - float(mine.last_norm)) <= 5e-5 * float(tn)
     assert max(float((p - q).abs().max()) for p, q in zip(net.parameters(), ref.parameters())) < 1e-6

@@ -36,10 +36,11 @@ def set_recurrent(on): pol_mod.RECURRENT_BATCHED = on
 def set_gather_ranges(on): nn_kernels.GATHER_RANGES = on
 def set_fanout(on): nn_kernels.FANOUT_GATHER = on
 def set_concat(on): nn_kernels.CONCAT_ROWS = on
+def set_wgrad_big(on): nn_kernels.WGRAD_BIG = on
 def set_recompute_h(on): os.environ["CATAN_TE_RECOMPUTE_H"] = "1" if on else "0"      # (read by every tile-encoder forward)
 
 
-SW = {"recompute_h": set_recompute_h, "grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred, "recurrent_batched": set_recurrent, "gather_ranges": set_gather_ranges, "fanout_gather": set_fanout, "concat_rows": set_concat}
+SW = {"wgrad_big": set_wgrad_big, "recompute_h": set_recompute_h, "grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred, "recurrent_batched": set_recurrent, "gather_ranges": set_gather_ranges, "fanout_gather": set_fanout, "concat_rows": set_concat}
 if hasattr(pol_mod, "TRUNK_WINDOWS"):
     SW["trunk_windows"] = set_trunk
 

@@ -36,3 +36,22 @@ for s, e, n in side:
         o = min(e, b_) - max(s, a_)
         if o > 0: ov[n] += o / 1e3
 print("side-stream kernel time that overlaps a k_step (us per pass):", {k: round(v / N, 2) for k, v in ov.items()})
+
+# is the main stream WAITING for tier 1?  per sampler launch: its start minus the end of the latest k_lr_finish that ended before it
+# (small and constant = the sampler starts as soon as that tier-1 launch is over); per k_lr_finish: its start minus the end of the k_step before it
+import bisect
+lf = sorted((int(r["End_Timestamp"]), int(r["Start_Timestamp"])) for r in win if "k_lr_finish" in r["Kernel_Name"])
+lf_end = [e for e, _ in lf]
+d1 = []
+for r in win:
+    if "k_sample_random" in r["Kernel_Name"]:
+        s0 = int(r["Start_Timestamp"]); i = bisect.bisect_right(lf_end, s0) - 1
+        if i >= 0: d1.append((s0 - lf_end[i]) / 1e3)
+ks_end = sorted(e for _, e in ks)
+d2 = []
+for e, s0 in lf:
+    i = bisect.bisect_right(ks_end, s0) - 1
+    if i >= 0: d2.append((s0 - ks_end[i]) / 1e3)
+q = lambda v, p: sorted(v)[int(p * (len(v) - 1))] if v else float("nan")
+print(f"sampler start - end of the latest finished k_lr_finish: p10 {q(d1, .1):.2f}  p50 {q(d1, .5):.2f}  p90 {q(d1, .9):.2f} us")
+print(f"k_lr_finish start - end of the k_step before it:        p10 {q(d2, .1):.2f}  p50 {q(d2, .5):.2f}  p90 {q(d2, .9):.2f} us")

@@ -44,4 +44,48 @@ for _ in range(REPS):
     gq, = torch.autograd.grad(o, qkv, go)
     db += int((gq != g0).flatten(1).any(1).sum())
 print(f"k_attn_mfma_fwd / _bwd: {REPS} runs of 204 800 sequences, differing rows {df} / sequences {db}", flush=True); bad += df + db
+# ---- round 5: the other kernels that pack bf16 pairs with v_cvt_pk_bf16_f32 - the row products, the LayerNorms of every width
+# (forward and the dX of their backward), the row gathers / per-board sums, the policy pass (tile encoder + heads + value, deterministic
+# arg-max actions) - each against its own first run.  (Weight gradients are fp32 atomic sums: their order is free by design, not checked.)
+def stable(name, fn, reps=REPS):
+    global bad
+    first = [t.detach().clone() for t in fn()]
+    diff = 0
+    for _ in range(reps):
+        diff += sum(int((a != b).reshape(a.shape[0], -1).any(1).sum()) for a, b in zip(fn(), first))
+    print(f"{name}: {reps} runs, differing rows {diff}", flush=True); bad += diff
+
+rows = 19 * 204800
+x64 = torch.randn(rows, 64, device="cuda", generator=g).to(torch.bfloat16)
+w128 = torch.randn(128, 64, device="cuda", generator=g).to(torch.bfloat16) * 0.1
+b128 = torch.randn(128, device="cuda", generator=g).to(torch.bfloat16)
+stable("k_linear_rows 64 -> 128 (3.9 M rows)", lambda: [nn_kernels._linear_rows(x64, w128, b128)], max(REPS // 3, 3))
+for width, nrows in ((64, rows), (128, 614400), (256, 614400), (512, 204800)):
+    ln = torch.nn.LayerNorm(width).cuda()
+    xs = torch.randn(nrows, width, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(nrows, width, device="cuda", generator=g).to(torch.bfloat16)
+    def fwd_bwd(ln=ln, xs=xs, gy=gy):
+        y = nn_kernels.small_layer_norm(xs, ln, relu=True)
+        gx, = torch.autograd.grad(y, xs, gy)
+        return [y, gx]
+    if nn_kernels.ln_supported(xs, ln):
+        stable(f"LayerNorm {width} forward + dX ({nrows} rows)", fwd_bwd, max(REPS // 3, 3))
+src = torch.randn(179200, 480, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+inv = torch.randint(0, 179200, (204800,), device="cuda", generator=g)
+order = torch.argsort(inv); start = torch.searchsorted(inv[order], torch.arange(179201, device="cuda"))
+gy = torch.randn(204800, 480, device="cuda", generator=g).to(torch.bfloat16)
+def expand():
+    y = nn_kernels.expand_rows(src, inv, order, start)
+    gs, = torch.autograd.grad(y, src, gy)
+    return [y, gs]
+stable("k_expand_rows16 + k_segment_sum16 (179 200 -> 204 800 rows of 480)", expand, max(REPS // 3, 3))
+env2 = VecCatanEnv(65536, seed=5); env2.random_rollout(0, 700)
+of, ol, on = env2.get_obs_rows(torch.bfloat16)
+mk = env2.get_action_masks()
+shadow = net.inference_copy(torch.bfloat16)
+def act():
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        v, a, lp = shadow.act(of, ol, on, mk, deterministic=True)[:3]
+    return [v.float(), a, lp.float()]
+stable("policy pass at 65 536 rows (k_tile_encoder_fwd, row kernels, k_head_fwd x 18, value head), arg-max actions", act, max(REPS // 3, 3))
 sys.exit(1 if bad else 0)
