@@ -55,7 +55,7 @@ struct catan_env {
     hipStream_t side;     // re-deals run here, concurrently with the longest-road kernels on the caller's stream
     hipEvent_t ev_fork, ev_join;
     hipStream_t fstream[2];  // deferred rollouts: tier-1 longest road + completion of iteration t run on fstream[t & 1] during t+1
-    hipEvent_t ev_fready[2], ev_fdone[2];
+    hipEvent_t ev_fready[3], ev_fdone[3];   // per tier-1 slot (the library's own deferred loop rotates three: deferred_iter_legacy)
     float* f_reward;      // [n][4] / [n]: outputs of the completions that run on fstream (scratch)
     u8* f_done;
     hipStream_t sstream;  // deferred rollouts: tier 2 + re-deals of window w run here during window w+1
@@ -351,7 +351,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // two tier-1 launches in flight take the SIMDs from k_step.)
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->fstream[0], hipStreamNonBlocking);
     e->fstream[1] = e->fstream[0];
-    for (int i = 0; i < 2 && rc == hipSuccess; i++) {
+    for (int i = 0; i < 3 && rc == hipSuccess; i++) {
         rc = hipEventCreateWithFlags(&e->ev_fready[i], EV_SYNC);
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_fdone[i], EV_SYNC);
     }
@@ -428,7 +428,7 @@ void catan_destroy(catan_env_t* e) {
     if (e->f_reward) hipFree(e->f_reward);
     if (e->f_done) hipFree(e->f_done);
     if (e->fstream[0]) hipStreamDestroy(e->fstream[0]);
-    for (int i = 0; i < 2; i++) { if (e->ev_fready[i]) hipEventDestroy(e->ev_fready[i]); if (e->ev_fdone[i]) hipEventDestroy(e->ev_fdone[i]); }
+    for (int i = 0; i < 3; i++) { if (e->ev_fready[i]) hipEventDestroy(e->ev_fready[i]); if (e->ev_fdone[i]) hipEventDestroy(e->ev_fdone[i]); }
     for (int i = 0; i < 2; i++) {
         if (e->pend.heavy[i]) hipFree(e->pend.heavy[i]);
         if (e->pend.resets[i][0]) hipFree(e->pend.resets[i][0]);
@@ -722,36 +722,47 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 }
 
 // The deferred iteration in its round 1-3 form (the default: catan_set_deferred_fused): a sampling + sorting kernel in front of
-// every k_step, busy tags cleared by it.  Iteration `it` uses tier-1 request list it & 1 with tag
-// 2 + (it & 1); window w = it / window uses slot w & 1 with tag 4 + (w & 1).
+// every k_step, busy tags cleared by it.  Window w = it / window uses slot w & 1 with tag 4 + (w & 1); the sort's bin sets alternate.
+// Tier 1 rotates D = 3 slots (request list, busy tag 2 / 3 / 6, event pair) by it % D: tier 1 of pass `it` runs on the side stream
+// during passes it+1 .. it+2 and its games play again in pass it + D.  With D = 2 (rounds 1-4: CATAN_T1_DEPTH=2) the loop's period was
+// set by a dependency cycle, not by the main stream's work: k_step(it) -> [event hand-over to the side stream, ~11 us] -> k_lr_finish
+// (~40 us: its slowest search) -> [hand-over back, ~11 us] -> sampler(it + 2), i.e. 2 P >= 62 us + sampler + k_step (43 us): P = 52.5 us
+// (measured 53.7-54.4, profiles/r05_k_step_pass_experiments.txt: "sampler start - end of the latest k_lr_finish: 11.3 us").  With D = 3
+// the cycle allows P >= 35 us and the pass is what the main stream runs, at the price of the longest-road games sitting out one more pass.
+static int t1_depth() {
+    static const int D = (getenv("CATAN_T1_DEPTH") && atoi(getenv("CATAN_T1_DEPTH")) == 2) ? 2 : 3;
+    return D;
+}
 static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
-    const int fa = (int)(it & 1);
+    const int D = t1_depth();
+    const int fa = (int)(it % D);                              // tier-1 slot of this pass
+    const int ftag = fa < 2 ? 2 + fa : 6;                      // (4, 5 are the window slots' tags)
+    const int ba = (int)(it & 1);                              // bin-count / list set of this pass
     e->ctr_clean = 0;                                          // (the lock-step path re-initialises the counters after this)
     const int64_t w = it / window;
     const int sa = (int)(w & 1);
     const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
-    if (it >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-2 is complete
+    if (it >= D) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));        // tier 1 of iteration it-D is complete
     if (it == 0) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
     else if (opens) {
         if (w >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));     // the slow path of window w-2 is complete
         HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
     }
-    e->pend.fa = fa; e->pend.ftag = 2 + fa; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = fa; e->pend.bclear = fa ^ 1; e->pend.sample = 0; e->pend.brel = -1;
+    e->pend.fa = fa; e->pend.ftag = ftag; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = ba; e->pend.bclear = ba ^ 1; e->pend.sample = 0; e->pend.brel = -1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
-                       e->pctr, e->pend.busy, 2 + fa, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + 4 + fa, 1,
-                       e->pend.ctr + 16 + NBINS * fa, e->pend.lists + (size_t)fa * NBINS * e->N);
+                       e->pctr, e->pend.busy, ftag, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + (fa < 2 ? 4 + fa : 7), 1,
+                       e->pend.ctr + 16 + NBINS * ba, e->pend.lists + (size_t)ba * NBINS * e->N);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
-    HIPCHK(hipStreamWaitEvent(e->fstream[fa], e->ev_fready[fa], 0));
-    r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[fa], ev, fa, e->lr_budget[1]);
+    HIPCHK(hipStreamWaitEvent(e->fstream[0], e->ev_fready[fa], 0));
+    r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[0], ev, fa, e->lr_budget[1]);
     if (r != CATAN_OK) return r;
-    HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[fa]));
+    HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[0]));
     if (closes) {
-        // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are
-        HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa], 0));
-        if (it >= 1) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[fa ^ 1], 0));
+        // the window's tier-2 / re-deal lists are complete once the outstanding tier-1 launches are (one side stream: the latest implies the others)
+        for (int k = 0; k < D && k <= it; k++) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[(fa + D - k) % D], 0));
         r = enqueue_slow(e, e->s_reward, e->s_done, e->sstream, ev, LR_HEAVY_GRID_DEFERRED);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_sdone[sa], e->sstream));

@@ -20,7 +20,11 @@ def _fwd(net, x):
     return net["c"](torch.relu(net["b"](net["ln"](net["a"](x)))))
 
 
-def _run(device, steps=50, clip=0.5):
+def _run(device, steps=50, clip=0.5, shared_grads=False):
+    """shared_grads: both optimisers are handed the SAME gradient values (the reference net's backward; `net` only follows).  On the
+    device the two nets' own backward passes are not bit-equal (the library GEMM's split-K sums depend on the launch), and fifty Adam
+    steps of a training run amplify that last-bit noise to 1e-5 in the parameters whoever's optimiser is used: what the kernel form
+    has to equal is torch's UPDATE of given gradients."""
     net, ref = _nets(device)
     mine, theirs = FusedAdam(net.parameters(), lr=3e-4, eps=1e-5), torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
     g = torch.Generator().manual_seed(1)
@@ -29,7 +33,12 @@ def _run(device, steps=50, clip=0.5):
         x = (torch.randn(16, 37, generator=g) * (1 + s % 5)).to(device)        # gradient norms on both sides of the clip threshold
         for n_, o in ((net, mine), (ref, theirs)):
             o.zero_grad()
+            if shared_grads and n_ is net:
+                continue
             (_fwd(n_, x) ** 2).mean().mul(0.02 if s % 3 else 5.0).backward()
+        if shared_grads:
+            for p, q in zip(net.parameters(), ref.parameters()):
+                p.grad = None if q.grad is None else q.grad.clone()
         tn = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
         theirs.step()
         mine.step(clip)
@@ -63,7 +72,10 @@ def test_state_dict_round_trip_cpu():
 
 @pytest.mark.gpu
 def test_fused_adam_kernels_equal_torch_adam_with_clipping(hip_lib):
-    _check(*_run("cuda"))
+    _check(*_run("cuda", shared_grads=True))
+    # two independent training runs (each net its own backward): equal up to the amplified last-bit noise of the backward passes
+    net, ref, norms, _ = _run("cuda")
+    assert max(float((p - q).abs().max()) for p, q in zip(net.parameters(), ref.parameters())) < 1e-4
 
 
 @pytest.mark.gpu
