@@ -225,6 +225,26 @@ typedef struct catan_te_saves {
 int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, const catan_te_saves_t* saves,
                                  int64_t boards, catan_stream_t stream);
 
+/* The tile encoder's backward with the forward RECOMPUTED on chip (csrc/catan_te_fused_bwd.hip; reference RL/models/tile_encoder.py:41-91 under
+ * RL/ppo/ppo.py:66's backward): the training forward stores ONE activation, the input of transformer layer 1 (128 B per token instead of the
+ * 2.4 KB of catan_te_saves_t), and two launches walk back through the encoder:
+ *   catan_tile_encoder_fwd_xin1     catan_tile_encoder_fwd + xin1 bf16 [boards * 19][64]
+ *   catan_tile_encoder_bwd_layer1   xin1, dout (bf16 [boards][out_pitch]: the gradient of `out`) -> dxin1 bf16 [boards * 19][64]
+ *   catan_tile_encoder_bwd_layer0   tiles (the forward's input), dxin1
+ * weights / vecs: catan_tile_encoder_fwd's packed parameters; wqt / wot / w1t / w2t: the layer's transposed bf16 weights Wqkv^T [64][192],
+ * Wo^T [64][64], W1^T [64][128], W2^T [128][64]; wpt32: out_proj^T [64][32] (columns 25..31 zero).  grads: float
+ * [catan_te_bwd_grad_floats(layer)], ZEROED by the caller, accumulated into (fp32 atomics): Wqkv [192][64] | bqkv [192] | Wo [64][64] | bo [64] |
+ * W1 [128][64] | b1 [128] | W2 [64][128] | b2 [64] | LayerNorm 1 weight, bias [64] each | LayerNorm 2 weight, bias [64] each | then layer 1:
+ * out_proj [32][64] (rows >= 25 unused) | its bias [32] | final LayerNorm weight, bias [32] each; layer 0: first_layer [64][64] (columns >= 60
+ * unused) | its bias [64] | its LayerNorm weight, bias [64] each. */
+int catan_tile_encoder_fwd_xin1(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, void* xin1, int64_t boards,
+                                catan_stream_t stream);
+int32_t catan_te_bwd_grad_floats(int32_t layer);
+int catan_tile_encoder_bwd_layer1(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t, const void* wpt32,
+                                  const void* xin1, const void* dout, int64_t out_pitch, void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
+int catan_tile_encoder_bwd_layer0(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t,
+                                  const void* tiles, const void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
+
 /* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
  * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.
  * pre: bfloat16 [B][..], the head's 128 columns of the trunk product all heads share (row pitch pre_ld elements); cond: float

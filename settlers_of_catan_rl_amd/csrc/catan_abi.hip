@@ -21,6 +21,7 @@
 #include "catan_te_bwd.hip"
 #include "catan_optim.hip"
 #include "catan_wgrad_big.hip"
+#include "catan_te_fused_bwd.hip"
 
 using namespace catan;
 
@@ -723,14 +724,15 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 
 // The deferred iteration in its round 1-3 form (the default: catan_set_deferred_fused): a sampling + sorting kernel in front of
 // every k_step, busy tags cleared by it.  Window w = it / window uses slot w & 1 with tag 4 + (w & 1); the sort's bin sets alternate.
-// Tier 1 rotates D = 3 slots (request list, busy tag 2 / 3 / 6, event pair) by it % D: tier 1 of pass `it` runs on the side stream
-// during passes it+1 .. it+2 and its games play again in pass it + D.  With D = 2 (rounds 1-4: CATAN_T1_DEPTH=2) the loop's period was
-// set by a dependency cycle, not by the main stream's work: k_step(it) -> [event hand-over to the side stream, ~11 us] -> k_lr_finish
-// (~40 us: its slowest search) -> [hand-over back, ~11 us] -> sampler(it + 2), i.e. 2 P >= 62 us + sampler + k_step (43 us): P = 52.5 us
-// (measured 53.7-54.4, profiles/r05_k_step_pass_experiments.txt: "sampler start - end of the latest k_lr_finish: 11.3 us").  With D = 3
-// the cycle allows P >= 35 us and the pass is what the main stream runs, at the price of the longest-road games sitting out one more pass.
+// Tier 1 rotates D slots (request list, busy tag 2 / 3 / 6, event pair) by it % D: tier 1 of pass `it` runs on the side stream during
+// the passes that follow and its games play again in pass it + D.  D = 2 is the default.  With D = 2 the loop's period is tied to a
+// dependency cycle: k_step(it) -> [event hand-over to the side stream, ~11 us] -> k_lr_finish (~40 us: its slowest search) -> [hand-over
+// back, ~11 us] -> sampler(it + 2), i.e. 2 P >= 62 us + sampler + k_step (profiles/r05_k_step_pass_experiments.txt).  D = 3
+// (CATAN_T1_DEPTH=3) frees the cycle (P >= 36 us) - measured (same file, session 12): 54.3 -> 52.8 us per pass, but the longest-road
+// games sit out one more pass (92.6 -> 90.0 % of the games active): 1.118 G env-steps/s either way.  What keeps the pass above the main
+// stream's own 45 us is then the event record / wait packets around every pass (~7 us of gaps) and the side work's share of the CUs.
 static int t1_depth() {
-    static const int D = (getenv("CATAN_T1_DEPTH") && atoi(getenv("CATAN_T1_DEPTH")) == 2) ? 2 : 3;
+    static const int D = (getenv("CATAN_T1_DEPTH") && atoi(getenv("CATAN_T1_DEPTH")) == 3) ? 3 : 2;
     return D;
 }
 static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
@@ -1642,7 +1644,7 @@ int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* 
     long nb = (boards + TE_G - 1) / TE_G;
     TeSaves sv;
     memset(&sv, 0, sizeof sv);
-    hipLaunchKernelGGL(k_tile_encoder_fwd<false>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+    hipLaunchKernelGGL(k_tile_encoder_fwd<0>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
                        (unsigned short*)out, (long)boards, sv, (long)(TE_L * TE_OUT));
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -1662,8 +1664,53 @@ int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const f
     TeSaves sv;
     memcpy(&sv, saves, sizeof sv);
     long nb = (boards + TE_G - 1) / TE_G;
-    hipLaunchKernelGGL(k_tile_encoder_fwd<true>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+    hipLaunchKernelGGL(k_tile_encoder_fwd<1>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
                        (unsigned short*)out, (long)boards, sv, (long)out_pitch);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+// The training forward of the recomputing backward: the inference kernel + the input of layer 1 (xin1 bf16 [boards * 19][64]).
+int catan_tile_encoder_fwd_xin1(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, void* xin1, int64_t boards,
+                                catan_stream_t stream) {
+    if (!tiles || !weights || !vecs || !out || !xin1 || boards <= 0 || out_pitch < TE_L * TE_OUT || ((uintptr_t)xin1 & 15))
+        return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_xin1: bad arguments");
+    TeSaves sv;
+    memset(&sv, 0, sizeof sv);
+    sv.xin[1] = (unsigned short*)xin1;
+    long nb = (boards + TE_G - 1) / TE_G;
+    hipLaunchKernelGGL(k_tile_encoder_fwd<2>, dim3((unsigned)nb), dim3(TE_THREADS), 0, S(stream), (const unsigned short*)tiles, (const unsigned short*)weights, vecs,
+                       (unsigned short*)out, (long)boards, sv, (long)out_pitch);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int32_t catan_te_bwd_grad_floats(int32_t layer) { return layer == 1 ? TG_TOTAL1 : TG_TOTAL0; }
+static int te_bwd_grid(long boards) {
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t p; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; if (cus <= 0) cus = 256; }
+    const long groups = (boards + TE_G - 1) / TE_G;
+    return (int)(groups < cus ? groups : cus);
+}
+int catan_tile_encoder_bwd_layer1(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t, const void* wpt32,
+                                  const void* xin1, const void* dout, int64_t out_pitch, void* dxin1, float* grads, int64_t boards, catan_stream_t stream) {
+    if (!weights || !vecs || !wqt || !wot || !w1t || !w2t || !wpt32 || !xin1 || !dout || !dxin1 || !grads || boards <= 0 || out_pitch < TE_L * TE_OUT ||
+        (((uintptr_t)weights | (uintptr_t)vecs | (uintptr_t)wqt | (uintptr_t)wot | (uintptr_t)w1t | (uintptr_t)w2t | (uintptr_t)wpt32 | (uintptr_t)xin1 | (uintptr_t)dxin1) & 15) ||
+        ((uintptr_t)dout & 1))
+        return fail(CATAN_EINVAL, "catan_tile_encoder_bwd_layer1: null or misaligned argument");
+    TeBwdArgs a = { (const unsigned short*)weights, vecs, (const unsigned short*)wqt, (const unsigned short*)wot, (const unsigned short*)w1t, (const unsigned short*)w2t,
+                    (const unsigned short*)wpt32, (const unsigned short*)xin1, (const unsigned short*)dout, (unsigned short*)dxin1, grads, (long)boards, (long)out_pitch };
+    hipLaunchKernelGGL(k_te_bwd_layer<1>, dim3((unsigned)te_bwd_grid(boards)), dim3(TB_THREADS), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_tile_encoder_bwd_layer0(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t,
+                                  const void* tiles, const void* dxin1, float* grads, int64_t boards, catan_stream_t stream) {
+    if (!weights || !vecs || !wqt || !wot || !w1t || !w2t || !tiles || !dxin1 || !grads || boards <= 0 ||
+        (((uintptr_t)weights | (uintptr_t)vecs | (uintptr_t)wqt | (uintptr_t)wot | (uintptr_t)w1t | (uintptr_t)w2t | (uintptr_t)dxin1) & 15) || ((uintptr_t)tiles & 7))
+        return fail(CATAN_EINVAL, "catan_tile_encoder_bwd_layer0: null or misaligned argument");
+    TeBwdArgs a = { (const unsigned short*)weights, vecs, (const unsigned short*)wqt, (const unsigned short*)wot, (const unsigned short*)w1t, (const unsigned short*)w2t,
+                    nullptr, (const unsigned short*)tiles, (const unsigned short*)dxin1, nullptr, grads, (long)boards, 0L };
+    hipLaunchKernelGGL(k_te_bwd_layer<0>, dim3((unsigned)te_bwd_grid(boards)), dim3(TB_THREADS), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

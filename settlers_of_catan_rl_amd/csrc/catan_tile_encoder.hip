@@ -258,13 +258,16 @@ DEVI void te_dump(const unsigned short* lds, int pitch, unsigned short* __restri
     }
 }
 // tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
-template <bool SAVE>
+// SAVE_MODE 0: inference; 1: every activation of TeSaves (the sub-layer backward kernels of catan_te_bwd.hip); 2: only sv.xin[1], the input
+// of layer 1 - what the recomputing backward (catan_te_fused_bwd.hip) reads besides the tile features
+template <int SAVE_MODE>
 __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
                                                           const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards, TeSaves sv, long out_pitch) {
     __shared__ __attribute__((aligned(16))) unsigned short X[TE_ROWS * TE_PX];     // residual stream
     __shared__ __attribute__((aligned(16))) unsigned short Nb[TE_ROWS * TE_PX];    // LayerNorm output / attention output / staged input
     __shared__ __attribute__((aligned(16))) unsigned short Q[TE_ROWS * TE_PQ];     // Q | K | V; the FFN hidden layer; the output projection
     __shared__ __attribute__((aligned(16))) float V[TE_VTOTAL];                    // every bias / LayerNorm vector (read in every phase)
+    constexpr bool SAVE = SAVE_MODE == 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* const gvecs = vecs;
     for (int c = tid; c < TE_VTOTAL / 4; c += TE_THREADS) reinterpret_cast<float4*>(V)[c] = reinterpret_cast<const float4*>(gvecs)[c];
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const float* vl = V + TE_VL + l * TE_VL_SIZE;
             // x = x + out_proj(attention(qkv(LayerNorm(x))))
             TeW<64, 192> wq; te_fetch<64, 192>(wq, wl, lane, wave);
-            if (SAVE) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
+            if (SAVE || (SAVE_MODE == 2 && l == 1)) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl, vl + 64, tid);
             __syncthreads();
             if (SAVE && sv.n1[l] != nullptr) te_dump<64>(Nb, TE_PX, sv.n1[l], t0, nt, tid);   // (optional: the backward can recompute it)

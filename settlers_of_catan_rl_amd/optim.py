@@ -66,6 +66,7 @@ class FusedAdam(object):
             # after the event recorded behind its copy has completed
             "grads_host": torch.zeros((self.RING, len(self.params)), dtype=torch.int64).pin_memory(),
             "grads": torch.zeros((self.RING, len(self.params)), dtype=torch.int64, device=dev),
+            "grads_host_np": None,
             "events": [None] * self.RING, "slot": 0,
             "partial": torch.zeros(len(chunks), dtype=torch.float64, device=dev),
             "norm": torch.zeros(1, dtype=torch.float32, device=dev),
@@ -94,18 +95,22 @@ class FusedAdam(object):
         if self._tables is None or self._tables["sig"] != tuple(p.data_ptr() for p in self.params):
             self._build_tables()
         t = self._tables
+        if t["grads_host_np"] is None:
+            t["grads_host_np"] = t["grads_host"].numpy()      # shares the pinned memory
         k = t["slot"] = (t["slot"] + 1) % self.RING
         if t["events"][k] is not None:
             t["events"][k].synchronize()                      # the copy (and the step) that last used this row is done
-        host = t["grads_host"][k]
-        for i, p in enumerate(self.params):
+        ptrs = []
+        for p in self.params:
             gr = p.grad
             if gr is None:
-                host[i] = 0
+                ptrs.append(0)
                 continue
             if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.data_ptr() % 16:
                 gr = p.grad = gr.float().contiguous().clone()
-            host[i] = gr.data_ptr()
+            ptrs.append(gr.data_ptr())
+        t["grads_host_np"][k, :] = ptrs                       # (one numpy assignment: element-wise writes into the tensor were ~300 aten ops per step)
+        host = t["grads_host"][k]
         t["grads"][k].copy_(host, non_blocking=True)
         P = lambda x: C.c_void_p(x.data_ptr())
         _lib.check(_lib.lib().catan_adam_step(P(t["tensors"]), P(t["chunks"]), t["n_chunks"], P(t["grads"][k]), P(t["partial"]), clip, lr, b1, b2, eps,

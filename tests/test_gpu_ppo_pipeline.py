@@ -1168,6 +1168,7 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             monkeypatch.setenv("CATAN_TE_BWD_OP", "0" if mode == "fused, out-projection backward in its own kernels" else "1")
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_N", {"fused, LayerNorm outputs stored": "0", "fused, LayerNorm-2 outputs stored": "1"}.get(mode, "2"))
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_H", "1" if mode == "fused, hidden FFN activation recomputed" else "0")
+            monkeypatch.setattr(nn_kernels, "TE_FUSED_BWD", mode == "fused, forward recomputed in the backward")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
@@ -1192,6 +1193,16 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         # backward passes see the same h up to MFMA summation order
         oh, gh = run(tiles, "fused, hidden FFN activation recomputed")
         assert torch.equal(oh, of)
+        # the backward that recomputes the forward on chip (k_te_bwd_layer<1>, <0>; the training forward stores only the input of layer 1;
+        # off by default: slower, nn_kernels.TE_FUSED_BWD).  Same forward arithmetic: the same output bits; gradients as close to the
+        # sub-layer kernels' as those are to each other
+        orc, grc = run(tiles, "fused, forward recomputed in the backward")
+        assert torch.equal(orc, of)
+        for n in names:
+            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
+            assert float((gf[n] - grc[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - grc[n]).norm()) / scale)
+            d_r, d_u = float((grc[n] - g32[n]).norm()) / scale, float((gu[n] - g32[n]).norm()) / scale
+            assert d_r <= max(2.0 * d_u, 0.05), (B, n, d_r, d_u)
         for n in names:
             scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
             assert float((gf[n] - gh[n]).norm()) / scale <= 0.01, (B, n, float((gf[n] - gh[n]).norm()) / scale)
