@@ -105,7 +105,8 @@ int catan_step_flush(catan_env_t* env, float* reward, uint8_t* done, uint8_t* st
 
 /* EnvWrapper.get_action_masks(): env/wrapper.py:168-290, batched float32 [n][325]. */
 int catan_masks(catan_env_t* env, float* out_masks, catan_stream_t stream);
-/* the same masks as 325-bit strings: uint32 [n][pitch], pitch = 16 words (bit i of the flat mask = word i>>5, bit i&31) */
+/* the same masks as 325-bit strings: uint32 [n][pitch], pitch AS RETURNED in *out_pitch (currently 32 words = one 128-byte line per game: words 0..10
+ * are the mask bits - bit i of the flat mask = word i>>5, bit i&31 - the rest is the library's own side data; never hard-code the pitch) */
 int catan_masks_packed(catan_env_t* env, const uint32_t** out_ptr, int64_t* out_pitch);
 /* the masks of catan_masks as packed rows of 11 words, uint32 [n][11] (what the rollout storage keeps per decision) */
 int catan_masks_packed_copy(catan_env_t* env, uint32_t* out, catan_stream_t stream);

@@ -111,8 +111,9 @@ int catan_concat_rows(const void* const* srcs, const int64_t* row_bytes, int n, 
  * head takes one or two runs of that order): out row perm[p] = the sum (fp32, rounded to bf16) of the bf16 rows dy[off_k + p - a_k]
  * over the ranges a_k <= p < b_k, plus the rows perm[p] of add0 / add1 (either may be NULL: the gradients that the source tensor's other
  * consumers produced, [n_perm][row] contiguous - autograd would add them in two more passes), zeros for a row with no term.
- * ranges: HOST array of n_ranges <= 16 triples (a, b, off); perm: a permutation of 0 .. n_perm - 1 (device); rows of whole
- * 16-byte pieces, dy's rows dy_pitch_bytes apart. */
+ * ranges: HOST array of n_ranges <= 16 triples (a, b, off), their rows of dy CONSECUTIVE from row 0 (off_0 = 0, off_k = off_k-1 + b_k-1 - a_k-1:
+ * dy holds sum(b_k - a_k) rows; anything else is rejected); perm (device): MUST be a permutation of 0 .. n_perm - 1 - a row that perm misses
+ * is not written (the caller's `out` is uninitialised memory); rows of whole 16-byte pieces, dy's rows dy_pitch_bytes apart. */
 int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges,
                               const void* add0, const void* add1, void* out, int64_t row_bytes, catan_stream_t stream);
 

@@ -522,10 +522,14 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     return CATAN_OK;
 }
 // tier 1 + completion of request list `fl` on stream `st`.  ev (optional): recorded on st: [8] before, [6] after
+static int lr_grid() {      // workgroups of k_lr_finish (CATAN_LR_GRID: diagnostics, tools/pass_experiments.py)
+    static const int g = (getenv("CATAN_LR_GRID") && atoi(getenv("CATAN_LR_GRID")) >= 64) ? atoi(getenv("CATAN_LR_GRID")) : LR_GRID;
+    return g;
+}
 static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    hipLaunchKernelGGL(k_lr_finish, dim3(LR_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    hipLaunchKernelGGL(k_lr_finish, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -1206,7 +1210,8 @@ int catan_linear_wgrad_grouped(const catan_wgrad_problem_t* problems, int32_t n,
             return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad problem / unsupported widths");
         if (((uintptr_t)q.x | (uintptr_t)q.dy) & 15) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: x and dy must be 16-byte aligned");
         const int I = q.in_features, O = q.out_features;
-        if (q.dw_ld < 0 || q.dw_col0 < 0 || (q.dw_ld != 0 && q.dw_col0 + I > q.dw_ld)) return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad dw window");
+        if (q.dw_ld < 0 || q.dw_col0 < 0 || (q.dw_ld != 0 && q.dw_col0 + I > q.dw_ld) || (q.dw_ld == 0 && q.dw_col0 != 0))
+            return fail(CATAN_EINVAL, "catan_linear_wgrad_grouped: bad dw window (a column offset needs the leading dimension of dw)");
         const long ldw = q.dw_ld ? q.dw_ld : I;
         const int otw = ((O + 15) / 16 + 3) / 4;
         Unit t; long per;
@@ -1335,6 +1340,9 @@ int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int6
     for (int k = 0; k < n_ranges; k++) {
         rg.a[k] = ranges[3 * k]; rg.b[k] = ranges[3 * k + 1]; rg.off[k] = ranges[3 * k + 2];
         if (rg.a[k] < 0 || rg.b[k] < rg.a[k] || rg.b[k] > n_perm || rg.off[k] < 0) return fail(CATAN_EINVAL, "catan_scatter_rows_ranges: a range outside the permutation");
+        // the ranges' rows of dy follow each other (nn_kernels.gather_ranges lays them out that way): range k starts where range k - 1 ended, so
+        // dy holds exactly the sum of the range lengths rows and no offset can point past it
+        if (rg.off[k] != (k ? rg.off[k - 1] + (rg.b[k - 1] - rg.a[k - 1]) : 0)) return fail(CATAN_EINVAL, "catan_scatter_rows_ranges: the ranges' rows of dy must be consecutive from row 0");
     }
     const int chunks = (int)(row_bytes / 16);
     const long total = n_perm * chunks, nb = (total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536;

@@ -46,6 +46,8 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     rng3 = (C.c_int64 * 3)(0, 9, 0)
     assert "16 ranges" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 17, None, None, P(b16), 1024, st))
     assert "outside the permutation" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng3, C.c_void_p), 1, None, None, P(b16), 1024, st))
+    rng6 = (C.c_int64 * 6)(0, 4, 0, 2, 6, 9)          # the second range's rows of dy do not follow the first's
+    assert "consecutive" in err(L.catan_scatter_rows_ranges(P(b16), 1024, P(idx), 8, C.cast(rng6, C.c_void_p), 2, None, None, P(b16), 1024, st))
     assert "null or misaligned" in err(L.catan_ffn_bwd_dx(P(b16), None, P(b16), P(b16), P(b16), P(dw), 1e-5, P(b16), P(b16), P(dw), P(dw), 16, st))
     assert "null or misaligned" in err(L.catan_qkv_bwd_dx(P(b16), P(b16), C.c_void_p(b16.data_ptr() + 8), P(b16), P(dw), 1e-5, P(b16), P(dw), P(dw), 16, st))
     assert "null or misaligned" in err(L.catan_ffn_bwd(P(b16), P(b16), P(b16), None, P(b16), P(b16), P(dw), None, 1e-5, P(b16), P(dw), P(dw), P(dw), P(dw), P(dw), P(dw), 16, st))
