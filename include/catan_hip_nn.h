@@ -106,6 +106,14 @@ int catan_segment_sum_rows(const void* dy, int64_t dy_pitch_bytes, const int64_t
  * the player modules' outputs).  srcs, row_bytes: HOST arrays of n <= 4 device pointers / row sizes (whole 16-byte pieces, contiguous
  * rows); out's rows lie out_pitch_bytes apart. */
 int catan_concat_rows(const void* const* srcs, const int64_t* row_bytes, int n, void* out, int64_t out_pitch_bytes, int64_t rows, catan_stream_t stream);
+/* The inputs of a recurrent resource head (RL/models/action_heads_module.py:258-329: give / receive lists of a proposed trade) evaluated
+ * for GIVEN picks: with the four picks known every step's conditioning columns, mask and weight are functions of the earlier picks, so the
+ * head runs ONCE over 4 * rows step-major rows (row i * rows + b = step i of row b).  acts int64, rows acts_ld elements apart, columns 0..3 =
+ * the picks (0 = stop .. 5); cur_res float [rows][6]; fixed float [rows][kf] or NULL (kf <= 32): columns in front of the running counts.
+ * -> cond [4 rows][kf + 6] (bfloat16 if cond_bf16 else float), mask float [4 rows][6], given int64 [4 rows], keep float [rows][4] (a step
+ * counts only behind a non-stop pick, :306-312), out_final float [rows][6] (the counts of all four picks, column 0 cleared). */
+int catan_recurrent_given(const int64_t* acts, int64_t acts_ld, const float* cur_res, const float* fixed, int32_t kf, int32_t from_hand, int64_t rows, int32_t cond_bf16,
+                          void* cond, float* mask, int64_t* given, float* keep, float* out_final, catan_stream_t stream);
 /* The backward of a gather whose index list is a concatenation of ranges of a permutation (the action heads' rows of a PPO minibatch:
  * action_heads_module.py:61-160 evaluates a head on the rows of its action types; here the rows are sorted by type once and every
  * head takes one or two runs of that order): out row perm[p] = the sum (fp32, rounded to bf16) of the bf16 rows dy[off_k + p - a_k]

@@ -1329,6 +1329,18 @@ int catan_concat_rows(const void* const* srcs, const int64_t* row_bytes, int n, 
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }
+int catan_recurrent_given(const int64_t* acts, int64_t acts_ld, const float* cur_res, const float* fixed, int32_t kf, int32_t from_hand, int64_t rows, int32_t cond_bf16,
+                          void* cond, float* mask, int64_t* given, float* keep, float* out_final, catan_stream_t stream) {
+    if (!acts || !cur_res || !cond || !mask || !given || !keep || !out_final || rows <= 0 || acts_ld < 4 || kf < 0 || kf > 32 || (kf > 0 && !fixed))
+        return fail(CATAN_EINVAL, "catan_recurrent_given: bad arguments");
+    const unsigned nb = (unsigned)((rows + 255) / 256);
+    if (cond_bf16) hipLaunchKernelGGL(k_recurrent_given<true>, dim3(nb), dim3(256), 0, S(stream), (const long long*)acts, (long)acts_ld, cur_res, fixed, (int)kf, (int)from_hand, (long)rows,
+                                      cond, mask, (long long*)given, keep, out_final);
+    else hipLaunchKernelGGL(k_recurrent_given<false>, dim3(nb), dim3(256), 0, S(stream), (const long long*)acts, (long)acts_ld, cur_res, fixed, (int)kf, (int)from_hand, (long)rows,
+                            cond, mask, (long long*)given, keep, out_final);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
 int catan_scatter_rows_ranges(const void* dy, int64_t dy_pitch_bytes, const int64_t* perm, int64_t n_perm, const int64_t* ranges, int n_ranges,
                               const void* add0, const void* add1, void* out, int64_t row_bytes, catan_stream_t stream) {
     if (!dy || !perm || !ranges || !out || n_perm <= 0 || n_ranges < 0 || n_ranges > SR_MAX || row_bytes <= 0 || (row_bytes & 15) ||

@@ -131,4 +131,52 @@ __global__ __launch_bounds__(256) void k_weight_images(const WeightImage* __rest
         else reinterpret_cast<float*>(w.dst)[o] = te_bf(te_to_bf(v));
     }
 }
+// The conditioning columns, masks and step weights of a recurrent resource head evaluated for GIVEN picks (the PPO update;
+// RL/models/action_heads_module.py:258-329: with the four picks known, every step's inputs are functions of the earlier picks alone).
+// One lane per row b; step-major outputs (row i * B + b = step i of row b), as policy._recurrent_given lays them out for ONE
+// evaluation of the head over 4 B rows:
+//   cond [4 B][kf + 6]  fixed[b][0..kf) | out_i[b][0..6): how often each resource was picked before step i, column 0 ("stop") cleared
+//   mask [4 B][6]       from_hand: (hand - earlier picks, clamped at 0) > 0, else ones; column 0: step 0: the hand is empty, later steps: 1
+//   given [4 B]         the picks, step-major;   keep [B][4]: 1, pick_0 > 0, pick_1 > 0, pick_2 > 0
+//   out_final [B][6]    the counts of all four picks, column 0 cleared
+// acts: int64 rows acts_ld elements apart (a column window of the action rows); cur_res: float [B][6]; fixed: float [B][kf] or null.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_recurrent_given(const long long* __restrict__ acts, long acts_ld, const float* __restrict__ cur_res, const float* __restrict__ fixed,
+                                                         int kf, int from_hand, long B, void* __restrict__ cond, float* __restrict__ mask, long long* __restrict__ given,
+                                                         float* __restrict__ keep, float* __restrict__ out_final) {
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float hand[6], cnt[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; r++) { hand[r] = cur_res[b * 6 + r]; tot += hand[r]; }
+    const int W = kf + 6;
+    int prev = 1;
+    for (int i = 0; i < 4; i++) {
+        const long row = (long)i * B + b;
+        long long a = acts[b * acts_ld + i];
+        a = a < 0 ? 0 : (a > 5 ? 5 : a);
+        given[row] = a;
+        keep[b * 4 + i] = prev > 0 ? 1.f : 0.f;
+        prev = (int)a;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            float m = from_hand ? (fmaxf(hand[r] - cnt[r], 0.f) > 0.f ? 1.f : 0.f) : 1.f;
+            if (r == 0) m = i == 0 ? (tot == 0.f ? 1.f : 0.f) : 1.f;
+            mask[row * 6 + r] = m;
+            const float o = r == 0 ? 0.f : cnt[r];
+            if (BF16) reinterpret_cast<__hip_bfloat16*>(cond)[row * W + kf + r] = __float2bfloat16(o);
+            else reinterpret_cast<float*>(cond)[row * W + kf + r] = o;
+        }
+        for (int k = 0; k < kf; k++) {
+            const float f = fixed[b * kf + k];
+            if (BF16) reinterpret_cast<__hip_bfloat16*>(cond)[row * W + k] = __float2bfloat16(f);
+            else reinterpret_cast<float*>(cond)[row * W + k] = f;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) cnt[r] += (r == (int)a) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) out_final[b * 6 + r] = r == 0 ? 0.f : cnt[r];
+}
+
 }  // namespace catan

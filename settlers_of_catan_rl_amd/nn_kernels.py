@@ -1575,6 +1575,27 @@ def categorical_supported(logits):
     return logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
 
 
+def recurrent_given(acts, cur_res, fixed, from_hand, dtype):
+    """catan_recurrent_given: acts int64 [B, >= 4] (any row stride), cur_res float [B, 6], fixed float [B, kf] or None ->
+    (cond [4B, kf + 6] in `dtype`, mask [4B, 6], given int64 [4B], keep [B, 4], out_final [B, 6])"""
+    B, dev = acts.shape[0], acts.device
+    if acts.stride(1) != 1:
+        acts = acts.contiguous()
+    cr = cur_res.float().contiguous()
+    fx = None if fixed is None else fixed.float().contiguous()
+    kf = 0 if fx is None else fx.shape[1]
+    bf = dtype == torch.bfloat16
+    cond = torch.empty((4 * B, kf + 6), dtype=torch.bfloat16 if bf else torch.float32, device=dev)
+    mask = torch.empty((4 * B, 6), dtype=torch.float32, device=dev)
+    given = torch.empty((4 * B,), dtype=torch.int64, device=dev)
+    keep = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    outf = torch.empty((B, 6), dtype=torch.float32, device=dev)
+    if B:
+        _lib.check(_lib.lib().catan_recurrent_given(_ptr(acts), acts.stride(0), _ptr(cr), _ptr(fx) if fx is not None else None, kf, int(bool(from_hand)), B, int(bf),
+                                                    _ptr(cond), _ptr(mask), _ptr(given), _ptr(keep), _ptr(outf), _stream()))
+    return cond, mask, given, keep, outf
+
+
 class UniformPool(object):
     """The uniforms of all the categorical draws of one policy pass from ONE `torch.rand` (a pass makes 18 draws; at rollout
     width every launch counts): pass it where a generator is expected; rows are handed out in call order."""

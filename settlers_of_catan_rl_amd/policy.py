@@ -29,6 +29,7 @@ from . import nn_kernels, spec
 T_SETTLE, T_ROAD, T_CITY, T_BUYDEV, T_PLAYDEV, T_EXCHANGE, T_PROPOSE, T_RESPOND, T_ROBBER, T_ROLL, T_ENDTURN, T_STEAL, T_DISCARD = range(13)
 C_YOP, C_MONO = 2, 4
 MO = spec.MASK_OFFSETS
+MASK_N = spec.MASK_WORDS
 
 
 def _ortho_linear(i, o, gain=math.sqrt(2)):
@@ -354,6 +355,32 @@ class _Head(nn.Module):
         return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
 
 
+class PackedActionMasks(object):
+    """The action masks of a batch as the env's packed rows (int32 [B, 11]: bit i of the flat 325-entry mask = word i >> 5, bit i & 31),
+    expanded on demand.  The learner's compact evaluation needs the 13 type bits of every row and the full rows of the ~170 000 rows
+    some head runs on: expanding all 204 800 rows to fp32 (266 MB) and gathering 1 300-byte rows out of that (another 440 MB moved) was
+    0.24 ms of a minibatch step; gathering the 44-byte packed rows and expanding those is 0.07."""
+
+    def __init__(self, packed, unpack):
+        self.packed, self.unpack, self._dense = packed, unpack, None
+        self.shape, self.device, self.is_cuda = (packed.shape[0], MASK_N), packed.device, packed.is_cuda
+
+    def float(self):
+        return self
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = self.unpack(self.packed)
+        return self._dense
+
+    def rows(self, idx):
+        return self.unpack(self.packed[idx])
+
+    def type_mask(self):
+        w = self.packed[:, 0]
+        return ((w[:, None] >> torch.arange(13, device=w.device, dtype=w.dtype)) & 1).float()
+
+
 def _masked_logp(logits, mask):
     """log-softmax of logits + log(mask) (distributions.py:35-38)."""
     return F.log_softmax(logits + torch.log(mask), dim=-1)
@@ -565,7 +592,8 @@ class _ActionHeads(nn.Module):
         B, dev, H, D = main.shape[0], main.device, self.action_heads, self.D
         typ, card = actions[:, 0], actions[:, 4]
         pre_of = lambda i, x: _lin(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
-        type_head = lambda x: _categorical(H[0].logits(pre_of(0, x)), m[:, MO[0]:MO[0] + 13], typ, False, None)
+        packed = isinstance(m, PackedActionMasks)
+        type_head = lambda x: _categorical(H[0].logits(pre_of(0, x)), m.type_mask() if packed else m[:, MO[0]:MO[0] + 13], typ, False, None)
         # one sort by (type, card of a played development card) and one host read give every head's rows
         perm, ends, ev = grouping if grouping is not None else self.start_grouping(actions)
         if ev is not None:
@@ -608,7 +636,7 @@ class _ActionHeads(nn.Module):
             mg = nn_kernels.gather_ranges(main, perm, all_rows, pieces)
         self.last_value = value_fn(m_val) if value_fn is not None else None
         _, logp0, e0 = type_head(m_type)
-        mm_g, ag = m[all_rows], actions[all_rows]
+        mm_g, ag = (m.rows(all_rows) if packed else m[all_rows]), actions[all_rows]
         at, off = {}, 0
         for i in order:
             at[i] = slice(off, off + sets[i].numel()); off += sets[i].numel()
@@ -621,7 +649,7 @@ class _ActionHeads(nn.Module):
 
         def run(i, sl, mask, col, extra=None, custom=None):
             _, lp, ent = _categorical(H[i].logits(pre[i], extra, custom), mask, ag[sl, col], False, None)
-            lps.append((sl, lp)); ents.append(ent.sum())
+            lps.append((sl, lp)); ents.append(ent)
 
         def two_hot(n_first, n):
             x = torch.zeros(n, 2, device=dev); x[:n_first, 0] = 1.0; x[n_first:, 1] = 1.0
@@ -645,7 +673,7 @@ class _ActionHeads(nn.Module):
             give_out, _, lp7, e7 = self._recurrent(H[7], pre[7], None, cr, True, ag[sl, 7:11], False, None)
             filt7 = (lp7 == 0).float()                                           # action_heads_module.py:175
             _, _, lp8, e8 = self._recurrent(H[8], pre[8], give_out * (1 - filt7)[:, None], cr, False, ag[sl, 11:15], False, None)
-            lps.append((sl, lp7 + lp8)); ents.append(e7.sum() + e8.sum())
+            lps.append((sl, lp7 + lp8)); ents.append(e7 + e8)
         n_ex, n_yop = rex.numel(), ryop.numel()
         for i in (9, 10):  # resources of an exchange / a Year of Plenty or Monopoly card
             if i not in at:
@@ -663,11 +691,12 @@ class _ActionHeads(nn.Module):
                 run(9, sl, mask, 15, x)
             else:
                 run(10, sl, mm_g[sl, MO[10]:MO[10] + 5], 16, torch.cat((x, F.one_hot(ag[sl, 15], 5).float()), -1))
-        lp_all = torch.zeros(all_rows.numel(), device=dev)
-        for sl, lp in lps:
-            lp_all[sl] = lp
-        logp = logp0.index_add(0, all_rows, lp_all)
-        return actions.clone(), logp, (e0.sum() + torch.stack(ents).sum()) / B
+        # every segment of all_rows got exactly one log-prob vector: ONE concatenation in segment order (not a zero fill + a slice copy per
+        # head), one index_add back to the batch rows; the entropies as one sum over one concatenation (not a reduction per head)
+        lps.sort(key=lambda t: t[0].start)
+        assert sum(lp.numel() for _, lp in lps) == all_rows.numel()
+        logp = logp0.index_add(0, all_rows, torch.cat([lp for _, lp in lps]))
+        return actions.clone(), logp, torch.cat([e0] + ents).sum() / B
 
     def _recurrent(self, head, pre, fixed, cur_res, from_hand, acts, deterministic, generator):
         """RecurrentResourceActionHead.forward (action_heads_module.py:258-329) without the final type mask.
@@ -715,6 +744,12 @@ class _ActionHeads(nn.Module):
         recurrence of action_heads_module.py:258-329 only exists while sampling.  Same values as the loop (rows are independent; the
         step's log-prob / entropy count only behind a non-stop pick, :306-312); a quarter of its launches, forward and backward."""
         B = pre.shape[0]
+        if pre.is_cuda and acts.dtype == torch.int64 and pre.dtype in (torch.bfloat16, torch.float32):
+            # every input of the one evaluation from ONE kernel (catan_recurrent_given) instead of ~45 small launches (one_hot, cumsum, clamp,
+            # comparisons, concatenations, repeats: 0.3 ms of a minibatch step for the two trade heads)
+            cond, mask, given, keep, out_final = nn_kernels.recurrent_given(acts, cur_res, fixed, from_hand, pre.dtype)
+            _, lp, ent = _categorical(head.logits(pre.repeat(4, 1), cond), mask, given, False, None)
+            return out_final, acts[:, :4], (lp.reshape(4, B).t() * keep).sum(1), (ent.reshape(4, B).t() * keep).sum(1)
         onehot = F.one_hot(acts[:, :4], 6).float()                                   # [B, 4, 6]
         before = torch.cumsum(onehot, 1) - onehot                                     # picks before step i
         res = torch.clamp(cur_res[:, None, :] - before, min=0)                        # [B, 4, 6]
@@ -739,6 +774,8 @@ class _ActionHeads(nn.Module):
         -> actions [B,18], joint log-prob [B], entropy (scalar, action_heads_module.py:159-160,174)."""
         if actions is not None and forced_type is None and self.compact_evaluate and main.shape[0] >= self.compact_min_rows:
             return self._evaluate_compact(main, masks, cur_res, trade, actions, grouping, value_fn)
+        if isinstance(masks, PackedActionMasks):
+            masks = masks.dense()
         self.last_value = value_fn(main) if value_fn is not None else None      # (value_fn: the caller's other consumer of `main`, see _evaluate_compact)
         B, dev = main.shape[0], main.device
         H = self.action_heads

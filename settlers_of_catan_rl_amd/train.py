@@ -13,6 +13,7 @@ consecutive pieces, a minibatch is a random set of pieces laid out time-major, e
 piece's first decision and carrying the terminal masks inside; the value re-evaluation is one LSTM step per stored
 decision from its stored state (process_batch.py:117-121, the `x.size(0) == hxs.size(0)` branch of policy.py:117-123).
 """
+import sys
 import time
 
 import torch
@@ -231,11 +232,15 @@ class PPOTrainer(object):
                 groupings = None                  # the heads' row sets of every minibatch: one sort and one host read per epoch
                 if ahm is not None and hasattr(ahm, "precompute_groupings") and dev.type == "cuda" and ahm.wants_grouping(mbs, acts_all):
                     groupings = ahm.precompute_groupings(acts_all, perm, cfg.num_mini_batch, mbs)
+            # (the packed mask rows go to the net as they are: policy.PackedActionMasks expands what the heads read)
+            pam = getattr(sys.modules.get(type(pol).__module__), "PackedActionMasks", None)
+            amasks = (lambda i: pam(amask_all[i], st.unpack_action_masks)) if (pam is not None and dev.type == "cuda" and amask_all.dtype == torch.int32) \
+                else (lambda i: st.unpack_action_masks(amask_all[i]))
             for bi, (idx, hidden) in enumerate(batches):
                 with self._autocast():
                     if rec:
                         v, lp, ent, _ = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
-                                                             st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                             amasks(idx), acts_all[idx],
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
                     elif dedupe:
                         uqk, invk, orderk, startk = boards[bi]
@@ -244,12 +249,12 @@ class PPOTrainer(object):
                         nn_kernels.gather_rows(f_all[:, :o], idx, out=fm[:, :o])
                         nn_kernels.gather_rows(f_all[:, o + 1140:], idx, out=fm[:, o + 1140:])
                         v, lp, ent = pol.evaluate_actions(cast(fm), nn_kernels.gather_rows(lists_all, idx), lens_all[idx].long(),
-                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                          amasks(idx), acts_all[idx],
                                                           tile_dedupe=(cast(nn_kernels.gather_rows(tiles_all, first_rows[uqk])), invk, orderk, startk),
                                                           **({} if groupings is None else {"grouping": groupings[bi]}))
                     else:
                         v, lp, ent = pol.evaluate_actions(cast(f_all[idx]), lists_all[idx], lens_all[idx].long(),
-                                                          st.unpack_action_masks(amask_all[idx]), acts_all[idx],
+                                                          amasks(idx), acts_all[idx],
                                                           **({} if groupings is None else {"grouping": groupings[bi]}))
                 loss, parts = ppo_kernels.ppo_loss(lp.float(), v.float(), old_lp_all[idx], advf[idx], vpred[idx], ret[idx],
                                                    cfg.clip_param, cfg.value_loss_coef,
