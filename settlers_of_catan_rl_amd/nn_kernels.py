@@ -365,9 +365,13 @@ class _LinearTallSkinny(torch.autograd.Function):
             bb = None if b is None else bf16_of(b)
             # a wide input whose width is not a multiple of 8 (the opponents' 159 features) is zero-padded: the weight gradient
             # then takes the transposing-read kernel (614 400 x 159 -> 256: 685 us; x 160: 307 us) and the rows are 16-byte aligned
-            ctx.pad = pad = (-x.shape[-1] % 8) if x.shape[-1] >= 64 else 0
+            # (x wider than w: the caller's rows are zero-padded already - policy.ObsParts - and only the weight gets its zero columns)
+            extra = x.shape[-1] - w.shape[1]
+            if extra < 0 or (extra > 0 and (x.shape[-1] % 8 or ctx.needs_input_grad[0])):
+                raise ValueError("_LinearTallSkinny: input narrower than the weight, or a padded input that is not whole 16-byte pieces / needs a gradient")
+            ctx.pad = pad = extra if extra > 0 else ((-x.shape[-1] % 8) if x.shape[-1] >= 64 else 0)
             if pad:
-                xb, wb = torch.nn.functional.pad(xb, (0, pad)), torch.nn.functional.pad(wb, (0, pad))
+                xb, wb = (xb if extra > 0 else torch.nn.functional.pad(xb, (0, pad))), torch.nn.functional.pad(wb, (0, pad))
             y = _linear_rows(xb, wb, bb)
             if y is None:
                 y = torch.nn.functional.linear(xb, wb, bb)
@@ -595,7 +599,7 @@ def linear_supported(x, w):
     if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
         return False
     O, I = w.shape
-    rows = x.numel() // I
+    rows = x.numel() // x.shape[-1]        # (x may be wider than w: rows already zero-padded to whole 16-byte pieces, _LinearTallSkinny)
     return rows >= 4096 and bool(_lib.lib().catan_linear_wgrad_supported(rows, I, O))
 
 

@@ -259,7 +259,10 @@ class _OtherPlayers(nn.Module):
 
     def forward(self, main, played, played_len, emb, played_mha):
         p = _ln(self.norm_2, _lin(_card_summary(played, played_len, emb, played_mha, self.norm), self.proj_played_dev_card.weight, self.proj_played_dev_card.bias), relu=True)
-        m = _ln(self.norm_1, _lin(main, self.main_input_layer_1.weight, self.main_input_layer_1.bias), relu=True)
+        w1 = self.main_input_layer_1.weight
+        if main.shape[-1] > w1.shape[1] and not (nn_kernels.linear_supported(main, w1) and torch.is_grad_enabled()):
+            main = main[:, :w1.shape[1]]                       # (rows zero-padded to whole 16-byte pieces - ObsParts.others - are for nn_kernels.linear)
+        m = _ln(self.norm_1, _lin(main, w1, self.main_input_layer_1.bias), relu=True)
         return _ln(self.norm_3, _lin_parts((m, p), self.final_linear_layer.weight, self.final_linear_layer.bias), relu=True)
 
 
@@ -283,9 +286,15 @@ class _ObservationModule(nn.Module):
         per board on the way back (the same function of the same inputs: identical boards give identical encodings)."""
         o = spec.OBS_FLOAT_OFFSETS
         B = obs_f.shape[0]
-        tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
-        cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
-        br = _OBS_BRANCHES.fork(obs_f)       # inference: the three independent parts on forked streams (see _Branches)
+        parts = obs_f if isinstance(obs_f, ObsParts) else None
+        if parts is not None:
+            if tile_dedupe is None and tile_features is None:
+                raise ValueError("ObsParts carries no tile features: pass tile_dedupe or tile_features")
+            tiles, cur = None, parts.cur
+        else:
+            tiles = obs_f[:, o["tile_representations"]:o["tile_representations"] + 1140].reshape(B, 19, 60)
+            cur = obs_f[:, o["current_player_main"]:o["current_player_main"] + 152]
+        br = _OBS_BRANCHES.fork(cur)         # inference: the three independent parts on forked streams (see _Branches)
         with br.on(1):
             te_pad = 0
             tiles_u = None if tile_dedupe is None else tile_dedupe[0].reshape(-1, 19, 60)
@@ -304,7 +313,7 @@ class _ObservationModule(nn.Module):
                                                     self.hidden_card_mha, self.played_card_mha))
         # the three opponents share one module: run them as one batch of 3B rows
         k0 = o["next_player_main"]
-        others = obs_f[:, k0:k0 + 3 * 159].reshape(B * 3, 159)
+        others = parts.others if parts is not None else obs_f[:, k0:k0 + 3 * 159].reshape(B * 3, 159)
         op = self.other_players_module(others, lists[:, 2:5].reshape(B * 3, -1), lens[:, 2:5].reshape(B * 3),
                                        self.dev_card_embedding, self.played_card_mha)
         br.join()
@@ -353,6 +362,18 @@ class _Head(nn.Module):
         # the 128 -> 128 and 128 -> (2..73) layers: their weight gradients are tall-skinny products over the batch rows (_lin)
         h = _lin(_ln(self.norm, pre, relu=True), self.mlp_2.weight, self.mlp_2.bias)
         return _lin(h, self.distribution.linear.weight, self.distribution.linear.bias).float()
+
+
+class ObsParts(object):
+    """The observation rows of a learner minibatch ALREADY split into the pieces the observation module multiplies (the gather that
+    builds the minibatch writes them there): `head` [B, 18] (proposed trade | current resources), `cur` [B, 152], `others` [3 B, 160]
+    (the three opponents' 159 features as rows, zero-padded to a whole number of 16-byte pieces).  As one [B, 1 787] row matrix every
+    piece was sliced out again and copied - and the opponents' rows padded - before its product: 0.23 ms of a minibatch step.  The tile
+    features come through `tile_dedupe` (the learner encodes every distinct board once)."""
+
+    def __init__(self, head, cur, others):
+        self.head, self.cur, self.others = head, cur, others
+        self.shape, self.device, self.is_cuda, self.dtype = (cur.shape[0], spec.OBS_FLOATS), cur.device, cur.is_cuda, cur.dtype
 
 
 class PackedActionMasks(object):
@@ -980,6 +1001,8 @@ class CatanPolicy(nn.Module):
 
     @staticmethod
     def _custom(obs_f):
+        if isinstance(obs_f, ObsParts):
+            obs_f = obs_f.head
         return obs_f[:, 12:18].float(), obs_f[:, 0:12].float()      # current_resources, proposed_trade
 
     # ---- reference-shaped API (with include_lstm the new hidden state is returned as a last extra item)

@@ -133,6 +133,31 @@ class PPOTrainer(object):
         start[:, :mbs].scatter_reduce_(1, pos, torch.arange(mbs, device=ids.device).expand(num_mini_batch, mbs), "amin", include_self=True)
         return [(uq[k, :counts[k]], inv[k], order[k], start[k, :counts[k] + 1]) for k in range(num_mini_batch)]
 
+    def _gather_obs_parts(self, pol, f_all, idx, o):
+        """the minibatch rows idx of the rollout's observation matrix f_all [rows, 1 787] without their tile features (columns o .. o + 1 139)
+        -> policy.ObsParts when the net takes them (CUDA, the storage's dtype = the compute dtype), else one [len(idx), 1 787] matrix whose
+        tile columns are not filled"""
+        cast = (lambda x: x) if (self.autocast_dtype is not None and f_all.dtype == self.autocast_dtype) else (lambda x: x.float())
+        parts_cls = getattr(sys.modules.get(type(pol).__module__), "ObsParts", None)
+        n = idx.numel()
+        if parts_cls is None or not f_all.is_cuda or f_all.dtype != torch.bfloat16 or self.autocast_dtype != torch.bfloat16 or o != 18 or f_all.shape[1] != 1787:
+            fm = torch.empty((n, f_all.shape[1]), dtype=f_all.dtype, device=f_all.device)
+            nn_kernels.gather_rows(f_all[:, :o], idx, out=fm[:, :o])
+            nn_kernels.gather_rows(f_all[:, o + 1140:], idx, out=fm[:, o + 1140:])
+            return cast(fm)
+        buf = getattr(self, "_obs_parts_buf", None)
+        if buf is None or buf[0].shape[0] != n or buf[0].device != f_all.device:
+            # persistent: the opponents' pad column is zeroed once and never written again
+            buf = self._obs_parts_buf = (torch.empty((n, 24), dtype=f_all.dtype, device=f_all.device), torch.empty((n, 152), dtype=f_all.dtype, device=f_all.device),
+                                         torch.zeros((n, 3, 160), dtype=f_all.dtype, device=f_all.device))
+        head, cur, oth = buf
+        c0 = o + 1140
+        nn_kernels.gather_rows(f_all[:, :o], idx, out=head[:, :o])
+        nn_kernels.gather_rows(f_all[:, c0:c0 + 152], idx, out=cur)
+        for j in range(3):
+            nn_kernels.gather_rows(f_all[:, c0 + 152 + 159 * j:c0 + 152 + 159 * (j + 1)], idx, out=oth[:, j, :159])
+        return parts_cls(head[:, :o], cur, oth.view(3 * n, 160))
+
     @torch.no_grad()
     def compute_values(self, st):
         """process_batch.py:108-132: V(obs) for all (T+1)*N observations, denormalised (RL/models/utils.py:20-21)."""
@@ -244,11 +269,10 @@ class PPOTrainer(object):
                                                              hidden=hidden, nonterminal=nt_all[idx])     # ppo.py:48-50
                     elif dedupe:
                         uqk, invk, orderk, startk = boards[bi]
-                        # the rows' observations WITHOUT their tile features (64 % of a row: they come per distinct board below)
-                        fm = torch.empty((idx.numel(), f_all.shape[1]), dtype=f_all.dtype, device=dev)
-                        nn_kernels.gather_rows(f_all[:, :o], idx, out=fm[:, :o])
-                        nn_kernels.gather_rows(f_all[:, o + 1140:], idx, out=fm[:, o + 1140:])
-                        v, lp, ent = pol.evaluate_actions(cast(fm), nn_kernels.gather_rows(lists_all, idx), lens_all[idx].long(),
+                        # the rows' observations WITHOUT their tile features (64 % of a row: they come per distinct board below), gathered
+                        # straight into the pieces the observation module multiplies (policy.ObsParts: no slicing / padding copies later)
+                        obs_in = self._gather_obs_parts(pol, f_all, idx, o)
+                        v, lp, ent = pol.evaluate_actions(obs_in, nn_kernels.gather_rows(lists_all, idx), lens_all[idx].long(),
                                                           amasks(idx), acts_all[idx],
                                                           tile_dedupe=(cast(nn_kernels.gather_rows(tiles_all, first_rows[uqk])), invk, orderk, startk),
                                                           **({} if groupings is None else {"grouping": groupings[bi]}))

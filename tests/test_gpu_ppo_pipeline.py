@@ -1395,3 +1395,59 @@ def test_rollout_log_probs_against_the_learners_at_rollout_width(hip_lib):
           f"learner bf16 vs fp32: max {float(g32.max()):.2e}")
     assert float(q[0]) < 2e-3 and float(q[1]) < 0.03 and float(gap.max()) < 0.1
     assert float(g32.max()) < 0.1
+
+
+def test_learner_minibatch_from_gathered_parts_equals_the_row_matrix(hip_lib):
+    """train.PPOTrainer._gather_obs_parts hands the observation module its pieces as the gather wrote them (policy.ObsParts: head, current
+    player, the opponents' rows zero-padded to 160 columns) and the heads the PACKED mask rows (policy.PackedActionMasks): the same
+    evaluate_actions as with the [B, 1 787] row matrix and the dense fp32 masks - values bit-equal (the same kernels see the same operands),
+    log-probs and gradients equal up to the order of their atomic sums."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels, spec
+    from settlers_of_catan_rl_amd.env import VecCatanEnv
+    from settlers_of_catan_rl_amd.policy import CatanPolicy, PackedActionMasks
+    from settlers_of_catan_rl_amd.rollout import RolloutStorage, pack_action_masks
+    from settlers_of_catan_rl_amd.train import PPOTrainer, PPOConfig
+    torch.manual_seed(0)
+    N = 65536
+    env = VecCatanEnv(N, seed=2); env.random_rollout(0, 800)
+    net = CatanPolicy().cuda()
+    f, lists, lens = env.get_obs()
+    masks = env.get_action_masks()
+    fb = f.to(torch.bfloat16)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _, actions, _ = net.act(fb, lists, lens.long(), masks, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert N >= net.action_head_module.compact_min_rows
+    tr = PPOTrainer(net, PPOConfig(), autocast_dtype=torch.bfloat16, seed=0)
+    idx = torch.randperm(N, device="cuda")
+    o = spec.OBS_FLOAT_OFFSETS["tile_representations"]
+    tiles = fb[idx][:, o:o + 1140]
+    uq, inv = torch.unique(tiles, dim=0, return_inverse=True)
+    order = torch.argsort(inv, stable=True)
+    start = torch.cat((torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(torch.bincount(inv, minlength=uq.shape[0]), 0)))
+    dd = (uq, inv, order, start)
+    packed = pack_action_masks(masks[idx]).to(torch.int32)
+    st = RolloutStorage.__new__(RolloutStorage)
+    res = {}
+    for mode in ("matrix", "parts"):
+        for p in net.parameters():
+            p.grad = None
+        nn_kernels.grad_arena.begin_step(fb.device); nn_kernels.wgrad_queue.begin()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if mode == "matrix":
+                obs_in, m_in = fb[idx], masks[idx]
+            else:
+                obs_in, m_in = tr._gather_obs_parts(net, fb, idx, o), PackedActionMasks(packed, st.unpack_action_masks)
+            v, lp, ent = net.evaluate_actions(obs_in, lists[idx], lens[idx].long(), m_in, actions[idx], tile_dedupe=dd)
+        (lp.float().mean() + 0.5 * v.float().mean() - 0.01 * ent).backward()
+        nn_kernels.wgrad_queue.flush(); nn_kernels.grad_arena.end_step()
+        res[mode] = (v.detach().float().clone(), lp.detach().float().clone(), float(ent), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert type(tr._gather_obs_parts(net, fb, idx, o)).__name__ == "ObsParts"
+    assert torch.equal(res["matrix"][0], res["parts"][0])
+    # (a row's joint log-prob is the sum of up to four heads' terms, added by index_add's atomics: the order, and with it the last bit, varies)
+    assert float((res["matrix"][1] - res["parts"][1]).abs().max()) <= 2e-5
+    assert abs(res["matrix"][2] - res["parts"][2]) <= 1e-6 * max(1.0, abs(res["matrix"][2]))
+    assert set(res["matrix"][3]) == set(res["parts"][3])
+    for k, g in res["matrix"][3].items():
+        scale = float(g.abs().max()) + 1e-12
+        assert float((g - res["parts"][3][k]).abs().max()) <= 2e-3 * scale + 1e-9, (k, float((g - res["parts"][3][k]).abs().max()), scale)
