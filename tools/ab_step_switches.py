@@ -64,6 +64,7 @@ def run():
     return (t["b"] - t["a"]) / STEPS * 1e3
 
 
+DEFAULT_OFF = {"te_fused_bwd", "recompute_h"}
 names = [n for n in os.environ.get("SWITCHES", ",".join(SW)).split(",") if n in SW]
 run()                                                   # warm-up (GEMM kernels, arena size)
 for rnd in range(3):
@@ -71,3 +72,4 @@ for rnd in range(3):
         for on in (False, True):
             SW[n](on)
             print(f"round {rnd}: {n}={'on ' if on else 'off'}: {run():.2f} ms per minibatch step", flush=True)
+        SW[n](n not in DEFAULT_OFF)                      # back to the library's default before the next pair
