@@ -479,7 +479,7 @@ def main():
         if ppo is not None:
             out["roofline_learner"] = ppo.pop("roofline_learner", None)
             out["ppo_update"] = ppo
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # (rank 0 at N = 1 only: with N ranks on the node the host cores are shared)
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
     if rank == 0:

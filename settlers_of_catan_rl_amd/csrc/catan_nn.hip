@@ -26,11 +26,19 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 // the halves with and / shift / two or_sdwa: six instructions per four elements instead of two.)
 typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
 typedef float f32pair_t __attribute__((ext_vector_type(2)));
+// CATAN_PK_BF_SCALAR (a build macro, off): the per-element form, kept as the fall-back should the packed conversion ever have to go
+// (the run-to-run instability of round 4 appeared only next to packed-f32 VALU, which the build now excludes and checks for;
+// tools/stress_determinism.py covers every kernel that converts through this function).
 __device__ __forceinline__ unsigned pk_bf(float a, float b) {
+#ifdef CATAN_PK_BF_SCALAR
+    const __hip_bfloat16 ha = __float2bfloat16(a), hb = __float2bfloat16(b);
+    return (unsigned)*reinterpret_cast<const unsigned short*>(&ha) | ((unsigned)*reinterpret_cast<const unsigned short*>(&hb) << 16);
+#else
     const f32pair_t f = {a, b};
     union { bf16pair_t h; unsigned u; } r;
     r.h = __builtin_convertvector(f, bf16pair_t);
     return r.u;
+#endif
 }
 
 // LDS rows are kept in the storage type (bf16 inputs: half the LDS, twice the blocks per CU) with a 16 B aligned pitch; a head
