@@ -350,7 +350,18 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // fstream + sstream = 4, so the two tier-1 slots share one stream (tier 1 of an iteration must fit in one iteration).
     // (A second tier-1 stream was measured with GPU_MAX_HW_QUEUES=4 and 8: 883 M and 447 M env-steps/s against 1 015 M -
     // two tier-1 launches in flight take the SIMDs from k_step.)
-    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->fstream[0], hipStreamNonBlocking);
+    // CATAN_LR_CUS=k (diagnostics, tools/pass_experiments.py): the tier-1 stream confined to k of the CUs (every (cus / k)-th bit of the
+    // CU mask), so that its one-wave workgroups do not hold LDS on the CUs k_step's 29 KB workgroups need
+    int lr_cus = getenv("CATAN_LR_CUS") ? atoi(getenv("CATAN_LR_CUS")) : 0;
+    if (rc == hipSuccess && lr_cus > 0) {
+        hipDeviceProp_t prop; int dev = 0;
+        int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        if (lr_cus > cus) lr_cus = cus;
+        std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+        const char* pat = getenv("CATAN_LR_CUS_PATTERN");             // "block": the first k CUs; default: evenly spread
+        for (int k = 0; k < lr_cus; k++) { const int b = (pat && pat[0] == 'b') ? k : (int)((long)k * cus / lr_cus); mask[b >> 5] |= 1u << (b & 31); }
+        rc = hipExtStreamCreateWithCUMask(&e->fstream[0], (uint32_t)mask.size(), mask.data());
+    } else if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->fstream[0], hipStreamNonBlocking);
     e->fstream[1] = e->fstream[0];
     for (int i = 0; i < 3 && rc == hipSuccess; i++) {
         rc = hipEventCreateWithFlags(&e->ev_fready[i], EV_SYNC);
