@@ -772,6 +772,10 @@ static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int w
                        e->pend.ctr + 16 + NBINS * ba, e->pend.lists + (size_t)ba * NBINS * e->N);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
+    // CATAN_DEBUG_EXTRA_EVENTS=k (diagnostics): k more event records per pass - what a queue packet on the main stream costs
+    // (profiles/r05_k_step_pass_experiments.txt: +2.9 .. 3.5 us per pass each; the loop has two, this record and the wait above)
+    static const int extra = getenv("CATAN_DEBUG_EXTRA_EVENTS") ? atoi(getenv("CATAN_DEBUG_EXTRA_EVENTS")) : 0;
+    for (int k = 0; k < extra; k++) HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipEventRecord(e->ev_fready[fa], st));
     HIPCHK(hipStreamWaitEvent(e->fstream[0], e->ev_fready[fa], 0));
     r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[0], ev, fa, e->lr_budget[1]);
