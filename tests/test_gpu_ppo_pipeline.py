@@ -1451,3 +1451,40 @@ def test_learner_minibatch_from_gathered_parts_equals_the_row_matrix(hip_lib):
     for k, g in res["matrix"][3].items():
         scale = float(g.abs().max()) + 1e-12
         assert float((g - res["parts"][3][k]).abs().max()) <= 2e-3 * scale + 1e-9, (k, float((g - res["parts"][3][k]).abs().max()), scale)
+
+
+def test_recurrent_given_kernel_equals_the_torch_formulation(hip_lib):
+    """catan_recurrent_given (the inputs of a recurrent trade head evaluated for given picks) against policy._recurrent_given's torch
+    formulation of RL/models/action_heads_module.py:258-329 on the CPU: conditioning columns, masks, step-major picks, step weights and
+    the final counts, bit for bit, with and without `fixed` columns, from-hand and free picks, bf16 and fp32 conditioning."""
+    import torch
+    import torch.nn.functional as F
+    from settlers_of_catan_rl_amd import nn_kernels
+    g = torch.Generator().manual_seed(4)
+    B = 5000
+    acts18 = torch.randint(0, 6, (B, 18), generator=g)
+    acts18[::7, 8] = 0; acts18[::5, 7] = 0                                   # early stops
+    cur = torch.randint(0, 4, (B, 6), generator=g).float()
+    cur[::11] = 0.0                                                          # empty hands
+    fixed = torch.randint(0, 3, (B, 6), generator=g).float()
+    for from_hand in (True, False):
+        for fx in (None, fixed):
+            for col0 in (7, 11):
+                acts = acts18[:, col0:col0 + 4]
+                onehot = F.one_hot(acts, 6).float()
+                before = torch.cumsum(onehot, 1) - onehot
+                res = torch.clamp(cur[:, None, :] - before, min=0)
+                mask = (res > 0).float() if from_hand else torch.ones_like(res)
+                first0 = (cur.sum(-1) == 0).float()
+                mask = torch.cat((torch.cat((first0[:, None, None], torch.ones(B, 3, 1)), 1), mask[:, :, 1:]), 2)
+                out = torch.cat((torch.zeros(B, 4, 1), before[:, :, 1:]), 2)
+                steps = lambda t: t.transpose(0, 1).reshape((4 * B,) + t.shape[2:])
+                cond = steps(out) if fx is None else torch.cat((fx.repeat(4, 1), steps(out)), -1)
+                keep = torch.cat((torch.ones(B, 1), (acts[:, :3] > 0).float()), 1)
+                total = before[:, 3] + onehot[:, 3]
+                out_final = torch.cat((torch.zeros(B, 1), total[:, 1:]), 1)
+                for dt in (torch.bfloat16, torch.float32):
+                    c, m, gv, kp, of = nn_kernels.recurrent_given(acts18.cuda()[:, col0:col0 + 4], cur.cuda(), None if fx is None else fx.cuda(), from_hand, dt)
+                    assert c.dtype == dt and torch.equal(c.float().cpu(), cond.to(dt).float())
+                    assert torch.equal(m.cpu(), steps(mask)) and torch.equal(gv.cpu(), steps(acts))
+                    assert torch.equal(kp.cpu(), keep) and torch.equal(of.cpu(), out_final)
