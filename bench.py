@@ -270,6 +270,7 @@ def main():
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     # backend "nccl" == RCCL over xGMI; CATAN_DIST_BACKEND=gloo lets two ranks share one GPU (smoke test of this code path)
     stage("init_process_group + allreduce_selfcheck")
+    cdist.on_hang = lambda msg: emit("failed during stage 'init_process_group + allreduce_selfcheck': " + msg)
     rank, local_rank, world = cdist.init_from_env(backend=os.environ.get("CATAN_DIST_BACKEND") or None)
     PARTIAL.update(n_gpus=world, steps=args.steps, warmup=args.warmup, world=world,
                    backend=(torch.distributed.get_backend() if world > 1 else None), dist_init=cdist.INIT_REPORT)

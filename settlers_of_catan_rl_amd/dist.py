@@ -110,6 +110,53 @@ def _drop_process_group():
 
 
 _attempt_hook = None          # tests: called as hook(attempt_number, rank) right after init_process_group of an attempt; may raise
+on_hang = None                # bench.py: called (from a timer thread) with a message when an init attempt outlives its deadline, before the process exits
+
+
+def _preflight(store, rank, world, local_rank, timeout_s):
+    """Before any communicator is built: every rank tells the others (side store, no collective) which device it sits on.  RCCL needs one
+    DISTINCT, EXISTING device per rank; a rank whose LOCAL_RANK has no device of its own (fewer visible devices than ranks: a one-GPU
+    rehearsal, a wrong HIP_VISIBLE_DEVICES) would leave its peers inside ncclCommInitRank with nobody to meet - that call has no time-out
+    and cannot be interrupted.  -> (RCCL can be tried, what every rank said)"""
+    from datetime import timedelta
+    import socket
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n == 0:
+        mine = "no-device"
+    else:
+        idx = local_rank % n
+        props = torch.cuda.get_device_properties(idx)
+        ident = str(getattr(props, "uuid", "")) or f"index-{idx}"
+        mine = f"{'own' if local_rank < n else 'shared'}|{socket.gethostname()}|{ident}"
+    store.set(f"catan/preflight/{rank}", mine)
+    keys = [f"catan/preflight/{r}" for r in range(world)]
+    try:
+        store.wait(keys, timedelta(seconds=timeout_s))
+    except Exception as e:
+        return False, [f"no word from some rank within {timeout_s:.0f} s ({type(e).__name__})"]
+    said = [store.get(k).decode("utf-8", "replace") for k in keys]
+    return all(v.startswith("own|") for v in said) and len(set(said)) == world, said
+
+
+def _deadline(seconds, what, rank):
+    """A timer that ends the process when an init attempt neither returns nor raises (a communicator set-up that waits for a peer for
+    ever): a message on stderr, bench.py's line through `on_hang`, exit code 86 - torch.distributed.run then stops the other ranks.
+    -> the timer (cancel() it when the attempt is over)."""
+    import sys
+    import threading
+
+    def fire():
+        msg = f"rank {rank}: {what} did not return within {seconds:.0f} s - giving up (a peer never arrived, or the communicator set-up hangs)"
+        try:
+            sys.stderr.write("[catan dist] " + msg + "\n"); sys.stderr.flush()
+            if on_hang is not None:
+                on_hang(msg)
+        finally:
+            os._exit(86)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def init_from_env(backend=None, device_index=None, timeout_s=None, selfcheck=True, plan=None):
@@ -120,7 +167,12 @@ def init_from_env(backend=None, device_index=None, timeout_s=None, selfcheck=Tru
     tell each other over a side TCPStore how it went (no collective), and if ANY of them failed all of them drop the group and take
     the next attempt together: "nccl" (= RCCL) bound eagerly to this rank's device -> "nccl" without `device_id` (lazy communicator)
     -> "gloo" (host-staged: slow but it yields a line that says so).  An explicit `backend` is tried alone.  What happened is in
-    INIT_REPORT; RCCL's warnings go to a per-rank file (`rccl_log_tail`)."""
+    INIT_REPORT; RCCL's warnings go to a per-rank file (`rccl_log_tail`).
+    Two guards around the attempts (round 5, after a two-rank run on a ONE-GPU box spent 870 s and produced nothing: rank 1 had no device
+    of its own, rank 0 sat inside the eager RCCL set-up - which has no time-out - and the ranks' attempts drifted apart): a PRE-FLIGHT over
+    the side store (every rank's device: RCCL is only tried when each rank has a distinct, existing one - otherwise all ranks go to gloo
+    together), and a DEADLINE per attempt (2 x time-out + 120 s: a set-up that neither returns nor raises ends the process with a message
+    and, on rank 0, bench.py's line, instead of holding the node until the launcher's own limit)."""
     from datetime import timedelta
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,9 +201,15 @@ def init_from_env(backend=None, device_index=None, timeout_s=None, selfcheck=Tru
             except Exception as e:                                   # no side store: a single attempt, errors propagate
                 INIT_REPORT["attempts"].append({"side_store": f"unavailable ({type(e).__name__}: {e})"})
                 plan = plan[:1]
+        if store is not None and have_gpu and any(be == "nccl" for be, _ in plan):
+            rccl_ok, said = _preflight(store, rank, world, local_rank, timeout_s)
+            INIT_REPORT["preflight"] = {"one_distinct_device_per_rank": rccl_ok, "ranks": said[:16]}
+            if not rccl_ok:                                          # (every rank reads the same words: all of them skip RCCL together)
+                plan = [(be, d) for be, d in plan if be != "nccl"] or [("gloo", None)]
         for k, (be, device_id) in enumerate(plan):
             rec = {"backend": be, "device_id": None if device_id is None else str(device_id), "timeout_s": timeout_s}
             ok, msg, chk = True, "", None
+            watchdog = _deadline(2.0 * timeout_s + 120.0, f"init attempt {k} ({be}{'' if device_id is None else ', bound to ' + str(device_id)})", rank)
             try:
                 kw = {"timeout": timedelta(seconds=timeout_s)}
                 if device_id is not None:
@@ -165,6 +223,8 @@ def init_from_env(backend=None, device_index=None, timeout_s=None, selfcheck=Tru
                     chk = allreduce_selfcheck(min(timeout_s, 60.0))
             except Exception as e:
                 ok, msg = False, f"{type(e).__name__}: {e}"
+            finally:
+                watchdog.cancel()
             all_ok, bad = _agree(store, f"catan/init/{k}", rank, world, ok, msg, timeout_s + 90.0)
             rec.update(ok=all_ok, this_rank=("ok" if ok else msg[:400]), failing_ranks=[(r, v[:200]) for r, v in bad][:8])
             INIT_REPORT["attempts"].append(rec)

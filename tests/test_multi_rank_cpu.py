@@ -127,3 +127,52 @@ def test_init_retries_on_every_rank_when_one_rank_fails_and_selfcheck_runs():
         said = dict((f[0], f[1]) for f in failing)       # (the other ranks' self-check timed out waiting for the failed one: they report too)
         assert "simulated" in said[fail_rank], said
         assert chk_ok and again_ok and abs(mean - (world - 1) / 2.0) < 1e-9
+
+
+def _preflight_worker(rank, world, port, q, devices):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CATAN_DIST_TIMEOUT_S="15")
+    sys.path.insert(0, ROOT)
+    from settlers_of_catan_rl_amd import dist as cdist
+
+    class Props(object):
+        def __init__(self, idx):
+            self.uuid = f"GPU-fake-{idx}"
+    # a box that SAYS it has `devices` GPUs (nothing is ever placed on them: the pre-flight only asks for their count and identity)
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: devices
+    torch.cuda.get_device_properties = lambda idx: Props(idx)
+    calls = []
+    real_init = torch.distributed.init_process_group
+
+    def spy(backend, **kw):
+        calls.append(backend)
+        kw.pop("device_id", None)
+        return real_init("gloo", **kw)          # (no RCCL here: what matters is WHICH attempts the ranks agree to make)
+    torch.distributed.init_process_group = spy
+    r, lr, w = cdist.init_from_env(selfcheck=False)
+    q.put((rank, calls, cdist.INIT_REPORT["preflight"]["one_distinct_device_per_rank"], cdist.INIT_REPORT["backend"]))
+    cdist.finalize()
+
+
+@pytest.mark.parametrize("devices", [1, 2])
+def test_preflight_skips_rccl_when_ranks_share_a_device(devices):
+    """Two ranks on a box with ONE visible device (a rehearsal, a wrong HIP_VISIBLE_DEVICES): the pre-flight over the side store makes BOTH
+    ranks skip the RCCL attempts - an eager RCCL set-up would wait for ever for the rank that has no device of its own (found on a
+    one-GPU MI355X box: 870 s, no line) - and go to gloo together.  With a device per rank the first attempt is the bound RCCL one."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q, devices)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, calls, distinct, backend in got:
+        if devices == 1:
+            assert not distinct and calls == ["gloo"] and backend == "gloo", (rank, calls, distinct, backend)
+        else:
+            assert distinct and calls == ["nccl"] and backend == "nccl", (rank, calls, distinct, backend)
