@@ -228,7 +228,7 @@ typedef struct catan_te_saves {
     void* n2[2];        /* [64]  LayerNorm 2 output; may be NULL: catan_ffn_bwd / catan_ffn_outproj_bwd recompute it from xmid */
     void* h[2];         /* [128] relu(linear1); may be NULL: catan_ffn_outproj_bwd_rh recomputes it */
     void* xfin;         /* [64]  last layer's output */
-    void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */
+    void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU; may be NULL (catan_tile_encoder_bwd_tail); so may tiles64 / a0 (..._bwd_head) */
 } catan_te_saves_t;
 /* out_pitch: elements between two boards' rows of `out` (>= 475; the columns beyond 475 are not written) */
 int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, const catan_te_saves_t* saves,
@@ -253,6 +253,18 @@ int catan_tile_encoder_bwd_layer1(const void* weights, const float* vecs, const 
                                   const void* xin1, const void* dout, int64_t out_pitch, void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
 int catan_tile_encoder_bwd_layer0(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t,
                                   const void* tiles, const void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
+
+/* The two ends of the encoder's backward beside the sub-layer kernels (catan_ffn_outproj_bwd / catan_attention_bwd / catan_qkv_bwd), one launch each,
+ * with the small activation of that end recomputed (catan_te_saves_t.p / .a0 / .tiles64 may then be NULL in the training forward):
+ *   catan_tile_encoder_bwd_tail   xfin bf16 [boards * 19][64] (catan_te_saves_t.xfin), dout bf16 [boards][out_pitch] -> dxfin bf16 [boards * 19][64];
+ *                                 grads float [catan_te_bwd_ends_grad_floats(1)]: out_proj [32][64] (rows >= 25 unused) | bias [32] | LayerNorm w, b [32 each]
+ *   catan_tile_encoder_bwd_head   tiles bf16 [boards][19][60], dx0 bf16 [boards * 19][64] (the gradient of the first layer's output);
+ *                                 grads float [catan_te_bwd_ends_grad_floats(0)]: first_layer [64][64] (columns >= 60 unused) | bias [64] | LayerNorm w, b [64 each]
+ * grads are ZEROED by the caller and accumulated into (fp32 atomics). */
+int32_t catan_te_bwd_ends_grad_floats(int32_t part);
+int catan_tile_encoder_bwd_tail(const void* weights, const float* vecs, const void* wpt32, const void* xfin, const void* dout, int64_t out_pitch, void* dxfin,
+                                float* grads, int64_t boards, catan_stream_t stream);
+int catan_tile_encoder_bwd_head(const void* weights, const float* vecs, const void* tiles, const void* dx0, float* grads, int64_t boards, catan_stream_t stream);
 
 /* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
  * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.

@@ -1690,11 +1690,12 @@ int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const f
     static_assert(sizeof(catan_te_saves_t) == sizeof(TeSaves), "the header's struct is the kernel's");
     const void* const* ptrs = reinterpret_cast<const void* const*>(saves);
     for (size_t i = 0; i < sizeof(TeSaves) / sizeof(void*); i++) {
-        const bool optional = (i >= offsetof(TeSaves, n1) / sizeof(void*) && i < offsetof(TeSaves, n1) / sizeof(void*) + 2) ||
+        const bool optional = i == offsetof(TeSaves, tiles64) / sizeof(void*) || i == offsetof(TeSaves, a0) / sizeof(void*) || i == offsetof(TeSaves, p) / sizeof(void*) ||
+                              (i >= offsetof(TeSaves, n1) / sizeof(void*) && i < offsetof(TeSaves, n1) / sizeof(void*) + 2) ||
                               (i >= offsetof(TeSaves, n2) / sizeof(void*) && i < offsetof(TeSaves, n2) / sizeof(void*) + 2) ||
                               (i >= offsetof(TeSaves, h) / sizeof(void*) && i < offsetof(TeSaves, h) / sizeof(void*) + 2);
         if ((!ptrs[i] && !optional) || ((uintptr_t)ptrs[i] & 15))
-            return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer but n1 / n2 / h must be set, all 16-byte aligned");
+            return fail(CATAN_EINVAL, "catan_tile_encoder_fwd_train: every save buffer but tiles64 / a0 / p / n1 / n2 / h must be set, all 16-byte aligned");
     }
     TeSaves sv;
     memcpy(&sv, saves, sizeof sv);
@@ -1746,6 +1747,32 @@ int catan_tile_encoder_bwd_layer0(const void* weights, const float* vecs, const 
     TeBwdArgs a = { (const unsigned short*)weights, vecs, (const unsigned short*)wqt, (const unsigned short*)wot, (const unsigned short*)w1t, (const unsigned short*)w2t,
                     nullptr, (const unsigned short*)tiles, (const unsigned short*)dxin1, nullptr, grads, (long)boards, 0L };
     hipLaunchKernelGGL(k_te_bwd_layer<0>, dim3((unsigned)te_bwd_grid(boards)), dim3(TB_THREADS), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+int32_t catan_te_bwd_ends_grad_floats(int32_t part) { return part == 1 ? TGE1_TOTAL : TGE0_TOTAL; }
+int catan_tile_encoder_bwd_tail(const void* weights, const float* vecs, const void* wpt32, const void* xfin, const void* dout, int64_t out_pitch, void* dxfin,
+                                float* grads, int64_t boards, catan_stream_t stream) {
+    if (!weights || !vecs || !wpt32 || !xfin || !dout || !dxfin || !grads || boards <= 0 || out_pitch < TE_L * TE_OUT ||
+        (((uintptr_t)weights | (uintptr_t)vecs | (uintptr_t)wpt32 | (uintptr_t)xfin | (uintptr_t)dxfin) & 15) || ((uintptr_t)dout & 1))
+        return fail(CATAN_EINVAL, "catan_tile_encoder_bwd_tail: null or misaligned argument");
+    TeBwdArgs a = { (const unsigned short*)weights, vecs, nullptr, nullptr, nullptr, nullptr, (const unsigned short*)wpt32, (const unsigned short*)xfin,
+                    (const unsigned short*)dout, (unsigned short*)dxfin, grads, (long)boards, (long)out_pitch };
+    const long groups = (boards + TE_G - 1) / TE_G;
+    const long want = 4L * te_bwd_grid(1L << 40);
+    hipLaunchKernelGGL(k_te_bwd_ends<1>, dim3((unsigned)(groups < want ? groups : want)), dim3(TB_THREADS), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_tile_encoder_bwd_head(const void* weights, const float* vecs, const void* tiles, const void* dx0, float* grads, int64_t boards, catan_stream_t stream) {
+    if (!weights || !vecs || !tiles || !dx0 || !grads || boards <= 0 || (((uintptr_t)weights | (uintptr_t)vecs | (uintptr_t)dx0) & 15) || ((uintptr_t)tiles & 7))
+        return fail(CATAN_EINVAL, "catan_tile_encoder_bwd_head: null or misaligned argument");
+    TeBwdArgs a = { (const unsigned short*)weights, vecs, nullptr, nullptr, nullptr, nullptr, nullptr, (const unsigned short*)tiles, (const unsigned short*)dx0, nullptr,
+                    grads, (long)boards, 0L };
+    const long groups = (boards + TE_G - 1) / TE_G;
+    const long want = 2L * te_bwd_grid(1L << 40);
+    hipLaunchKernelGGL(k_te_bwd_ends<0>, dim3((unsigned)(groups < want ? groups : want)), dim3(TB_THREADS), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
 }

@@ -678,4 +678,111 @@ __global__ __launch_bounds__(TB_THREADS) void k_te_bwd_layer(TeBwdArgs a) {
     else tb_wgrad_out<1, 2>(G + TG_W0, 64, 16 * wq, 32 * wh, ax, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The two ENDS of the encoder's backward as one kernel each, beside the sub-layer kernels of catan_te_bwd.hip (the default chain):
+//   k_te_bwd_ends<1>  behind the last transformer layer: out = relu(LayerNorm25(xfin Wp^T + bp)).  xfin [tokens][64] and dOut in; P is
+//                     recomputed (one 64 x 32 product per token tile), LayerNorm + ReLU backward, dWp / dbp / LayerNorm gradients, d(xfin) out.
+//                     As separate kernels (LayerNorm-25 backward over 50-byte rows, a 25 -> 64 row product, a weight gradient) the chain moved
+//                     506 B per token in three passes and needed P stored by the forward; here 306 B in one.
+//   k_te_bwd_ends<0>  in front of the first layer: x0 = relu(LayerNorm(tiles W0^T + b0)).  The tile features and d(x0) in; a0 is recomputed,
+//                     LayerNorm + ReLU backward, dW0 / db0 / LayerNorm gradients.  (Separately: 640 B per token in two passes and a0 + the padded
+//                     tile features stored by the forward; here 248 B in one.)
+// Same phase functions as k_te_bwd_layer (95-token groups in LDS, 512 threads); the tiles are few (28 / 55 KB), so several workgroups share a CU.
+// G: <1>: Wp [32][64] | bp [32] | LayerNorm weight, bias [32 each];  <0>: W0 [64][64] | b0 [64] | LayerNorm weight, bias [64 each].
+constexpr int TGE_W = 0, TGE1_B = 32 * 64, TGE1_LW = TGE1_B + 32, TGE1_LB = TGE1_LW + 32, TGE1_TOTAL = TGE1_LB + 32;
+constexpr int TGE0_B = 64 * 64, TGE0_LW = TGE0_B + 64, TGE0_LB = TGE0_LW + 64, TGE0_TOTAL = TGE0_LB + 64;
+template <int PART>
+__global__ __launch_bounds__(TB_THREADS) void k_te_bwd_ends(TeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short XA[TE_ROWS * TB_PX];                  // <1>: xfin, then d(xfin);  <0>: the tile features
+    __shared__ __attribute__((aligned(16))) unsigned short TMP[TE_ROWS * TB_PX];                 // <1>: P | dP;  <0>: dA0
+    __shared__ __attribute__((aligned(16))) unsigned short A0[PART == 0 ? TE_ROWS * TB_PX : 8];  // <0>: a0
+    __shared__ __attribute__((aligned(16))) unsigned short DX[PART == 0 ? TE_ROWS * TB_PX : 8];  // <0>: d(x0)
+    __shared__ __attribute__((aligned(16))) float V[PART == 1 ? 96 : 192];                       // the part's bias / LayerNorm vectors
+    __shared__ __attribute__((aligned(16))) float STAT[TE_ROWS * 2];
+    __shared__ float CS[192];                                                                    // bias | LayerNorm weight | LayerNorm bias column sums (64 each)
+    const int tid0 = threadIdx.x, wave = tid0 >> 6;
+    {
+        const float* gv = a.vecs + (PART == 1 ? TE_VP : TE_V0);
+        for (int c = tid0; c < (PART == 1 ? 96 : 192); c += TB_THREADS) V[c] = gv[c];
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int c = tid0; c < TE_ROWS * TB_PX / 8; c += TB_THREADS) {
+            reinterpret_cast<uint4*>(XA)[c] = z; reinterpret_cast<uint4*>(TMP)[c] = z;
+            if (PART == 0) { reinterpret_cast<uint4*>(A0)[c] = z; reinterpret_cast<uint4*>(DX)[c] = z; }
+        }
+        for (int c = tid0; c < 192; c += TB_THREADS) CS[c] = 0.f;
+    }
+    f32x4_t ax[1][PART == 0 ? 2 : 1];
+    const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+    ax[0][0] = z4; ax[0][PART == 0 ? 1 : 0] = z4;
+    const int wq = wave >> 1, wh = wave & 1;
+    const long ngroups = (a.boards + TE_G - 1) / TE_G;
+    __syncthreads();
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int lane_ = tid0 & 63;
+        asm volatile("" : "+v"(lane_));                                  // (see k_te_bwd_layer: keeps the per-lane addresses out of the loop-invariant set)
+        const int lane = lane_, tid = wave * 64 + lane;
+        const long g0 = grp * TE_G;
+        const int nb = (int)(a.boards - g0 < TE_G ? a.boards - g0 : TE_G);
+        const int nt = nb * TE_L;
+        const long t0 = g0 * TE_L;
+        if constexpr (PART == 1) {
+            TbW<64, 32> wp; tb_fetch<64, 32>(wp, a.wts + TE_WP, lane, wave);
+            TbW<32, 64> wpt; tb_fetch<32, 64>(wpt, a.wpt, lane, wave);
+            for (int c = tid; c < TE_ROWS * 8; c += TB_THREADS) {
+                const int row = c >> 3, ch = c & 7;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < nt) v = *reinterpret_cast<const uint4*>(a.in_rows + (t0 + row) * 64 + ch * 8);
+                *reinterpret_cast<uint4*>(XA + row * TB_PX + ch * 8) = v;
+            }
+            __syncthreads();
+            tb_gemm<64, 32, 0>(XA, TB_PX, wp, V, TMP, TB_PX, nullptr, 0, lane, wave);                          // P: columns 0..31 of TMP
+            __syncthreads();
+            tb_lnp_bwd(TMP, TMP + 32, a.dgrad + g0 * a.out_pitch, a.out_pitch, V + 32, V + 64, STAT, nt, tid);  // dP: columns 32..63
+            __syncthreads();
+            tb_lnp_colgrad(TMP, a.dgrad + g0 * a.out_pitch, a.out_pitch, V + 32, V + 64, STAT, nt, tid, CS + 64, CS + 128);
+            tb_colsum<32>(TMP + 32, TB_PX, nt, tid, CS);
+            tb_wgrad<1, 1>(TMP + 32, TB_PX, 16 * (wave >> 2), XA, TB_PX, 16 * (wave & 3), ax, lane);             // dWp += dP^T xfin
+            __syncthreads();
+            tb_gemm<32, 64, 4>(TMP + 32, TB_PX, wpt, nullptr, XA, TB_PX, nullptr, 0, lane, wave);               // d(xfin) = dP Wp
+            __syncthreads();
+            for (int c = tid; c < nt * 8; c += TB_THREADS) {
+                const int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<uint4*>(a.dx_out + (t0 + row) * 64 + ch * 8) = *reinterpret_cast<const uint4*>(XA + row * TB_PX + ch * 8);
+            }
+        } else {
+            TbW<64, 64> w0; tb_fetch<64, 64>(w0, a.wts + TE_W0, lane, wave);
+            for (int c = tid; c < TE_ROWS * 16; c += TB_THREADS) {
+                const int row = c >> 4, ch = c & 15;
+                uint2 v = make_uint2(0u, 0u);
+                if (ch < 15 && row < nt) v = *reinterpret_cast<const uint2*>(a.in_rows + (t0 + row) * TE_IN + ch * 4);
+                *reinterpret_cast<uint2*>(XA + row * TB_PX + ch * 4) = v;
+            }
+            for (int c = tid; c < TE_ROWS * 8; c += TB_THREADS) {
+                const int row = c >> 3, ch = c & 7;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < nt) v = *reinterpret_cast<const uint4*>(a.dgrad + (t0 + row) * 64 + ch * 8);
+                *reinterpret_cast<uint4*>(DX + row * TB_PX + ch * 8) = v;
+            }
+            __syncthreads();
+            tb_gemm<64, 64, 0>(XA, TB_PX, w0, V, A0, TB_PX, nullptr, 0, lane, wave);                           // a0
+            __syncthreads();
+            tb_ln64_bwd<false>(A0, TB_PX, DX, TB_PX, TMP, TB_PX, V + 64, V + 128, STAT, nt, tid);               // dA0
+            __syncthreads();
+            tb_ln64_colgrad<true>(A0, TB_PX, DX, TB_PX, V + 64, V + 128, STAT, nt, tid, CS + 64, CS + 128);
+            tb_wgrad<1, 2>(TMP, TB_PX, 16 * wq, XA, TB_PX, 32 * wh, ax, lane);                                  // dW0 += dA0^T tiles
+            tb_colsum<64>(TMP, TB_PX, nt, tid, CS);
+        }
+        __syncthreads();
+    }
+    const int lane = tid0 & 63;
+    float* G = a.G;
+    if constexpr (PART == 1) {
+        tb_wgrad_out<1, 1>(G + TGE_W, 64, 16 * (wave >> 2), 16 * (wave & 3), ax, lane);
+        if (tid0 < 96 && (tid0 & 31) < 32) { const float v = CS[(tid0 >> 5) * 64 + (tid0 & 31)]; if (v != 0.f) atomicAdd(G + TGE1_B + tid0, v); }
+    } else {
+        tb_wgrad_out<1, 2>(G + TGE_W, 64, 16 * wq, 32 * wh, ax, lane);
+        if (tid0 < 192) { const float v = CS[tid0]; if (v != 0.f) atomicAdd(G + TGE0_B + tid0, v); }
+    }
+}
+
 }  // namespace catan

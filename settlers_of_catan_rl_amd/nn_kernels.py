@@ -1066,6 +1066,19 @@ def te_fused_backward():
     return TE_FUSED_BWD
 
 
+# The two ENDS of the sub-layer chain as one kernel each (k_te_bwd_ends: the final LayerNorm-25 / out_proj and the first layer's LayerNorm /
+# product, their small activations recomputed): the forward stores 306 B per token less (tiles64, a0, p) and the backward's five passes over
+# those rows become two.  A/B switch (tools/ab_step_switches.py "te_ends"); needs the weight images (wpt32).  OFF by default: measured
+# 21.14 / 21.20 / 21.32 ms per minibatch step with the separate kernels against 21.34 / 21.44 / 21.46 with these (profiles/r05_ab_te_ends.txt) -
+# like the whole-layer kernels above, a 95-token group walked through barrier-separated phases costs more issue time than the streaming
+# kernels cost in bytes.  CATAN_TE_ENDS_FUSED=1 selects them (306 B per token less stored).
+TE_ENDS_FUSED = os.environ.get("CATAN_TE_ENDS_FUSED", "0") == "1"
+
+
+def te_ends_fused():
+    return TE_ENDS_FUSED and weight_images.enabled and _te_backward_fused_w()
+
+
 def _te_fused_backward(ctx, dout):
     """_TileEncoderTrain.backward through catan_tile_encoder_bwd_layer1 / _layer0: two launches, the forward recomputed on chip.  The
     gradient blocks' layout is include/catan_hip_nn.h's (catan_te_bwd_grad_floats)."""
@@ -1139,6 +1152,10 @@ class _TileEncoderTrain(torch.autograd.Function):
         if ctx.recompute_h:
             drop = drop + ("h",)
             ctx.packed = (wts, vecs)
+        ctx.ends = te_ends_fused()
+        if ctx.ends:
+            drop = drop + ("tiles64", "a0", "p")
+            ctx.tiles = x
         names = [(n, w) for n, w in _TE_SAVES if not (drop and n.startswith(drop))]
         need = T * sum(w for _, w in names)
         lease = _TeWorkspace.lease(need, x.device)
@@ -1177,11 +1194,19 @@ class _TileEncoderTrain(torch.autograd.Function):
         T = B * 19
         g = [None] * len(P)
         im = _te_images(ctx.te) if weight_images.enabled else None
+        L = _lib.lib()
         with torch.autocast("cuda", enabled=False):
-            d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
-            dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
-            dx = _rows_product(dp, im.wpt if im is not None else P[36].to(bf).t().contiguous())   # [T, 64]
-            g[36], g[37] = _wgrad(sv["xfin"], dp, True)
+            if ctx.ends:                        # k_te_bwd_ends<1>: P recomputed, LayerNorm + ReLU backward, dWp / dbp, d(xfin): one pass over xfin and dOut
+                dd = dout if (dout.dtype == bf and dout.is_contiguous()) else dout.to(bf).contiguous()
+                gt = grad_zeros((int(L.catan_te_bwd_ends_grad_floats(1)),), dd.device)
+                dx = torch.empty_like(sv["xfin"])
+                _lib.check(L.catan_tile_encoder_bwd_tail(_ptr(im.wts), _ptr(im.vecs), _ptr(im.wpt32), _ptr(sv["xfin"]), _ptr(dd), dd.shape[1], _ptr(dx), _ptr(gt), B, _stream()))
+                g[36], g[37], g[38], g[39] = gt[:2048].view(32, 64)[:25], gt[2048:2073], gt[2080:2105], gt[2112:2137]
+            else:
+                d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
+                dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
+                dx = _rows_product(dp, im.wpt if im is not None else P[36].to(bf).t().contiguous())   # [T, 64]
+                g[36], g[37] = _wgrad(sv["xfin"], dp, True)
             for l in (1, 0):
                 b = 4 + 16 * l
                 xin, n1, qkv, o, xmid, n2, h = (sv.get(k + str(l)) for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
@@ -1262,9 +1287,14 @@ class _TileEncoderTrain(torch.autograd.Function):
                     lw = P[b].detach().float().contiguous()
                     _lib.check(_lib.lib().catan_qkv_bwd_dx(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
                     g[b], g[b + 1] = dl[0], dl[1]
-            da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
-            dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
-            g[0] = dw0[:, :60]
+            if ctx.ends:                        # k_te_bwd_ends<0>: a0 recomputed from the tile features, LayerNorm + ReLU backward, dW0 / db0
+                gh = grad_zeros((int(L.catan_te_bwd_ends_grad_floats(0)),), dx.device)
+                _lib.check(L.catan_tile_encoder_bwd_head(_ptr(im.wts), _ptr(im.vecs), _ptr(ctx.tiles), _ptr(dx), _ptr(gh), B, _stream()))
+                g[0], g[1], g[2], g[3] = gh[:4096].view(64, 64)[:, :60], gh[4096:4160], gh[4160:4224], gh[4224:4288]
+            else:
+                da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
+                dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
+                g[0] = dw0[:, :60]
         if ctx.lease is not None:
             ctx.lease.release()
         return (None, None, None) + tuple(g)

@@ -1169,6 +1169,7 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_N", {"fused, LayerNorm outputs stored": "0", "fused, LayerNorm-2 outputs stored": "1"}.get(mode, "2"))
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_H", "1" if mode == "fused, hidden FFN activation recomputed" else "0")
             monkeypatch.setattr(nn_kernels, "TE_FUSED_BWD", mode == "fused, forward recomputed in the backward")
+            monkeypatch.setattr(nn_kernels, "TE_ENDS_FUSED", mode == "fused, the chain's two ends as one kernel each")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
@@ -1193,6 +1194,13 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         # backward passes see the same h up to MFMA summation order
         oh, gh = run(tiles, "fused, hidden FFN activation recomputed")
         assert torch.equal(oh, of)
+        # the two ends of the chain as k_te_bwd_ends<1> / <0> (P and a0 recomputed, not stored; off by default: not faster) instead of the
+        # separate LayerNorm / row-product / weight-gradient kernels on stored activations
+        oe, ge = run(tiles, "fused, the chain's two ends as one kernel each")
+        assert torch.equal(oe, of)
+        for n in names:
+            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
+            assert float((gf[n] - ge[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - ge[n]).norm()) / scale)
         # the backward that recomputes the forward on chip (k_te_bwd_layer<1>, <0>; the training forward stores only the input of layer 1;
         # off by default: slower, nn_kernels.TE_FUSED_BWD).  Same forward arithmetic: the same output bits; gradients as close to the
         # sub-layer kernels' as those are to each other
