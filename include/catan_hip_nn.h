@@ -199,6 +199,16 @@ int catan_categorical_fwd(const float* logits, const float* mask, int64_t mask_l
                           float* logp, float* entropy, float* lse, int64_t rows, int K, catan_stream_t stream);
 int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_ld, const int64_t* action, const float* lse, const float* entropy,
                           const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream);
+/* catan_categorical_fwd / _bwd for GIVEN actions with the mask read as bits of the env's packed mask rows (catan_masks_packed's format: uint32
+ * [n][pitch_words], bit i of the flat mask = word i >> 5, bit i & 31) instead of a float window: row j of the launch uses packed row rows_idx[j]
+ * (NULL: j).  segs (HOST, 8 ints): n0, n1, then (bit offset, AND offset or -1) for the rows j < n0, n0 <= j < n1 and j >= n1 - the heads whose
+ * mask row depends on the action type run on rows sorted by type (build_agent_model.py:113-124); an AND offset multiplies a second mask row in.
+ * given: int64, given_ld elements between consecutive rows (a column of an action matrix), or NULL (arg-max). */
+int catan_categorical_bits_fwd(const float* logits, const uint32_t* packed, int64_t pitch_words, const int64_t* rows_idx, const int32_t* segs, const int64_t* given,
+                               int64_t given_ld, int64_t* action, float* logp, float* entropy, float* lse, int64_t rows, int K, catan_stream_t stream);
+int catan_categorical_bits_bwd(const float* logits, const uint32_t* packed, int64_t pitch_words, const int64_t* rows_idx, const int32_t* segs, const int64_t* action,
+                               const float* lse, const float* entropy, const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream);
+
 
 /* The tile encoder of the policy net (RL/models/tile_encoder.py:41-91: Linear(60, 64) + LayerNorm + ReLU, two pre-norm
  * transformer layers with 4 heads x 16 and a x2 feed-forward net, Linear(64, 25) + LayerNorm + ReLU per tile) as ONE forward

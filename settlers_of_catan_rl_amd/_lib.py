@@ -193,6 +193,8 @@ _SIGS = {
     "catan_te_bwd_ends_grad_floats": (C.c_int32, [C.c_int32]),
     "catan_tile_encoder_bwd_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, _vp]),
     "catan_tile_encoder_bwd_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "catan_categorical_bits_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp]),
+    "catan_categorical_bits_bwd": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp]),
     "catan_wgrad_big_workspace_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "catan_linear_wgrad_big": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp]),
     "catan_adam_chunk_elements": (C.c_int32, []),

@@ -1672,6 +1672,37 @@ int catan_categorical_bwd(const float* logits, const float* mask, int64_t mask_l
     return CATAN_OK;
 }
 
+static int cat_bits_args(CatBits& mb, const uint32_t* packed, int64_t pitch_words, const int64_t* rows_idx, const int32_t* segs, int64_t rows, int K) {
+    if (!packed || !segs || pitch_words < 1 || rows <= 0 || K <= 0) return 1;
+    mb.pm = packed; mb.pitch = (long)pitch_words; mb.rows = (const long long*)rows_idx;
+    mb.n0 = segs[0]; mb.n1 = segs[1];
+    for (int k = 0; k < 3; k++) {
+        mb.off[k] = segs[2 + 2 * k]; mb.aoff[k] = segs[3 + 2 * k];
+        if (mb.off[k] < 0 || mb.off[k] + K > pitch_words * 32 || mb.aoff[k] + K > pitch_words * 32) return 1;
+    }
+    return mb.n0 < 0 || mb.n1 < mb.n0;
+}
+int catan_categorical_bits_fwd(const float* logits, const uint32_t* packed, int64_t pitch_words, const int64_t* rows_idx, const int32_t* segs, const int64_t* given,
+                               int64_t given_ld, int64_t* action, float* logp, float* entropy, float* lse, int64_t rows, int K, catan_stream_t stream) {
+    CatBits mb;
+    if (!logits || !action || !logp || !entropy || !lse || cat_bits_args(mb, packed, pitch_words, rows_idx, segs, rows, K) || (given && given_ld < 1))
+        return fail(CATAN_EINVAL, "catan_categorical_bits_fwd: bad arguments (segs: n0, n1, then (bit offset, AND offset or -1) x 3, inside the packed row)");
+    hipLaunchKernelGGL(k_categorical_bits_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), logits, mb, (const long long*)given, (long)given_ld,
+                       (long long*)action, logp, entropy, lse, (long)rows, K);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+int catan_categorical_bits_bwd(const float* logits, const uint32_t* packed, int64_t pitch_words, const int64_t* rows_idx, const int32_t* segs, const int64_t* action,
+                               const float* lse, const float* entropy, const float* dlogp, const float* dent, float* dlogits, int64_t rows, int K, catan_stream_t stream) {
+    CatBits mb;
+    if (!logits || !action || !lse || !entropy || !dlogp || !dent || !dlogits || cat_bits_args(mb, packed, pitch_words, rows_idx, segs, rows, K))
+        return fail(CATAN_EINVAL, "catan_categorical_bits_bwd: bad arguments");
+    hipLaunchKernelGGL(k_categorical_bits_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S(stream), logits, mb, (const long long*)action, lse, entropy, dlogp, dent,
+                       dlogits, (long)rows, K);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
 int32_t catan_tile_encoder_weight_elems(void) { return TE_WTOTAL; }
 int32_t catan_tile_encoder_vec_elems(void) { return TE_VTOTAL; }
 int catan_tile_encoder_fwd(const void* tiles, const void* weights, const float* vecs, void* out, int64_t boards, catan_stream_t stream) {

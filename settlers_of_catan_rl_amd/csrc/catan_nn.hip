@@ -1040,6 +1040,72 @@ __global__ __launch_bounds__(256) void k_categorical_bwd(const float* __restrict
     }
 }
 
+
+// The same head with the mask read as BITS of the env's packed mask rows (uint32 [n][pitch], bit i of the flat 325-entry mask = word
+// i >> 5, bit i & 31) - the learner's evaluation of given actions.  As float windows of an expanded [rows, 325] matrix every lane's K mask
+// values sat 1 300 bytes from its neighbour's (a cache line per lane and pass), on top of expanding 170 000 x 325 floats per minibatch step
+// and gathering them per head.  Row j of the launch reads packed row rows[j] (rows == nullptr: j).  Up to three SEGMENTS of rows use different
+// bit offsets (rows j < n0: segment 0, j < n1: segment 1, else 2) - the heads whose mask row depends on the action type (corner: settlement /
+// city; relative player: propose / steal; resource: exchange / year of plenty / monopoly) run on rows sorted by type - and a segment may AND
+// a second bit range in (aoff >= 0: the env's "card playable" row x the card's resource row, build_agent_model.py:113-124).
+// given: int64, given_ld elements between rows (a column of the gathered action rows).
+struct CatBits { const unsigned* pm; long pitch; const long long* rows; int n0, n1; int off[3], aoff[3]; };
+__device__ __forceinline__ bool cat_bit(const unsigned* w, int off, int aoff, int k) {
+    bool b = (w[(off + k) >> 5] >> ((off + k) & 31)) & 1u;
+    if (aoff >= 0) b = b && ((w[(aoff + k) >> 5] >> ((aoff + k) & 31)) & 1u);
+    return b;
+}
+__global__ __launch_bounds__(256) void k_categorical_bits_fwd(const float* __restrict__ logits, CatBits mb, const long long* __restrict__ given, long given_ld,
+                                                              long long* __restrict__ action, float* __restrict__ logp, float* __restrict__ entropy,
+                                                              float* __restrict__ lse_out, long B, int K) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    const float* z = logits + row * K;
+    const unsigned* w = mb.pm + (mb.rows ? mb.rows[row] : row) * mb.pitch;
+    const int seg = row < mb.n0 ? 0 : (row < mb.n1 ? 1 : 2);
+    const int off = mb.off[seg], aoff = mb.aoff[seg];
+    float mx = -INFINITY;
+    int amax = 0;
+    for (int k = 0; k < K; k++) if (cat_bit(w, off, aoff, k) && z[k] > mx) { mx = z[k]; amax = k; }
+    float sum = 0.0f;
+    for (int k = 0; k < K; k++) if (cat_bit(w, off, aoff, k)) sum += __expf(z[k] - mx);
+    const float lse = mx + __logf(sum);
+    float ent = 0.0f;
+    for (int k = 0; k < K; k++) {
+        if (!cat_bit(w, off, aoff, k)) continue;
+        const float lp = z[k] - lse, p = __expf(lp);
+        if (p > 0.0f) ent -= p * lp;
+    }
+    int a = given ? (int)given[row * given_ld] : amax;
+    a = min(max(a, 0), K - 1);
+    action[row] = a;
+    logp[row] = (cat_bit(w, off, aoff, a) ? z[a] : -INFINITY) - lse;
+    entropy[row] = ent;
+    lse_out[row] = lse;
+}
+__global__ __launch_bounds__(256) void k_categorical_bits_bwd(const float* __restrict__ logits, CatBits mb, const long long* __restrict__ action,
+                                                              const float* __restrict__ lse, const float* __restrict__ entropy, const float* __restrict__ dlogp,
+                                                              const float* __restrict__ dent, float* __restrict__ dlogits, long B, int K) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    const float* z = logits + row * K;
+    const unsigned* w = mb.pm + (mb.rows ? mb.rows[row] : row) * mb.pitch;
+    const int seg = row < mb.n0 ? 0 : (row < mb.n1 ? 1 : 2);
+    const int off = mb.off[seg], aoff = mb.aoff[seg];
+    float* dz = dlogits + row * K;
+    const int a = (int)action[row];
+    const float l = lse[row], H = entropy[row], gl = dlogp[row], ge = dent[row];
+    for (int k = 0; k < K; k++) {
+        float g = 0.0f;
+        if (cat_bit(w, off, aoff, k)) {
+            const float lp = z[k] - l, p = __expf(lp);
+            g = gl * ((k == a ? 1.0f : 0.0f) - p);
+            if (p > 0.0f) g -= ge * p * (lp + H);
+        }
+        dz[k] = g;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Attention on MFMA for bf16 (L = 19 tiles x 4 heads x 16; L = 25 cards x 4 heads x 4 with a key-length mask): the VALU
 // kernels above spend 115 k FMAs per tile sequence in the backward and ran 4-5x off the HBM floor (config-3 minibatch: 19 of

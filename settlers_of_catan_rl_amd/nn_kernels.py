@@ -1605,6 +1605,60 @@ class _MaskedCategorical(torch.autograd.Function):
         return dlogits, None, None, None
 
 
+# the learner's heads read packed mask bits (policy._evaluate_compact); "0": the float mask rows expanded and gathered per minibatch step
+CATEGORICAL_BITS = os.environ.get("CATAN_CATEGORICAL_BITS", "1") != "0"
+
+
+class _MaskedCategoricalBits(torch.autograd.Function):
+    """k_categorical_bits_fwd / _bwd: _MaskedCategorical for given actions with the mask as bits of the packed mask rows (no float mask matrix)"""
+
+    @staticmethod
+    def forward(ctx, logits, packed, rows_idx, segs, given, given_ld):
+        import ctypes as C
+        B, K = logits.shape
+        logits = logits.contiguous()
+        action = torch.empty(B, dtype=torch.int64, device=logits.device)
+        logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+        ent, lse = torch.empty_like(logp), torch.empty_like(logp)
+        sg = (C.c_int32 * 8)(*segs)
+        _lib.check(_lib.lib().catan_categorical_bits_fwd(_ptr(logits), _ptr(packed), packed.stride(0), _ptr(rows_idx) if rows_idx is not None else None, C.cast(sg, C.c_void_p),
+                                                         C.c_void_p(given.data_ptr()), given_ld, _ptr(action), _ptr(logp), _ptr(ent), _ptr(lse), B, K, _stream()))
+        ctx.save_for_backward(logits, packed, action, lse, ent, *(() if rows_idx is None else (rows_idx,)))
+        ctx.segs = tuple(segs)
+        ctx.mark_non_differentiable(action)
+        return action, logp, ent
+
+    @staticmethod
+    def backward(ctx, _da, dlogp, dent):
+        import ctypes as C
+        logits, packed, action, lse, ent = ctx.saved_tensors[:5]
+        rows_idx = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
+        B, K = logits.shape
+        dlogits = torch.empty_like(logits)
+        dl, de = dlogp.float().contiguous(), dent.float().contiguous()
+        sg = (C.c_int32 * 8)(*ctx.segs)
+        _lib.check(_lib.lib().catan_categorical_bits_bwd(_ptr(logits), _ptr(packed), packed.stride(0), _ptr(rows_idx) if rows_idx is not None else None, C.cast(sg, C.c_void_p),
+                                                         _ptr(action), _ptr(lse), _ptr(ent), _ptr(dl), _ptr(de), _ptr(dlogits), B, K, _stream()))
+        return dlogits, None, None, None, None, None
+
+
+def masked_categorical_bits(logits, packed, rows_idx, segments, given):
+    """logits fp32 [B, K]; packed int32 [n, pitch] (the env's mask rows); rows_idx int64 [B] (row j -> packed row) or None; segments: a list
+    of 1..3 (row count, bit offset, AND offset or None) - consecutive row ranges of the launch; given: int64 [B], any stride (a column of an
+    action matrix).  -> (action, log-prob, entropy) as masked_categorical."""
+    B = logits.shape[0]
+    segs = list(segments) + [(0, segments[-1][1], segments[-1][2])] * (3 - len(segments))
+    n0 = segs[0][0]
+    n1 = n0 + segs[1][0] if len(segments) > 1 else B
+    if len(segments) == 1:
+        n0 = B
+    flat = [n0, n1]
+    for _, off, aoff in segs:
+        flat += [int(off), -1 if aoff is None else int(aoff)]
+    assert given.dtype == torch.int64 and given.dim() == 1 and packed.dtype == torch.int32 and packed.stride(1) == 1
+    return _MaskedCategoricalBits.apply(logits, packed, rows_idx, flat, given, given.stride(0) if B > 1 else 1)
+
+
 def categorical_supported(logits):
     return logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
 

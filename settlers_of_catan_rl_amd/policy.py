@@ -614,7 +614,13 @@ class _ActionHeads(nn.Module):
         typ, card = actions[:, 0], actions[:, 4]
         pre_of = lambda i, x: _lin(x, H[i].mlp_1.weight[:, :D], H[i].mlp_1.bias)
         packed = isinstance(m, PackedActionMasks)
-        type_head = lambda x: _categorical(H[0].logits(pre_of(0, x)), m.type_mask() if packed else m[:, MO[0]:MO[0] + 13], typ, False, None)
+        # packed masks on the GPU: the heads read their mask as BITS of the env's rows (nn_kernels.masked_categorical_bits) - no float mask
+        # matrix, no mask gather, no concatenation of the type-dependent mask rows
+        bits = packed and main.is_cuda and nn_kernels.CATEGORICAL_BITS
+        if bits:
+            type_head = lambda x: nn_kernels.masked_categorical_bits(H[0].logits(pre_of(0, x)), m.packed, None, [(B, MO[0], None)], typ)
+        else:
+            type_head = lambda x: _categorical(H[0].logits(pre_of(0, x)), m.type_mask() if packed else m[:, MO[0]:MO[0] + 13], typ, False, None)
         # one sort by (type, card of a played development card) and one host read give every head's rows
         perm, ends, ev = grouping if grouping is not None else self.start_grouping(actions)
         if ev is not None:
@@ -657,7 +663,7 @@ class _ActionHeads(nn.Module):
             mg = nn_kernels.gather_ranges(main, perm, all_rows, pieces)
         self.last_value = value_fn(m_val) if value_fn is not None else None
         _, logp0, e0 = type_head(m_type)
-        mm_g, ag = (m.rows(all_rows) if packed else m[all_rows]), actions[all_rows]
+        mm_g, ag = (None if bits else m.rows(all_rows) if packed else m[all_rows]), actions[all_rows]
         at, off = {}, 0
         for i in order:
             at[i] = slice(off, off + sets[i].numel()); off += sets[i].numel()
@@ -669,7 +675,12 @@ class _ActionHeads(nn.Module):
         pre = {j: p for (j, _), p in zip(jobs, pres)}
 
         def run(i, sl, mask, col, extra=None, custom=None):
-            _, lp, ent = _categorical(H[i].logits(pre[i], extra, custom), mask, ag[sl, col], False, None)
+            """mask: a float [rows, K] matrix - or, with `bits`, the (row count, bit offset, AND offset or None) segments of the head's rows"""
+            logits = H[i].logits(pre[i], extra, custom)
+            if bits:
+                _, lp, ent = nn_kernels.masked_categorical_bits(logits, m.packed, all_rows[sl], mask, ag[sl, col])
+            else:
+                _, lp, ent = _categorical(logits, mask, ag[sl, col], False, None)
             lps.append((sl, lp)); ents.append(ent)
 
         def two_hot(n_first, n):
@@ -678,17 +689,27 @@ class _ActionHeads(nn.Module):
 
         if 1 in at:        # corner (settlement / city), its mask row picked by the type (build_agent_model.py:113-115)
             sl, n1 = at[1], rs.numel()
-            mk = mm_g[sl, MO[1]:MO[1] + 108]
-            run(1, sl, torch.cat((mk[:n1, :54], mk[n1:, 54:])), 1, two_hot(n1, mk.shape[0]))
+            nr = sl.stop - sl.start
+            if bits:
+                mask = [(n1, MO[1], None), (nr - n1, MO[1] + 54, None)]
+            else:
+                mk = mm_g[sl, MO[1]:MO[1] + 108]
+                mask = torch.cat((mk[:n1, :54], mk[n1:, 54:]))
+            run(1, sl, mask, 1, two_hot(n1, nr))
         for i, (lo, w, col) in {2: (MO[2], 73, 2), 3: (MO[3], 19, 3), 4: (MO[4], 5, 4), 11: (MO[11], 5, 17)}.items():
             if i in at:
-                run(i, at[i], mm_g[at[i], lo:lo + w], col)
+                run(i, at[i], [(at[i].stop - at[i].start, lo, None)] if bits else mm_g[at[i], lo:lo + w], col)
         if 5 in at:
-            run(5, at[5], mm_g[at[5], MO[5]:MO[5] + 2], 5, custom=trade[sets[5]].to(main.dtype))
+            run(5, at[5], [(at[5].stop - at[5].start, MO[5], None)] if bits else mm_g[at[5], MO[5]:MO[5] + 2], 5, custom=trade[sets[5]].to(main.dtype))
         if 6 in at:        # relative player (propose: mask row 0, steal: row 1)
             sl, n1 = at[6], rp.numel()
-            mk = mm_g[sl, MO[6]:MO[6] + 6]
-            run(6, sl, torch.cat((mk[:n1, :3], mk[n1:, 3:])), 6, two_hot(n1, mk.shape[0]))
+            nr = sl.stop - sl.start
+            if bits:
+                mask = [(n1, MO[6], None), (nr - n1, MO[6] + 3, None)]
+            else:
+                mk = mm_g[sl, MO[6]:MO[6] + 6]
+                mask = torch.cat((mk[:n1, :3], mk[n1:, 3:]))
+            run(6, sl, mask, 6, two_hot(n1, nr))
         if 7 in at:        # the recurrent give / receive lists of a proposed trade
             sl, cr = at[7], cur_res[rp]
             give_out, _, lp7, e7 = self._recurrent(H[7], pre[7], None, cr, True, ag[sl, 7:11], False, None)
@@ -706,12 +727,15 @@ class _ActionHeads(nn.Module):
             x[n_ex:n_ex + n_yop, 2] = 1.0                                         # (card is YoP, card is Monopoly)
             if i == 9:
                 x[n_ex + n_yop:, 3] = 1.0
-                m9 = mm_g[sl, MO[9]:MO[9] + 20].reshape(-1, 4, 5)
                 # exchange: row 0; a card: row 1 (all ones in the env's masks) x the card's row (Monopoly 2, YoP 3)
-                mask = torch.cat((m9[:n_ex, 0], m9[n_ex:n_ex + n_yop, 1] * m9[n_ex:n_ex + n_yop, 3], m9[n_ex + n_yop:, 1] * m9[n_ex + n_yop:, 2]))
+                if bits:
+                    mask = [(n_ex, MO[9], None), (n_yop, MO[9] + 5, MO[9] + 15), (n - n_ex - n_yop, MO[9] + 5, MO[9] + 10)]
+                else:
+                    m9 = mm_g[sl, MO[9]:MO[9] + 20].reshape(-1, 4, 5)
+                    mask = torch.cat((m9[:n_ex, 0], m9[n_ex:n_ex + n_yop, 1] * m9[n_ex:n_ex + n_yop, 3], m9[n_ex + n_yop:, 1] * m9[n_ex + n_yop:, 2]))
                 run(9, sl, mask, 15, x)
             else:
-                run(10, sl, mm_g[sl, MO[10]:MO[10] + 5], 16, torch.cat((x, F.one_hot(ag[sl, 15], 5).float()), -1))
+                run(10, sl, [(n, MO[10], None)] if bits else mm_g[sl, MO[10]:MO[10] + 5], 16, torch.cat((x, F.one_hot(ag[sl, 15], 5).float()), -1))
         # every segment of all_rows got exactly one log-prob vector: ONE concatenation in segment order (not a zero fill + a slice copy per
         # head), one index_add back to the batch rows; the entropies as one sum over one concatenation (not a reduction per head)
         lps.sort(key=lambda t: t[0].start)

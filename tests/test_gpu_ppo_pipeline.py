@@ -1496,3 +1496,53 @@ def test_recurrent_given_kernel_equals_the_torch_formulation(hip_lib):
                     assert c.dtype == dt and torch.equal(c.float().cpu(), cond.to(dt).float())
                     assert torch.equal(m.cpu(), steps(mask)) and torch.equal(gv.cpu(), steps(acts))
                     assert torch.equal(kp.cpu(), keep) and torch.equal(of.cpu(), out_final)
+
+
+def test_categorical_on_packed_mask_bits_equals_the_float_mask_kernel(hip_lib):
+    """catan_categorical_bits_fwd / _bwd (the learner's heads reading their mask as bits of the env's packed rows, through a row list, with
+    up to three row segments at different bit offsets and an AND of two mask rows) against catan_categorical_fwd / _bwd on the float mask the
+    bits expand to: actions, log-probs, entropies and logit gradients bit for bit (same arithmetic, same order)."""
+    import torch
+    from settlers_of_catan_rl_amd import nn_kernels, spec
+    g = torch.Generator().manual_seed(12)
+    n, W = 4000, 32
+    dense = (torch.rand(n, spec.MASK_WORDS, generator=g) < 0.6).float()
+    dense[::13] = 0.0                                                        # rows with an empty mask (NaN log-probs in both kernels)
+    same = lambda a, b: torch.equal(a.nan_to_num(nan=123.0, posinf=1e30, neginf=-1e30), b.nan_to_num(nan=123.0, posinf=1e30, neginf=-1e30))
+    bitsl = torch.zeros(n, W * 32, dtype=torch.int64)
+    bitsl[:, :dense.shape[1]] = dense.long()
+    words = (bitsl.view(n, W, 32) << torch.arange(32)).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).cuda()
+    dense = dense.cuda()
+    acts = torch.randint(0, 5, (n, 18), generator=g).cuda()
+    for K, segs in ((13, [(None, 0, None)]), (54, [(700, 40, None), (None, 94, None)]), (5, [(900, 301, None), (300, 306, 316), (None, 306, 311)]),
+                    (73, [(None, 148, None)]), (3, [(0, 280, None), (None, 283, None)])):
+        B = 2500
+        rows = torch.randperm(n, generator=g)[:B].cuda()
+        counts, left = [], B
+        for c, _, _ in segs:
+            c = left if c is None else c
+            counts.append(c); left -= c
+        segs = [(c, o, a) for c, (_, o, a) in zip(counts, segs)]
+        mask, at = [], 0
+        for c, o, a in segs:
+            r = rows[at:at + c]; at += c
+            mk = dense[r, o:o + K]
+            mask.append(mk if a is None else mk * dense[r, a:a + K])
+        mask = torch.cat(mask)
+        for idx in (rows, None):
+            if idx is None:                                                  # no row list: row j reads packed row j
+                pk, mk = words[rows].contiguous(), mask
+            else:
+                pk, mk = words, mask
+            z = torch.randn(B, K, generator=g).cuda()
+            z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            given = acts[:B, 3] % K                                          # a strided column
+            a1, lp1, e1 = nn_kernels.masked_categorical(z1, mk, given.contiguous(), False, None)
+            a2, lp2, e2 = nn_kernels.masked_categorical_bits(z2, pk, idx, segs, given)
+            assert torch.equal(a1, a2) and same(lp1, lp2) and same(e1, e2)
+            ok = torch.isfinite(lp1)
+            w1, w2 = torch.randn(B, generator=g).cuda(), torch.randn(B, generator=g).cuda()
+            for lp, e, zz in ((lp1, e1, z1), (lp2, e2, z2)):
+                (torch.where(ok, lp, torch.zeros_like(lp)) * w1 + e * w2).sum().backward()
+            assert same(z1.grad, z2.grad)
