@@ -46,6 +46,11 @@ struct catan_env {
     Pending pend;         // tier-2 longest-road hand-off (device arrays)
     unsigned long long* prof; // device [12] phase profile of k_step, enabled by catan_profile_enable
     int prof_on;
+    int lr_mid_budget;    // deferred windows: the middle tier's budget (0: off), and k_lr_heavy's workgroups behind it
+    int lr_mid_heavy_grid;
+    int lr_split;         // tier 1 as search (k_lr_finish<LRF_SPLIT>) + lane-per-game completion (k_lr_complete)
+    int step_bin_order;   // k_step: longest-lasting bins first (StepCfg::bin_order)
+    int step_agpr;        // experiment: accumulation registers reserved by k_step (0, 96, 160: see the kernel)
     int step_wpb;         // waves per k_step workgroup (4: one workgroup per CU, a SIMD per wave; 1: one-wave workgroups)
     u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
@@ -374,6 +379,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
         if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.resets[i][2], (size_t)e->N * sizeof(i32));
         if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e->ev_sdone[i], EV_SYNC);
     }
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.heavy2, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->sstream, hipStreamNonBlocking);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_reward, (size_t)e->n * 4 * sizeof(float));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->s_done, (size_t)e->n);
@@ -406,7 +412,18 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
     // previous pass hold LDS on most CUs, so a 116 KB workgroup often has to wait for a CU where the 29 KB one-wave workgroup fits at once
     e->step_wpb = 1;
-    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : 1;
+    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : (atoi(wp) == 2 ? 2 : 1);
+    e->step_agpr = 0;
+    e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
+    if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
+    e->lr_split = 0;
+    // the middle tier of a deferred window: on since round 5 (budget 256, 32 tier-2 workgroups behind it: 53.9 -> 51.2-51.6 us per pass,
+    // same file); CATAN_LR_MID_BUDGET=0: every tier-2 request straight to k_lr_heavy on 128 workgroups
+    e->lr_mid_budget = 256; e->lr_mid_heavy_grid = 32;
+    if (const char* mb = getenv("CATAN_LR_MID_BUDGET")) { e->lr_mid_budget = atoi(mb) > 0 ? atoi(mb) : 0; if (e->lr_mid_budget == 0) e->lr_mid_heavy_grid = 128; }
+    if (const char* mg = getenv("CATAN_LR_MID_HEAVY_GRID")) { const int g = atoi(mg); if (g >= 8 && g <= 256) e->lr_mid_heavy_grid = g; }
+    if (const char* ls = getenv("CATAN_LR_SPLIT")) e->lr_split = atoi(ls) != 0;
+    if (const char* ag = getenv("CATAN_STEP_AGPR")) e->step_agpr = atoi(ag) == 96 ? 96 : (atoi(ag) == 160 ? 160 : 0);
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
     HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
@@ -448,6 +465,7 @@ void catan_destroy(catan_env_t* e) {
         if (e->pend.resets[i][2]) hipFree(e->pend.resets[i][2]);
         if (e->ev_sdone[i]) hipEventDestroy(e->ev_sdone[i]);
     }
+    if (e->pend.heavy2) hipFree(e->pend.heavy2);
     if (e->sstream) hipStreamDestroy(e->sstream);
     if (e->s_reward) hipFree(e->s_reward);
     if (e->s_done) hipFree(e->s_done);
@@ -484,6 +502,7 @@ static StepCfg step_cfg(const catan_env_t* e) {
     sc.prof = e->prof_on ? e->prof : nullptr;
     sc.prof_wave = e->prof_on >= 2 ? e->prof_wave : nullptr;
     sc.prof_timeline = e->prof_on == 3;
+    sc.bin_order = e->step_bin_order;
     return sc;
 }
 // One env step = the games listed by action type (k_sample_random / k_classify), then k_step (fused: apply + done/reward +
@@ -501,6 +520,8 @@ static StepCfg step_cfg(const catan_env_t* e) {
 constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x split parts are strided over them
 constexpr int LR_HEAVY_GRID_DEFERRED = 128;  // next to the fast path: leave most CUs (and their LDS) to k_step
 constexpr int LR_GRID = 4096;
+constexpr int LR_MID_GRID = 2048;          // the middle tier: one request per one-wave workgroup (a window leaves ~640)
+constexpr int LR_COMPLETE_GRID = 128;   // k_lr_complete: 64 requests per one-wave workgroup, grid-stride beyond 8 192 requests
 constexpr int RESET_GRID = 2048;
 // ev (optional): [0] before the sort, [1] after it, [2] after k_step
 static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev,
@@ -525,6 +546,9 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     case 32: hipLaunchKernelGGL(k_step<32>, dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
     default:
         if (e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, false, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else if (e->step_wpb == 2) hipLaunchKernelGGL((k_step<64, false, 2>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 2)), dim3(128), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else if (e->step_agpr == 96) hipLaunchKernelGGL((k_step<64, false, 1, 96>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else if (e->step_agpr == 160) hipLaunchKernelGGL((k_step<64, false, 1, 160>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else hipLaunchKernelGGL(k_step<64>, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         break;
     }
@@ -540,7 +564,12 @@ static int lr_grid() {      // workgroups of k_lr_finish (CATAN_LR_GRID: diagnos
 static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    hipLaunchKernelGGL(k_lr_finish, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    if (e->lr_split && !e->pend.sample) {
+        hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+                           sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
+        hipLaunchKernelGGL(k_lr_complete, dim3(LR_COMPLETE_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl);
+    } else
+    hipLaunchKernelGGL(k_lr_finish<LRF_TIER1>, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -570,6 +599,14 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
         }
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
+    if (!lockstep && e->lr_mid_budget > 0 && !e->pend.sample) {
+        // the middle tier: one wave per tier-2 request with a large budget; k_lr_heavy - fewer workgroups: few requests are left - takes the rest
+        HIPCHK(hipMemsetAsync(e->pend.ctr + CTR_HEAVY2, 0, sizeof(u32), st));
+        hipLaunchKernelGGL(k_lr_finish<LRF_MID>, dim3(LR_MID_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, 0, e->lr_mid_budget,
+                           (unsigned long long*)nullptr, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_lr_heavy, dim3(e->lr_mid_heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)(e->pend.ctr + CTR_HEAVY2), (const u64*)e->pend.heavy2,
+                           e->pend.len, e->lr_round[1], e->mpk, reward, done, sc, e->pend);
+    } else
     hipLaunchKernelGGL(k_lr_heavy, dim3(heavy_grid), dim3(LR_HEAVY_THREADS), 0, st, e->ctx, (const u32*)sctr, (const u64*)e->pend.heavy[sa], e->pend.len,
                        e->lr_round[lockstep ? 0 : 1], e->mpk, reward, done, sc, e->pend);   // search + completion
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
@@ -747,7 +784,7 @@ int catan_random_rollout(catan_env_t* e, uint32_t step_idx0, int64_t steps, cata
 // games sit out one more pass (92.6 -> 90.0 % of the games active): 1.118 G env-steps/s either way.  What keeps the pass above the main
 // stream's own 45 us is then the event record / wait packets around every pass (~7 us of gaps) and the side work's share of the CUs.
 static int t1_depth() {
-    static const int D = (getenv("CATAN_T1_DEPTH") && atoi(getenv("CATAN_T1_DEPTH")) == 3) ? 3 : 2;
+    static const int D = (getenv("CATAN_T1_DEPTH") && atoi(getenv("CATAN_T1_DEPTH")) == 2) ? 2 : 3;
     return D;
 }
 static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {

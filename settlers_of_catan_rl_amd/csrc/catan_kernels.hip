@@ -1022,18 +1022,6 @@ DEVI u64 settle_spots(const Boards& b, bool initial) {
     if (!initial) return ~blocked & topo_touched(b.own_rlo, b.own_rhi) & ALL54;
     return ~blocked & ALL54;
 }
-// ref: env/wrapper.py:322-339 + game/components/edge.py:23-42.  Returns 73 bits (lo 64, hi 9; bit 72 = dummy edge).
-template <class S>
-DEVI void road_spots(const S& s, const Boards& b, int pid, int flags, bool road_building, u64& lo, u32& hi) {
-    const u64 elo = ~b.all_rlo;
-    const u32 ehi = ~b.all_rhi & 0xFFu;
-    u64 anchors;
-    if ((flags & F_INITIAL) && s.pb(pid, P_ISET) == 2) anchors = 1ull << s.pb(pid, P_ISECOND);
-    else anchors = b.own_bld | (topo_touched(b.own_rlo, b.own_rhi) & ~b.occ);
-    topo_edges_at(anchors, lo, hi);
-    lo &= elo; hi &= ehi;
-    if (road_building && lo == 0 && hi == 0) hi = 1u << 8;
-}
 // ref: env/wrapper.py:368-388.  returns 5-bit card mask; yop_ok -> bank vector valid
 template <class S>
 DEVI int dev_card_mask(const S& s, int pid, u32& bank_bits) {
@@ -1067,89 +1055,94 @@ DEVI void compute_masks(const S& s, u32 (&m)[MASK_WORDS], Limits lim) {
         setr<M11, 5>(m, rb);
         return;
     }
-    Boards b;
-    if (flags & F_INITIAL) {                                               // wrapper.py:195-204
-        load_boards(s, pid, b);
-        int iset = s.pb(pid, P_ISET), iroad = s.pb(pid, P_IROAD);
-        if (iset == 0 || (iset == 1 && iroad == 1)) {
-            setr<M0, 13>(m, 1u << T_SETTLE);
-            setr<M1, 54>(m, settle_spots(b, true));
-        } else {
-            u64 lo; u32 hi;
-            road_spots(s, b, pid, flags, false, lo, hi);
-            setr<M0, 13>(m, 1u << T_ROAD);
-            setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi);
+    // Phases that read the board - the initial placements, road building, the normal turn - share ONE call site per topology function
+    // below: a wave's 64 games are in different phases, every divergent branch taken by any lane is executed by the wave, and the
+    // board-to-mask functions (54-72 test / select steps each) were up to four call sites deep (topo_touched: initial road, road
+    // building, settlement spots, road spots).
+    const bool initial = (flags & F_INITIAL) != 0, rbuild = !initial && (flags & F_RB_ACTIVE) != 0;
+    if (!initial && !rbuild) {
+        if (flags & F_JUST_ROBBER) {                                           // wrapper.py:210-213, 341-351
+            int seatof = s.b(B_SEATOF);
+            const u64 tm = topo_tile_corners(s.b(B_ROBBER));
+            u32 tg = 0;
+            for (int o = 0; o < 4; o++) if (o != pid && ((s.settle(o) | s.city(o)) & tm)) tg |= 1u << label_of(seatof, pid, o);
+            setr<M0, 13>(m, 1u << T_STEAL);
+            setr<M6 + 3, 3>(m, tg);
+            return;
         }
-        return;
-    }
-    if (flags & F_RB_ACTIVE) {                                             // wrapper.py:206-209
-        load_boards(s, pid, b);
-        u64 lo; u32 hi;
-        road_spots(s, b, pid, flags, true, lo, hi);
-        setr<M0, 13>(m, 1u << T_ROAD);
-        setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi);
-        return;
-    }
-    if (flags & F_JUST_ROBBER) {                                           // wrapper.py:210-213, 341-351
-        int seatof = s.b(B_SEATOF);
-        const u64 tm = topo_tile_corners(s.b(B_ROBBER));
-        u32 tg = 0;
-        for (int o = 0; o < 4; o++) if (o != pid && ((s.settle(o) | s.city(o)) & tm)) tg |= 1u << label_of(seatof, pid, o);
-        setr<M0, 13>(m, 1u << T_STEAL);
-        setr<M6 + 3, 3>(m, tg);
-        return;
-    }
-    if (flags & F_MUST_RESPOND) {                                          // wrapper.py:214-218, 353-365
-        int tgt = s.b(B_TRADE_TGT), nr = s.b(B_TRADE_NR);
-        int need[5] = { 0, 0, 0, 0, 0 };
-        for (int i = 0; i < 4; i++) if (i < nr) {
-            int r = s.b(B_TRADE_RECV + i) - 1;
+        if (flags & F_MUST_RESPOND) {                                          // wrapper.py:214-218, 353-365
+            int tgt = s.b(B_TRADE_TGT), nr = s.b(B_TRADE_NR);
+            int need[5] = { 0, 0, 0, 0, 0 };
+            for (int i = 0; i < 4; i++) if (i < nr) {
+                int r = s.b(B_TRADE_RECV + i) - 1;
 #pragma unroll
-            for (int k = 0; k < 5; k++) need[k] += (k == r) ? 1 : 0;
-        }
-        bool have = true;
-#pragma unroll
-        for (int k = 0; k < 5; k++) if (need[k] > s.res(tgt, k)) have = false;
-        setr<M0, 13>(m, 1u << T_RESPOND);
-        setr<M5, 2>(m, have ? 3u : 2u);
-        return;
-    }
-    u32 types = 0;
-    if (!(flags & F_ROLLED)) {                                             // wrapper.py:219-229
-        types = 1u << T_ROLL;
-        if (s.pb(pid, P_NHID) > 0 && !(flags & F_PLAYED_DEV)) {
-            u32 bank_bits;
-            int cm = dev_card_mask(s, pid, bank_bits);
-            if (cm) {
-                types |= 1u << T_PLAYDEV;
-                setr<M4, 5>(m, cm);
-                if (cm & (1 << C_YOP)) { setr<M9 + 10, 5>(m, bank_bits); setr<M10, 5>(m, bank_bits); }
+                for (int k = 0; k < 5; k++) need[k] += (k == r) ? 1 : 0;
             }
-        }
-        setr<M0, 13>(m, types);
-        return;
-    }
-    types = 1u << T_ENDTURN;                                               // wrapper.py:232
-    if (lim.max_actions >= 0 && (int)s.w(W_ACTIONS) > lim.max_actions) {   // wrapper.py:233-234: only EndTurn is left
-        setr<M0, 13>(m, types);
-        return;
-    }
-    load_boards(s, pid, b);
-    int res[5];
+            bool have = true;
 #pragma unroll
-    for (int r = 0; r < 5; r++) res[r] = s.res(pid, r);
-    if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_WOOD] > 0 && res[R_BRICK] > 0) {   // :238-243
-        u64 v = settle_spots(b, false);
+            for (int k = 0; k < 5; k++) if (need[k] > s.res(tgt, k)) have = false;
+            setr<M0, 13>(m, 1u << T_RESPOND);
+            setr<M5, 2>(m, have ? 3u : 2u);
+            return;
+        }
+        if (!(flags & F_ROLLED)) {                                             // wrapper.py:219-229
+            u32 types = 1u << T_ROLL;
+            if (s.pb(pid, P_NHID) > 0 && !(flags & F_PLAYED_DEV)) {
+                u32 bank_bits;
+                int cm = dev_card_mask(s, pid, bank_bits);
+                if (cm) {
+                    types |= 1u << T_PLAYDEV;
+                    setr<M4, 5>(m, cm);
+                    if (cm & (1 << C_YOP)) { setr<M9 + 10, 5>(m, bank_bits); setr<M10, 5>(m, bank_bits); }
+                }
+            }
+            setr<M0, 13>(m, types);
+            return;
+        }
+        if (lim.max_actions >= 0 && (int)s.w(W_ACTIONS) > lim.max_actions) {   // wrapper.py:232-234: only EndTurn is left
+            setr<M0, 13>(m, 1u << T_ENDTURN);
+            return;
+        }
+    }
+    Boards b;
+    load_boards(s, pid, b);
+    int res[5] = { 0, 0, 0, 0, 0 };
+    bool ini_settle = false, second = false;
+    if (initial) {                                                         // wrapper.py:195-204
+        const int iset = s.pb(pid, P_ISET), iroad = s.pb(pid, P_IROAD);
+        ini_settle = iset == 0 || (iset == 1 && iroad == 1);
+        second = iset == 2;                                                // edge.py:23-42 after_second_settlement
+    } else if (!rbuild) {
+#pragma unroll
+        for (int r = 0; r < 5; r++) res[r] = s.res(pid, r);
+    }
+    const bool turn = !initial && !rbuild;
+    const bool want_settle = ini_settle || (turn && res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_WOOD] > 0 && res[R_BRICK] > 0);   // :238-243
+    const bool want_road = (initial && !ini_settle) || rbuild || (turn && res[R_WOOD] > 0 && res[R_BRICK] > 0);                      // :206-209, 252-256
+    u64 blocked = 0, touched = 0, rlo = 0;
+    u32 rhi = 0;
+    if (want_settle) blocked = topo_blocked(b.occ);                        // corner.py:24-39
+    if ((want_settle && !ini_settle) || (want_road && !second)) touched = topo_touched(b.own_rlo, b.own_rhi);
+    if (want_road) {                                                       // wrapper.py:322-339 + edge.py:23-42; bit 72 = the dummy edge
+        const u64 anchors = second ? 1ull << s.pb(pid, P_ISECOND) : b.own_bld | (touched & ~b.occ);
+        topo_edges_at(anchors, rlo, rhi);
+        rlo &= ~b.all_rlo; rhi &= ~b.all_rhi & 0xFFu;
+        if (rbuild && rlo == 0 && rhi == 0) rhi = 1u << 8;
+    }
+    if (initial || rbuild) {
+        if (ini_settle) { setr<M0, 13>(m, 1u << T_SETTLE); setr<M1, 54>(m, ~blocked & ALL54); }
+        else { setr<M0, 13>(m, 1u << T_ROAD); setr<M2, 64>(m, rlo); setr<M2 + 64, 9>(m, rhi); }
+        return;
+    }
+    u32 types = 1u << T_ENDTURN;                                           // wrapper.py:232
+    if (want_settle) {
+        const u64 v = ~blocked & touched & ALL54;
         if (v && s.pb(pid, P_SLEFT) > 0) { types |= 1u << T_SETTLE; setr<M1, 54>(m, v); }
     }
     if (res[R_WHEAT] >= 2 && res[R_ORE] >= 3 && s.pb(pid, P_CLEFT) > 0 && b.own_set) {   // :245-250
         types |= 1u << T_CITY; setr<M1 + 54, 54>(m, b.own_set);
     }
-    if (res[R_WOOD] > 0 && res[R_BRICK] > 0) {                                            // :252-256
-        u64 lo; u32 hi;
-        road_spots(s, b, pid, flags, false, lo, hi);
-        if (lo | hi) { types |= 1u << T_ROAD; setr<M2, 64>(m, lo); setr<M2 + 64, 9>(m, hi); }
-    }
+    if (want_road && (rlo | rhi)) { types |= 1u << T_ROAD; setr<M2, 64>(m, rlo); setr<M2 + 64, 9>(m, rhi); }
     if (res[R_WHEAT] > 0 && res[R_SHEEP] > 0 && res[R_ORE] > 0 && s.b(B_PILE_LEN) > 0) types |= 1u << T_BUYDEV;   // :258-260
     u32 bank_bits;
     {
@@ -1655,7 +1648,8 @@ struct StepCfg { int validate; int dense_reward; double win_reward; double annea
                  double* reward64;              // optional unrounded rewards [n][4] (catan_set_reward_f64_buffer)
                  unsigned long long* prof;      // optional phase profile: sums / maxima over waves (atomics: coarse, perturbing)
                  u32* prof_wave;                // optional per-wave phase durations of k_step: [wave][8] ticks, plain stores
-                 int prof_timeline; };          // ... with slot 2 = the wave's START (low 32 bits of the 100 MHz wall clock) and slot 3 = where it ran
+                 int prof_timeline;
+                 int bin_order; };              // k_step: bins laid over the waves in BIN_ORDER_LPT order (0: in bin order)          // ... with slot 2 = the wave's START (low 32 bits of the 100 MHz wall clock) and slot 3 = where it ran
                                                 //     (HW_ID | XCC_ID << 28) instead of the request-push time and the validate / switch split
 constexpr int LRF_PROF_ROW = 1088, LRF_PROF_ROWS = 2000;   // k_lr_finish's rows of the per-wave buffer ((N / 16 + SORT_PAD_WAVES) rows)
 constexpr int LRH_PROF_ROW = 3088, LRH_PROF_ROWS = 1000;   // k_lr_heavy's: one row per workgroup (its first request)
@@ -1696,7 +1690,7 @@ DEVI void prof_mark(const StepCfg& cfg, int phase, long long& t_prev) {
 //   Tags: 1 = the kernel that completes the game clears it (lock-step: everything on one stream); >= 2 = the sampler
 //   clears it at a point fixed by the schedule (deferred rollouts: tier 1 two iterations later, slot `sa` two windows
 //   later), never by when a side stream happens to finish.
-struct Pending { u32* ctr; u64* req[3]; u64* heavy[2]; u8* type; u8* who; u64* len; u32* arrive; i32* resets[2][3]; u8* busy;
+struct Pending { u32* ctr; u64* req[3]; u64* heavy[2]; u64* heavy2; u8* type; u8* who; u64* len; u32* arrive; i32* resets[2][3]; u8* busy;
                  u64* spec;                 // lock-step steps: the longest-road requests of games that this step may end (ctr[6])
                  i32* lists;                // the sort: game ids per action-type bin, three sets of [NBINS][N] (set s, bin b, rank r at (s * NBINS + b) * N + r)
                  int bsel;                  // which bin-count set (ctr[16 + NBINS * bsel ..]) and list set this pass reads
@@ -1726,6 +1720,10 @@ DEVI int bin_of(int t, int card) {
     card = min(max(card, 0), 4);                           // the clamp k_step applies to an unvalidated card index
     return card >= 1 ? 12 + card : t;
 }
+// The order in which the bins take the launch's waves (StepCfg::bin_order): workgroups start roughly in index order over a ramp of
+// several microseconds, so the bins whose waves last longest go first (longest processing time first) and the short ones - propose,
+// steal, monopoly - start last; wave durations per bin: profiles/r05_k_step_timeline.txt.  The no-op bin (its waves return at once) stays last.
+__device__ constexpr int BIN_ORDER_LPT[18] = { 0, 9, 7, 11, 16, 2, 14, 3, 5, 4, 13, 1, 12, 8, 15, 6, 10, 17 };
 DEVI int type_of_bin(int bin) { return bin <= 12 ? bin : (bin < BIN_NOOP ? T_PLAYDEV : -1); }
 
 // Fused-sampling rollouts, ONE lane (the slow-path completions: k_lr_finish, the tier-2 completion, the re-deal): the game's
@@ -1897,10 +1895,15 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // per wave): the hardware spreads a workgroup's waves over the four SIMDs of its CU and the 116 KB of LDS admit one workgroup per CU,
 // so every working wave has a SIMD to itself.  As 1 041 one-wave workgroups the dispatcher used 800 of the 1 024 SIMDs and put two to
 // four waves on 208 of them (tools/step_timeline.py, profiles/r05_k_step_timeline.txt): the launch lasted as long as those.
-template <int G, bool SAMPLE = false, int WPB = 1>
+// AG (experiment, CATAN_STEP_AGPR): reserve AG accumulation registers the kernel never uses, so that its allocation (172 -> 176 + AG
+// of a SIMD's 512 registers per lane) admits ONE k_step wave per SIMD - the dispatcher then cannot put two of the launch's waves on one SIMD
+// while it leaves others empty - and still leaves room for tier-1 waves (120 registers each) beside it.
+template <int G, bool SAMPLE = false, int WPB = 1, int AG = 0>
 __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
+    if constexpr (AG == 96) asm volatile("" ::: "a95");
+    if constexpr (AG == 160) asm volatile("" ::: "a159");
     constexpr int TSG = G + 1;
     typedef StLT<TSG> StG;
     __shared__ u32 tile_all[WPB][ROWS_HOT * TSG];
@@ -1919,7 +1922,8 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
         const int pos = wv * G;
         int start = 0;
 #pragma unroll
-        for (int k = 0; k < NBINS; k++) {
+        for (int kk = 0; kk < NBINS; kk++) {
+            const int k = cfg.bin_order ? BIN_ORDER_LPT[kk] : kk;
             const int ck = (int)bins[k], len = (ck + G - 1) & ~(G - 1);
             if (bin < 0 && pos < start + len) { bin = k; cnt = ck; first = pos - start; }
             start += len;
@@ -2132,10 +2136,25 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
     }
     case T_PLAYDEV: {                                                      // game.py:653-693, wrapper.py:140-147
         int card = a[4];
+        // hidden_cards.remove(card): the ordered list lives in the COLD part of the record (global memory).  Read in batches of eight
+        // bytes whose loads are all in flight together - element by element every iteration was a dependent HBM / L2 round trip
+        // (0.5-1 us each with one wave per SIMD), and this type's waves were among the launch's slowest.
         int nh = s.pb(pid, P_NHID), at = -1;
-        for (int i = 0; i < nh; i++) if (at < 0 && s.hidden(pid, i) == card) at = i;
+        for (int base = 0; base < nh && at < 0; base += 8) {
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = base + j < nh ? s.hidden(pid, base + j) : -1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (at < 0 && v[j] == card) at = base + j;
+        }
         if (at >= 0) {
-            for (int i = at; i + 1 < nh; i++) s.set_hidden(pid, i, s.hidden(pid, i + 1));
+            for (int base = at; base + 1 < nh; base += 8) {
+                int v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = base + j + 1 < nh ? s.hidden(pid, base + j + 1) : 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (base + j + 1 < nh) s.set_hidden(pid, base + j, v[j]);
+            }
             s.spb(pid, P_NHID, nh - 1);
             s.spb(pid, P_HCNT + card, s.pb(pid, P_HCNT + card) - 1);
         }
@@ -2380,6 +2399,20 @@ DEVI int lr_apply(LrCache& lc, int who, bool through, u64 found) {
 // Tier 1 of the longest road and the completion of the step, one request per wave: all 64 lanes cooperate on the path
 // search (budgeted; overflow hands the game to the tier-2 list), then the game's hot record is staged linearly in LDS and
 // lane 0 completes the step (holder logic, done/reward, next masks).  `fl` selects the request list.
+// SPLIT (catan_set_lr_split / CATAN_LR_SPLIT): the wave only searches.  Unless the holder's own road was cut (rare: finish_step<2>
+// then needs the other players' paths, possibly more searches) it stores the cache, leaves the new length in pend.len[game] with bit 63
+// set and goes on to its next request; k_lr_complete, launched behind this kernel, completes those steps LANE per game - the one-lane
+// completion (holder logic, done / rewards, compute_masks by lane 0: 3.7 of a request's 8.5 us) was nearly half of tier 1's wave time,
+// and tier 1's waves share the SIMDs with the next pass's sampler and k_step.
+// MODE 2 (the MIDDLE tier of a deferred window, catan_set_lr_mid_budget / CATAN_LR_MID_BUDGET): the same one-wave search with a much larger
+// budget over the window's TIER-2 requests (pend.heavy[sa]) in front of k_lr_heavy, completing what it finishes as the tier-2 completion
+// would (re-deal list 1, window tag) and handing only what still overflows to k_lr_heavy (pend.heavy2, ctr[CTR_HEAVY2]).  A tier-2 workgroup
+// is 1 024 threads with 142 KB of LDS and every register of its CU: while k_lr_heavy runs (606 us of a 1.7 ms window on 128 CUs) half the
+// machine takes no k_step wave - profiles/r05_dispatch_ramp.txt - and most of its requests are searches one wave ends in a few hundred
+// iterations.
+constexpr int CTR_HEAVY2 = 88;
+constexpr int LRF_TIER1 = 0, LRF_SPLIT = 1, LRF_MID = 2;
+template <int MODE>
 __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
                                                   StepCfg cfg, Pending pend, int fl, int budget, unsigned long long* stat,
                                                   unsigned long long* slow_ctr) {
@@ -2388,15 +2421,16 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
     const int lane = threadIdx.x;
     u32 nbr_c, nbr_e;
     lr_load_nbr(lane, nbr_c, nbr_e);
-    const u32 count = pend.ctr[lrq_ctr(fl)];
-    if (blockIdx.x == 0 && lane == 0 && slow_ctr != nullptr) { atomicAdd(&slow_ctr[0], (unsigned long long)count); atomicAdd(&slow_ctr[2], 1ull); }
+    constexpr bool SPLIT = MODE == LRF_SPLIT, MID = MODE == LRF_MID;
+    const u32 count = MID ? pend.ctr[8 + 4 * pend.sa] : pend.ctr[lrq_ctr(fl)];
+    if (!MID && blockIdx.x == 0 && lane == 0 && slow_ctr != nullptr) { atomicAdd(&slow_ctr[0], (unsigned long long)count); atomicAdd(&slow_ctr[2], 1ull); }
     StepCfg cfg2 = cfg;
     cfg2.prof = nullptr;
     // per-request phase ticks (catan_profile_enable(env, 2)): rows LRF_PROF_ROW.. of the per-wave buffer, one request per workgroup
     cfg2.prof_wave = cfg.prof_wave != nullptr && blockIdx.x < LRF_PROF_ROWS && count <= gridDim.x && c.N >= 65536 ? cfg.prof_wave + LRF_PROF_ROW * 8 : nullptr;
     for (u32 r = blockIdx.x; r < count; r += gridDim.x) {
         long long tprof = wall_clock64();
-        const u64 rq = pend.req[fl][r];
+        const u64 rq = MID ? pend.heavy[pend.sa][r] : pend.req[fl][r];
         const long e = (long)(rq & LR_GAME_MASK);
         const int who = (int)(rq >> 56), edge = (int)((rq >> 40) & 127);
         __builtin_amdgcn_wave_barrier();
@@ -2410,6 +2444,10 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         u64 BL = 0;
         for (int o = 0; o < 4; o++) if (o != who) BL |= s.settle(o) | s.city(o);
         const u64 found = lr_wave_search(s.road_lo(who), s.road_hi(who), BL, pl.through, pl.u, pl.v, scratch.lr, budget, nbr_c, nbr_e, stat);
+        if (MID && found == LR_OVERFLOW) {               // still too deep for one wave: k_lr_heavy (len / arrive / busy were set when tier 1 gave up)
+            if (lane == 0) pend.heavy2[atomicAdd(&pend.ctr[CTR_HEAVY2], 1u)] = rq;
+            continue;
+        }
         if (found == LR_OVERFLOW) {                      // tier 2 takes over; the record is untouched
             if (lane == 0) {
                 const u32 slot = atomicAdd(&pend.ctr[8 + 4 * pend.sa], 1u);
@@ -2420,10 +2458,16 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         }
         const int len = lr_apply(lc, who, pl.through, found);
         prof_mark(cfg2, 1, tprof);
+        if constexpr (SPLIT) {
+            if (!(s.b(B_LR_PLAYER) == who + 1 && s.b(B_LR_COUNT) > len)) {      // (wave-uniform: every lane reads the same record)
+                if (lane == 0) { lc.store(s.P); pend.len[e] = (1ull << 63) | (u64)len; }
+                continue;
+            }
+        }
         u32 mn[MASK_WORDS];
         bool mv = false;
         finish_step<2>(c, s, &scratch, cfg2, lane, lane == 0, (int)pend.type[e] - 1, who, len, reward, done, mpk, tprof, nbr_c, nbr_e, pend,
-                       pend.stag < 2 ? 2 : 0, pend.ftag < 2, pend.sample ? mn : nullptr, pend.sample ? &mv : nullptr, &lc);
+                       MID ? 1 : (pend.stag < 2 ? 2 : 0), MID ? pend.stag < 2 : pend.ftag < 2, pend.sample ? mn : nullptr, pend.sample ? &mv : nullptr, &lc);
         if (mv) {                                         // fused-sampling rollouts (lane 0, the game goes on): masks, next action, its place in the pass it returns in
 #pragma unroll
             for (int i = 0; i < MASK_WORDS; i++) mpk[e * MPK_STRIDE + i] = mn[i];
@@ -2433,6 +2477,41 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
         if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(c.R + e * REC)[lane] = reinterpret_cast<const uint4*>(rec)[lane];
         if (lane == 0) lc.store(s.P);
         prof_mark(cfg2, 7, tprof);
+    }
+}
+
+// The completion of the tier-1 requests k_lr_finish<true> left (pend.len[game] bit 63): lane per game through an LDS tile, as k_step
+// completes the games whose length the cache knew - holder logic (no cut among these), done / rewards, next masks, write-back.
+__global__ __launch_bounds__(64) void k_lr_complete(Ctx c, u32* __restrict__ mpk, float* __restrict__ reward, u8* __restrict__ done,
+                                                    StepCfg cfg, Pending pend, int fl) {
+    __shared__ u32 tile[ROWS_HOT * TS];
+    const int lane = threadIdx.x;
+    const u32 count = pend.ctr[lrq_ctr(fl)];
+    cfg.prof = nullptr; cfg.prof_wave = nullptr;
+    for (u32 base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+        const u32 r = base + lane;
+        long e = -1;
+        int who = 0, len = 0, type = -1;
+        if (r < count) {
+            const u64 rq = pend.req[fl][r];
+            const long g = (long)(rq & LR_GAME_MASK);
+            const u64 L = pend.len[g];
+            if (L >> 63) { e = g; who = (int)(rq >> 56); len = (int)(L & 0xFFu); type = (int)pend.type[g] - 1; pend.len[g] = 0; }
+        }
+        if (__ballot(e >= 0) == 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        stage_in(tile, c.R, (int)e, lane);
+        __builtin_amdgcn_wave_barrier();
+        StL s(tile + lane, c.R, c.N, e >= 0 ? e : 0);
+        u32 m_new[MASK_WORDS];
+        bool have_masks = false;
+        long long tprof = 0;
+        finish_step<1>(c, s, (StepScratch*)nullptr, cfg, lane, e >= 0, type, who, len, reward, done, mpk, tprof, 0u, 0u, pend,
+                       pend.stag < 2 ? 2 : 0, pend.ftag < 2, m_new, &have_masks);
+        __builtin_amdgcn_wave_barrier();
+        stage_out<28, 0, 64>(tile, c.R, (int)e, lane);
+        __builtin_amdgcn_wave_barrier();
+        stage_out_masks<64>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     }
 }
 

@@ -53,7 +53,7 @@ def test_bad_arguments_are_reported_not_crashed(hip_lib):
     assert "null or misaligned" in err(L.catan_ffn_bwd(P(b16), P(b16), P(b16), None, P(b16), P(b16), P(dw), None, 1e-5, P(b16), P(dw), P(dw), P(dw), P(dw), P(dw), P(dw), 16, st))
     assert "null or misaligned" in err(L.catan_qkv_bwd(P(b16), P(b16), P(b16), P(b16), C.c_void_p(b16.data_ptr() + 4), P(dw), P(dw), 1e-5, P(b16), P(dw), P(dw), P(dw), P(dw), 16, st))
     assert "bad arguments" in err(L.catan_weight_images(None, 3, st)) and "bad arguments" in err(L.catan_weight_images(P(b16), 0, st))
-    saves = (C.c_void_p * 18)(*([b16.data_ptr()] * 17 + [0]))
+    saves = (C.c_void_p * 18)(*([b16.data_ptr()] * 16 + [0, b16.data_ptr()]))    # xfin missing (p, the last, is optional)
     assert "save buffer" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 475, C.cast(saves, C.c_void_p), 4, st))
     assert "bad arguments" in err(L.catan_tile_encoder_fwd_train(P(b16), P(b16), P(dw), P(b16), 400, C.cast(saves, C.c_void_p), 4, st))
     assert "bad arguments" in err(L.catan_collector_pre(64, 0, P(idx), P(idx), P(idx), P(idx), st))

@@ -22,16 +22,18 @@ rows = n // 16 + 17
 BIN = ["settle", "road", "city", "roll", "end_turn", "robber", "steal", "play_dev", "buy_dev", "exchange", "propose", "respond", "discard",
        "play:1", "play:2", "play:3", "play:4", "no-op"]
 spans, ramps, durs, by_bin, shared, tails, lates = [], [], [], {}, [], [], []
+own_ramps, order_corr, own_spans = [], [], []
 for rep in range(32):
     env.random_rollout_deferred(33 + rep, 32)
     out = np.zeros((rows, 8), dtype=np.uint32)
     L.catan_profile_read_waves(env.h, out.ctypes.data_as(C.c_void_p))
     a = out[:n // 64 + 17]
+    rowidx = np.nonzero(a[:, 5] > 0)[0]
     a = a[a[:, 5] > 0]
     start = a[:, 2].astype(np.int64)
     # (rows of waves that this launch did not have keep an EARLIER launch's record: only the starts within 100 us of the latest belong)
     keep = start > start.max() - 10000
-    a, start = a[keep], start[keep]
+    a, start, rowidx = a[keep], start[keep], rowidx[keep]
     start = start - start.min()
     dur = a[:, [0, 1, 6, 7]].astype(np.int64).sum(1)
     end = start + dur
@@ -46,6 +48,15 @@ for rep in range(32):
     late = np.argsort(end)[-16:]
     tails.append([(BIN[int(a[i, 5]) - 1], start[i] / 100.0, dur[i] / 100.0) for i in late[::-1][:4]])
     lates.append(float((start > np.percentile(end, 5)).mean()))
+    # the launch's OWN ramp: rows kept from an earlier launch (54 us before) shift the origin above, so measure the spread of the
+    # starts around their median among the rows within 30 us of it, and the wave index (= dispatch order) against the start
+    med = np.median(start)
+    own = np.abs(start - med) < 3000
+    so = start[own] - med
+    own_ramps.append(np.percentile(so, [1, 10, 50, 90, 99]) / 100.0)
+    idx = rowidx[own]
+    order_corr.append(float(np.corrcoef(idx, so)[0, 1]))
+    own_spans.append((end[own].max() - start[own].min()) / 100.0)
     for b in np.unique(a[:, 5]):
         sel = a[:, 5] == b
         by_bin.setdefault(int(b), []).append((a[sel][:, [0, 1, 6, 7]].astype(np.float64) / 100.0, start[sel] / 100.0))
@@ -55,6 +66,9 @@ print(f"launch span (first wave start -> last wave end): mean {np.mean(spans):.2
 r = np.array(ramps)
 print(f"wave START offsets: median {r[:, 0].mean():.2f}  p90 {r[:, 1].mean():.2f}  p99 {r[:, 2].mean():.2f}  last {r[:, 3].mean():.2f}")
 d = np.concatenate(durs)
+ro = np.array(own_ramps)
+print(f"the launch's own waves (within 30 us of the median start): start - median at p1 {ro[:, 0].mean():.2f}  p10 {ro[:, 1].mean():.2f}  p90 {ro[:, 3].mean():.2f}  p99 {ro[:, 4].mean():.2f} us; "
+      f"first start -> last end {np.mean(own_spans):.2f} us (min {np.min(own_spans):.2f}); correlation of wave index and start {np.mean(order_corr):.2f}")
 print(f"wave durations: mean {d.mean():.2f}  p50 {np.percentile(d, 50):.2f}  p90 {np.percentile(d, 90):.2f}  p99 {np.percentile(d, 99):.2f}  max {d.max():.2f}")
 print(f"waves that start after 5 % of the waves have already ended (a second round): {100 * np.mean(lates):.1f} %")
 s = np.array(shared)
