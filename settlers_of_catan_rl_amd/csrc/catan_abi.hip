@@ -599,7 +599,7 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
         }
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
-    if (!lockstep && e->lr_mid_budget > 0 && !e->pend.sample) {
+    if (!lockstep && e->lr_mid_budget > 0) {
         // the middle tier: one wave per tier-2 request with a large budget; k_lr_heavy - fewer workgroups: few requests are left - takes the rest
         HIPCHK(hipMemsetAsync(e->pend.ctr + CTR_HEAVY2, 0, sizeof(u32), st));
         hipLaunchKernelGGL(k_lr_finish<LRF_MID>, dim3(LR_MID_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, 0, e->lr_mid_budget,

@@ -1,0 +1,34 @@
+"""Diagnostics (GPU box): k_step's per-wave phase times by action type inside the deferred loop, with the validate / switch split of the
+apply phase (catan_profile_enable(env, 2): slot 3 = ticks before the switch | ticks in the switch << 16)."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from settlers_of_catan_rl_amd.env import VecCatanEnv
+from settlers_of_catan_rl_amd import _lib
+
+n = 65536
+env = VecCatanEnv(n, seed=0)
+L = _lib.lib()
+env.random_rollout_deferred(3000, 32)
+L.catan_profile_enable(env.h, 2)
+waves = n // 16 + 17
+BIN = ["settle", "road", "city", "roll", "end_turn", "robber", "steal", "play_dev", "buy_dev", "exchange", "propose", "respond", "discard",
+       "play:1", "play:2", "play:3", "play:4", "no-op"]
+acc = []
+for rep in range(24):
+    env.random_rollout_deferred(33 + rep, 32)
+    out = np.zeros((waves, 8), dtype=np.uint32)
+    L.catan_profile_read_waves(env.h, out.ctypes.data_as(C.c_void_p))
+    acc.append(out[:n // 64 + 17].copy())
+L.catan_profile_enable(env.h, 0)
+a = np.concatenate(acc)
+a = a[a[:, 5] > 0]
+print(f"{'type':10s} {'waves':>7s} {'stage-in':>9s} {'validate':>9s} {'switch':>7s} {'apply':>7s} {'push':>6s} {'finish':>7s} {'write':>7s} {'total':>7s}   (us; apply = validate + switch + the rest up to the mark)")
+for b in sorted(np.unique(a[:, 5])):
+    x = a[a[:, 5] == b].astype(np.float64)
+    v = a[a[:, 5] == b][:, 3].astype(np.int64)
+    tot = x[:, [0, 1, 2, 6, 7]].sum(1)
+    print(f"{BIN[int(b) - 1]:10s} {len(x) / 24:7.1f} {x[:, 0].mean() / 100:9.2f} {(v & 0xFFFF).mean() / 100:9.2f} {(v >> 16).mean() / 100:7.2f} {x[:, 1].mean() / 100:7.2f} {x[:, 2].mean() / 100:6.2f} "
+          f"{x[:, 6].mean() / 100:7.2f} {x[:, 7].mean() / 100:7.2f} {tot.mean() / 100:7.2f}")
