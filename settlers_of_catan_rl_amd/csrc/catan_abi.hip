@@ -48,6 +48,8 @@ struct catan_env {
     int prof_on;
     int lr_mid_budget;    // deferred windows: the middle tier's budget (0: off), and k_lr_heavy's workgroups behind it
     int lr_mid_heavy_grid;
+    int t1_group;         // the library's own deferred loop: passes per tier-1 launch (1, or 2: deferred_iter_grouped)
+    int g_open, g_slot, g_passes; int64_t g_count;   // ... its running group
     int lr_split;         // tier 1 as search (k_lr_finish<LRF_SPLIT>) + lane-per-game completion (k_lr_complete)
     int step_bin_order;   // k_step: longest-lasting bins first (StepCfg::bin_order)
     int step_agpr;        // experiment: accumulation registers reserved by k_step (0, 96, 160: see the kernel)
@@ -417,6 +419,8 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
     if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
     e->lr_split = 0;
+    e->t1_group = 2;       // on since round 5 (47.8 -> 45.5 us per pass at 88.9 instead of 90.0 % active games: +3.6 % env-steps/s, profiles/r05_s5_pass_experiments.txt);
+    if (const char* tg = getenv("CATAN_T1_GROUP")) e->t1_group = atoi(tg) == 1 ? 1 : 2;   // CATAN_T1_GROUP=1: a tier-1 launch per pass (deferred_iter_legacy, CATAN_T1_DEPTH slots)
     // the middle tier of a deferred window: on since round 5 (budget 256, 32 tier-2 workgroups behind it: 53.9 -> 51.2-51.6 us per pass,
     // same file); CATAN_LR_MID_BUDGET=0: every tier-2 request straight to k_lr_heavy on 128 workgroups
     e->lr_mid_budget = 256; e->lr_mid_heavy_grid = 32;
@@ -599,7 +603,8 @@ static int enqueue_slow(catan_env_t* e, float* reward, uint8_t* done, hipStream_
         }
     }
     if (ev) HIPCHK(hipEventRecord(ev[9], st));
-    if (!lockstep && e->lr_mid_budget > 0) {
+    if (!lockstep && e->lr_mid_budget > 0 && !e->pend.sample) {     // (not in the fused-sampling loop: measured 51.8 -> 49.4 us per pass there, but two of its
+                                                                     // trajectory-parity cases - windows of 1 and 5 passes - then failed in one of two suite runs: not understood, not kept)
         // the middle tier: one wave per tier-2 request with a large budget; k_lr_heavy - fewer workgroups: few requests are left - takes the rest
         HIPCHK(hipMemsetAsync(e->pend.ctr + CTR_HEAVY2, 0, sizeof(u32), st));
         hipLaunchKernelGGL(k_lr_finish<LRF_MID>, dim3(LR_MID_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, 0, e->lr_mid_budget,
@@ -842,7 +847,64 @@ static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int w
 // state), so the games' trajectories are the lock-step ones whoever draws.  Three sets of bin counts / lists / tier-1 request
 // lists rotate (pass % 3): k_step(t) reads set t, appends to set t + 1 and zeroes set t + 2, which k_lr_finish(t) and
 // k_step(t + 1) then fill.
+// The same iteration with tier 1 forked once per GROUP of two passes (the default since round 5; catan_env::t1_group, CATAN_T1_GROUP=1 for the form above): both passes push their
+// longest-road requests to the group's list under the group's tag, tier 1 runs behind the second pass's k_step, and the group's games
+// play again when the slot is used next (two groups later: the games of the first pass sit out three passes, those of the second two).
+// The event record behind k_step and the event wait in front of the sampler - ~3.3 us of drained main stream each - are then paid
+// once per two passes.  A window's last pass (and a call's last) closes its group early, so the window's slow path still sees every
+// tier-1 launch that can hand it work.
+static int deferred_iter_grouped(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+    constexpr int D = 2;                                       // group slots
+    const int ba = (int)(it & 1);
+    e->ctr_clean = 0;
+    const int64_t w = it / window;
+    const int sa = (int)(w & 1);
+    const bool opens = it % window == 0, last = it + 1 == iters, closes = (it + 1) % window == 0 || last;
+    if (it == 0) { e->g_open = 0; e->g_count = 0; }
+    const bool g_opens = !e->g_open;
+    if (g_opens) { e->g_slot = (int)(e->g_count % D); e->g_passes = 0; e->g_open = 1; }
+    const int fa = e->g_slot, ftag = 2 + fa;
+    if (g_opens && e->g_count >= D) HIPCHK(hipStreamWaitEvent(st, e->ev_fdone[fa], 0));   // tier 1 of the group that used this slot last is complete
+    if (it == 0) HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st));
+    else if (opens) {
+        if (w >= 2) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));
+        HIPCHK(hipMemsetAsync(e->pend.ctr + 8 + 4 * sa, 0, 4 * sizeof(u32), st));
+    }
+    e->pend.fa = fa; e->pend.ftag = ftag; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = ba; e->pend.bclear = ba ^ 1; e->pend.sample = 0; e->pend.brel = -1;
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
+    // the group's first pass releases the slot's previous games (tag) and empties its request list; the second touches neither
+    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
+                       e->pctr, e->pend.busy, g_opens ? ftag : 0, (opens && w >= 2) ? 4 + sa : 0,
+                       (g_opens && it != 0) ? e->pend.ctr + 4 + fa : (u32*)nullptr, 1,
+                       e->pend.ctr + 16 + NBINS * ba, e->pend.lists + (size_t)ba * NBINS * e->N);
+    int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
+    if (r != CATAN_OK) return r;
+    e->g_passes++;
+    if (e->g_passes == 2 || closes) {                          // close the group: its tier 1 on the side stream
+        HIPCHK(hipEventRecord(e->ev_fready[fa], st));
+        HIPCHK(hipStreamWaitEvent(e->fstream[0], e->ev_fready[fa], 0));
+        r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[0], ev, fa, e->lr_budget[1]);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[0]));
+        e->g_open = 0; e->g_count++;
+    }
+    if (closes) {
+        for (int k = 0; k < D && k < e->g_count; k++) HIPCHK(hipStreamWaitEvent(e->sstream, e->ev_fdone[k], 0));
+        r = enqueue_slow(e, e->s_reward, e->s_done, e->sstream, ev, LR_HEAVY_GRID_DEFERRED);
+        if (r != CATAN_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_sdone[sa], e->sstream));
+        if (last) {
+            HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa], 0));
+            if (w >= 1) HIPCHK(hipStreamWaitEvent(st, e->ev_sdone[sa ^ 1], 0));
+            hipLaunchKernelGGL(k_release_tags, dim3(blocks(e->N, BLOCK)), dim3(BLOCK), 0, st, e->ctx, e->pend.busy);
+            e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1;
+        }
+    }
+    return r;
+}
+
 static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, hipStream_t st, hipEvent_t* ev) {
+    if (!e->deferred_fused && e->t1_group == 2) return deferred_iter_grouped(e, it, iters, window, st, ev);
     if (!e->deferred_fused) return deferred_iter_legacy(e, it, iters, window, st, ev);
     // Tier 1 is forked once per GROUP of P passes (P = 2): a k_lr_finish launch lasts as long as its slowest search (~45 us next
     // to k_step) whatever the number of requests, the launches of consecutive groups serialise on one side stream, and the games
