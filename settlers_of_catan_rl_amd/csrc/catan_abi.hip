@@ -405,6 +405,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pend.ctr, 0, CTR_WORDS * sizeof(u32)));
     HIPCHK(hipMemset(e->pend.type, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
+    HIPCHK(hipMemset(e->pend.len, 0, (size_t)e->N * sizeof(u64)));      // (bit 63 of a game's word is k_lr_finish<LRF_SPLIT>'s mark for k_lr_complete)
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
@@ -418,7 +419,10 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->step_agpr = 0;
     e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
     if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
-    e->lr_split = 0;
+    // tier 1 as search + lane-per-game completion: in the deferred schedules since round 5 (a tier-1 launch there has two passes to finish and its waves
+    // share the SIMDs with the sampler and k_step: 44.7 -> 43.8 us per pass), not inside a lock-step step (one more kernel on its critical path: 184 -> 197 us).
+    // CATAN_LR_SPLIT=0: never, 2: everywhere
+    e->lr_split = 1;
     e->t1_group = 2;       // on since round 5 (47.8 -> 45.5 us per pass at 88.9 instead of 90.0 % active games: +3.6 % env-steps/s, profiles/r05_s5_pass_experiments.txt);
     if (const char* tg = getenv("CATAN_T1_GROUP")) e->t1_group = atoi(tg) == 1 ? 1 : 2;   // CATAN_T1_GROUP=1: a tier-1 launch per pass (deferred_iter_legacy, CATAN_T1_DEPTH slots)
     // the middle tier of a deferred window: on since round 5 (budget 256, 32 tier-2 workgroups behind it: 53.9 -> 51.2-51.6 us per pass,
@@ -426,7 +430,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_mid_budget = 256; e->lr_mid_heavy_grid = 32;
     if (const char* mb = getenv("CATAN_LR_MID_BUDGET")) { e->lr_mid_budget = atoi(mb) > 0 ? atoi(mb) : 0; if (e->lr_mid_budget == 0) e->lr_mid_heavy_grid = 128; }
     if (const char* mg = getenv("CATAN_LR_MID_HEAVY_GRID")) { const int g = atoi(mg); if (g >= 8 && g <= 256) e->lr_mid_heavy_grid = g; }
-    if (const char* ls = getenv("CATAN_LR_SPLIT")) e->lr_split = atoi(ls) != 0;
+    if (const char* ls = getenv("CATAN_LR_SPLIT")) e->lr_split = atoi(ls) == 0 ? 0 : (atoi(ls) == 2 ? 2 : 1);
     if (const char* ag = getenv("CATAN_STEP_AGPR")) e->step_agpr = atoi(ag) == 96 ? 96 : (atoi(ag) == 160 ? 160 : 0);
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
@@ -524,6 +528,7 @@ static StepCfg step_cfg(const catan_env_t* e) {
 constexpr int LR_HEAVY_GRID = 256;   // one 1024-thread workgroup per CU; requests x split parts are strided over them
 constexpr int LR_HEAVY_GRID_DEFERRED = 128;  // next to the fast path: leave most CUs (and their LDS) to k_step
 constexpr int LR_GRID = 4096;
+constexpr int LR_GRID_DEFERRED = 3072;
 constexpr int LR_MID_GRID = 2048;          // the middle tier: one request per one-wave workgroup (a window leaves ~640)
 constexpr int LR_COMPLETE_GRID = 128;   // k_lr_complete: 64 requests per one-wave workgroup, grid-stride beyond 8 192 requests
 constexpr int RESET_GRID = 2048;
@@ -561,19 +566,22 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     return CATAN_OK;
 }
 // tier 1 + completion of request list `fl` on stream `st`.  ev (optional): recorded on st: [8] before, [6] after
-static int lr_grid() {      // workgroups of k_lr_finish (CATAN_LR_GRID: diagnostics, tools/pass_experiments.py)
-    static const int g = (getenv("CATAN_LR_GRID") && atoi(getenv("CATAN_LR_GRID")) >= 64) ? atoi(getenv("CATAN_LR_GRID")) : LR_GRID;
-    return g;
+// workgroups of k_lr_finish (CATAN_LR_GRID: diagnostics, tools/pass_experiments.py).  Deferred schedules (tags >= 2): 3 072 - three tier-1 waves
+// per SIMD leave registers for a sampler / k_step wave beside them (4 x 120 of a SIMD's 512 do not), and the launch - one per two passes - has the
+// time to take its ~4 000 requests in two rounds: 45.6 -> 44.9 us per pass (profiles/r05_s5_pass_experiments.txt, run 9)
+static int lr_grid(bool deferred) {
+    static const int g = (getenv("CATAN_LR_GRID") && atoi(getenv("CATAN_LR_GRID")) >= 64) ? atoi(getenv("CATAN_LR_GRID")) : 0;
+    return g ? g : (deferred ? LR_GRID_DEFERRED : LR_GRID);
 }
 static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    if (e->lr_split && !e->pend.sample) {
-        hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    if ((e->lr_split == 2 || (e->lr_split == 1 && e->pend.ftag >= 2)) && !e->pend.sample) {
+        hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(lr_grid(e->pend.ftag >= 2)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                            sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
         hipLaunchKernelGGL(k_lr_complete, dim3(LR_COMPLETE_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl);
     } else
-    hipLaunchKernelGGL(k_lr_finish<LRF_TIER1>, dim3(lr_grid()), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    hipLaunchKernelGGL(k_lr_finish<LRF_TIER1>, dim3(lr_grid(e->pend.ftag >= 2)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());

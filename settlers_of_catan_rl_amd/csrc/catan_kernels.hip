@@ -2399,12 +2399,12 @@ DEVI int lr_apply(LrCache& lc, int who, bool through, u64 found) {
 // Tier 1 of the longest road and the completion of the step, one request per wave: all 64 lanes cooperate on the path
 // search (budgeted; overflow hands the game to the tier-2 list), then the game's hot record is staged linearly in LDS and
 // lane 0 completes the step (holder logic, done/reward, next masks).  `fl` selects the request list.
-// SPLIT (catan_set_lr_split / CATAN_LR_SPLIT): the wave only searches.  Unless the holder's own road was cut (rare: finish_step<2>
+// LRF_SPLIT (the deferred schedules' tier 1; CATAN_LR_SPLIT): the wave only searches.  Unless the holder's own road was cut (rare: finish_step<2>
 // then needs the other players' paths, possibly more searches) it stores the cache, leaves the new length in pend.len[game] with bit 63
 // set and goes on to its next request; k_lr_complete, launched behind this kernel, completes those steps LANE per game - the one-lane
 // completion (holder logic, done / rewards, compute_masks by lane 0: 3.7 of a request's 8.5 us) was nearly half of tier 1's wave time,
 // and tier 1's waves share the SIMDs with the next pass's sampler and k_step.
-// MODE 2 (the MIDDLE tier of a deferred window, catan_set_lr_mid_budget / CATAN_LR_MID_BUDGET): the same one-wave search with a much larger
+// LRF_MID (the MIDDLE tier of a deferred window; CATAN_LR_MID_BUDGET): the same one-wave search with a much larger
 // budget over the window's TIER-2 requests (pend.heavy[sa]) in front of k_lr_heavy, completing what it finishes as the tier-2 completion
 // would (re-deal list 1, window tag) and handing only what still overflows to k_lr_heavy (pend.heavy2, ctr[CTR_HEAVY2]).  A tier-2 workgroup
 // is 1 024 threads with 142 KB of LDS and every register of its CU: while k_lr_heavy runs (606 us of a 1.7 ms window on 128 CUs) half the
@@ -2463,6 +2463,7 @@ __global__ __launch_bounds__(64) void k_lr_finish(Ctx c, u32* __restrict__ mpk, 
                 if (lane == 0) { lc.store(s.P); pend.len[e] = (1ull << 63) | (u64)len; }
                 continue;
             }
+            if (lane == 0) pend.len[e] = 0;               // the cut case is completed here: k_lr_complete must find no mark (whatever the word held)
         }
         u32 mn[MASK_WORDS];
         bool mv = false;
