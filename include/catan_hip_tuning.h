@@ -62,6 +62,17 @@ int32_t catan_step_algorithmic_bytes(void);
  *                SIMD time of k_step + the path searches, not by the launches on the main stream. */
 int catan_set_deferred_fused(catan_env_t* env, int32_t on);
 
+/* Environment switches read at catan_create (A/B diagnostics of the schedules; results never depend on them; defaults are the measured best,
+ * DESIGN.md 4.0 / profiles/r05_s5_pass_experiments.txt):
+ *   CATAN_STEP_BIN_ORDER=0        k_step's bins over the launch's waves in index order instead of longest-lasting first
+ *   CATAN_LR_MID_BUDGET=b         budget of the middle tier of a deferred window (default 256; 0: every tier-2 request straight to k_lr_heavy)
+ *   CATAN_LR_MID_HEAVY_GRID=g     workgroups of k_lr_heavy behind the middle tier (default 32)
+ *   CATAN_T1_GROUP=1              one tier-1 launch per pass of the library's own deferred loop instead of one per two passes
+ *   CATAN_T1_DEPTH=2              ... then with two rotating tier-1 slots instead of three
+ *   CATAN_LR_SPLIT=0 | 2          tier 1 as search + lane-per-game completion never / in every schedule (default: where a launch has two passes)
+ *   CATAN_LR_GRID=g               workgroups of k_lr_finish (default 4 096 inside a lock-step step, 3 072 in the deferred schedules)
+ *   CATAN_STEP_WAVES_PER_BLOCK=4  four-wave k_step workgroups;  CATAN_STEP_WAVE_GAMES, CATAN_DEFERRED_FUSED: as the setters above */
+
 #ifdef __cplusplus
 }
 #endif

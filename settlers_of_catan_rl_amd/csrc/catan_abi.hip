@@ -52,7 +52,6 @@ struct catan_env {
     int g_open, g_slot, g_passes; int64_t g_count;   // ... its running group
     int lr_split;         // tier 1 as search (k_lr_finish<LRF_SPLIT>) + lane-per-game completion (k_lr_complete)
     int step_bin_order;   // k_step: longest-lasting bins first (StepCfg::bin_order)
-    int step_agpr;        // experiment: accumulation registers reserved by k_step (0, 96, 160: see the kernel)
     int step_wpb;         // waves per k_step workgroup (4: one workgroup per CU, a SIMD per wave; 1: one-wave workgroups)
     u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
@@ -415,12 +414,12 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
     // previous pass hold LDS on most CUs, so a 116 KB workgroup often has to wait for a CU where the 29 KB one-wave workgroup fits at once
     e->step_wpb = 1;
-    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : (atoi(wp) == 2 ? 2 : 1);
-    e->step_agpr = 0;
+    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : 1;
     e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
     if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
-    // tier 1 as search + lane-per-game completion: in the deferred schedules since round 5 (a tier-1 launch there has two passes to finish and its waves
-    // share the SIMDs with the sampler and k_step: 44.7 -> 43.8 us per pass), not inside a lock-step step (one more kernel on its critical path: 184 -> 197 us).
+    // tier 1 as search + lane-per-game completion: in the library's own deferred loop since round 5 (a tier-1 launch there has two passes to finish and its
+    // waves share the SIMDs with the sampler and k_step: 44.7 -> 43.8 us per pass), not inside a lock-step step (one more kernel on its critical path:
+    // 184 -> 197 us) nor in catan_step_deferred (a launch per call: 64.0 -> 65.3 us per call).
     // CATAN_LR_SPLIT=0: never, 2: everywhere
     e->lr_split = 1;
     e->t1_group = 2;       // on since round 5 (47.8 -> 45.5 us per pass at 88.9 instead of 90.0 % active games: +3.6 % env-steps/s, profiles/r05_s5_pass_experiments.txt);
@@ -431,7 +430,6 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (const char* mb = getenv("CATAN_LR_MID_BUDGET")) { e->lr_mid_budget = atoi(mb) > 0 ? atoi(mb) : 0; if (e->lr_mid_budget == 0) e->lr_mid_heavy_grid = 128; }
     if (const char* mg = getenv("CATAN_LR_MID_HEAVY_GRID")) { const int g = atoi(mg); if (g >= 8 && g <= 256) e->lr_mid_heavy_grid = g; }
     if (const char* ls = getenv("CATAN_LR_SPLIT")) e->lr_split = atoi(ls) == 0 ? 0 : (atoi(ls) == 2 ? 2 : 1);
-    if (const char* ag = getenv("CATAN_STEP_AGPR")) e->step_agpr = atoi(ag) == 96 ? 96 : (atoi(ag) == 160 ? 160 : 0);
     if (const char* sg = getenv("CATAN_STEP_WAVE_GAMES")) { const int g = atoi(sg); if (g == 64 || g == 32 || g == 16) e->step_games = g; }
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.bnext = 0; e->pend.brel = -1; e->pend.bclear = 1; e->pend.lrq_clear = -1;
     HIPCHK(hipMemset(e->mpk, 0, (size_t)e->N * MPK_STRIDE * sizeof(u32)));
@@ -555,9 +553,6 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     case 32: hipLaunchKernelGGL(k_step<32>, dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins); break;
     default:
         if (e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, false, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
-        else if (e->step_wpb == 2) hipLaunchKernelGGL((k_step<64, false, 2>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 2)), dim3(128), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
-        else if (e->step_agpr == 96) hipLaunchKernelGGL((k_step<64, false, 1, 96>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
-        else if (e->step_agpr == 160) hipLaunchKernelGGL((k_step<64, false, 1, 160>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else hipLaunchKernelGGL(k_step<64>, dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         break;
     }
@@ -573,10 +568,10 @@ static int lr_grid(bool deferred) {
     static const int g = (getenv("CATAN_LR_GRID") && atoi(getenv("CATAN_LR_GRID")) >= 64) ? atoi(getenv("CATAN_LR_GRID")) : 0;
     return g ? g : (deferred ? LR_GRID_DEFERRED : LR_GRID);
 }
-static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget) {
+static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget, bool two_passes = false) {
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
-    if ((e->lr_split == 2 || (e->lr_split == 1 && e->pend.ftag >= 2)) && !e->pend.sample) {
+    if ((e->lr_split == 2 || (e->lr_split == 1 && two_passes)) && !e->pend.sample) {     // (1: only where a launch has two passes to finish - deferred_iter_grouped)
         hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(lr_grid(e->pend.ftag >= 2)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                            sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
         hipLaunchKernelGGL(k_lr_complete, dim3(LR_COMPLETE_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl);
@@ -891,7 +886,7 @@ static int deferred_iter_grouped(catan_env_t* e, int64_t it, int64_t iters, int 
     if (e->g_passes == 2 || closes) {                          // close the group: its tier 1 on the side stream
         HIPCHK(hipEventRecord(e->ev_fready[fa], st));
         HIPCHK(hipStreamWaitEvent(e->fstream[0], e->ev_fready[fa], 0));
-        r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[0], ev, fa, e->lr_budget[1]);
+        r = enqueue_tier1(e, e->f_reward, e->f_done, e->fstream[0], ev, fa, e->lr_budget[1], true);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_fdone[fa], e->fstream[0]));
         e->g_open = 0; e->g_count++;

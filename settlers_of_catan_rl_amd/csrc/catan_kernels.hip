@@ -1721,8 +1721,9 @@ DEVI int bin_of(int t, int card) {
     return card >= 1 ? 12 + card : t;
 }
 // The order in which the bins take the launch's waves (StepCfg::bin_order): workgroups start roughly in index order over a ramp of
-// several microseconds, so the bins whose waves last longest go first (longest processing time first) and the short ones - propose,
-// steal, monopoly - start last; wave durations per bin: profiles/r05_k_step_timeline.txt.  The no-op bin (its waves return at once) stays last.
+// several microseconds, so the bins whose waves last longest go first (longest processing time first: settle, roll, respond, steal ...)
+// and the short ones - propose, end_turn - start last; wave durations per bin: profiles/r05_k_step_timeline.txt.  The no-op bin (its waves
+// return at once) stays last.
 __device__ constexpr int BIN_ORDER_LPT[18] = { 0, 9, 7, 11, 16, 2, 14, 3, 5, 4, 13, 1, 12, 8, 15, 6, 10, 17 };
 DEVI int type_of_bin(int bin) { return bin <= 12 ? bin : (bin < BIN_NOOP ? T_PLAYDEV : -1); }
 
@@ -1895,15 +1896,10 @@ DEVI void finish_step(const Ctx& c, const S& s, StepScratch* scratch, const Step
 // per wave): the hardware spreads a workgroup's waves over the four SIMDs of its CU and the 116 KB of LDS admit one workgroup per CU,
 // so every working wave has a SIMD to itself.  As 1 041 one-wave workgroups the dispatcher used 800 of the 1 024 SIMDs and put two to
 // four waves on 208 of them (tools/step_timeline.py, profiles/r05_k_step_timeline.txt): the launch lasted as long as those.
-// AG (experiment, CATAN_STEP_AGPR): reserve AG accumulation registers the kernel never uses, so that its allocation (172 -> 176 + AG
-// of a SIMD's 512 registers per lane) admits ONE k_step wave per SIMD - the dispatcher then cannot put two of the launch's waves on one SIMD
-// while it leaves others empty - and still leaves room for tier-1 waves (120 registers each) beside it.
-template <int G, bool SAMPLE = false, int WPB = 1, int AG = 0>
+template <int G, bool SAMPLE = false, int WPB = 1>
 __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict__ actions, u32* __restrict__ mpk,
                                              float* __restrict__ reward, u8* __restrict__ done,
                                              u32* __restrict__ err, StepCfg cfg, Pending pend, const u32* __restrict__ bins) {
-    if constexpr (AG == 96) asm volatile("" ::: "a95");
-    if constexpr (AG == 160) asm volatile("" ::: "a159");
     constexpr int TSG = G + 1;
     typedef StLT<TSG> StG;
     __shared__ u32 tile_all[WPB][ROWS_HOT * TSG];

@@ -19,8 +19,8 @@ if FUSED:
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 3)
 rows = n // 16 + 17
-BIN = ["settle", "road", "city", "roll", "end_turn", "robber", "steal", "play_dev", "buy_dev", "exchange", "propose", "respond", "discard",
-       "play:1", "play:2", "play:3", "play:4", "no-op"]
+BIN = ["settle", "road", "city", "buy_dev", "play_dev", "exchange", "propose", "respond", "robber", "roll", "end_turn", "steal", "discard",
+       "play:1", "play:2", "play:3", "play:4", "no-op"]      # bins 0..12 = the action types in enum order (catan_state.h T_*, = the reference's ActionTypes), 13..16 = play_dev by card
 spans, ramps, durs, by_bin, shared, tails, lates = [], [], [], {}, [], [], []
 own_ramps, order_corr, own_spans = [], [], []
 for rep in range(32):

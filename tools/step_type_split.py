@@ -14,8 +14,8 @@ L = _lib.lib()
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 2)
 waves = n // 16 + 17
-BIN = ["settle", "road", "city", "roll", "end_turn", "robber", "steal", "play_dev", "buy_dev", "exchange", "propose", "respond", "discard",
-       "play:1", "play:2", "play:3", "play:4", "no-op"]
+BIN = ["settle", "road", "city", "buy_dev", "play_dev", "exchange", "propose", "respond", "robber", "roll", "end_turn", "steal", "discard",
+       "play:1", "play:2", "play:3", "play:4", "no-op"]      # bins 0..12 = the action types in enum order (catan_state.h T_*, = the reference's ActionTypes), 13..16 = play_dev by card
 acc = []
 for rep in range(24):
     env.random_rollout_deferred(33 + rep, 32)
