@@ -80,6 +80,41 @@ def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, s
     assert ob.games.value > 0
 
 
+@pytest.mark.parametrize("switches", [
+    {"CATAN_T1_GROUP": "1"},                                              # a tier-1 launch per pass (three rotating slots)
+    {"CATAN_LR_SPLIT": "0"},                                              # the search waves complete their games themselves
+    {"CATAN_LR_SPLIT": "2"},                                              # ... search + lane-per-game completion in every schedule
+    {"CATAN_LR_MID_BUDGET": "0"},                                         # no middle tier: every tier-2 request to k_lr_heavy
+    {"CATAN_LR_MID_BUDGET": "8", "CATAN_LR_MID_HEAVY_GRID": "16"},        # a middle tier that hands most of its requests on
+    {"CATAN_STEP_BIN_ORDER": "0"},                                        # bins over the waves in index order
+    {"CATAN_T1_GROUP": "1", "CATAN_LR_SPLIT": "2", "CATAN_LR_MID_BUDGET": "0", "CATAN_STEP_BIN_ORDER": "0"},
+])
+def test_deferred_schedule_switches_keep_the_trajectories(oracle, hip_lib, monkeypatch, switches):
+    """The schedule pieces of round 5 (include/catan_hip_tuning.h: groups of two passes per tier-1 launch, the search / completion
+    split, the middle tier, the bin order) are read from the environment when a handle is created and move only WHEN a game's slow
+    path runs: under every setting each game must follow its lock-step trajectory (state, masks, decision counters against the
+    oracle), in the library's own loop and - lock-step - through catan_random_rollout (CATAN_LR_SPLIT=2 reaches it)."""
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    n, seed, window = 2048, 21, 8
+    env = _env(n, seed)
+    env.set_lr_budgets(16, 4)                                             # many tier-1 overflows: the window's slow path is busy
+    ob = oracle.OracleBatch(n, seed)
+    total = np.zeros(n, dtype=np.int64)
+    for chunk in (window + 1, 1200):
+        env.random_rollout_deferred(chunk, window)
+        cnt = env.policy_counters().cpu().numpy()
+        o = ob.run_random_counts(cnt - total, start=total)
+        total = cnt
+        _assert_blobs_equal(env.export_state().cpu().numpy(), o, f"state after {chunk} deferred iterations under {switches}")
+        assert np.array_equal(env.get_action_masks().cpu().numpy(), ob.masks())
+    assert env.invalid_action_count() == 0 and env.slow_path_counts()[1] > 0 and total.mean() > 600
+    env2 = _env(512, seed + 1)
+    ob2 = oracle.OracleBatch(512, seed + 1)
+    env2.random_rollout(0, 400)
+    _assert_blobs_equal(env2.export_state().cpu().numpy(), ob2.run_random(400, n_threads=0), f"lock-step state under {switches}")
+
+
 def test_deferred_rollout_is_reproducible(hip_lib):
     """Two deferred rollouts of the same environment (seed, passes, window) end in the same records with the same decision
     counts - also when many longest-road requests overflow into tier 2 (tier-1 budget 4), whose waves share work through a pool
