@@ -30,5 +30,9 @@ for b in sorted(np.unique(a[:, 5])):
     x = a[a[:, 5] == b].astype(np.float64)
     v = a[a[:, 5] == b][:, 3].astype(np.int64)
     tot = x[:, [0, 1, 2, 6, 7]].sum(1)
+    if BIN[int(b) - 1] == "roll":                          # slot 4 of a roll wave: dice draws | tile scan + bank << 10 | hands + estimates << 20 (10 ns ticks)
+        v4 = a[a[:, 5] == b][:, 4].astype(np.int64)
+        roll_split = f"           roll's switch (medians): dice draws {np.median(v4 & 1023) / 100:.2f} us, tile scan + bank {np.median((v4 >> 10) & 1023) / 100:.2f} us, hands + estimates {np.median((v4 >> 20) & 1023) / 100:.2f} us"
     print(f"{BIN[int(b) - 1]:10s} {len(x) / 24:7.1f} {x[:, 0].mean() / 100:9.2f} {(v & 0xFFFF).mean() / 100:9.2f} {(v >> 16).mean() / 100:7.2f} {x[:, 1].mean() / 100:7.2f} {x[:, 2].mean() / 100:6.2f} "
           f"{x[:, 6].mean() / 100:7.2f} {x[:, 7].mean() / 100:7.2f} {tot.mean() / 100:7.2f}")
+print(roll_split)
