@@ -647,7 +647,7 @@ static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* d
     if (!e->ctr_clean) { HIPCHK(hipMemsetAsync(e->pend.ctr, 0, CTR_WORDS * sizeof(u32), st)); e->ctr_clean = 1; e->lock_parity = 0; }
     e->pend.bsel = e->lock_parity; e->pend.bclear = e->lock_parity ^ 1; e->lock_parity ^= 1;
     if (sample_step)
-        hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
+        hipLaunchKernelGGL(k_sample_random<BLOCK>, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, *sample_step, actions,
                            (u32*)nullptr, (u8*)nullptr, 0, 0, e->pend.ctr + 4, 12, e->pend.ctr + 16 + NBINS * e->pend.bsel,
                            e->pend.lists + (size_t)e->pend.bsel * NBINS * e->N);
     int r = enqueue_fast(e, actions, reward, done, st, ev, sample_step != nullptr);
@@ -729,7 +729,7 @@ int catan_players_turn_sim(catan_env_t* e, int32_t* out, catan_stream_t stream) 
 
 int catan_sample_random_actions(catan_env_t* e, uint32_t step_idx, int32_t* actions, catan_stream_t stream) {
     if (!e || !actions) return fail(CATAN_EINVAL, "catan_sample_random_actions: null argument");
-    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
+    hipLaunchKernelGGL(k_sample_random<BLOCK>, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, S(stream), e->ctx, e->mpk, step_idx, actions,
                        (u32*)nullptr, (u8*)nullptr, 0, 0, (u32*)nullptr, 0, (u32*)nullptr, (i32*)nullptr);
     HIPCHK(hipGetLastError());
     return CATAN_OK;
@@ -812,7 +812,7 @@ static int deferred_iter_legacy(catan_env_t* e, int64_t it, int64_t iters, int w
     }
     e->pend.fa = fa; e->pend.ftag = ftag; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = ba; e->pend.bclear = ba ^ 1; e->pend.sample = 0; e->pend.brel = -1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
-    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
+    hipLaunchKernelGGL(k_sample_random<BLOCK>, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
                        e->pctr, e->pend.busy, ftag, (opens && w >= 2) ? 4 + sa : 0, it == 0 ? (u32*)nullptr : e->pend.ctr + (fa < 2 ? 4 + fa : 7), 1,
                        e->pend.ctr + 16 + NBINS * ba, e->pend.lists + (size_t)ba * NBINS * e->N);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
@@ -876,7 +876,7 @@ static int deferred_iter_grouped(catan_env_t* e, int64_t it, int64_t iters, int 
     e->pend.fa = fa; e->pend.ftag = ftag; e->pend.sa = sa; e->pend.stag = 4 + sa; e->pend.bsel = ba; e->pend.bclear = ba ^ 1; e->pend.sample = 0; e->pend.brel = -1;
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     // the group's first pass releases the slot's previous games (tag) and empties its request list; the second touches neither
-    hipLaunchKernelGGL(k_sample_random, dim3(blocks(e->n, BLOCK)), dim3(BLOCK), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
+    hipLaunchKernelGGL(k_sample_random<512>, dim3(blocks(e->n, 512)), dim3(512), 0, st, e->ctx, (const u32*)e->mpk, 0u, e->scratch_actions,
                        e->pctr, e->pend.busy, g_opens ? ftag : 0, (opens && w >= 2) ? 4 + sa : 0,
                        (g_opens && it != 0) ? e->pend.ctr + 4 + fa : (u32*)nullptr, 1,
                        e->pend.ctr + 16 + NBINS * ba, e->pend.lists + (size_t)ba * NBINS * e->N);

@@ -1611,14 +1611,16 @@ DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof, const u64* tct, 
     u32 pw[4], tw[4], pc[4], tc[4];
 #pragma unroll
     for (int X = 0; X < 4; X++) {
-        int tot = s.total(X);
+        int hand[5], tot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { hand[r] = s.res(X, r); tot += hand[r]; }
         int add[5], bound[5];
 #pragma unroll
         for (int r = 0; r < 5; r++) add[r] = ((okbits >> r) & 1) ? (int)((alloc[r] >> (8 * X)) & 255) : 0;
 #pragma unroll
         for (int i = 0; i < 5; i++) { const int r = res_order[i]; tot += add[r]; bound[r] = tot; }   // the running hand total is the clip bound
 #pragma unroll
-        for (int r = 0; r < 5; r++) if (add[r]) s.spb(X, P_RES + r, s.pb(X, P_RES + r) + add[r]);
+        for (int r = 0; r < 5; r++) s.spb(X, P_RES + r, hand[r] + add[r]);       // (all twenty bytes from registers: no re-read, no branch per resource)
         pw[X] = (u32)add[0] | ((u32)add[1] << 8) | ((u32)add[2] << 16) | ((u32)add[3] << 24);
         tw[X] = (u32)bound[0] | ((u32)bound[1] << 8) | ((u32)bound[2] << 16) | ((u32)bound[3] << 24);
         pc[X] = (u32)add[4] * 0x0101u; tc[X] = (u32)bound[4] * 0x0101u;
@@ -2268,23 +2270,33 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
         if (a[5] == 0) {
             int p1 = s.b(B_TRADE_PROP), p2 = s.b(B_TRADE_TGT);
             int ng = s.b(B_TRADE_NG), nr = s.b(B_TRADE_NR);
-            D5 d1 = d5_zero(), d2 = d5_zero();
-            int t1 = 0;
+            // The lists move one card at a time in the reference (gives first, then receives; visible counts clamp at zero on the way down).
+            // Per resource that is: g cards from p1 to p2, then rc back - in closed form on the twenty hand bytes, read once and written
+            // once (card by card every move was four dependent LDS read-modify-writes: up to 64 in a row with one wave per SIMD).
+            int g[5] = { 0, 0, 0, 0, 0 }, rc[5] = { 0, 0, 0, 0, 0 };
             for (int i = 0; i < 4; i++) if (i < ng) {
-                int r0 = s.b(B_TRADE_GIVE + i) - 1;
-                s.spb(p1, P_RES + r0, s.pb(p1, P_RES + r0) - 1);
-                s.spb(p1, P_VIS + r0, max(s.pb(p1, P_VIS + r0) - 1, 0));
-                s.spb(p2, P_RES + r0, s.pb(p2, P_RES + r0) + 1);
-                s.spb(p2, P_VIS + r0, s.pb(p2, P_VIS + r0) + 1);
-                d5_add(d1, r0, -1); d5_add(d2, r0, 1); t1 |= 1 << r0;
+                const int r0 = s.b(B_TRADE_GIVE + i) - 1;
+#pragma unroll
+                for (int k = 0; k < 5; k++) g[k] += (k == r0) ? 1 : 0;
             }
             for (int i = 0; i < 4; i++) if (i < nr) {
-                int r0 = s.b(B_TRADE_RECV + i) - 1;
-                s.spb(p1, P_RES + r0, s.pb(p1, P_RES + r0) + 1);
-                s.spb(p1, P_VIS + r0, s.pb(p1, P_VIS + r0) + 1);
-                s.spb(p2, P_RES + r0, s.pb(p2, P_RES + r0) - 1);
-                s.spb(p2, P_VIS + r0, max(s.pb(p2, P_VIS + r0) - 1, 0));
-                d5_add(d1, r0, 1); d5_add(d2, r0, -1); t1 |= 1 << r0;
+                const int r0 = s.b(B_TRADE_RECV + i) - 1;
+#pragma unroll
+                for (int k = 0; k < 5; k++) rc[k] += (k == r0) ? 1 : 0;
+            }
+            D5 d1, d2;
+            int t1 = 0;
+            int r1[5], v1[5], r2[5], v2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { r1[k] = s.pb(p1, P_RES + k); v1[k] = s.pb(p1, P_VIS + k); r2[k] = s.pb(p2, P_RES + k); v2[k] = s.pb(p2, P_VIS + k); }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                s.spb(p1, P_RES + k, r1[k] - g[k] + rc[k]);
+                s.spb(p1, P_VIS + k, max(v1[k] - g[k], 0) + rc[k]);
+                s.spb(p2, P_RES + k, r2[k] + g[k] - rc[k]);
+                s.spb(p2, P_VIS + k, max(v2[k] + g[k] - rc[k], 0));
+                d1.v[k] = rc[k] - g[k]; d2.v[k] = g[k] - rc[k];
+                t1 |= (g[k] | rc[k]) ? 1 << k : 0;
             }
             update_estimates(s, seatof, d1, t1, p1, -1);
             update_estimates(s, seatof, d2, t1, p2, -1);
@@ -2895,7 +2907,10 @@ constexpr int SORT_PAD_WAVES = NBINS - 1;                // one partial wave per
 // bins != nullptr: also the histogram of the counting sort (k_classify_hist fused in; rollout loops) and the per-game
 // action types for k_classify_scatter.  (Staging the mask / action rows through LDS with coalesced transfers was tried:
 // 2.5 us slower - the kernel is bound by its divergent sampling chain, not by the row accesses.)
-__global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
+// BS threads per workgroup: 512 in the library's own deferred loop (43.2-43.4 against 43.5-43.6 us per pass with 256: half the range
+// reservations per bin; 128 and 1 024 are slower: profiles/r05_s5_pass_experiments.txt, run 13)
+template <int BS = BLOCK>
+__global__ __launch_bounds__(BS) void k_sample_random(Ctx c, const u32* __restrict__ mpk, u32 step_idx, i32* __restrict__ actions,
                                                         u32* __restrict__ pctr, u8* __restrict__ busy, int tag_now, int tag_now2,
                                                         u32* __restrict__ zero_me, int zero_n, u32* __restrict__ bins, i32* __restrict__ lists) {
     __shared__ u32 hist[NBINS], base[NBINS];
@@ -2903,7 +2918,7 @@ __global__ __launch_bounds__(BLOCK) void k_sample_random(Ctx c, const u32* __res
         if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
         __syncthreads();
     }
-    St s(c.R, c.N, (long)blockIdx.x * BLOCK + threadIdx.x);
+    St s(c.R, c.N, (long)blockIdx.x * BS + threadIdx.x);
     // the list counters this step / iteration starts from zero with: the tier-1 request counter of the iteration (deferred),
     // every slow-path list counter (lock-step: ctr[4..15]); nothing else touches them before k_step
     if (zero_me != nullptr && s.e < zero_n) zero_me[s.e] = 0;
