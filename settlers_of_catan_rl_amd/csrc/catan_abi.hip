@@ -75,7 +75,10 @@ struct catan_env {
     hipStream_t d_stream; // ... and the caller's stream (one stream per sequence)
 };
 
-constexpr int DEFAULT_STEP_WAVE_GAMES = 64;   // games per k_step wave (catan_set_step_wave_games)
+// games per k_step wave (catan_set_step_wave_games).  32 since the end of round 5: two waves per SIMD, so that one wave's gather overlaps the other's
+// rules code - 41.4 -> 40.9 us per pass, lock-step 180.8 -> 178 us (profiles/r05_s5_pass_experiments.txt, run 20; 16: 43.2 us).  In round 3 the
+// same switch bought nothing (28.3 -> 27.6 us of k_step): the launch was then bound by the CUs tier 2 held, not by its waves.
+constexpr int DEFAULT_STEP_WAVE_GAMES = 32;
 constexpr int LR_BUDGET_DEFERRED = 12;   // (swept together with the window length: tools/deferred_sweep.py)
 // cross-stream ordering inside one device: no timing, no system-scope release (which would flush L2 at every record)
 constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;

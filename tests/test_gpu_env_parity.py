@@ -87,6 +87,8 @@ def test_deferred_rollout_trajectory_parity(oracle, hip_lib, n, iters, window, s
     {"CATAN_LR_MID_BUDGET": "0"},                                         # no middle tier: every tier-2 request to k_lr_heavy
     {"CATAN_LR_MID_BUDGET": "8", "CATAN_LR_MID_HEAVY_GRID": "16"},        # a middle tier that hands most of its requests on
     {"CATAN_STEP_BIN_ORDER": "0"},                                        # bins over the waves in index order
+    {"CATAN_STEP_WAVE_GAMES": "64"},                                      # games per k_step wave: 64 / 16 (the default is 32)
+    {"CATAN_STEP_WAVE_GAMES": "16", "CATAN_LR_SPLIT": "0"},
     {"CATAN_T1_GROUP": "1", "CATAN_LR_SPLIT": "2", "CATAN_LR_MID_BUDGET": "0", "CATAN_STEP_BIN_ORDER": "0"},
 ])
 def test_deferred_schedule_switches_keep_the_trajectories(oracle, hip_lib, monkeypatch, switches):

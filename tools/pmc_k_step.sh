@@ -20,7 +20,7 @@ for p in ("p1", "p2", "p3"):
             tail = v[-96:]
             res[c] = {"per_launch_mean": sum(tail) / len(tail), "launches": len(tail)}
 w = res.get("SQ_WAVES", {}).get("per_launch_mean")
-out = {"kernel": "catan::k_step<64>", "workload": "tools/pmc_workload.py: 65 536 games, deferred W = 32, the last 96 launches", "counters": res}
+out = {"kernel": "catan::k_step (the default games-per-wave instantiation)", "workload": "tools/pmc_workload.py: 65 536 games, deferred W = 32, the last 96 launches", "counters": res}
 if w:
     d = {}
     for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH"):

@@ -11,6 +11,10 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd import _lib
 
 n = 65536
+# profiled at 64 games per wave: the per-wave buffer keeps k_lr_finish's rows from row 1 088 on, where k_step's waves of the default
+# (32 games per wave: 2 065 rows) would run into them; the per-type phase times are what this tool is for
+os.environ.setdefault("CATAN_STEP_WAVE_GAMES", "64")
+G = int(os.environ["CATAN_STEP_WAVE_GAMES"])
 FUSED = int(os.environ.get("FUSED", "0"))
 env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
@@ -27,7 +31,7 @@ for rep in range(32):
     env.random_rollout_deferred(33 + rep, 32)
     out = np.zeros((rows, 8), dtype=np.uint32)
     L.catan_profile_read_waves(env.h, out.ctypes.data_as(C.c_void_p))
-    a = out[:n // 64 + 17]
+    a = out[:n // G + 17]
     rowidx = np.nonzero(a[:, 5] > 0)[0]
     a = a[a[:, 5] > 0]
     start = a[:, 2].astype(np.int64)

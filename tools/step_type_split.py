@@ -9,6 +9,10 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd import _lib
 
 n = 65536
+# profiled at 64 games per wave: the per-wave buffer keeps k_lr_finish's rows from row 1 088 on, where k_step's waves of the default
+# (32 games per wave: 2 065 rows) would run into them; the per-type phase times are what this tool is for
+os.environ.setdefault("CATAN_STEP_WAVE_GAMES", "64")
+G = int(os.environ["CATAN_STEP_WAVE_GAMES"])
 env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
 env.random_rollout_deferred(3000, 32)
@@ -21,7 +25,7 @@ for rep in range(24):
     env.random_rollout_deferred(33 + rep, 32)
     out = np.zeros((waves, 8), dtype=np.uint32)
     L.catan_profile_read_waves(env.h, out.ctypes.data_as(C.c_void_p))
-    acc.append(out[:n // 64 + 17].copy())
+    acc.append(out[:n // G + 17].copy())
 L.catan_profile_enable(env.h, 0)
 a = np.concatenate(acc)
 a = a[a[:, 5] > 0]
