@@ -431,7 +431,7 @@ def main():
             "end_to_end": {"algorithmic_bytes_per_env_step": per_step_bytes,
                            "timed_schedule_gbs": per_step_bytes * env_steps / world / dt / 1e9,
                            "timed_schedule_frac": per_step_bytes * env_steps / world / dt / 1e9 / HBM_PEAK_GBS},
-            "note": "integer/byte rules engine at one wave per SIMD: latency- and divergence-bound, far below the HBM "
+            "note": "integer/byte rules engine at one or two waves per SIMD: latency- and divergence-bound, far below the HBM "
                     "roofline by nature (SURVEY.md 8(d)); frac is reported for the dominant kernel of the timed loop; "
                     "the slow-path kernels (k_lr_*, k_reset_list) are latency-bound path searches / re-deals (LDS + ALU, "
                     "a few MB per launch) and run on side streams in the deferred loop",
