@@ -238,43 +238,11 @@ typedef struct catan_te_saves {
     void* n2[2];        /* [64]  LayerNorm 2 output; may be NULL: catan_ffn_bwd / catan_ffn_outproj_bwd recompute it from xmid */
     void* h[2];         /* [128] relu(linear1); may be NULL: catan_ffn_outproj_bwd_rh recomputes it */
     void* xfin;         /* [64]  last layer's output */
-    void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU; may be NULL (catan_tile_encoder_bwd_tail); so may tiles64 / a0 (..._bwd_head) */
+    void* p;            /* [25]  out_proj output, before the final LayerNorm + ReLU */
 } catan_te_saves_t;
 /* out_pitch: elements between two boards' rows of `out` (>= 475; the columns beyond 475 are not written) */
 int catan_tile_encoder_fwd_train(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, const catan_te_saves_t* saves,
                                  int64_t boards, catan_stream_t stream);
-
-/* The tile encoder's backward with the forward RECOMPUTED on chip (csrc/catan_te_fused_bwd.hip; reference RL/models/tile_encoder.py:41-91 under
- * RL/ppo/ppo.py:66's backward): the training forward stores ONE activation, the input of transformer layer 1 (128 B per token instead of the
- * 2.4 KB of catan_te_saves_t), and two launches walk back through the encoder:
- *   catan_tile_encoder_fwd_xin1     catan_tile_encoder_fwd + xin1 bf16 [boards * 19][64]
- *   catan_tile_encoder_bwd_layer1   xin1, dout (bf16 [boards][out_pitch]: the gradient of `out`) -> dxin1 bf16 [boards * 19][64]
- *   catan_tile_encoder_bwd_layer0   tiles (the forward's input), dxin1
- * weights / vecs: catan_tile_encoder_fwd's packed parameters; wqt / wot / w1t / w2t: the layer's transposed bf16 weights Wqkv^T [64][192],
- * Wo^T [64][64], W1^T [64][128], W2^T [128][64]; wpt32: out_proj^T [64][32] (columns 25..31 zero).  grads: float
- * [catan_te_bwd_grad_floats(layer)], ZEROED by the caller, accumulated into (fp32 atomics): Wqkv [192][64] | bqkv [192] | Wo [64][64] | bo [64] |
- * W1 [128][64] | b1 [128] | W2 [64][128] | b2 [64] | LayerNorm 1 weight, bias [64] each | LayerNorm 2 weight, bias [64] each | then layer 1:
- * out_proj [32][64] (rows >= 25 unused) | its bias [32] | final LayerNorm weight, bias [32] each; layer 0: first_layer [64][64] (columns >= 60
- * unused) | its bias [64] | its LayerNorm weight, bias [64] each. */
-int catan_tile_encoder_fwd_xin1(const void* tiles, const void* weights, const float* vecs, void* out, int64_t out_pitch, void* xin1, int64_t boards,
-                                catan_stream_t stream);
-int32_t catan_te_bwd_grad_floats(int32_t layer);
-int catan_tile_encoder_bwd_layer1(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t, const void* wpt32,
-                                  const void* xin1, const void* dout, int64_t out_pitch, void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
-int catan_tile_encoder_bwd_layer0(const void* weights, const float* vecs, const void* wqt, const void* wot, const void* w1t, const void* w2t,
-                                  const void* tiles, const void* dxin1, float* grads, int64_t boards, catan_stream_t stream);
-
-/* The two ends of the encoder's backward beside the sub-layer kernels (catan_ffn_outproj_bwd / catan_attention_bwd / catan_qkv_bwd), one launch each,
- * with the small activation of that end recomputed (catan_te_saves_t.p / .a0 / .tiles64 may then be NULL in the training forward):
- *   catan_tile_encoder_bwd_tail   xfin bf16 [boards * 19][64] (catan_te_saves_t.xfin), dout bf16 [boards][out_pitch] -> dxfin bf16 [boards * 19][64];
- *                                 grads float [catan_te_bwd_ends_grad_floats(1)]: out_proj [32][64] (rows >= 25 unused) | bias [32] | LayerNorm w, b [32 each]
- *   catan_tile_encoder_bwd_head   tiles bf16 [boards][19][60], dx0 bf16 [boards * 19][64] (the gradient of the first layer's output);
- *                                 grads float [catan_te_bwd_ends_grad_floats(0)]: first_layer [64][64] (columns >= 60 unused) | bias [64] | LayerNorm w, b [64 each]
- * grads are ZEROED by the caller and accumulated into (fp32 atomics). */
-int32_t catan_te_bwd_ends_grad_floats(int32_t part);
-int catan_tile_encoder_bwd_tail(const void* weights, const float* vecs, const void* wpt32, const void* xfin, const void* dout, int64_t out_pitch, void* dxfin,
-                                float* grads, int64_t boards, catan_stream_t stream);
-int catan_tile_encoder_bwd_head(const void* weights, const float* vecs, const void* tiles, const void* dx0, float* grads, int64_t boards, catan_stream_t stream);
 
 /* One action head of the policy net for inference (RL/models/action_heads_module.py:202-228 + RL/distributions.py:10-40):
  * x = pre (+ cond . W1e^T) -> LayerNorm -> ReLU -> 128 x 128 -> 128 x K -> masked categorical, ONE kernel per head evaluation.
@@ -301,13 +269,6 @@ int32_t catan_head_state_floats(void);
 int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const float* vec, float eps, int32_t head_id, int32_t step, float* state,
                      const float* maskmat, const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* u,
                      int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream);
-/* The same pass in ONE launch: a workgroup takes its 256 rows through all eighteen evaluations with the chained state in LDS (the rows are
- * independent).  pre_all: bfloat16 [B][pre_ld >= 1536], head h's trunk product in columns 128 h .. 128 h + 127; wts12 / vec12: HOST arrays
- * of the twelve heads' device packs; u18: HOST array of eighteen device rows of B uniforms in the chain's order, or NULL (arg-max).
- * Identical results to the eighteen catan_head_chain calls for the same uniforms. */
-int catan_head_chain_all(const void* pre_all, int64_t pre_ld, const void* const* wts12, const float* const* vec12, float eps, const float* maskmat,
-                         const float* cur_res, const float* trade, const float* custom, const int64_t* forced, const float* const* u18,
-                         int64_t* actions, float* logp_out, int64_t B, catan_stream_t stream);
 
 /* The dev-card list modules of the policy net (RL/models/player_modules.py:55-69: embedding(6 x 16) -> 4-head attention with
  * key mask -> out projection -> LayerNorm(16) -> zero the padding -> sum over the list), one fused kernel, evaluated per card

@@ -210,14 +210,13 @@ struct HeadShared {
     float sCnt[WAVES][RT][16];
     __attribute__((aligned(16))) float sState[WAVES][RT][16][HD_STATE];   // the rows' chained state (LDS: ordered within the wave)
 };
-// One head evaluation of a workgroup's 256 rows.  ALL (k_heads_all: every evaluation of a policy pass in one launch): the rows' chained
-// state lives in sh.sState from one evaluation to the next - it is neither read from nor written to a.state.
-template <int KT, bool ALL, int RT, int WAVES>
+// One head evaluation of a workgroup's 256 rows.
+template <int KT, int RT, int WAVES>
 DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
     constexpr int HD_RT = RT, HD_WAVES = WAVES, HD_THREADS = WAVES * 64, HD_ROWS = WAVES * RT * 16;
     auto& sW2 = sh.sW2; auto& sW3 = sh.sW3; auto& sW1 = sh.sW1; auto& sV = sh.sV; auto& sLg = sh.sLg; auto& sCond = sh.sCond; auto& sCnt = sh.sCnt;
     auto& sState = sh.sState;
-    const bool chained = ALL || a.state != nullptr;
+    const bool chained = a.state != nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, g = lane >> 4;
     const int rr = lane >> 2, part = lane & 3, c0 = part * 20;   // the categorical's split: four lanes per row, 20 columns each
     // Everything a wave's row tiles need from HBM is requested before the weights are staged: the trunk products, the rows' state,
@@ -233,7 +232,7 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
         const long grow = row0 + rr < a.B ? row0 + rr : a.B - 1;
 #pragma unroll
         for (int s = 0; s < 4; s++) xr[tt][s] = *reinterpret_cast<const uint4*>(a.pre + row * a.pre_ld + s * 32 + g * 8);
-        if (chained && !ALL) {
+        if (chained) {
             const float4* src = reinterpret_cast<const float4*>(a.state + grow * HD_STATE + part * 8);
             sr[tt][0] = src[0]; sr[tt][1] = src[1];
         }
@@ -255,12 +254,10 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
     unsigned short* lg = sLg[wave];
     u32 mkb[HD_RT];                                                  // the rows' mask entries of this lane's 20 columns, as bits
     if (chained) {
-        if (!ALL) {
 #pragma unroll
-            for (int tt = 0; tt < HD_RT; tt++) {
-                float4* dst = reinterpret_cast<float4*>(&sState[wave][tt][rr][part * 8]);
-                dst[0] = sr[tt][0]; dst[1] = sr[tt][1];
-            }
+        for (int tt = 0; tt < HD_RT; tt++) {
+            float4* dst = reinterpret_cast<float4*>(&sState[wave][tt][rr][part * 8]);
+            dst[0] = sr[tt][0]; dst[1] = sr[tt][1];
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 16 * HD_RT) {                                       // one lane per row: conditioning columns, log-prob factor
@@ -462,7 +459,7 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (chained && !ALL && row0 + rr < a.B) {                      // the rows' state goes back for the next evaluation
+        if (chained && row0 + rr < a.B) {                      // the rows' state goes back for the next evaluation
             float4* dst = reinterpret_cast<float4*>(a.state + (row0 + rr) * HD_STATE + part * 8);
             const float4* src = reinterpret_cast<const float4*>(&sState[wave][tt][rr][part * 8]);
             dst[0] = src[0]; dst[1] = src[1];
@@ -473,35 +470,6 @@ DEVI void hd_eval(const HeadArgs& a, HeadShared<RT, WAVES>& sh) {
 template <int KT, int RT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_head_fwd(HeadArgs a) {
     __shared__ HeadShared<RT, WAVES> sh;
-    hd_eval<KT, false, RT, WAVES>(a, sh);
+    hd_eval<KT, RT, WAVES>(a, sh);
 }
-// Every head evaluation of a policy pass - head 0; 1, 2, 3; 5, 6, 11; 4, 9, 10; 7 and 8 with four steps each - in ONE launch: the rows are
-// independent, so a workgroup takes its 256 rows through all of them, re-staging one head's weights (64 KB from L2) per evaluation, with
-// the rows' chained state in LDS throughout.  Same arithmetic as eighteen launches of k_head_fwd (each 30 us of mostly ramp, tail and
-// two exposed round trips for 5-10 us of work): identical actions and log-probs for the same uniforms.
-constexpr int HD_EVS = 18;
-struct HeadEv { const unsigned short* pre; const unsigned short* wts; const float* vec; const float* u; int K, ncond, head_id, step; };
-struct HeadEvs { HeadEv e[HD_EVS]; int n; };
-template <int RT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_heads_all(HeadArgs a, HeadEvs evs) {
-    __shared__ HeadShared<RT, WAVES> sh;
-    {
-        float* z = &sh.sState[0][0][0][0];
-        for (int i = threadIdx.x; i < WAVES * RT * 16 * HD_STATE; i += WAVES * 64) z[i] = 0.0f;
-    }
-    for (int k = 0; k < evs.n; k++) {
-        __syncthreads();                                     // the previous evaluation is done with the weights (and the state is zeroed)
-        HeadArgs b = a;
-        const HeadEv& e = evs.e[k];
-        b.pre = e.pre; b.wts = e.wts; b.vec = e.vec; b.u = e.u; b.K = e.K; b.ncond = e.ncond; b.head_id = e.head_id; b.step = e.step;
-        switch ((b.K + 15) / 16) {
-        case 1: hd_eval<1, true, RT, WAVES>(b, sh); break;
-        case 2: hd_eval<2, true, RT, WAVES>(b, sh); break;
-        case 3: hd_eval<3, true, RT, WAVES>(b, sh); break;
-        case 4: hd_eval<4, true, RT, WAVES>(b, sh); break;
-        default: hd_eval<5, true, RT, WAVES>(b, sh); break;
-        }
-    }
-}
-
 }  // namespace catan

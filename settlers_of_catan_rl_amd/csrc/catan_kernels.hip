@@ -1738,6 +1738,13 @@ struct Pending { u32* ctr; u64* req[3]; u64* heavy[2]; u64* heavy2; u8* type; u8
                  int bnext;                 // k_step: the set the games it completes are appended to (the next pass)
                  int brel;                  // slow-path completions: >= 0 the set of the pass their games return in (tier 1: pass + 2);
                                             // < 0: the window's release list resets[sa][2] (tier 2 / re-deals: k_release_window enqueues them)
+                 // Fused-sampling rollouts keep every bin's list as `nsub` SUB-LISTS with a counter each (bctr, one 128-byte line per counter):
+                 // k_step's waves reserve their ranges on sub-list (wave index % nsub), the one-lane producers on (game id % nsub), and the
+                 // next pass reads a bin as the concatenation of its sub-lists.  With ONE counter per bin the ~2 000 waves of a launch queue up
+                 // on 17 addresses (~9 us per 1 000 same-address atomics: tools/native/atomic_contention_probe.hip) - round 4's fused loop.
+                 // nsub = 1 outside those rollouts (the lists' layout is then the plain [set][bin][N]).
+                 u32* bctr;                 // [BIN_SETS][NBINS][nsub][BCTR_PAD]
+                 int nsub;
                };
 constexpr int CTR_WORDS = 96;
 constexpr int BIN_SETS = 4;                  // bin-count / list sets (fused-sampling rollouts rotate period + 2 of them)
@@ -1746,6 +1753,10 @@ DEVI int lrq_ctr(int fl) { return fl < 2 ? 4 + fl : 7; }     // length of tier-1
 // five different code paths, and the launch lasts as long as its slowest wave), NBINS-1 = no-op / busy / padding.
 constexpr int NBINS = 18, BIN_NOOP = NBINS - 1;
 static_assert(16 + BIN_SETS * NBINS <= CTR_WORDS, "the sets of bin counts live in ctr[16 ..]");
+constexpr int BCTR_PAD = 32;                 // words between two sub-list counters (a 128-byte line each)
+constexpr int MAX_SUBS = 16;
+DEVI u32* sub_ctr(const Pending& pend, int set, int bin, int sub) { return pend.bctr + (((long)set * NBINS + bin) * pend.nsub + sub) * BCTR_PAD; }
+DEVI i32* sub_list(const Pending& pend, int set, int bin, int sub, long N) { return pend.lists + (((long)set * NBINS + bin) * pend.nsub + sub) * N; }
 DEVI int bin_of(int t, int card) {
     if (t < 0 || t > 12) return BIN_NOOP;
     if (t != T_PLAYDEV) return t;
@@ -1774,9 +1785,9 @@ DEVI void sample_enqueue_lane(const Ctx& c, const S& s, const u32 (&m)[MASK_WORD
     for (int i = 0; i < 4; i++) dst[i] = make_uint4((u32)a[4 * i], (u32)a[4 * i + 1], (u32)a[4 * i + 2], (u32)a[4 * i + 3]);
     *reinterpret_cast<uint2*>(row + ROW_ACT + 16) = make_uint2((u32)a[16], (u32)a[17]);
     if (pend.brel >= 0) {
-        const int bin = bin_of(t, a[4]);
-        const u32 rank = atomicAdd(&pend.ctr[16 + NBINS * pend.brel + bin], 1u);
-        pend.lists[((long)pend.brel * NBINS + bin) * c.N + rank] = (i32)e;
+        const int bin = bin_of(t, a[4]), sub = (int)(e & (pend.nsub - 1));
+        const u32 rank = atomicAdd(sub_ctr(pend, pend.brel, bin, sub), 1u);
+        sub_list(pend, pend.brel, bin, sub, c.N)[rank] = (i32)e;
     } else {
         const u32 rank = atomicAdd(&pend.ctr[11 + 4 * pend.sa], 1u);
         pend.resets[pend.sa][2][rank] = (i32)e;
@@ -1940,13 +1951,36 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
     const int wv = (int)blockIdx.x * WPB + wib;             // this wave's position among the sorted waves
     u32* const tile = tile_all[wib];
     u64* const tct = tct_all[wib];
-    if (wv == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
-    if (SAMPLE && wv == 0 && lane == 0 && pend.lrq_clear >= 0) pend.ctr[lrq_ctr(pend.lrq_clear)] = 0;   // ... and the next group's tier-1 request list (its last reader is done)
+    if constexpr (SAMPLE) {
+        if (wv == 0)                                                                 // the sub-list counters of a later pass (nobody appends to that set yet)
+            for (int i = lane; i < NBINS * pend.nsub; i += 64) pend.bctr[((long)pend.bclear * NBINS * pend.nsub + i) * BCTR_PAD] = 0;
+        if (wv == 0 && lane == 0 && pend.lrq_clear >= 0) pend.ctr[lrq_ctr(pend.lrq_clear)] = 0;   // ... and the next group's tier-1 request list (its last reader is done)
+    } else if (wv == 0 && lane < NBINS) pend.ctr[16 + NBINS * pend.bclear + lane] = 0;     // the bin counts of a later pass (nobody appends to that set yet)
     // Wave w takes the sorted positions 64w .. 64w+63.  The sort is never materialised: the sampler / k_classify left the
     // game ids in one list per bin, every bin occupies ceil(count / 64) waves (type-pure waves), and a wave finds its bin
     // and offset from the 18 counts.
     int bin = -1, cnt = 0, first = 0;
-    {
+    u32 subc[SAMPLE ? MAX_SUBS : 1];                        // SAMPLE: the lengths of the wave's bin's sub-lists (wave-uniform)
+    if constexpr (SAMPLE) {
+        // lane b sums bin b's sub-list counters (all loads in flight together); the 18 totals and then the chosen bin's lengths are broadcast
+        u32 mine[MAX_SUBS], tot = 0;
+#pragma unroll
+        for (int j = 0; j < MAX_SUBS; j++) mine[j] = (lane < NBINS && j < pend.nsub) ? *sub_ctr(pend, pend.bsel, lane, j) : 0u;
+#pragma unroll
+        for (int j = 0; j < MAX_SUBS; j++) tot += mine[j];
+        const int pos = wv * G;
+        int start = 0;
+#pragma unroll
+        for (int kk = 0; kk < NBINS; kk++) {
+            const int k = cfg.bin_order ? BIN_ORDER_LPT[kk] : kk;
+            const int ck = __builtin_amdgcn_readlane((int)tot, k), len = (ck + G - 1) & ~(G - 1);
+            if (bin < 0 && pos < start + len) { bin = k; cnt = ck; first = pos - start; }
+            start += len;
+        }
+        if (bin < 0) return;                               // behind the last bin
+#pragma unroll
+        for (int j = 0; j < MAX_SUBS; j++) subc[j] = (u32)__builtin_amdgcn_readlane((int)mine[j], bin);
+    } else {
         const int pos = wv * G;
         int start = 0;
 #pragma unroll
@@ -1956,10 +1990,19 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
             if (bin < 0 && pos < start + len) { bin = k; cnt = ck; first = pos - start; }
             start += len;
         }
+        if (bin < 0) return;                               // behind the last bin
     }
-    if (bin < 0) return;                                   // behind the last bin
     const int rnk = first + lane;
-    const long e = (lane < G && rnk < cnt) ? (long)pend.lists[((long)pend.bsel * NBINS + bin) * c.N + rnk] : 0x7fffffffL;
+    long e = 0x7fffffffL;
+    if (lane < G && rnk < cnt) {
+        if constexpr (SAMPLE) {                             // position rnk of the bin = position `off` of sub-list `sub`
+            int sub = 0;
+            u32 off = (u32)rnk;
+#pragma unroll
+            for (int j = 0; j < MAX_SUBS - 1; j++) if (sub == j && j + 1 < pend.nsub && off >= subc[j]) { off -= subc[j]; sub = j + 1; }
+            e = (long)sub_list(pend, pend.bsel, bin, sub, c.N)[off];
+        } else e = (long)pend.lists[((long)pend.bsel * NBINS + bin) * c.N + rnk];
+    }
     long long tprof = (cfg.prof || cfg.prof_wave) ? wall_clock64() : 0;
     if (cfg.prof_wave != nullptr && cfg.prof_timeline && lane == 0) cfg.prof_wave[(long)wv * 8 + 2] = (u32)tprof;
     const bool live = e < c.n;
@@ -2387,7 +2430,7 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
             if (nb == b) { rank = (u32)__popcll(mk & ((1ull << lane) - 1)); cntb = (u32)__popcll(mk); leader = __ffsll((long long)mk) - 1; }
         }
         // (the atomic's round trip - device scope: ~2 us - runs under the write-back of the records below; its result is used after it)
-        if (nb >= 0 && lane == leader) abase = atomicAdd(&pend.ctr[16 + NBINS * pend.bnext + nb], cntb);
+        if (nb >= 0 && lane == leader) abase = atomicAdd(sub_ctr(pend, pend.bnext, nb, wv & (pend.nsub - 1)), cntb);
         arank = rank; aleader = leader; anb = nb;
         if (cfg.prof_wave != nullptr) {                     // slot 4 (SAMPLE): the draw | the ranking << 16
             const long long t_s2 = clock_fenced();
@@ -2402,7 +2445,7 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
     __builtin_amdgcn_wave_barrier();
     if constexpr (SAMPLE) {
         abase = __shfl(abase, aleader);
-        if (anb >= 0) pend.lists[((long)pend.bnext * NBINS + anb) * c.N + abase + arank] = (i32)e;
+        if (anb >= 0) sub_list(pend, pend.bnext, anb, wv & (pend.nsub - 1), c.N)[abase + arank] = (i32)e;
     }
     if constexpr (SAMPLE) stage_out_row<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new, an, dctr);
     else stage_out_masks<G>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
@@ -2547,10 +2590,20 @@ __global__ __launch_bounds__(64) void k_lr_complete(Ctx c, u32* __restrict__ mpk
         long long tprof = 0;
         finish_step<1>(c, s, (StepScratch*)nullptr, cfg, lane, e >= 0, type, who, len, reward, done, mpk, tprof, 0u, 0u, pend,
                        pend.stag < 2 ? 2 : 0, pend.ftag < 2, m_new, &have_masks);
+        // fused-sampling rollouts: the next action of every game completed here (decision index = the counter k_step left in the side row) and its
+        // place in the pass it returns in - as sample_enqueue_lane does for the one-lane completions, here lane per game
+        int an[ACTION_WORDS] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        u32 dctr = 0;
+        if (pend.sample && have_masks) {
+            dctr = mpk[e * MPK_STRIDE + ROW_CTR];
+            const int nb = bin_of(sample_random(c, s, m_new, dctr, an, (u32*)nullptr, (u8*)nullptr, 0, 0), an[4]), sub = (int)(e & (pend.nsub - 1));
+            sub_list(pend, pend.brel, nb, sub, c.N)[atomicAdd(sub_ctr(pend, pend.brel, nb, sub), 1u)] = (i32)e;
+        }
         __builtin_amdgcn_wave_barrier();
         stage_out<28, 0, 64>(tile, c.R, (int)e, lane);
         __builtin_amdgcn_wave_barrier();
-        stage_out_masks<64>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
+        if (pend.sample) stage_out_row<64>(tile, mpk, have_masks ? (int)e : -1, lane, m_new, an, dctr);
+        else stage_out_masks<64>(tile, mpk, have_masks ? (int)e : -1, lane, m_new);
     }
 }
 
@@ -2685,8 +2738,7 @@ __global__ __launch_bounds__(BLOCK) void k_release_tags(Ctx c, u8* __restrict__ 
 // ---- fused-sampling deferred rollouts: the three small kernels around the loop
 // first pass of a call: every game's first action (decision index pctr[e], which is NOT advanced: k_step counts a decision when
 // it applies it) into its side row, the counter next to it, the game into bin set 0
-__global__ __launch_bounds__(BLOCK) void k_sample_first(Ctx c, u32* __restrict__ mpk, const u32* __restrict__ pctr, u32* __restrict__ bins,
-                                                       i32* __restrict__ lists) {
+__global__ __launch_bounds__(BLOCK) void k_sample_first(Ctx c, u32* __restrict__ mpk, const u32* __restrict__ pctr, Pending pend, int set) {
     __shared__ u32 hist[NBINS], base[NBINS];
     if (threadIdx.x < NBINS) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -2710,20 +2762,21 @@ __global__ __launch_bounds__(BLOCK) void k_sample_first(Ctx c, u32* __restrict__
     const bool valid = s.e < c.n;
     if (valid) rank = atomicAdd(&hist[bin], 1u);
     __syncthreads();
-    if (threadIdx.x < NBINS) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&bins[threadIdx.x], hist[threadIdx.x]) : 0u;
+    const int sub = (int)(blockIdx.x & (pend.nsub - 1));
+    if (threadIdx.x < NBINS) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(sub_ctr(pend, set, threadIdx.x, sub), hist[threadIdx.x]) : 0u;
     __syncthreads();
-    if (valid) lists[(long)bin * c.N + base[bin] + rank] = (i32)s.e;
+    if (valid) sub_list(pend, set, bin, sub, c.N)[base[bin] + rank] = (i32)s.e;
 }
 // opening of window w + 2: the games whose step the slow path of window w completed (tier 2, re-deals) sit in that window's
 // release list with their next action already in their side rows - enqueue them for this pass
 __global__ __launch_bounds__(BLOCK) void k_release_window(Ctx c, const u32* __restrict__ mpk, const u32* __restrict__ count_p, const i32* __restrict__ list,
-                                                         u32* __restrict__ bins, i32* __restrict__ lists) {
+                                                         Pending pend, int set) {
     const u32 count = *count_p;
     for (u32 r = blockIdx.x * BLOCK + threadIdx.x; r < count; r += gridDim.x * BLOCK) {
         const long e = list[r];
         const u32* row = mpk + e * MPK_STRIDE;
-        const int bin = bin_of((int)row[ROW_ACT], (int)row[ROW_ACT + 4]);
-        lists[(long)bin * c.N + atomicAdd(&bins[bin], 1u)] = (i32)e;
+        const int bin = bin_of((int)row[ROW_ACT], (int)row[ROW_ACT + 4]), sub = (int)(e & (pend.nsub - 1));
+        sub_list(pend, set, bin, sub, c.N)[atomicAdd(sub_ctr(pend, set, bin, sub), 1u)] = (i32)e;
     }
 }
 // end of a call: the decision counters back into the handle's array (catan_policy_counters), every slow-path tag cleared
@@ -3067,6 +3120,13 @@ __global__ __launch_bounds__(64) void k_randomise_uncertainty(Ctx c, const i32* 
 // FETCH_SIZE / WRITE_SIZE counters on this GPU (profiles/README.md).
 __global__ __launch_bounds__(BLOCK) void k_calib_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (long)gridDim.x * BLOCK) dst[i] = src[i];
+}
+
+// Diagnostics (CATAN_DEBUG_STEP_DELAY_US): one wave that spins for `ticks` of the 100 MHz wall clock - in front of a k_step it makes
+// that launch late, which turns a missing stream dependency on it into a deterministic failure (the fused loop's window close).
+__global__ __launch_bounds__(64) void k_debug_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 // ------------------------------------------------------------------------------------------------ deciding seat

@@ -236,8 +236,8 @@ DEVI void te_attention(const unsigned short* qkv, unsigned short* out, int lane,
 // (csrc/catan_nn.hip: LayerNorm, attention, row products, weight gradients) - the tensors the unfused training forward keeps for
 // autograd, written once from LDS as 16-byte row pieces while the next phase computes: bf16 [boards * 19][width] each.
 struct TeSaves {
-    unsigned short* tiles64;          // [64]: the tile features, zero-padded 60 -> 64 (the first layer's input); may be null (k_te_bwd_ends<0>)
-    unsigned short* a0;               // [64]: first_layer output (before its LayerNorm + ReLU); may be null (k_te_bwd_ends<0>)
+    unsigned short* tiles64;          // [64]: the tile features, zero-padded 60 -> 64 (the first layer's input)
+    unsigned short* a0;               // [64]: first_layer output (before its LayerNorm + ReLU)
     unsigned short* xin[2];           // [64]: the layer's input (residual stream)
     unsigned short* n1[2];            // [64]: LayerNorm 1 output (the QKV product's input); may be null: k_qkv_bwd_w<true> recomputes it from xin
     unsigned short* qkv[2];           // [192]
@@ -246,7 +246,7 @@ struct TeSaves {
     unsigned short* n2[2];            // [64]: LayerNorm 2 output (the FFN's input); may be null: k_ffn_bwd_w<., true> recomputes it from xmid
     unsigned short* h[2];             // [128]: relu(linear1); may be null: k_ffn_bwd_w<., true, true> recomputes it from the recomputed n2
     unsigned short* xfin;             // [64]: the last layer's output (out_proj's input)
-    unsigned short* p;                // [25]: out_proj output (before the final LayerNorm + ReLU); may be null (k_te_bwd_ends<1>)
+    unsigned short* p;                // [25]: out_proj output (before the final LayerNorm + ReLU)
 };
 template <int W>
 DEVI void te_dump(const unsigned short* lds, int pitch, unsigned short* __restrict__ g, long row0, int rows, int tid) {
@@ -258,8 +258,7 @@ DEVI void te_dump(const unsigned short* lds, int pitch, unsigned short* __restri
     }
 }
 // tiles: bf16 [boards][19][60] contiguous (8-byte aligned); out: bf16 [boards][19 * 25]; wts / vecs: the packed parameters
-// SAVE_MODE 0: inference; 1: every activation of TeSaves (the sub-layer backward kernels of catan_te_bwd.hip); 2: only sv.xin[1], the input
-// of layer 1 - what the recomputing backward (catan_te_fused_bwd.hip) reads besides the tile features
+// SAVE_MODE 0: inference; 1: every activation of TeSaves (the sub-layer backward kernels of catan_te_bwd.hip)
 template <int SAVE_MODE>
 __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tile_encoder_fwd(const unsigned short* __restrict__ tiles, const unsigned short* __restrict__ wts,
                                                           const float* __restrict__ vecs, unsigned short* __restrict__ out, long boards, TeSaves sv, long out_pitch) {
@@ -297,10 +296,10 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const long t0 = g0 * TE_L;                                              // this group's first token row
         const int nt = nb * TE_L;
         // ---- x = relu(LayerNorm(first_layer(tiles)))
-        if (SAVE && sv.tiles64 != nullptr) te_dump<64>(Nb, TE_PX, sv.tiles64, t0, nt, tid);      // (optional: catan_tile_encoder_bwd_head re-stages the features)
+        if (SAVE) te_dump<64>(Nb, TE_PX, sv.tiles64, t0, nt, tid);
         te_gemm<64, 64, 0>(Nb, TE_PX, w0, V + TE_V0, X, TE_PX, lane, wave);
         __syncthreads();
-        if (SAVE && sv.a0 != nullptr) { te_dump<64>(X, TE_PX, sv.a0, t0, nt, tid); __syncthreads(); }   // (the LayerNorm below is in place; optional: ..._bwd_head recomputes a0)
+        if (SAVE) { te_dump<64>(X, TE_PX, sv.a0, t0, nt, tid); __syncthreads(); }   // (the LayerNorm below is in place)
         te_layer_norm<TE_D, true>(X, TE_PX, X, TE_PX, V + TE_V0 + 64, V + TE_V0 + 128, tid);
         __syncthreads();
 #pragma unroll 1
@@ -309,7 +308,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const float* vl = V + TE_VL + l * TE_VL_SIZE;
             // x = x + out_proj(attention(qkv(LayerNorm(x))))
             TeW<64, 192> wq; te_fetch<64, 192>(wq, wl, lane, wave);
-            if (SAVE || (SAVE_MODE == 2 && l == 1)) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
+            if (SAVE) te_dump<64>(X, TE_PX, sv.xin[l], t0, nt, tid);
             te_layer_norm<TE_D, false>(X, TE_PX, Nb, TE_PX, vl, vl + 64, tid);
             __syncthreads();
             if (SAVE && sv.n1[l] != nullptr) te_dump<64>(Nb, TE_PX, sv.n1[l], t0, nt, tid);   // (optional: the backward can recompute it)
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(TE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             te_gemm<64, 32, 0>(X, TE_PX, wp, V + TE_VP, Q, TE_PX, lane, wave);
         }
         __syncthreads();
-        if (SAVE && sv.p != nullptr) {                                      // (optional: catan_tile_encoder_bwd_tail recomputes P)
+        if (SAVE) {
             for (int c = tid; c < nt * TE_OUT; c += TE_THREADS) {
                 const int t = c / TE_OUT, i = c - t * TE_OUT;
                 sv.p[(t0 + t) * TE_OUT + i] = Q[t * TE_PX + i];

@@ -322,14 +322,19 @@ class GradBucket(object):
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("all parameters of a bucket must share device and dtype")
         self.group = process_group
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        # every view starts on a 16-byte boundary (offsets padded to ALIGN elements; the padding stays zero and travels with the message):
+        # optim.FusedAdam's kernels read gradients with 16-byte loads, and of CatanPolicy's 203 parameters 108 would start mid-vector in
+        # an unpadded bucket (the optimiser then cloned those gradients every step on the multi-rank path)
+        self.ALIGN = max(1, 16 // torch.empty((), dtype=dt).element_size())
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(sum(pad(p.numel()) for p in self.params), dtype=dt, device=dev)
         self._views = []
         off = 0
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             p.grad = v
             self._views.append(v)
-            off += p.numel()
+            off += pad(p.numel())
 
     def zero(self):
         if self.assign_when_single_rank and not (dist.is_initialized() and dist.get_world_size(self.group) > 1):

@@ -991,9 +991,6 @@ class _TeImages(object):
         W(te.out_proj.weight, 32, 64)
         V([te.out_proj.bias], 32, 2); V([te.norm.weight], 32, 1); V([te.norm.bias], 32, 1)
         self.wpt = T([te.out_proj.weight])
-        # out_proj^T padded to [64][32] (16-byte rows, columns 25..31 zero): the A operand of d(xfin) = dP Wp in k_te_bwd_layer<1>
-        self.wpt32 = torch.zeros((64, 32), dtype=torch.bfloat16, device=dev)
-        self.entries.append(weight_images.add(te.out_proj.weight, self.wpt32[:, :te.out_proj.weight.shape[0]].t(), 0, None))
         assert wo[0] == self.wts.numel() and vo[0] == self.vecs.numel()
         self.stamp = (te.first_layer.weight.data_ptr(), dev)
 
@@ -1053,65 +1050,6 @@ def _te_backward_fused_w():
     return os.environ.get("CATAN_TE_BWD_UNFUSED") != "1" and os.environ.get("CATAN_TE_BWD_W", "1") == "1"
 
 
-# The recomputing backward (csrc/catan_te_fused_bwd.hip) is OFF by default: measured at a minibatch's 180 000 boards (tools/bench_te_fused_bwd.py,
-# profiles/r05_te_fused_bwd.txt) the forward drops from 2.40 to 1.69 ms and the activation workspace from 12.8 GB to 0.2 GB, but the two
-# layer kernels take 14.4 ms against the 6.6 ms of the sub-layer kernels.  The encoder's backward is bound by VALU issue (LayerNorm,
-# softmax, bf16 conversions, epilogues: ~7 000 instructions per wave and 95-token group and layer, 144 of them MFMAs), not by the bytes
-# of the stored activations - recomputing the forward adds a third to that instruction stream.  CATAN_TE_FUSED_BWD=1 / TE_FUSED_BWD = True
-# select it (memory-bound set-ups: 48 KB -> 2.4 KB of saved activations per board).
-TE_FUSED_BWD = os.environ.get("CATAN_TE_FUSED_BWD", "0") == "1"         # (A/B switch, tools/ab_step_switches.py)
-
-
-def te_fused_backward():
-    return TE_FUSED_BWD
-
-
-# The two ENDS of the sub-layer chain as one kernel each (k_te_bwd_ends: the final LayerNorm-25 / out_proj and the first layer's LayerNorm /
-# product, their small activations recomputed): the forward stores 306 B per token less (tiles64, a0, p) and the backward's five passes over
-# those rows become two.  A/B switch (tools/ab_step_switches.py "te_ends"); needs the weight images (wpt32).  OFF by default: measured
-# 21.14 / 21.20 / 21.32 ms per minibatch step with the separate kernels against 21.34 / 21.44 / 21.46 with these (profiles/r05_ab_te_ends.txt) -
-# like the whole-layer kernels above, a 95-token group walked through barrier-separated phases costs more issue time than the streaming
-# kernels cost in bytes.  CATAN_TE_ENDS_FUSED=1 selects them (306 B per token less stored).
-TE_ENDS_FUSED = os.environ.get("CATAN_TE_ENDS_FUSED", "0") == "1"
-
-
-def te_ends_fused():
-    return TE_ENDS_FUSED and weight_images.enabled and _te_backward_fused_w()
-
-
-def _te_fused_backward(ctx, dout):
-    """_TileEncoderTrain.backward through catan_tile_encoder_bwd_layer1 / _layer0: two launches, the forward recomputed on chip.  The
-    gradient blocks' layout is include/catan_hip_nn.h's (catan_te_bwd_grad_floats)."""
-    x, xin1 = ctx.saved_tensors[:2]
-    P = ctx.saved_tensors[2:]
-    B, bf = ctx.B, torch.bfloat16
-    L = _lib.lib()
-    im = _te_images(ctx.te)
-    d = dout if (dout.dtype == bf and dout.is_contiguous()) else dout.to(bf).contiguous()
-    n1, n0 = int(L.catan_te_bwd_grad_floats(1)), int(L.catan_te_bwd_grad_floats(0))
-    G = grad_zeros((n1 + n0,), x.device)
-    g1, g0 = G[:n1], G[n1:]
-    dxin1 = torch.empty_like(xin1)
-    with torch.autocast("cuda", enabled=False):
-        _lib.check(L.catan_tile_encoder_bwd_layer1(_ptr(im.wts), _ptr(im.vecs), _ptr(im.wqt[1]), _ptr(im.wot[1]), _ptr(im.w1t[1]), _ptr(im.w2t[1]), _ptr(im.wpt32),
-                                                   _ptr(xin1), _ptr(d), d.shape[1], _ptr(dxin1), _ptr(g1), B, _stream()))
-        _lib.check(L.catan_tile_encoder_bwd_layer0(_ptr(im.wts), _ptr(im.vecs), _ptr(im.wqt[0]), _ptr(im.wot[0]), _ptr(im.w1t[0]), _ptr(im.w2t[0]),
-                                                   _ptr(x), _ptr(dxin1), _ptr(g0), B, _stream()))
-    g = [None] * len(P)
-    for l, blk in ((0, g0), (1, g1)):
-        b = 4 + 16 * l
-        dwq, dbq = blk[:12288].view(192, 64), blk[12288:12480]
-        for k in range(3):
-            g[b + 2 + 2 * k], g[b + 3 + 2 * k] = dwq[64 * k:64 * k + 64], dbq[64 * k:64 * k + 64]
-        g[b + 8], g[b + 9] = blk[12480:16576].view(64, 64), blk[16576:16640]
-        g[b + 12], g[b + 13] = blk[16640:24832].view(128, 64), blk[24832:24960]
-        g[b + 14], g[b + 15] = blk[24960:33152].view(64, 128), blk[33152:33216]
-        g[b], g[b + 1], g[b + 10], g[b + 11] = blk[33216:33280], blk[33280:33344], blk[33344:33408], blk[33408:33472]
-    g[36], g[37], g[38], g[39] = g1[33472:35520].view(32, 64)[:25], g1[35520:35545], g1[35552:35577], g1[35584:35609]
-    g[0], g[1], g[2], g[3] = g0[33472:37568].view(64, 64)[:, :60], g0[37568:37632], g0[37632:37696], g0[37696:37760]
-    return (None, None, None) + tuple(g)
-
-
 class _TileEncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tiles, te, out_cols, *params):
@@ -1125,15 +1063,6 @@ class _TileEncoderTrain(torch.autograd.Function):
         x = _aligned(tiles.detach().to(torch.bfloat16))
         B = x.shape[0]
         T = B * 19
-        ctx.fused_bwd = te_fused_backward() and weight_images.enabled
-        if ctx.fused_bwd:
-            # the recomputing backward (csrc/catan_te_fused_bwd.hip): the inference kernel + ONE stored activation, the input of layer 1
-            xin1 = torch.empty((T, 64), dtype=torch.bfloat16, device=x.device)
-            out = (torch.empty if out_cols == 475 else torch.zeros)((B, out_cols), dtype=torch.bfloat16, device=x.device)
-            _lib.check(_lib.lib().catan_tile_encoder_fwd_xin1(_ptr(x), _ptr(wts), _ptr(vecs), _ptr(out), out_cols, _ptr(xin1), B, _stream()))
-            ctx.save_for_backward(x, xin1, *params)
-            ctx.B, ctx.lease = B, None
-            return out
         # 3 KB per token = 11 GB at a minibatch's 180 000 boards, and the board count differs from step to step: taken from the
         # caching allocator every step, the slightly different sizes fragment it (reserved memory grew from 100 to 190 GB in three
         # updates).  ONE workspace is kept instead and leased to the forward whose backward has not run yet; a second forward
@@ -1152,10 +1081,6 @@ class _TileEncoderTrain(torch.autograd.Function):
         if ctx.recompute_h:
             drop = drop + ("h",)
             ctx.packed = (wts, vecs)
-        ctx.ends = te_ends_fused()
-        if ctx.ends:
-            drop = drop + ("tiles64", "a0", "p")
-            ctx.tiles = x
         names = [(n, w) for n, w in _TE_SAVES if not (drop and n.startswith(drop))]
         need = T * sum(w for _, w in names)
         lease = _TeWorkspace.lease(need, x.device)
@@ -1185,8 +1110,6 @@ class _TileEncoderTrain(torch.autograd.Function):
             raise RuntimeError("_TileEncoderTrain: second backward over a forward whose activation workspace has been released "
                                "(retain_graph is not supported with the shared workspace; set CATAN_TE_WORKSPACE=0)")
         ctx.consumed = True
-        if ctx.fused_bwd:
-            return _te_fused_backward(ctx, dout)
         ns = len(ctx.save_names)
         sv = dict(zip(ctx.save_names, ctx.saved_tensors[:ns]))
         P = ctx.saved_tensors[ns:]
@@ -1196,17 +1119,10 @@ class _TileEncoderTrain(torch.autograd.Function):
         im = _te_images(ctx.te) if weight_images.enabled else None
         L = _lib.lib()
         with torch.autocast("cuda", enabled=False):
-            if ctx.ends:                        # k_te_bwd_ends<1>: P recomputed, LayerNorm + ReLU backward, dWp / dbp, d(xfin): one pass over xfin and dOut
-                dd = dout if (dout.dtype == bf and dout.is_contiguous()) else dout.to(bf).contiguous()
-                gt = grad_zeros((int(L.catan_te_bwd_ends_grad_floats(1)),), dd.device)
-                dx = torch.empty_like(sv["xfin"])
-                _lib.check(L.catan_tile_encoder_bwd_tail(_ptr(im.wts), _ptr(im.vecs), _ptr(im.wpt32), _ptr(sv["xfin"]), _ptr(dd), dd.shape[1], _ptr(dx), _ptr(gt), B, _stream()))
-                g[36], g[37], g[38], g[39] = gt[:2048].view(32, 64)[:25], gt[2048:2073], gt[2080:2105], gt[2112:2137]
-            else:
-                d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
-                dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
-                dx = _rows_product(dp, im.wpt if im is not None else P[36].to(bf).t().contiguous())   # [T, 64]
-                g[36], g[37] = _wgrad(sv["xfin"], dp, True)
+            d = _aligned(dout[:, :475].reshape(T, 25).to(bf))
+            dp, g[38], g[39] = _ln_backward(sv["p"], P[38], P[39], d, eps, True)
+            dx = _rows_product(dp, im.wpt if im is not None else P[36].to(bf).t().contiguous())   # [T, 64]
+            g[36], g[37] = _wgrad(sv["xfin"], dp, True)
             for l in (1, 0):
                 b = 4 + 16 * l
                 xin, n1, qkv, o, xmid, n2, h = (sv.get(k + str(l)) for k in ("xin", "n1_", "qkv", "o", "xmid", "n2_", "h"))
@@ -1287,14 +1203,9 @@ class _TileEncoderTrain(torch.autograd.Function):
                     lw = P[b].detach().float().contiguous()
                     _lib.check(_lib.lib().catan_qkv_bwd_dx(_ptr(dqkv), _ptr(xin), _ptr(dxmid), _ptr(wqt), _ptr(lw), eps, _ptr(dx), _ptr(dl[0]), _ptr(dl[1]), T, _stream()))
                     g[b], g[b + 1] = dl[0], dl[1]
-            if ctx.ends:                        # k_te_bwd_ends<0>: a0 recomputed from the tile features, LayerNorm + ReLU backward, dW0 / db0
-                gh = grad_zeros((int(L.catan_te_bwd_ends_grad_floats(0)),), dx.device)
-                _lib.check(L.catan_tile_encoder_bwd_head(_ptr(im.wts), _ptr(im.vecs), _ptr(ctx.tiles), _ptr(dx), _ptr(gh), B, _stream()))
-                g[0], g[1], g[2], g[3] = gh[:4096].view(64, 64)[:, :60], gh[4096:4160], gh[4160:4224], gh[4224:4288]
-            else:
-                da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
-                dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
-                g[0] = dw0[:, :60]
+            da0, g[2], g[3] = _ln_backward(sv["a0"], P[2], P[3], dx, eps, True)
+            dw0, g[1] = _wgrad(sv["tiles64"], da0, True)
+            g[0] = dw0[:, :60]
         if ctx.lease is not None:
             ctx.lease.release()
         return (None, None, None) + tuple(g)
@@ -1386,9 +1297,6 @@ def head_sample(head, trunk_dim, pre, cond, mask, deterministic=False, generator
     return action, logp
 
 
-HEADS_ONE_LAUNCH = False     # True: the eighteen evaluations in ONE launch (catan_head_chain_all) - bit-identical, and measured SLOWER at
-                             # 65 536 rows (640 vs 560 us; equal at 4 096-16 384: tools/bench_head_chain.py): an evaluation is ~25 us of
-                             # in-kernel dependent latency whatever the row count, not launch overhead, so nothing is won by removing launches
 HEAD_CHAIN_ORDER = ((0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (6, 0), (11, 0), (4, 0), (9, 0), (10, 0),
                     (7, 0), (7, 1), (7, 2), (7, 3), (8, 0), (8, 1), (8, 2), (8, 3))       # (head, step): the order of the pass's 18 draws
 
@@ -1433,15 +1341,6 @@ def heads_chain(heads, trunk_dim, pre_all, masks, cur_res, trade, deterministic=
             us = [u_all[k] for k in range(len(HEAD_CHAIN_ORDER))]
     custom = head5_custom_pack(heads[5])
     st = _stream()
-    if HEADS_ONE_LAUNCH and pre_all.stride(0) >= 12 * 128 and pre_all.stride(1) == 1 and len({float(h.norm.eps) for h in heads}) == 1:
-        import ctypes as C
-        packs = [head_pack(heads[h], trunk_dim) for h in range(12)]
-        w12 = (C.c_void_p * 12)(*[p[0].data_ptr() for p in packs])
-        v12 = (C.c_void_p * 12)(*[p[1].data_ptr() for p in packs])
-        u18 = None if us is None else (C.c_void_p * len(HEAD_CHAIN_ORDER))(*[u.data_ptr() for u in us])
-        _lib.check(L.catan_head_chain_all(_ptr(pre_all), pre_all.stride(0), w12, v12, float(heads[0].norm.eps), _ptr(masks), _ptr(cur_res), _ptr(trade),
-                                          _ptr(custom), _ptr(forced), u18, _ptr(actions), _ptr(logp), B, st))
-        return actions, logp
     for k, (h, step) in enumerate(HEAD_CHAIN_ORDER):
         wts, vec = head_pack(heads[h], trunk_dim)
         pre = pre_all[:, 128 * h:128 * (h + 1)]

@@ -37,6 +37,7 @@ class FusedAdam(object):
         self._v = [self.exp_avg_sq[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
         self.last_norm = None
         self._tables = None
+        self.copied_grads = 0            # gradients that went through a temporary aligned fp32 copy (expected 0: tests / diagnostics)
 
     # ---- the device tables (built once; rebuilt if a parameter's storage moved)
     def _build_tables(self):
@@ -100,14 +101,18 @@ class FusedAdam(object):
         k = t["slot"] = (t["slot"] + 1) % self.RING
         if t["events"][k] is not None:
             t["events"][k].synchronize()                      # the copy (and the step) that last used this row is done
-        ptrs = []
+        ptrs, keep = [], []
         for p in self.params:
             gr = p.grad
             if gr is None:
                 ptrs.append(0)
                 continue
             if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.data_ptr() % 16:
-                gr = p.grad = gr.float().contiguous().clone()
+                # the kernels read 16-byte vectors of fp32: anything else goes through a temporary copy.  p.grad itself is never replaced
+                # (it may be a view of dist.GradBucket's flat buffer - whose views are 16-byte aligned, so that path does not come here)
+                gr = gr.float().contiguous().clone()
+                keep.append(gr)          # (freed after the launch is queued: the caching allocator keeps it valid for this stream's kernels)
+                self.copied_grads += 1
             ptrs.append(gr.data_ptr())
         t["grads_host_np"][k, :] = ptrs                       # (one numpy assignment: element-wise writes into the tensor were ~300 aten ops per step)
         host = t["grads_host"][k]
@@ -143,7 +148,17 @@ class FusedAdam(object):
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"} | {"params": list(range(len(self.params)))}]}
 
     def load_state_dict(self, sd):
+        # one step counter for all parameters (torch.optim.Adam keeps one per parameter; they only differ there when a parameter had no
+        # gradient in some step - under a multi-rank GradBucket every parameter has one in every step): refuse a checkpoint whose counters
+        # disagree or whose parameter list is not this optimiser's instead of loading something subtly different
+        if len(sd["state"]) not in (0, len(self.params)):
+            raise ValueError(f"FusedAdam.load_state_dict: {len(sd['state'])} parameter states for {len(self.params)} parameters")
+        steps = {int(float(s["step"])) for s in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdam.load_state_dict: per-parameter step counts differ ({sorted(steps)[:4]} ...): not a state this optimiser can continue")
         for i, s in sd["state"].items():
+            if tuple(s["exp_avg"].shape) != tuple(self._m[int(i)].shape):
+                raise ValueError(f"FusedAdam.load_state_dict: state {i} has shape {tuple(s['exp_avg'].shape)}, the parameter {tuple(self._m[int(i)].shape)}")
             self._m[int(i)].copy_(s["exp_avg"]); self._v[int(i)].copy_(s["exp_avg_sq"])
             self.steps = int(float(s["step"]))
         for k in ("lr", "betas", "eps"):

@@ -965,43 +965,6 @@ def test_value_reevaluation_encodes_distinct_boards_only(hip_lib):
         col.after_rollouts()
 
 
-def test_head_chain_in_one_launch_equals_the_eighteen_launches(hip_lib):
-    """catan_head_chain_all (k_heads_all: a workgroup takes its rows through all eighteen head evaluations, the chained state in LDS)
-    against eighteen catan_head_chain launches: the same uniforms give bit-identical actions and joint log-probs - arg-max and sampled,
-    with and without forced types, on a ragged row count and on one that leaves partial tiles."""
-    from settlers_of_catan_rl_amd import policy as P, nn_kernels
-    from settlers_of_catan_rl_amd.env import VecCatanEnv
-    torch.manual_seed(0)
-    for B in (8192 + 5, 300, 49152 + 700):      # (the narrow and the wide configuration of the head kernel: <= / > 49 152 rows)
-        env = VecCatanEnv(B, seed=34); env.random_rollout(0, 1100)
-        f, lists, lens = env.get_obs(); masks = env.get_action_masks(); lens = lens.long()
-        net = P.CatanPolicy().cuda()
-        with torch.no_grad():
-            for p in net.parameters():
-                p.add_(0.05 * torch.randn_like(p))
-        net = net.inference_copy(torch.bfloat16)
-        legal_types = masks[:, :13] > 0
-        forced = torch.where(torch.rand(B, device="cuda") < 0.5, torch.multinomial(legal_types.float(), 1).squeeze(1), torch.full((B,), -1, device="cuda"))
-
-        def act_pass(one_launch, deterministic, cond):
-            nn_kernels.HEADS_ONE_LAUNCH = one_launch
-            try:
-                gg = torch.Generator(device="cuda").manual_seed(7)
-                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-                    return net.act(f, lists, lens, masks, deterministic=deterministic, generator=gg, condition_on_action_type=cond)
-            finally:
-                nn_kernels.HEADS_ONE_LAUNCH = False
-        kinds = set()
-        for deterministic in (True, False):
-            for cond in (None, forced):
-                v1, a1, lp1 = act_pass(True, deterministic, cond)
-                v0, a0, lp0 = act_pass(False, deterministic, cond)
-                assert torch.equal(v1, v0) and torch.equal(a1, a0), (B, deterministic, cond is not None, int((a1 != a0).any(1).sum()))
-                assert torch.equal(lp1, lp0) and torch.isfinite(lp1).all()
-                kinds |= set(a1[:, 0].tolist())
-        assert len(kinds) >= (11 if B > 1000 else 5), kinds
-
-
 def test_chained_heads_equal_the_glued_heads(hip_lib):
     """nn_kernels.heads_chain (the twelve heads' glue inside the fused head kernels: type-conditional mask rows, conditioning
     columns, log-prob masks, the trade heads' lists, condition_on_action_type) against the same kernels with the glue as torch ops:
@@ -1170,8 +1133,6 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
             monkeypatch.setenv("CATAN_TE_BWD_OP", "0" if mode == "fused, out-projection backward in its own kernels" else "1")
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_N", {"fused, LayerNorm outputs stored": "0", "fused, LayerNorm-2 outputs stored": "1"}.get(mode, "2"))
             monkeypatch.setenv("CATAN_TE_RECOMPUTE_H", "1" if mode == "fused, hidden FFN activation recomputed" else "0")
-            monkeypatch.setattr(nn_kernels, "TE_FUSED_BWD", mode == "fused, forward recomputed in the backward")
-            monkeypatch.setattr(nn_kernels, "TE_ENDS_FUSED", mode == "fused, the chain's two ends as one kernel each")
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 assert nn_kernels.tile_encoder_train_supported(te, tiles) == (mode != "unfused")
                 out = te(tiles)
@@ -1196,23 +1157,6 @@ def test_fused_tile_encoder_training_forward_vs_unfused(hip_lib, monkeypatch):
         # backward passes see the same h up to MFMA summation order
         oh, gh = run(tiles, "fused, hidden FFN activation recomputed")
         assert torch.equal(oh, of)
-        # the two ends of the chain as k_te_bwd_ends<1> / <0> (P and a0 recomputed, not stored; off by default: not faster) instead of the
-        # separate LayerNorm / row-product / weight-gradient kernels on stored activations
-        oe, ge = run(tiles, "fused, the chain's two ends as one kernel each")
-        assert torch.equal(oe, of)
-        for n in names:
-            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
-            assert float((gf[n] - ge[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - ge[n]).norm()) / scale)
-        # the backward that recomputes the forward on chip (k_te_bwd_layer<1>, <0>; the training forward stores only the input of layer 1;
-        # off by default: slower, nn_kernels.TE_FUSED_BWD).  Same forward arithmetic: the same output bits; gradients as close to the
-        # sub-layer kernels' as those are to each other
-        orc, grc = run(tiles, "fused, forward recomputed in the backward")
-        assert torch.equal(orc, of)
-        for n in names:
-            scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
-            assert float((gf[n] - grc[n]).norm()) / scale <= 0.02, (B, n, float((gf[n] - grc[n]).norm()) / scale)
-            d_r, d_u = float((grc[n] - g32[n]).norm()) / scale, float((gu[n] - g32[n]).norm()) / scale
-            assert d_r <= max(2.0 * d_u, 0.05), (B, n, d_r, d_u)
         for n in names:
             scale = float(g32[n].norm()) + 1e-3 * max(float(x.norm()) for x in g32.values())
             assert float((gf[n] - gh[n]).norm()) / scale <= 0.01, (B, n, float((gf[n] - gh[n]).norm()) / scale)

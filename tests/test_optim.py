@@ -95,3 +95,27 @@ def test_fused_adam_on_the_policy_net_one_ppo_step(hip_lib):
         theirs.step(); mine.step(0.5)
         assert abs(float(tn) - float(mine.last_norm)) <= 5e-5 * float(tn)
     assert max(float((p - q).abs().max()) for p, q in zip(net.parameters(), ref.parameters())) < 1e-6
+
+
+@pytest.mark.gpu
+def test_fused_adam_reads_the_grad_bucket_views_in_place(hip_lib):
+    """The multi-rank layout on the device: every .grad a view of dist.GradBucket's flat buffer.  The kernels take the views as they are
+    (16-byte aligned by the bucket's padding): no gradient goes through a copy, no .grad is replaced, and the update equals the one on
+    free-standing gradients."""
+    from settlers_of_catan_rl_amd import dist as cdist
+    from settlers_of_catan_rl_amd.policy import CatanPolicy
+    torch.manual_seed(1)
+    net = CatanPolicy().cuda()
+    ref = copy.deepcopy(net)
+    bucket = cdist.GradBucket(net.parameters())
+    mine, theirs = FusedAdam(net.parameters(), lr=3e-4, eps=1e-5), FusedAdam(ref.parameters(), lr=3e-4, eps=1e-5)
+    for s in range(3):
+        bucket.zero()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            gr = torch.randn_like(p) * 0.05
+            p.grad.add_(gr); q.grad = gr
+        mine.step(0.5); theirs.step(0.5)
+        bucket.check()
+    assert mine.copied_grads == 0 and theirs.copied_grads == 0
+    assert all(torch.equal(p, q) for p, q in zip(net.parameters(), ref.parameters()))
+

@@ -40,10 +40,8 @@ def set_wgrad_big(on): nn_kernels.WGRAD_BIG = on
 def set_recompute_h(on): os.environ["CATAN_TE_RECOMPUTE_H"] = "1" if on else "0"      # (read by every tile-encoder forward)
 
 
-def set_te_fused(on): nn_kernels.TE_FUSED_BWD = on
-def set_te_ends(on): nn_kernels.TE_ENDS_FUSED = on
 def set_cat_bits(on): nn_kernels.CATEGORICAL_BITS = on
-SW = {"cat_bits": set_cat_bits, "te_ends": set_te_ends, "te_fused_bwd": set_te_fused, "wgrad_big": set_wgrad_big, "recompute_h": set_recompute_h, "grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred, "recurrent_batched": set_recurrent, "gather_ranges": set_gather_ranges, "fanout_gather": set_fanout, "concat_rows": set_concat}
+SW = {"cat_bits": set_cat_bits, "wgrad_big": set_wgrad_big, "recompute_h": set_recompute_h, "grad_arena": set_arena, "tuned_gemms": set_tuned, "grouped_wgrad": set_grouped, "deferred_wgrad": set_deferred, "recurrent_batched": set_recurrent, "gather_ranges": set_gather_ranges, "fanout_gather": set_fanout, "concat_rows": set_concat}
 if hasattr(pol_mod, "TRUNK_WINDOWS"):
     SW["trunk_windows"] = set_trunk
 
@@ -66,7 +64,7 @@ def run():
     return (t["b"] - t["a"]) / STEPS * 1e3
 
 
-DEFAULT_OFF = {"te_fused_bwd", "recompute_h", "te_ends"}
+DEFAULT_OFF = {"recompute_h"}
 names = [n for n in os.environ.get("SWITCHES", ",".join(SW)).split(",") if n in SW]
 run()                                                   # warm-up (GEMM kernels, arena size)
 for rnd in range(3):
