@@ -39,6 +39,10 @@ ALGO_BYTES = {
     # library at run time (catan_step_algorithmic_bytes).  Rounds 1-3 also read the previous masks (44): validate mode now
     # restates Game.validate_action from the state.
     "k_step": 72 + 44 + 17 + 448 + 160,
+    # the fused-sampling step (the default deferred loop since round 6: no sampler kernel): action + decision counter in from the game's side row
+    # (76), hot record in (448), masks + next action + counter out into the side row (120), reward / done out (17), the ideal write-back (160),
+    # the game's id out of this pass's list and into the next pass's (8).  STEP_FUSED_ALGO_BYTES in csrc/catan_state.h, checked at run time.
+    "k_step_fused": 76 + 448 + 120 + 17 + 160 + 8,
     "k_lr_finish": 0,                               # slow path: priced per REQUEST below (LR_REQUEST_BYTES), not per game
     "k_lr_heavy": 0,
     "k_reset_list": 0,
@@ -280,6 +284,7 @@ def main():
 
     from settlers_of_catan_rl_amd import _lib as _clib
     assert _clib.lib().catan_step_algorithmic_bytes() == ALGO_BYTES["k_step"], "bench.py's byte table and csrc/catan_state.h disagree"
+    assert _clib.lib().catan_step_fused_algorithmic_bytes() == ALGO_BYTES["k_step_fused"], "bench.py's byte table and csrc/catan_state.h disagree"
     env_id0, n = cdist.shard(rank, args.envs)                # global game ids: results do not depend on `world`
     env = VecCatanEnv(n, seed=args.seed, env_id0=env_id0, validate_actions=not args.no_validate, auto_reset=True)
 
@@ -399,10 +404,15 @@ def main():
         slow_launches = prof_steps if args.window <= 0 else -(-prof_steps // args.window)
         launches = {k: (slow_launches if k in ("k_lr_heavy", "k_reset_list") else prof_steps) for k in kms}
         per_launch_us = {k: v * 1e3 / launches[k] for k, v in kms.items() if k in ALGO_BYTES}
-        dom = max(FAST_PATH, key=per_launch_us.get)
+        fused_loop = args.window > 0 and env.deferred_fused   # ONE kernel per pass: k_step<G, true> samples the next action itself
+        fast_path = ("k_step",) if fused_loop else FAST_PATH
+        if fused_loop:
+            per_launch_us.pop("k_sample_random", None)        # (no such kernel in this loop: the slot holds the gap between two event records)
+        algo = dict(ALGO_BYTES, k_step=ALGO_BYTES["k_step_fused"]) if fused_loop else ALGO_BYTES
+        dom = max(fast_path, key=per_launch_us.get)
         active = my_steps / (n * timed_passes)                # games that take a step in a pass (the others are busy)
-        achieved = ALGO_BYTES[dom] * n * active / (per_launch_us[dom] * 1e-6) / 1e9
-        fast_us = sum(per_launch_us[k] for k in FAST_PATH)
+        achieved = algo[dom] * n * active / (per_launch_us[dom] * 1e-6) / 1e9
+        fast_us = sum(per_launch_us[k] for k in fast_path)
         traffic, traffic_src = None, None
         if world == 1 and n == 65536 and not args.no_live_pmc:     # (the counter workload runs the BASELINE size)
             traffic, traffic_src = live_pmc_traffic(dom)
@@ -417,12 +427,12 @@ def main():
             traffic_src = live_note + (f"steady-state PMC of the same kernel, NOT collected in this run: "
                            f"{os.path.relpath(PMC_SUMMARY, ROOT)}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated, "
                            f"65 536 games after the same pre-roll")
-        per_step_bytes = sum(ALGO_BYTES[k] for k in FAST_PATH)
+        per_step_bytes = sum(algo[k] for k in fast_path)
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": dom + ("<G, SAMPLE> (fused-sampling step)" if fused_loop else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_game": ALGO_BYTES[dom],
-            "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n * active,
+            "algorithmic_bytes_per_game": algo[dom],
+            "algorithmic_bytes_per_launch": algo[dom] * n * active,
             "avg_launch_us": per_launch_us[dom],
             "all_kernels_avg_launch_us": per_launch_us,
             "fast_path_algorithmic_bytes_per_game": per_step_bytes,
@@ -462,7 +472,7 @@ def main():
                                     f"summed over the {world} shards"),
                        "games_per_gpu": n, "games_total": world * n, "validate_actions": not args.no_validate,
                        "auto_reset": True, "parallelism": f"games sharded over {world} GPU(s), no collective",
-                       "schedule": (f"deferred, window {args.window}: slow-path games sit out; value = executed env steps / time"
+                       "schedule": (f"deferred, window {args.window}, {'fused-sampling loop (one kernel per pass)' if env.deferred_fused else 'sampler + k_step per pass'}: slow-path games sit out; value = executed env steps / time"
                                     if args.window > 0 else "lock-step: every game steps in every pass"),
                        "timed_region": f"{reps} x --steps passes in one region (>= {MIN_TIMED_S} s), after {max(args.preroll, 64)} "
                                        f"untimed pre-roll passes + --warmup"},

@@ -73,6 +73,22 @@ int64_t catan_num_envs(const catan_env_t* env);
 /* EnvWrapper.reset(): env/wrapper.py:30-34.  reset_mask (uint8[n], device) selects games; NULL = all. */
 int catan_reset(catan_env_t* env, const uint8_t* reset_mask, catan_stream_t stream);
 
+/* RNG contract (A) of SURVEY.md 8.4 for a SINGLE-GAME handle (n_envs == 1; CATAN_EINVAL otherwise): from this call on the game draws from the
+ * reference's two process-global Mersenne Twisters instead of its Philox stream - np.random.shuffle / np.random.randint (game/components/board.py:72-84,
+ * game/game.py:42,77,139-140) from an MT19937 seeded as np.random.seed(numpy_seed) does (init_genrand, masked rejection on the low bits),
+ * random.choice of the steal (game/game.py:643) from an MT19937 seeded as random.seed(python_seed) does (init_by_array, the TOP bits of an output).
+ * Both generators live in device memory and are advanced by the library's kernels; nothing is drawn on the host.  The game itself is not touched:
+ * what the reference's `np.random.seed(s); random.seed(s); env = EnvWrapper(); env.reset()` draws is catan_reset_board_only (the Board() constructor,
+ * board.py:47), catan_reset (Game.__init__ -> reset, game.py:40) and catan_reset again (EnvWrapper.reset, env/wrapper.py:30-34).
+ * catan_mt19937_set_state installs a generator's full state instead (which: 0 = numpy's, 1 = `random`'s; key[624], pos in 0..624: the tuples
+ * np.random.get_state() / random.getstate() return).  Lock-step entry points only: the deferred calls, the deferred rollouts and
+ * catan_randomise_uncertainty return CATAN_EINVAL for such a handle (the oracle has no MT form of randomise_uncertainty to pin one against);
+ * catan_state_import does not rewind the generators (the reference's restore_state does not either). */
+int catan_seed_mt19937(catan_env_t* env, uint32_t numpy_seed, uint32_t python_seed, catan_stream_t stream);
+int catan_mt19937_set_state(catan_env_t* env, int32_t which, const uint32_t* key624, int32_t pos, catan_stream_t stream);
+/* Board.reset alone (game/components/board.py:67-100): takes its draws; the game must be reset afterwards (see above). */
+int catan_reset_board_only(catan_env_t* env, catan_stream_t stream);
+
 /* EnvWrapper.step(action): env/wrapper.py:36-50 (translate + apply + done/reward); then, per cfg, auto-reset of
  * (a game whose action type is negative is left untouched: explicit no-op, reward 0, done 0)
  * finished games; then the next legal-action masks are refreshed (kept packed inside the handle). */

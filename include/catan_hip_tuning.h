@@ -45,8 +45,9 @@ int catan_calib_copy(void* dst, const void* src, int64_t bytes, catan_stream_t s
 int catan_profile_enable(catan_env_t* env, int on);
 int catan_profile_read(catan_env_t* env, uint64_t* out16);
 /* catan_profile_enable(env, 2): contention-free variant for k_step - every wave stores its own phase durations of the LAST
- * launch; out: HOST uint32 [ceil(n/256)*4 + 17][8] (slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = sort bin + 1: bins
- * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort) */
+ * launch; out: HOST uint32 [max(ceil(n/256)*16 + 17, 7128)][8] (k_step's waves first - slots 0,1,2,6,7 as above in 100 MHz ticks, slot 5 = sort bin + 1: bins
+ * 0..12 = action types, 13..16 = play_dev with card 1..4; 17 = one partial wave per bin of the sort; rows 4128.. / 6128..: k_lr_finish's requests / k_lr_heavy's
+ * workgroups of the last launch at 65 536 games) */
 int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
 /* catan_profile_enable(env, 3): as 2, but slot 2 = the wave's START time (low 32 bits of the 100 MHz wall clock at entry; the
  * phases 0, 1, 6, 7 follow it back to back) and slot 3 = where the wave ran (HW_REG_HW_ID bits 0..27 | HW_REG_XCC_ID << 28):
@@ -55,12 +56,15 @@ int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
 /* Algorithmic HBM bytes of one fused env step per stepped game, from the static_assert-ed layout constants of csrc/catan_state.h
  * (action row in, hot record in, masks + reward + done out, the ideal write-back): bench.py's roofline numerator. */
 int32_t catan_step_algorithmic_bytes(void);
+/* ... and of the fused-sampling step (the game's action and decision counter out of its side row, the next action and the new masks back into it) */
+int32_t catan_step_fused_algorithmic_bytes(void);
 /* Which form of the deferred rollout loop catan_random_rollout_deferred runs (results are identical, game for game):
- *   0 (default)  a sampling + sorting kernel in front of every k_step (rounds 1-3)
- *   1            fused sampling (round 4): k_step draws each completed game's next action into its side row and enqueues it for
- *                the next pass; tier 1 forks once per two passes.  Measured at parity: the pass is bound by the
- *                SIMD time of k_step + the path searches, not by the launches on the main stream. */
+ *   1 (default since round 6)  fused sampling: k_step draws each completed game's next action into its side row and appends the game to the next
+ *                pass's lists (per bin CATAN_FUSED_SUBS sub-lists with a counter each, so that the launch's waves do not queue up on one address);
+ *                ONE kernel per pass on the main stream, tier 1 forks once per two passes
+ *   0            a sampling + sorting kernel in front of every k_step (rounds 1-5) */
 int catan_set_deferred_fused(catan_env_t* env, int32_t on);
+int32_t catan_deferred_fused(const catan_env_t* env);
 
 /* Environment switches read at catan_create (A/B diagnostics of the schedules; results never depend on them; defaults are the measured best,
  * DESIGN.md 4.0 / profiles/r05_s5_pass_experiments.txt):
@@ -71,7 +75,10 @@ int catan_set_deferred_fused(catan_env_t* env, int32_t on);
  *   CATAN_T1_DEPTH=2              ... then with two rotating tier-1 slots instead of three
  *   CATAN_LR_SPLIT=0 | 2          tier 1 as search + lane-per-game completion never / in every schedule (default: where a launch has two passes)
  *   CATAN_LR_GRID=g               workgroups of k_lr_finish (default 4 096 inside a lock-step step, 3 072 in the deferred schedules)
- *   CATAN_STEP_WAVES_PER_BLOCK=4  four-wave k_step workgroups;  CATAN_STEP_WAVE_GAMES, CATAN_DEFERRED_FUSED: as the setters above */
+ *   CATAN_STEP_WAVES_PER_BLOCK=4  four-wave k_step workgroups;  CATAN_STEP_WAVE_GAMES, CATAN_DEFERRED_FUSED: as the setters above
+ *   CATAN_FUSED_SUBS=s            sub-lists per sort bin in the fused-sampling loop: 1, 2, 4, 8 (default) or 16
+ *   CATAN_DEBUG_FUSED_CLOSE_UNORDERED=1, CATAN_DEBUG_STEP_DELAY_US=k   the fused loop's window close as it was ordered until round 6 / the closing pass's
+ *                                 k_step k microseconds late: reproduce the round-5 parity failures at will (tools/fused_close_race.py; these two DO change results) */
 
 #ifdef __cplusplus
 }

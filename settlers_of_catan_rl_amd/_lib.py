@@ -195,6 +195,9 @@ _SIGS = {
     "catan_last_error": (C.c_char_p, []),
     "catan_num_envs": (C.c_int64, [_vp]),
     "catan_reset": (C.c_int, [_vp, _vp, _vp]),
+    "catan_reset_board_only": (C.c_int, [_vp, _vp]),
+    "catan_seed_mt19937": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "catan_mt19937_set_state": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp]),
     "catan_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "catan_step_deferred": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "catan_step_flush": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -257,6 +260,8 @@ _SIGS = {
     "catan_set_lr_budgets": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "catan_set_deferred_fused": (C.c_int, [_vp, C.c_int32]),
     "catan_step_algorithmic_bytes": (C.c_int32, []),
+    "catan_step_fused_algorithmic_bytes": (C.c_int32, []),
+    "catan_deferred_fused": (C.c_int32, [_vp]),
     "catan_set_step_wave_games": (C.c_int, [_vp, C.c_int32]),
     "catan_set_lr_rounds": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "catan_slow_path_counts": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),

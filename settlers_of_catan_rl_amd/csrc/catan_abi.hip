@@ -73,6 +73,7 @@ struct catan_env {
     int64_t d_it;         // calls since the last flush (0: no deferred sequence is open)
     int d_window;         // its window length
     hipStream_t d_stream; // ... and the caller's stream (one stream per sequence)
+    MtPair* mt_dev;       // RNG contract (A): the handle's two MT19937 generators on the device (catan_seed_mt19937), else NULL
 };
 
 // games per k_step wave (catan_set_step_wave_games).  32 since the end of round 5: two waves per SIMD, so that one wave's gather overlaps the other's
@@ -406,7 +407,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.spec, (size_t)e->N * sizeof(u64));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pend.busy, (size_t)e->N);
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->pctr, (size_t)e->N * sizeof(u32));
-    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)(e->N / 16 + SORT_PAD_WAVES) * 8 * sizeof(u32));
+    if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof_wave, (size_t)prof_wave_rows(e->N) * 8 * sizeof(u32));
     if (rc == hipSuccess) rc = hipMalloc((void**)&e->prof, PROF_WORDS * sizeof(unsigned long long));
     if (rc != hipSuccess) { catan_destroy(e); return fail(CATAN_ENOMEM, std::string("catan_create: hipMalloc: ") + hipGetErrorString(rc)); }
     HIPCHK(hipMemset(e->state, 0, bytes));
@@ -420,6 +421,9 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
+    // the fused-sampling loop is the library's own deferred loop since round 6 (one kernel per pass on the main stream; with per-bin sub-lists,
+    // 32-game waves and the middle tier: 38.9 us per pass against 41.4 for sampler + k_step, profiles/r06_fused_loop_ab.txt); CATAN_DEFERRED_FUSED=0: the sampler form
+    e->deferred_fused = 1;
     if (const char* df = getenv("CATAN_DEFERRED_FUSED")) e->deferred_fused = atoi(df) != 0;
     // one-wave workgroups by default.  Four waves per workgroup (CATAN_STEP_WAVES_PER_BLOCK=4: one 116 KB workgroup per CU, a SIMD per wave) was
     // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
@@ -490,6 +494,7 @@ void catan_destroy(catan_env_t* e) {
     if (e->s_done) hipFree(e->s_done);
     if (e->pend.lists) hipFree(e->pend.lists);
     if (e->pend.bctr) hipFree(e->pend.bctr);
+    if (e->mt_dev) hipFree(e->mt_dev);
     if (e->side) hipStreamDestroy(e->side);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -506,12 +511,87 @@ void catan_destroy(catan_env_t* e) {
 
 static int deferred_open_error(const catan_env_t* e, const char* what);
 #define NOT_DEFERRED(e, what) do { int r_ = deferred_open_error(e, what); if (r_ != CATAN_OK) return r_; } while (0)
+// contract (A): the generators' output rings topped up in front of a kernel that may draw
+static int mt_refill(catan_env_t* e, hipStream_t st) {
+    if (e->ctx.mt == nullptr) return CATAN_OK;
+    hipLaunchKernelGGL(k_mt_refill, dim3(1), dim3(64), 0, st, e->ctx);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+#define NOT_MT(e, what) do { if ((e)->ctx.mt != nullptr) return fail(CATAN_EINVAL, std::string(what) + ": not available for a handle under the MT19937 contract (catan_seed_mt19937)"); } while (0)
 int catan_reset(catan_env_t* e, const uint8_t* reset_mask, catan_stream_t stream) {
     if (!e) return fail(CATAN_EINVAL, "catan_reset: null handle");
     NOT_DEFERRED(e, "catan_reset");
-    hipLaunchKernelGGL(k_reset, dim3((unsigned)(e->N < 16384 ? e->N : 16384)), dim3(64), 0, S(stream), e->ctx, reset_mask);
+    int r = mt_refill(e, S(stream));
+    if (r != CATAN_OK) return r;
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)(e->N < 16384 ? e->N : 16384)), dim3(64), 0, S(stream), e->ctx, reset_mask, 0);
     HIPCHK(hipGetLastError());
     return launch_masks(e, S(stream));
+}
+int catan_reset_board_only(catan_env_t* e, catan_stream_t stream) {
+    if (!e) return fail(CATAN_EINVAL, "catan_reset_board_only: null handle");
+    NOT_DEFERRED(e, "catan_reset_board_only");
+    int r = mt_refill(e, S(stream));
+    if (r != CATAN_OK) return r;
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)(e->N < 16384 ? e->N : 16384)), dim3(64), 0, S(stream), e->ctx, (const u8*)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    return CATAN_OK;
+}
+
+// ---- RNG contract (A): MT19937 as numpy (init_genrand) and CPython (init_by_array with a one-word key) seed it; the outputs are generated on the
+// device (k_mt_refill), here only the 624-word start states
+static void mt_host_init_genrand(uint32_t* mt, uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+static void mt_host_init_by_array(uint32_t* mt, const uint32_t* key, int klen) {
+    mt_host_init_genrand(mt, 19650218u);
+    int i = 1, j = 0;
+    for (int k = 624 > klen ? 624 : klen; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+// installs generator `which` (its 624 state words and position) with an empty output ring; the consumers' positions restart at 0
+static int mt_install(catan_env_t* e, int which, const uint32_t* key, int pos, hipStream_t st) {
+    if (e->n != 1) return fail(CATAN_EINVAL, "MT19937 contract: a single-game handle only (the reference's generators are process-global: SURVEY.md 8.4)");
+    if (e->d_it > 0) return fail(CATAN_EINVAL, "MT19937 contract: a deferred step sequence is open");
+    if (!e->mt_dev) {
+        HIPCHK(hipMalloc((void**)&e->mt_dev, sizeof(MtPair)));
+        HIPCHK(hipMemset(e->mt_dev, 0, sizeof(MtPair)));
+        // (an uninstalled generator: position 624 of an all-zero state; both are installed by catan_seed_mt19937)
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    MtGen* g = which == 0 ? &e->mt_dev->np : &e->mt_dev->py;
+    uint32_t head[626];
+    memcpy(head, key, 624 * sizeof(uint32_t));
+    head[624] = (uint32_t)pos; head[625] = 0u;                 // idx, produced
+    HIPCHK(hipMemcpy(g, head, sizeof head, hipMemcpyHostToDevice));
+    if (which == 0) HIPCHK(hipMemset(e->ctx.R + W_RNG, 0, sizeof(u32)));           // the numpy stream's position = the game's draw counter
+    else HIPCHK(hipMemset(&e->mt_dev->cons_py, 0, sizeof(u32)));
+    e->ctx.mt = e->mt_dev;
+    return CATAN_OK;
+}
+int catan_seed_mt19937(catan_env_t* e, uint32_t numpy_seed, uint32_t python_seed, catan_stream_t stream) {
+    if (!e) return fail(CATAN_EINVAL, "catan_seed_mt19937: null handle");
+    uint32_t mt[624];
+    mt_host_init_genrand(mt, numpy_seed);                      // np.random.seed(int)
+    int r = mt_install(e, 0, mt, 624, S(stream));
+    if (r != CATAN_OK) return r;
+    mt_host_init_by_array(mt, &python_seed, 1);                // random.seed(int), int < 2**32
+    return mt_install(e, 1, mt, 624, S(stream));
+}
+int catan_mt19937_set_state(catan_env_t* e, int32_t which, const uint32_t* key624, int32_t pos, catan_stream_t stream) {
+    if (!e || !key624 || (which != 0 && which != 1) || pos < 0 || pos > 624) return fail(CATAN_EINVAL, "catan_mt19937_set_state: bad arguments");
+    return mt_install(e, which, key624, pos, S(stream));
 }
 
 static StepCfg step_cfg(const catan_env_t* e) {
@@ -656,6 +736,7 @@ constexpr int EV_PER_STEP = 10;
 static int step_impl(catan_env_t* e, int32_t* actions, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev = nullptr,
                      const uint32_t* sample_step = nullptr) {
     e->pend.fa = 0; e->pend.ftag = 1; e->pend.sa = 0; e->pend.stag = 1; e->pend.sample = 0; e->pend.brel = -1; e->pend.nsub = 1;
+    { int rr = mt_refill(e, st); if (rr != CATAN_OK) return rr; }
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
     // the step's first kernel zeroes the slow-path list counters (ctr[4..15]) and k_step the count set of the NEXT sort, so a
     // memset is only needed after anything else used the counters (creation, a deferred rollout)
@@ -968,7 +1049,9 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         hipStream_t fs = t1_serial ? st : e->fstream[ga];
         HIPCHK(hipEventRecord(e->ev_fready[ga], st));
         HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[ga], 0));
-        r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[1], P == 2);
+        // (search + lane-per-game completion only with CATAN_LR_SPLIT=2: measured 41.0 us per pass with the split against 38.9 without - here the
+        // completion kernel samples and enqueues lane per game with one atomic each, and tier 1's launches are not what bounds this loop)
+        r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[1], false);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_fdone[ga], fs));
     }
@@ -1004,6 +1087,7 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
 int catan_random_rollout_deferred(catan_env_t* e, int64_t iters, int32_t window, catan_stream_t stream) {
     if (!e || iters < 0 || window <= 0) return fail(CATAN_EINVAL, "catan_random_rollout_deferred: bad arguments");
     NOT_DEFERRED(e, "catan_random_rollout_deferred");
+    NOT_MT(e, "catan_random_rollout_deferred");
     for (int64_t it = 0; it < iters; it++) {
         int r = deferred_iter(e, it, iters, window, S(stream), nullptr);
         if (r != CATAN_OK) return r;
@@ -1022,6 +1106,7 @@ static int deferred_open_error(const catan_env_t* e, const char* what) {
 }
 int catan_step_deferred(catan_env_t* e, const int32_t* actions, int32_t window, float* reward, uint8_t* done, uint8_t* status, catan_stream_t stream) {
     if (!e || !actions || !reward || !done || !status || window <= 0) return fail(CATAN_EINVAL, "catan_step_deferred: bad arguments");
+    NOT_MT(e, "catan_step_deferred");
     hipStream_t st = S(stream);
     if (e->d_it > 0 && (window != e->d_window || st != e->d_stream))
         return fail(CATAN_EINVAL, "catan_step_deferred: window and stream must stay the same between two flushes");
@@ -1111,6 +1196,8 @@ int catan_set_step_wave_games(catan_env_t* e, int32_t games) {
 }
 
 int32_t catan_step_algorithmic_bytes(void) { return STEP_ALGO_BYTES; }
+int32_t catan_step_fused_algorithmic_bytes(void) { return STEP_FUSED_ALGO_BYTES; }
+int32_t catan_deferred_fused(const catan_env_t* e) { return e ? e->deferred_fused : -1; }
 int catan_set_deferred_fused(catan_env_t* e, int32_t on) {
     if (!e) return fail(CATAN_EINVAL, "catan_set_deferred_fused: null handle");
     e->deferred_fused = on != 0;
@@ -1142,6 +1229,7 @@ int catan_set_lr_rounds(catan_env_t* e, int32_t lockstep, int32_t deferred) {
 // its games)  [4] re-deals / installs (k_reset_list, k_install_list).
 int catan_random_rollout_timed(catan_env_t* e, uint32_t step_idx0, int64_t steps, int32_t window, catan_stream_t stream, float* kernel_ms) {
     if (!e || steps <= 0 || !kernel_ms) return fail(CATAN_EINVAL, "catan_random_rollout_timed: bad arguments");
+    if (window > 0) NOT_MT(e, "catan_random_rollout_timed (deferred)");
     hipStream_t st = S(stream);
     const int K = EV_PER_STEP;             // see enqueue_fast / enqueue_tier1 / enqueue_slow; [5] = before the sampler
     std::vector<hipEvent_t> ev((size_t)steps * K);
@@ -1688,6 +1776,7 @@ int catan_head_chain(const void* pre, int64_t pre_ld, const void* wts, const flo
 int catan_randomise_uncertainty(catan_env_t* e, const int32_t* controlling_player, catan_stream_t stream) {
     if (!e || !controlling_player) return fail(CATAN_EINVAL, "catan_randomise_uncertainty: null argument");
     NOT_DEFERRED(e, "catan_randomise_uncertainty");
+    NOT_MT(e, "catan_randomise_uncertainty");
     hipLaunchKernelGGL(k_randomise_uncertainty, dim3(blocks(e->n, 64)), dim3(64), 0, S(stream), e->ctx, controlling_player, e->mpk, e->err,
                        100000, limits_of(e));
     HIPCHK(hipGetLastError());
@@ -1902,7 +1991,7 @@ int catan_profile_enable(catan_env_t* e, int on) {
 int catan_profile_read_waves(catan_env_t* e, uint32_t* out) {
     if (!e || !out) return fail(CATAN_EINVAL, "catan_profile_read_waves: bad arguments");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)(e->N / 16 + SORT_PAD_WAVES) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, e->prof_wave, (size_t)prof_wave_rows(e->N) * 8 * sizeof(u32), hipMemcpyDeviceToHost));
     return CATAN_OK;
 }
 int catan_profile_read(catan_env_t* e, uint64_t* out16) {

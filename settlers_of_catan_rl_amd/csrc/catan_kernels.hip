@@ -39,12 +39,23 @@ constexpr int BLOCK = 256;
 constexpr u64 ALL54 = (1ull << 54) - 1;
 
 // ------------------------------------------------------------------------------------------------ state view
+// RNG contract (A) on the device (single-game handles, catan_seed_mt19937): the two process-global Mersenne Twisters of the
+// reference - numpy's legacy RandomState behind np.random.shuffle / randint, CPython's `random` behind random.choice - as two MT19937
+// generators in device memory.  Each keeps the last MT_RING of its outputs: draw number d of a stream is ring[d % MT_RING], valid from the
+// consumer's position up to `produced` (k_mt_refill runs in front of every kernel that may draw and keeps MT_AHEAD outputs ahead), so the
+// kernels read "the value of draw d" exactly as they compute it from the Philox counter under contract (B) - including the re-deal's
+// look-ahead over the next 1 536 draws.  The numpy stream's position is the game's own draw counter (record word W_RNG; a speculative
+// re-deal that is not taken does not move it), the `random` stream's position is cons_py.
+constexpr int MT_RING = 8192, MT_AHEAD = 6144, MT_AHEAD_PY = 1024;
+struct MtGen { u32 mt[624]; u32 idx; u32 produced; u32 ring[MT_RING]; };
+struct MtPair { MtGen np, py; u32 cons_py; };
 struct Ctx {          // launch-invariant handle fields
     u32* R;           // game records, REC words each
     long N;           // padded number of games (row pitch)
     long n;           // real number of games
     u32 key0, key1;   // philox key = seed
     u64 env_id0;      // global id of game 0 (multi-GPU shards keep their global ids)
+    MtPair* mt;       // contract (A): the handle's two MT19937 generators (n == 1), or null = contract (B), per-game Philox streams
 };
 
 // Derived helpers shared by the two state views (CRTP).
@@ -286,11 +297,19 @@ DEVI void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&ou
 struct Rng {
     u32 k0, k1, e0, e1, draws;
     u32 blk_idx, o0, o1, o2, o3;      // cached philox block (4 draws per block)
+    const u32* ring;                  // contract (A): the numpy-side MT19937 stream's output ring (draw d = ring[d % MT_RING]); null: Philox
+    // the four draws 4 bi .. 4 bi + 3 of the game's stream
+    DEVI void block(u32 bi, u32 (&o)[4]) const {
+        if (ring != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = ring[(4u * bi + (u32)i) & (u32)(MT_RING - 1)];
+        } else philox4x32_10(bi, 0u, e0, e1, k0, k1, o);
+    }
     DEVI u32 next() {
         const u32 bi = draws >> 2;
         if (bi != blk_idx) {
             u32 o[4];
-            philox4x32_10(bi, 0u, e0, e1, k0, k1, o);
+            block(bi, o);
             o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3]; blk_idx = bi;
         }
         const u32 sel = draws & 3;
@@ -311,7 +330,30 @@ DEVI Rng rng_load(const Ctx& c, const S& s) {
     Rng r;
     u64 id = c.env_id0 + (u64)s.e;
     r.k0 = c.key0; r.k1 = c.key1; r.e0 = (u32)id; r.e1 = (u32)(id >> 32); r.draws = s.w(W_RNG); r.blk_idx = 0xFFFFFFFFu; r.o0 = r.o1 = r.o2 = r.o3 = 0;
+    r.ring = c.mt != nullptr ? c.mt->np.ring : nullptr;
     return r;
+}
+// random.choice(seq) under contract (A): CPython's _randbelow_with_getrandbits - k = n.bit_length(), the TOP k bits of one output of the
+// `random` module's generator, redrawn while >= n
+DEVI int mt_choice_index(MtPair* m, int n) {
+    const int k = 32 - __clz(n);
+    u32 d = m->cons_py, r;
+    do { r = m->py.ring[d++ & (u32)(MT_RING - 1)] >> (32 - k); } while ((int)r >= n);
+    m->cons_py = d;
+    return (int)r;
+}
+// MT19937 (Matsumoto & Nishimura 1998): one output of generator g
+DEVI u32 mt_next(MtGen& g) {
+    if (g.idx >= 624u) {
+        for (int kk = 0; kk < 624; kk++) {
+            const u32 y = (g.mt[kk] & 0x80000000u) | (g.mt[(kk + 1) % 624] & 0x7fffffffu);
+            g.mt[kk] = g.mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g.idx = 0;
+    }
+    u32 y = g.mt[g.idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
 }
 
 // ------------------------------------------------------------------------------------------------ estimates
@@ -933,7 +975,7 @@ DEVI bool reset_tokens_parallel(ResetScratch& sc, int lane) {
     return false;
 }
 template <class S>
-DEVI void reset_part2(const S& s, RngBuf& rng, ResetScratch& sc, bool tokens_done) {   // lane 0
+DEVI void reset_part2(const S& s, RngBuf& rng, ResetScratch& sc, bool tokens_done, bool board_only = false) {   // lane 0
     u8* arr = sc.arr; u8* terr = sc.terr;
     // tile terrains in registers, indexed by constants below
     int tr[19];
@@ -969,6 +1011,9 @@ DEVI void reset_part2(const S& s, RngBuf& rng, ResetScratch& sc, bool tokens_don
     for (int i = 0; i < 9; i++) arr[i] = (u8)i;
     shuffle_bytes(arr, 9, rng);                                // board.py:84
     for (int i = 0; i < 9; i++) s.sb(B_HARB + i, arr[i]);
+    // Board.reset alone (the Board() constructor, board.py:47, which runs before Game.reset deals for the first time): its draws are taken,
+    // the record is not a game yet - the caller resets again (catan_reset_board_only)
+    if (board_only) { s.sw(W_RNG, rng.slow.draws); return; }
     for (int i = 0; i < 4; i++) arr[i] = (u8)i;                // game.py:41
     shuffle_bytes(arr, 4, rng);                                // game.py:42
     {
@@ -1520,7 +1565,7 @@ DEVI int roll_dice(const S& s, Rng& rng, int order, int seatof, const u64* tct, 
         u64 vals = 0;
         auto take = [&](int k) {
             u32 o[4];
-            philox4x32_10(b0 + (u32)k, 0u, rng.e0, rng.e1, rng.k0, rng.k1, o);
+            rng.block(b0 + (u32)k, o);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const u32 v = o[i] & 7u;
@@ -1683,8 +1728,10 @@ struct StepCfg { int validate; int dense_reward; double win_reward; double annea
                  int prof_timeline;
                  int bin_order; };              // k_step: bins laid over the waves in BIN_ORDER_LPT order (0: in bin order)          // ... with slot 2 = the wave's START (low 32 bits of the 100 MHz wall clock) and slot 3 = where it ran
                                                 //     (HW_ID | XCC_ID << 28) instead of the request-push time and the validate / switch split
-constexpr int LRF_PROF_ROW = 1088, LRF_PROF_ROWS = 2000;   // k_lr_finish's rows of the per-wave buffer ((N / 16 + SORT_PAD_WAVES) rows)
-constexpr int LRH_PROF_ROW = 3088, LRH_PROF_ROWS = 1000;   // k_lr_heavy's: one row per workgroup (its first request)
+// the per-wave profile buffer: PROF_WAVE_ROWS(N) rows of 8 words - k_step's waves (up to N / 16 + 17 at 16 games per wave), then at N = 65 536:
+constexpr int LRF_PROF_ROW = 4128, LRF_PROF_ROWS = 2000;   // k_lr_finish's rows (one request per workgroup)
+constexpr int LRH_PROF_ROW = 6128, LRH_PROF_ROWS = 1000;   // k_lr_heavy's: one row per workgroup (its first request)
+constexpr long prof_wave_rows(long N) { return (N / 16 + 17 > LRH_PROF_ROW + LRH_PROF_ROWS) ? N / 16 + 17 : LRH_PROF_ROW + LRH_PROF_ROWS; }
 constexpr int PROF_PHASES = 8;    // k_step: 0 stage-in, 1 validate+apply, 2 request push, 6 holder+done/reward+masks, 7 write-back;
                                   // k_reset_list: 3 philox draws per re-deal, 4 re-deals, 5 serial shuffle time
 constexpr int PROF_TOTAL = 2 * PROF_PHASES + 4;   // then 14 sums, 14 counts, 14 maxima of validate+apply per action type
@@ -2184,9 +2231,13 @@ __global__ __launch_bounds__(64 * WPB) void k_step(Ctx c, const i32* __restrict_
         int victim = player_at_label(order, seatof, pid, a[6]);
         int n = s.total(victim);
         if (n > 0) {
-            Rng rng = rng_load(c, s);
-            int k = (int)rng.bounded((u32)(n - 1));
-            s.sw(W_RNG, rng.draws);
+            int k;
+            if (c.mt != nullptr) k = mt_choice_index(c.mt, n);             // contract (A): random.choice on the `random` module's generator
+            else {
+                Rng rng = rng_load(c, s);
+                k = (int)rng.bounded((u32)(n - 1));
+                s.sw(W_RNG, rng.draws);
+            }
             const int ord[5] = { R_BRICK, R_WHEAT, R_WOOD, R_SHEEP, R_ORE };   // game.py:638
             int r0 = 0;
             bool found = false;
@@ -2792,7 +2843,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish_rollout(Ctx c, const u32* __re
 // dstR != nullptr: a SPECULATIVE re-deal - the fresh record (and its masks, through `mpk`) go to the shadow arrays, the game
 // itself is only read (its stream position).  k_install_list copies the shadow over the game if the game did end.
 DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int lane, u32* __restrict__ mpk, Limits lim, u8* busy,
-                           unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr, const Pending* pend = nullptr) {
+                           unsigned long long* prof = nullptr, u32* __restrict__ dstR = nullptr, const Pending* pend = nullptr, bool board_only = false) {
     u32* const outR = dstR ? dstR : c.R;
     __builtin_amdgcn_wave_barrier();
     if (lane < ROWS_HOT / 4) reinterpret_cast<uint4*>(rec)[lane] = reinterpret_cast<const uint4*>(c.R + e * REC)[lane];
@@ -2803,7 +2854,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
 #pragma unroll
     for (int b = 0; b < RND_WORDS / 256; b++) {
         u32 o[4];
-        philox4x32_10(blk0 + b * 64 + lane, 0u, mine.e0, mine.e1, c.key0, c.key1, o);
+        mine.block(blk0 + b * 64 + lane, o);
         const int at = (b * 64 + lane) * 4;
         sc.rnd[at] = o[0]; sc.rnd[at + 1] = o[1]; sc.rnd[at + 2] = o[2]; sc.rnd[at + 3] = o[3];
     }
@@ -2817,7 +2868,7 @@ DEVI void wave_reset_game(const Ctx& c, long e, u32* rec, ResetScratch& sc, int 
     const bool tokens_done = reset_tokens_parallel(sc, lane);
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        reset_part2(s, rb, sc, tokens_done);
+        reset_part2(s, rb, sc, tokens_done, board_only);
         if (prof) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
             atomicAdd(&prof[5], dt); atomicMax(&prof[PROF_PHASES + 5], dt);
@@ -2880,13 +2931,22 @@ __global__ __launch_bounds__(64) void k_install_list(Ctx c, u32* __restrict__ mp
     }
 }
 // catan_reset: every game (sel == nullptr) or the selected ones.
-__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel) {
+__global__ __launch_bounds__(64) void k_reset(Ctx c, const u8* __restrict__ sel, int board_only) {
     __shared__ __attribute__((aligned(16))) u32 rec[ROWS_HOT];
     __shared__ ResetScratch sc;
     for (long e = blockIdx.x; e < c.N; e += gridDim.x) {
         if (sel != nullptr && (e >= c.n || sel[e] == 0)) continue;
-        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, Limits{ -1, -1 }, nullptr);
+        wave_reset_game(c, e, rec, sc, threadIdx.x, nullptr, Limits{ -1, -1 }, nullptr, nullptr, nullptr, nullptr, board_only != 0);
     }
+}
+// Contract (A): tops the two generators' output rings up to MT_AHEAD / MT_AHEAD_PY draws beyond the consumers' positions (the game's W_RNG,
+// cons_py).  One lane: MT19937 is serial, and a handle under this contract holds ONE game (a step draws 0-3 words, a re-deal ~250).
+__global__ __launch_bounds__(64) void k_mt_refill(Ctx c) {
+    if (threadIdx.x != 0 || c.mt == nullptr) return;
+    MtPair& m = *c.mt;
+    const u32 want_np = c.R[W_RNG] + (u32)MT_AHEAD, want_py = m.cons_py + (u32)MT_AHEAD_PY;
+    while ((int)(want_np - m.np.produced) > 0) { m.np.ring[m.np.produced & (u32)(MT_RING - 1)] = mt_next(m.np); m.np.produced++; }
+    while ((int)(want_py - m.py.produced) > 0) { m.py.ring[m.py.produced & (u32)(MT_RING - 1)] = mt_next(m.py); m.py.produced++; }
 }
 
 // ------------------------------------------------------------------------------------------------ sort by action type
@@ -3309,7 +3369,7 @@ __global__ __launch_bounds__(BLOCK) void k_import(Ctx c, const long* __restrict_
     for (int p = 0; p < 4; p++) s.spb(p, P_ARMY, in.get());
     for (int p = 0; p < 4; p++) s.sb(B_CURVP + p, in.get());
     s.sb(B_WINNER, in.get());
-    s.sw(W_RNG, (u32)in.get());
+    { const u32 draws = (u32)in.get(); if (c.mt == nullptr) s.sw(W_RNG, draws); }    // (contract (A): the generators are the handle's, a restored game does not rewind them - as in the reference)
     LrCache lc;                    // nothing is known about the longest paths of an imported position
     lc.load(s.P);
     lc.invalidate_all();

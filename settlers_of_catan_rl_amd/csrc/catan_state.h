@@ -119,6 +119,11 @@ constexpr int IDEAL_WRITEBACK_WORDS = 3 + WB_CONTROL_WORDS + 2 * WB_PLAYER_WORDS
 constexpr int STEP_ALGO_BYTES = ACTION_WORDS_C * 4 + ROWS_HOT * 4 + 11 * 4 + 17 + IDEAL_WRITEBACK_WORDS * 4;
 static_assert(WB_CONTROL_WORDS == 12 && WB_PLAYER_WORDS == 7 && IDEAL_WRITEBACK_WORDS == 40 && STEP_ALGO_BYTES == 741,
               "restate bench.py / DESIGN.md 6 when the layout changes (round 4: the step no longer reads its previous masks: 785 -> 741)");
+// ... and of the FUSED-SAMPLING step (k_step<G, true>, the default deferred loop since round 6): the action and the game's decision counter come
+// out of the game's side row and the next action goes back into it with the new masks (what the sampler kernel moved - masks in, action out -
+// has moved into the step); the game's id is read from this pass's list and written to the next pass's
+constexpr int STEP_FUSED_ALGO_BYTES = (ACTION_WORDS_C + 1) * 4 + ROWS_HOT * 4 + (11 + ACTION_WORDS_C + 1) * 4 + 17 + IDEAL_WRITEBACK_WORDS * 4 + 8;
+static_assert(STEP_FUSED_ALGO_BYTES == 829, "restate bench.py / DESIGN.md 6 when the layout changes");
 static_assert(NROWS * 4 == 676 && ROWS_HOT == 112 && ROWS_HOT * 4 % 64 == 0 && REC >= NROWS && REC * 4 % 64 == 0,
               "restate DESIGN.md byte table when the layout changes");
 

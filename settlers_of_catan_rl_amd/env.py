@@ -83,6 +83,28 @@ class VecCatanEnv(object):
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         _lib.check(self.L.catan_reset(self.h, _ptr(m), _stream()))
 
+    # ---- RNG contract (A): a single-game handle on the reference's two Mersenne Twisters (include/catan_hip.h)
+    def seed_mt19937(self, numpy_seed, python_seed):
+        """as `np.random.seed(numpy_seed); random.seed(python_seed)` in front of the reference's EnvWrapper"""
+        _lib.check(self.L.catan_seed_mt19937(self.h, int(numpy_seed) & 0xFFFFFFFF, int(python_seed) & 0xFFFFFFFF, _stream()))
+
+    def mt19937_from_process_globals(self):
+        """installs COPIES of this process's np.random / random generator states (np.random.get_state(), random.getstate()): what
+        `np.random.seed(s); random.seed(s)` left there.  The library's kernels advance the copies; the process's own generators stay put."""
+        import random
+        kind, key, pos = np.random.get_state()[:3]
+        if kind != "MT19937":
+            raise ValueError("np.random is not the legacy MT19937 RandomState")
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        _lib.check(self.L.catan_mt19937_set_state(self.h, 0, key.ctypes.data_as(C.c_void_p), int(pos), _stream()))
+        st = random.getstate()[1]
+        pkey = np.array(st[:624], dtype=np.uint32)
+        _lib.check(self.L.catan_mt19937_set_state(self.h, 1, pkey.ctypes.data_as(C.c_void_p), int(st[624]), _stream()))
+
+    def reset_board_only(self):
+        """Board.reset alone: the draws of the reference's Board() constructor (game/components/board.py:47)"""
+        _lib.check(self.L.catan_reset_board_only(self.h, _stream()))
+
     def step(self, actions):
         """actions: int32 [n][18] (a negative type = no-op).  Returns (reward [n][4] float32 indexed by PlayerId-1,
         done [n] uint8) - views of buffers owned by the env, overwritten by the next step."""
@@ -189,6 +211,10 @@ class VecCatanEnv(object):
     def set_deferred_fused(self, on):
         """which form of the deferred loop runs (include/catan_hip_tuning.h): results are identical, game for game"""
         _lib.check(self.L.catan_set_deferred_fused(self.h, int(bool(on))))
+
+    @property
+    def deferred_fused(self):
+        return bool(self.L.catan_deferred_fused(self.h))
 
     def set_lr_budgets(self, lockstep, deferred):
         _lib.check(self.L.catan_set_lr_budgets(self.h, int(lockstep), int(deferred)))
@@ -316,10 +342,13 @@ class EnvWrapper(object):
     """Single-game view with the reference EnvWrapper signatures (env/wrapper.py:11-50)."""
 
     def __init__(self, interactive=False, max_actions_per_turn=None, max_proposed_trades_per_turn=4, validate_actions=True,
-                 debug_mode=False, win_reward=500, dense_reward=False, policies=None, seed=0, env_id=0):
+                 debug_mode=False, win_reward=500, dense_reward=False, policies=None, seed=0, env_id=0, rng="philox"):
         """The reference's keyword arguments in the reference's order (env/wrapper.py:12-13) plus the game's Philox stream
         (seed, env_id).  Anything else is a TypeError, as with the reference; `interactive` / `debug_mode` / `policies` drive
-        the reference's pygame display and its text log (game/game.py:30-37), which are out of scope: only their defaults."""
+        the reference's pygame display and its text log (game/game.py:30-37), which are out of scope: only their defaults.
+        rng="mt19937": RNG contract (A) - the game draws from copies of THIS PROCESS's np.random / random generators as they are now
+        (`np.random.seed(s); random.seed(s); env = EnvWrapper(rng="mt19937")` replays the unpatched reference draw for draw,
+        tests/test_gpu_golden.py::test_mt19937_known_answer_on_the_hip_path); the constructor takes the draws of Board() and Game()."""
         if interactive or debug_mode or policies is not None:
             raise NotImplementedError("EnvWrapper(interactive / debug_mode / policies): the reference's display and text log "
                                       "are not part of the batched HIP path")
@@ -334,6 +363,13 @@ class EnvWrapper(object):
         self.game = _GameView(self)
         self._cache = None
         self._fresh = True          # catan_create already reset the game: the first reset() must not draw again
+        if rng == "mt19937":
+            self.vec.mt19937_from_process_globals()
+            self.vec.reset_board_only()          # Board() (game/components/board.py:47)
+            self.vec.reset()                     # Game.__init__ -> reset (game/game.py:40)
+            self._fresh = False                  # EnvWrapper.reset() deals again, as the reference's does
+        elif rng != "philox":
+            raise ValueError("rng: 'philox' or 'mt19937'")
         self._reward_annealing_factor = 1.0
 
     @property

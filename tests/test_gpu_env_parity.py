@@ -90,8 +90,6 @@ def test_deferred_small_windows_repeated_with_the_middle_tier(oracle, hip_lib, f
     games compared with the oracle after every call, tier-1 budget 4 so that the window's slow path is busy.  Round 5's failures were the fused
     loop's window close (a window of an odd number of passes closes in the middle of a tier-1 group: DESIGN.md 4.0); a few idle handles in
     front shift which hardware queue the env's streams land on - the failures came and went with the suite's order."""
-    if fused and wave_games != 64:
-        pytest.skip("the fused-sampling k_step runs 64 games per wave")
     n, seed, pre = 2048, 40 + window + wave_games, 1100
     idle = [_env(256, 1) for _ in range((window + wave_games // 16) % 4)]
     env = _env(n, seed)

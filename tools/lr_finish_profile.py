@@ -1,5 +1,5 @@
 """Diagnostics: per-request phase times of k_lr_finish in lock-step steps (every one-game wave stores its own durations in
-rows 1088.. of the per-wave profile buffer): record load, path search, holder logic, done / rewards, masks, write-back."""
+rows 4128.. of the per-wave profile buffer): record load, path search, holder logic, done / rewards, masks, write-back."""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 2)
-rows = n // 16 + 17
+rows = max(n // 16 + 17, 7128)
 names = {0: "record load", 1: "plan + search + cache", 2: "call", 5: "holder update", 3: "cut case", 4: "done / rewards", 6: "masks", 7: "write-back"}
 acc = []
 heavy = []
@@ -22,8 +22,8 @@ for step in range(48):
     env.random_rollout(100000 + step, 1)
     out = np.zeros((rows, 8), dtype=np.uint32)
     L.catan_profile_read_waves(env.h, out.ctypes.data_as(C.c_void_p))
-    acc.append(out[1088:1088 + 2000].copy())
-    h = out[3088:3088 + 1000].astype(np.int64)
+    acc.append(out[4128:4128 + 2000].copy())
+    h = out[6128:6128 + 1000].astype(np.int64)
     h = h[h[:, 1] > 0]
     heavy.append(h)
 L.catan_profile_enable(env.h, 0)

@@ -11,18 +11,14 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd import _lib
 
 n = 65536
-# profiled at 64 games per wave: the per-wave buffer keeps k_lr_finish's rows from row 1 088 on, where k_step's waves of the default
-# (32 games per wave: 2 065 rows) would run into them; the per-type phase times are what this tool is for
-os.environ.setdefault("CATAN_STEP_WAVE_GAMES", "64")
-G = int(os.environ["CATAN_STEP_WAVE_GAMES"])
-FUSED = int(os.environ.get("FUSED", "0"))
+G = int(os.environ.get("CATAN_STEP_WAVE_GAMES", "32"))        # games per k_step wave (the library's default: 32)
+FUSED = int(os.environ.get("FUSED", "1"))          # the fused-sampling loop (the default) / FUSED=0: sampler + k_step
 env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
-if FUSED:
-    L.catan_set_deferred_fused(env.h, 1)
+L.catan_set_deferred_fused(env.h, FUSED)
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 3)
-rows = n // 16 + 17
+rows = max(n // 16 + 17, 7128)
 BIN = ["settle", "road", "city", "buy_dev", "play_dev", "exchange", "propose", "respond", "robber", "roll", "end_turn", "steal", "discard",
        "play:1", "play:2", "play:3", "play:4", "no-op"]      # bins 0..12 = the action types in enum order (catan_state.h T_*, = the reference's ActionTypes), 13..16 = play_dev by card
 spans, ramps, durs, by_bin, shared, tails, lates = [], [], [], {}, [], [], []

@@ -9,15 +9,14 @@ from settlers_of_catan_rl_amd.env import VecCatanEnv
 from settlers_of_catan_rl_amd import _lib
 
 n = 65536
-# profiled at 64 games per wave: the per-wave buffer keeps k_lr_finish's rows from row 1 088 on, where k_step's waves of the default
-# (32 games per wave: 2 065 rows) would run into them; the per-type phase times are what this tool is for
-os.environ.setdefault("CATAN_STEP_WAVE_GAMES", "64")
-G = int(os.environ["CATAN_STEP_WAVE_GAMES"])
+G = int(os.environ.get("CATAN_STEP_WAVE_GAMES", "32"))        # games per k_step wave (the library's default: 32)
 env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
+FUSED = int(os.environ.get("FUSED", "1"))
+L.catan_set_deferred_fused(env.h, FUSED)
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 2)
-waves = n // 16 + 17
+waves = max(n // 16 + 17, 7128)
 BIN = ["settle", "road", "city", "buy_dev", "play_dev", "exchange", "propose", "respond", "robber", "roll", "end_turn", "steal", "discard",
        "play:1", "play:2", "play:3", "play:4", "no-op"]      # bins 0..12 = the action types in enum order (catan_state.h T_*, = the reference's ActionTypes), 13..16 = play_dev by card
 acc = []
@@ -34,9 +33,13 @@ for b in sorted(np.unique(a[:, 5])):
     x = a[a[:, 5] == b].astype(np.float64)
     v = a[a[:, 5] == b][:, 3].astype(np.int64)
     tot = x[:, [0, 1, 2, 6, 7]].sum(1)
-    if BIN[int(b) - 1] == "roll":                          # slot 4 of a roll wave: dice draws | tile scan + bank << 10 | hands + estimates << 20 (10 ns ticks)
+    if FUSED:                                             # slot 4 of a fused-sampling wave: the next action's draw | the ranking + range reservation << 16
+        v4 = a[a[:, 5] == b][:, 4].astype(np.int64)
+        extra = f"   next-action draw {(v4 & 0xFFFF).mean() / 100:5.2f}  rank + reserve {(v4 >> 16).mean() / 100:5.2f}"
+    elif BIN[int(b) - 1] == "roll":                          # slot 4 of a roll wave: dice draws | tile scan + bank << 10 | hands + estimates << 20 (10 ns ticks)
         v4 = a[a[:, 5] == b][:, 4].astype(np.int64)
         roll_split = f"           roll's switch (medians): dice draws {np.median(v4 & 1023) / 100:.2f} us, tile scan + bank {np.median((v4 >> 10) & 1023) / 100:.2f} us, hands + estimates {np.median((v4 >> 20) & 1023) / 100:.2f} us"
     print(f"{BIN[int(b) - 1]:10s} {len(x) / 24:7.1f} {x[:, 0].mean() / 100:9.2f} {(v & 0xFFFF).mean() / 100:9.2f} {(v >> 16).mean() / 100:7.2f} {x[:, 1].mean() / 100:7.2f} {x[:, 2].mean() / 100:6.2f} "
-          f"{x[:, 6].mean() / 100:7.2f} {x[:, 7].mean() / 100:7.2f} {tot.mean() / 100:7.2f}")
-print(roll_split)
+          f"{x[:, 6].mean() / 100:7.2f} {x[:, 7].mean() / 100:7.2f} {tot.mean() / 100:7.2f}" + (extra if FUSED else ""))
+if not FUSED:
+    print(roll_split)

@@ -13,7 +13,7 @@ env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 2)
-waves = n // 16 + 17                                # the buffer is sized for 16 games per wave (+ one partial wave per action-type bin)
+waves = max(n // 16 + 17, 7128)                                # the buffer is sized for 16 games per wave (+ one partial wave per action-type bin)
 names = {0: "stage-in", 1: "validate+apply", 2: "request push", 6: "done/reward+masks", 7: "write-back"}
 tn = ["no-op", "settle", "road", "city", "buy_dev", "play_knight", "exchange", "propose", "respond", "robber", "roll", "end_turn", "steal", "discard",
       "play_vp", "play_yop", "play_rb", "play_mono"]

@@ -12,7 +12,7 @@ env = VecCatanEnv(n, seed=0)
 L = _lib.lib()
 env.random_rollout_deferred(3000, 32)
 L.catan_profile_enable(env.h, 2)
-waves = n // 16 + 17                                # (the buffer is sized for 16 games per wave)
+waves = max(n // 16 + 17, 7128)                                # (the buffer is sized for 16 games per wave)
 names = {0: "stage-in", 1: "validate+apply", 2: "request push", 6: "done/reward+masks", 7: "sample+append+write-back"}
 acc = []
 for rep in range(24):
