@@ -53,6 +53,9 @@ int catan_profile_read_waves(catan_env_t* env, uint32_t* out);
  * phases 0, 1, 6, 7 follow it back to back) and slot 3 = where the wave ran (HW_REG_HW_ID bits 0..27 | HW_REG_XCC_ID << 28):
  * the launch's timeline - dispatch ramp, waves that share a SIMD, the tail (tools/step_timeline.py). */
 
+/* hipRuntimeGetVersion() of the HIP runtime this process runs on, or -1 (policy._Branches keys its hipGraph work-around on it: DESIGN.md 4.6) */
+int32_t catan_hip_runtime_version(void);
+
 /* Algorithmic HBM bytes of one fused env step per stepped game, from the static_assert-ed layout constants of csrc/catan_state.h
  * (action row in, hot record in, masks + reward + done out, the ideal write-back): bench.py's roofline numerator. */
 int32_t catan_step_algorithmic_bytes(void);

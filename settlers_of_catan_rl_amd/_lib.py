@@ -261,6 +261,7 @@ _SIGS = {
     "catan_set_deferred_fused": (C.c_int, [_vp, C.c_int32]),
     "catan_step_algorithmic_bytes": (C.c_int32, []),
     "catan_step_fused_algorithmic_bytes": (C.c_int32, []),
+    "catan_hip_runtime_version": (C.c_int32, []),
     "catan_deferred_fused": (C.c_int32, [_vp]),
     "catan_set_step_wave_games": (C.c_int, [_vp, C.c_int32]),
     "catan_set_lr_rounds": (C.c_int, [_vp, C.c_int32, C.c_int32]),

@@ -1195,6 +1195,7 @@ int catan_set_step_wave_games(catan_env_t* e, int32_t games) {
     return CATAN_OK;
 }
 
+int32_t catan_hip_runtime_version(void) { int v = 0; return hipRuntimeGetVersion(&v) == hipSuccess ? (int32_t)v : -1; }
 int32_t catan_step_algorithmic_bytes(void) { return STEP_ALGO_BYTES; }
 int32_t catan_step_fused_algorithmic_bytes(void) { return STEP_FUSED_ALGO_BYTES; }
 int32_t catan_deferred_fused(const catan_env_t* e) { return e ? e->deferred_fused : -1; }

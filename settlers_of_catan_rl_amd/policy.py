@@ -445,7 +445,30 @@ class _Branches(object):
     # process dies with SIGSEGV inside libamdhip64 (tools/rollout_schedules.py's fourth env + collector in round 4; reproduced with a
     # native backtrace, gone with single-chain graphs or DEBUG_HIP_FORCE_GRAPH_QUEUES=1: profiles/r05_graph_launch_segv.txt).  A
     # captured policy pass is therefore ONE chain; the branches cost 0.12 s of a 2.3 s rollout at 65 536 games (same file).
-    in_graphs = False
+    # The work-around is GATED on the runtime (round 6): branched graphs come back on a HIP runtime listed in GOOD_RUNTIMES (hipRuntimeGetVersion
+    # values on which tools/repro_four_collectors.py with CATAN_GRAPH_BRANCHES=1 completes its six sets - none is known yet: the ROCm 7.2.0
+    # runtime of this image, 70253xxx, has the defect) or with CATAN_GRAPH_BRANCHES=1; CATAN_GRAPH_BRANCHES=0 keeps single chains everywhere.
+    GOOD_RUNTIMES = frozenset()
+    _in_graphs = None
+
+    @classmethod
+    def graphs_allowed(cls):
+        if cls._in_graphs is None:
+            import os
+            v = os.environ.get("CATAN_GRAPH_BRANCHES")
+            if v in ("0", "1"):
+                cls._in_graphs = v == "1"
+            else:
+                try:
+                    from . import _lib
+                    cls._in_graphs = int(_lib.lib().catan_hip_runtime_version()) in cls.GOOD_RUNTIMES
+                except Exception:
+                    cls._in_graphs = False
+        return cls._in_graphs
+
+    @property
+    def in_graphs(self):
+        return type(self).graphs_allowed()
 
     def __init__(self):
         self.side = None
@@ -453,7 +476,7 @@ class _Branches(object):
 
     def fork(self, ref):
         self.active = bool(self.enabled and ref.is_cuda and not torch.is_grad_enabled()
-                           and (self.in_graphs or not torch.cuda.is_current_stream_capturing()))
+                           and (not torch.cuda.is_current_stream_capturing() or self.in_graphs))
         if not self.active:
             return self
         if self.side is None or self.side[0].device != ref.device:

@@ -17,6 +17,8 @@ Also: four full-size env + collector + storage sets created and destroyed in one
 tools/rollout_schedules.py)."""
 import gc
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -227,7 +229,10 @@ def test_four_full_size_collector_sets_in_one_process(hip_lib):
     from settlers_of_catan_rl_amd.env import VecCatanEnv
     from settlers_of_catan_rl_amd.policy import CatanPolicy, _Branches
     from settlers_of_catan_rl_amd.rollout import RolloutCollector
-    assert not _Branches.in_graphs
+    from settlers_of_catan_rl_amd import _lib
+    rt = int(_lib.lib().catan_hip_runtime_version())
+    # the gate (round 6): branched graphs only on a runtime listed as good or by explicit opt-in; this image's runtime is not listed
+    assert rt > 0 and _Branches.graphs_allowed() == (rt in _Branches.GOOD_RUNTIMES or os.environ.get("CATAN_GRAPH_BRANCHES") == "1")
     n, T = 65536, 200
     torch.manual_seed(0)
     net = CatanPolicy().cuda()

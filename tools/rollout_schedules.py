@@ -11,7 +11,7 @@ from settlers_of_catan_rl_amd.rollout import RolloutCollector
 
 if os.environ.get("CATAN_BRANCHES_IN_GRAPHS"):  # the policy pass captured WITH its forked streams (round 4's form: see policy._Branches.in_graphs)
     from settlers_of_catan_rl_amd import policy as _pol
-    _pol._Branches.in_graphs = True
+    _pol._Branches._in_graphs = True
 N = int(os.environ.get("GAMES", "65536")); T = int(os.environ.get("T", "200"))
 torch.manual_seed(0)
 net = CatanPolicy().cuda()
