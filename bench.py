@@ -53,7 +53,7 @@ ALGO_BYTES = {
 LR_REQUEST_BYTES = 448 + 448 + 28 + 28 + 44 + 17
 FAST_PATH = ("k_sample_random", "k_step")     # the kernels on the timed loop's critical path
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round5.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")   # rocprofv3 --pmc passes (tools/profile_round6.sh)
 
 
 def cpu_baseline(sample_envs=16384, sample_steps=2048):

@@ -1,4 +1,4 @@
-"""Workload for `rocprofv3 --kernel-trace --stats` (tools/profile_round3.sh): the kernels bench.py lists under `roofline_learner`,
+"""Workload for `rocprofv3 --kernel-trace --stats` (tools/profile_round6.sh): the kernels bench.py lists under `roofline_learner`,
 launched by the same code (tools/learner_rooflines.py) at the same shapes, so that the AverageNs of every kernel in the stats file can
 be set beside the HIP-event time of the bench line.  Prints the list as JSON."""
 import json, os, sys

@@ -1,4 +1,4 @@
-"""Workload for rocprofv3 --pmc passes over the learner-side kernels (tools/profile_round3.sh): each kernel of interest launched a few
+"""Workload for rocprofv3 --pmc passes over the learner-side kernels (tools/profile_round6.sh): each kernel of interest launched a few
 times at the shapes of a config-3 minibatch step, plus k_calib_copy launches with exactly known HBM traffic (256 MiB read + 256 MiB
 written each).  tools/pmc_summarise.py (PMC_TAIL=4) averages the last launches of every kernel; the algorithmic bytes to set the
 measured traffic against are those of tools/learner_rooflines.py (same shapes)."""
