@@ -80,6 +80,7 @@ int32_t catan_deferred_fused(const catan_env_t* env);
  *   CATAN_LR_GRID=g               workgroups of k_lr_finish (default 4 096 inside a lock-step step, 3 072 in the deferred schedules)
  *   CATAN_STEP_WAVES_PER_BLOCK=4  four-wave k_step workgroups;  CATAN_STEP_WAVE_GAMES, CATAN_DEFERRED_FUSED: as the setters above
  *   CATAN_FUSED_SUBS=s            sub-lists per sort bin in the fused-sampling loop: 1, 2, 4, 8 (default) or 16
+ *   CATAN_T1_DELAY_US=k           the fused-sampling loop: tier 1 staggered k microseconds behind the group's last k_step (default 4; 0: not staggered)
  *   CATAN_DEBUG_FUSED_CLOSE_UNORDERED=1, CATAN_DEBUG_STEP_DELAY_US=k   the fused loop's window close as it was ordered until round 6 / the closing pass's
  *                                 k_step k microseconds late: reproduce the round-5 parity failures at will (tools/fused_close_race.py; these two DO change results) */
 

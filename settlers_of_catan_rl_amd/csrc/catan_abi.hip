@@ -54,7 +54,7 @@ struct catan_env {
     int step_wpb;         // waves per k_step workgroup (4: one workgroup per CU, a SIMD per wave; 1: one-wave workgroups)
     u32* prof_wave;       // [N/64][8] per-wave phase ticks of the last k_step (catan_profile_enable(env, 2))
     u32* pctr;            // [N] per-game decision counters of the random policy (deferred rollouts)
-    int lr_budget[2];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there)
+    int lr_budget[3];     // tier-1 longest-road iteration budget: [0] lock-step, [1] deferred (tails are amortised there), [2] the fused-sampling loop
     int lr_round[2];      // tier-2 iterations per bulk-synchronous round: [0] lock-step, [1] deferred
     int deferred_fused;   // catan_set_deferred_fused (CATAN_DEFERRED_FUSED at creation)
     int fused_subs;       // ... its sub-lists per bin (CATAN_FUSED_SUBS at creation: 1, 2, 4, 8 or 16; Pending::nsub while that loop runs)
@@ -83,6 +83,12 @@ constexpr int DEFAULT_STEP_WAVE_GAMES = 32;
 // sub-lists per sort bin in the fused-sampling deferred loop (Pending::bctr): one counter per bin serialises the launch's range reservations
 constexpr int DEFAULT_FUSED_SUBS = 8;
 constexpr int LR_BUDGET_DEFERRED = 12;   // (swept together with the window length: tools/deferred_sweep.py)
+// The fused-sampling loop (round 6; profiles/r06_t1_stagger_ab.txt): tier 1's launch is STAGGERED - a one-wave kernel that idles T1_STAGGER_US in front of
+// it on the side stream - so that the next pass's k_step, which becomes eligible at the same moment, gets its workgroups dispatched first (with both
+// kernels' workgroups interleaved, tier 1's 3 072-4 096 one-wave workgroups held the LDS and registers k_step's second wave per SIMD needs: its waves
+// started over ~20 us, 9 % of them in a second round; staggered: within 5-7 us, 2 %).  Any delay from 1 to 6 us gives the same 38.9 -> 36.9 us per pass:
+// it is the ORDER of dispatch that matters, not the time.  With it, 4 096 tier-1 workgroups and budget 10 measure best (36.0 us).
+constexpr int T1_STAGGER_US = 4, LR_GRID_FUSED = 4096, LR_BUDGET_FUSED = 10;
 // cross-stream ordering inside one device: no timing, no system-scope release (which would flush L2 at every record)
 constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
 static thread_local std::string g_err;
@@ -418,7 +424,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     HIPCHK(hipMemset(e->pend.busy, 0, (size_t)e->N));
     HIPCHK(hipMemset(e->pend.len, 0, (size_t)e->N * sizeof(u64)));      // (bit 63 of a game's word is k_lr_finish<LRF_SPLIT>'s mark for k_lr_complete)
     HIPCHK(hipMemset(e->pctr, 0, (size_t)e->N * sizeof(u32)));
-    e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED;
+    e->lr_budget[0] = LR_BUDGET; e->lr_budget[1] = LR_BUDGET_DEFERRED; e->lr_budget[2] = LR_BUDGET_FUSED;
     e->lr_round[0] = LR_ROUND_LOCKSTEP; e->lr_round[1] = LR_ROUND;
     e->step_games = DEFAULT_STEP_WAVE_GAMES;
     // the fused-sampling loop is the library's own deferred loop since round 6 (one kernel per pass on the main stream; with per-bin sub-lists,
@@ -429,7 +435,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
     // previous pass hold LDS on most CUs, so a 116 KB workgroup often has to wait for a CU where the 29 KB one-wave workgroup fits at once
     e->step_wpb = 1;
-    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : 1;
+    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : (atoi(wp) == 2 ? 2 : 1);
     e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
     if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
     // tier 1 as search + lane-per-game completion: in the library's own deferred loop since round 5 (a tier-1 launch there has two passes to finish and its
@@ -638,6 +644,8 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     if (e->pend.sample) {                                 // fused-sampling rollouts: actions from / to the side rows
         if (e->step_games == 64 && e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, true, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else if (e->step_games == 64) hipLaunchKernelGGL((k_step<64, true>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else if (e->step_games == 32 && e->step_wpb == 4) hipLaunchKernelGGL((k_step<32, true, 4>), dim3(blocks(blocks(e->N, 32) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
+        else if (e->step_games == 32 && e->step_wpb == 2) hipLaunchKernelGGL((k_step<32, true, 2>), dim3(blocks(blocks(e->N, 32) + SORT_PAD_WAVES, 2)), dim3(128), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else if (e->step_games == 32) hipLaunchKernelGGL((k_step<32, true>), dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else hipLaunchKernelGGL((k_step<16, true>), dim3(blocks(e->N, 16) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
@@ -664,15 +672,16 @@ static int lr_grid(bool deferred) {
     static const int g = (getenv("CATAN_LR_GRID") && atoi(getenv("CATAN_LR_GRID")) >= 64) ? atoi(getenv("CATAN_LR_GRID")) : 0;
     return g ? g : (deferred ? LR_GRID_DEFERRED : LR_GRID);
 }
-static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget, bool two_passes = false) {
+static int enqueue_tier1(catan_env_t* e, float* reward, uint8_t* done, hipStream_t st, hipEvent_t* ev, int fl, int lr_budget, bool two_passes = false, int grid = 0) {
+    if (grid <= 0 || getenv("CATAN_LR_GRID")) grid = lr_grid(e->pend.ftag >= 2);
     StepCfg sc = step_cfg(e);
     if (ev) HIPCHK(hipEventRecord(ev[8], st));
     if (e->lr_split == 2 || (e->lr_split == 1 && two_passes)) {     // (1: only where a launch has two passes to finish - the library's own deferred loops)
-        hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(lr_grid(e->pend.ftag >= 2)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+        hipLaunchKernelGGL(k_lr_finish<LRF_SPLIT>, dim3(grid), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                            sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
         hipLaunchKernelGGL(k_lr_complete, dim3(LR_COMPLETE_GRID), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl);
     } else
-    hipLaunchKernelGGL(k_lr_finish<LRF_TIER1>, dim3(lr_grid(e->pend.ftag >= 2)), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
+    hipLaunchKernelGGL(k_lr_finish<LRF_TIER1>, dim3(grid), dim3(64), 0, st, e->ctx, e->mpk, reward, done, sc, e->pend, fl, lr_budget,
                        sc.prof && e->prof_on < 2 ? sc.prof + 2 * PROF_PHASES : nullptr, reinterpret_cast<unsigned long long*>(e->err + 4));
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
@@ -1041,7 +1050,7 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
     e->pend.brel = (int)(((g + 2) * P) % S);                   // tier 1 of this group: its games return in the first pass of group g + 2
     // CATAN_DEBUG_STEP_DELAY_US=k (diagnostics): the k_step of a pass that closes a window in the middle of its group starts k microseconds late
     static const int dbg_delay_us = getenv("CATAN_DEBUG_STEP_DELAY_US") ? atoi(getenv("CATAN_DEBUG_STEP_DELAY_US")) : 0;
-    if (dbg_delay_us > 0 && closes && !(glast || last)) hipLaunchKernelGGL(k_debug_spin, dim3(1), dim3(64), 0, st, (long long)dbg_delay_us * 100);
+    if (dbg_delay_us > 0 && closes && !(glast || last)) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, (long long)dbg_delay_us * 100);
     int r = enqueue_fast(e, e->scratch_actions, e->scratch_reward, e->scratch_done, st, ev, true);
     if (r != CATAN_OK) return r;
     if (glast || last) {
@@ -1051,7 +1060,10 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         HIPCHK(hipStreamWaitEvent(fs, e->ev_fready[ga], 0));
         // (search + lane-per-game completion only with CATAN_LR_SPLIT=2: measured 41.0 us per pass with the split against 38.9 without - here the
         // completion kernel samples and enqueues lane per game with one atomic each, and tier 1's launches are not what bounds this loop)
-        r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[1], false);
+        // tier 1 staggered behind the next pass's dispatch (T1_STAGGER_US above; CATAN_T1_DELAY_US=k: k microseconds, 0: not staggered)
+        static const int t1_delay_us = getenv("CATAN_T1_DELAY_US") ? atoi(getenv("CATAN_T1_DELAY_US")) : T1_STAGGER_US;
+        if (t1_delay_us > 0 && !t1_serial) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, fs, (long long)t1_delay_us * 100);
+        r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[2], false, LR_GRID_FUSED);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_fdone[ga], fs));
     }
@@ -1206,7 +1218,7 @@ int catan_set_deferred_fused(catan_env_t* e, int32_t on) {
 }
 int catan_set_lr_budgets(catan_env_t* e, int32_t lockstep, int32_t deferred) {
     if (!e || lockstep < 1 || deferred < 1) return fail(CATAN_EINVAL, "catan_set_lr_budgets: bad arguments");
-    e->lr_budget[0] = lockstep; e->lr_budget[1] = deferred;
+    e->lr_budget[0] = lockstep; e->lr_budget[1] = deferred; e->lr_budget[2] = deferred;
     return CATAN_OK;
 }
 

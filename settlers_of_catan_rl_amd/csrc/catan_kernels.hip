@@ -3182,9 +3182,10 @@ __global__ __launch_bounds__(BLOCK) void k_calib_copy(const uint4* __restrict__ 
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (long)gridDim.x * BLOCK) dst[i] = src[i];
 }
 
-// Diagnostics (CATAN_DEBUG_STEP_DELAY_US): one wave that spins for `ticks` of the 100 MHz wall clock - in front of a k_step it makes
-// that launch late, which turns a missing stream dependency on it into a deterministic failure (the fused loop's window close).
-__global__ __launch_bounds__(64) void k_debug_spin(long long ticks) {
+// One wave that idles for `ticks` of the 100 MHz wall clock.  In front of tier 1 on its side stream it STAGGERS that launch behind the next pass's
+// k_step (catan_abi.hip: T1_STAGGER_US); in front of a k_step (CATAN_DEBUG_STEP_DELAY_US, diagnostics) it makes that launch late, which turns a
+// missing stream dependency on it into a deterministic failure (the fused loop's window close).
+__global__ __launch_bounds__(64) void k_spin(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
