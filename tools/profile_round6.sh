@@ -9,6 +9,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 run() { name=$1; shift; ( "$@" ) > $OUT/$name.txt 2> $OUT/$name.err.full; rc=$?; echo "$name rc=$rc" >> $OUT/status.txt; grep -v "amdgpu.ids" $OUT/$name.err.full | tail -30 > $OUT/$name.err; rm -f $OUT/$name.err.full; [ -s $OUT/$name.err ] || rm -f $OUT/$name.err; return 0; }
 run gpu_tests timeout 2400 python -m pytest tests -q -m gpu
+run smoke timeout 600 python -c "import __graft_entry__ as g; g.smoke()"
 cd /tmp
 run bench_default timeout 1200 python $REPO/bench.py
 run bench_driver_args_env_only timeout 300 python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --ppo-steps 0 --no-live-pmc
