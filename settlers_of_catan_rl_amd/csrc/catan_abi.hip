@@ -435,7 +435,7 @@ int catan_create(catan_env_t** out, int device, int64_t n_envs, uint64_t seed, u
     // measured SLOWER (k_step 31.8 -> 39.6 us, pass 54.4 -> 61.8 us, profiles/r05_k_step_pass_experiments.txt): the tier-1 waves of the
     // previous pass hold LDS on most CUs, so a 116 KB workgroup often has to wait for a CU where the 29 KB one-wave workgroup fits at once
     e->step_wpb = 1;
-    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : (atoi(wp) == 2 ? 2 : 1);
+    if (const char* wp = getenv("CATAN_STEP_WAVES_PER_BLOCK")) e->step_wpb = atoi(wp) == 4 ? 4 : 1;
     e->step_bin_order = 1;   // on since round 5 (54.5 -> 52.3-53.4 us per pass: profiles/r05_s5_pass_experiments.txt); CATAN_STEP_BIN_ORDER=0: bins in index order
     if (const char* bo = getenv("CATAN_STEP_BIN_ORDER")) e->step_bin_order = atoi(bo) != 0;
     // tier 1 as search + lane-per-game completion: in the library's own deferred loop since round 5 (a tier-1 launch there has two passes to finish and its
@@ -644,8 +644,6 @@ static int enqueue_fast(catan_env_t* e, const int32_t* actions, float* reward, u
     if (e->pend.sample) {                                 // fused-sampling rollouts: actions from / to the side rows
         if (e->step_games == 64 && e->step_wpb == 4) hipLaunchKernelGGL((k_step<64, true, 4>), dim3(blocks(blocks(e->N, 64) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else if (e->step_games == 64) hipLaunchKernelGGL((k_step<64, true>), dim3(blocks(e->N, 64) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
-        else if (e->step_games == 32 && e->step_wpb == 4) hipLaunchKernelGGL((k_step<32, true, 4>), dim3(blocks(blocks(e->N, 32) + SORT_PAD_WAVES, 4)), dim3(256), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
-        else if (e->step_games == 32 && e->step_wpb == 2) hipLaunchKernelGGL((k_step<32, true, 2>), dim3(blocks(blocks(e->N, 32) + SORT_PAD_WAVES, 2)), dim3(128), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else if (e->step_games == 32) hipLaunchKernelGGL((k_step<32, true>), dim3(blocks(e->N, 32) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         else hipLaunchKernelGGL((k_step<16, true>), dim3(blocks(e->N, 16) + SORT_PAD_WAVES), dim3(64), 0, st, e->ctx, actions, e->mpk, reward, done, e->err, sc, e->pend, (const u32*)bins);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
