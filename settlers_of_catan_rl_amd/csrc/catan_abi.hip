@@ -1060,7 +1060,11 @@ static int deferred_iter(catan_env_t* e, int64_t it, int64_t iters, int window, 
         // completion kernel samples and enqueues lane per game with one atomic each, and tier 1's launches are not what bounds this loop)
         // tier 1 staggered behind the next pass's dispatch (T1_STAGGER_US above; CATAN_T1_DELAY_US=k: k microseconds, 0: not staggered)
         static const int t1_delay_us = getenv("CATAN_T1_DELAY_US") ? atoi(getenv("CATAN_T1_DELAY_US")) : T1_STAGGER_US;
-        if (t1_delay_us > 0 && !t1_serial) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, fs, (long long)t1_delay_us * 100);
+        // (the instrumented loop - catan_random_rollout_timed - has an event record in front of every k_step, which holds that launch back by ~3 us: the
+        // stagger is lengthened by 4 us there, so that the ORDER of dispatch - and with it k_step's duration by the events - is the uninstrumented
+        // loop's: 30.2 us by the events against 30.1 us by rocprofv3 over the plain loop; without the compensation the events read 33 us)
+        const int t1_us = t1_delay_us > 0 && ev != nullptr ? t1_delay_us + 4 : t1_delay_us;
+        if (t1_us > 0 && !t1_serial) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, fs, (long long)t1_us * 100);
         r = enqueue_tier1(e, e->f_reward, e->f_done, fs, ev, gl, e->lr_budget[2], false, LR_GRID_FUSED);
         if (r != CATAN_OK) return r;
         HIPCHK(hipEventRecord(e->ev_fdone[ga], fs));
