@@ -406,6 +406,7 @@ class _LinearTallSkinny(torch.autograd.Function):
 
 
 ROWS_KERNEL_MIN_ROWS = 262144      # below this the library GEMM is as fast (measured: 65 536 x 128 x 128: 20 us vs 25 us)
+ROWS_KERNEL_MIN_ROWS_SKINNY = 65536
 
 
 MODE_NONE, MODE_RELU, MODE_ADD, MODE_RELU_MASK = 0, 1, 2, 3
@@ -416,7 +417,11 @@ def _linear_rows(x, w, b, aux=None, mode=MODE_NONE):
     epilogue of catan_linear_rows_fused (ReLU, + residual, ReLU-backward mask)."""
     N, K = w.shape
     rows = x.numel() // K
-    if rows < ROWS_KERNEL_MIN_ROWS or not _lib.lib().catan_linear_rows_supported(rows, K, N) or (mode != MODE_NONE and N % 8):
+    # (skinny products - at most 32 columns on one side - from 65 536 rows on: the library runs them at 0.3-0.7 TB/s, and its NN form, which the
+    # input gradient of a narrow layer is, at a third of that: 204 800 x (128 -> 25): 68 us NN / 26 us NT / 19 us here; x (16 -> 25): 65 / 25 / 10 us;
+    # x (128 -> 1): 44 / 43 / 11 us - profiles/r06_skinny_products.txt)
+    min_rows = ROWS_KERNEL_MIN_ROWS_SKINNY if min(N, K) <= 32 else ROWS_KERNEL_MIN_ROWS
+    if rows < min_rows or not _lib.lib().catan_linear_rows_supported(rows, K, N) or (mode != MODE_NONE and N % 8):
         return None
     x2, w2 = _aligned(x.reshape(rows, K)), _aligned(w)
     a2 = None if aux is None else _aligned(aux.reshape(rows, N))
