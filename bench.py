@@ -226,8 +226,8 @@ def ppo_update_record(env, n, rank, world, T, cdist):
     # The reference's ACTUAL rollout workload (VERDICT r5 missing #3): seat 0 of every game plays the central policy against three league
     # snapshots per worker (RL/ppo/game_manager.py:15,25-31; update_opponent_policies.py:13-43) instead of all four seats playing the central
     # policy.  One more rollout, not followed by an update (the update's work does not depend on who the opponents were): the league's bounded
-    # variant with max_distinct = 3 snapshots in play (4 nets with the central one; league.py), workers of 5 games, one batched forward per
-    # distinct net per pass (eager grouped inference: the captured single-net pass does not apply).
+    # variant with max_distinct = 3 snapshots in play (4 nets with the central one; league.py), workers of 5 games, one captured policy pass per
+    # distinct net per env pass on that net's rows (rollout.RolloutCollector._act).
     league = None
     try:
         from settlers_of_catan_rl_amd.league import League
@@ -235,15 +235,18 @@ def ppo_update_record(env, n, rank, world, T, cdist):
         for _ in range(3):
             lg.add(net)                                   # (three snapshots with the current weights: what is timed does not depend on their values)
         distinct = lg.assign(col, lambda: CatanPolicy().cuda())
-        cdist.barrier()
-        t0 = time.perf_counter()
-        st_l = col.gather_rollouts()
-        cdist.barrier()
-        league_s = cdist.max_over_ranks(time.perf_counter() - t0)
-        col.after_rollouts()
-        league = {"rollout_s": league_s, "max_distinct": 3, "nets_in_play": 1 + len(distinct), "envs_per_worker": 5, "env_passes_in_rollout": col.iters,
+        league_all = []
+        for _ in range(2):                                # (the first captures the per-net policy passes: reported beside the second)
+            cdist.barrier()
+            t0 = time.perf_counter()
+            st_l = col.gather_rollouts()
+            cdist.barrier()
+            league_all.append(cdist.max_over_ranks(time.perf_counter() - t0))
+            col.after_rollouts()
+        league_s = league_all[-1]
+        league = {"rollout_s": league_s, "first_rollout_s": league_all[0], "max_distinct": 3, "nets_in_play": 1 + len(distinct), "envs_per_worker": 5, "env_passes_in_rollout": col.iters,
                   "note": "seat 0 = the central policy, the other three seats = league snapshots drawn per worker of 5 games (bounded league: 3 distinct "
-                          "snapshots in play); one batched forward per distinct net per pass; beside `rollout_s` (every seat plays the central policy)"}
+                          "snapshots in play); one captured policy pass per distinct net per env pass on that net's rows; beside `rollout_s` (every seat plays the central policy)"}
         del st_l
         col.set_opponents([], None)
     except Exception as e:                                # (the bench line must still be printed)
