@@ -460,12 +460,13 @@ class RolloutCollector(object):
             if self.recurrent:
                 sel = slice(None) if idx is None else idx
                 kw.update(hidden=(h_in[sel], c_in[sel]), nonterminal=term[sel])
-            if idx is None and self.graph_act and not self.recurrent:
+            if idx is None and getattr(self, "graph_act", False) and not self.recurrent:
                 if self._graphed is None or self._graphed.policy is not net:
                     from .forward_search import GraphedAct
                     self._graphed = GraphedAct(net, buckets=self._bucket_list(), autocast_dtype=self.autocast_dtype, generator=self.sample_gen)
                 res = self._graphed(f, lists, lens, masks, with_logp=True, clone=False)
-            elif idx is not None and self.graph_act and not self.recurrent and not getattr(net, "wants_games", False) and hasattr(net, "refresh_kernel_packs"):
+            elif (idx is not None and getattr(self, "graph_act", False) and not self.recurrent and not getattr(net, "wants_games", False)
+                  and hasattr(net, "refresh_kernel_packs")):
                 # league opponents (round 6): one captured pass per net in play and row-count bucket instead of an eager pass per net
                 # (~150 launches each, host-bound: 9.4 s per rollout of T = 200 at 65 536 games against 2.4 s for self-play);
                 # the rows beyond the group are padding.  Same generator, registered with every graph.
